@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def small_problem():
+    """40 cameras / 400 landmarks, preprocessed like the reference pipeline."""
+    from rootba_amd import problem as P
+    raw = P.synthetic_problem(40, 400, 1700, seed=7)
+    # start far from the optimum (like real BAL data) so that the gradient is
+    # not a cancellation residue and f32 comparisons are meaningful
+    return P.preprocess(raw, seed=7, translation_sigma=0.5, point_sigma=0.5)
+
+
+@pytest.fixture(scope="session")
+def ladybug_problem():
+    """Synthetic stand-in for BAL ladybug problem-49-7776."""
+    from rootba_amd import problem as P
+    return P.preprocess(P.named_synthetic("ladybug-49"))
+
+
+def rel_err(a, b):
+    """Reference test metric |a-b| / (|a|+|b|) (src/rootba/testing/eigen_utils.hpp:105-108)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    d = np.linalg.norm(a - b)
+    s = np.linalg.norm(a) + np.linalg.norm(b)
+    return 0.0 if s == 0 else d / s
