@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""bench.py — LM iterations/sec of the MI355X-native square-root BA solver.
+
+Metric (BASELINE.json): LM iterations/sec (linearize + QR + PCG + back-sub) on
+BAL venice-1778 (synthetic stand-in of the same size/shape; the
+real BAL file is used when present). A "step" is ONE LM iteration = one row of
+the reference's iteration log (bal_bundle_adjustment.cpp:291-521): compute_error,
+stage 1 (when the linearisation point moved), stage 2 + preconditioner + PCG,
+back-substitution + camera update, compute_error.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 shards the landmarks of the SAME problem over the ranks (strong scaling);
+the camera-sized vectors are all-reduced with RCCL inside the library.
+Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def shard_ranges(k: np.ndarray, n: int):
+    """Contiguous landmark ranges balanced by sum(k^2) (bytes of the blocks)."""
+    w = np.cumsum(k.astype(np.float64) ** 2)
+    cuts = [0]
+    for r in range(1, n):
+        cuts.append(int(np.searchsorted(w, w[-1] * r / n)))
+    cuts.append(k.size)
+    return [(cuts[i], cuts[i + 1]) for i in range(n)]
+
+
+def take_landmarks(prob, lo: int, hi: int):
+    from rootba_amd.problem import BalProblem
+    off = prob.lm_obs_offsets
+    o0, o1 = int(off[lo]), int(off[hi])
+    return BalProblem(prob.cams, prob.lms[lo:hi].copy(), (off[lo:hi + 1] - o0).copy(),
+                      prob.obs_cam_idx[o0:o1].copy(), prob.obs_xy[o0:o1].copy(), prob.name)
+
+
+def make_problem(workload: str, args):
+    from rootba_amd import problem as P
+    real = os.path.join(ROOT, "..", "rootba_data", "bal", *{
+        "venice-1778": ("venice", "problem-1778-993923-pre.txt"),
+        "ladybug-49": ("ladybug", "problem-49-7776-pre.txt"),
+        "trafalgar-257": ("trafalgar", "problem-257-65132-pre.txt"),
+        "final-13682": ("final", "problem-13682-4456117-pre.txt"),
+    }[workload])
+    if os.path.exists(real):
+        raw, data = P.read_bal(real), "real"
+    else:
+        raw, data = P.named_synthetic(workload), "synthetic"
+    prob = P.preprocess(raw, translation_sigma=args.translation_sigma, point_sigma=args.point_sigma,
+                        rotation_sigma=args.rotation_sigma)
+    return prob, data
+
+
+def solver_options(mod, n_iter: int):
+    # reference defaults + CVPR'21 common settings (Huber 1.0); no early stop so
+    # that exactly warmup+steps LM iterations are executed
+    return mod.default_options(robust_norm=1, huber_parameter=1.0, max_num_iterations=n_iter,
+                               function_tolerance=0.0)
+
+
+def cpu_baseline(prob, n_iter: int, gpu_rows):
+    """Oracle (CPU restatement of the reference path) on a bounded sample:
+    the first `n_iter` LM iterations of the same problem, all host cores."""
+    from oracle import oracle as O
+    t0 = time.perf_counter()
+    o = O.Oracle(prob, np.float32, solver_options(O, n_iter))
+    log(f"[cpu_baseline] oracle set up in {time.perf_counter() - t0:.1f}s, threads={o.num_threads()}")
+    rows, _ = o.optimize_lm()
+    its = [r for r in rows if r.iteration >= 1]
+    t = sum(r.iteration_time for r in its)
+    g = [r for r in gpu_rows if 1 <= r.iteration <= n_iter]
+    tg = sum(r.iteration_time for r in g)
+    for r in its:
+        log(f"[cpu_baseline] it {r.iteration} cg {r.cg_iterations} cost {r.cost:.6e} t {r.iteration_time:.2f}s")
+    return {
+        "value": len(its) / t if t > 0 else None,
+        "unit": "LM iterations/s",
+        "cores": o.num_threads(),
+        "kind": "port",
+        "sample": (f"LM iterations 1..{n_iter} of the same problem, f32, "
+                   f"{sum(r.cg_iterations for r in its)} CG iterations in total; "
+                   f"the GPU path runs the same {n_iter} iterations at {len(g) / tg if tg > 0 else 0:.1f} it/s"),
+        "final_cost_rel_diff_vs_gpu": (abs(its[-1].cost - g[-1].cost) / its[-1].cost) if g and its else None,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=18)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="venice-1778")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=2,
+                    help="LM iterations of the CPU oracle timed beside the GPU (0 = skip)")
+    ap.add_argument("--translation-sigma", type=float, default=0.5)
+    ap.add_argument("--point-sigma", type=float, default=0.5)
+    ap.add_argument("--rotation-sigma", type=float, default=0.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the solver has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+
+    t0 = time.perf_counter()
+    prob, data = make_problem(args.workload, args)
+    log(f"[rank {rank}] problem {prob.name}: {prob.n_cams} cams, {prob.n_lms} lms, {prob.n_obs} obs "
+        f"({time.perf_counter() - t0:.1f}s)")
+    lo, hi = shard_ranges(prob.obs_per_lm(), world)[rank]
+    local = prob if world == 1 else take_landmarks(prob, lo, hi)
+
+    n_iter = args.warmup + args.steps - 1  # the first warmup step is iteration 0 (evaluation)
+    lin = LinearizorHIP(local, np.float32, solver_options(L, max(n_iter, 1)), device=local_rank)
+    if world > 1:
+        uid = [LinearizorHIP.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        lin.comm_init(rank, world, uid[0])
+    stats = lin.problem_stats()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    rows, hx_time, hx_calls = [], 0.0, 0
+    lin.lm_begin()
+    for _ in range(args.warmup):
+        row, _more = lin.lm_step()
+        rows.append(row)
+    lin.synchronize()
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        row, _more = lin.lm_step()
+        rows.append(row)
+        tm = lin.timings()
+        hx_time += tm.hx_time
+        hx_calls += tm.hx_calls
+    lin.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        timed = rows[args.warmup:]
+        for r in rows:
+            log(f"  it {r.iteration:2d} ok {r.step_is_successful} cg {r.cg_iterations:3d} cost {r.cost:.8e} "
+                f"lambda {r.lambda_:.2e} t {r.iteration_time * 1e3:8.2f} ms (s1 {r.stage1_time * 1e3:.2f} "
+                f"s2 {r.stage2_time * 1e3:.2f} pcg {r.pcg_time * 1e3:.2f} bs {r.backsub_time * 1e3:.2f} "
+                f"err {r.residual_time * 1e3:.2f})")
+        avg_hx = hx_time / hx_calls if hx_calls else None
+        achieved = stats["hx_bytes"] / avg_hx / 1e9 if avg_hx else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hx_traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get(args.workload, {}).get("traffic_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "LM iterations/sec (linearize+QR+PCG+back-sub) on BAL venice-1778",
+            "value": args.steps / elapsed,
+            "unit": "LM iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": data,
+            "config": {
+                "workload": f"BAL {args.workload} ({data}): {prob.n_cams} cams, {prob.n_lms} lms, {prob.n_obs} obs, "
+                            "solver=SQUARE_ROOT, SCHUR_JACOBI, Huber(1), float32",
+                "parallelism": f"landmarks sharded over {world} GPU(s), RCCL all-reduce of camera vectors",
+                "cg_iterations_per_step": sum(r.cg_iterations for r in timed) / max(1, len(timed)),
+                "successful_steps": sum(r.step_is_successful for r in timed),
+                "initial_cost": rows[0].cost,
+                "final_cost": [r.cost for r in rows if r.step_is_successful][-1],
+            },
+            "roofline": {
+                "kernel": "k_hx (H*x = sum_l A_l^T A_l x, all k-classes of one right_multiply)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": stats["hx_bytes"],
+                "avg_launch_ms": avg_hx * 1e3 if avg_hx else None,
+                "launches_timed": hx_calls,
+            },
+        }
+        if world == 1 and args.cpu_baseline_iters > 0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(prob, args.cpu_baseline_iters, rows)
+            except Exception as e:  # the baseline must never take the GPU number down
+                log(f"[cpu_baseline] failed: {e!r}")
+                out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    lin.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,224 @@
+/* ============================================================================
+ * rootba_hip.h — C ABI of the MI355X-native square-root BA inner solver.
+ *
+ * Drop-in boundary for the reference's QR solver path (NikolausDemmel/rootba).
+ * The reference has no C ABI: its seams are the C++ interfaces
+ *   Linearizor<Scalar>               src/rootba/solver/linearizor.hpp:48-83
+ *   LinearizationQR<Scalar, 9>       src/rootba/qr/linearization_qr.hpp:54-841
+ *   LandmarkBlock<Scalar>            src/rootba/qr/landmark_block.hpp:49-150
+ * Each entry point below cites the reference call it replaces (file:line under
+ * /root/reference). A `LinearizorHIP<Scalar> : Linearizor<Scalar>` that binds
+ * these calls is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C: pointers, sizes, POD structs; no C++/torch types.
+ *  - one opaque handle per solver instance; `dtype` chosen at creation
+ *    (RBA_F32 / RBA_F64  <->  SolverOptions::use_double,
+ *    src/rootba/bal/solver_options.hpp:257-259). All `void*` vectors are arrays
+ *    of that scalar type in HOST memory, borrowed for the duration of the call.
+ *  - every function returns an int status: RBA_OK (0), RBA_NUMERICAL_FAILURE (1:
+ *    the reference returns an empty vector / NaN / LOG(FATAL)s here),
+ *    negative = API or HIP/RCCL error (see rba_last_error). Nothing aborts, no
+ *    exception crosses the boundary.
+ *  - a handle is not thread-safe (single caller, like the reference's LM loop);
+ *    the library owns all device memory.
+ *  - landmarks are given in CSR form: observations of landmark l are
+ *    [lm_obs_offsets[l], lm_obs_offsets[l+1]), camera indices ascending inside a
+ *    landmark (std::map order, src/rootba/bal/bal_problem.hpp:131), every
+ *    landmark has >= 2 observations (landmark_block_base.ipp:70-73).
+ *  - camera state: 10 scalars (qx,qy,qz,qw,tx,ty,tz,f,k1,k2) = Camera::params()
+ *    (bal_problem.hpp:84-95); pose/intrinsics increments: 9 per camera.
+ * ==========================================================================*/
+#ifndef ROOTBA_HIP_H_
+#define ROOTBA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBA_OK 0
+#define RBA_NUMERICAL_FAILURE 1
+#define RBA_ERR_INVALID_ARGUMENT (-1)
+#define RBA_ERR_HIP (-2)
+#define RBA_ERR_UNSUPPORTED (-3)
+#define RBA_ERR_COMM (-4)
+
+#define RBA_F32 0
+#define RBA_F64 1
+
+/* SolverOptions fields consumed by the hot path
+ * (src/rootba/bal/solver_options.hpp:111-281; read at
+ *  src/rootba/solver/linearizor_qr.cpp:58-68, linearizor_base.cpp:87-93,
+ *  bal_bundle_adjustment.cpp:264-272). Field names follow SolverOptions. */
+typedef struct rba_options {
+  int use_householder;            /* use_householder_marginalization (only 1 supported) */
+  int use_valid_projections_only; /* = use_projection_validity_check()            */
+  int robust_norm;                /* 0 NONE, 1 HUBER (bal_residual_options.hpp)   */
+  double huber_parameter;
+  double jacobi_scaling_eps;      /* 0 -> Sophus epsilonSqrt<Scalar>              */
+  int preconditioner_type;        /* 0 JACOBI, 1 SCHUR_JACOBI                     */
+  int reduction_alg;              /* accepted, ignored (always device scatter-add)*/
+  int power_order;                /* reserved for the power-series preconditioner */
+  int min_cg_it;                  /* min_linear_solver_iterations                 */
+  int max_cg_it;                  /* max_linear_solver_iterations                 */
+  double eta;
+  int num_threads;                /* accepted, ignored                            */
+  int max_num_iterations;
+  double min_relative_decrease;
+  double initial_trust_region_radius;
+  double min_trust_region_radius;
+  double max_trust_region_radius;
+  double function_tolerance;
+  double initial_vee;
+  double vee_factor;
+  int optimized_cost;             /* 0 ERROR, 1 ERROR_VALID, 2 ERROR_VALID_AVG    */
+  int staged_execution;           /* accepted; execution is always staged         */
+} rba_options;
+
+/* ResidualInfo (src/rootba/bal/residual_info.hpp:57-96), sums in double */
+typedef struct rba_residual_info {
+  int all_num_obs;
+  double all_error;
+  double all_residual_sum;
+  int valid_num_obs;
+  double valid_error;
+  double valid_residual_sum;
+  int is_numerically_valid;
+} rba_residual_info;
+
+/* ConjugateGradientsSolver::Summary (src/rootba/cg/conjugate_gradient.hpp:97-108) */
+typedef struct rba_cg_summary {
+  int termination_type; /* 0 NO_CONVERGENCE, 1 SUCCESS, 2 FAILURE */
+  int num_iterations;
+} rba_cg_summary;
+
+/* IterationSummary stage timings (src/rootba/solver/solver_summary.hpp:183-204),
+ * seconds, measured with HIP events on the solver stream. */
+typedef struct rba_iter_timings {
+  double residual_evaluation_time;
+  double stage1_time;
+  double stage2_time;
+  double compute_preconditioner_time;
+  double solve_reduced_system_time;
+  double back_substitution_time;
+  double update_cameras_time;
+  double hx_time;      /* sum over right_multiply launches of the last solve */
+  int hx_calls;        /* number of right_multiply calls in the last solve  */
+} rba_iter_timings;
+
+/* One row of the LM log: subset of IterationSummary
+ * (src/rootba/solver/solver_summary.hpp:99-204). */
+typedef struct rba_lm_iteration {
+  int iteration;
+  int step_is_valid;
+  int step_is_successful;
+  int cg_iterations;
+  int cg_termination;
+  double cost;       /* cost.all.error after the step attempt   */
+  double cost_valid; /* cost.valid.error                        */
+  double lambda;     /* damping used for this iteration's solve */
+  double relative_decrease;
+  double l_diff;
+  double inc_norm;
+  double iteration_time;
+  double stage1_time, stage2_time, precond_time, pcg_time, backsub_time,
+      residual_time;
+} rba_lm_iteration;
+
+typedef struct rba_solver* rba_handle;
+
+/* Defaults = examples/config/rootba_config_default.toml of the reference. */
+void rba_default_options(rba_options* out);
+const char* rba_last_error(void);
+/* Number of visible HIP devices (>= 1 required for rba_create). */
+int rba_device_count(int* out);
+
+/* LinearizationQR ctor (linearization_qr.hpp:80-111) + LinearizorQR ctor option
+ * mapping (linearizor_qr.cpp:58-68). Allocates all device storage. */
+int rba_create(int dtype, int device, int32_t n_cams, int32_t n_lms,
+               const int64_t* lm_obs_offsets, const int32_t* obs_cam_idx,
+               const void* obs_xy, const rba_options* options, rba_handle* out);
+int rba_destroy(rba_handle h);
+
+/* Landmark sharding across GPUs (no reference equivalent; the reference's
+ * thread-level reductions become all-reduces). Each rank creates
+ * a handle for ITS landmarks and ALL cameras; `unique_id` is the 128-byte
+ * ncclUniqueId produced by rank 0 with rba_comm_unique_id and distributed by
+ * the caller's launcher. */
+int rba_comm_unique_id(void* out128);
+int rba_comm_init(rba_handle h, int rank, int nranks, const void* unique_id128);
+
+/* BalProblem state upload/download (Camera::params()/from_params(),
+ * bal_problem.hpp:84-95; copy_to/from_camera_state, bal_problem.cpp:570-588). */
+int rba_set_state(rba_handle h, const void* cams10, const void* lms3);
+int rba_get_state(rba_handle h, void* cams10, void* lms3);
+/* BalProblem::backup / restore (bal_problem.cpp:590-608), device-side copies. */
+int rba_backup(rba_handle h);
+int rba_restore(rba_handle h);
+
+/* LinearizorBase::compute_error -> BalBundleAdjustmentHelper::compute_error
+ * (linearizor_base.cpp:60-68, bal_bundle_adjustment_helper.cpp:68-109). */
+int rba_compute_error(rba_handle h, rba_residual_info* out);
+
+/* LinearizationQR::get_stage1 (linearization_qr.hpp:634-712) + the scaling
+ * vector of LinearizorQR::linearize (linearizor_qr.cpp:78-138).
+ * jp_diag2_out (9*n_cams, nullable) receives the squared column norms of Jp.
+ * Returns RBA_NUMERICAL_FAILURE where the reference returns an empty vector. */
+int rba_linearize(rba_handle h, void* jp_diag2_out);
+
+/* LinearizorQR::solve (linearizor_qr.cpp:141-265): set_pose_damping,
+ * get_stage2 (linearization_qr.hpp:716-815), BlockDiagonalPreconditioner
+ * (preconditioner.hpp:79-120), PCG (conjugate_gradient.hpp:113-298). inc_out
+ * (9*n_cams) is already negated (linearizor_base.cpp:100). */
+int rba_solve(rba_handle h, double lambda, void* inc_out, rba_cg_summary* cg);
+
+/* Pieces of rba_solve, exposed because the reference's tests call them
+ * directly (linearization_qr.test.cpp:150-187): get_stage2 -> (b, SCHUR_JACOBI
+ * blocks 81*n_cams, nullable) and right_multiply (linearization_qr.hpp:821-825). */
+int rba_stage2(rba_handle h, double lambda, void* b_out, void* blocks_out);
+int rba_right_multiply(rba_handle h, const void* x, void* y);
+
+/* LinearizorQR::apply (linearizor_qr.cpp:268-291): back_substitute
+ * (linearization_qr.hpp:165-179, landmark_block_base.ipp:212-284), un-scale,
+ * camera retraction. l_diff_out is NaN (status 1) on a non-finite update. */
+int rba_apply(rba_handle h, const void* inc, double* l_diff_out);
+/* LinearizationQR::back_substitute alone (landmarks only; reference tests call
+ * it with a random increment, linearization_qr.test.cpp:194-200). */
+int rba_back_substitute(rba_handle h, const void* inc, double* l_diff_out);
+
+/* optimize_lm_ours (src/rootba/solver/bal_bundle_adjustment.cpp:249-544): the
+ * serial LM loop, same lambda schedule and termination. Writes at most max_rows
+ * log rows; *n_rows_out = rows produced; *termination_out = 0 NO_CONVERGENCE,
+ * 1 CONVERGENCE, -1 numerical failure. */
+int rba_optimize_lm(rba_handle h, rba_lm_iteration* log, int max_rows,
+                    int* n_rows_out, int* termination_out);
+
+/* The same loop, resumable: rba_lm_begin resets lambda / counters, every
+ * rba_lm_step performs exactly ONE LM iteration (= one row of the reference's
+ * iteration log; iteration 0 is the evaluation-only row) and sets *more_out to
+ * 0 once the loop has terminated. rba_optimize_lm == begin + step until 0. */
+int rba_lm_begin(rba_handle h);
+int rba_lm_step(rba_handle h, rba_lm_iteration* row, int* more_out);
+int rba_lm_termination(rba_handle h, int* termination_out);
+/* Block until all work queued on the handle's stream has finished. */
+int rba_synchronize(rba_handle h);
+
+int rba_get_timings(rba_handle h, rba_iter_timings* out);
+
+/* Introspection used by the parity tests (invariants of SURVEY.md §8c). */
+int rba_get_jl_col_scale(rba_handle h, void* out3_per_lm);
+int rba_get_pose_scaling(rba_handle h, void* out9_per_cam);
+/* R (3x3 upper, 6 scalars r00 r01 r02 r11 r12 r22) and Q1^T r (3) per landmark,
+ * undamped (damped = 0) or with the current landmark damping (damped = 1). */
+int rba_get_landmark_R(rba_handle h, int damped, void* R6_per_lm,
+                       void* q1tr3_per_lm);
+/* Algorithmic byte/flop counts of the resident topology. */
+int rba_get_problem_stats(rba_handle h, int64_t* block_storage_bytes,
+                          int64_t* hx_algorithmic_bytes, int64_t* hx_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROOTBA_HIP_H_ */

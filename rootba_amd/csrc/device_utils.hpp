@@ -1,0 +1,221 @@
+// device_utils.hpp — wave64 primitives and per-observation geometry for gfx950.
+//
+// MI355X-native building blocks shared by all landmark kernels:
+//  * wave_sum(): 64-lane reduction on the DPP network (no LDS, no shuffles
+//    through the LDS crossbar), result broadcast through an SGPR readlane;
+//  * hardware floating-point atomics for the camera-indexed scatter-adds;
+//  * the BAL/Snavely projection with analytic Jacobians, i.e. what the reference
+//    evaluates per observation in BalBundleAdjustmentHelper::linearize_point
+//    (reference src/rootba/bal/bal_bundle_adjustment_helper.cpp:111-149, camera
+//    model basalt::BalCamera) — restated for one GPU lane.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+namespace rba {
+
+constexpr int P = 9;  // POSE_SIZE: 6 pose + 3 intrinsics (linearizor_qr.hpp:51)
+
+// ---------------------------------------------------------------------------
+// DPP wave reduction (wave64). Steps: quad_perm[1,0,3,2], quad_perm[2,3,0,1],
+// row_ror:4, row_ror:8 give every lane its 16-lane row sum; row_bcast:15 and
+// row_bcast:31 fold the four rows into lane 63.
+// MUST be called with all 64 lanes active (wave-uniform control flow).
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov0(float v) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov0(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, int(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, int(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) |
+                              static_cast<unsigned int>(lo));
+}
+
+__device__ __forceinline__ float read_lane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane(int(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane(int(b >> 32), lane);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) |
+                              static_cast<unsigned int>(lo));
+}
+
+template <class S>
+__device__ __forceinline__ S wave_sum(S v) {
+  v += dpp_mov0<0xb1>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_mov0<0x4e>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_mov0<0x124>(v);  // row_ror:4
+  v += dpp_mov0<0x128>(v);  // row_ror:8
+  v += dpp_mov0<0x142>(v);  // row_bcast:15
+  v += dpp_mov0<0x143>(v);  // row_bcast:31
+  return read_lane(v, 63);
+}
+
+// compiler-level ordering of LDS traffic inside ONE wave (the LDS itself
+// executes a wave's DS instructions in issue order)
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// hardware FP atomics (global_atomic_add_f32 / _f64), no CAS loop
+__device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+template <class S>
+struct Eps;
+// Sophus::Constants<Scalar>::epsilon() / epsilonSqrt()
+template <>
+struct Eps<float> {
+  static constexpr float eps = 1e-5f;
+  static constexpr float eps_sqrt = 3.1622776601683794e-3f;
+  static constexpr float tiny = 1.17549435e-38f;  // FLT_MIN (Eigen makeHouseholder tol)
+};
+template <>
+struct Eps<double> {
+  static constexpr double eps = 1e-10;
+  static constexpr double eps_sqrt = 1e-5;
+  static constexpr double tiny = 2.2250738585072014e-308;
+};
+
+template <class S>
+__device__ __forceinline__ bool is_finite(S v) {
+  return isfinite(v);
+}
+
+// unit quaternion (x,y,z,w) -> rotation matrix, row-major
+template <class S>
+__device__ __forceinline__ void quat_to_rot(S x, S y, S z, S w, S R[9]) {
+  const S tx = S(2) * x, ty = S(2) * y, tz = S(2) * z;
+  const S twx = tx * w, twy = ty * w, twz = tz * w;
+  const S txx = tx * x, txy = ty * x, txz = tz * x;
+  const S tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = S(1) - (tyy + tzz);
+  R[1] = txy - twz;
+  R[2] = txz + twy;
+  R[3] = txy + twz;
+  R[4] = S(1) - (txx + tzz);
+  R[5] = tyz - twx;
+  R[6] = txz - twy;
+  R[7] = tyz + twx;
+  R[8] = S(1) - (txx + tyy);
+}
+
+// Residual only (compute_error path). cam = (q xyzw, t, f, k1, k2).
+template <class S>
+__device__ __forceinline__ bool project_residual(const S* __restrict__ cam, S pwx, S pwy, S pwz,
+                                                 S ox, S oy, S& rx, S& ry) {
+  S R[9];
+  quat_to_rot(cam[0], cam[1], cam[2], cam[3], R);
+  const S px = R[0] * pwx + R[1] * pwy + R[2] * pwz + cam[4];
+  const S py = R[3] * pwx + R[4] * pwy + R[5] * pwz + cam[5];
+  const S pz = R[6] * pwx + R[7] * pwy + R[8] * pwz + cam[6];
+  const S mx = px / pz, my = py / pz;
+  const S r2 = mx * mx + my * my;
+  const S rp = S(1) + cam[8] * r2 + cam[9] * r2 * r2;
+  rx = cam[7] * mx * rp - ox;
+  ry = cam[7] * my * rp - oy;
+  return pz >= Eps<S>::eps_sqrt;
+}
+
+// Huber / trivial loss: weighted error and weight
+// (compute_error_weight, bal_bundle_adjustment_helper.cpp:43-66)
+template <class S>
+__device__ __forceinline__ void error_weight(int robust_norm, S huber, S res_sq, S& err, S& w) {
+  if (robust_norm == 1) {
+    w = res_sq < huber * huber ? S(1) : huber / sqrt(res_sq);
+    err = S(0.5) * (S(2) - w) * w * res_sq;
+  } else {
+    w = S(1);
+    err = S(0.5) * res_sq;
+  }
+}
+
+// Full linearisation of one observation.
+// Jp: 2x9 row-major ([pose(6) | intrinsics(3)]), Jl: 2x3, res: 2.
+template <class S>
+__device__ __forceinline__ bool linearize_obs(const S* __restrict__ cam, S pwx, S pwy, S pwz,
+                                              S ox, S oy, S res[2], S Jp[18], S Jl[6]) {
+  S R[9];
+  quat_to_rot(cam[0], cam[1], cam[2], cam[3], R);
+  const S f = cam[7], k1 = cam[8], k2 = cam[9];
+  const S px = R[0] * pwx + R[1] * pwy + R[2] * pwz + cam[4];
+  const S py = R[3] * pwx + R[4] * pwy + R[5] * pwz + cam[5];
+  const S pz = R[6] * pwx + R[7] * pwy + R[8] * pwz + cam[6];
+  const S iz = S(1) / pz;
+  const S mx = px * iz, my = py * iz;
+  const S r2 = mx * mx + my * my;
+  const S r4 = r2 * r2;
+  const S rp = S(1) + k1 * r2 + k2 * r4;
+  res[0] = f * mx * rp - ox;
+  res[1] = f * my * rp - oy;
+  const S tmp = k1 + S(2) * k2 * r2;
+  // d proj / d p_cam
+  S J[6];
+  J[0] = f * (rp + S(2) * mx * mx * tmp) * iz;
+  J[1] = S(2) * f * mx * my * tmp * iz;
+  J[2] = -f * mx * (rp + S(2) * r2 * tmp) * iz;
+  J[3] = J[1];
+  J[4] = f * (rp + S(2) * my * my * tmp) * iz;
+  J[5] = -f * my * (rp + S(2) * r2 * tmp) * iz;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const S j0 = J[3 * r], j1 = J[3 * r + 1], j2 = J[3 * r + 2];
+    // pose part: [I | -hat(p_cam)]
+    Jp[9 * r + 0] = j0;
+    Jp[9 * r + 1] = j1;
+    Jp[9 * r + 2] = j2;
+    Jp[9 * r + 3] = j2 * py - j1 * pz;
+    Jp[9 * r + 4] = j0 * pz - j2 * px;
+    Jp[9 * r + 5] = j1 * px - j0 * py;
+    // landmark part: J * R
+    Jl[3 * r + 0] = j0 * R[0] + j1 * R[3] + j2 * R[6];
+    Jl[3 * r + 1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
+    Jl[3 * r + 2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
+  }
+  // intrinsics part (f, k1, k2)
+  Jp[6] = mx * rp;
+  Jp[7] = f * mx * r2;
+  Jp[8] = f * mx * r4;
+  Jp[15] = my * rp;
+  Jp[16] = f * my * r2;
+  Jp[17] = f * my * r4;
+  return pz >= Eps<S>::eps_sqrt;
+}
+
+// Eigen-style Givens coefficients: G^T [p; q] = [r; 0]
+template <class S>
+__device__ __forceinline__ void make_givens(S p, S q, S& c, S& s) {
+  if (q == S(0)) {
+    c = p < S(0) ? S(-1) : S(1);
+    s = S(0);
+  } else if (p == S(0)) {
+    c = S(0);
+    s = q < S(0) ? S(1) : S(-1);
+  } else if (fabs(p) > fabs(q)) {
+    const S t = q / p;
+    S u = sqrt(S(1) + t * t);
+    if (p < S(0)) u = -u;
+    c = S(1) / u;
+    s = -t * c;
+  } else {
+    const S t = p / q;
+    S u = sqrt(S(1) + t * t);
+    if (q < S(0)) u = -u;
+    s = -S(1) / u;
+    c = -t * s;
+  }
+}
+
+}  // namespace rba

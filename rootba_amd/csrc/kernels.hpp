@@ -1,0 +1,1121 @@
+// kernels.hpp — hand-written HIP kernels (gfx950) of the square-root BA solver.
+//
+// Mapping used by every landmark kernel: ONE WAVEFRONT PER LANDMARK, lanes run
+// along the 9k pose columns of the landmark's block. A chunk is 7 whole cameras
+// = 63 columns (lane 63 idles), so a camera's 9 columns never straddle chunks:
+// column j = 63*chunk + lane, camera slot i = 7*chunk + lane/9, component
+// lane%9; CH chunks per lane are chosen per k-class (k <= 7*CH). Rows are streamed. Cross-lane sums
+// (one per block row) use the DPP network. Landmarks are sorted by k at setup
+// so that a launch covers one contiguous k-class with a compile-time CH.
+//
+// Device layout per landmark s (k observations, sorted order):
+//   A     [2k x 9k] row-major, dense: rows 0..2k-4 = Q2^T Jp (scaled), rows
+//         2k-3..2k-1 = the three landmark-damping rows      -> operand of H*x
+//   top0  [k][3][9] Q1^T Jp (undamped), observation-major; topd: with damping
+//   qtr   [2k]      Q^T r (first 3 = Q1^T r);   R0 / Rd [6] upper 3x3 of R
+// i.e. the reference's (2k+3) x (9k+pad+4) LandmarkBlock storage
+// (landmark_block_dynamic.hpp:49-69) split into its streamed and its small
+// parts. See DESIGN.md for bytes per kernel.
+#pragma once
+
+#include "device_utils.hpp"
+
+namespace rba {
+
+template <class S>
+struct Params {
+  int n_cams;
+  int n_lms;
+  // topology (sorted landmark order)
+  const int* __restrict__ lm_k;         // [n_lms]
+  const int64_t* __restrict__ lm_obs;   // [n_lms+1] first observation
+  const int64_t* __restrict__ lm_blk;   // [n_lms+1] offset of A block (scalars)
+  const int* __restrict__ obs_cam;      // [n_obs]
+  const int* __restrict__ obs_lm;       // [n_obs] sorted landmark index
+  const S* __restrict__ obs_xy;         // [2 n_obs]
+  const int64_t* __restrict__ cam_obs_off;  // [n_cams+1] CSC: observations of a camera
+  const int* __restrict__ cam_obs;          // [n_obs] sorted-observation indices
+  // state
+  S* cams;  // [10 n_cams]
+  S* lms;   // [3 n_lms]
+  // landmark blocks
+  S* A;
+  S* top0;      // [n_obs][3][9] Q1^T Jp, undamped (observation-major)
+  S* topd;      // [n_obs][3][9] with landmark damping
+  S* dampO;     // [n_obs][3][9] copy of the damping rows (observation-major)
+  S* JpS;       // [n_obs][2][9] weighted, column-scaled pose Jacobian
+  S* bmO;       // [n_obs][9]    per-observation part of b from the Q2 rows
+  S* qtr;       // [2 n_obs]
+  S* R0;        // [6 n_lms]
+  S* Rd;        // [6 n_lms]
+  S* q1trd;     // [3 n_lms]
+  S* damp_r;    // [3 n_lms]
+  S* jl_scale;  // [3 n_lms]
+  // camera-sized vectors
+  S* jp_diag2;      // [9 n_cams]
+  S* pose_scaling;  // [9 n_cams]
+  S* b_mid;         // [9 n_cams]
+  S* B_mid;         // [81 n_cams]
+  S* b;             // [9 n_cams]
+  S* blocks;        // [81 n_cams]
+  int* fail_flag;   // numerical failure
+  double* lm_ldiff;  // [n_lms] per-landmark model cost change
+  // options
+  int robust_norm;
+  int valid_only;
+  int jacobi;  // preconditioner_type == JACOBI
+  S huber;
+  S eps;  // jacobi scaling epsilon
+};
+
+// ===========================================================================
+// compute_error: one thread per observation, per-block partial sums (double)
+// (BalBundleAdjustmentHelper::compute_error, helper.cpp:68-109;
+//  ResidualInfoAccu::add, residual_info.cpp:97-110)
+// partials layout: [block][8] = {n_all, e_all, r_all, n_valid, e_valid, r_valid, n_nonfinite, 0}
+// ===========================================================================
+template <class S>
+__global__ __launch_bounds__(256) void k_compute_error(Params<S> p, int64_t n_obs,
+                                                       double* __restrict__ partials) {
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int64_t o = blockIdx.x * 256ll + threadIdx.x; o < n_obs; o += gridDim.x * 256ll) {
+    const int cam = p.obs_cam[o];
+    const int l = p.obs_lm[o];
+    S rx, ry;
+    const bool valid = project_residual<S>(p.cams + 10 * cam, p.lms[3 * l], p.lms[3 * l + 1],
+                                           p.lms[3 * l + 2], p.obs_xy[2 * o], p.obs_xy[2 * o + 1],
+                                           rx, ry);
+    const S r2 = rx * rx + ry * ry;
+    S err, w;
+    error_weight<S>(p.robust_norm, p.huber, r2, err, w);
+    const double rn = double(sqrt(r2));
+    acc[0] += 1.0;
+    acc[1] += double(err);
+    acc[2] += rn;
+    if (valid) {
+      acc[3] += 1.0;
+      acc[4] += double(err);
+      acc[5] += rn;
+    }
+    if (!(is_finite(rx) && is_finite(ry))) acc[6] += 1.0;
+  }
+  __shared__ double sm[4][7];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const double t = wave_sum(acc[i]);
+    if (lane == 0) sm[wave][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7)
+    partials[blockIdx.x * 8 + threadIdx.x] =
+        sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+// Sum rows of a [n][W] double array into out[W] (single block, deterministic).
+template <int W>
+__global__ __launch_bounds__(256) void k_reduce_rows(const double* __restrict__ in, int64_t n,
+                                                     double* __restrict__ out) {
+  double acc[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) acc[i] = 0;
+  for (int64_t r = threadIdx.x; r < n; r += 256) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) acc[i] += in[r * W + i];
+  }
+  __shared__ double sm[4][W];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    const double t = wave_sum(acc[i]);
+    if (lane == 0) sm[wave][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < W)
+    out[threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+// ===========================================================================
+// Camera-major reductions. Every camera-indexed accumulator of the reference
+// (Jp_diag2, b, the 9x9 block diagonal; reduction table in SURVEY.md §2) is
+// produced by ONE workgroup per camera that walks the camera's observation list
+// (CSC index built at setup) — no atomics, fixed summation order, double
+// accumulators. The landmark-major kernels only write per-observation records.
+// ===========================================================================
+__device__ __forceinline__ double block_sum_256(double v, double* sm4) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double t = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sm4[wave] = t;
+  __syncthreads();
+  return sm4[0] + sm4[1] + sm4[2] + sm4[3];
+}
+
+// Stage 1, pass A: squared column norms of the weighted pose Jacobian
+// (add_Jp_diag2, landmark_block_base.ipp:493-518) and the non-finite check of
+// linearize_landmark (ipp:123-146).
+template <class S>
+__global__ __launch_bounds__(256) void k_cam_jp_diag2(Params<S> p) {
+  __shared__ double sm4[4];
+  const int c = blockIdx.x;
+  S cam[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) cam[i] = p.cams[10 * c + i];
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool fin = true;
+  for (int64_t t = p.cam_obs_off[c] + threadIdx.x; t < p.cam_obs_off[c + 1]; t += 256) {
+    const int o = p.cam_obs[t];
+    const int l = p.obs_lm[o];
+    S res[2], Jp[18], Jl[6];
+    const bool valid = linearize_obs<S>(cam, p.lms[3 * l], p.lms[3 * l + 1], p.lms[3 * l + 2],
+                                        p.obs_xy[2 * o], p.obs_xy[2 * o + 1], res, Jp, Jl);
+    if (p.valid_only && !valid) continue;
+    fin = fin && is_finite(res[0]) && is_finite(res[1]);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) fin = fin && is_finite(Jp[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fin = fin && is_finite(Jl[i]);
+    S err, w;
+    error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
+#pragma unroll
+    for (int a = 0; a < 9; ++a) acc[a] += double(w * (Jp[a] * Jp[a] + Jp[9 + a] * Jp[9 + a]));
+  }
+  if (!fin) atomicOr(p.fail_flag, 1);
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+    const double t = block_sum_256(acc[a], sm4);
+    if (threadIdx.x == 0) p.jp_diag2[9 * c + a] = S(t);
+  }
+}
+
+// Stage 1, camera-major part: damping-independent terms of the preconditioner
+// and of the gradient,
+//   B_mid[c] = sum_obs ( JpS^T JpS - top0^T top0 )   (== sum over the Q2 rows of
+//              (Q2^T Jp)_c^T (Q2^T Jp)_c, because Q is orthogonal;
+//              add_Q2TJp_T_Q2TJp_blockdiag ipp:520-552 without the damping rows;
+//              JACOBI: JpS^T JpS only, add_Jp_T_Jp_blockdiag ipp:554-569)
+//   b_mid[c] = sum_obs bmO                           (add_Q2TJp_T_Q2Tr ipp:443-466)
+// Threads 0..242: 3 observation groups x 81 block entries; 243..251: b.
+template <class S>
+__global__ __launch_bounds__(256) void k_cam_stage1(Params<S> p) {
+  constexpr int TILE = 48;
+  __shared__ S rec[TILE][54];  // [JpS 18 | top0 27 | bmO 9]
+  __shared__ double red[3][81];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
+  double acc = 0;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  for (int64_t base = t0; base < t1; base += TILE) {
+    const int n = int(min<int64_t>(TILE, t1 - base));
+    __syncthreads();
+    for (int idx = tid; idx < n * 54; idx += 256) {
+      const int q = idx / 54, f = idx - 54 * q;
+      const int64_t o = p.cam_obs[base + q];
+      S v;
+      if (f < 18)
+        v = p.JpS[o * 18 + f];
+      else if (f < 45)
+        v = p.top0[o * 27 + (f - 18)];
+      else
+        v = p.bmO[o * 9 + (f - 45)];
+      rec[q][f] = v;
+    }
+    __syncthreads();
+    if (grp < 3) {
+      for (int q = grp; q < n; q += 3) {
+        const S* r = rec[q];
+        S v = r[ea] * r[eb] + r[9 + ea] * r[9 + eb];
+        if (!p.jacobi)
+          v -= r[18 + ea] * r[18 + eb] + r[27 + ea] * r[27 + eb] + r[36 + ea] * r[36 + eb];
+        acc += double(v);
+      }
+    } else if (tid < 252) {
+      const int a = tid - 243;
+      for (int q = 0; q < n; ++q) acc += double(rec[q][45 + a]);
+    }
+  }
+  if (grp < 3) red[grp][e] = acc;
+  __syncthreads();
+  if (tid < 81) p.B_mid[81 * c + tid] = S(red[0][tid] + red[1][tid] + red[2][tid]);
+  if (tid >= 243 && tid < 252) p.b_mid[9 * c + (tid - 243)] = S(acc);
+}
+
+// Stage 2, camera-major part:
+//   blocks[c] = B_mid[c] + lambda I + sum_obs dampO^T dampO
+//   b[c]      = b_mid[c] + sum_obs dampO^T damp_r[landmark]
+// (last three rows of add_Q2TJp_T_Q2TJp_blockdiag / add_Q2TJp_T_Q2Tr; pose
+//  damping on the preconditioner: linearization_qr.hpp:796-802, JACOBI:
+//  linearizor_qr.cpp:227-232)
+template <class S>
+__global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
+  constexpr int TILE = 64;
+  __shared__ S rec[TILE][30];  // [dampO 27 | damp_r 3]
+  __shared__ double red[3][81];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
+  double acc = 0;
+  if (lambda != S(0)) {
+    const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+    for (int64_t base = t0; base < t1; base += TILE) {
+      const int n = int(min<int64_t>(TILE, t1 - base));
+      __syncthreads();
+      for (int idx = tid; idx < n * 30; idx += 256) {
+        const int q = idx / 30, f = idx - 30 * q;
+        const int64_t o = p.cam_obs[base + q];
+        rec[q][f] = f < 27 ? p.dampO[o * 27 + f] : p.damp_r[3 * int64_t(p.obs_lm[o]) + (f - 27)];
+      }
+      __syncthreads();
+      if (grp < 3) {
+        if (!p.jacobi) {
+          for (int q = grp; q < n; q += 3) {
+            const S* r = rec[q];
+            acc += double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb] + r[18 + ea] * r[18 + eb]);
+          }
+        }
+      } else if (tid < 252) {
+        const int a = tid - 243;
+        for (int q = 0; q < n; ++q) {
+          const S* r = rec[q];
+          acc += double(r[a] * r[27] + r[9 + a] * r[28] + r[18 + a] * r[29]);
+        }
+      }
+    }
+  }
+  if (grp < 3) red[grp][e] = acc;
+  __syncthreads();
+  if (tid < 81)
+    p.blocks[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + red[0][tid] + red[1][tid] +
+                               red[2][tid] + ((tid / 9 == tid % 9) ? double(lambda) : 0.0));
+  if (tid >= 243 && tid < 252)
+    p.b[9 * c + (tid - 243)] = S(double(p.b_mid[9 * c + (tid - 243)]) + acc);
+}
+
+// pose_jacobian_scaling = 1 / (eps + sqrt(Jp_diag2))   (linearizor_qr.cpp:130-132)
+template <class S>
+__global__ void k_pose_scaling(const S* __restrict__ d2, S* __restrict__ sc, S eps, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sc[i] = S(1) / (eps + sqrt(d2[i]));
+}
+
+// ===========================================================================
+// Stage 1, pass B: linearise + scale + Householder-marginalise one landmark per
+// wavefront, write the block, and accumulate the damping-independent parts of
+// the RCS gradient and of the block-diagonal preconditioner.
+//   (linearize_landmark ipp:88-147, scale_Jl_cols ipp:571-587,
+//    perform_qr_householder ipp:717-743, scale_Jp_cols ipp:589-614,
+//    mid-row parts of add_Q2TJp_T_Q2Tr ipp:443-466 and
+//    add_Q2TJp_T_Q2TJp_blockdiag ipp:520-552 / add_Jp_T_Jp_blockdiag ipp:554-569)
+// The three reflectors are applied in compact form: column j of Jp has only two
+// non-zero rows, so v_m^T Jp[:,j] costs 2 FMAs and the rank-3 update is 3 FMAs
+// per element; Q depends on Jl only, so the Jp column scaling commutes with it
+// and is folded in here (pass A made the scale available).
+// LDS per wave: JpL[k][18], V[2k][4] (v0,v1,v2,Q^T r).
+// ===========================================================================
+template <int CH>
+struct ClassCfg {
+  static constexpr int KMAX = 7 * CH;
+  static constexpr int RCH = (2 * KMAX + 63) / 64;
+  static constexpr int WAVE_LDS = 18 * KMAX + 8 * KMAX;  // scalars
+};
+
+template <class S, int CH>
+__global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin, int lm_end) {
+  using Cfg = ClassCfg<CH>;
+  constexpr int RCH = Cfg::RCH;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;  // whole wave exits; no block-level barriers below
+  S* JpL = reinterpret_cast<S*>(smem_raw) + size_t(wave) * Cfg::WAVE_LDS;
+  S* V = JpL + 18 * Cfg::KMAX;   // [2k][4]
+
+  const int k = p.lm_k[s];
+  const int64_t o0 = p.lm_obs[s];
+  const int nrows = 2 * k, ncols = 9 * k;
+  const S pwx = p.lms[3 * s], pwy = p.lms[3 * s + 1], pwz = p.lms[3 * s + 2];
+
+  // ---- geometry: one lane per observation --------------------------------
+  for (int i = lane; i < k; i += 64) {
+    const int64_t o = o0 + i;
+    const int cam = p.obs_cam[o];
+    S res[2], Jp[18], Jl[6];
+    const bool valid = linearize_obs<S>(p.cams + 10 * cam, pwx, pwy, pwz, p.obs_xy[2 * o],
+                                        p.obs_xy[2 * o + 1], res, Jp, Jl);
+    S sw = S(0);
+    if (!p.valid_only || valid) {
+      S err, w;
+      error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
+      sw = sqrt(w);
+    }
+#pragma unroll
+    for (int c = 0; c < 18; ++c) JpL[18 * i + c] = sw * Jp[c];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      V[4 * (2 * i + r) + 0] = sw * Jl[3 * r + 0];
+      V[4 * (2 * i + r) + 1] = sw * Jl[3 * r + 1];
+      V[4 * (2 * i + r) + 2] = sw * Jl[3 * r + 2];
+      V[4 * (2 * i + r) + 3] = sw * res[r];
+    }
+  }
+  wave_lds_fence();
+
+  // ---- row lanes: Jl (2k x 3) and residual --------------------------------
+  S jl[RCH][3], rs[RCH];
+  bool rvalid[RCH];
+#pragma unroll
+  for (int rc = 0; rc < RCH; ++rc) {
+    const int r = rc * 64 + lane;
+    rvalid[rc] = r < nrows;
+    jl[rc][0] = rvalid[rc] ? V[4 * r + 0] : S(0);
+    jl[rc][1] = rvalid[rc] ? V[4 * r + 1] : S(0);
+    jl[rc][2] = rvalid[rc] ? V[4 * r + 2] : S(0);
+    rs[rc] = rvalid[rc] ? V[4 * r + 3] : S(0);
+  }
+  wave_lds_fence();
+
+  // Jl column scaling (scale_Jl_cols)
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    S ss = S(0);
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) ss += jl[rc][c] * jl[rc][c];
+    ss = wave_sum(ss);
+    const S sc = S(1) / (p.eps + sqrt(ss));
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) jl[rc][c] *= sc;
+    if (lane == 0) p.jl_scale[3 * s + c] = sc;
+  }
+
+  // Householder QR of Jl; reflectors v_m kept in registers and in LDS
+  S vm[3][RCH];
+  S tau[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const S c0 = read_lane(jl[0][m], m);
+    S tail = S(0);
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) {
+      const int r = rc * 64 + lane;
+      tail += (r > m && rvalid[rc]) ? jl[rc][m] * jl[rc][m] : S(0);
+    }
+    tail = wave_sum(tail);
+    S beta, inv;
+    if (tail <= Eps<S>::tiny) {
+      tau[m] = S(0);
+      beta = c0;
+      inv = S(0);
+    } else {
+      beta = sqrt(c0 * c0 + tail);
+      if (c0 >= S(0)) beta = -beta;
+      inv = S(1) / (c0 - beta);
+      tau[m] = (beta - c0) / beta;
+    }
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) {
+      const int r = rc * 64 + lane;
+      vm[m][rc] = (r == m) ? S(1) : ((r > m && rvalid[rc]) ? jl[rc][m] * inv : S(0));
+    }
+    // apply to the remaining Jl columns and to the residual
+#pragma unroll
+    for (int c2 = m + 1; c2 < 3; ++c2) {
+      S d = S(0);
+#pragma unroll
+      for (int rc = 0; rc < RCH; ++rc) d += vm[m][rc] * jl[rc][c2];
+      d = tau[m] * wave_sum(d);
+#pragma unroll
+      for (int rc = 0; rc < RCH; ++rc) jl[rc][c2] -= d * vm[m][rc];
+    }
+    {
+      S d = S(0);
+#pragma unroll
+      for (int rc = 0; rc < RCH; ++rc) d += vm[m][rc] * rs[rc];
+      d = tau[m] * wave_sum(d);
+#pragma unroll
+      for (int rc = 0; rc < RCH; ++rc) rs[rc] -= d * vm[m][rc];
+    }
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) {
+      const int r = rc * 64 + lane;
+      if (r == m) jl[rc][m] = beta;
+      if (r > m) jl[rc][m] = S(0);
+    }
+  }
+  // cross products of the reflectors (compact application)
+  S g10 = S(0), g20 = S(0), g21 = S(0);
+#pragma unroll
+  for (int rc = 0; rc < RCH; ++rc) {
+    g10 += vm[1][rc] * vm[0][rc];
+    g20 += vm[2][rc] * vm[0][rc];
+    g21 += vm[2][rc] * vm[1][rc];
+  }
+  g10 = wave_sum(g10);
+  g20 = wave_sum(g20);
+  g21 = wave_sum(g21);
+
+  // R (upper 3x3), Q^T r -> global; reflectors + Q^T r -> LDS
+  {
+    const S r00 = read_lane(jl[0][0], 0), r01 = read_lane(jl[0][1], 0),
+            r02 = read_lane(jl[0][2], 0), r11 = read_lane(jl[0][1], 1),
+            r12 = read_lane(jl[0][2], 1), r22 = read_lane(jl[0][2], 2);
+    if (lane == 0) {
+      S* R = p.R0 + 6 * s;
+      R[0] = r00;
+      R[1] = r01;
+      R[2] = r02;
+      R[3] = r11;
+      R[4] = r12;
+      R[5] = r22;
+    }
+  }
+#pragma unroll
+  for (int rc = 0; rc < RCH; ++rc) {
+    const int r = rc * 64 + lane;
+    if (rvalid[rc]) {
+      V[4 * r + 0] = vm[0][rc];
+      V[4 * r + 1] = vm[1][rc];
+      V[4 * r + 2] = vm[2][rc];
+      V[4 * r + 3] = rs[rc];
+      p.qtr[2 * o0 + r] = rs[rc];
+    }
+  }
+  wave_lds_fence();
+
+  // ---- column lanes: apply Q^T to the scaled Jp, stream the block out ------
+  S* Ablk = p.A + p.lm_blk[s];
+  S* T0 = p.top0 + 27 * o0;
+  const int lane9 = lane / 9, comp = lane - 9 * lane9;
+#pragma unroll 1
+  for (int ch = 0; ch < CH; ++ch) {
+    const int islot = 7 * ch + lane9;
+    const bool act = lane < 63 && islot < k;
+    const int i = act ? islot : 0;
+    const int j = 9 * i + comp;
+    const int cam = act ? p.obs_cam[o0 + i] : 0;
+    S m0 = S(0), m1 = S(0);
+    if (act) {
+      const S d = p.pose_scaling[9 * cam + comp];
+      m0 = JpL[18 * i + comp] * d;
+      m1 = JpL[18 * i + 9 + comp] * d;
+    }
+    const S va0 = V[4 * (2 * i) + 0], va1 = V[4 * (2 * i) + 1], va2 = V[4 * (2 * i) + 2];
+    const S vb0 = V[4 * (2 * i + 1) + 0], vb1 = V[4 * (2 * i + 1) + 1],
+            vb2 = V[4 * (2 * i + 1) + 2];
+    const S c0 = tau[0] * (va0 * m0 + vb0 * m1);
+    const S c1 = tau[1] * (va1 * m0 + vb1 * m1 - c0 * g10);
+    const S c2 = tau[2] * (va2 * m0 + vb2 * m1 - c0 * g20 - c1 * g21);
+    S bm = S(0);
+    for (int r = 0; r < nrows; ++r) {
+      const S w0 = V[4 * r + 0], w1 = V[4 * r + 1], w2 = V[4 * r + 2], cr = V[4 * r + 3];
+      S val = -(c0 * w0 + c1 * w1 + c2 * w2);
+      if (r == 2 * i) val += m0;
+      if (r == 2 * i + 1) val += m1;
+      if (r < 3) {
+        if (act) T0[27 * i + 9 * r + comp] = val;  // [i][r][comp]
+      } else {
+        if (act) Ablk[size_t(r - 3) * ncols + j] = val;
+        bm += val * cr;
+      }
+    }
+    if (act) {
+      // landmark-damping rows start out as zeros
+      Ablk[size_t(nrows - 3) * ncols + j] = S(0);
+      Ablk[size_t(nrows - 2) * ncols + j] = S(0);
+      Ablk[size_t(nrows - 1) * ncols + j] = S(0);
+      p.JpS[(o0 + i) * 18 + comp] = m0;
+      p.JpS[(o0 + i) * 18 + 9 + comp] = m1;
+      p.bmO[(o0 + i) * 9 + comp] = bm;
+    }
+  }
+}
+
+// ===========================================================================
+// Stage 2: landmark damping by 6 Givens rotations against the stored undamped
+// top rows, plus the damping rows' contribution to b and to the block diagonal
+// (set_landmark_damping ipp:165-210; add_Q2TJp_T_Q2Tr ipp:443-466 and
+//  add_Q2TJp_T_Q2TJp_blockdiag ipp:520-552, last three rows).
+// Nothing is "undone": the damped rows are always rebuilt from top0/R0. The
+// camera-indexed sums of the damping rows are taken by k_cam_stage2 from the
+// observation-major copy dampO written here.
+// ===========================================================================
+template <class S, int CH>
+__global__ __launch_bounds__(256) void k_stage2(Params<S> p, int lm_begin, int lm_end, S lambda) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;
+  const int k = p.lm_k[s];
+  const int64_t o0 = p.lm_obs[s];
+  const int nrows = 2 * k, ncols = 9 * k;
+
+  // small part, computed redundantly by every lane: [R | q] rows 0..2 and the
+  // damping rows [sqrt(lambda) I | 0]
+  S T[3][4], D[3][4];
+  {
+    const S* R = p.R0 + 6 * s;
+    T[0][0] = R[0];
+    T[0][1] = R[1];
+    T[0][2] = R[2];
+    T[1][0] = S(0);
+    T[1][1] = R[3];
+    T[1][2] = R[4];
+    T[2][0] = S(0);
+    T[2][1] = S(0);
+    T[2][2] = R[5];
+    T[0][3] = p.qtr[2 * o0 + 0];
+    T[1][3] = p.qtr[2 * o0 + 1];
+    T[2][3] = p.qtr[2 * o0 + 2];
+  }
+  const S sl = sqrt(lambda);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) D[a][b] = (a == b) ? sl : S(0);
+  S gc[6], gs[6];
+  {
+    int idx = 0;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+#pragma unroll
+      for (int m = 0; m <= n; ++m) {
+        S c = S(1), sn = S(0);
+        if (lambda != S(0)) make_givens<S>(T[n][n], D[n - m][n], c, sn);
+        gc[idx] = c;
+        gs[idx] = sn;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const S x = D[n - m][b], y = T[n][b];
+          D[n - m][b] = c * x + sn * y;
+          T[n][b] = -sn * x + c * y;
+        }
+        ++idx;
+      }
+    }
+  }
+  if (lane == 0) {
+    S* R = p.Rd + 6 * s;
+    R[0] = T[0][0];
+    R[1] = T[0][1];
+    R[2] = T[0][2];
+    R[3] = T[1][1];
+    R[4] = T[1][2];
+    R[5] = T[2][2];
+    p.q1trd[3 * s + 0] = T[0][3];
+    p.q1trd[3 * s + 1] = T[1][3];
+    p.q1trd[3 * s + 2] = T[2][3];
+    p.damp_r[3 * s + 0] = D[0][3];
+    p.damp_r[3 * s + 1] = D[1][3];
+    p.damp_r[3 * s + 2] = D[2][3];
+  }
+
+  S* Ablk = p.A + p.lm_blk[s];
+  const S* T0 = p.top0 + 27 * o0;
+  S* Td = p.topd + 27 * o0;
+  S* DO = p.dampO + 27 * o0;
+  const int lane9 = lane / 9, comp = lane - 9 * lane9;
+#pragma unroll 1
+  for (int ch = 0; ch < CH; ++ch) {
+    const int islot = 7 * ch + lane9;
+    const bool act = lane < 63 && islot < k;
+    const int i = act ? islot : 0;
+    const int j = 9 * i + comp;
+    S t[3] = {S(0), S(0), S(0)}, d[3] = {S(0), S(0), S(0)};
+    if (act) {
+      t[0] = T0[27 * i + comp];
+      t[1] = T0[27 * i + 9 + comp];
+      t[2] = T0[27 * i + 18 + comp];
+    }
+    {
+      int idx = 0;
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+#pragma unroll
+        for (int m = 0; m <= n; ++m) {
+          const S x = d[n - m], y = t[n];
+          d[n - m] = gc[idx] * x + gs[idx] * y;
+          t[n] = -gs[idx] * x + gc[idx] * y;
+          ++idx;
+        }
+      }
+    }
+    if (act) {
+      Td[27 * i + comp] = t[0];
+      Td[27 * i + 9 + comp] = t[1];
+      Td[27 * i + 18 + comp] = t[2];
+      DO[27 * i + comp] = d[0];
+      DO[27 * i + 9 + comp] = d[1];
+      DO[27 * i + 18 + comp] = d[2];
+      Ablk[size_t(nrows - 3) * ncols + j] = d[0];
+      Ablk[size_t(nrows - 2) * ncols + j] = d[1];
+      Ablk[size_t(nrows - 1) * ncols + j] = d[2];
+    }
+  }
+}
+
+// ===========================================================================
+// H*x = sum_l A_l^T (A_l x_l)  — the dominant kernel
+// (add_Q2TJp_T_Q2TJp_mult_x ipp:400-441 via get_Q2TJp_T_Q2TJp_mult_x_v3,
+//  linearization_qr.hpp:406-429). A is read exactly once: a row lives in
+// registers between the dot product (DPP reduction) and the rank-1 update.
+// ===========================================================================
+template <class S, int CH, int U>
+__global__ __launch_bounds__(256) void k_hx(Params<S> p, int lm_begin, int lm_end,
+                                            const S* __restrict__ x, S* __restrict__ y) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;
+  const int k = p.lm_k[s];
+  const int64_t o0 = p.lm_obs[s];
+  const int nrows = 2 * k, ncols = 9 * k;
+  const S* __restrict__ Ablk = p.A + p.lm_blk[s];
+
+  S xr[CH], yr[CH];
+  int yidx[CH];
+  bool act[CH];
+  const int lane9 = lane / 9, comp = lane - 9 * lane9;
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const int islot = 7 * ch + lane9;
+    act[ch] = lane < 63 && islot < k;
+    const int cam = act[ch] ? p.obs_cam[o0 + islot] : 0;
+    yidx[ch] = 9 * cam + comp;
+    xr[ch] = act[ch] ? x[yidx[ch]] : S(0);
+    yr[ch] = S(0);
+  }
+  int r = 0;
+  for (; r + U <= nrows; r += U) {
+    S a[U][CH];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch)
+        a[u][ch] = act[ch] ? Ablk[size_t(r + u) * ncols + ch * 63 + lane] : S(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      S d = S(0);
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) d += a[u][ch] * xr[ch];
+      const S t = wave_sum(d);
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) yr[ch] += a[u][ch] * t;
+    }
+  }
+  for (; r < nrows; ++r) {
+    S a[CH];
+    S d = S(0);
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      a[ch] = act[ch] ? Ablk[size_t(r) * ncols + ch * 63 + lane] : S(0);
+      d += a[ch] * xr[ch];
+    }
+    const S t = wave_sum(d);
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) yr[ch] += a[ch] * t;
+  }
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch)
+    if (act[ch]) atomic_add(y + yidx[ch], yr[ch]);
+}
+
+// ===========================================================================
+// Back-substitution (back_substitute ipp:212-284; loop linearization_qr.hpp:165-179)
+//   delta = -Rd^{-1} (Q1^T r + Q1^T Jp x)        on the DAMPED top rows
+//   l_diff -= g^T (g/2 + Q^T r), g = (Q^T J)[x; delta] on the UNDAMPED 2k rows
+//   p_w += delta o Jl_col_scale
+// ===========================================================================
+template <class S, int CH>
+__global__ __launch_bounds__(256) void k_back_substitute(Params<S> p, int lm_begin, int lm_end,
+                                                         const S* __restrict__ x) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;
+  const int k = p.lm_k[s];
+  const int64_t o0 = p.lm_obs[s];
+  const int nrows = 2 * k, ncols = 9 * k;
+  const S* __restrict__ Ablk = p.A + p.lm_blk[s];
+  const S* __restrict__ T0 = p.top0 + 27 * o0;
+  const S* __restrict__ Td = p.topd + 27 * o0;
+
+  S xr[CH];
+  bool act[CH];
+  const int lane9 = lane / 9, comp = lane - 9 * lane9;
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const int islot = 7 * ch + lane9;
+    act[ch] = lane < 63 && islot < k;
+    const int cam = act[ch] ? p.obs_cam[o0 + islot] : 0;
+    xr[ch] = act[ch] ? x[9 * cam + comp] : S(0);
+  }
+  S u[3], g0[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    S d = S(0), e = S(0);
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      if (act[ch]) {
+        const int idx = 27 * (7 * ch + lane9) + 9 * m + comp;
+        d += Td[idx] * xr[ch];
+        e += T0[idx] * xr[ch];
+      }
+    }
+    u[m] = wave_sum(d);
+    g0[m] = wave_sum(e);
+  }
+  const S* Rd = p.Rd + 6 * s;
+  const S* R0 = p.R0 + 6 * s;
+  S rhs[3], inc[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) rhs[m] = p.q1trd[3 * s + m] + u[m];
+  inc[2] = rhs[2] / Rd[5];
+  inc[1] = (rhs[1] - Rd[4] * inc[2]) / Rd[3];
+  inc[0] = (rhs[0] - Rd[1] * inc[1] - Rd[2] * inc[2]) / Rd[0];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) inc[m] = -inc[m];
+  // undamped top rows: g = Q1^T Jp x + R0 delta
+  g0[0] += R0[0] * inc[0] + R0[1] * inc[1] + R0[2] * inc[2];
+  g0[1] += R0[3] * inc[1] + R0[4] * inc[2];
+  g0[2] += R0[5] * inc[2];
+  const S* __restrict__ qtr = p.qtr + 2 * o0;
+  S acc = S(0);
+#pragma unroll
+  for (int m = 0; m < 3; ++m) acc += g0[m] * (S(0.5) * g0[m] + qtr[m]);
+  for (int r = 0; r < nrows - 3; ++r) {
+    S d = S(0);
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+      if (act[ch]) d += Ablk[size_t(r) * ncols + ch * 63 + lane] * xr[ch];
+    const S g = wave_sum(d);
+    acc += g * (S(0.5) * g + qtr[3 + r]);
+  }
+  if (lane == 0) {
+    p.lm_ldiff[s] = -double(acc);
+    const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) &&
+                     is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) &&
+                     is_finite(p.lms[3 * s + 2]);
+    if (!fin) atomicOr(p.fail_flag, 2);
+    p.lms[3 * s + 0] += inc[0] * p.jl_scale[3 * s + 0];
+    p.lms[3 * s + 1] += inc[1] * p.jl_scale[3 * s + 1];
+    p.lms[3 * s + 2] += inc[2] * p.jl_scale[3 * s + 2];
+  }
+}
+
+// deterministic sum of the per-landmark model cost changes
+__global__ __launch_bounds__(256) void k_sum_ldiff(const double* __restrict__ v, int n,
+                                                   double* __restrict__ partials) {
+  double acc = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) acc += v[i];
+  __shared__ double sm[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double t = wave_sum(acc);
+  if (lane == 0) sm[wave] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// ===========================================================================
+// Camera update: inc *= pose_scaling; T <- (exp(w) R, exp(w) t + v);
+// intrinsics += inc[6..8]   (linearizor_qr.cpp:280-287, bal_problem.hpp:97-109)
+// ===========================================================================
+template <class S>
+__global__ void k_update_cameras(Params<S> p, const S* __restrict__ inc_scaled) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.n_cams) return;
+  S inc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) inc[i] = inc_scaled[9 * c + i] * p.pose_scaling[9 * c + i];
+  S* cam = p.cams + 10 * c;
+  // SO3::exp as a unit quaternion
+  const S th2 = inc[3] * inc[3] + inc[4] * inc[4] + inc[5] * inc[5];
+  S im, re;
+  if (th2 < Eps<S>::eps * Eps<S>::eps) {
+    const S th4 = th2 * th2;
+    im = S(0.5) - S(1.0 / 48.0) * th2 + S(1.0 / 3840.0) * th4;
+    re = S(1) - S(1.0 / 8.0) * th2 + S(1.0 / 384.0) * th4;
+  } else {
+    const S th = sqrt(th2);
+    im = sin(S(0.5) * th) / th;
+    re = cos(S(0.5) * th);
+  }
+  const S ax = im * inc[3], ay = im * inc[4], az = im * inc[5], aw = re;
+  S dR[9];
+  quat_to_rot(ax, ay, az, aw, dR);
+  const S bx = cam[0], by = cam[1], bz = cam[2], bw = cam[3];
+  S qx = aw * bx + ax * bw + ay * bz - az * by;
+  S qy = aw * by - ax * bz + ay * bw + az * bx;
+  S qz = aw * bz + ax * by - ay * bx + az * bw;
+  S qw = aw * bw - ax * bx - ay * by - az * bz;
+  const S nrm = S(1) / sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+  const S tx = cam[4], ty = cam[5], tz = cam[6];
+  cam[0] = qx * nrm;
+  cam[1] = qy * nrm;
+  cam[2] = qz * nrm;
+  cam[3] = qw * nrm;
+  cam[4] = dR[0] * tx + dR[1] * ty + dR[2] * tz + inc[0];
+  cam[5] = dR[3] * tx + dR[4] * ty + dR[5] * tz + inc[1];
+  cam[6] = dR[6] * tx + dR[7] * ty + dR[8] * tz + inc[2];
+  cam[7] += inc[6];
+  cam[8] += inc[7];
+  cam[9] += inc[8];
+}
+
+// ===========================================================================
+// Block-diagonal preconditioner (BlockDiagonalPreconditioner,
+// src/rootba/cg/preconditioner.hpp:79-136): one thread per camera inverts its
+// SPD 9x9 block by Cholesky (upper triangle is the definition, App. A.5).
+// ===========================================================================
+template <class S>
+__global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ inv, int n_cams,
+                                int* fail_flag) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cams) return;
+  S L[45];  // lower triangle, row-major packed: L(i,j) at i(i+1)/2 + j
+  const S* a = blocks + 81 * c;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    S d = a[9 * j + j];
+#pragma unroll
+    for (int q = 0; q < j; ++q) d -= L[j * (j + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
+    ok = ok && (d > S(0));
+    const S ljj = sqrt(d);
+    L[j * (j + 1) / 2 + j] = ljj;
+    const S ij = S(1) / ljj;
+#pragma unroll
+    for (int i = j + 1; i < 9; ++i) {
+      S v = a[9 * j + i];  // upper triangle entry (j,i)
+#pragma unroll
+      for (int q = 0; q < j; ++q) v -= L[i * (i + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
+      L[i * (i + 1) / 2 + j] = v * ij;
+    }
+  }
+  if (!ok) atomicOr(fail_flag, 4);
+  S* out = inv + 81 * c;
+#pragma unroll
+  for (int col = 0; col < 9; ++col) {
+    S yv[9], xv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      S v = (i == col) ? S(1) : S(0);
+#pragma unroll
+      for (int q = 0; q < i; ++q) v -= L[i * (i + 1) / 2 + q] * yv[q];
+      yv[i] = v / L[i * (i + 1) / 2 + i];
+    }
+#pragma unroll
+    for (int i = 8; i >= 0; --i) {
+      S v = yv[i];
+#pragma unroll
+      for (int q = i + 1; q < 9; ++q) v -= L[q * (q + 1) / 2 + i] * xv[q];
+      xv[i] = v / L[i * (i + 1) / 2 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[9 * i + col] = xv[i];
+  }
+}
+
+// ===========================================================================
+// PCG vector kernels (ConjugateGradientsSolver::solve,
+// src/rootba/cg/conjugate_gradient.hpp:113-298). All scalars stay on the device
+// in `CgState` (double, as in the reference); the host only polls `done`.
+// ===========================================================================
+struct CgState {
+  double rho, last_rho, pq, q0, q1, norm_b2, dot_tmp;
+  double alpha, beta;
+  int iter;         // iterations completed
+  int done;         // 0 running, 1 finished
+  int termination;  // 0 NO_CONVERGENCE, 1 SUCCESS, 2 FAILURE
+  int refresh;      // next update recomputes r from scratch
+};
+
+template <class S>
+__device__ __forceinline__ void block_accumulate(double v, double* target) {
+  __shared__ double sm[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double t = wave_sum(v);
+  if (lane == 0) sm[wave] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(target, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+// generic dot product -> *out (must be zeroed before)
+template <class S>
+__global__ __launch_bounds__(256) void k_dot(const S* __restrict__ a, const S* __restrict__ b,
+                                             int n, double* out) {
+  double acc = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    acc += double(a[i]) * double(b[i]);
+  block_accumulate<S>(acc, out);
+}
+
+// z = M^-1 r (9x9 block per camera, one thread per vector element); rho = r.z
+template <class S>
+__global__ __launch_bounds__(256) void k_precond_rho(const S* __restrict__ inv,
+                                                     const S* __restrict__ r, S* __restrict__ z,
+                                                     int n, CgState* st) {
+  if (st->done) return;
+  double acc = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int c = i / 9, row = i - 9 * c;
+    const S* M = inv + 81 * c + 9 * row;
+    const S* rc = r + 9 * c;
+    S v = S(0);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v += M[j] * rc[j];
+    z[i] = v;
+    acc += double(r[i]) * double(v);
+  }
+  block_accumulate<S>(acc, &st->rho);
+}
+
+// scalar step A (1 thread): rho checks, beta
+__global__ void k_cg_scalar_a(CgState* st) {
+  if (st->done) return;
+  const double rho = st->rho;
+  if (rho == 0.0 || isinf(rho)) {
+    st->termination = 2;
+    st->done = 1;
+    st->iter += 1;
+    return;
+  }
+  if (st->iter == 0) {
+    st->beta = 0.0;
+  } else {
+    const double beta = rho / st->last_rho;
+    if (beta == 0.0 || isinf(beta)) {
+      st->termination = 2;
+      st->done = 1;
+      st->iter += 1;
+      return;
+    }
+    st->beta = beta;
+  }
+  st->pq = 0.0;
+}
+
+// p = z + beta p ; q = 0 (accumulation target of H*x)
+template <class S>
+__global__ void k_update_p(const S* __restrict__ z, S* __restrict__ pvec, S* __restrict__ q, int n,
+                           const CgState* st) {
+  if (st->done) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const S beta = S(st->beta);
+  pvec[i] = (st->iter == 0) ? z[i] : z[i] + beta * pvec[i];
+  q[i] = S(0);
+}
+
+// q += lambda p (pose damping term of right_multiply, linearization_qr.hpp:424-426); pq = p.q
+template <class S>
+__global__ __launch_bounds__(256) void k_damp_pq(const S* __restrict__ pvec, S* __restrict__ q,
+                                                 S lambda, int n, CgState* st) {
+  if (st->done) return;
+  double acc = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const S v = q[i] + lambda * pvec[i];
+    q[i] = v;
+    acc += double(pvec[i]) * double(v);
+  }
+  block_accumulate<S>(acc, &st->pq);
+}
+
+// scalar step B (1 thread): pq checks, alpha
+__global__ void k_cg_scalar_b(CgState* st, int residual_reset_period) {
+  if (st->done) return;
+  const double pq = st->pq;
+  if (pq <= 0.0 || isinf(pq)) {
+    st->termination = 0;
+    st->done = 1;
+    st->iter += 1;
+    return;
+  }
+  const double alpha = st->rho / pq;
+  if (isinf(alpha)) {
+    st->termination = 2;
+    st->done = 1;
+    st->iter += 1;
+    return;
+  }
+  st->alpha = alpha;
+  st->q1 = 0.0;
+  st->refresh = ((st->iter + 1) % residual_reset_period) == 0 ? 1 : 0;
+}
+
+// x += alpha p ; r -= alpha q (unless refresh) ; tmp = 0 when refreshing
+template <class S>
+__global__ void k_update_x_r(S* __restrict__ x, S* __restrict__ r, const S* __restrict__ pvec,
+                             const S* __restrict__ q, S* __restrict__ tmp, int n,
+                             const CgState* st) {
+  if (st->done) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const S a = S(st->alpha);
+  x[i] = x[i] + a * pvec[i];
+  if (st->refresh)
+    tmp[i] = S(0);
+  else
+    r[i] = r[i] - a * q[i];
+}
+
+// refresh: r = b - (tmp + lambda x)
+template <class S>
+__global__ void k_refresh_r(const S* __restrict__ bvec, const S* __restrict__ tmp,
+                            const S* __restrict__ x, S* __restrict__ r, S lambda, int n,
+                            const CgState* st) {
+  if (st->done || !st->refresh) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  r[i] = bvec[i] - (tmp[i] + lambda * x[i]);
+}
+
+// q1 = -x.(b + r)
+template <class S>
+__global__ __launch_bounds__(256) void k_q1(const S* __restrict__ x, const S* __restrict__ bvec,
+                                            const S* __restrict__ r, int n, CgState* st) {
+  if (st->done) return;
+  double acc = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    acc -= double(x[i]) * double(bvec[i] + r[i]);
+  block_accumulate<S>(acc, &st->q1);
+}
+
+// scalar step C (1 thread): quadratic-model termination, iteration bookkeeping
+__global__ void k_cg_scalar_c(CgState* st, double q_tolerance, int min_it, int max_it) {
+  if (st->done) return;
+  st->iter += 1;
+  const double q1 = st->q1, q0 = st->q0;
+  const double zeta = st->iter * (q1 - q0) / q1;
+  if (zeta < q_tolerance && st->iter >= min_it) {
+    st->termination = 1;
+    st->done = 1;
+    return;
+  }
+  st->q0 = q1;
+  // residual-based termination is disabled (r_tolerance = -1, linearizor_base.cpp:91)
+  if (st->iter >= max_it) {
+    st->termination = 0;
+    st->done = 1;
+    return;
+  }
+  st->last_rho = st->rho;
+  st->rho = 0.0;
+}
+
+// blocks[c](d,d) -= excess  (multi-GPU: lambda*I was added once per rank)
+template <class S>
+__global__ void k_sub_diag(S* __restrict__ blocks, S excess, int n_cams) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 9 * n_cams) blocks[81 * (i / 9) + 10 * (i % 9)] -= excess;
+}
+
+template <class S>
+__global__ void k_negate(S* __restrict__ v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = -v[i];
+}
+
+template <class S>
+__global__ void k_axpy_lambda(const S* __restrict__ x, S* __restrict__ y, S lambda, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += lambda * x[i];
+}
+
+}  // namespace rba

@@ -1,0 +1,1164 @@
+// solver.hip — host side of librootba_hip.so: device-resident solver state, the
+// C ABI of include/rootba_hip.h, and the LM driver.
+//
+// Mirrors, call for call, what LinearizorQR does with LinearizationQR in the
+// reference (src/rootba/solver/linearizor_qr.cpp:53-291) and what
+// optimize_lm_ours does with the Linearizor
+// (src/rootba/solver/bal_bundle_adjustment.cpp:249-544); everything indented
+// under those calls runs on the GPU (kernels.hpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/rootba_hip.h"
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct HipError {
+  std::string msg;
+  int code;
+};
+
+#define HIP_CHECK(expr)                                                              \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      throw HipError{std::string(#expr) + ": " + hipGetErrorString(_e) + " (" +     \
+                         __FILE__ + ":" + std::to_string(__LINE__) + ")",            \
+                     RBA_ERR_HIP};                                                   \
+    }                                                                                \
+  } while (0)
+
+template <class T>
+class DevBuf {
+ public:
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void alloc(size_t n) {
+    release();
+    n_ = n;
+    if (n) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p_), n * sizeof(T)));
+  }
+  void release() {
+    if (p_) (void)hipFree(p_);
+    p_ = nullptr;
+    n_ = 0;
+  }
+  T* get() const { return p_; }
+  size_t size() const { return n_; }
+  void upload(const T* src, size_t n, hipStream_t st) {
+    HIP_CHECK(hipMemcpyAsync(p_, src, n * sizeof(T), hipMemcpyHostToDevice, st));
+  }
+  void download(T* dst, size_t n, hipStream_t st) const {
+    HIP_CHECK(hipMemcpyAsync(dst, p_, n * sizeof(T), hipMemcpyDeviceToHost, st));
+  }
+  void zero(hipStream_t st) {
+    if (n_) HIP_CHECK(hipMemsetAsync(p_, 0, n_ * sizeof(T), st));
+  }
+
+ private:
+  T* p_ = nullptr;
+  size_t n_ = 0;
+};
+
+double wall_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch())
+      .count();
+}
+
+// ---------------------------------------------------------------------------
+// RCCL, loaded lazily (single-GPU runs never touch it)
+// ---------------------------------------------------------------------------
+struct Rccl {
+  using UniqueId = struct { char internal[128]; };
+  void* lib = nullptr;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load() {
+    if (lib) return true;
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return false;
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    return GetUniqueId && CommInitRank && CommDestroy && AllReduce;
+  }
+};
+Rccl g_rccl;
+// ncclDataType_t / ncclRedOp_t values (rccl.h): ncclInt32 = 2, ncclFloat32 = 7,
+// ncclFloat64 = 8; ncclSum = 0, ncclMax = 2
+constexpr int kNcclInt32 = 2, kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0, kNcclMax = 2;
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Solver
+// ---------------------------------------------------------------------------
+struct rba_solver {
+  virtual ~rba_solver() = default;
+  virtual void comm_init(int rank, int nranks, const void* uid) = 0;
+  virtual void set_state(const void* cams, const void* lms) = 0;
+  virtual void get_state(void* cams, void* lms) = 0;
+  virtual void backup() = 0;
+  virtual void restore() = 0;
+  virtual void compute_error(rba_residual_info* out) = 0;
+  virtual int linearize(void* jp_diag2_out) = 0;
+  virtual int solve(double lambda, void* inc_out, rba_cg_summary* cg) = 0;
+  virtual int stage2(double lambda, void* b_out, void* blocks_out) = 0;
+  virtual void right_multiply(const void* x, void* y) = 0;
+  virtual int apply(const void* inc, double* l_diff, bool update_cams) = 0;
+  virtual int optimize_lm(rba_lm_iteration* log, int max_rows, int* n_rows, int* term) = 0;
+  virtual void lm_begin() = 0;
+  virtual int lm_step(rba_lm_iteration* out) = 0;
+  virtual int lm_termination() const = 0;
+  virtual void device_sync() = 0;
+  virtual void get_timings(rba_iter_timings* out) = 0;
+  virtual void get_jl_col_scale(void* out) = 0;
+  virtual void get_pose_scaling(void* out) = 0;
+  virtual void get_landmark_R(int damped, void* R6, void* q3) = 0;
+  virtual void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) = 0;
+};
+
+namespace {
+
+constexpr int kNumClasses = 5;
+constexpr int kClassCH[kNumClasses] = {1, 2, 4, 8, 16};
+
+template <class S>
+class Solver final : public rba_solver {
+ public:
+  Solver(int device, int n_cams, int n_lms, const int64_t* lm_off, const int32_t* obs_cam,
+         const S* obs_xy, const rba_options& opt)
+      : device_(device), n_cams_(n_cams), n_lms_(n_lms), opt_(opt) {
+    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    n_obs_ = lm_off[n_lms];
+    nvec_ = 9 * n_cams_;
+
+    // ---- sort landmarks by number of observations (stable) ----------------
+    perm_.resize(n_lms);
+    std::iota(perm_.begin(), perm_.end(), 0);
+    std::stable_sort(perm_.begin(), perm_.end(), [&](int a, int b) {
+      return (lm_off[a + 1] - lm_off[a]) < (lm_off[b + 1] - lm_off[b]);
+    });
+    std::vector<int> lm_k(n_lms);
+    std::vector<int64_t> lm_obs(n_lms + 1), lm_blk(n_lms + 1);
+    std::vector<int> s_obs_cam(n_obs_), s_obs_lm(n_obs_);
+    std::vector<S> s_obs_xy(2 * size_t(n_obs_));
+    int64_t o = 0, blk = 0;
+    int kmax = 0;
+    hx_bytes_ = 0;
+    hx_flops_ = 0;
+    storage_bytes_ = 0;
+    for (int s = 0; s < n_lms; ++s) {
+      const int l = perm_[s];
+      const int k = int(lm_off[l + 1] - lm_off[l]);
+      if (k < 2)
+        throw HipError{"every landmark needs >= 2 observations (landmark " + std::to_string(l) + ")",
+                       RBA_ERR_INVALID_ARGUMENT};
+      lm_k[s] = k;
+      lm_obs[s] = o;
+      lm_blk[s] = blk;
+      kmax = std::max(kmax, k);
+      for (int i = 0; i < k; ++i) {
+        const int64_t src = lm_off[l] + i;
+        if (obs_cam[src] < 0 || obs_cam[src] >= n_cams)
+          throw HipError{"camera index out of range", RBA_ERR_INVALID_ARGUMENT};
+        if (i > 0 && obs_cam[src] <= obs_cam[src - 1])
+          throw HipError{"camera indices must be strictly ascending inside a landmark",
+                         RBA_ERR_INVALID_ARGUMENT};
+        s_obs_cam[o] = obs_cam[src];
+        s_obs_lm[o] = s;
+        s_obs_xy[2 * o] = obs_xy[2 * src];
+        s_obs_xy[2 * o + 1] = obs_xy[2 * src + 1];
+        ++o;
+      }
+      const int64_t elems = int64_t(2 * k) * (9 * k);
+      blk += (elems + 3) / 4 * 4;
+      // algorithmic counts in the reference's padded layout
+      const int64_t pad = (4 - (9 * k) % 4) % 4;
+      hx_bytes_ += int64_t(sizeof(S)) * 2 * k * (9 * k + pad);
+      hx_flops_ += int64_t(72) * k * k;
+      storage_bytes_ += int64_t(sizeof(S)) * (2 * k + 3) * (9 * k + pad + 4);
+    }
+    lm_obs[n_lms] = o;
+    lm_blk[n_lms] = blk;
+    // CSC index camera -> observations (sorted-observation numbering), used by
+    // the camera-major reductions
+    std::vector<int64_t> cam_off(n_cams + 1, 0);
+    for (int64_t q = 0; q < n_obs_; ++q) ++cam_off[s_obs_cam[q] + 1];
+    for (int c = 0; c < n_cams; ++c) cam_off[c + 1] += cam_off[c];
+    std::vector<int> cam_obs(n_obs_);
+    {
+      std::vector<int64_t> cur(cam_off.begin(), cam_off.end() - 1);
+      for (int64_t q = 0; q < n_obs_; ++q) cam_obs[cur[s_obs_cam[q]]++] = int(q);
+    }
+    hx_bytes_ += 4 * n_obs_ + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
+    if (kmax > 7 * kClassCH[kNumClasses - 1])
+      throw HipError{"landmark with " + std::to_string(kmax) + " observations: more than " +
+                         std::to_string(7 * kClassCH[kNumClasses - 1]) + " is not supported yet",
+                     RBA_ERR_UNSUPPORTED};
+    // class ranges (k <= 7*CH)
+    int begin = 0;
+    for (int c = 0; c < kNumClasses; ++c) {
+      int end = begin;
+      while (end < n_lms && lm_k[end] <= 7 * kClassCH[c]) ++end;
+      cls_begin_[c] = begin;
+      cls_end_[c] = end;
+      begin = end;
+    }
+
+    // ---- device memory ------------------------------------------------------
+    d_lm_k_.alloc(n_lms);
+    d_lm_obs_.alloc(n_lms + 1);
+    d_lm_blk_.alloc(n_lms + 1);
+    d_obs_cam_.alloc(n_obs_);
+    d_obs_lm_.alloc(n_obs_);
+    d_obs_xy_.alloc(2 * size_t(n_obs_));
+    d_lm_k_.upload(lm_k.data(), n_lms, stream_);
+    d_lm_obs_.upload(lm_obs.data(), n_lms + 1, stream_);
+    d_lm_blk_.upload(lm_blk.data(), n_lms + 1, stream_);
+    d_obs_cam_.upload(s_obs_cam.data(), n_obs_, stream_);
+    d_obs_lm_.upload(s_obs_lm.data(), n_obs_, stream_);
+    d_obs_xy_.upload(s_obs_xy.data(), 2 * size_t(n_obs_), stream_);
+    d_cam_off_.alloc(n_cams + 1);
+    d_cam_obs_.alloc(n_obs_);
+    d_cam_off_.upload(cam_off.data(), n_cams + 1, stream_);
+    d_cam_obs_.upload(cam_obs.data(), n_obs_, stream_);
+    d_cams_.alloc(10 * size_t(n_cams));
+    d_lms_.alloc(3 * size_t(n_lms));
+    d_cams_bak_.alloc(10 * size_t(n_cams));
+    d_lms_bak_.alloc(3 * size_t(n_lms));
+    d_A_.alloc(size_t(blk));
+    d_top0_.alloc(27 * size_t(n_obs_));
+    d_topd_.alloc(27 * size_t(n_obs_));
+    d_qtr_.alloc(2 * size_t(n_obs_));
+    d_dampO_.alloc(27 * size_t(n_obs_));
+    d_JpS_.alloc(18 * size_t(n_obs_));
+    d_bmO_.alloc(9 * size_t(n_obs_));
+    d_R0_.alloc(6 * size_t(n_lms));
+    d_Rd_.alloc(6 * size_t(n_lms));
+    d_q1trd_.alloc(3 * size_t(n_lms));
+    d_damp_r_.alloc(3 * size_t(n_lms));
+    d_jl_scale_.alloc(3 * size_t(n_lms));
+    d_jp_diag2_.alloc(nvec_);
+    d_pose_scaling_.alloc(nvec_);
+    d_mid_.alloc(size_t(90) * n_cams);  // [b_mid | B_mid]
+    d_bb_.alloc(size_t(90) * n_cams);   // [b | blocks]
+    d_inv_.alloc(size_t(81) * n_cams);
+    d_fail_.alloc(1);
+    d_lm_ldiff_.alloc(n_lms);
+    d_partials_.alloc(size_t(kReduceBlocks) * 8 + 16);
+    d_cg_.alloc(1);
+    for (auto* v : {&d_x_, &d_r_, &d_p_, &d_z_, &d_q_, &d_tmp_, &d_inc_, &d_vin_}) v->alloc(nvec_);
+    d_A_.zero(stream_);
+    d_top0_.zero(stream_);
+    d_topd_.zero(stream_);
+    d_dampO_.zero(stream_);
+    d_pose_scaling_.zero(stream_);
+    d_fail_.zero(stream_);
+    d_partials_.zero(stream_);
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 4096));
+    HIP_CHECK(hipEventCreate(&ev_a_));
+    HIP_CHECK(hipEventCreate(&ev_b_));
+    hx_events_.resize(2 * kMaxHxEvents);
+    for (auto& e : hx_events_) HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+
+    prm_.n_cams = n_cams;
+    prm_.n_lms = n_lms;
+    prm_.lm_k = d_lm_k_.get();
+    prm_.lm_obs = d_lm_obs_.get();
+    prm_.lm_blk = d_lm_blk_.get();
+    prm_.obs_cam = d_obs_cam_.get();
+    prm_.obs_lm = d_obs_lm_.get();
+    prm_.obs_xy = d_obs_xy_.get();
+    prm_.cam_obs_off = d_cam_off_.get();
+    prm_.cam_obs = d_cam_obs_.get();
+    prm_.dampO = d_dampO_.get();
+    prm_.JpS = d_JpS_.get();
+    prm_.bmO = d_bmO_.get();
+    prm_.cams = d_cams_.get();
+    prm_.lms = d_lms_.get();
+    prm_.A = d_A_.get();
+    prm_.top0 = d_top0_.get();
+    prm_.topd = d_topd_.get();
+    prm_.qtr = d_qtr_.get();
+    prm_.R0 = d_R0_.get();
+    prm_.Rd = d_Rd_.get();
+    prm_.q1trd = d_q1trd_.get();
+    prm_.damp_r = d_damp_r_.get();
+    prm_.jl_scale = d_jl_scale_.get();
+    prm_.jp_diag2 = d_jp_diag2_.get();
+    prm_.pose_scaling = d_pose_scaling_.get();
+    prm_.b_mid = d_mid_.get();
+    prm_.B_mid = d_mid_.get() + nvec_;
+    prm_.b = d_bb_.get();
+    prm_.blocks = d_bb_.get() + nvec_;
+    prm_.fail_flag = d_fail_.get();
+    prm_.lm_ldiff = d_lm_ldiff_.get();
+    prm_.robust_norm = opt_.robust_norm;
+    prm_.valid_only = opt_.use_valid_projections_only;
+    prm_.jacobi = opt_.preconditioner_type == 0;
+    prm_.huber = S(opt_.huber_parameter);
+    prm_.eps = opt_.jacobi_scaling_eps > 0 ? S(opt_.jacobi_scaling_eps) : rba::Eps<S>::eps_sqrt;
+  }
+
+  ~Solver() override {
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    if (comm_ && g_rccl.CommDestroy) g_rccl.CommDestroy(comm_);
+    for (auto& e : hx_events_) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(ev_a_);
+    (void)hipEventDestroy(ev_b_);
+    if (h_pinned_) (void)hipHostFree(h_pinned_);
+    (void)hipStreamDestroy(stream_);
+  }
+
+  // ---- multi-GPU ------------------------------------------------------------
+  void comm_init(int rank, int nranks, const void* uid) override {
+    if (nranks <= 1) return;
+    if (!g_rccl.load()) throw HipError{"cannot load librccl.so", RBA_ERR_COMM};
+    Rccl::UniqueId id;
+    std::memcpy(&id, uid, sizeof(id));
+    HIP_CHECK(hipSetDevice(device_));
+    const int rc = g_rccl.CommInitRank(&comm_, nranks, id, rank);
+    if (rc != 0) throw HipError{"ncclCommInitRank failed: " + std::to_string(rc), RBA_ERR_COMM};
+    rank_ = rank;
+    nranks_ = nranks;
+  }
+
+  template <class T>
+  void all_reduce(T* buf, size_t count, int op = kNcclSum) {
+    if (nranks_ <= 1) return;
+    const int dt = std::is_same<T, float>::value    ? kNcclFloat32
+                   : std::is_same<T, double>::value ? kNcclFloat64
+                                                    : kNcclInt32;
+    const int rc = g_rccl.AllReduce(buf, buf, count, dt, op, comm_, stream_);
+    if (rc != 0) throw HipError{"ncclAllReduce failed: " + std::to_string(rc), RBA_ERR_COMM};
+  }
+
+  // ---- state ------------------------------------------------------------------
+  void set_state(const void* cams, const void* lms) override {
+    use_device();
+    const S* l = static_cast<const S*>(lms);
+    std::vector<S> sorted(3 * size_t(n_lms_));
+    for (int s = 0; s < n_lms_; ++s)
+      for (int c = 0; c < 3; ++c) sorted[3 * size_t(s) + c] = l[3 * size_t(perm_[s]) + c];
+    d_cams_.upload(static_cast<const S*>(cams), 10 * size_t(n_cams_), stream_);
+    d_lms_.upload(sorted.data(), sorted.size(), stream_);
+    sync();
+  }
+  void get_state(void* cams, void* lms) override {
+    use_device();
+    std::vector<S> sorted(3 * size_t(n_lms_));
+    d_cams_.download(static_cast<S*>(cams), 10 * size_t(n_cams_), stream_);
+    d_lms_.download(sorted.data(), sorted.size(), stream_);
+    sync();
+    S* l = static_cast<S*>(lms);
+    for (int s = 0; s < n_lms_; ++s)
+      for (int c = 0; c < 3; ++c) l[3 * size_t(perm_[s]) + c] = sorted[3 * size_t(s) + c];
+  }
+  void backup() override {
+    use_device();
+    HIP_CHECK(hipMemcpyAsync(d_cams_bak_.get(), d_cams_.get(), d_cams_.size() * sizeof(S),
+                             hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_lms_bak_.get(), d_lms_.get(), d_lms_.size() * sizeof(S),
+                             hipMemcpyDeviceToDevice, stream_));
+  }
+  void restore() override {
+    use_device();
+    HIP_CHECK(hipMemcpyAsync(d_cams_.get(), d_cams_bak_.get(), d_cams_.size() * sizeof(S),
+                             hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_lms_.get(), d_lms_bak_.get(), d_lms_.size() * sizeof(S),
+                             hipMemcpyDeviceToDevice, stream_));
+  }
+
+  // ---- compute_error ----------------------------------------------------------
+  void compute_error(rba_residual_info* out) override {
+    use_device();
+    time_begin();
+    const int blocks = int(std::min<int64_t>(kReduceBlocks, (n_obs_ + 255) / 256));
+    hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, stream_, prm_,
+                       n_obs_, d_partials_.get());
+    double* red = d_partials_.get() + size_t(kReduceBlocks) * 8;
+    hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, stream_,
+                       d_partials_.get(), int64_t(blocks), red);
+    all_reduce(red, 8);
+    double h[8];
+    HIP_CHECK(hipMemcpyAsync(h, red, sizeof(h), hipMemcpyDeviceToHost, stream_));
+    timings_.residual_evaluation_time += time_end();
+    out->all_num_obs = int(std::llround(h[0]));
+    out->all_error = h[1];
+    out->all_residual_sum = h[2];
+    out->valid_num_obs = int(std::llround(h[3]));
+    out->valid_error = h[4];
+    out->valid_residual_sum = h[5];
+    out->is_numerically_valid = h[6] == 0.0 ? 1 : 0;
+  }
+
+  // ---- stage 1 ------------------------------------------------------------------
+  int linearize(void* jp_diag2_out) override {
+    use_device();
+    time_begin();
+    d_fail_.zero(stream_);
+    hipLaunchKernelGGL((rba::k_cam_jp_diag2<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
+    all_reduce(d_jp_diag2_.get(), nvec_);
+    all_reduce(d_fail_.get(), 1, kNcclMax);
+    hipLaunchKernelGGL((rba::k_pose_scaling<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
+                       d_jp_diag2_.get(), d_pose_scaling_.get(), prm_.eps, nvec_);
+    for_each_class([&](auto ch_tag, int begin, int end) {
+      constexpr int CH = decltype(ch_tag)::value;
+      const size_t lds = 4 * size_t(rba::ClassCfg<CH>::WAVE_LDS) * sizeof(S);
+      hipLaunchKernelGGL((rba::k_linearize_qr<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
+                         lds, stream_, prm_, begin, end);
+    });
+    hipLaunchKernelGGL((rba::k_cam_stage1<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
+    HIP_CHECK(hipGetLastError());
+    int fail = 0;
+    HIP_CHECK(hipMemcpyAsync(&fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (jp_diag2_out) d_jp_diag2_.download(static_cast<S*>(jp_diag2_out), nvec_, stream_);
+    timings_.stage1_time = time_end();
+    pose_damping_ = S(0);
+    landmark_damping_valid_ = false;
+    return (fail & 1) ? RBA_NUMERICAL_FAILURE : RBA_OK;
+  }
+
+  // ---- stage 2 ------------------------------------------------------------------
+  void run_stage2(S lambda) {
+    for_each_class([&](auto ch_tag, int begin, int end) {
+      constexpr int CH = decltype(ch_tag)::value;
+      hipLaunchKernelGGL((rba::k_stage2<S, CH>), dim3((end - begin + 3) / 4), dim3(256), 0,
+                         stream_, prm_, begin, end, lambda);
+    });
+    hipLaunchKernelGGL((rba::k_cam_stage2<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_, lambda);
+    if (nranks_ > 1) {
+      // every rank added lambda*I and holds only its landmarks' sums: make the
+      // diagonal term count once
+      all_reduce(d_bb_.get(), size_t(90) * n_cams_);
+      hipLaunchKernelGGL((rba::k_sub_diag<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
+                         prm_.blocks, S(lambda) * S(nranks_ - 1), n_cams_);
+    }
+    pose_damping_ = lambda;
+    landmark_damping_valid_ = true;
+  }
+
+  int stage2(double lambda, void* b_out, void* blocks_out) override {
+    use_device();
+    time_begin();
+    run_stage2(S(lambda));
+    if (b_out) d_bb_.download(static_cast<S*>(b_out), nvec_, stream_);
+    if (blocks_out)
+      HIP_CHECK(hipMemcpyAsync(blocks_out, prm_.blocks, size_t(81) * n_cams_ * sizeof(S),
+                               hipMemcpyDeviceToHost, stream_));
+    timings_.stage2_time = time_end();
+    return RBA_OK;
+  }
+
+  // y += sum_l A_l^T A_l x_l over the local landmarks (no pose damping term)
+  void launch_hx(const S* x, S* y) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hx_event_count_ < kMaxHxEvents) {
+      e0 = hx_events_[2 * hx_event_count_];
+      e1 = hx_events_[2 * hx_event_count_ + 1];
+      ++hx_event_count_;
+      HIP_CHECK(hipEventRecord(e0, stream_));
+    }
+    for_each_class([&](auto ch_tag, int begin, int end) {
+      constexpr int CH = decltype(ch_tag)::value;
+      constexpr int U = CH <= 2 ? 4 : 2;
+      hipLaunchKernelGGL((rba::k_hx<S, CH, U>), dim3((end - begin + 3) / 4), dim3(256), 0,
+                         stream_, prm_, begin, end, x, y);
+    });
+    if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
+    ++hx_calls_;
+  }
+
+  void right_multiply(const void* x, void* y) override {
+    use_device();
+    d_vin_.upload(static_cast<const S*>(x), nvec_, stream_);
+    d_tmp_.zero(stream_);
+    launch_hx(d_vin_.get(), d_tmp_.get());
+    all_reduce(d_tmp_.get(), nvec_);
+    hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
+                       d_vin_.get(), d_tmp_.get(), pose_damping_, nvec_);
+    d_tmp_.download(static_cast<S*>(y), nvec_, stream_);
+    sync();
+  }
+
+  // ---- solve = stage 2 + preconditioner + PCG ------------------------------------
+  int solve(double lambda_d, void* inc_out, rba_cg_summary* cg_out) override {
+    use_device();
+    const S lambda = S(lambda_d);
+    time_begin();
+    run_stage2(lambda);
+    timings_.stage2_time = time_end();
+
+    time_begin();
+    hipLaunchKernelGGL((rba::k_invert_blocks<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_,
+                       prm_.blocks, d_inv_.get(), n_cams_, d_fail_.get());
+    timings_.compute_preconditioner_time = time_end();
+
+    time_begin();
+    hx_event_count_ = 0;
+    hx_calls_ = 0;
+    rba_cg_summary cg = pcg(lambda);
+    hipLaunchKernelGGL((rba::k_negate<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
+                       d_x_.get(), nvec_);
+    d_x_.download(static_cast<S*>(inc_out), nvec_, stream_);
+    timings_.solve_reduced_system_time = time_end();
+    double hx_ms = 0;
+    for (int i = 0; i < hx_event_count_; ++i) {
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, hx_events_[2 * i], hx_events_[2 * i + 1]));
+      hx_ms += ms;
+    }
+    timings_.hx_time = hx_event_count_ ? hx_ms * 1e-3 * hx_calls_ / hx_event_count_ : 0.0;
+    timings_.hx_calls = hx_calls_;
+    if (cg_out) *cg_out = cg;
+    return RBA_OK;
+  }
+
+  rba_cg_summary pcg(S lambda) {
+    rba_cg_summary summary{0, 0};
+    const int n = nvec_;
+    const int vb = (n + 255) / 256;
+    const int rb = std::min(vb, 64);
+    rba::CgState* st = d_cg_.get();
+    const S* b = prm_.b;
+    // x = 0, r = b - H*0 = b
+    HIP_CHECK(hipMemsetAsync(st, 0, sizeof(rba::CgState), stream_));
+    d_x_.zero(stream_);
+    HIP_CHECK(hipMemcpyAsync(d_r_.get(), b, n * sizeof(S), hipMemcpyDeviceToDevice, stream_));
+    hipLaunchKernelGGL((rba::k_dot<S>), dim3(rb), dim3(256), 0, stream_, b, b, n, &st->norm_b2);
+    rba::CgState* hst = reinterpret_cast<rba::CgState*>(h_pinned_);
+    HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
+    sync();
+    if (hst->norm_b2 == 0.0) {
+      summary.termination_type = 1;
+      return summary;
+    }
+    const int max_it = opt_.max_cg_it;
+    for (int it = 1; it <= max_it; ++it) {
+      hipLaunchKernelGGL((rba::k_precond_rho<S>), dim3(rb), dim3(256), 0, stream_, d_inv_.get(),
+                         d_r_.get(), d_z_.get(), n, st);
+      hipLaunchKernelGGL((rba::k_cg_scalar_a), dim3(1), dim3(1), 0, stream_, st);
+      hipLaunchKernelGGL((rba::k_update_p<S>), dim3(vb), dim3(256), 0, stream_, d_z_.get(),
+                         d_p_.get(), d_q_.get(), n, st);
+      launch_hx(d_p_.get(), d_q_.get());
+      all_reduce(d_q_.get(), n);
+      hipLaunchKernelGGL((rba::k_damp_pq<S>), dim3(rb), dim3(256), 0, stream_, d_p_.get(),
+                         d_q_.get(), lambda, n, st);
+      hipLaunchKernelGGL((rba::k_cg_scalar_b), dim3(1), dim3(1), 0, stream_, st, 10);
+      hipLaunchKernelGGL((rba::k_update_x_r<S>), dim3(vb), dim3(256), 0, stream_, d_x_.get(),
+                         d_r_.get(), d_p_.get(), d_q_.get(), d_tmp_.get(), n, st);
+      if (it % 10 == 0) {
+        // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
+        launch_hx(d_x_.get(), d_tmp_.get());
+        all_reduce(d_tmp_.get(), n);
+        hipLaunchKernelGGL((rba::k_refresh_r<S>), dim3(vb), dim3(256), 0, stream_, b,
+                           d_tmp_.get(), d_x_.get(), d_r_.get(), lambda, n, st);
+      }
+      hipLaunchKernelGGL((rba::k_q1<S>), dim3(rb), dim3(256), 0, stream_, d_x_.get(), b,
+                         d_r_.get(), n, st);
+      hipLaunchKernelGGL((rba::k_cg_scalar_c), dim3(1), dim3(1), 0, stream_, st, opt_.eta,
+                         opt_.min_cg_it, max_it);
+      HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
+      sync();
+      if (hst->done) break;
+    }
+    summary.termination_type = hst->termination;
+    summary.num_iterations = hst->iter;
+    return summary;
+  }
+
+  // ---- apply ------------------------------------------------------------------------
+  int apply(const void* inc, double* l_diff_out, bool update_cams) override {
+    use_device();
+    if (!landmark_damping_valid_) run_stage2(S(0));
+    time_begin();
+    d_inc_.upload(static_cast<const S*>(inc), nvec_, stream_);
+    HIP_CHECK(hipMemsetAsync(d_fail_.get(), 0, sizeof(int), stream_));
+    for_each_class([&](auto ch_tag, int begin, int end) {
+      constexpr int CH = decltype(ch_tag)::value;
+      hipLaunchKernelGGL((rba::k_back_substitute<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
+                         0, stream_, prm_, begin, end, d_inc_.get());
+    });
+    const int blocks = std::min(kReduceBlocks, (n_lms_ + 255) / 256);
+    hipLaunchKernelGGL((rba::k_sum_ldiff), dim3(blocks), dim3(256), 0, stream_,
+                       d_lm_ldiff_.get(), n_lms_, d_partials_.get());
+    double* red = d_partials_.get() + size_t(kReduceBlocks) * 8;
+    hipLaunchKernelGGL((rba::k_reduce_rows<1>), dim3(1), dim3(256), 0, stream_,
+                       d_partials_.get(), int64_t(blocks), red);
+    all_reduce(red, 1);
+    all_reduce(d_fail_.get(), 1, kNcclMax);
+    double l_diff = 0;
+    int fail = 0;
+    HIP_CHECK(hipMemcpyAsync(&l_diff, red, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(&fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
+    timings_.back_substitution_time = time_end();
+    // the back-substitution leaves the blocks undamped in the reference
+    // (ipp:247-248); here damped rows are rebuilt by the next stage 2 anyway
+    if (!std::isfinite(l_diff) || (fail & 2)) {
+      *l_diff_out = std::numeric_limits<double>::quiet_NaN();
+      return RBA_NUMERICAL_FAILURE;
+    }
+    *l_diff_out = double(S(l_diff));
+    if (update_cams) {
+      time_begin();
+      hipLaunchKernelGGL((rba::k_update_cameras<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0,
+                         stream_, prm_, d_inc_.get());
+      timings_.update_cameras_time = time_end();
+    }
+    return RBA_OK;
+  }
+
+  // ---- LM driver (optimize_lm_ours) -----------------------------------------------------
+  // The reference's nested loop (bal_bundle_adjustment.cpp:291-521) as a
+  // resumable state machine: one call of lm_step() = one LM iteration (one row
+  // of the iteration log), so callers can time / interleave iterations.
+  void lm_begin() override {
+    lm_ = LmState{};
+    lm_.lambda = S(1.0 / opt_.initial_trust_region_radius);
+    lm_.lambda_vee = S(opt_.initial_vee);
+    lm_.active = true;
+  }
+
+  // returns 1 while the loop continues, 0 once terminated (row still valid
+  // unless the termination was a numerical failure before any work)
+  int lm_step(rba_lm_iteration* out) override {
+    if (!lm_.active) lm_begin();
+    const S min_lambda = S(1.0 / opt_.max_trust_region_radius);
+    const S max_lambda = S(1.0 / opt_.min_trust_region_radius);
+    const int max_lm_iter = opt_.max_num_iterations;
+    rba_lm_iteration row{};
+    row.iteration = lm_.it;
+    if (lm_.terminated || lm_.it > max_lm_iter) {
+      lm_.terminated = true;
+      *out = row;
+      return 0;
+    }
+    reset_timings();
+    const double t_it = wall_seconds();
+    auto finish = [&](bool keep_going) {
+      row.iteration_time = wall_seconds() - t_it;
+      row.stage1_time = timings_.stage1_time;
+      row.stage2_time = timings_.stage2_time;
+      row.precond_time = timings_.compute_preconditioner_time;
+      row.pcg_time = timings_.solve_reduced_system_time;
+      row.backsub_time = timings_.back_substitution_time;
+      row.residual_time = timings_.residual_evaluation_time;
+      *out = row;
+      if (lm_.it > max_lm_iter) lm_.terminated = true;
+      return (keep_going && !lm_.terminated) ? 1 : 0;
+    };
+    if (lm_.it == 0 || lm_.need_linearize) {
+      compute_error(&lm_.ri);
+      if (!lm_.ri.is_numerically_valid) {
+        lm_.terminated = true;
+        lm_.termination = -1;
+        return finish(false);
+      }
+    }
+    if (lm_.it == 0) {
+      // iteration 0 is evaluation only (bal_bundle_adjustment.cpp:311-322)
+      row.cost = lm_.ri.all_error;
+      row.cost_valid = lm_.ri.valid_error;
+      row.lambda = lm_.lambda;
+      row.step_is_successful = row.step_is_valid = 1;
+      lm_.prev_all = lm_.ri.all_error;
+      lm_.prev_valid = lm_.ri.valid_error;
+      lm_.it = 1;
+      lm_.need_linearize = true;
+      return finish(true);
+    }
+    if (lm_.need_linearize) {
+      if (linearize(nullptr) != RBA_OK) {
+        lm_.terminated = true;
+        lm_.termination = -1;
+        return finish(false);
+      }
+      lm_.need_linearize = false;
+    }
+    const rba_residual_info& ri = lm_.ri;
+    row.lambda = lm_.lambda;
+    rba_cg_summary cg{};
+    lm_inc_.resize(nvec_);
+    solve(lm_.lambda, lm_inc_.data(), &cg);
+    row.cg_iterations = cg.num_iterations;
+    row.cg_termination = cg.termination_type;
+    double nrm = 0;
+    bool finite = true;
+    for (S v : lm_inc_) {
+      nrm += double(v) * double(v);
+      finite = finite && std::isfinite(v);
+    }
+    row.inc_norm = std::sqrt(nrm);
+    if (!finite) {
+      // non-finite increment: reject, increase damping (:360-399)
+      lm_.lambda = lm_.lambda_vee * lm_.lambda;
+      lm_.lambda_vee *= S(opt_.vee_factor);
+      lm_.prev_all = lm_.prev_valid = 0;  // the reference leaves it_summary.cost zeroed here
+      ++lm_.it;
+      if (lm_.lambda > max_lambda) lm_.terminated = true;
+      return finish(true);
+    }
+    backup();
+    double l_diff_d = 0;
+    apply(lm_inc_.data(), &l_diff_d, true);
+    S l_diff = S(l_diff_d);
+    rba_residual_info ri2{};
+    compute_error(&ri2);
+    row.cost = ri2.all_error;
+    row.cost_valid = ri2.valid_error;
+    row.l_diff = l_diff;
+    if (!std::isfinite(l_diff) || !ri2.is_numerically_valid) {
+      row.step_is_valid = row.step_is_successful = 0;
+    } else {
+      S f_diff;
+      if (opt_.optimized_cost == 0)
+        f_diff = S(ri.all_error - ri2.all_error);
+      else if (opt_.optimized_cost == 1)
+        f_diff = S(ri.valid_error - ri2.valid_error);
+      else
+        f_diff = S(ri.valid_error / std::max(1, ri.valid_num_obs) -
+                   ri2.valid_error / std::max(1, ri2.valid_num_obs));
+      if (opt_.optimized_cost == 2) l_diff /= S(ri.valid_num_obs);
+      const S step_quality = f_diff / l_diff;
+      row.relative_decrease = step_quality;
+      row.step_is_valid = l_diff > 0;
+      row.step_is_successful = row.step_is_valid && step_quality > S(opt_.min_relative_decrease);
+    }
+    if (row.step_is_successful) {
+      lm_.lambda *= S(std::max(1.0 / 3, 1 - std::pow(2 * row.relative_decrease - 1, 3)));
+      lm_.lambda = std::max(min_lambda, lm_.lambda);
+      lm_.lambda_vee = S(opt_.initial_vee);
+      ++lm_.it;
+      double cost, change;
+      if (opt_.optimized_cost == 0) {
+        cost = ri2.all_error;
+        change = std::abs(lm_.prev_all - ri2.all_error);
+      } else {
+        cost = ri2.valid_error;
+        change = std::abs(lm_.prev_valid - ri2.valid_error);
+      }
+      lm_.prev_all = ri2.all_error;
+      lm_.prev_valid = ri2.valid_error;
+      if (change <= opt_.function_tolerance * cost) {
+        lm_.terminated = true;
+        lm_.termination = 1;
+      }
+      lm_.need_linearize = true;
+      return finish(true);
+    }
+    lm_.lambda = lm_.lambda_vee * lm_.lambda;
+    lm_.lambda_vee *= S(opt_.vee_factor);
+    lm_.prev_all = ri2.all_error;
+    lm_.prev_valid = ri2.valid_error;
+    restore();
+    ++lm_.it;
+    if (lm_.lambda > max_lambda) lm_.terminated = true;
+    return finish(true);
+  }
+
+  int lm_termination() const override { return lm_.termination; }
+
+  int optimize_lm(rba_lm_iteration* log, int max_rows, int* n_rows_out, int* term_out) override {
+    lm_begin();
+    int n_rows = 0;
+    for (;;) {
+      rba_lm_iteration row{};
+      const int more = lm_step(&row);
+      const bool produced = !(lm_.termination == -1 && row.cg_iterations == 0 && row.cost == 0) &&
+                            row.iteration <= opt_.max_num_iterations;
+      if (produced) {
+        if (n_rows < max_rows) log[n_rows] = row;
+        ++n_rows;
+      }
+      if (!more) break;
+    }
+    sync();
+    *n_rows_out = n_rows;
+    *term_out = lm_.termination;
+    return RBA_OK;
+  }
+
+  // ---- misc -----------------------------------------------------------------------------
+  void device_sync() override {
+    use_device();
+    sync();
+  }
+  void get_timings(rba_iter_timings* out) override { *out = timings_; }
+  void get_jl_col_scale(void* out) override {
+    use_device();
+    std::vector<S> sorted(3 * size_t(n_lms_));
+    d_jl_scale_.download(sorted.data(), sorted.size(), stream_);
+    sync();
+    S* o = static_cast<S*>(out);
+    for (int s = 0; s < n_lms_; ++s)
+      for (int c = 0; c < 3; ++c) o[3 * size_t(perm_[s]) + c] = sorted[3 * size_t(s) + c];
+  }
+  void get_pose_scaling(void* out) override {
+    use_device();
+    d_pose_scaling_.download(static_cast<S*>(out), nvec_, stream_);
+    sync();
+  }
+  void get_landmark_R(int damped, void* R6, void* q3) override {
+    use_device();
+    std::vector<S> R(6 * size_t(n_lms_)), q(3 * size_t(n_lms_));
+    if (damped) {
+      d_Rd_.download(R.data(), R.size(), stream_);
+      d_q1trd_.download(q.data(), q.size(), stream_);
+      sync();
+    } else {
+      d_R0_.download(R.data(), R.size(), stream_);
+      std::vector<S> qtr(2 * size_t(n_obs_));
+      std::vector<int64_t> lm_obs(n_lms_ + 1);
+      d_qtr_.download(qtr.data(), qtr.size(), stream_);
+      d_lm_obs_.download(lm_obs.data(), lm_obs.size(), stream_);
+      sync();
+      for (int s = 0; s < n_lms_; ++s)
+        for (int c = 0; c < 3; ++c) q[3 * size_t(s) + c] = qtr[2 * lm_obs[s] + c];
+    }
+    S* Ro = static_cast<S*>(R6);
+    S* qo = static_cast<S*>(q3);
+    for (int s = 0; s < n_lms_; ++s) {
+      for (int c = 0; c < 6; ++c) Ro[6 * size_t(perm_[s]) + c] = R[6 * size_t(s) + c];
+      for (int c = 0; c < 3; ++c) qo[3 * size_t(perm_[s]) + c] = q[3 * size_t(s) + c];
+    }
+  }
+  void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) override {
+    *storage = storage_bytes_;
+    *hx_bytes = hx_bytes_;
+    *hx_flops = hx_flops_;
+  }
+
+ private:
+  static constexpr int kReduceBlocks = 1024;
+  static constexpr int kMaxHxEvents = 1024;
+
+  void use_device() { HIP_CHECK(hipSetDevice(device_)); }
+  void sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+  void time_begin() { HIP_CHECK(hipEventRecord(ev_a_, stream_)); }
+  double time_end() {
+    HIP_CHECK(hipEventRecord(ev_b_, stream_));
+    HIP_CHECK(hipEventSynchronize(ev_b_));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+    return double(ms) * 1e-3;
+  }
+  void reset_timings() { timings_ = rba_iter_timings{}; }
+
+  template <class F>
+  void for_each_class(F&& f) {
+    if (cls_end_[0] > cls_begin_[0]) f(std::integral_constant<int, 1>{}, cls_begin_[0], cls_end_[0]);
+    if (cls_end_[1] > cls_begin_[1]) f(std::integral_constant<int, 2>{}, cls_begin_[1], cls_end_[1]);
+    if (cls_end_[2] > cls_begin_[2]) f(std::integral_constant<int, 4>{}, cls_begin_[2], cls_end_[2]);
+    if (cls_end_[3] > cls_begin_[3]) f(std::integral_constant<int, 8>{}, cls_begin_[3], cls_end_[3]);
+    if (cls_end_[4] > cls_begin_[4]) f(std::integral_constant<int, 16>{}, cls_begin_[4], cls_end_[4]);
+  }
+
+  int device_;
+  int n_cams_, n_lms_;
+  int64_t n_obs_ = 0;
+  int nvec_ = 0;
+  rba_options opt_;
+  hipStream_t stream_ = nullptr;
+  std::vector<int> perm_;
+  int cls_begin_[kNumClasses], cls_end_[kNumClasses];
+  int64_t hx_bytes_ = 0, hx_flops_ = 0, storage_bytes_ = 0;
+  rba::Params<S> prm_{};
+  S pose_damping_ = S(0);
+  bool landmark_damping_valid_ = false;
+  rba_iter_timings timings_{};
+  // device buffers
+  DevBuf<int> d_lm_k_, d_obs_cam_, d_obs_lm_, d_fail_;
+  DevBuf<int64_t> d_lm_obs_, d_lm_blk_, d_cam_off_;
+  DevBuf<int> d_cam_obs_;
+  DevBuf<S> d_dampO_, d_JpS_, d_bmO_;
+  DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
+  DevBuf<S> d_A_, d_top0_, d_topd_, d_qtr_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;
+  DevBuf<S> d_jp_diag2_, d_pose_scaling_, d_mid_, d_bb_, d_inv_;
+  DevBuf<S> d_x_, d_r_, d_p_, d_z_, d_q_, d_tmp_, d_inc_, d_vin_;
+  DevBuf<double> d_lm_ldiff_, d_partials_;
+  DevBuf<rba::CgState> d_cg_;
+  char* h_pinned_ = nullptr;
+  hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
+  std::vector<hipEvent_t> hx_events_;
+  int hx_event_count_ = 0, hx_calls_ = 0;
+  // LM state machine
+  struct LmState {
+    bool active = false, terminated = false, need_linearize = true;
+    int it = 0, termination = 0;
+    S lambda = S(0), lambda_vee = S(0);
+    double prev_all = 0, prev_valid = 0;
+    rba_residual_info ri{};
+  };
+  LmState lm_;
+  std::vector<S> lm_inc_;
+  // multi-GPU
+  void* comm_ = nullptr;
+  int rank_ = 0, nranks_ = 1;
+};
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const HipError& e) {
+    g_last_error = e.msg;
+    return e.code;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return RBA_ERR_INVALID_ARGUMENT;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+void rba_default_options(rba_options* o) {
+  o->use_householder = 1;
+  o->use_valid_projections_only = 0;
+  o->robust_norm = 0;
+  o->huber_parameter = 1.0;
+  o->jacobi_scaling_eps = 0.0;
+  o->preconditioner_type = 1;
+  o->reduction_alg = 1;
+  o->power_order = 10;
+  o->min_cg_it = 0;
+  o->max_cg_it = 500;
+  o->eta = 0.1;
+  o->num_threads = 0;
+  o->max_num_iterations = 20;
+  o->min_relative_decrease = 0.0;
+  o->initial_trust_region_radius = 1e4;
+  o->min_trust_region_radius = 1e-32;
+  o->max_trust_region_radius = 1e16;
+  o->function_tolerance = 1e-6;
+  o->initial_vee = 2.0;
+  o->vee_factor = 2.0;
+  o->optimized_cost = 0;
+  o->staged_execution = 1;
+}
+
+const char* rba_last_error(void) { return g_last_error.c_str(); }
+
+int rba_device_count(int* out) {
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    *out = 0;
+    return RBA_ERR_HIP;
+  }
+  *out = n;
+  return RBA_OK;
+}
+
+int rba_create(int dtype, int device, int32_t n_cams, int32_t n_lms,
+               const int64_t* lm_obs_offsets, const int32_t* obs_cam_idx, const void* obs_xy,
+               const rba_options* options, rba_handle* out) {
+  return guarded([&]() -> int {
+    if (!out || !lm_obs_offsets || !obs_cam_idx || !obs_xy || !options || n_cams <= 0 ||
+        n_lms <= 0) {
+      g_last_error = "rba_create: invalid argument";
+      return RBA_ERR_INVALID_ARGUMENT;
+    }
+    if (options->preconditioner_type != 0 && options->preconditioner_type != 1) {
+      // the reference LOG(FATAL)s for anything else in the QR solver
+      // (linearizor_qr.cpp:208-240)
+      g_last_error = "preconditioner_type must be JACOBI (0) or SCHUR_JACOBI (1)";
+      return RBA_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      g_last_error = "no HIP device available: the solver has no CPU fallback";
+      return RBA_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+      g_last_error = "device index out of range";
+      return RBA_ERR_INVALID_ARGUMENT;
+    }
+    if (dtype == RBA_F32)
+      *out = new Solver<float>(device, n_cams, n_lms, lm_obs_offsets, obs_cam_idx,
+                               static_cast<const float*>(obs_xy), *options);
+    else if (dtype == RBA_F64)
+      *out = new Solver<double>(device, n_cams, n_lms, lm_obs_offsets, obs_cam_idx,
+                                static_cast<const double*>(obs_xy), *options);
+    else {
+      g_last_error = "dtype must be RBA_F32 or RBA_F64";
+      return RBA_ERR_INVALID_ARGUMENT;
+    }
+    return RBA_OK;
+  });
+}
+
+int rba_destroy(rba_handle h) {
+  return guarded([&]() -> int {
+    delete h;
+    return RBA_OK;
+  });
+}
+
+int rba_comm_unique_id(void* out128) {
+  return guarded([&]() -> int {
+    if (!g_rccl.load()) {
+      g_last_error = "cannot load librccl.so";
+      return RBA_ERR_COMM;
+    }
+    Rccl::UniqueId id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) {
+      g_last_error = "ncclGetUniqueId failed";
+      return RBA_ERR_COMM;
+    }
+    std::memcpy(out128, &id, sizeof(id));
+    return RBA_OK;
+  });
+}
+
+int rba_comm_init(rba_handle h, int rank, int nranks, const void* uid) {
+  return guarded([&]() -> int {
+    h->comm_init(rank, nranks, uid);
+    return RBA_OK;
+  });
+}
+
+int rba_set_state(rba_handle h, const void* cams, const void* lms) {
+  return guarded([&]() -> int {
+    h->set_state(cams, lms);
+    return RBA_OK;
+  });
+}
+int rba_get_state(rba_handle h, void* cams, void* lms) {
+  return guarded([&]() -> int {
+    h->get_state(cams, lms);
+    return RBA_OK;
+  });
+}
+int rba_backup(rba_handle h) {
+  return guarded([&]() -> int {
+    h->backup();
+    return RBA_OK;
+  });
+}
+int rba_restore(rba_handle h) {
+  return guarded([&]() -> int {
+    h->restore();
+    return RBA_OK;
+  });
+}
+int rba_compute_error(rba_handle h, rba_residual_info* out) {
+  return guarded([&]() -> int {
+    h->compute_error(out);
+    return RBA_OK;
+  });
+}
+int rba_linearize(rba_handle h, void* jp_diag2_out) {
+  return guarded([&]() -> int { return h->linearize(jp_diag2_out); });
+}
+int rba_solve(rba_handle h, double lambda, void* inc_out, rba_cg_summary* cg) {
+  return guarded([&]() -> int { return h->solve(lambda, inc_out, cg); });
+}
+int rba_stage2(rba_handle h, double lambda, void* b_out, void* blocks_out) {
+  return guarded([&]() -> int { return h->stage2(lambda, b_out, blocks_out); });
+}
+int rba_right_multiply(rba_handle h, const void* x, void* y) {
+  return guarded([&]() -> int {
+    h->right_multiply(x, y);
+    return RBA_OK;
+  });
+}
+int rba_apply(rba_handle h, const void* inc, double* l_diff_out) {
+  return guarded([&]() -> int { return h->apply(inc, l_diff_out, true); });
+}
+int rba_back_substitute(rba_handle h, const void* inc, double* l_diff_out) {
+  return guarded([&]() -> int { return h->apply(inc, l_diff_out, false); });
+}
+int rba_optimize_lm(rba_handle h, rba_lm_iteration* log, int max_rows, int* n_rows_out,
+                    int* termination_out) {
+  return guarded([&]() -> int { return h->optimize_lm(log, max_rows, n_rows_out, termination_out); });
+}
+int rba_lm_begin(rba_handle h) {
+  return guarded([&]() -> int {
+    h->lm_begin();
+    return RBA_OK;
+  });
+}
+int rba_lm_step(rba_handle h, rba_lm_iteration* row, int* more_out) {
+  return guarded([&]() -> int {
+    const int more = h->lm_step(row);
+    if (more_out) *more_out = more;
+    return RBA_OK;
+  });
+}
+int rba_lm_termination(rba_handle h, int* termination_out) {
+  return guarded([&]() -> int {
+    *termination_out = h->lm_termination();
+    return RBA_OK;
+  });
+}
+int rba_synchronize(rba_handle h) {
+  return guarded([&]() -> int {
+    h->device_sync();
+    return RBA_OK;
+  });
+}
+int rba_get_timings(rba_handle h, rba_iter_timings* out) {
+  return guarded([&]() -> int {
+    h->get_timings(out);
+    return RBA_OK;
+  });
+}
+int rba_get_jl_col_scale(rba_handle h, void* out) {
+  return guarded([&]() -> int {
+    h->get_jl_col_scale(out);
+    return RBA_OK;
+  });
+}
+int rba_get_pose_scaling(rba_handle h, void* out) {
+  return guarded([&]() -> int {
+    h->get_pose_scaling(out);
+    return RBA_OK;
+  });
+}
+int rba_get_landmark_R(rba_handle h, int damped, void* R6, void* q3) {
+  return guarded([&]() -> int {
+    h->get_landmark_R(damped, R6, q3);
+    return RBA_OK;
+  });
+}
+int rba_get_problem_stats(rba_handle h, int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) {
+  return guarded([&]() -> int {
+    h->get_problem_stats(storage, hx_bytes, hx_flops);
+    return RBA_OK;
+  });
+}
+
+}  // extern "C"
