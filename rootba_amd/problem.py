@@ -181,14 +181,17 @@ def project(cams: np.ndarray, p_w: np.ndarray):
 # Synthetic BAL-shaped scenes
 # ---------------------------------------------------------------------------
 def synthetic_problem(n_cams: int, n_lms: int, n_obs_target: int, seed: int = RANDOM_SEED,
-                      obs_noise: float = 0.5, name: str = "synthetic") -> BalProblem:
+                      obs_noise: float = 0.5, name: str = "synthetic", k=None) -> BalProblem:
     """Cameras on a closed loop of radius 10 looking inward (+-5 deg jitter),
     landmarks in front of a random camera observed by it and its k-1 nearest
     loop neighbours, k = min(n_c, 2 + Geometric0(1/(kbar-1)))."""
     rng = np.random.default_rng(seed)
     kbar = n_obs_target / n_lms
     p = 1.0 / (kbar - 1.0)
-    k = np.minimum(n_cams, 2 + (rng.geometric(p, size=n_lms) - 1)).astype(np.int64)
+    k_draw = np.minimum(n_cams, 2 + (rng.geometric(p, size=n_lms) - 1)).astype(np.int64)
+    # `k` (optional) overrides the observation counts, e.g. to hit every k-class in tests
+    k = k_draw if k is None else np.minimum(n_cams, np.asarray(k, dtype=np.int64))
+    assert k.shape == (n_lms,) and k.min() >= 2
 
     # cameras
     theta = 2 * np.pi * np.arange(n_cams) / n_cams

@@ -1,0 +1,81 @@
+"""CPU-side checks of the product boundary (no GPU needed):
+the C-ABI library loads, exports every symbol include/rootba_hip.h declares,
+its POD structs match the header, and it refuses to run without a GPU (there is
+no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rootba_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rootba_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from rootba_amd import build
+    build.build()
+    return L.lib()
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rba_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    declared = _declared_functions()
+    assert len(declared) >= 25
+    missing = [f for f in declared if not hasattr(lib, f)]
+    assert not missing, missing
+    assert sorted(L.EXPORTS) == declared
+
+
+def test_default_options_match_reference_defaults(lib):
+    # reference examples/config/rootba_config_default.toml
+    o = L.default_options()
+    assert (o.use_householder, o.preconditioner_type, o.max_cg_it, o.min_cg_it) == (1, 1, 500, 0)
+    assert (o.max_num_iterations, o.robust_norm, o.optimized_cost, o.staged_execution) == (20, 0, 0, 1)
+    assert o.eta == 0.1 and o.jacobi_scaling_eps == 0.0 and o.function_tolerance == 1e-6
+    assert o.initial_trust_region_radius == 1e4 and o.min_trust_region_radius == 1e-32
+    assert o.max_trust_region_radius == 1e16 and o.initial_vee == 2.0 and o.vee_factor == 2.0
+
+
+def test_option_struct_layout_matches_oracle_mirror():
+    from oracle import oracle as O
+    assert [f[0] for f in L.RbaOptions._fields_] == [f[0] for f in O.Options._fields_]
+    assert C.sizeof(L.RbaOptions) == C.sizeof(O.Options)
+    assert [f[0] for f in L.RbaLmIteration._fields_] == [f[0] for f in O.LmIteration._fields_]
+    assert C.sizeof(L.RbaLmIteration) == C.sizeof(O.LmIteration)
+
+
+@pytest.mark.skipif(L.device_count() > 0 if os.path.exists(L.LIB_PATH) else False,
+                    reason="only meaningful on a box without a GPU")
+def test_create_fails_loudly_without_gpu(lib, small_problem):
+    from rootba_amd.linearizor import LinearizorHIP
+    with pytest.raises(RuntimeError, match="no CPU fallback|HIP device"):
+        LinearizorHIP(small_problem, np.float32)
+    # and through the raw C ABI
+    h = C.c_void_p()
+    off = np.ascontiguousarray(small_problem.lm_obs_offsets, dtype=np.int64)
+    cam = np.ascontiguousarray(small_problem.obs_cam_idx, dtype=np.int32)
+    xy = np.ascontiguousarray(small_problem.obs_xy, dtype=np.float32)
+    o = L.default_options()
+    st = lib.rba_create(0, 0, small_problem.n_cams, small_problem.n_lms, off.ctypes.data_as(C.c_void_p),
+                        cam.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p), C.byref(o), C.byref(h))
+    assert st < 0 and "fallback" in L.last_error()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "rootba_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("oracle/", "").replace("(oracle)", "") or \
+                    "never imported" in txt or "test infrastructure" in txt, f

@@ -1,0 +1,356 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs — the first gate. Quantities compared are the invariants of
+SURVEY.md §8c (Q2^T Jp itself is not unique): Jp_diag2 / scaling, Jl_col_scale,
+R^T R, b, block diagonal, H*x, PCG increment, landmark update, l_diff, costs and
+the LM trajectory.
+
+Tolerances (metric |a-b|/(|a|+|b|), reference src/rootba/testing/eigen_utils.hpp:105-108):
+  f64: 1e-10  (reference: 1e-12 between two CPU paths; summation order differs here)
+  f32: 1e-4 on vectors, 1e-6 relative on the final cost (north_star)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float32: 1e-4, np.float64: 1e-10}
+LAMBDA = 0.1
+
+
+def _opts(mod, **kw):
+    base = dict(robust_norm=1, huber_parameter=1.0)
+    base.update(kw)
+    return mod.default_options(**base)
+
+
+def _pair(prob, dtype, **kw):
+    import torch  # noqa: F401  (HIP runtime first, as in bench.py)
+    from oracle import oracle as O
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    return LinearizorHIP(prob, dtype, _opts(L, **kw)), O.Oracle(prob, dtype, _opts(O, **kw))
+
+
+@pytest.fixture(scope="module")
+def mixed_k_problem():
+    """Exercises every k-class: k = 2 ... 60 (CH = 1, 2, 4, 8, 16)."""
+    from rootba_amd import problem as P
+    k = np.concatenate([np.arange(2, 81), np.random.default_rng(21).integers(2, 30, 181)])
+    raw = P.synthetic_problem(90, k.size, int(k.sum()), seed=21, k=k)
+    prob = P.preprocess(raw, seed=21, translation_sigma=0.3, point_sigma=0.3)
+    k = prob.obs_per_lm()
+    assert k.min() == 2 and k.max() > 56 and np.unique(k).size > 50
+    return prob
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_compute_error(small_problem, dtype):
+    g, o = _pair(small_problem, dtype)
+    a, b = g.compute_error(), o.compute_error()
+    assert (a.all_num_obs, a.valid_num_obs, a.is_numerically_valid) == (b.all_num_obs, b.valid_num_obs, 1)
+    tol = 1e-6 if dtype == np.float32 else 1e-13
+    assert abs(a.all_error - b.all_error) / b.all_error < tol
+    assert abs(a.valid_error - b.valid_error) / b.valid_error < tol
+    assert abs(a.all_residual_sum - b.all_residual_sum) / b.all_residual_sum < tol
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("which", ["small", "mixed"])
+def test_linearization_stage2_operator_backsub(small_problem, mixed_k_problem, dtype, which):
+    prob = small_problem if which == "small" else mixed_k_problem
+    tol = TOL[dtype]
+    g, o = _pair(prob, dtype)
+    st, d2 = g.linearize(want_jp_diag2=True)
+    assert st == 0 and o.linearize() == 0
+    assert rel_err(g.pose_scaling(), o.pose_scaling()) < tol
+    assert rel_err(g.jl_col_scale(), o.jl_col_scale()) < tol
+    # R^T R and |Q1^T r| are invariant to the reflector sign conventions
+    Rg, qg = g.landmark_R(damped=False)
+    for l in (0, prob.n_lms // 2, prob.n_lms - 1):
+        blk, li = o.block(l)
+        Ro = np.triu(blk[:3, li:li + 3].astype(np.float64))
+        Rl = np.zeros((3, 3))
+        Rl[np.triu_indices(3)] = Rg[l]
+        assert rel_err(Rl.T @ Rl, Ro.T @ Ro) < 10 * tol
+        assert rel_err(np.abs(qg[l]), np.abs(blk[:3, li + 3])) < 10 * tol
+    for lam in (LAMBDA, 0.0):
+        o.set_pose_damping(lam)
+        b_o, bl_o = o.stage2(lam, o.pose_scaling() if lam == LAMBDA else None)
+        b_g, bl_g = g.stage2(lam)
+        assert rel_err(b_g, b_o) < tol
+        assert rel_err(bl_g, bl_o) < tol
+        x = np.random.default_rng(0).uniform(-1, 1, 9 * prob.n_cams).astype(dtype)
+        assert rel_err(g.right_multiply(x), o.right_multiply(x)) < tol
+    # back-substitution with a random small increment (linearization_qr.test.cpp:194-211)
+    o.set_pose_damping(LAMBDA)
+    o.stage2(LAMBDA, None)
+    g.stage2(LAMBDA)
+    inc = (np.random.default_rng(1).uniform(-1, 1, 9 * prob.n_cams) * 0.01).astype(dtype)
+    lg, lo = g.back_substitute(inc), o.back_substitute(inc)
+    assert abs(lg - lo) / (abs(lg) + abs(lo)) < tol
+    assert rel_err(g.get_state()[1], o.get_state()[1]) < tol
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("precond", [0, 1])
+def test_solve_and_apply(small_problem, dtype, precond):
+    tol = TOL[dtype]
+    g, o = _pair(small_problem, dtype, preconditioner_type=precond)
+    assert g.linearize() == 0 and o.linearize() == 0
+    ig, cg = g.solve(1e-4)
+    io, co = o.solve(1e-4)
+    assert cg.termination_type == co.termination_type == 1
+    assert abs(cg.num_iterations - co.num_iterations) <= 1
+    assert rel_err(ig, io) < 10 * tol
+    lg, lo = g.apply(io), o.apply(io)  # same increment on both sides
+    assert abs(lg - lo) / (abs(lg) + abs(lo)) < tol
+    (cg_, lg_), (co_, lo_) = g.get_state(), o.get_state()
+    assert rel_err(cg_, co_) < tol and rel_err(lg_, lo_) < tol
+    assert np.allclose(np.linalg.norm(cg_[:, :4], axis=1), 1.0, atol=1e-6)
+
+
+def test_operator_is_symmetric_positive(small_problem):
+    g, _ = _pair(small_problem, np.float64)
+    assert g.linearize() == 0
+    g.stage2(LAMBDA)
+    rng = np.random.default_rng(2)
+    n = 9 * small_problem.n_cams
+    x, y = rng.normal(size=n), rng.normal(size=n)
+    hx, hy = g.right_multiply(x), g.right_multiply(y)
+    assert abs(y @ hx - x @ hy) < 1e-10 * abs(y @ hx)
+    assert x @ hx > 0
+    assert rel_err(g.right_multiply(2 * x - 3 * y), 2 * hx - 3 * hy) < 1e-12  # linearity
+
+
+@pytest.fixture(scope="module")
+def ladybug_far():
+    """ladybug-49 stand-in started far from the optimum (like real BAL data)."""
+    from rootba_amd import problem as P
+    return P.preprocess(P.named_synthetic("ladybug-49"), translation_sigma=0.5, point_sigma=0.5)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lm_trajectory_matches_oracle(ladybug_far, dtype):
+    """Whole LM runs: same accept/reject decisions, CG iteration counts and costs
+    while the steps are large, and the SAME FINAL COST within 1e-6 relative
+    (north_star). Both sides run a fixed 12 iterations (function_tolerance = 0):
+    the default stopping rule |dcost| <= 1e-6 cost has itself only 1e-6 resolution,
+    so two valid runs may stop one iteration apart. Two float32 runs with
+    different summation orders drift apart at the 1e-3 level in the late, tiny
+    increments (truncated CG, eta = 0.1); increments are therefore compared in
+    lock-step in the next test."""
+    g, o = _pair(ladybug_far, dtype, max_num_iterations=12, function_tolerance=0.0)
+    lg, tg = g.optimize_lm()
+    lo, to = o.optimize_lm()
+    for a, b in zip(lg[:5], lo[:5]):
+        assert a.step_is_successful == b.step_is_successful
+        assert abs(a.cg_iterations - b.cg_iterations) <= (1 if dtype == np.float32 else 0)
+        assert abs(a.inc_norm - b.inc_norm) <= (1e-3 if dtype == np.float32 else 1e-8) * b.inc_norm + 1e-12
+        assert abs(a.cost - b.cost) <= (1e-5 if dtype == np.float32 else 1e-10) * b.cost
+        assert abs(a.lambda_ - b.lambda_) <= 1e-3 * b.lambda_
+    if dtype == np.float64:
+        assert len(lg) == len(lo) and tg == to
+    fg = min(r.cost for r in lg if r.step_is_successful)
+    fo = min(r.cost for r in lo if r.step_is_successful)
+    if dtype == np.float64:
+        assert abs(fg - fo) / fo < 1e-9
+    else:
+        # float32 resolution of the cost itself on this problem: residuals ~0.5 px are
+        # differences of ~1e3 px projections (rel. error ~1e-4 each), 3e4 observations
+        # => ~6e-7 relative noise on the sum. Both float32 runs must sit within that
+        # noise of the float64 optimum (and hence of each other).
+        from oracle import oracle as O
+        o64 = O.Oracle(ladybug_far, np.float64, _opts(O, max_num_iterations=12, function_tolerance=0.0))
+        f64 = min(r.cost for r in o64.optimize_lm()[0] if r.step_is_successful)
+        assert abs(fg - f64) / f64 < 2e-6 and abs(fo - f64) / f64 < 2e-6
+        assert abs(fg - fo) / fo < 3e-6
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_per_iteration_increment_lockstep(ladybug_far, dtype):
+    """Per-iteration pose increment from the SAME state and lambda. The oracle
+    drives the trajectory, the GPU is re-synchronised every step.
+    f64: 1e-10. f32: 1e-4 while the truncated PCG runs a handful
+    of iterations; with 20+ PCG iterations float32 rounding is amplified in BOTH
+    implementations, so there the bound is accuracy parity: the GPU increment is
+    as close to the float64 solution as the float32 oracle's is."""
+    from oracle import oracle as O
+    g, o = _pair(ladybug_far, dtype)
+    o64 = O.Oracle(ladybug_far, np.float64, _opts(O))
+    lam = 1e-4
+    for it in range(5):
+        g.set_state(*o.get_state())
+        o64.set_state(*o.get_state())
+        assert g.linearize() == 0 and o.linearize() == 0 and o64.linearize() == 0
+        ig, cg = g.solve(lam)
+        io, co = o.solve(lam)
+        i64, c64 = o64.solve(lam)
+        assert abs(cg.num_iterations - co.num_iterations) <= (1 if dtype == np.float32 else 0)
+        if dtype == np.float64:
+            assert rel_err(ig, io) < 1e-10
+        elif cg.num_iterations == co.num_iterations == c64.num_iterations:
+            if cg.num_iterations <= 8:
+                assert rel_err(ig, io) < 1e-4
+            assert rel_err(ig, io) < 5e-3
+            assert rel_err(ig, i64) <= 3 * rel_err(io, i64) + 1e-5
+        lg, lo = g.apply(io), o.apply(io)
+        # l_diff is a small difference of large sums once the steps get small: f32 2e-3
+        assert abs(lg - lo) <= (2e-3 if dtype == np.float32 else 1e-10) * abs(lo)
+        lam /= 3
+
+
+def test_golden_vectors_f64():
+    """HIP path vs the committed oracle-generated fixture (tests/golden)."""
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    from test_oracle_golden import G, golden_problem
+    prob = golden_problem()
+    g = LinearizorHIP(prob, np.float64, _opts(L))
+    ri = g.compute_error()
+    assert abs(ri.all_error - float(G["error"])) / float(G["error"]) < 1e-12
+    assert g.linearize() == 0
+    assert rel_err(g.pose_scaling(), G["pose_scaling"]) < 1e-12
+    assert rel_err(g.jl_col_scale(), G["jl_col_scale"]) < 1e-12
+    b, blocks = g.stage2(float(G["lam"]))
+    assert rel_err(b, G["b"]) < 1e-10 and rel_err(blocks, G["blocks"]) < 1e-10
+    assert rel_err(g.right_multiply(G["x"]), G["hx"]) < 1e-10
+    l = g.back_substitute(G["inc_rand"])
+    assert abs(l - float(G["l_diff"])) / abs(float(G["l_diff"])) < 1e-10
+    assert rel_err(g.get_state()[1], G["lms_after"]) < 1e-12
+    g2 = LinearizorHIP(prob, np.float64, _opts(L))
+    assert g2.linearize() == 0
+    inc, cg = g2.solve(1e-4)
+    assert cg.num_iterations == int(G["cg_iterations"]) and rel_err(inc, G["inc"]) < 1e-9
+    g2.apply(G["inc"])
+    assert rel_err(g2.get_state()[0], G["cams_after"]) < 1e-12
+    g3 = LinearizorHIP(prob, np.float64, _opts(L, max_num_iterations=10))
+    log, term = g3.optimize_lm()
+    assert term == int(G["lm_term"]) and len(log) == len(G["lm_cost"])
+    assert np.allclose([r.cost for r in log], G["lm_cost"], rtol=1e-8)
+    assert abs(log[-1].cost - G["lm_cost"][-1]) / G["lm_cost"][-1] < 1e-6
+
+
+# ---------------------------------------------------------------------------
+# edge cases
+# ---------------------------------------------------------------------------
+def _two_obs_problem():
+    from rootba_amd import problem as P
+    raw = P.synthetic_problem(30, 500, 1000, seed=4)
+    # force every landmark to exactly two observations
+    keep_lm = np.arange(raw.n_lms)
+    off = raw.lm_obs_offsets
+    idx = np.concatenate([np.arange(off[l], off[l] + 2) for l in keep_lm])
+    two = P.BalProblem(raw.cams, raw.lms, np.arange(0, 2 * raw.n_lms + 1, 2, dtype=np.int64),
+                       raw.obs_cam_idx[idx], raw.obs_xy[idx], "k2")
+    return P.preprocess(two, seed=4, translation_sigma=0.3, point_sigma=0.3, init_depth_threshold=0.0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_all_landmarks_with_two_observations(dtype):
+    prob = _two_obs_problem()
+    assert prob.obs_per_lm().max() == 2
+    g, o = _pair(prob, dtype)
+    assert g.linearize() == 0 and o.linearize() == 0
+    o.set_pose_damping(LAMBDA)
+    b_o, bl_o = o.stage2(LAMBDA, o.pose_scaling())
+    b_g, bl_g = g.stage2(LAMBDA)
+    assert rel_err(b_g, b_o) < TOL[dtype] and rel_err(bl_g, bl_o) < TOL[dtype]
+    x = np.random.default_rng(3).uniform(-1, 1, 9 * prob.n_cams).astype(dtype)
+    assert rel_err(g.right_multiply(x), o.right_multiply(x)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("kw", [dict(robust_norm=0), dict(use_valid_projections_only=1, optimized_cost=1),
+                                dict(jacobi_scaling_eps=1.0)])
+def test_option_variants(small_problem, kw):
+    g, o = _pair(small_problem, np.float64, **kw)
+    a, b = g.compute_error(), o.compute_error()
+    assert abs(a.all_error - b.all_error) / b.all_error < 1e-12
+    assert g.linearize() == 0 and o.linearize() == 0
+    ig, cg = g.solve(1e-3)
+    io, co = o.solve(1e-3)
+    assert cg.num_iterations == co.num_iterations and rel_err(ig, io) < 1e-9
+
+
+def test_backup_restore_and_determinism(small_problem):
+    g, _ = _pair(small_problem, np.float32)
+    c0, l0 = g.get_state()
+    g.backup()
+    assert g.linearize() == 0
+    b1, bl1 = g.stage2(LAMBDA)
+    inc, _ = g.solve(1e-4)
+    g.apply(inc)
+    c1, l1 = g.get_state()
+    assert not np.array_equal(c0, c1) and not np.array_equal(l0, l1)
+    g.restore()
+    c2, l2 = g.get_state()
+    assert np.array_equal(c0, c2) and np.array_equal(l0, l2)
+    # camera-major reductions have a fixed summation order: bitwise reproducible
+    assert g.linearize() == 0
+    b2, bl2 = g.stage2(LAMBDA)
+    assert np.array_equal(b1, b2) and np.array_equal(bl1, bl2)
+
+
+def test_invalid_inputs_are_rejected(small_problem):
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd import problem as P
+    from rootba_amd.linearizor import LinearizorHIP
+    bad = small_problem.copy()
+    bad.obs_cam_idx[0], bad.obs_cam_idx[1] = bad.obs_cam_idx[1], bad.obs_cam_idx[0]  # not ascending
+    with pytest.raises(RuntimeError, match="ascending"):
+        LinearizorHIP(bad, np.float32)
+    one = P.BalProblem(small_problem.cams, small_problem.lms[:2], np.array([0, 1, 3]),
+                       small_problem.obs_cam_idx[:3].copy(), small_problem.obs_xy[:3], "one-obs")
+    with pytest.raises(RuntimeError, match=">= 2 observations"):  # landmark_block_base.ipp:70-73
+        LinearizorHIP(one, np.float32)
+    with pytest.raises(RuntimeError, match="preconditioner_type"):  # linearizor_qr.cpp:208-240
+        LinearizorHIP(small_problem, np.float32, L.default_options(preconditioner_type=2))
+
+
+def test_numerical_failure_is_reported_not_fatal(small_problem):
+    g, _ = _pair(small_problem, np.float32)
+    cams, lms = g.get_state()
+    lms = lms.copy()
+    lms[3] = np.nan
+    g.set_state(cams, lms)
+    assert g.compute_error().is_numerically_valid == 0
+    assert g.linearize() == 1  # reference: empty vector (linearization_qr.hpp:702-711)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json's full size: size-independent properties on venice-1778
+# ---------------------------------------------------------------------------
+def test_full_size_venice_properties():
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd import problem as P
+    from rootba_amd.linearizor import LinearizorHIP
+    prob = P.preprocess(P.named_synthetic("venice-1778"), translation_sigma=0.5, point_sigma=0.5)
+    g = LinearizorHIP(prob, np.float32, _opts(L, max_num_iterations=3))
+    stats = g.problem_stats()
+    assert stats == {k: prob.block_stats()[k] for k in stats}
+    e0 = g.compute_error()
+    assert e0.all_num_obs == prob.n_obs and e0.is_numerically_valid
+    c0, l0 = g.get_state()
+    g.backup()
+    assert g.linearize() == 0
+    g.stage2(1e-4)
+    rng = np.random.default_rng(0)
+    n = 9 * prob.n_cams
+    x, y = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    hx, hy = g.right_multiply(x), g.right_multiply(y)
+    assert abs(float(y @ hx) - float(x @ hy)) < 1e-4 * abs(float(y @ hx))  # symmetry
+    assert float(x @ hx) > 0  # positive definite with damping
+    assert rel_err(g.right_multiply(x + y), hx + hy) < 1e-5  # linearity
+    log, _ = g.optimize_lm()
+    costs = [r.cost for r in log if r.step_is_successful]
+    assert costs[-1] < 0.05 * costs[0] and all(b <= a for a, b in zip(costs, costs[1:]))
+    g.restore()  # optimize_lm's own backups are newer; restore returns the last accepted state's backup
+    c1, _ = g.get_state()
+    assert np.isfinite(c1).all()
