@@ -660,10 +660,12 @@ __global__ __launch_bounds__(256) void k_stage2(Params<S> p, int lm_begin, int l
 // ===========================================================================
 template <class S, int CH, int U>
 __global__ __launch_bounds__(256) void k_hx(Params<S> p, int lm_begin, int lm_end,
-                                            const S* __restrict__ x, S* __restrict__ y) {
+                                            const S* __restrict__ x, S* __restrict__ y,
+                                            const int* __restrict__ done_flag) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s = lm_begin + blockIdx.x * 4 + wave;
   if (s >= lm_end) return;
+  if (done_flag && *done_flag) return;  // PCG already terminated (host polls lazily)
   const int k = p.lm_k[s];
   const int64_t o0 = p.lm_obs[s];
   const int nrows = 2 * k, ncols = 9 * k;
@@ -715,6 +717,130 @@ __global__ __launch_bounds__(256) void k_hx(Params<S> p, int lm_begin, int lm_en
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch)
     if (act[ch]) atomic_add(y + yidx[ch], yr[ch]);
+}
+
+// ===========================================================================
+// H*x for SMALL landmarks (k <= 7): LDS-staged batches.
+// One wavefront per 0.3-3.5 KB landmark is latency bound (profiles/README.md),
+// so a workgroup takes G consecutive landmarks of the SAME k — their blocks are
+// contiguous in HBM because landmarks are sorted by k — copies the whole
+// G x (2k x 9k) region into LDS with 16-byte coalesced loads, then
+//   phase 1: thread (g, row i):  t[g][i] = A_g[i,:] . x_g      (9k LDS reads)
+//   phase 2: thread (g, col j):  y[g][j] = A_g[:,j] . t[g][:]  (2k LDS reads)
+// and scatter-adds y (9 consecutive threads <-> 9 consecutive floats).
+// A is read from HBM exactly once; no cross-lane reductions at all.
+// ===========================================================================
+struct SmallBatch {
+  int s0;       // first (sorted) landmark
+  int G;        // landmarks in the batch, G * 2k <= 256
+  int K;        // observations per landmark (2..7)
+  int pad;
+  int64_t blk;  // = lm_blk[s0]: offset of the batch's first block in A
+  int64_t obs;  // = lm_obs[s0]: first observation of the batch
+};
+
+template <class S, int K>
+__device__ __forceinline__ void hx_small_body(const Params<S>& p, const SmallBatch d,
+                                              const S* __restrict__ x, S* __restrict__ y,
+                                              char* smem) {
+  constexpr int NC = 9 * K, NR = 2 * K, BLK = (NR * NC + 3) / 4 * 4;
+  const int tid = threadIdx.x;
+  const int G = d.G;
+  S* Al = reinterpret_cast<S*>(smem);
+  S* xs = Al + G * BLK;
+  S* ts = xs + G * NC;
+  int* yidx = reinterpret_cast<int*>(ts + 256);
+  // 1. global -> LDS, 16 B per lane, fully coalesced
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(p.A + d.blk);
+    uint4* dst = reinterpret_cast<uint4*>(Al);
+    const int n16 = G * BLK * int(sizeof(S)) / 16;
+    // all loads are issued before the first LDS store (<= 8 x 16 B in flight per lane)
+    // (the host caps a batch at kSmallLdsBudget = NLD x 256 x 16 B)
+    constexpr int NLD = 4;
+    uint4 buf[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int q = u * 256 + tid;
+      buf[u] = (q < n16) ? src[q] : uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int q = u * 256 + tid;
+      if (q < n16) dst[q] = buf[u];
+    }
+  }
+  // 2. gather x, remember the scatter index
+  const int64_t o0 = d.obs;
+  {
+    constexpr int NG = 5;  // G * NC <= 64 * 18 = 1152 < 5 * 256
+    int idx[NG];
+    S xv[NG];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int e = u * 256 + tid;
+      idx[u] = 0;
+      if (e < G * NC) {
+        const int g = e / NC, j = e - NC * g;
+        const int i = j / 9, comp = j - 9 * i;
+        idx[u] = 9 * p.obs_cam[o0 + g * K + i] + comp;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NG; ++u) xv[u] = (u * 256 + tid < G * NC) ? x[idx[u]] : S(0);
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int e = u * 256 + tid;
+      if (e < G * NC) {
+        yidx[e] = idx[u];
+        xs[e] = xv[u];
+      }
+    }
+  }
+  __syncthreads();
+  // 3. rows: t = A x  (column order rotated per thread when 9k is even so that
+  //    the 9k-strided rows do not collide on LDS banks)
+  if (tid < G * NR) {
+    const int g = tid / NR, i = tid - NR * g;
+    const S* row = Al + g * BLK + i * NC;
+    const S* xv = xs + g * NC;
+    int c = (K % 2 == 0) ? tid % NC : 0;
+    S acc = S(0);
+#pragma unroll 9
+    for (int jj = 0; jj < NC; ++jj) {
+      acc += row[c] * xv[c];
+      c = (c + 1 == NC) ? 0 : c + 1;
+    }
+    ts[tid] = acc;
+  }
+  __syncthreads();
+  // 4. columns: y = A^T t, scatter
+  for (int e = tid; e < G * NC; e += 256) {
+    const int g = e / NC, j = e - NC * g;
+    const S* col = Al + g * BLK + j;
+    const S* tv = ts + g * NR;
+    S acc = S(0);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) acc += col[i * NC] * tv[i];
+    atomic_add(y + yidx[e], acc);
+  }
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void k_hx_small(Params<S> p, const SmallBatch* __restrict__ batches,
+                                                  const S* __restrict__ x, S* __restrict__ y,
+                                                  const int* __restrict__ done_flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (done_flag && *done_flag) return;  // PCG already terminated (host polls lazily)
+  const SmallBatch d = batches[blockIdx.x];
+  switch (d.K) {
+    case 2: hx_small_body<S, 2>(p, d, x, y, smem_raw); break;
+    case 3: hx_small_body<S, 3>(p, d, x, y, smem_raw); break;
+    case 4: hx_small_body<S, 4>(p, d, x, y, smem_raw); break;
+    case 5: hx_small_body<S, 5>(p, d, x, y, smem_raw); break;
+    case 6: hx_small_body<S, 6>(p, d, x, y, smem_raw); break;
+    default: hx_small_body<S, 7>(p, d, x, y, smem_raw); break;
+  }
 }
 
 // ===========================================================================
@@ -913,47 +1039,81 @@ __global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ in
 }
 
 // ===========================================================================
-// PCG vector kernels (ConjugateGradientsSolver::solve,
-// src/rootba/cg/conjugate_gradient.hpp:113-298). All scalars stay on the device
-// in `CgState` (double, as in the reference); the host only polls `done`.
+// PCG (ConjugateGradientsSolver::solve, src/rootba/cg/conjugate_gradient.hpp:113-298)
+// Three fused single-workgroup kernels per iteration around H*x:
+//   k_pcg_a : z = M^-1 r, rho = r.z, beta, p = z + beta p, q = 0
+//   k_pcg_b : q += lambda p, pq = p.q, alpha, x += alpha p, r -= alpha q,
+//             Q-model termination test (or prepares the residual refresh)
+//   k_pcg_c : (every 10th iteration) r = b - H x, then the termination test
+// All scalars stay on the device in `CgState` (double, as in the reference);
+// kernels are no-ops once `done`; the host only polls the state. Reductions use
+// one workgroup and a fixed order, so every rank of a multi-GPU run computes
+// bit-identical scalars from the (identical) all-reduced vectors.
 // ===========================================================================
 struct CgState {
-  double rho, last_rho, pq, q0, q1, norm_b2, dot_tmp;
+  double rho, last_rho, pq, q0, q1, norm_b2;
   double alpha, beta;
   int iter;         // iterations completed
   int done;         // 0 running, 1 finished
   int termination;  // 0 NO_CONVERGENCE, 1 SUCCESS, 2 FAILURE
-  int refresh;      // next update recomputes r from scratch
+  int refresh;      // the current iteration recomputes r from scratch
 };
 
-template <class S>
-__device__ __forceinline__ void block_accumulate(double v, double* target) {
-  __shared__ double sm[4];
+constexpr int kPcgThreads = 1024;
+
+// deterministic sum over the workgroup (<= 16 waves); result valid in all threads
+__device__ __forceinline__ double pcg_block_sum(double v, double* sm) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nw = blockDim.x >> 6;
   const double t = wave_sum(v);
+  __syncthreads();
   if (lane == 0) sm[wave] = t;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(target, sm[0] + sm[1] + sm[2] + sm[3]);
+  double r = 0;
+  for (int w = 0; w < nw; ++w) r += sm[w];
+  return r;
 }
 
-// generic dot product -> *out (must be zeroed before)
+// x = 0, r = b, state reset, |b|^2
 template <class S>
-__global__ __launch_bounds__(256) void k_dot(const S* __restrict__ a, const S* __restrict__ b,
-                                             int n, double* out) {
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_init(const S* __restrict__ bvec,
+                                                         S* __restrict__ x, S* __restrict__ r,
+                                                         int n, CgState* st) {
+  __shared__ double sm[16];
   double acc = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-    acc += double(a[i]) * double(b[i]);
-  block_accumulate<S>(acc, out);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const S v = bvec[i];
+    x[i] = S(0);
+    r[i] = v;
+    acc += double(v) * double(v);
+  }
+  const double nb2 = pcg_block_sum(acc, sm);
+  if (threadIdx.x == 0) {
+    st->rho = 1.0;
+    st->last_rho = 1.0;
+    st->pq = 0;
+    st->q0 = 0;  // -x.(b + r) with x = 0
+    st->q1 = 0;
+    st->norm_b2 = nb2;
+    st->alpha = st->beta = 0;
+    st->iter = 0;
+    st->refresh = 0;
+    st->termination = nb2 == 0.0 ? 1 : 0;  // "Convergence. |b| = 0."
+    st->done = nb2 == 0.0 ? 1 : 0;
+  }
 }
 
-// z = M^-1 r (9x9 block per camera, one thread per vector element); rho = r.z
 template <class S>
-__global__ __launch_bounds__(256) void k_precond_rho(const S* __restrict__ inv,
-                                                     const S* __restrict__ r, S* __restrict__ z,
-                                                     int n, CgState* st) {
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_a(const S* __restrict__ inv,
+                                                      const S* __restrict__ r, S* __restrict__ z,
+                                                      S* __restrict__ pvec, S* __restrict__ q, int n,
+                                                      CgState* st) {
+  __shared__ double sm[16];
+  __shared__ double s_beta;
+  __shared__ int s_stop;
   if (st->done) return;
   double acc = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int c = i / 9, row = i - 9 * c;
     const S* M = inv + 81 * c + 9 * row;
     const S* rc = r + 9 * c;
@@ -963,140 +1123,145 @@ __global__ __launch_bounds__(256) void k_precond_rho(const S* __restrict__ inv,
     z[i] = v;
     acc += double(r[i]) * double(v);
   }
-  block_accumulate<S>(acc, &st->rho);
-}
-
-// scalar step A (1 thread): rho checks, beta
-__global__ void k_cg_scalar_a(CgState* st) {
-  if (st->done) return;
-  const double rho = st->rho;
-  if (rho == 0.0 || isinf(rho)) {
-    st->termination = 2;
-    st->done = 1;
-    st->iter += 1;
-    return;
-  }
-  if (st->iter == 0) {
-    st->beta = 0.0;
-  } else {
-    const double beta = rho / st->last_rho;
-    if (beta == 0.0 || isinf(beta)) {
+  const double rho = pcg_block_sum(acc, sm);
+  if (threadIdx.x == 0) {
+    int stop = 0;
+    double beta = 0.0;
+    if (rho == 0.0 || isinf(rho)) {
+      stop = 1;
+    } else if (st->iter > 0) {
+      beta = rho / st->rho;  // st->rho still holds the previous iteration's value
+      if (beta == 0.0 || isinf(beta)) stop = 1;
+    }
+    if (stop) {
       st->termination = 2;
       st->done = 1;
       st->iter += 1;
-      return;
+    } else {
+      st->last_rho = st->rho;
+      st->rho = rho;
+      st->beta = beta;
     }
-    st->beta = beta;
+    s_beta = beta;
+    s_stop = stop;
   }
-  st->pq = 0.0;
-}
-
-// p = z + beta p ; q = 0 (accumulation target of H*x)
-template <class S>
-__global__ void k_update_p(const S* __restrict__ z, S* __restrict__ pvec, S* __restrict__ q, int n,
-                           const CgState* st) {
-  if (st->done) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const S beta = S(st->beta);
-  pvec[i] = (st->iter == 0) ? z[i] : z[i] + beta * pvec[i];
-  q[i] = S(0);
-}
-
-// q += lambda p (pose damping term of right_multiply, linearization_qr.hpp:424-426); pq = p.q
-template <class S>
-__global__ __launch_bounds__(256) void k_damp_pq(const S* __restrict__ pvec, S* __restrict__ q,
-                                                 S lambda, int n, CgState* st) {
-  if (st->done) return;
-  double acc = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const S v = q[i] + lambda * pvec[i];
-    q[i] = v;
-    acc += double(pvec[i]) * double(v);
+  __syncthreads();
+  if (s_stop) return;
+  const S beta = S(s_beta);
+  const bool first = st->iter == 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    pvec[i] = first ? z[i] : z[i] + beta * pvec[i];
+    q[i] = S(0);
   }
-  block_accumulate<S>(acc, &st->pq);
 }
 
-// scalar step B (1 thread): pq checks, alpha
-__global__ void k_cg_scalar_b(CgState* st, int residual_reset_period) {
-  if (st->done) return;
-  const double pq = st->pq;
-  if (pq <= 0.0 || isinf(pq)) {
-    st->termination = 0;
-    st->done = 1;
-    st->iter += 1;
-    return;
-  }
-  const double alpha = st->rho / pq;
-  if (isinf(alpha)) {
-    st->termination = 2;
-    st->done = 1;
-    st->iter += 1;
-    return;
-  }
-  st->alpha = alpha;
-  st->q1 = 0.0;
-  st->refresh = ((st->iter + 1) % residual_reset_period) == 0 ? 1 : 0;
-}
-
-// x += alpha p ; r -= alpha q (unless refresh) ; tmp = 0 when refreshing
-template <class S>
-__global__ void k_update_x_r(S* __restrict__ x, S* __restrict__ r, const S* __restrict__ pvec,
-                             const S* __restrict__ q, S* __restrict__ tmp, int n,
-                             const CgState* st) {
-  if (st->done) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const S a = S(st->alpha);
-  x[i] = x[i] + a * pvec[i];
-  if (st->refresh)
-    tmp[i] = S(0);
-  else
-    r[i] = r[i] - a * q[i];
-}
-
-// refresh: r = b - (tmp + lambda x)
-template <class S>
-__global__ void k_refresh_r(const S* __restrict__ bvec, const S* __restrict__ tmp,
-                            const S* __restrict__ x, S* __restrict__ r, S lambda, int n,
-                            const CgState* st) {
-  if (st->done || !st->refresh) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  r[i] = bvec[i] - (tmp[i] + lambda * x[i]);
-}
-
-// q1 = -x.(b + r)
-template <class S>
-__global__ __launch_bounds__(256) void k_q1(const S* __restrict__ x, const S* __restrict__ bvec,
-                                            const S* __restrict__ r, int n, CgState* st) {
-  if (st->done) return;
-  double acc = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-    acc -= double(x[i]) * double(bvec[i] + r[i]);
-  block_accumulate<S>(acc, &st->q1);
-}
-
-// scalar step C (1 thread): quadratic-model termination, iteration bookkeeping
-__global__ void k_cg_scalar_c(CgState* st, double q_tolerance, int min_it, int max_it) {
-  if (st->done) return;
+// shared tail: Q-model termination (conjugate_gradient.hpp:239-276) and bookkeeping
+__device__ __forceinline__ void pcg_finish_iteration(CgState* st, double q1, double q_tolerance,
+                                                     int min_it, int max_it) {
   st->iter += 1;
-  const double q1 = st->q1, q0 = st->q0;
-  const double zeta = st->iter * (q1 - q0) / q1;
+  const double zeta = st->iter * (q1 - st->q0) / q1;
   if (zeta < q_tolerance && st->iter >= min_it) {
     st->termination = 1;
     st->done = 1;
     return;
   }
   st->q0 = q1;
-  // residual-based termination is disabled (r_tolerance = -1, linearizor_base.cpp:91)
+  // residual-based termination is off (r_tolerance = -1, linearizor_base.cpp:91)
   if (st->iter >= max_it) {
     st->termination = 0;
     st->done = 1;
-    return;
   }
-  st->last_rho = st->rho;
-  st->rho = 0.0;
+}
+
+template <class S>
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_b(const S* __restrict__ bvec,
+                                                      S* __restrict__ x, S* __restrict__ r,
+                                                      const S* __restrict__ pvec, S* __restrict__ q,
+                                                      S* __restrict__ tmp, S lambda, int n,
+                                                      CgState* st, int residual_reset_period,
+                                                      double q_tolerance, int min_it, int max_it) {
+  __shared__ double sm[16];
+  __shared__ double s_alpha;
+  __shared__ int s_stop, s_refresh;
+  if (st->done) return;
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const S v = q[i] + lambda * pvec[i];  // pose damping term of right_multiply
+    q[i] = v;
+    acc += double(pvec[i]) * double(v);
+  }
+  const double pq = pcg_block_sum(acc, sm);
+  if (threadIdx.x == 0) {
+    int stop = 0;
+    double alpha = 0;
+    if (pq <= 0.0 || isinf(pq)) {
+      st->termination = 0;  // "Matrix is indefinite, no more progress can be made."
+      stop = 1;
+    } else {
+      alpha = st->rho / pq;
+      if (isinf(alpha)) {
+        st->termination = 2;
+        stop = 1;
+      }
+    }
+    st->pq = pq;
+    if (stop) {
+      st->done = 1;
+      st->iter += 1;
+    }
+    st->alpha = alpha;
+    const int refresh = ((st->iter + 1) % residual_reset_period) == 0 ? 1 : 0;
+    st->refresh = refresh;
+    s_alpha = alpha;
+    s_stop = stop;
+    s_refresh = refresh;
+  }
+  __syncthreads();
+  if (s_stop) return;
+  const S a = S(s_alpha);
+  if (s_refresh) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      x[i] = x[i] + a * pvec[i];
+      tmp[i] = S(0);
+    }
+    return;  // k_pcg_c finishes the iteration after H*x(x)
+  }
+  double acc1 = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const S xv = x[i] + a * pvec[i];
+    const S rv = r[i] - a * q[i];
+    x[i] = xv;
+    r[i] = rv;
+    acc1 -= double(xv) * double(bvec[i] + rv);
+  }
+  const double q1 = pcg_block_sum(acc1, sm);
+  if (threadIdx.x == 0) {
+    st->q1 = q1;
+    pcg_finish_iteration(st, q1, q_tolerance, min_it, max_it);
+  }
+}
+
+// residual refresh r = b - (H x) (conjugate_gradient.hpp:230-235), then the test
+template <class S>
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_c(const S* __restrict__ bvec,
+                                                      const S* __restrict__ x, S* __restrict__ r,
+                                                      const S* __restrict__ tmp, S lambda, int n,
+                                                      CgState* st, double q_tolerance, int min_it,
+                                                      int max_it) {
+  __shared__ double sm[16];
+  if (st->done || !st->refresh) return;
+  double acc1 = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const S rv = bvec[i] - (tmp[i] + lambda * x[i]);
+    r[i] = rv;
+    acc1 -= double(x[i]) * double(bvec[i] + rv);
+  }
+  const double q1 = pcg_block_sum(acc1, sm);
+  if (threadIdx.x == 0) {
+    st->q1 = q1;
+    st->refresh = 0;
+    pcg_finish_iteration(st, q1, q_tolerance, min_it, max_it);
+  }
 }
 
 // blocks[c](d,d) -= excess  (multi-GPU: lambda*I was added once per rank)

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <limits>
@@ -228,6 +229,35 @@ class Solver final : public rba_solver {
       cls_end_[c] = end;
       begin = end;
     }
+
+    // batches of same-k small landmarks for the LDS-staged H*x (k <= 7)
+    std::vector<rba::SmallBatch> batches;
+    small_lds_bytes_ = 0;
+    {
+      int s = cls_begin_[0];
+      while (s < cls_end_[0]) {
+        const int k = lm_k[s];
+        int e = s;
+        while (e < cls_end_[0] && lm_k[e] == k) ++e;
+        const int blk_elems = (2 * k * 9 * k + 3) / 4 * 4;
+        const int g_rows = 256 / (2 * k);
+        size_t budget = kSmallLdsBudget;
+        if (const char* ev = std::getenv("RBA_SMALL_LDS_KB")) budget = std::min<size_t>(kSmallLdsBudget, size_t(std::atoi(ev)) * 1024);
+        const int g_lds = int(budget / (size_t(blk_elems) * sizeof(S)));
+        const int gmax = std::max(1, std::min(g_rows, g_lds));
+        for (int b0 = s; b0 < e; b0 += gmax) {
+          const int G = std::min(gmax, e - b0);
+          batches.push_back(rba::SmallBatch{b0, G, k, 0, lm_blk[b0], lm_obs[b0]});
+          const size_t lds = size_t(G) * blk_elems * sizeof(S) + size_t(G) * 9 * k * sizeof(S) +
+                             256 * sizeof(S) + size_t(G) * 9 * k * sizeof(int);
+          small_lds_bytes_ = std::max(small_lds_bytes_, lds);
+        }
+        s = e;
+      }
+    }
+    n_small_batches_ = int(batches.size());
+    d_batches_.alloc(batches.size());
+    if (!batches.empty()) d_batches_.upload(batches.data(), batches.size(), stream_);
 
     // ---- device memory ------------------------------------------------------
     d_lm_k_.alloc(n_lms);
@@ -477,7 +507,7 @@ class Solver final : public rba_solver {
   }
 
   // y += sum_l A_l^T A_l x_l over the local landmarks (no pose damping term)
-  void launch_hx(const S* x, S* y) {
+  void launch_hx(const S* x, S* y, const int* done_flag = nullptr) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hx_event_count_ < kMaxHxEvents) {
       e0 = hx_events_[2 * hx_event_count_];
@@ -485,11 +515,15 @@ class Solver final : public rba_solver {
       ++hx_event_count_;
       HIP_CHECK(hipEventRecord(e0, stream_));
     }
+    if (n_small_batches_ > 0)
+      hipLaunchKernelGGL((rba::k_hx_small<S>), dim3(n_small_batches_), dim3(256), small_lds_bytes_,
+                         stream_, prm_, d_batches_.get(), x, y, done_flag);
     for_each_class([&](auto ch_tag, int begin, int end) {
       constexpr int CH = decltype(ch_tag)::value;
       constexpr int U = CH <= 2 ? 4 : 2;
+      if (CH == 1) return;  // k <= 7 is handled by the LDS-staged kernel
       hipLaunchKernelGGL((rba::k_hx<S, CH, U>), dim3((end - begin + 3) / 4), dim3(256), 0,
-                         stream_, prm_, begin, end, x, y);
+                         stream_, prm_, begin, end, x, y, done_flag);
     });
     if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
     ++hx_calls_;
@@ -528,14 +562,17 @@ class Solver final : public rba_solver {
                        d_x_.get(), nvec_);
     d_x_.download(static_cast<S*>(inc_out), nvec_, stream_);
     timings_.solve_reduced_system_time = time_end();
+    // H*x launches that did real work: one per PCG iteration plus the residual
+    // refreshes; launches queued after termination are no-ops and are excluded
+    const int real_hx = std::min(hx_event_count_, cg.num_iterations + cg.num_iterations / 10);
     double hx_ms = 0;
-    for (int i = 0; i < hx_event_count_; ++i) {
+    for (int i = 0; i < real_hx; ++i) {
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, hx_events_[2 * i], hx_events_[2 * i + 1]));
       hx_ms += ms;
     }
-    timings_.hx_time = hx_event_count_ ? hx_ms * 1e-3 * hx_calls_ / hx_event_count_ : 0.0;
-    timings_.hx_calls = hx_calls_;
+    timings_.hx_time = hx_ms * 1e-3;
+    timings_.hx_calls = real_hx;
     if (cg_out) *cg_out = cg;
     return RBA_OK;
   }
@@ -543,50 +580,37 @@ class Solver final : public rba_solver {
   rba_cg_summary pcg(S lambda) {
     rba_cg_summary summary{0, 0};
     const int n = nvec_;
-    const int vb = (n + 255) / 256;
-    const int rb = std::min(vb, 64);
     rba::CgState* st = d_cg_.get();
+    const int* done = &st->done;
     const S* b = prm_.b;
-    // x = 0, r = b - H*0 = b
-    HIP_CHECK(hipMemsetAsync(st, 0, sizeof(rba::CgState), stream_));
-    d_x_.zero(stream_);
-    HIP_CHECK(hipMemcpyAsync(d_r_.get(), b, n * sizeof(S), hipMemcpyDeviceToDevice, stream_));
-    hipLaunchKernelGGL((rba::k_dot<S>), dim3(rb), dim3(256), 0, stream_, b, b, n, &st->norm_b2);
+    constexpr int T = rba::kPcgThreads;
+    const int max_it = opt_.max_cg_it, min_it = opt_.min_cg_it;
+    const double eta = opt_.eta;
     rba::CgState* hst = reinterpret_cast<rba::CgState*>(h_pinned_);
-    HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
-    sync();
-    if (hst->norm_b2 == 0.0) {
-      summary.termination_type = 1;
-      return summary;
-    }
-    const int max_it = opt_.max_cg_it;
+    hipLaunchKernelGGL((rba::k_pcg_init<S>), dim3(1), dim3(T), 0, stream_, b, d_x_.get(),
+                       d_r_.get(), n, st);
+    // The host polls the device state lazily: every iteration at first (many
+    // solves need 2-3 iterations), every 4th later; kernels queued past the end
+    // are no-ops (`done`).
     for (int it = 1; it <= max_it; ++it) {
-      hipLaunchKernelGGL((rba::k_precond_rho<S>), dim3(rb), dim3(256), 0, stream_, d_inv_.get(),
-                         d_r_.get(), d_z_.get(), n, st);
-      hipLaunchKernelGGL((rba::k_cg_scalar_a), dim3(1), dim3(1), 0, stream_, st);
-      hipLaunchKernelGGL((rba::k_update_p<S>), dim3(vb), dim3(256), 0, stream_, d_z_.get(),
-                         d_p_.get(), d_q_.get(), n, st);
-      launch_hx(d_p_.get(), d_q_.get());
+      hipLaunchKernelGGL((rba::k_pcg_a<S>), dim3(1), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(),
+                         d_z_.get(), d_p_.get(), d_q_.get(), n, st);
+      launch_hx(d_p_.get(), d_q_.get(), done);
       all_reduce(d_q_.get(), n);
-      hipLaunchKernelGGL((rba::k_damp_pq<S>), dim3(rb), dim3(256), 0, stream_, d_p_.get(),
-                         d_q_.get(), lambda, n, st);
-      hipLaunchKernelGGL((rba::k_cg_scalar_b), dim3(1), dim3(1), 0, stream_, st, 10);
-      hipLaunchKernelGGL((rba::k_update_x_r<S>), dim3(vb), dim3(256), 0, stream_, d_x_.get(),
-                         d_r_.get(), d_p_.get(), d_q_.get(), d_tmp_.get(), n, st);
+      hipLaunchKernelGGL((rba::k_pcg_b<S>), dim3(1), dim3(T), 0, stream_, b, d_x_.get(), d_r_.get(),
+                         d_p_.get(), d_q_.get(), d_tmp_.get(), lambda, n, st, 10, eta, min_it,
+                         max_it);
       if (it % 10 == 0) {
-        // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
-        launch_hx(d_x_.get(), d_tmp_.get());
+        launch_hx(d_x_.get(), d_tmp_.get(), done);
         all_reduce(d_tmp_.get(), n);
-        hipLaunchKernelGGL((rba::k_refresh_r<S>), dim3(vb), dim3(256), 0, stream_, b,
-                           d_tmp_.get(), d_x_.get(), d_r_.get(), lambda, n, st);
+        hipLaunchKernelGGL((rba::k_pcg_c<S>), dim3(1), dim3(T), 0, stream_, b, d_x_.get(),
+                           d_r_.get(), d_tmp_.get(), lambda, n, st, eta, min_it, max_it);
       }
-      hipLaunchKernelGGL((rba::k_q1<S>), dim3(rb), dim3(256), 0, stream_, d_x_.get(), b,
-                         d_r_.get(), n, st);
-      hipLaunchKernelGGL((rba::k_cg_scalar_c), dim3(1), dim3(1), 0, stream_, st, opt_.eta,
-                         opt_.min_cg_it, max_it);
-      HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
-      sync();
-      if (hst->done) break;
+      if (it <= 8 || it % 4 == 0 || it == max_it) {
+        HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
+        sync();
+        if (hst->done) break;
+      }
     }
     summary.termination_type = hst->termination;
     summary.num_iterations = hst->iter;
@@ -856,6 +880,7 @@ class Solver final : public rba_solver {
 
  private:
   static constexpr int kReduceBlocks = 1024;
+  static constexpr size_t kSmallLdsBudget = 16 * 1024;  // bytes of A per small-landmark batch
   static constexpr int kMaxHxEvents = 1024;
 
   void use_device() { HIP_CHECK(hipSetDevice(device_)); }
@@ -903,6 +928,9 @@ class Solver final : public rba_solver {
   DevBuf<S> d_x_, d_r_, d_p_, d_z_, d_q_, d_tmp_, d_inc_, d_vin_;
   DevBuf<double> d_lm_ldiff_, d_partials_;
   DevBuf<rba::CgState> d_cg_;
+  DevBuf<rba::SmallBatch> d_batches_;
+  int n_small_batches_ = 0;
+  size_t small_lds_bytes_ = 0;
   char* h_pinned_ = nullptr;
   hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
   std::vector<hipEvent_t> hx_events_;
