@@ -731,98 +731,127 @@ __global__ __launch_bounds__(256) void k_hx(Params<S> p, int lm_begin, int lm_en
 // A is read from HBM exactly once; no cross-lane reductions at all.
 // ===========================================================================
 struct SmallBatch {
-  int s0;       // first (sorted) landmark
-  int G;        // landmarks in the batch, G * 2k <= 256
+  int s0;       // first (sorted) landmark of the super-batch
+  int G;        // landmarks per LDS batch, G * 2k <= 256
   int K;        // observations per landmark (2..7)
-  int pad;
-  int64_t blk;  // = lm_blk[s0]: offset of the batch's first block in A
-  int64_t obs;  // = lm_obs[s0]: first observation of the batch
+  int count;    // landmarks in the super-batch (processed G at a time)
+  int64_t blk;  // = lm_blk[s0]: offset of the first block in A
+  int64_t obs;  // = lm_obs[s0]: first observation
 };
 
+// One workgroup walks a super-batch G landmarks at a time. The global loads of
+// batch b+1 (A through registers, camera indices, x) are in flight while batch b
+// is being reduced out of LDS, so the workgroup keeps ~16 KB outstanding all the
+// time instead of only during its prologue.
 template <class S, int K>
 __device__ __forceinline__ void hx_small_body(const Params<S>& p, const SmallBatch d,
                                               const S* __restrict__ x, S* __restrict__ y,
                                               char* smem) {
   constexpr int NC = 9 * K, NR = 2 * K, BLK = (NR * NC + 3) / 4 * 4;
+  constexpr int NLD = 4;  // host caps a batch at NLD x 256 x 16 B of A
+  constexpr int NG = 5;   // G * NC <= 64 * 18 = 1152 < NG * 256
   const int tid = threadIdx.x;
   const int G = d.G;
   S* Al = reinterpret_cast<S*>(smem);
   S* xs = Al + G * BLK;
   S* ts = xs + G * NC;
   int* yidx = reinterpret_cast<int*>(ts + 256);
-  // 1. global -> LDS, 16 B per lane, fully coalesced
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(p.A + d.blk);
-    uint4* dst = reinterpret_cast<uint4*>(Al);
-    const int n16 = G * BLK * int(sizeof(S)) / 16;
-    // all loads are issued before the first LDS store (<= 8 x 16 B in flight per lane)
-    // (the host caps a batch at kSmallLdsBudget = NLD x 256 x 16 B)
-    constexpr int NLD = 4;
-    uint4 buf[NLD];
+  const int nb = (d.count + G - 1) / G;
+
+  uint4 buf[NLD];
+  int idx[NG];
+  S xv[NG];
+
+  auto issue_idx_and_A = [&](int b) {
+    const int gb = min(G, d.count - b * G);
+    const int64_t o0 = d.obs + int64_t(b) * G * K;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int e = u * 256 + tid;
+      idx[u] = 0;
+      if (e < gb * NC) {
+        const int g = e / NC, j = e - NC * g;
+        const int i = j / 9;
+        idx[u] = p.obs_cam[o0 + g * K + i];
+      }
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(p.A + d.blk + int64_t(b) * G * BLK);
+    const int n16 = gb * BLK * int(sizeof(S)) / 16;
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int q = u * 256 + tid;
       buf[u] = (q < n16) ? src[q] : uint4{0, 0, 0, 0};
     }
+  };
+  auto issue_x = [&](int b) {
+    const int gb = min(G, d.count - b * G);
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int e = u * 256 + tid;
+      const int j = e % NC;
+      idx[u] = 9 * idx[u] + (j % 9);
+      xv[u] = (e < gb * NC) ? x[idx[u]] : S(0);
+    }
+  };
+  auto store_lds = [&](int b) {
+    const int gb = min(G, d.count - b * G);
+    uint4* dst = reinterpret_cast<uint4*>(Al);
+    const int n16 = gb * BLK * int(sizeof(S)) / 16;
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int q = u * 256 + tid;
       if (q < n16) dst[q] = buf[u];
     }
-  }
-  // 2. gather x, remember the scatter index
-  const int64_t o0 = d.obs;
-  {
-    constexpr int NG = 5;  // G * NC <= 64 * 18 = 1152 < 5 * 256
-    int idx[NG];
-    S xv[NG];
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
       const int e = u * 256 + tid;
-      idx[u] = 0;
-      if (e < G * NC) {
-        const int g = e / NC, j = e - NC * g;
-        const int i = j / 9, comp = j - 9 * i;
-        idx[u] = 9 * p.obs_cam[o0 + g * K + i] + comp;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NG; ++u) xv[u] = (u * 256 + tid < G * NC) ? x[idx[u]] : S(0);
-#pragma unroll
-    for (int u = 0; u < NG; ++u) {
-      const int e = u * 256 + tid;
-      if (e < G * NC) {
+      if (e < gb * NC) {
         yidx[e] = idx[u];
         xs[e] = xv[u];
       }
     }
-  }
-  __syncthreads();
-  // 3. rows: t = A x  (column order rotated per thread when 9k is even so that
-  //    the 9k-strided rows do not collide on LDS banks)
-  if (tid < G * NR) {
-    const int g = tid / NR, i = tid - NR * g;
-    const S* row = Al + g * BLK + i * NC;
-    const S* xv = xs + g * NC;
-    int c = (K % 2 == 0) ? tid % NC : 0;
-    S acc = S(0);
+  };
+
+  issue_idx_and_A(0);
+  issue_x(0);
+  for (int b = 0; b < nb; ++b) {
+    const int gb = min(G, d.count - b * G);
+    store_lds(b);
+    __syncthreads();
+    const bool more = b + 1 < nb;
+    if (more) issue_idx_and_A(b + 1);  // stays in flight during the two phases below
+    // rows: t = A x  (column order rotated per thread when 9k is even so that
+    // the 9k-strided rows do not collide on LDS banks)
+    if (tid < gb * NR) {
+      const int g = tid / NR, i = tid - NR * g;
+      const S* row = Al + g * BLK + i * NC;
+      const S* xr = xs + g * NC;
+      int c = (K % 2 == 0) ? tid % NC : 0;
+      S acc = S(0);
 #pragma unroll 9
-    for (int jj = 0; jj < NC; ++jj) {
-      acc += row[c] * xv[c];
-      c = (c + 1 == NC) ? 0 : c + 1;
+      for (int jj = 0; jj < NC; ++jj) {
+        acc += row[c] * xr[c];
+        c = (c + 1 == NC) ? 0 : c + 1;
+      }
+      ts[tid] = acc;
     }
-    ts[tid] = acc;
-  }
-  __syncthreads();
-  // 4. columns: y = A^T t, scatter
-  for (int e = tid; e < G * NC; e += 256) {
-    const int g = e / NC, j = e - NC * g;
-    const S* col = Al + g * BLK + j;
-    const S* tv = ts + g * NR;
-    S acc = S(0);
+    __syncthreads();
+    if (more) issue_x(b + 1);  // camera indices have arrived; A may still be in flight
+    // columns: y = A^T t, scatter
+    for (int e = tid; e < gb * NC; e += 256) {
+      const int g = e / NC, j = e - NC * g;
+      const S* col = Al + g * BLK + j;
+      const S* tv = ts + g * NR;
+      S acc = S(0);
 #pragma unroll
-    for (int i = 0; i < NR; ++i) acc += col[i * NC] * tv[i];
-    atomic_add(y + yidx[e], acc);
+      for (int i = 0; i < NR; ++i) acc += col[i * NC] * tv[i];
+#ifdef RBA_EXPERIMENT_NO_ATOMIC
+      y[yidx[e]] = acc;
+#else
+      atomic_add(y + yidx[e], acc);
+#endif
+    }
+    __syncthreads();
   }
 }
 

@@ -154,6 +154,9 @@ class Solver final : public rba_solver {
       : device_(device), n_cams_(n_cams), n_lms_(n_lms), opt_(opt) {
     HIP_CHECK(hipSetDevice(device_));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     n_obs_ = lm_off[n_lms];
     nvec_ = 9 * n_cams_;
 
@@ -245,9 +248,15 @@ class Solver final : public rba_solver {
         if (const char* ev = std::getenv("RBA_SMALL_LDS_KB")) budget = std::min<size_t>(kSmallLdsBudget, size_t(std::atoi(ev)) * 1024);
         const int g_lds = int(budget / (size_t(blk_elems) * sizeof(S)));
         const int gmax = std::max(1, std::min(g_rows, g_lds));
-        for (int b0 = s; b0 < e; b0 += gmax) {
-          const int G = std::min(gmax, e - b0);
-          batches.push_back(rba::SmallBatch{b0, G, k, 0, lm_blk[b0], lm_obs[b0]});
+        int nbatch = kSmallBatchesPerBlock;
+        if (const char* ev = std::getenv("RBA_SMALL_NB")) nbatch = std::max(1, std::atoi(ev));
+        const int span = gmax * nbatch;
+        const char* only_k = std::getenv("RBA_EXPERIMENT_ONLY_K");  // timing experiments only
+        for (int b0 = s; b0 < e; b0 += span) {
+          if (only_k && std::atoi(only_k) != k) break;
+          const int count = std::min(span, e - b0);
+          const int G = std::min(gmax, count);
+          batches.push_back(rba::SmallBatch{b0, G, k, count, lm_blk[b0], lm_obs[b0]});
           const size_t lds = size_t(G) * blk_elems * sizeof(S) + size_t(G) * 9 * k * sizeof(S) +
                              256 * sizeof(S) + size_t(G) * 9 * k * sizeof(int);
           small_lds_bytes_ = std::max(small_lds_bytes_, lds);
@@ -358,11 +367,15 @@ class Solver final : public rba_solver {
   ~Solver() override {
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
+    (void)hipStreamSynchronize(stream2_);
     if (comm_ && g_rccl.CommDestroy) g_rccl.CommDestroy(comm_);
     for (auto& e : hx_events_) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ev_a_);
     (void)hipEventDestroy(ev_b_);
     if (h_pinned_) (void)hipHostFree(h_pinned_);
+    (void)hipEventDestroy(ev_fork_);
+    (void)hipEventDestroy(ev_join_);
+    (void)hipStreamDestroy(stream2_);
     (void)hipStreamDestroy(stream_);
   }
 
@@ -515,9 +528,16 @@ class Solver final : public rba_solver {
       ++hx_event_count_;
       HIP_CHECK(hipEventRecord(e0, stream_));
     }
-    if (n_small_batches_ > 0)
+    // The LDS-staged small-landmark kernel (latency bound) and the register-streaming
+    // kernels of the larger classes run concurrently on two streams; both scatter-add
+    // into y with atomics, so there is no ordering between them.
+    if (n_small_batches_ > 0) {
+      HIP_CHECK(hipEventRecord(ev_fork_, stream_));
+      HIP_CHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
       hipLaunchKernelGGL((rba::k_hx_small<S>), dim3(n_small_batches_), dim3(256), small_lds_bytes_,
-                         stream_, prm_, d_batches_.get(), x, y, done_flag);
+                         stream2_, prm_, d_batches_.get(), x, y, done_flag);
+      HIP_CHECK(hipEventRecord(ev_join_, stream2_));
+    }
     for_each_class([&](auto ch_tag, int begin, int end) {
       constexpr int CH = decltype(ch_tag)::value;
       constexpr int U = CH <= 2 ? 4 : 2;
@@ -525,6 +545,7 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_hx<S, CH, U>), dim3((end - begin + 3) / 4), dim3(256), 0,
                          stream_, prm_, begin, end, x, y, done_flag);
     });
+    if (n_small_batches_ > 0) HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
     if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
     ++hx_calls_;
   }
@@ -880,7 +901,8 @@ class Solver final : public rba_solver {
 
  private:
   static constexpr int kReduceBlocks = 1024;
-  static constexpr size_t kSmallLdsBudget = 16 * 1024;  // bytes of A per small-landmark batch
+  static constexpr size_t kSmallLdsBudget = 16 * 1024;
+  static constexpr int kSmallBatchesPerBlock = 8;  // LDS batches walked by one workgroup  // bytes of A per small-landmark batch
   static constexpr int kMaxHxEvents = 1024;
 
   void use_device() { HIP_CHECK(hipSetDevice(device_)); }
@@ -909,7 +931,8 @@ class Solver final : public rba_solver {
   int64_t n_obs_ = 0;
   int nvec_ = 0;
   rba_options opt_;
-  hipStream_t stream_ = nullptr;
+  hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   std::vector<int> perm_;
   int cls_begin_[kNumClasses], cls_end_[kNumClasses];
   int64_t hx_bytes_ = 0, hx_flops_ = 0, storage_bytes_ = 0;
