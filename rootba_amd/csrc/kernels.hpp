@@ -198,8 +198,9 @@ __global__ __launch_bounds__(256) void k_cam_jp_diag2(Params<S> p) {
 // Threads 0..242: 3 observation groups x 81 block entries; 243..251: b.
 template <class S>
 __global__ __launch_bounds__(256) void k_cam_stage1(Params<S> p) {
-  constexpr int TILE = 48;
-  __shared__ S rec[TILE][54];  // [JpS 18 | top0 27 | bmO 9]
+  constexpr int TILE = 64, W = 54, NLD = (TILE * W + 255) / 256;
+  __shared__ S rec[TILE][W];  // [JpS 18 | top0 27 | bmO 9]
+  __shared__ int olist[TILE];
   __shared__ double red[3][81];
   const int c = blockIdx.x;
   const int tid = threadIdx.x;
@@ -209,26 +210,33 @@ __global__ __launch_bounds__(256) void k_cam_stage1(Params<S> p) {
   for (int64_t base = t0; base < t1; base += TILE) {
     const int n = int(min<int64_t>(TILE, t1 - base));
     __syncthreads();
-    for (int idx = tid; idx < n * 54; idx += 256) {
-      const int q = idx / 54, f = idx - 54 * q;
-      const int64_t o = p.cam_obs[base + q];
-      S v;
-      if (f < 18)
-        v = p.JpS[o * 18 + f];
-      else if (f < 45)
-        v = p.top0[o * 27 + (f - 18)];
-      else
-        v = p.bmO[o * 9 + (f - 45)];
-      rec[q][f] = v;
+    if (tid < n) olist[tid] = p.cam_obs[base + tid];
+    __syncthreads();
+    // all record loads of the tile are issued before the first LDS store
+    S v[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = u * 256 + tid;
+      v[u] = S(0);
+      if (idx < n * W) {
+        const int q = idx / W, f = idx - W * q;
+        const int64_t o = olist[q];
+        v[u] = f < 18 ? p.JpS[o * 18 + f] : (f < 45 ? p.top0[o * 27 + (f - 18)] : p.bmO[o * 9 + (f - 45)]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = u * 256 + tid;
+      if (idx < n * W) rec[idx / W][idx % W] = v[u];
     }
     __syncthreads();
     if (grp < 3) {
       for (int q = grp; q < n; q += 3) {
         const S* r = rec[q];
-        S v = r[ea] * r[eb] + r[9 + ea] * r[9 + eb];
+        S t = r[ea] * r[eb] + r[9 + ea] * r[9 + eb];
         if (!p.jacobi)
-          v -= r[18 + ea] * r[18 + eb] + r[27 + ea] * r[27 + eb] + r[36 + ea] * r[36 + eb];
-        acc += double(v);
+          t -= r[18 + ea] * r[18 + eb] + r[27 + ea] * r[27 + eb] + r[36 + ea] * r[36 + eb];
+        acc += double(t);
       }
     } else if (tid < 252) {
       const int a = tid - 243;
@@ -249,8 +257,9 @@ __global__ __launch_bounds__(256) void k_cam_stage1(Params<S> p) {
 //  linearizor_qr.cpp:227-232)
 template <class S>
 __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
-  constexpr int TILE = 64;
-  __shared__ S rec[TILE][30];  // [dampO 27 | damp_r 3]
+  constexpr int TILE = 64, W = 30, NLD = (TILE * W + 255) / 256;
+  __shared__ S rec[TILE][W];  // [dampO 27 | damp_r 3]
+  __shared__ int olist[TILE], llist[TILE];
   __shared__ double red[3][81];
   const int c = blockIdx.x;
   const int tid = threadIdx.x;
@@ -261,10 +270,26 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
     for (int64_t base = t0; base < t1; base += TILE) {
       const int n = int(min<int64_t>(TILE, t1 - base));
       __syncthreads();
-      for (int idx = tid; idx < n * 30; idx += 256) {
-        const int q = idx / 30, f = idx - 30 * q;
-        const int64_t o = p.cam_obs[base + q];
-        rec[q][f] = f < 27 ? p.dampO[o * 27 + f] : p.damp_r[3 * int64_t(p.obs_lm[o]) + (f - 27)];
+      if (tid < n) {
+        const int o = p.cam_obs[base + tid];
+        olist[tid] = o;
+        llist[tid] = p.obs_lm[o];
+      }
+      __syncthreads();
+      S v[NLD];
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int idx = u * 256 + tid;
+        v[u] = S(0);
+        if (idx < n * W) {
+          const int q = idx / W, f = idx - W * q;
+          v[u] = f < 27 ? p.dampO[int64_t(olist[q]) * 27 + f] : p.damp_r[3 * int64_t(llist[q]) + (f - 27)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int idx = u * 256 + tid;
+        if (idx < n * W) rec[idx / W][idx % W] = v[u];
       }
       __syncthreads();
       if (grp < 3) {
@@ -934,13 +959,34 @@ __global__ __launch_bounds__(256) void k_back_substitute(Params<S> p, int lm_beg
   S acc = S(0);
 #pragma unroll
   for (int m = 0; m < 3; ++m) acc += g0[m] * (S(0.5) * g0[m] + qtr[m]);
-  for (int r = 0; r < nrows - 3; ++r) {
-    S d = S(0);
+  {
+    constexpr int U = CH <= 2 ? 4 : 2;
+    const int nmid = nrows - 3;
+    int r = 0;
+    for (; r + U <= nmid; r += U) {
+      S a[U][CH];
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch)
-      if (act[ch]) d += Ablk[size_t(r) * ncols + ch * 63 + lane] * xr[ch];
-    const S g = wave_sum(d);
-    acc += g * (S(0.5) * g + qtr[3 + r]);
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch)
+          a[u][ch] = act[ch] ? Ablk[size_t(r + u) * ncols + ch * 63 + lane] : S(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        S d = S(0);
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) d += a[u][ch] * xr[ch];
+        const S g = wave_sum(d);
+        acc += g * (S(0.5) * g + qtr[3 + r + u]);
+      }
+    }
+    for (; r < nmid; ++r) {
+      S d = S(0);
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch)
+        if (act[ch]) d += Ablk[size_t(r) * ncols + ch * 63 + lane] * xr[ch];
+      const S g = wave_sum(d);
+      acc += g * (S(0.5) * g + qtr[3 + r]);
+    }
   }
   if (lane == 0) {
     p.lm_ldiff[s] = -double(acc);

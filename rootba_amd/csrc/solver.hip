@@ -538,7 +538,9 @@ class Solver final : public rba_solver {
                          stream2_, prm_, d_batches_.get(), x, y, done_flag);
       HIP_CHECK(hipEventRecord(ev_join_, stream2_));
     }
-    for_each_class([&](auto ch_tag, int begin, int end) {
+    // largest landmarks first: the low-parallelism tail classes then overlap with
+    // the bulk instead of running alone at the end
+    for_each_class_reverse([&](auto ch_tag, int begin, int end) {
       constexpr int CH = decltype(ch_tag)::value;
       constexpr int U = CH <= 2 ? 4 : 2;
       if (CH == 1) return;  // k <= 7 is handled by the LDS-staged kernel
@@ -924,6 +926,15 @@ class Solver final : public rba_solver {
     if (cls_end_[2] > cls_begin_[2]) f(std::integral_constant<int, 4>{}, cls_begin_[2], cls_end_[2]);
     if (cls_end_[3] > cls_begin_[3]) f(std::integral_constant<int, 8>{}, cls_begin_[3], cls_end_[3]);
     if (cls_end_[4] > cls_begin_[4]) f(std::integral_constant<int, 16>{}, cls_begin_[4], cls_end_[4]);
+  }
+
+  template <class F>
+  void for_each_class_reverse(F&& f) {
+    if (cls_end_[4] > cls_begin_[4]) f(std::integral_constant<int, 16>{}, cls_begin_[4], cls_end_[4]);
+    if (cls_end_[3] > cls_begin_[3]) f(std::integral_constant<int, 8>{}, cls_begin_[3], cls_end_[3]);
+    if (cls_end_[2] > cls_begin_[2]) f(std::integral_constant<int, 4>{}, cls_begin_[2], cls_end_[2]);
+    if (cls_end_[1] > cls_begin_[1]) f(std::integral_constant<int, 2>{}, cls_begin_[1], cls_end_[1]);
+    if (cls_end_[0] > cls_begin_[0]) f(std::integral_constant<int, 1>{}, cls_begin_[0], cls_end_[0]);
   }
 
   int device_;
