@@ -206,6 +206,10 @@ int rba_lm_termination(rba_handle h, int* termination_out);
 int rba_synchronize(rba_handle h);
 
 int rba_get_timings(rba_handle h, rba_iter_timings* out);
+/* Profiling aid: streams the landmark-block storage once with 4-byte
+ * (vec_width = 1) or 16-byte (vec_width = 4) loads and reports the bytes read —
+ * a known byte count for calibrating rocprofv3's FETCH_SIZE on gfx950. */
+int rba_debug_read_blocks(rba_handle h, int vec_width, int64_t* bytes_out);
 
 /* Introspection used by the parity tests (invariants of SURVEY.md §8c). */
 int rba_get_jl_col_scale(rba_handle h, void* out3_per_lm);

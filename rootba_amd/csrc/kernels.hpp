@@ -1339,6 +1339,25 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_c(const S* __restrict__ bve
   }
 }
 
+// PMC calibration: stream `n` floats once with dword (VEC = 1) or 16-byte
+// (VEC = 4) loads — a known byte count in this code's own access patterns, to
+// calibrate rocprofv3's FETCH_SIZE on gfx950 (MI355X_MICROARCH.md §HBM).
+template <int VEC>
+__global__ __launch_bounds__(256) void k_calib_read(const float* __restrict__ src, size_t n,
+                                                    float* __restrict__ sink) {
+  float acc = 0.f;
+  const size_t stride = size_t(gridDim.x) * 256 * VEC;
+  for (size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * VEC; i + VEC <= n; i += stride) {
+    if (VEC == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + i);
+      acc += v.x + v.y + v.z + v.w;
+    } else {
+      acc += src[i];
+    }
+  }
+  if (acc == 123.456f) sink[0] = acc;  // keep the loads alive
+}
+
 // blocks[c](d,d) -= excess  (multi-GPU: lambda*I was added once per rank)
 template <class S>
 __global__ void k_sub_diag(S* __restrict__ blocks, S excess, int n_cams) {

@@ -134,6 +134,7 @@ struct rba_solver {
   virtual int lm_step(rba_lm_iteration* out) = 0;
   virtual int lm_termination() const = 0;
   virtual void device_sync() = 0;
+  virtual int64_t debug_read_A(int vec) = 0;
   virtual void get_timings(rba_iter_timings* out) = 0;
   virtual void get_jl_col_scale(void* out) = 0;
   virtual void get_pose_scaling(void* out) = 0;
@@ -852,6 +853,19 @@ class Solver final : public rba_solver {
   }
 
   // ---- misc -----------------------------------------------------------------------------
+  // PMC calibration helper: stream the block storage once; returns bytes read
+  int64_t debug_read_A(int vec) override {
+    use_device();
+    const size_t n = d_A_.size() * sizeof(S) / sizeof(float);
+    const float* src = reinterpret_cast<const float*>(d_A_.get());
+    float* sink = reinterpret_cast<float*>(d_tmp_.get());
+    if (vec == 4)
+      hipLaunchKernelGGL((rba::k_calib_read<4>), dim3(8192), dim3(256), 0, stream_, src, n, sink);
+    else
+      hipLaunchKernelGGL((rba::k_calib_read<1>), dim3(8192), dim3(256), 0, stream_, src, n, sink);
+    sync();
+    return int64_t(n / (vec == 4 ? 4 : 1) * (vec == 4 ? 4 : 1)) * 4;
+  }
   void device_sync() override {
     use_device();
     sync();
@@ -1189,6 +1203,12 @@ int rba_lm_termination(rba_handle h, int* termination_out) {
 int rba_synchronize(rba_handle h) {
   return guarded([&]() -> int {
     h->device_sync();
+    return RBA_OK;
+  });
+}
+int rba_debug_read_blocks(rba_handle h, int vec_width, int64_t* bytes_out) {
+  return guarded([&]() -> int {
+    *bytes_out = h->debug_read_A(vec_width);
     return RBA_OK;
   });
 }
