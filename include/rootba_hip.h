@@ -149,6 +149,12 @@ int rba_destroy(rba_handle h);
  * the caller's launcher. */
 int rba_comm_unique_id(void* out128);
 int rba_comm_init(rba_handle h, int rank, int nranks, const void* unique_id128);
+/* Same sharding with a caller-provided collective instead of RCCL (MPI, gloo,
+ * a test harness ...): `fn` must all-reduce `count` elements of HOST memory in
+ * place across the ranks and return 0. dtype: 0 f32, 1 f64, 2 i32; op: 0 sum,
+ * 1 max. The library stages device <-> host around the call. */
+typedef int (*rba_allreduce_fn)(void* ctx, void* host_buf, int64_t count, int dtype, int op);
+int rba_comm_init_callback(rba_handle h, int rank, int nranks, rba_allreduce_fn fn, void* ctx);
 
 /* BalProblem state upload/download (Camera::params()/from_params(),
  * bal_problem.hpp:84-95; copy_to/from_camera_state, bal_problem.cpp:570-588). */

@@ -119,6 +119,7 @@ constexpr int kNcclInt32 = 2, kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0, 
 struct rba_solver {
   virtual ~rba_solver() = default;
   virtual void comm_init(int rank, int nranks, const void* uid) = 0;
+  virtual void comm_init_callback(int rank, int nranks, rba_allreduce_fn fn, void* ctx) = 0;
   virtual void set_state(const void* cams, const void* lms) = 0;
   virtual void get_state(void* cams, void* lms) = 0;
   virtual void backup() = 0;
@@ -393,9 +394,28 @@ class Solver final : public rba_solver {
     nranks_ = nranks;
   }
 
+  void comm_init_callback(int rank, int nranks, rba_allreduce_fn fn, void* ctx) override {
+    rank_ = rank;
+    nranks_ = nranks;
+    cb_fn_ = fn;
+    cb_ctx_ = ctx;
+  }
+
   template <class T>
   void all_reduce(T* buf, size_t count, int op = kNcclSum) {
     if (nranks_ <= 1) return;
+    if (cb_fn_) {
+      // caller-provided collective on a host staging buffer (MPI, gloo, ...)
+      cb_stage_.resize(count * sizeof(T));
+      HIP_CHECK(hipMemcpyAsync(cb_stage_.data(), buf, count * sizeof(T), hipMemcpyDeviceToHost, stream_));
+      sync();
+      const int dt = std::is_same<T, float>::value ? 0 : std::is_same<T, double>::value ? 1 : 2;
+      const int rc = cb_fn_(cb_ctx_, cb_stage_.data(), int64_t(count), dt, op == kNcclMax ? 1 : 0);
+      if (rc != 0) throw HipError{"all-reduce callback failed: " + std::to_string(rc), RBA_ERR_COMM};
+      HIP_CHECK(hipMemcpyAsync(buf, cb_stage_.data(), count * sizeof(T), hipMemcpyHostToDevice, stream_));
+      sync();
+      return;
+    }
     const int dt = std::is_same<T, float>::value    ? kNcclFloat32
                    : std::is_same<T, double>::value ? kNcclFloat64
                                                     : kNcclInt32;
@@ -996,6 +1016,9 @@ class Solver final : public rba_solver {
   // multi-GPU
   void* comm_ = nullptr;
   int rank_ = 0, nranks_ = 1;
+  rba_allreduce_fn cb_fn_ = nullptr;
+  void* cb_ctx_ = nullptr;
+  std::vector<char> cb_stage_;
 };
 
 template <class F>
@@ -1122,6 +1145,17 @@ int rba_comm_unique_id(void* out128) {
 int rba_comm_init(rba_handle h, int rank, int nranks, const void* uid) {
   return guarded([&]() -> int {
     h->comm_init(rank, nranks, uid);
+    return RBA_OK;
+  });
+}
+
+int rba_comm_init_callback(rba_handle h, int rank, int nranks, rba_allreduce_fn fn, void* ctx) {
+  return guarded([&]() -> int {
+    if (nranks > 1 && !fn) {
+      g_last_error = "rba_comm_init_callback: null callback";
+      return RBA_ERR_INVALID_ARGUMENT;
+    }
+    h->comm_init_callback(rank, nranks, fn, ctx);
     return RBA_OK;
   });
 }

@@ -84,6 +84,25 @@ class LinearizorHIP:
         L.check(self.lib.rba_comm_init(self.h, C.c_int(rank), C.c_int(nranks),
                                        C.c_char_p(unique_id)), "rba_comm_init")
 
+    def comm_init_callback(self, rank: int, nranks: int, allreduce):
+        """`allreduce(array, op)` all-reduces a numpy array in place (op: 'sum' | 'max')."""
+        np_dt = {0: np.float32, 1: np.float64, 2: np.int32}
+
+        def _cb(_ctx, buf, count, dtype, op):
+            try:
+                dt = np.dtype(np_dt[dtype])
+                arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_char)), shape=(count * dt.itemsize,)).view(dt)
+                allreduce(arr, "max" if op == 1 else "sum")
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._allreduce_cb = L.ALLREDUCE_FN(_cb)  # keep alive
+        L.check(self.lib.rba_comm_init_callback(self.h, C.c_int(rank), C.c_int(nranks), self._allreduce_cb,
+                                                None), "rba_comm_init_callback")
+
     # -- BalProblem state -----------------------------------------------------------
     def set_state(self, cams, lms):
         c, l = self._in(cams, 10 * self.n_cams), self._in(lms, 3 * self.n_lms)

@@ -1,0 +1,97 @@
+"""Landmark sharding of the HIP solver itself, two ranks sharing ONE GPU.
+
+RCCL refuses two ranks on one device, so the ranks all-reduce through the
+library's callback transport (`rba_comm_init_callback`, here backed by gloo).
+Everything else is the production multi-GPU path: per-rank landmark shards, the
+all-reduce points of SURVEY.md §8e inside the library, the lambda*I bookkeeping,
+the lazily polled PCG state that must stay identical on all ranks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, dtype_name, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bench import shard_ranges, take_landmarks
+    from rootba_amd import _lib as L
+    from rootba_amd import problem as P
+    from rootba_amd.linearizor import LinearizorHIP
+    dtype = np.dtype(dtype_name)
+    prob = P.preprocess(P.named_synthetic("ladybug-49"), translation_sigma=0.5, point_sigma=0.5)
+    lo, hi = shard_ranges(prob.obs_per_lm(), world)[rank]
+    g = LinearizorHIP(take_landmarks(prob, lo, hi), dtype,
+                      L.default_options(robust_norm=1, max_num_iterations=6), device=0)
+
+    def allreduce(arr, op):
+        t = torch.from_numpy(arr)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+
+    g.comm_init_callback(rank, world, allreduce)
+    err = g.compute_error()
+    assert g.linearize() == 0
+    b, blocks = g.stage2(0.1)
+    x = np.random.default_rng(0).uniform(-1, 1, 9 * prob.n_cams).astype(dtype)
+    hx = g.right_multiply(x)
+    inc, cg = g.solve(1e-4)
+    l_diff = g.apply(inc)
+    cams, _ = g.get_state()
+    g2 = LinearizorHIP(take_landmarks(prob, lo, hi), dtype,
+                       L.default_options(robust_norm=1, max_num_iterations=6), device=0)
+    g2.comm_init_callback(rank, world, allreduce)
+    log, term = g2.optimize_lm()
+    ret[rank] = dict(err=(err.all_error, err.all_num_obs), b=b, blocks=blocks, hx=hx, inc=inc,
+                     cg=cg.num_iterations, l_diff=l_diff, cams=cams,
+                     lm=[(r.cost, r.cg_iterations, r.step_is_successful) for r in log], term=term)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_two_ranks_one_gpu_match_unsharded(dtype):
+    import torch  # noqa: F401
+    import torch.multiprocessing as mp
+    from conftest import rel_err
+    from rootba_amd import _lib as L
+    from rootba_amd import problem as P
+    from rootba_amd.linearizor import LinearizorHIP
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29600 + os.getpid() % 2000, np.dtype(dtype).name, ret), nprocs=world,
+             join=True)
+    r0, r1 = ret[0], ret[1]
+    # replicated quantities are bit-identical on both ranks
+    for key in ("b", "blocks", "hx", "inc", "cams"):
+        assert np.array_equal(r0[key], r1[key]), key
+    assert r0["cg"] == r1["cg"] and r0["lm"] == r1["lm"] and r0["term"] == r1["term"]
+
+    prob = P.preprocess(P.named_synthetic("ladybug-49"), translation_sigma=0.5, point_sigma=0.5)
+    g = LinearizorHIP(prob, dtype, L.default_options(robust_norm=1, max_num_iterations=6))
+    tol = 1e-5 if dtype == np.float32 else 1e-12
+    err = g.compute_error()
+    assert r0["err"][1] == err.all_num_obs and abs(r0["err"][0] - err.all_error) < tol * err.all_error
+    assert g.linearize() == 0
+    b, blocks = g.stage2(0.1)
+    assert rel_err(r0["b"], b) < tol and rel_err(r0["blocks"], blocks) < tol
+    x = np.random.default_rng(0).uniform(-1, 1, 9 * prob.n_cams).astype(dtype)
+    assert rel_err(r0["hx"], g.right_multiply(x)) < tol
+    inc, cg = g.solve(1e-4)
+    assert abs(cg.num_iterations - r0["cg"]) <= (1 if dtype == np.float32 else 0)
+    assert rel_err(r0["inc"], inc) < (1e-3 if dtype == np.float32 else 1e-9)
+    g3 = LinearizorHIP(prob, dtype, L.default_options(robust_norm=1, max_num_iterations=6))
+    log, term = g3.optimize_lm()
+    assert len(log) == len(r0["lm"])
+    for a, (cost, cgi, ok) in zip(log, r0["lm"]):
+        assert a.step_is_successful == ok
+        assert abs(a.cost - cost) <= (1e-5 if dtype == np.float32 else 1e-9) * cost
