@@ -22,13 +22,32 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+APP = os.path.join(HERE, "bal_qr_hip")
+HOST_DEPS = [os.path.join("host", f) for f in ("bal_qr_hip.cpp", "linearizor_hip.hpp", "bal_problem.hpp")]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         cmd = [HIPCC, *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB, "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_app(force, verbose)
     return LIB
+
+
+def build_app(force: bool = False, verbose: bool = False) -> str:
+    """The C++17 host layer + `bal_qr_hip` CLI (plain g++, links the C ABI only)."""
+    stale = (not os.path.exists(APP) or any(
+        os.path.getmtime(os.path.join(CSRC, d)) > os.path.getmtime(APP) for d in HOST_DEPS)
+        or os.path.getmtime(LIB) > os.path.getmtime(APP))
+    if force or stale:
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", os.path.join(CSRC, "host", "bal_qr_hip.cpp"),
+               "-o", APP, "-L" + HERE, "-lrootba_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return APP
 
 
 if __name__ == "__main__":

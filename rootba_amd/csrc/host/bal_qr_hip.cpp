@@ -1,0 +1,147 @@
+// bal_qr_hip — command-line entry mirroring the reference's `bal_qr`
+// (reference src/app/bal_qr.cpp:44-115): load a BAL problem, run the square-root
+// solver (here: the MI355X-native library behind include/rootba_hip.h), write
+// ba_log.json. Flags keep the reference's names (docs/Configuration.md:45-259),
+// restricted to the ones that reach the hot path; the TOML/clipp machinery of
+// the reference is out of scope.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "linearizor_hip.hpp"
+
+using namespace rootba_hip;
+
+namespace {
+void usage() {
+  std::puts(
+      "Solve BAL problem with the MI355X-native Square Root solver.\n"
+      "usage: bal_qr_hip --input <bal file> [options]\n"
+      "  --input <path>                         BAL text file\n"
+      "  --[no-]normalize, --normalization-scale <s>\n"
+      "  --rotation-sigma <s> --translation-sigma <s> --point-sigma <s> --random-seed <n>\n"
+      "  --init-depth-threshold <z>\n"
+      "  --max-num-iterations <n>               (default 20)\n"
+      "  --[no-]use-double                      (default double)\n"
+      "  --preconditioner-type JACOBI|SCHUR_JACOBI\n"
+      "  --robust-norm NONE|HUBER --huber-parameter <t>\n"
+      "  --optimized-cost ERROR|ERROR_VALID|ERROR_VALID_AVG\n"
+      "  --eta <e> --max-linear-solver-iterations <n> --function-tolerance <t>\n"
+      "  --jacobi-scaling-epsilon <e> --log-path <ba_log.json> --device <n>\n"
+      "  --dry-run                              load + preprocess only, print problem statistics");
+}
+
+template <class Scalar>
+int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string& log_path, bool dry_run, int device) {
+  auto prob = load_normalized_bal_problem<Scalar>(ds);
+  double sx = 0, sy = 0, sz = 0;
+  for (const auto& l : prob.landmarks) {
+    sx += l.p_w[0];
+    sy += l.p_w[1];
+    sz += l.p_w[2];
+  }
+  std::printf("Loaded BAL problem (%d cams, %d lms, %lld obs) from '%s'\n", prob.num_cameras(), prob.num_landmarks(),
+              static_cast<long long>(prob.num_observations()), ds.input.c_str());
+  if (dry_run) {
+    std::printf("{\"num_cameras\": %d, \"num_landmarks\": %d, \"num_observations\": %lld, "
+                "\"landmark_sum\": [%.12e, %.12e, %.12e], \"cam0\": [%.12e, %.12e, %.12e, %.12e, %.12e, %.12e, %.12e]}\n",
+                prob.num_cameras(), prob.num_landmarks(), static_cast<long long>(prob.num_observations()), sx, sy, sz,
+                double(prob.cameras[0][0]), double(prob.cameras[0][1]), double(prob.cameras[0][2]),
+                double(prob.cameras[0][3]), double(prob.cameras[0][4]), double(prob.cameras[0][5]),
+                double(prob.cameras[0][6]));
+    return 0;
+  }
+  SolverSummary summary;
+  bundle_adjust_manual(prob, so, &summary, device);
+  // ba_log.json: flat object, one array per iteration field (reference
+  // src/rootba/bal/ba_log.cpp:62-149), restricted to the fields produced here
+  std::ofstream f(log_path);
+  auto arr = [&](const char* name, auto getter, bool last = false) {
+    f << "  \"" << name << "\": [";
+    for (size_t i = 0; i < summary.iterations.size(); ++i) f << (i ? ", " : "") << getter(summary.iterations[i]);
+    f << "]" << (last ? "\n" : ",\n");
+  };
+  f.precision(17);
+  f << "{\n  \"_type\": \"rootba\",\n  \"_static\": {\"solver\": {\"solver_type\": \"bal_qr_hip\", \"message\": \""
+    << summary.message << "\", \"initial_cost\": " << summary.initial_cost << ", \"final_cost\": " << summary.final_cost
+    << "}},\n";
+  arr("iteration", [](const IterationSummary& s) { return s.iteration; });
+  arr("cost_all_error", [](const IterationSummary& s) { return s.cost.all.error; });
+  arr("cost_valid_error", [](const IterationSummary& s) { return s.cost.valid.error; });
+  arr("step_is_successful", [](const IterationSummary& s) { return int(s.step_is_successful); });
+  arr("step_is_valid", [](const IterationSummary& s) { return int(s.step_is_valid); });
+  arr("linear_solver_iterations", [](const IterationSummary& s) { return s.linear_solver_iterations; });
+  arr("trust_region_radius", [](const IterationSummary& s) { return s.trust_region_radius; });
+  arr("iteration_time_in_seconds", [](const IterationSummary& s) { return s.iteration_time_in_seconds; });
+  arr("stage1_time_in_seconds", [](const IterationSummary& s) { return s.stage1_time_in_seconds; });
+  arr("stage2_time_in_seconds", [](const IterationSummary& s) { return s.stage2_time_in_seconds; });
+  arr("solve_reduced_system_time_in_seconds",
+      [](const IterationSummary& s) { return s.solve_reduced_system_time_in_seconds; });
+  arr("back_substitution_time_in_seconds", [](const IterationSummary& s) { return s.back_substitution_time_in_seconds; },
+      true);
+  f << "}\n";
+  return 0;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  BalDatasetOptions ds;
+  SolverOptions so;
+  std::string log_path = "ba_log.json";
+  bool dry_run = false;
+  int device = 0;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto val = [&]() -> std::string {
+      if (i + 1 >= argc) {
+        std::fprintf(stderr, "missing value for %s\n", a.c_str());
+        std::exit(1);
+      }
+      return argv[++i];
+    };
+    if (a == "--help" || a == "-h") { usage(); return 0; }
+    else if (a == "--input") ds.input = val();
+    else if (a == "--normalize") ds.normalize = true;
+    else if (a == "--no-normalize") ds.normalize = false;
+    else if (a == "--normalization-scale") ds.normalization_scale = std::stod(val());
+    else if (a == "--rotation-sigma") ds.rotation_sigma = std::stod(val());
+    else if (a == "--translation-sigma") ds.translation_sigma = std::stod(val());
+    else if (a == "--point-sigma") ds.point_sigma = std::stod(val());
+    else if (a == "--random-seed") ds.random_seed = std::stoi(val());
+    else if (a == "--init-depth-threshold") ds.init_depth_threshold = std::stod(val());
+    else if (a == "--max-num-iterations") so.max_num_iterations = std::stoi(val());
+    else if (a == "--use-double") so.use_double = true;
+    else if (a == "--no-use-double") so.use_double = false;
+    else if (a == "--preconditioner-type") {
+      const std::string v = val();
+      if (v == "JACOBI") so.preconditioner_type = SolverOptions::PreconditionerType::JACOBI;
+      else if (v == "SCHUR_JACOBI") so.preconditioner_type = SolverOptions::PreconditionerType::SCHUR_JACOBI;
+      else { std::fprintf(stderr, "preconditioner %s not implemented\n", v.c_str()); return 1; }
+    } else if (a == "--robust-norm") {
+      const std::string v = val();
+      so.residual.robust_norm = v == "HUBER" ? BalResidualOptions::RobustNorm::HUBER : BalResidualOptions::RobustNorm::NONE;
+    } else if (a == "--huber-parameter") so.residual.huber_parameter = std::stod(val());
+    else if (a == "--optimized-cost") {
+      const std::string v = val();
+      so.optimized_cost = v == "ERROR_VALID" ? SolverOptions::OptimizedCost::ERROR_VALID
+                          : v == "ERROR_VALID_AVG" ? SolverOptions::OptimizedCost::ERROR_VALID_AVG
+                                                   : SolverOptions::OptimizedCost::ERROR;
+    } else if (a == "--eta") so.eta = std::stod(val());
+    else if (a == "--max-linear-solver-iterations") so.max_linear_solver_iterations = std::stoi(val());
+    else if (a == "--function-tolerance") so.function_tolerance = std::stod(val());
+    else if (a == "--jacobi-scaling-epsilon") so.jacobi_scaling_epsilon = std::stod(val());
+    else if (a == "--log-path") log_path = val();
+    else if (a == "--device") device = std::stoi(val());
+    else if (a == "--dry-run") dry_run = true;
+    else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 1; }
+  }
+  if (ds.input.empty()) { usage(); return 1; }
+  try {
+    return so.use_double ? run<double>(ds, so, log_path, dry_run, device) : run<float>(ds, so, log_path, dry_run, device);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "FATAL: %s\n", e.what());
+    return 2;
+  }
+}
