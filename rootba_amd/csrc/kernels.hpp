@@ -1115,18 +1115,25 @@ __global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ in
 
 // ===========================================================================
 // PCG (ConjugateGradientsSolver::solve, src/rootba/cg/conjugate_gradient.hpp:113-298)
-// Three fused single-workgroup kernels per iteration around H*x:
-//   k_pcg_a : z = M^-1 r, rho = r.z, beta, p = z + beta p, q = 0
-//   k_pcg_b : q += lambda p, pq = p.q, alpha, x += alpha p, r -= alpha q,
-//             Q-model termination test (or prepares the residual refresh)
-//   k_pcg_c : (every 10th iteration) r = b - H x, then the termination test
+// Five small multi-workgroup kernels per iteration around H*x:
+//   k_pcg_a1 : z = M^-1 r, per-block partial of rho = r.z
+//   k_pcg_a2 : rho, beta (every block sums the partials in the same fixed order),
+//              p = z + beta p, q = 0
+//   k_pcg_b1 : q += lambda p, partial of pq = p.q
+//   k_pcg_b2 : alpha, x += alpha p, r -= alpha q, partial of Q = -x.(b + r)
+//              (or, every 10th iteration, prepares the residual refresh)
+//   k_pcg_fin: Q-model termination test, iteration counter
+//   k_pcg_c1 : (refresh) r = b - H x, partial of Q
+// One workgroup cannot pull the 81 n_c preconditioner through a single CU fast
+// enough (H*x evicts it from L2 every iteration), hence kPcgBlocks workgroups.
 // All scalars stay on the device in `CgState` (double, as in the reference);
-// kernels are no-ops once `done`; the host only polls the state. Reductions use
-// one workgroup and a fixed order, so every rank of a multi-GPU run computes
-// bit-identical scalars from the (identical) all-reduced vectors.
+// kernels are no-ops once `done`; the host only polls the state. Every reduction
+// has a fixed order, so all ranks of a multi-GPU run compute bit-identical
+// scalars from the (identical) all-reduced vectors.
 // ===========================================================================
 struct CgState {
-  double rho, last_rho, pq, q0, q1, norm_b2;
+  double rho_hist[2];  // rho of iteration i lives in rho_hist[i & 1]
+  double pq, q0, q1, norm_b2;
   double alpha, beta;
   int iter;         // iterations completed
   int done;         // 0 running, 1 finished
@@ -1134,26 +1141,29 @@ struct CgState {
   int refresh;      // the current iteration recomputes r from scratch
 };
 
-constexpr int kPcgThreads = 1024;
+constexpr int kPcgBlocks = 64;  // workgroups of the PCG vector kernels
+constexpr int kPcgThreads = 256;
 
-// deterministic sum over the workgroup (<= 16 waves); result valid in all threads
+// deterministic sum over the workgroup (4 waves); result valid in all threads
 __device__ __forceinline__ double pcg_block_sum(double v, double* sm) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nw = blockDim.x >> 6;
   const double t = wave_sum(v);
   __syncthreads();
   if (lane == 0) sm[wave] = t;
   __syncthreads();
+  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// sum of the per-block partials, same order in every block
+__device__ __forceinline__ double pcg_sum_partials(const double* __restrict__ partial) {
   double r = 0;
-  for (int w = 0; w < nw; ++w) r += sm[w];
+  for (int b = 0; b < kPcgBlocks; ++b) r += partial[b];
   return r;
 }
 
-// x = 0, r = b, state reset, |b|^2
+// x = 0, r = b, state reset, |b|^2   (single workgroup)
 template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_pcg_init(const S* __restrict__ bvec,
-                                                         S* __restrict__ x, S* __restrict__ r,
-                                                         int n, CgState* st) {
+__global__ __launch_bounds__(1024) void k_pcg_init(const S* __restrict__ bvec, S* __restrict__ x,
+                                                  S* __restrict__ r, int n, CgState* st) {
   __shared__ double sm[16];
   double acc = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1162,10 +1172,14 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_init(const S* __restrict__ 
     r[i] = v;
     acc += double(v) * double(v);
   }
-  const double nb2 = pcg_block_sum(acc, sm);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double t = wave_sum(acc);
+  if (lane == 0) sm[wave] = t;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    st->rho = 1.0;
-    st->last_rho = 1.0;
+    double nb2 = 0;
+    for (int w = 0; w < int(blockDim.x >> 6); ++w) nb2 += sm[w];
+    st->rho_hist[0] = st->rho_hist[1] = 1.0;
     st->pq = 0;
     st->q0 = 0;  // -x.(b + r) with x = 0
     st->q1 = 0;
@@ -1179,16 +1193,14 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_init(const S* __restrict__ 
 }
 
 template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_pcg_a(const S* __restrict__ inv,
-                                                      const S* __restrict__ r, S* __restrict__ z,
-                                                      S* __restrict__ pvec, S* __restrict__ q, int n,
-                                                      CgState* st) {
-  __shared__ double sm[16];
-  __shared__ double s_beta;
-  __shared__ int s_stop;
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_a1(const S* __restrict__ inv,
+                                                       const S* __restrict__ r, S* __restrict__ z,
+                                                       int n, const CgState* st,
+                                                       double* __restrict__ partial) {
+  __shared__ double sm[4];
   if (st->done) return;
   double acc = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
     const int c = i / 9, row = i - 9 * c;
     const S* M = inv + 81 * c + 9 * row;
     const S* rc = r + 9 * c;
@@ -1198,41 +1210,140 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_a(const S* __restrict__ inv
     z[i] = v;
     acc += double(r[i]) * double(v);
   }
-  const double rho = pcg_block_sum(acc, sm);
-  if (threadIdx.x == 0) {
-    int stop = 0;
-    double beta = 0.0;
-    if (rho == 0.0 || isinf(rho)) {
-      stop = 1;
-    } else if (st->iter > 0) {
-      beta = rho / st->rho;  // st->rho still holds the previous iteration's value
-      if (beta == 0.0 || isinf(beta)) stop = 1;
-    }
+  const double t = pcg_block_sum(acc, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+template <class S>
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_a2(const S* __restrict__ z, S* __restrict__ pvec,
+                                                       S* __restrict__ q, int n, CgState* st,
+                                                       const double* __restrict__ partial) {
+  if (st->done) return;
+  const int iter = st->iter;
+  const double rho = pcg_sum_partials(partial);
+  const double rho_prev = st->rho_hist[(iter + 1) & 1];  // written one iteration ago
+  int stop = 0;
+  double beta = 0.0;
+  if (rho == 0.0 || isinf(rho)) {
+    stop = 1;
+  } else if (iter > 0) {
+    beta = rho / rho_prev;
+    if (beta == 0.0 || isinf(beta)) stop = 1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (stop) {
-      st->termination = 2;
+      st->termination = 2;  // "Numerical failure. rho / beta"
       st->done = 1;
-      st->iter += 1;
+      st->iter = iter + 1;
     } else {
-      st->last_rho = st->rho;
-      st->rho = rho;
+      st->rho_hist[iter & 1] = rho;
       st->beta = beta;
     }
-    s_beta = beta;
-    s_stop = stop;
   }
-  __syncthreads();
-  if (s_stop) return;
-  const S beta = S(s_beta);
-  const bool first = st->iter == 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    pvec[i] = first ? z[i] : z[i] + beta * pvec[i];
+  if (stop) return;
+  const S bs = S(beta);
+  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
+    pvec[i] = iter == 0 ? z[i] : z[i] + bs * pvec[i];
     q[i] = S(0);
   }
 }
 
-// shared tail: Q-model termination (conjugate_gradient.hpp:239-276) and bookkeeping
-__device__ __forceinline__ void pcg_finish_iteration(CgState* st, double q1, double q_tolerance,
-                                                     int min_it, int max_it) {
+template <class S>
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_b1(const S* __restrict__ pvec, S* __restrict__ q,
+                                                       S lambda, int n, const CgState* st,
+                                                       double* __restrict__ partial) {
+  __shared__ double sm[4];
+  if (st->done) return;
+  double acc = 0;
+  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
+    const S v = q[i] + lambda * pvec[i];  // pose damping term of right_multiply
+    q[i] = v;
+    acc += double(pvec[i]) * double(v);
+  }
+  const double t = pcg_block_sum(acc, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+template <class S>
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_b2(const S* __restrict__ bvec, S* __restrict__ x,
+                                                       S* __restrict__ r, const S* __restrict__ pvec,
+                                                       const S* __restrict__ q, S* __restrict__ tmp,
+                                                       int n, CgState* st, int residual_reset_period,
+                                                       const double* __restrict__ partial_pq,
+                                                       double* __restrict__ partial_q1) {
+  __shared__ double sm[4];
+  if (st->done) return;
+  const int iter = st->iter;
+  const double pq = pcg_sum_partials(partial_pq);
+  int stop = 0, term = 0;
+  double alpha = 0;
+  if (pq <= 0.0 || isinf(pq)) {
+    stop = 1;  // "Matrix is indefinite, no more progress can be made." -> NO_CONVERGENCE
+  } else {
+    alpha = st->rho_hist[iter & 1] / pq;
+    if (isinf(alpha)) {
+      stop = 1;
+      term = 2;
+    }
+  }
+  const int refresh = ((iter + 1) % residual_reset_period) == 0 ? 1 : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->pq = pq;
+    st->alpha = alpha;
+    st->refresh = refresh;
+    if (stop) {
+      st->termination = term;
+      st->done = 1;
+      st->iter = iter + 1;
+    }
+  }
+  if (stop) return;
+  const S a = S(alpha);
+  double acc1 = 0;
+  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
+    const S xv = x[i] + a * pvec[i];
+    x[i] = xv;
+    if (refresh) {
+      tmp[i] = S(0);
+    } else {
+      const S rv = r[i] - a * q[i];
+      r[i] = rv;
+      acc1 -= double(xv) * double(bvec[i] + rv);
+    }
+  }
+  const double t = pcg_block_sum(acc1, sm);
+  if (threadIdx.x == 0) partial_q1[blockIdx.x] = t;
+}
+
+// residual refresh r = b - (H x) (conjugate_gradient.hpp:230-235), partial of Q
+template <class S>
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_c1(const S* __restrict__ bvec,
+                                                       const S* __restrict__ x, S* __restrict__ r,
+                                                       const S* __restrict__ tmp, S lambda, int n,
+                                                       const CgState* st,
+                                                       double* __restrict__ partial_q1) {
+  __shared__ double sm[4];
+  if (st->done || !st->refresh) return;
+  double acc1 = 0;
+  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
+    const S rv = bvec[i] - (tmp[i] + lambda * x[i]);
+    r[i] = rv;
+    acc1 -= double(x[i]) * double(bvec[i] + rv);
+  }
+  const double t = pcg_block_sum(acc1, sm);
+  if (threadIdx.x == 0) partial_q1[blockIdx.x] = t;
+}
+
+// Q-model termination (conjugate_gradient.hpp:239-276) and bookkeeping; one thread.
+// `phase` 0: after k_pcg_b2 (skipped on refresh iterations), 1: after k_pcg_c1.
+__global__ void k_pcg_fin(CgState* st, const double* __restrict__ partial_q1, int phase,
+                          double q_tolerance, int min_it, int max_it) {
+  if (st->done) return;
+  if (phase == 0 && st->refresh) return;
+  if (phase == 1 && !st->refresh) return;
+  const double q1 = pcg_sum_partials(partial_q1);
+  st->q1 = q1;
+  st->refresh = 0;
   st->iter += 1;
   const double zeta = st->iter * (q1 - st->q0) / q1;
   if (zeta < q_tolerance && st->iter >= min_it) {
@@ -1245,97 +1356,6 @@ __device__ __forceinline__ void pcg_finish_iteration(CgState* st, double q1, dou
   if (st->iter >= max_it) {
     st->termination = 0;
     st->done = 1;
-  }
-}
-
-template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_pcg_b(const S* __restrict__ bvec,
-                                                      S* __restrict__ x, S* __restrict__ r,
-                                                      const S* __restrict__ pvec, S* __restrict__ q,
-                                                      S* __restrict__ tmp, S lambda, int n,
-                                                      CgState* st, int residual_reset_period,
-                                                      double q_tolerance, int min_it, int max_it) {
-  __shared__ double sm[16];
-  __shared__ double s_alpha;
-  __shared__ int s_stop, s_refresh;
-  if (st->done) return;
-  double acc = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const S v = q[i] + lambda * pvec[i];  // pose damping term of right_multiply
-    q[i] = v;
-    acc += double(pvec[i]) * double(v);
-  }
-  const double pq = pcg_block_sum(acc, sm);
-  if (threadIdx.x == 0) {
-    int stop = 0;
-    double alpha = 0;
-    if (pq <= 0.0 || isinf(pq)) {
-      st->termination = 0;  // "Matrix is indefinite, no more progress can be made."
-      stop = 1;
-    } else {
-      alpha = st->rho / pq;
-      if (isinf(alpha)) {
-        st->termination = 2;
-        stop = 1;
-      }
-    }
-    st->pq = pq;
-    if (stop) {
-      st->done = 1;
-      st->iter += 1;
-    }
-    st->alpha = alpha;
-    const int refresh = ((st->iter + 1) % residual_reset_period) == 0 ? 1 : 0;
-    st->refresh = refresh;
-    s_alpha = alpha;
-    s_stop = stop;
-    s_refresh = refresh;
-  }
-  __syncthreads();
-  if (s_stop) return;
-  const S a = S(s_alpha);
-  if (s_refresh) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      x[i] = x[i] + a * pvec[i];
-      tmp[i] = S(0);
-    }
-    return;  // k_pcg_c finishes the iteration after H*x(x)
-  }
-  double acc1 = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const S xv = x[i] + a * pvec[i];
-    const S rv = r[i] - a * q[i];
-    x[i] = xv;
-    r[i] = rv;
-    acc1 -= double(xv) * double(bvec[i] + rv);
-  }
-  const double q1 = pcg_block_sum(acc1, sm);
-  if (threadIdx.x == 0) {
-    st->q1 = q1;
-    pcg_finish_iteration(st, q1, q_tolerance, min_it, max_it);
-  }
-}
-
-// residual refresh r = b - (H x) (conjugate_gradient.hpp:230-235), then the test
-template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_pcg_c(const S* __restrict__ bvec,
-                                                      const S* __restrict__ x, S* __restrict__ r,
-                                                      const S* __restrict__ tmp, S lambda, int n,
-                                                      CgState* st, double q_tolerance, int min_it,
-                                                      int max_it) {
-  __shared__ double sm[16];
-  if (st->done || !st->refresh) return;
-  double acc1 = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const S rv = bvec[i] - (tmp[i] + lambda * x[i]);
-    r[i] = rv;
-    acc1 -= double(x[i]) * double(bvec[i] + rv);
-  }
-  const double q1 = pcg_block_sum(acc1, sm);
-  if (threadIdx.x == 0) {
-    st->q1 = q1;
-    st->refresh = 0;
-    pcg_finish_iteration(st, q1, q_tolerance, min_it, max_it);
   }
 }
 

@@ -312,6 +312,7 @@ class Solver final : public rba_solver {
     d_lm_ldiff_.alloc(n_lms);
     d_partials_.alloc(size_t(kReduceBlocks) * 8 + 16);
     d_cg_.alloc(1);
+    d_pcg_partials_.alloc(3 * rba::kPcgBlocks);
     for (auto* v : {&d_x_, &d_r_, &d_p_, &d_z_, &d_q_, &d_tmp_, &d_inc_, &d_vin_}) v->alloc(nvec_);
     d_A_.zero(stream_);
     d_top0_.zero(stream_);
@@ -627,28 +628,40 @@ class Solver final : public rba_solver {
     rba::CgState* st = d_cg_.get();
     const int* done = &st->done;
     const S* b = prm_.b;
-    constexpr int T = rba::kPcgThreads;
+    constexpr int NB = rba::kPcgBlocks, T = rba::kPcgThreads;
+    double* part_rho = d_pcg_partials_.get();
+    double* part_pq = part_rho + NB;
+    double* part_q1 = part_pq + NB;
     const int max_it = opt_.max_cg_it, min_it = opt_.min_cg_it;
     const double eta = opt_.eta;
     rba::CgState* hst = reinterpret_cast<rba::CgState*>(h_pinned_);
-    hipLaunchKernelGGL((rba::k_pcg_init<S>), dim3(1), dim3(T), 0, stream_, b, d_x_.get(),
+    hipLaunchKernelGGL((rba::k_pcg_init<S>), dim3(1), dim3(1024), 0, stream_, b, d_x_.get(),
                        d_r_.get(), n, st);
     // The host polls the device state lazily: every iteration at first (many
     // solves need 2-3 iterations), every 4th later; kernels queued past the end
     // are no-ops (`done`).
     for (int it = 1; it <= max_it; ++it) {
-      hipLaunchKernelGGL((rba::k_pcg_a<S>), dim3(1), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(),
-                         d_z_.get(), d_p_.get(), d_q_.get(), n, st);
+      hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(),
+                         d_z_.get(), n, st, part_rho);
+      hipLaunchKernelGGL((rba::k_pcg_a2<S>), dim3(NB), dim3(T), 0, stream_, d_z_.get(), d_p_.get(),
+                         d_q_.get(), n, st, part_rho);
       launch_hx(d_p_.get(), d_q_.get(), done);
       all_reduce(d_q_.get(), n);
-      hipLaunchKernelGGL((rba::k_pcg_b<S>), dim3(1), dim3(T), 0, stream_, b, d_x_.get(), d_r_.get(),
-                         d_p_.get(), d_q_.get(), d_tmp_.get(), lambda, n, st, 10, eta, min_it,
-                         max_it);
+      hipLaunchKernelGGL((rba::k_pcg_b1<S>), dim3(NB), dim3(T), 0, stream_, d_p_.get(), d_q_.get(),
+                         lambda, n, st, part_pq);
+      hipLaunchKernelGGL((rba::k_pcg_b2<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
+                         d_r_.get(), d_p_.get(), d_q_.get(), d_tmp_.get(), n, st, 10, part_pq, part_q1);
       if (it % 10 == 0) {
+        // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
         launch_hx(d_x_.get(), d_tmp_.get(), done);
         all_reduce(d_tmp_.get(), n);
-        hipLaunchKernelGGL((rba::k_pcg_c<S>), dim3(1), dim3(T), 0, stream_, b, d_x_.get(),
-                           d_r_.get(), d_tmp_.get(), lambda, n, st, eta, min_it, max_it);
+        hipLaunchKernelGGL((rba::k_pcg_c1<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
+                           d_r_.get(), d_tmp_.get(), lambda, n, st, part_q1);
+        hipLaunchKernelGGL((rba::k_pcg_fin), dim3(1), dim3(1), 0, stream_, st, part_q1, 1, eta, min_it,
+                           max_it);
+      } else {
+        hipLaunchKernelGGL((rba::k_pcg_fin), dim3(1), dim3(1), 0, stream_, st, part_q1, 0, eta, min_it,
+                           max_it);
       }
       if (it <= 8 || it % 4 == 0 || it == max_it) {
         HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
@@ -994,7 +1007,7 @@ class Solver final : public rba_solver {
   DevBuf<S> d_A_, d_top0_, d_topd_, d_qtr_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;
   DevBuf<S> d_jp_diag2_, d_pose_scaling_, d_mid_, d_bb_, d_inv_;
   DevBuf<S> d_x_, d_r_, d_p_, d_z_, d_q_, d_tmp_, d_inc_, d_vin_;
-  DevBuf<double> d_lm_ldiff_, d_partials_;
+  DevBuf<double> d_lm_ldiff_, d_partials_, d_pcg_partials_;
   DevBuf<rba::CgState> d_cg_;
   DevBuf<rba::SmallBatch> d_batches_;
   int n_small_batches_ = 0;
