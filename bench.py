@@ -70,11 +70,15 @@ def make_problem(workload: str, args):
     return prob, data
 
 
+PRECOND = {"JACOBI": 0, "SCHUR_JACOBI": 1, "POWER_SCHUR_COMPLEMENT": 2}
+_SOLVER_KW = {}
+
+
 def solver_options(mod, n_iter: int):
     # reference defaults + CVPR'21 common settings (Huber 1.0); no early stop so
     # that exactly warmup+steps LM iterations are executed
     return mod.default_options(robust_norm=1, huber_parameter=1.0, max_num_iterations=n_iter,
-                               function_tolerance=0.0)
+                               function_tolerance=0.0, **_SOLVER_KW)
 
 
 def cpu_baseline(prob, n_iter: int, gpu_rows):
@@ -114,7 +118,11 @@ def main():
     ap.add_argument("--translation-sigma", type=float, default=0.5)
     ap.add_argument("--point-sigma", type=float, default=0.5)
     ap.add_argument("--rotation-sigma", type=float, default=0.0)
+    ap.add_argument("--preconditioner", choices=sorted(PRECOND), default="SCHUR_JACOBI",
+                    help="reference default: SCHUR_JACOBI")
+    ap.add_argument("--power-order", type=int, default=10)
     args = ap.parse_args()
+    _SOLVER_KW.update(preconditioner_type=PRECOND[args.preconditioner], power_order=args.power_order)
 
     import torch
     import torch.distributed as dist
@@ -209,7 +217,7 @@ def main():
             "data": data,
             "config": {
                 "workload": f"BAL {args.workload} ({data}): {prob.n_cams} cams, {prob.n_lms} lms, {prob.n_obs} obs, "
-                            "solver=SQUARE_ROOT, SCHUR_JACOBI, Huber(1), float32",
+                            f"solver=SQUARE_ROOT, {args.preconditioner}, Huber(1), float32",
                 "parallelism": f"landmarks sharded over {world} GPU(s), RCCL all-reduce of camera vectors",
                 "cg_iterations_per_step": sum(r.cg_iterations for r in timed) / max(1, len(timed)),
                 "successful_steps": sum(r.step_is_successful for r in timed),

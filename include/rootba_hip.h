@@ -58,9 +58,9 @@ typedef struct rba_options {
   int robust_norm;                /* 0 NONE, 1 HUBER (bal_residual_options.hpp)   */
   double huber_parameter;
   double jacobi_scaling_eps;      /* 0 -> Sophus epsilonSqrt<Scalar>              */
-  int preconditioner_type;        /* 0 JACOBI, 1 SCHUR_JACOBI                     */
+  int preconditioner_type;        /* 0 JACOBI, 1 SCHUR_JACOBI, 2 POWER_SCHUR_COMPLEMENT */
   int reduction_alg;              /* accepted, ignored (always device scatter-add)*/
-  int power_order;                /* reserved for the power-series preconditioner */
+  int power_order;                /* order m of the power-series preconditioner   */
   int min_cg_it;                  /* min_linear_solver_iterations                 */
   int max_cg_it;                  /* max_linear_solver_iterations                 */
   double eta;

@@ -257,6 +257,13 @@ class Oracle:
         self._fn("get_precond_blocks")(self.h, _ptr(out, self.ct))
         return out.reshape(-1, 9, 9)
 
+    def power_precond(self, lam, b):
+        """PowerSCPreconditioner::solve_assign at the current linearisation point."""
+        x = self._vec(9 * self.n_cams)
+        bb = self._in(b)
+        self._fn("power_precond")(self.h, self.ct(lam), _ptr(bb, self.ct), _ptr(x, self.ct))
+        return x
+
     def sc_build(self, lam, pose_lambda=0.0, pose_scaling=None, want_H=True):
         n = 9 * self.n_cams
         H = self._vec(n * n) if want_H else None

@@ -249,6 +249,12 @@ static void fill_ri(const orc::ResidualInfo& ri, orc_residual_info* out) {
   void orc_apply_inc_camera_##SUF(S* cam, const S* inc9) {                     \
     orc::apply_inc_camera<S>(cam, inc9);                                       \
   }                                                                            \
+  /* power-series preconditioner (after orc_linearize): prepare + apply */      \
+  void orc_power_precond_##SUF(void* h, S lambda, const S* b, S* x) {          \
+    auto* o = static_cast<orc::Oracle<S>*>(h);                                 \
+    o->power_precond_prepare(lambda);                                          \
+    o->power_precond_solve(b, x);                                              \
+  }                                                                            \
   /* explicit Schur complement cross-check (dense H, small problems) */        \
   void orc_sc_build_##SUF(void* h, S lambda, S pose_lambda,                    \
                           const S* pose_scaling, S* H_out, S* b_out,           \

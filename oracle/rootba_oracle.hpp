@@ -57,7 +57,7 @@ struct Options {
   int robust_norm = 0;                 // 0 NONE, 1 HUBER
   double huber_parameter = 1.0;
   double jacobi_scaling_eps = 0.0;  // 0 -> Sophus epsilonSqrt<Scalar>
-  int preconditioner_type = 1;      // 0 JACOBI, 1 SCHUR_JACOBI
+  int preconditioner_type = 1;      // 0 JACOBI, 1 SCHUR_JACOBI, 2 POWER_SCHUR_COMPLEMENT
   int reduction_alg = 1;
   int power_order = 10;
   int min_cg_it = 0;
@@ -1009,6 +1009,94 @@ class Oracle {
     }
   }
 
+  // -------------------------------------------------------------------------
+  // PowerSCPreconditioner (src/rootba/cg/preconditioner.hpp:145-254) on the
+  // landmark pieces of LandmarkBlockSC (src/rootba/sc/landmark_block.hpp:
+  // 342-364 stage/Hll_inv, 381-407 add_Jp_x/add_JpT_x, get_jacobi
+  // linearization_sc.hpp:244-264):
+  //   x = sum_{i=0..order} (Hpp^-1 E0)^i Hpp^-1 b,
+  //   E0 v = sum_l Jp^T Jl Hll^-1 Jl^T Jp v,  Hll^-1 = (Jl^T Jl + lambda I)^-1,
+  //   Hpp = sum Jp^T Jp + lambda I  (scaled Jacobians, JACOBI blocks).
+  // The reference wires it only for the SC solver (linearizor_sc.cpp:166-171);
+  // with the QR solver it is a new combination whose operator
+  // is mathematically the same, so this is its oracle.
+  // -------------------------------------------------------------------------
+  void power_precond_prepare(S lambda) {
+    pw_Jp_.assign(size_t(18) * n_obs_, S(0));
+    pw_Jl_.assign(size_t(6) * n_obs_, S(0));
+    pw_Hll_inv_.assign(size_t(9) * n_lms_, S(0));
+    std::vector<S> Hpp(size_t(81) * n_cams_, S(0));
+    for (int l = 0; l < n_lms_; ++l) {
+      const int K = k(l);
+      std::vector<S> Jp(size_t(2 * K) * P), Jl(size_t(2 * K) * 3), r(2 * K);
+      sc_linearize(l, pose_scaling_.data(), Jp, Jl, r, nullptr, nullptr);
+      S Hll[9] = {0};
+      for (int row = 0; row < 2 * K; ++row)
+        for (int a = 0; a < 3; ++a)
+          for (int c = 0; c < 3; ++c) Hll[a * 3 + c] += Jl[row * 3 + a] * Jl[row * 3 + c];
+      for (int d = 0; d < 3; ++d) Hll[d * 3 + d] += lambda;
+      inverse3(Hll, &pw_Hll_inv_[size_t(9) * l]);
+      const int64_t o0 = lm_off_[l];
+      std::copy(Jp.begin(), Jp.end(), pw_Jp_.begin() + 18 * o0);
+      std::copy(Jl.begin(), Jl.end(), pw_Jl_.begin() + 6 * o0);
+      for (int i = 0; i < K; ++i) {
+        S* B = &Hpp[size_t(81) * obs_cam_[o0 + i]];
+        for (int a = 0; a < P; ++a)
+          for (int bb = 0; bb < P; ++bb)
+            B[a * P + bb] += Jp[(2 * i) * P + a] * Jp[(2 * i) * P + bb] +
+                             Jp[(2 * i + 1) * P + a] * Jp[(2 * i + 1) * P + bb];
+      }
+    }
+    std::vector<S> diag(size_t(P) * n_cams_, lambda);
+    build_preconditioner(Hpp, diag.data());  // inv_blocks_ = Hpp^-1
+  }
+
+  // right_mul_e0 (preconditioner.hpp:223-245)
+  void power_e0_mult(const S* x, S* res) const {
+    std::fill(res, res + size_t(P) * n_cams_, S(0));
+    for (int l = 0; l < n_lms_; ++l) {
+      const int K = k(l);
+      const int64_t o0 = lm_off_[l];
+      const S* Jp = &pw_Jp_[18 * o0];
+      const S* Jl = &pw_Jl_[6 * o0];
+      const S* Hi = &pw_Hll_inv_[size_t(9) * l];
+      std::vector<S> Jp_x(2 * K);
+      S JlT[3] = {0, 0, 0};
+      for (int i = 0; i < K; ++i) {
+        const S* v = x + P * obs_cam_[o0 + i];
+        for (int rr = 0; rr < 2; ++rr) {
+          S acc = 0;
+          for (int a = 0; a < P; ++a) acc += Jp[(2 * i + rr) * P + a] * v[a];
+          Jp_x[2 * i + rr] = acc;
+          for (int c = 0; c < 3; ++c) JlT[c] += Jl[(2 * i + rr) * 3 + c] * acc;
+        }
+      }
+      S h[3];
+      for (int a = 0; a < 3; ++a) h[a] = Hi[a * 3] * JlT[0] + Hi[a * 3 + 1] * JlT[1] + Hi[a * 3 + 2] * JlT[2];
+      for (int i = 0; i < K; ++i) {
+        S* out = res + P * obs_cam_[o0 + i];
+        for (int rr = 0; rr < 2; ++rr) {
+          const int row = 2 * i + rr;
+          const S t = Jl[row * 3] * h[0] + Jl[row * 3 + 1] * h[1] + Jl[row * 3 + 2] * h[2];
+          for (int a = 0; a < P; ++a) out[a] += Jp[row * P + a] * t;
+        }
+      }
+    }
+  }
+
+  // solve_assign (preconditioner.hpp:180-192)
+  void power_precond_solve(const S* b, S* x) const {
+    const size_t n = size_t(P) * n_cams_;
+    std::vector<S> tmp(n), e(n);
+    precond_solve(b, x);
+    std::copy(x, x + n, tmp.begin());
+    for (int i = 1; i <= opt_.power_order; ++i) {
+      power_e0_mult(tmp.data(), e.data());
+      precond_solve(e.data(), tmp.data());
+      for (size_t j = 0; j < n; ++j) x[j] += tmp[j];
+    }
+  }
+
   CgSummary pcg(const std::vector<S>& bref, std::vector<S>& xref) {
     CgSummary summary;
     const size_t n = size_t(P) * n_cams_;
@@ -1038,7 +1126,10 @@ class Oracle {
     double q0 = -1.0 * double(dot(xref.data(), br.data(), n));
 
     for (summary.num_iterations = 1;; ++summary.num_iterations) {
-      precond_solve(r.data(), z.data());
+      if (opt_.preconditioner_type == 2)
+        power_precond_solve(r.data(), z.data());
+      else
+        precond_solve(r.data(), z.data());
       const double last_rho = rho;
       rho = double(dot(r.data(), z.data(), n));
       if (rho == 0.0 || std::isinf(rho)) {
@@ -1141,6 +1232,8 @@ class Oracle {
       }
       std::vector<S> diag(n, lambda);
       build_preconditioner(precond_blocks_, diag.data());
+    } else if (opt_.preconditioner_type == 2) {
+      power_precond_prepare(lambda);
     } else {
       build_preconditioner(precond_blocks_, nullptr);
     }
@@ -1518,6 +1611,7 @@ class Oracle {
   std::vector<char> damped_, failed_;
   S pose_damping_ = 0;
   std::vector<S> jp_diag2_, pose_scaling_, precond_blocks_, inv_blocks_, b_;
+  std::vector<S> pw_Jp_, pw_Jl_, pw_Hll_inv_;
   bool new_linearization_point_ = false;
 };
 

@@ -25,7 +25,7 @@ void usage() {
       "  --init-depth-threshold <z>\n"
       "  --max-num-iterations <n>               (default 20)\n"
       "  --[no-]use-double                      (default double)\n"
-      "  --preconditioner-type JACOBI|SCHUR_JACOBI\n"
+      "  --preconditioner-type JACOBI|SCHUR_JACOBI|POWER_SCHUR_COMPLEMENT  --power-order <m>\n"
       "  --robust-norm NONE|HUBER --huber-parameter <t>\n"
       "  --optimized-cost ERROR|ERROR_VALID|ERROR_VALID_AVG\n"
       "  --eta <e> --max-linear-solver-iterations <n> --function-tolerance <t>\n"
@@ -118,6 +118,7 @@ int main(int argc, char** argv) {
       const std::string v = val();
       if (v == "JACOBI") so.preconditioner_type = SolverOptions::PreconditionerType::JACOBI;
       else if (v == "SCHUR_JACOBI") so.preconditioner_type = SolverOptions::PreconditionerType::SCHUR_JACOBI;
+      else if (v == "POWER_SCHUR_COMPLEMENT") so.preconditioner_type = SolverOptions::PreconditionerType::POWER_SCHUR_COMPLEMENT;
       else { std::fprintf(stderr, "preconditioner %s not implemented\n", v.c_str()); return 1; }
     } else if (a == "--robust-norm") {
       const std::string v = val();

@@ -33,7 +33,7 @@ struct BalResidualOptions {
 };
 
 struct SolverOptions {
-  enum class PreconditionerType { JACOBI, SCHUR_JACOBI };
+  enum class PreconditionerType { JACOBI, SCHUR_JACOBI, POWER_SCHUR_COMPLEMENT };
   enum class OptimizedCost { ERROR, ERROR_VALID, ERROR_VALID_AVG };
   int verbosity_level = 2;
   BalResidualOptions residual;
@@ -67,7 +67,7 @@ struct SolverOptions {
     o.robust_norm = residual.robust_norm == BalResidualOptions::RobustNorm::HUBER;
     o.huber_parameter = residual.huber_parameter;
     o.jacobi_scaling_eps = jacobi_scaling_epsilon;
-    o.preconditioner_type = preconditioner_type == PreconditionerType::JACOBI ? 0 : 1;
+    o.preconditioner_type = int(preconditioner_type);
     o.reduction_alg = reduction_alg;
     o.power_order = power_order;
     o.min_cg_it = min_linear_solver_iterations;

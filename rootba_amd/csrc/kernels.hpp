@@ -898,6 +898,50 @@ __global__ __launch_bounds__(256) void k_hx_small(Params<S> p, const SmallBatch*
 }
 
 // ===========================================================================
+// E0 * v = sum_l (Q1^T Jp)_l^T (Q1^T Jp)_l v_l  with the DAMPED top rows, i.e.
+// Jp^T Jl (Jl^T Jl + lambda I)^-1 Jl^T Jp v of the power-series (PoBA)
+// preconditioner (right_mul_e0, src/rootba/cg/preconditioner.hpp:223-245) —
+// expressed through the square-root factors that stage 2 already holds, so one
+// application reads 27 scalars per observation instead of the sparse Jacobians
+// plus a 3x3 inverse per landmark.
+// ===========================================================================
+template <class S, int CH>
+__global__ __launch_bounds__(256) void k_e0(Params<S> p, int lm_begin, int lm_end,
+                                            const S* __restrict__ v, S* __restrict__ y,
+                                            const int* __restrict__ done_flag) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;
+  if (done_flag && *done_flag) return;
+  const int k = p.lm_k[s];
+  const int64_t o0 = p.lm_obs[s];
+  const S* __restrict__ Td = p.topd + 27 * o0;
+  const int lane9 = lane / 9, comp = lane - 9 * lane9;
+  S t[3][CH];
+  int yidx[CH];
+  bool act[CH];
+  S w[3] = {S(0), S(0), S(0)};
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const int islot = 7 * ch + lane9;
+    act[ch] = lane < 63 && islot < k;
+    const int cam = act[ch] ? p.obs_cam[o0 + islot] : 0;
+    yidx[ch] = 9 * cam + comp;
+    const S xv = act[ch] ? v[yidx[ch]] : S(0);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      t[m][ch] = act[ch] ? Td[27 * islot + 9 * m + comp] : S(0);
+      w[m] += t[m][ch] * xv;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 3; ++m) w[m] = wave_sum(w[m]);
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch)
+    if (act[ch]) atomic_add(y + yidx[ch], t[0][ch] * w[0] + t[1][ch] * w[1] + t[2][ch] * w[2]);
+}
+
+// ===========================================================================
 // Back-substitution (back_substitute ipp:212-284; loop linearization_qr.hpp:165-179)
 //   delta = -Rd^{-1} (Q1^T r + Q1^T Jp x)        on the DAMPED top rows
 //   l_diff -= g^T (g/2 + Q^T r), g = (Q^T J)[x; delta] on the UNDAMPED 2k rows
@@ -1210,6 +1254,47 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_a1(const S* __restrict__ in
     z[i] = v;
     acc += double(r[i]) * double(v);
   }
+  const double t = pcg_block_sum(acc, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// out = M^-1 in (9x9 block per camera); optionally accum += out; optionally zero a vector
+template <class S>
+__global__ __launch_bounds__(kPcgThreads) void k_block_apply(const S* __restrict__ inv,
+                                                            const S* __restrict__ in,
+                                                            S* __restrict__ out, S* __restrict__ accum,
+                                                            S* __restrict__ zero_me, int n,
+                                                            const CgState* st) {
+  if (st->done) return;
+  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
+    const int c = i / 9, row = i - 9 * c;
+    const S* M = inv + 81 * c + 9 * row;
+    const S* rc = in + 9 * c;
+    S v = S(0);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v += M[j] * rc[j];
+    out[i] = v;
+    if (accum) accum[i] += v;
+  }
+  if (zero_me) {
+    // `in` may alias zero_me only when every block has finished reading: the caller
+    // passes a different buffer (ping-pong)
+    for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads)
+      zero_me[i] = S(0);
+  }
+}
+
+// per-block partial of rho = r.z
+template <class S>
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_rho(const S* __restrict__ r,
+                                                        const S* __restrict__ z, int n,
+                                                        const CgState* st,
+                                                        double* __restrict__ partial) {
+  __shared__ double sm[4];
+  if (st->done) return;
+  double acc = 0;
+  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads)
+    acc += double(r[i]) * double(z[i]);
   const double t = pcg_block_sum(acc, sm);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }

@@ -313,7 +313,8 @@ class Solver final : public rba_solver {
     d_partials_.alloc(size_t(kReduceBlocks) * 8 + 16);
     d_cg_.alloc(1);
     d_pcg_partials_.alloc(3 * rba::kPcgBlocks);
-    for (auto* v : {&d_x_, &d_r_, &d_p_, &d_z_, &d_q_, &d_tmp_, &d_inc_, &d_vin_}) v->alloc(nvec_);
+    for (auto* v : {&d_x_, &d_r_, &d_p_, &d_z_, &d_q_, &d_tmp_, &d_inc_, &d_vin_, &d_pw_t_, &d_pw_e_})
+      v->alloc(nvec_);
     d_A_.zero(stream_);
     d_top0_.zero(stream_);
     d_topd_.zero(stream_);
@@ -362,7 +363,8 @@ class Solver final : public rba_solver {
     prm_.lm_ldiff = d_lm_ldiff_.get();
     prm_.robust_norm = opt_.robust_norm;
     prm_.valid_only = opt_.use_valid_projections_only;
-    prm_.jacobi = opt_.preconditioner_type == 0;
+    // JACOBI and the power-series preconditioner both start from Hpp = sum Jp^T Jp
+    prm_.jacobi = opt_.preconditioner_type == 0 || opt_.preconditioner_type == 2;
     prm_.huber = S(opt_.huber_parameter);
     prm_.eps = opt_.jacobi_scaling_eps > 0 ? S(opt_.jacobi_scaling_eps) : rba::Eps<S>::eps_sqrt;
   }
@@ -574,6 +576,15 @@ class Solver final : public rba_solver {
     ++hx_calls_;
   }
 
+  // y += E0 v over the local landmarks (power-series preconditioner)
+  void launch_e0(const S* v, S* y, const int* done_flag) {
+    for_each_class([&](auto ch_tag, int begin, int end) {
+      constexpr int CH = decltype(ch_tag)::value;
+      hipLaunchKernelGGL((rba::k_e0<S, CH>), dim3((end - begin + 3) / 4), dim3(256), 0, stream_,
+                         prm_, begin, end, v, y, done_flag);
+    });
+  }
+
   void right_multiply(const void* x, void* y) override {
     use_device();
     d_vin_.upload(static_cast<const S*>(x), nvec_, stream_);
@@ -641,8 +652,28 @@ class Solver final : public rba_solver {
     // solves need 2-3 iterations), every 4th later; kernels queued past the end
     // are no-ops (`done`).
     for (int it = 1; it <= max_it; ++it) {
-      hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(),
-                         d_z_.get(), n, st, part_rho);
+      if (opt_.preconditioner_type == 2) {
+        // z = sum_{i=0..order} (Hpp^-1 E0)^i Hpp^-1 r   (PowerSCPreconditioner::solve_assign,
+        // preconditioner.hpp:180-192); d_inv_ holds Hpp^-1
+        S* t = d_pw_t_.get();
+        S* e = d_pw_e_.get();
+        hipLaunchKernelGGL((rba::k_block_apply<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(),
+                           d_r_.get(), t, static_cast<S*>(nullptr), e, n, st);
+        HIP_CHECK(hipMemcpyAsync(d_z_.get(), t, n * sizeof(S), hipMemcpyDeviceToDevice, stream_));
+        for (int i = 1; i <= opt_.power_order; ++i) {
+          launch_e0(t, e, done);
+          all_reduce(e, n);
+          // t = Hpp^-1 e; z += t; (e is re-zeroed by the next round's first kernel)
+          hipLaunchKernelGGL((rba::k_block_apply<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), e,
+                             t, d_z_.get(), static_cast<S*>(nullptr), n, st);
+          if (i < opt_.power_order) HIP_CHECK(hipMemsetAsync(e, 0, n * sizeof(S), stream_));
+        }
+        hipLaunchKernelGGL((rba::k_pcg_rho<S>), dim3(NB), dim3(T), 0, stream_, d_r_.get(), d_z_.get(),
+                           n, st, part_rho);
+      } else {
+        hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(),
+                           d_r_.get(), d_z_.get(), n, st, part_rho);
+      }
       hipLaunchKernelGGL((rba::k_pcg_a2<S>), dim3(NB), dim3(T), 0, stream_, d_z_.get(), d_p_.get(),
                          d_q_.get(), n, st, part_rho);
       launch_hx(d_p_.get(), d_q_.get(), done);
@@ -1006,7 +1037,7 @@ class Solver final : public rba_solver {
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
   DevBuf<S> d_A_, d_top0_, d_topd_, d_qtr_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;
   DevBuf<S> d_jp_diag2_, d_pose_scaling_, d_mid_, d_bb_, d_inv_;
-  DevBuf<S> d_x_, d_r_, d_p_, d_z_, d_q_, d_tmp_, d_inc_, d_vin_;
+  DevBuf<S> d_x_, d_r_, d_p_, d_z_, d_q_, d_tmp_, d_inc_, d_vin_, d_pw_t_, d_pw_e_;
   DevBuf<double> d_lm_ldiff_, d_partials_, d_pcg_partials_;
   DevBuf<rba::CgState> d_cg_;
   DevBuf<rba::SmallBatch> d_batches_;
@@ -1102,10 +1133,11 @@ int rba_create(int dtype, int device, int32_t n_cams, int32_t n_lms,
       g_last_error = "rba_create: invalid argument";
       return RBA_ERR_INVALID_ARGUMENT;
     }
-    if (options->preconditioner_type != 0 && options->preconditioner_type != 1) {
-      // the reference LOG(FATAL)s for anything else in the QR solver
-      // (linearizor_qr.cpp:208-240)
-      g_last_error = "preconditioner_type must be JACOBI (0) or SCHUR_JACOBI (1)";
+    if (options->preconditioner_type < 0 || options->preconditioner_type > 2) {
+      // the reference LOG(FATAL)s for anything but JACOBI / SCHUR_JACOBI in the QR
+      // solver (linearizor_qr.cpp:208-240); POWER_SCHUR_COMPLEMENT (2) is the new
+      // combination of BASELINE.json config 5
+      g_last_error = "preconditioner_type must be JACOBI (0), SCHUR_JACOBI (1) or POWER_SCHUR_COMPLEMENT (2)";
       return RBA_ERR_UNSUPPORTED;
     }
     int ndev = 0;

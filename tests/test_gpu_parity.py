@@ -114,6 +114,38 @@ def test_solve_and_apply(small_problem, dtype, precond):
     assert np.allclose(np.linalg.norm(cg_[:, :4], axis=1), 1.0, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_power_series_preconditioner(ladybug_far, dtype):
+    """SURVEY.md §8a row T / BASELINE config 5: PCG on the QR operator with the
+    PoBA power-series preconditioner; oracle = PowerSCPreconditioner::solve_assign
+    restated on the Schur-complement pieces."""
+    from oracle import oracle as O
+    g, o = _pair(ladybug_far, dtype, preconditioner_type=2, power_order=5)
+    gj, _ = _pair(ladybug_far, dtype, preconditioner_type=1)
+    # move to a state where the reduced system is hard (a few LM iterations in)
+    adv = O.Oracle(ladybug_far, dtype, _opts(O, max_num_iterations=3))
+    adv.optimize_lm()
+    for s_ in (g, o, gj):
+        s_.set_state(*adv.get_state())
+    assert g.linearize() == 0 and o.linearize() == 0 and gj.linearize() == 0
+    lam = 1e-6
+    ig, cg = g.solve(lam)
+    io, co = o.solve(lam)
+    ij, cj = gj.solve(lam)
+    assert cg.termination_type == co.termination_type == 1
+    assert abs(cg.num_iterations - co.num_iterations) <= (1 if dtype == np.float32 else 0)
+    if cg.num_iterations == co.num_iterations:
+        assert rel_err(ig, io) < (5e-3 if dtype == np.float32 else 1e-9)
+    assert cj.num_iterations >= 10
+    assert cg.num_iterations < cj.num_iterations  # it does precondition better than SCHUR_JACOBI
+    # whole LM run converges to the same cost as with SCHUR_JACOBI
+    g2, _ = _pair(ladybug_far, dtype, preconditioner_type=2, power_order=5, max_num_iterations=10)
+    g3, _ = _pair(ladybug_far, dtype, preconditioner_type=1, max_num_iterations=10)
+    c2 = min(r.cost for r in g2.optimize_lm()[0] if r.step_is_successful)
+    c3 = min(r.cost for r in g3.optimize_lm()[0] if r.step_is_successful)
+    assert abs(c2 - c3) / c3 < (5e-6 if dtype == np.float32 else 1e-6)
+
+
 def test_operator_is_symmetric_positive(small_problem):
     g, _ = _pair(small_problem, np.float64)
     assert g.linearize() == 0
@@ -310,7 +342,7 @@ def test_invalid_inputs_are_rejected(small_problem):
     with pytest.raises(RuntimeError, match=">= 2 observations"):  # landmark_block_base.ipp:70-73
         LinearizorHIP(one, np.float32)
     with pytest.raises(RuntimeError, match="preconditioner_type"):  # linearizor_qr.cpp:208-240
-        LinearizorHIP(small_problem, np.float32, L.default_options(preconditioner_type=2))
+        LinearizorHIP(small_problem, np.float32, L.default_options(preconditioner_type=3))
 
 
 def test_numerical_failure_is_reported_not_fatal(small_problem):

@@ -48,7 +48,7 @@ def test_cpp_loader_and_preprocessing_match_numpy_mirror(app, bal_file):
 
 def test_cli_rejects_bad_input(app, tmp_path):
     assert subprocess.run([app, "--input", str(tmp_path / "missing.txt")], capture_output=True).returncode == 2
-    assert subprocess.run([app, "--input", "x", "--preconditioner-type", "POWER_SCHUR_COMPLEMENT"],
+    assert subprocess.run([app, "--input", "x", "--preconditioner-type", "POWER_VARIABLE_PROJECTION"],
                           capture_output=True).returncode == 1
 
 

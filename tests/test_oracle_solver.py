@@ -180,3 +180,37 @@ def test_lm_reduces_cost_and_matches_across_precisions(ladybug_problem, dtype):
     rlog, _ = ref.optimize_lm()
     rcost = [r.cost for r in rlog if r.step_is_successful][-1]
     assert abs(costs[-1] - rcost) / rcost < 1e-5
+
+
+def test_power_series_preconditioner_matches_its_definition(small_problem):
+    """Row T oracle: PowerSCPreconditioner::solve_assign (preconditioner.hpp:180-245)
+    == sum_i (Hpp^-1 E0)^i Hpp^-1 built explicitly from the Schur-complement pieces
+    (the reference pins it against the PoBA solver, preconditioner.test.cpp:59-145)."""
+    lam, order = 1e-2, 6
+    o = O.Oracle(small_problem, np.float64, _opts(preconditioner_type=2, power_order=order))
+    assert o.linearize() == 0
+    n = 9 * small_problem.n_cams
+    scaling = o.pose_scaling()
+    # H_sc = Hpp - E0 (explicit SC with pose damping); Hpp block diagonal of J^T J + lam I
+    H_sc, _, _ = o.sc_build(lam, lam, scaling)
+    # JACOBI blocks: with landmark damping -> inf the Schur complement loses the E0 term
+    H_pp, _, _ = o.sc_build(1e30, lam, scaling)
+    Hpp = np.zeros((n, n))
+    for c in range(small_problem.n_cams):
+        Hpp[9 * c:9 * c + 9, 9 * c:9 * c + 9] = H_pp[9 * c:9 * c + 9, 9 * c:9 * c + 9]
+    E0 = Hpp - H_sc
+    Hinv = np.linalg.inv(Hpp)
+    M = sum(np.linalg.matrix_power(Hinv @ E0, i) @ Hinv for i in range(order + 1))
+    b = np.random.default_rng(4).normal(size=n)
+    assert rel_err(o.power_precond(lam, b), M @ b) < 1e-9
+    # and it is a better approximation of H_sc^-1 than block Jacobi
+    x_true = np.linalg.solve(H_sc, b)
+    assert np.linalg.norm(M @ b - x_true) < np.linalg.norm(Hinv @ b - x_true)
+    # PCG with it converges in fewer iterations than SCHUR_JACOBI
+    o.options  # noqa: B018
+    inc_p, cg_p = o.solve(lam)
+    o2 = O.Oracle(small_problem, np.float64, _opts(preconditioner_type=1))
+    assert o2.linearize() == 0
+    inc_j, cg_j = o2.solve(lam)
+    assert cg_p.termination_type == 1 and cg_p.num_iterations <= cg_j.num_iterations
+    assert rel_err(inc_p, inc_j) < 0.2  # both truncated at eta = 0.1
