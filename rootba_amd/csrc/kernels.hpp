@@ -196,6 +196,146 @@ __global__ __launch_bounds__(256) void k_cam_jp_diag2(Params<S> p) {
 //              JACOBI: JpS^T JpS only, add_Jp_T_Jp_blockdiag ipp:554-569)
 //   b_mid[c] = sum_obs bmO                           (add_Q2TJp_T_Q2Tr ipp:443-466)
 // Threads 0..242: 3 observation groups x 81 block entries; 243..251: b.
+// ---------------------------------------------------------------------------
+// The 9x9 tile contractions sum_obs X_o^T X_o (X_o = the 2 Jacobian rows, the 3
+// top rows or the 3 damping rows of one observation, 9 wide) run on the matrix
+// cores: v_mfma_f32_16x16x4_f32 takes 4 rows of X per instruction; both operands
+// are the SAME register because lane l holds A[i=l&15][k=l>>4] = X[k][i] and
+// B[k=l>>4][j=l&15] = X[k][j]. Exact f32 (an fmaf chain), no LDS staging of the
+// records, the accumulator tile D[(l>>4)*4+reg][l&15] is summed over the four
+// waves of the workgroup at the end. double uses the VALU path below.
+// ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// acc += sum over this wave's share of the observation list [t0, t1) of 4-row
+// tiles. The wave takes 64-observation chunks (wave w: chunks w, w+4, ...), loads
+// the chunk's indices with ONE coalesced load, broadcasts them with v_readlane and
+// keeps 8 record loads in flight ahead of the MFMAs.
+template <int ROWS_PER_OBS>
+__device__ __forceinline__ f32x4 mfma_xtx(const float* __restrict__ rec, int rec_stride,
+                                          const int* __restrict__ cam_obs, int64_t t0, int64_t t1,
+                                          int wave, int lane, f32x4 acc) {
+  const int i = lane & 15, kk = lane >> 4;
+  constexpr int OPI = ROWS_PER_OBS == 2 ? 2 : 1;  // observations per instruction
+  constexpr int U = 8;
+  for (int64_t base = t0 + 64 * wave; base < t1; base += 256) {
+    const int cnt = int(min<int64_t>(64, t1 - base));
+    const int idxreg = lane < cnt ? cam_obs[base + lane] : 0;
+    for (int s0 = 0; s0 < cnt; s0 += U * OPI) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int s = s0 + u * OPI;
+        float val = 0.f;
+        if (ROWS_PER_OBS == 2) {
+          const int oa = __builtin_amdgcn_readlane(idxreg, s & 63);
+          const int ob = __builtin_amdgcn_readlane(idxreg, (s + 1) & 63);
+          const int so = s + (kk >> 1);
+          const int o = (kk >> 1) ? ob : oa;
+          if (i < 9 && so < cnt) val = rec[int64_t(o) * rec_stride + 9 * (kk & 1) + i];
+        } else {
+          const int o = __builtin_amdgcn_readlane(idxreg, s & 63);
+          if (i < 9 && kk < 3 && s < cnt) val = rec[int64_t(o) * rec_stride + 9 * kk + i];
+        }
+        v[u] = val;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u], v[u], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+// sum over the camera's observations of a 9-vector per observation (double
+// accumulators, fixed order): thread = (group g of 28, component a); 4 loads in flight
+template <class F>
+__device__ __forceinline__ double cam_sum9(const int* __restrict__ cam_obs, int64_t t0, int64_t t1,
+                                           int g, F&& term) {
+  double acc = 0;
+  int64_t t = t0 + g;
+  for (; t + 3 * 28 < t1; t += 4 * 28) {
+    const int o0 = cam_obs[t], o1 = cam_obs[t + 28], o2 = cam_obs[t + 56], o3 = cam_obs[t + 84];
+    const float v0 = term(o0), v1 = term(o1), v2 = term(o2), v3 = term(o3);
+    acc += (double(v0) + double(v1)) + (double(v2) + double(v3));
+  }
+  for (; t < t1; t += 28) acc += double(term(cam_obs[t]));
+  return acc;
+}
+
+// float: matrix-core version
+__global__ __launch_bounds__(256) void k_cam_stage1_mfma(Params<float> p) {
+  __shared__ float tile[2][4][16][16];
+  __shared__ double bsum[28][9];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  f32x4 accJ = {0.f, 0.f, 0.f, 0.f}, accT = {0.f, 0.f, 0.f, 0.f};
+  accJ = mfma_xtx<2>(p.JpS, 18, p.cam_obs, t0, t1, wave, lane, accJ);
+  if (!p.jacobi) accT = mfma_xtx<3>(p.top0, 27, p.cam_obs, t0, t1, wave, lane, accT);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    tile[0][wave][(lane >> 4) * 4 + r][lane & 15] = accJ[r];
+    tile[1][wave][(lane >> 4) * 4 + r][lane & 15] = accT[r];
+  }
+  // b_mid: 28 groups x 9 components on the VALU, double
+  if (tid < 252) {
+    const int g = tid / 9, a = tid - 9 * g;
+    bsum[g][a] = cam_sum9(p.cam_obs, t0, t1, g, [&](int o) { return p.bmO[int64_t(o) * 9 + a]; });
+  }
+  __syncthreads();
+  if (tid < 81) {
+    const int i = tid / 9, j = tid - 9 * i;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += tile[0][w][i][j] - tile[1][w][i][j];
+    p.B_mid[81 * c + tid] = v;
+  }
+  if (tid >= 128 && tid < 137) {
+    const int a = tid - 128;
+    double acc = 0;
+    for (int g = 0; g < 28; ++g) acc += bsum[g][a];
+    p.b_mid[9 * c + a] = float(acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float lambda) {
+  __shared__ float tile[4][16][16];
+  __shared__ double bsum[28][9];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const bool damped = lambda != 0.f;
+  if (damped && !p.jacobi) acc = mfma_xtx<3>(p.dampO, 27, p.cam_obs, t0, t1, wave, lane, acc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+  if (tid < 252) {
+    const int g = tid / 9, a = tid - 9 * g;
+    double accb = 0;
+    if (damped)
+      accb = cam_sum9(p.cam_obs, t0, t1, g, [&](int o) {
+        const float* d = p.dampO + int64_t(o) * 27;
+        const float* dr = p.damp_r + 3 * int64_t(p.obs_lm[o]);
+        return d[a] * dr[0] + d[9 + a] * dr[1] + d[18 + a] * dr[2];
+      });
+    bsum[g][a] = accb;
+  }
+  __syncthreads();
+  if (tid < 81) {
+    const int i = tid / 9, j = tid - 9 * i;
+    float v = p.B_mid[81 * c + tid] + (i == j ? lambda : 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += tile[w][i][j];
+    p.blocks[81 * c + tid] = v;
+  }
+  if (tid >= 128 && tid < 137) {
+    const int a = tid - 128;
+    double accb = double(p.b_mid[9 * c + a]);
+    for (int g = 0; g < 28; ++g) accb += bsum[g][a];
+    p.b[9 * c + a] = float(accb);
+  }
+}
+
 template <class S>
 __global__ __launch_bounds__(256) void k_cam_stage1(Params<S> p) {
   constexpr int TILE = 64, W = 54, NLD = (TILE * W + 255) / 256;

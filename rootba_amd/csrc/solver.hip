@@ -501,7 +501,7 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_linearize_qr<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
                          lds, stream_, prm_, begin, end);
     });
-    hipLaunchKernelGGL((rba::k_cam_stage1<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
+    launch_cam_stage1(prm_);
     HIP_CHECK(hipGetLastError());
     int fail = 0;
     HIP_CHECK(hipMemcpyAsync(&fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -519,7 +519,7 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_stage2<S, CH>), dim3((end - begin + 3) / 4), dim3(256), 0,
                          stream_, prm_, begin, end, lambda);
     });
-    hipLaunchKernelGGL((rba::k_cam_stage2<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_, lambda);
+    launch_cam_stage2(prm_, lambda);
     if (nranks_ > 1) {
       // every rank added lambda*I and holds only its landmarks' sums: make the
       // diagonal term count once
@@ -574,6 +574,20 @@ class Solver final : public rba_solver {
     if (n_small_batches_ > 0) HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
     if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
     ++hx_calls_;
+  }
+
+  // camera-major 9x9 contractions: matrix cores for float, VALU (double accumulators) for double
+  void launch_cam_stage1(const rba::Params<float>& prm) {
+    hipLaunchKernelGGL((rba::k_cam_stage1_mfma), dim3(n_cams_), dim3(256), 0, stream_, prm);
+  }
+  void launch_cam_stage1(const rba::Params<double>& prm) {
+    hipLaunchKernelGGL((rba::k_cam_stage1<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
+  }
+  void launch_cam_stage2(const rba::Params<float>& prm, float lambda) {
+    hipLaunchKernelGGL((rba::k_cam_stage2_mfma), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
+  }
+  void launch_cam_stage2(const rba::Params<double>& prm, double lambda) {
+    hipLaunchKernelGGL((rba::k_cam_stage2<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
   }
 
   // y += E0 v over the local landmarks (power-series preconditioner)
