@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librootba_hip.so")
 SOURCES = ["solver.hip"]
-DEPS = ["solver.hip", "kernels.hpp", "device_utils.hpp", os.path.join("..", "..", "include", "rootba_hip.h")]
+DEPS = ["solver.hip", "kernels.hpp", "kernels_big.hpp", "device_utils.hpp", os.path.join("..", "..", "include", "rootba_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]

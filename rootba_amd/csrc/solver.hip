@@ -23,6 +23,7 @@
 
 #include "../../include/rootba_hip.h"
 #include "kernels.hpp"
+#include "kernels_big.hpp"
 
 namespace {
 
@@ -221,9 +222,9 @@ class Solver final : public rba_solver {
       for (int64_t q = 0; q < n_obs_; ++q) cam_obs[cur[s_obs_cam[q]]++] = int(q);
     }
     hx_bytes_ += 4 * n_obs_ + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
-    if (kmax > 7 * kClassCH[kNumClasses - 1])
+    if (kmax > rba::kBigMaxK)
       throw HipError{"landmark with " + std::to_string(kmax) + " observations: more than " +
-                         std::to_string(7 * kClassCH[kNumClasses - 1]) + " is not supported yet",
+                         std::to_string(rba::kBigMaxK) + " is not supported",
                      RBA_ERR_UNSUPPORTED};
     // class ranges (k <= 7*CH)
     int begin = 0;
@@ -233,6 +234,24 @@ class Solver final : public rba_solver {
       cls_begin_[c] = begin;
       cls_end_[c] = end;
       begin = end;
+    }
+    // everything beyond k = 112: one workgroup per landmark (kernels_big.hpp)
+    big_begin_ = begin;
+    n_big_ = n_lms - begin;
+    big_kmax_ = n_big_ > 0 ? kmax : 0;
+    if (n_big_ > 0) {
+      const size_t lds = size_t(18) * big_kmax_ * sizeof(S);  // largest request of the big kernels
+      if (lds > 160 * 1024)
+        throw HipError{"landmark with " + std::to_string(kmax) + " observations does not fit the 160 KB LDS",
+                       RBA_ERR_UNSUPPORTED};
+      if (lds > 64 * 1024) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_linearize_qr_big<S>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_big<S>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_back_substitute_big<S>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+      }
     }
 
     // batches of same-k small landmarks for the LDS-staged H*x (k <= 7)
@@ -501,6 +520,9 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_linearize_qr<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
                          lds, stream_, prm_, begin, end);
     });
+    if (n_big_ > 0)
+      hipLaunchKernelGGL((rba::k_linearize_qr_big<S>), dim3(n_big_), dim3(256),
+                         size_t(16) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_);
     launch_cam_stage1(prm_);
     HIP_CHECK(hipGetLastError());
     int fail = 0;
@@ -519,6 +541,9 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_stage2<S, CH>), dim3((end - begin + 3) / 4), dim3(256), 0,
                          stream_, prm_, begin, end, lambda);
     });
+    if (n_big_ > 0)
+      hipLaunchKernelGGL((rba::k_stage2_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
+                         lambda);
     launch_cam_stage2(prm_, lambda);
     if (nranks_ > 1) {
       // every rank added lambda*I and holds only its landmarks' sums: make the
@@ -562,6 +587,9 @@ class Solver final : public rba_solver {
                          stream2_, prm_, d_batches_.get(), x, y, done_flag);
       HIP_CHECK(hipEventRecord(ev_join_, stream2_));
     }
+    if (n_big_ > 0)
+      hipLaunchKernelGGL((rba::k_hx_big<S>), dim3(n_big_), dim3(256), size_t(18) * big_kmax_ * sizeof(S),
+                         stream_, prm_, big_begin_, x, y, done_flag);
     // largest landmarks first: the low-parallelism tail classes then overlap with
     // the bulk instead of running alone at the end
     for_each_class_reverse([&](auto ch_tag, int begin, int end) {
@@ -597,6 +625,9 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_e0<S, CH>), dim3((end - begin + 3) / 4), dim3(256), 0, stream_,
                          prm_, begin, end, v, y, done_flag);
     });
+    if (n_big_ > 0)
+      hipLaunchKernelGGL((rba::k_e0_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_, v, y,
+                         done_flag);
   }
 
   void right_multiply(const void* x, void* y) override {
@@ -731,6 +762,9 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_back_substitute<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
                          0, stream_, prm_, begin, end, d_inc_.get());
     });
+    if (n_big_ > 0)
+      hipLaunchKernelGGL((rba::k_back_substitute_big<S>), dim3(n_big_), dim3(256),
+                         size_t(9) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_, d_inc_.get());
     const int blocks = std::min(kReduceBlocks, (n_lms_ + 255) / 256);
     hipLaunchKernelGGL((rba::k_sum_ldiff), dim3(blocks), dim3(256), 0, stream_,
                        d_lm_ldiff_.get(), n_lms_, d_partials_.get());
@@ -1038,6 +1072,7 @@ class Solver final : public rba_solver {
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   std::vector<int> perm_;
   int cls_begin_[kNumClasses], cls_end_[kNumClasses];
+  int big_begin_ = 0, n_big_ = 0, big_kmax_ = 0;
   int64_t hx_bytes_ = 0, hx_flops_ = 0, storage_bytes_ = 0;
   rba::Params<S> prm_{};
   S pose_damping_ = S(0);

@@ -48,6 +48,44 @@ def mixed_k_problem():
     return prob
 
 
+@pytest.fixture(scope="module")
+def long_track_problem():
+    """A few very long tracks (k up to 300 > 112): the workgroup-per-landmark kernels."""
+    from rootba_amd import problem as P
+    k = np.concatenate([[113, 150, 200, 257, 300], np.random.default_rng(5).integers(2, 40, 120)])
+    raw = P.synthetic_problem(320, k.size, int(k.sum()), seed=23, k=k)
+    prob = P.preprocess(raw, seed=23, translation_sigma=0.3, point_sigma=0.3)
+    assert prob.obs_per_lm().max() >= 250
+    return prob
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("precond", [1, 2])
+def test_long_tracks(long_track_problem, dtype, precond):
+    prob = long_track_problem
+    tol = TOL[dtype]
+    g, o = _pair(prob, dtype, preconditioner_type=precond, power_order=3)
+    assert g.linearize() == 0 and o.linearize() == 0
+    assert rel_err(g.jl_col_scale(), o.jl_col_scale()) < tol
+    if precond == 1:
+        o.set_pose_damping(LAMBDA)
+        b_o, bl_o = o.stage2(LAMBDA, o.pose_scaling())
+        b_g, bl_g = g.stage2(LAMBDA)
+        assert rel_err(b_g, b_o) < tol and rel_err(bl_g, bl_o) < 10 * tol
+        x = np.random.default_rng(0).uniform(-1, 1, 9 * prob.n_cams).astype(dtype)
+        assert rel_err(g.right_multiply(x), o.right_multiply(x)) < tol
+        inc = (np.random.default_rng(1).uniform(-1, 1, 9 * prob.n_cams) * 0.01).astype(dtype)
+        lg, lo = g.back_substitute(inc), o.back_substitute(inc)
+        assert abs(lg - lo) / (abs(lg) + abs(lo)) < tol
+        assert rel_err(g.get_state()[1], o.get_state()[1]) < tol
+    else:
+        ig, cg = g.solve(1e-4)
+        io, co = o.solve(1e-4)
+        assert abs(cg.num_iterations - co.num_iterations) <= (1 if dtype == np.float32 else 0)
+        if cg.num_iterations == co.num_iterations:
+            assert rel_err(ig, io) < (5e-3 if dtype == np.float32 else 1e-9)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_compute_error(small_problem, dtype):
     g, o = _pair(small_problem, dtype)
