@@ -72,6 +72,7 @@ def make_problem(workload: str, args):
 
 PRECOND = {"JACOBI": 0, "SCHUR_JACOBI": 1, "POWER_SCHUR_COMPLEMENT": 2}
 _SOLVER_KW = {}
+_GPU_KW = {}  # switches that exist only in the HIP library
 
 
 def solver_options(mod, n_iter: int):
@@ -121,8 +122,11 @@ def main():
     ap.add_argument("--preconditioner", choices=sorted(PRECOND), default="SCHUR_JACOBI",
                     help="reference default: SCHUR_JACOBI")
     ap.add_argument("--power-order", type=int, default=10)
+    ap.add_argument("--implicit-q", action="store_true",
+                    help="H*x from the QR factors (SURVEY.md 8f #1) instead of the dense blocks")
     args = ap.parse_args()
     _SOLVER_KW.update(preconditioner_type=PRECOND[args.preconditioner], power_order=args.power_order)
+    _GPU_KW.update(implicit_q=int(args.implicit_q))
 
     import torch
     import torch.distributed as dist
@@ -151,7 +155,10 @@ def main():
     local = prob if world == 1 else take_landmarks(prob, lo, hi)
 
     n_iter = args.warmup + args.steps - 1  # the first warmup step is iteration 0 (evaluation)
-    lin = LinearizorHIP(local, np.float32, solver_options(L, max(n_iter, 1)), device=local_rank)
+    gpu_opts = solver_options(L, max(n_iter, 1))
+    for key, val in _GPU_KW.items():
+        setattr(gpu_opts, key, val)
+    lin = LinearizorHIP(local, np.float32, gpu_opts, device=local_rank)
     if world > 1:
         uid = [LinearizorHIP.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -225,7 +232,9 @@ def main():
                 "final_cost": [r.cost for r in rows if r.step_is_successful][-1],
             },
             "roofline": {
-                "kernel": "k_hx (H*x = sum_l A_l^T A_l x, all k-classes of one right_multiply)",
+                "kernel": ("k_hx_implicit (H*x from the QR factors; algorithmic bytes = SURVEY.md 8d implicit-Q formula)"
+                           if args.implicit_q else
+                           "k_hx (H*x = sum_l A_l^T A_l x, all k-classes of one right_multiply)"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

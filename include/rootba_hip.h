@@ -75,6 +75,9 @@ typedef struct rba_options {
   double vee_factor;
   int optimized_cost;             /* 0 ERROR, 1 ERROR_VALID, 2 ERROR_VALID_AVG    */
   int staged_execution;           /* accepted; execution is always staged         */
+  int implicit_q;                 /* 0 (default): H*x streams the dense Q2^T Jp blocks the
+                                     reference materialises; 1: same operator evaluated from
+                                     the factors (Jp, Householder vectors, damping rotations) */
 } rba_options;
 
 /* ResidualInfo (src/rootba/bal/residual_info.hpp:57-96), sums in double */

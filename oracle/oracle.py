@@ -40,6 +40,7 @@ class Options(C.Structure):
         ("vee_factor", C.c_double),
         ("optimized_cost", C.c_int),
         ("staged_execution", C.c_int),
+        ("implicit_q", C.c_int),  # product-only switch; the oracle has one operator
     ]
 
 

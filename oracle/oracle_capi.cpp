@@ -32,6 +32,7 @@ struct orc_options {
   double vee_factor;
   int optimized_cost;
   int staged_execution;
+  int implicit_q;  // product-only switch (ignored here)
 };
 
 struct orc_residual_info {
@@ -73,6 +74,7 @@ void orc_default_options(orc_options* o) {
   o->vee_factor = d.vee_factor;
   o->optimized_cost = d.optimized_cost;
   o->staged_execution = d.staged_execution;
+  o->implicit_q = 0;
 }
 
 int orc_sizeof_lm_iteration() { return int(sizeof(orc::LmIteration)); }

@@ -41,6 +41,7 @@ class RbaOptions(C.Structure):
         ("vee_factor", C.c_double),
         ("optimized_cost", C.c_int),
         ("staged_execution", C.c_int),
+        ("implicit_q", C.c_int),
     ]
 
 

@@ -30,6 +30,7 @@ void usage() {
       "  --optimized-cost ERROR|ERROR_VALID|ERROR_VALID_AVG\n"
       "  --eta <e> --max-linear-solver-iterations <n> --function-tolerance <t>\n"
       "  --jacobi-scaling-epsilon <e> --log-path <ba_log.json> --device <n>\n"
+      "  --implicit-q                           evaluate H*x from the QR factors instead of the dense blocks\n"
       "  --dry-run                              load + preprocess only, print problem statistics");
 }
 
@@ -136,6 +137,7 @@ int main(int argc, char** argv) {
     else if (a == "--log-path") log_path = val();
     else if (a == "--device") device = std::stoi(val());
     else if (a == "--dry-run") dry_run = true;
+    else if (a == "--implicit-q") so.implicit_q = true;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 1; }
   }
   if (ds.input.empty()) { usage(); return 1; }

@@ -57,6 +57,7 @@ struct SolverOptions {
   int power_order = 10;
   double initial_vee = 2.0;
   double vee_factor = 2.0;
+  bool implicit_q = false;  // not in the reference: evaluate H*x from the QR factors
   bool use_projection_validity_check() const { return optimized_cost != OptimizedCost::ERROR; }
 
   rba_options to_rba() const {
@@ -83,6 +84,7 @@ struct SolverOptions {
     o.vee_factor = vee_factor;
     o.optimized_cost = int(optimized_cost);
     o.staged_execution = staged_execution;
+    o.implicit_q = implicit_q;
     return o;
   }
 };

@@ -45,6 +45,10 @@ struct Params {
   S* dampO;     // [n_obs][3][9] copy of the damping rows (observation-major)
   S* JpS;       // [n_obs][2][9] weighted, column-scaled pose Jacobian
   S* bmO;       // [n_obs][9]    per-observation part of b from the Q2 rows
+  // implicit-Q operator (k_hx_implicit): the factors instead of the product
+  S* Vh;        // [2 n_obs][4]  Householder vectors (v0, v1, v2, Q^T r) per block row
+  S* tauH;      // [3 n_lms]     their tau
+  S* Zd;        // [9 n_lms]     3x3 map of the top rows through damp / drop-Q1 / undamp
   S* qtr;       // [2 n_obs]
   S* R0;        // [6 n_lms]
   S* Rd;        // [6 n_lms]
@@ -643,7 +647,17 @@ __global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin,
       V[4 * r + 2] = vm[2][rc];
       V[4 * r + 3] = rs[rc];
       p.qtr[2 * o0 + r] = rs[rc];
+      S* vh = p.Vh + 4 * (2 * o0 + r);
+      vh[0] = vm[0][rc];
+      vh[1] = vm[1][rc];
+      vh[2] = vm[2][rc];
+      vh[3] = rs[rc];
     }
+  }
+  if (lane == 0) {
+    p.tauH[3 * s + 0] = tau[0];
+    p.tauH[3 * s + 1] = tau[1];
+    p.tauH[3 * s + 2] = tau[2];
   }
   wave_lds_fence();
 
@@ -771,6 +785,39 @@ __global__ __launch_bounds__(256) void k_stage2(Params<S> p, int lm_begin, int l
     p.damp_r[3 * s + 0] = D[0][3];
     p.damp_r[3 * s + 1] = D[1][3];
     p.damp_r[3 * s + 2] = D[2][3];
+    // Z: what "apply the 6 damping rotations, drop the three Q1 rows, rotate back"
+    // does to the top three entries of a vector (the three extra rows start at 0
+    // and are discarded afterwards). Used by the implicit-Q operator.
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      S u[3] = {S(0), S(0), S(0)}, e[3] = {S(0), S(0), S(0)};
+      u[j] = S(1);
+      int idx = 0;
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+#pragma unroll
+        for (int m = 0; m <= n; ++m) {
+          const S x = e[n - m], y = u[n];
+          e[n - m] = gc[idx] * x + gs[idx] * y;
+          u[n] = -gs[idx] * x + gc[idx] * y;
+          ++idx;
+        }
+      }
+      u[0] = u[1] = u[2] = S(0);
+#pragma unroll
+      for (int n = 2; n >= 0; --n) {
+#pragma unroll
+        for (int m = n; m >= 0; --m) {
+          --idx;
+          const S x = e[n - m], y = u[n];
+          e[n - m] = gc[idx] * x - gs[idx] * y;
+          u[n] = gs[idx] * x + gc[idx] * y;
+        }
+      }
+      p.Zd[9 * s + 0 + j] = u[0];
+      p.Zd[9 * s + 3 + j] = u[1];
+      p.Zd[9 * s + 6 + j] = u[2];
+    }
   }
 
   S* Ablk = p.A + p.lm_blk[s];
@@ -882,6 +929,204 @@ __global__ __launch_bounds__(256) void k_hx(Params<S> p, int lm_begin, int lm_en
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch)
     if (act[ch]) atomic_add(y + yidx[ch], yr[ch]);
+}
+
+// ===========================================================================
+// Implicit-Q  H*x  (same operator as k_hx up to rounding):
+//   A^T A x = Jp^T W S^T S W^T Jp x,   W^T = (6 Givens) (H2 H1 H0),  S = drop Q1 rows
+// evaluated with the FACTORS instead of the dense (2k x 9k) product: per block
+// row the 9 Jacobian entries (JpS) and the 3 reflector entries (Vh), per landmark
+// tau[3] and the 3x3 matrix Z (damp / drop / undamp of the top rows). Only
+// orthogonal transforms are applied, never a normal-equation inverse.
+// Mapping: ONE LANE PER BLOCK ROW, a landmark occupies an aligned group of P2
+// lanes (P2 = 4..64 >= 2k), 64/P2 landmarks per wavefront; the six reflector dot
+// products are segmented DPP reductions; results are transposed through LDS so
+// that the scatter-add is 9 consecutive lanes <-> 9 consecutive floats.
+// Traffic: (9 + 4) s + 4 bytes per block row instead of 9k s.
+// ===========================================================================
+template <class S, int P2>
+__device__ __forceinline__ S seg_sum(S v) {
+  // all lanes of each aligned P2-lane group receive the group sum
+  v += dpp_mov0<0xb1>(v);  // quad_perm:[1,0,3,2]
+  v += dpp_mov0<0x4e>(v);  // quad_perm:[2,3,0,1]
+  if (P2 >= 8) v += dpp_mov0<0x141>(v);   // row_half_mirror
+  if (P2 >= 16) v += dpp_mov0<0x140>(v);  // row_mirror
+  if (P2 >= 32) v += __shfl_xor(v, 16);
+  if (P2 >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <class S, int P2>
+__global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, int lm_begin, int lm_end,
+                                                     const S* __restrict__ x, S* __restrict__ y,
+                                                     const int* __restrict__ done_flag) {
+  constexpr int LPW = 64 / P2;  // landmarks per wavefront
+  __shared__ S ybuf[4][32 * 9 + 8];
+  __shared__ int cbuf[4][32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int seg = lane / P2, r = lane - P2 * seg;
+  const int s = lm_begin + (blockIdx.x * 4 + wave) * LPW + seg;
+  if (done_flag && *done_flag) return;
+  if (lm_begin + (blockIdx.x * 4 + wave) * LPW >= lm_end) return;  // whole wave idle
+  const bool lm_ok = s < lm_end;
+  const int k = lm_ok ? p.lm_k[s] : 0;
+  const int64_t o0 = lm_ok ? p.lm_obs[s] : 0;
+  const bool act = r < 2 * k;
+  const int64_t obs = o0 + (r >> 1);
+  S jp[9], xv[9];
+  S v0 = S(0), v1 = S(0), v2 = S(0);
+  int cam = 0;
+  if (act) {
+    cam = p.obs_cam[obs];
+    const S* jrow = p.JpS + obs * 18 + 9 * (r & 1);
+    const S* vh = p.Vh + 4 * (2 * o0 + r);
+    v0 = vh[0];
+    v1 = vh[1];
+    v2 = vh[2];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) jp[c] = jrow[c];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) xv[c] = x[9 * cam + c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) jp[c] = xv[c] = S(0);
+  }
+  const S t0 = lm_ok ? p.tauH[3 * s + 0] : S(0), t1 = lm_ok ? p.tauH[3 * s + 1] : S(0),
+          t2 = lm_ok ? p.tauH[3 * s + 2] : S(0);
+  S u = S(0);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) u += jp[c] * xv[c];
+  // W^T: reflectors 0,1,2
+  u -= t0 * seg_sum<S, P2>(v0 * u) * v0;
+  u -= t1 * seg_sum<S, P2>(v1 * u) * v1;
+  u -= t2 * seg_sum<S, P2>(v2 * u) * v2;
+  // top three rows: damp, drop Q1, undamp == 3x3 matrix Z
+  {
+    const int base = lane - r;
+    const S u0 = __shfl(u, base), u1 = __shfl(u, base + 1), u2 = __shfl(u, base + 2);
+    if (act && r < 3) {
+      const S* Z = p.Zd + 9 * s + 3 * r;
+      u = Z[0] * u0 + Z[1] * u1 + Z[2] * u2;
+    }
+  }
+  // W: reflectors 2,1,0
+  u -= t2 * seg_sum<S, P2>(v2 * u) * v2;
+  u -= t1 * seg_sum<S, P2>(v1 * u) * v1;
+  u -= t0 * seg_sum<S, P2>(v0 * u) * v0;
+  // y_obs = Jp_obs^T u_obs: add the two rows of an observation (lanes r, r^1),
+  // transpose through LDS, scatter with 9-lane coalescing
+  S* yb = ybuf[wave];
+  int* cb = cbuf[wave];
+  const int obs_local = lane >> 1;  // 32 observation slots per wavefront
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    S v = jp[c] * u;
+    v += dpp_mov0<0xb1>(v);  // partner row of the same observation
+    if ((lane & 1) == 0) yb[9 * obs_local + c] = act ? v : S(0);
+  }
+  if ((lane & 1) == 0) cb[obs_local] = act ? cam : -1;
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int e = q * 64 + lane;
+    if (e < 288) {
+      const int ol = e / 9, c = e - 9 * ol;
+      const int cc = cb[ol];
+      if (cc >= 0) atomic_add(y + 9 * cc + c, yb[e]);
+    }
+  }
+}
+
+// rows of one landmark spread over RCH x 64 lanes (32 < k <= 112): one landmark
+// per wavefront, reflector sums via wave_sum
+template <class S, int RCH>
+__global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_begin, int lm_end,
+                                                          const S* __restrict__ x,
+                                                          S* __restrict__ y,
+                                                          const int* __restrict__ done_flag) {
+  __shared__ S ybuf[4][32 * 9 + 8];
+  __shared__ int cbuf[4][32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;
+  if (done_flag && *done_flag) return;
+  const int k = p.lm_k[s];
+  const int64_t o0 = p.lm_obs[s];
+  S jp[RCH][9], u[RCH], v[3][RCH];
+  int cam[RCH];
+  bool act[RCH];
+#pragma unroll
+  for (int rc = 0; rc < RCH; ++rc) {
+    const int r = rc * 64 + lane;
+    act[rc] = r < 2 * k;
+    cam[rc] = 0;
+    u[rc] = S(0);
+    v[0][rc] = v[1][rc] = v[2][rc] = S(0);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) jp[rc][c] = S(0);
+    if (act[rc]) {
+      const int64_t obs = o0 + (r >> 1);
+      cam[rc] = p.obs_cam[obs];
+      const S* jrow = p.JpS + obs * 18 + 9 * (r & 1);
+      const S* vh = p.Vh + 4 * (2 * o0 + r);
+      v[0][rc] = vh[0];
+      v[1][rc] = vh[1];
+      v[2][rc] = vh[2];
+      S acc = S(0);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        jp[rc][c] = jrow[c];
+        acc += jrow[c] * x[9 * cam[rc] + c];
+      }
+      u[rc] = acc;
+    }
+  }
+  const S tau[3] = {p.tauH[3 * s], p.tauH[3 * s + 1], p.tauH[3 * s + 2]};
+  auto reflect = [&](int m) {
+    S d = S(0);
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) d += v[m][rc] * u[rc];
+    d = tau[m] * wave_sum(d);
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) u[rc] -= d * v[m][rc];
+  };
+  reflect(0);
+  reflect(1);
+  reflect(2);
+  {
+    const S u0 = read_lane(u[0], 0), u1 = read_lane(u[0], 1), u2 = read_lane(u[0], 2);
+    if (lane < 3) {
+      const S* Z = p.Zd + 9 * s + 3 * lane;
+      u[0] = Z[0] * u0 + Z[1] * u1 + Z[2] * u2;
+    }
+  }
+  reflect(2);
+  reflect(1);
+  reflect(0);
+  S* yb = ybuf[wave];
+  int* cb = cbuf[wave];
+  const int obs_local = lane >> 1;
+#pragma unroll
+  for (int rc = 0; rc < RCH; ++rc) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      S w = jp[rc][c] * u[rc];
+      w += dpp_mov0<0xb1>(w);
+      if ((lane & 1) == 0) yb[9 * obs_local + c] = act[rc] ? w : S(0);
+    }
+    if ((lane & 1) == 0) cb[obs_local] = act[rc] ? cam[rc] : -1;
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int e = q * 64 + lane;
+      if (e < 288) {
+        const int ol = e / 9, c = e - 9 * ol;
+        const int cc = cb[ol];
+        if (cc >= 0) atomic_add(y + 9 * cc + c, yb[e]);
+      }
+    }
+    wave_lds_fence();
+  }
 }
 
 // ===========================================================================

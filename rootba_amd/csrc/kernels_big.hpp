@@ -129,7 +129,19 @@ __global__ __launch_bounds__(256) void k_linearize_qr_big(Params<S> p, int lm_be
     R[4] = V[4 + 2];
     R[5] = V[8 + 2];
   }
-  for (int r = tid; r < nrows; r += 256) p.qtr[2 * o0 + r] = V[4 * r + 3];
+  for (int r = tid; r < nrows; r += 256) {
+    p.qtr[2 * o0 + r] = V[4 * r + 3];
+    S* vh = p.Vh + 4 * (2 * o0 + r);
+    vh[0] = W[4 * r + 0];
+    vh[1] = W[4 * r + 1];
+    vh[2] = W[4 * r + 2];
+    vh[3] = V[4 * r + 3];
+  }
+  if (tid == 0) {
+    p.tauH[3 * s + 0] = tau[0];
+    p.tauH[3 * s + 1] = tau[1];
+    p.tauH[3 * s + 2] = tau[2];
+  }
 
   // column passes of 28 cameras
   S* Ablk = p.A + p.lm_blk[s];

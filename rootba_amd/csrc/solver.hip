@@ -208,6 +208,8 @@ class Solver final : public rba_solver {
       hx_bytes_ += int64_t(sizeof(S)) * 2 * k * (9 * k + pad);
       hx_flops_ += int64_t(72) * k * k;
       storage_bytes_ += int64_t(sizeof(S)) * (2 * k + 3) * (9 * k + pad + 4);
+      // implicit-Q variant, formula of SURVEY.md §8d: s * (2k (9+3) + 3 (2k+3) + 12)
+      hx_implicit_bytes_ += int64_t(sizeof(S)) * (2 * k * 12 + 3 * (2 * k + 3) + 12);
     }
     lm_obs[n_lms] = o;
     lm_blk[n_lms] = blk;
@@ -222,6 +224,7 @@ class Solver final : public rba_solver {
       for (int64_t q = 0; q < n_obs_; ++q) cam_obs[cur[s_obs_cam[q]]++] = int(q);
     }
     hx_bytes_ += 4 * n_obs_ + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
+    hx_implicit_bytes_ += 4 * n_obs_ + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
     if (kmax > rba::kBigMaxK)
       throw HipError{"landmark with " + std::to_string(kmax) + " observations: more than " +
                          std::to_string(rba::kBigMaxK) + " is not supported",
@@ -234,6 +237,19 @@ class Solver final : public rba_solver {
       cls_begin_[c] = begin;
       cls_end_[c] = end;
       begin = end;
+    }
+    // ranges of the implicit-Q operator: a landmark's 2k rows fit an aligned group of
+    // P2 = 4, 8, 16, 32, 64 lanes, or 2 / 4 x 64 lanes
+    {
+      const int kmax_of[kNumImplicit] = {2, 4, 8, 16, 32, 64, 112};
+      int b0 = 0;
+      for (int c = 0; c < kNumImplicit; ++c) {
+        int e0 = b0;
+        while (e0 < n_lms && lm_k[e0] <= kmax_of[c]) ++e0;
+        imp_begin_[c] = b0;
+        imp_end_[c] = e0;
+        b0 = e0;
+      }
     }
     // everything beyond k = 112: one workgroup per landmark (kernels_big.hpp)
     big_begin_ = begin;
@@ -317,6 +333,10 @@ class Solver final : public rba_solver {
     d_dampO_.alloc(27 * size_t(n_obs_));
     d_JpS_.alloc(18 * size_t(n_obs_));
     d_bmO_.alloc(9 * size_t(n_obs_));
+    d_Vh_.alloc(8 * size_t(n_obs_));
+    d_tauH_.alloc(3 * size_t(n_lms));
+    d_Zd_.alloc(9 * size_t(n_lms));
+    d_Zd_.zero(stream_);
     d_R0_.alloc(6 * size_t(n_lms));
     d_Rd_.alloc(6 * size_t(n_lms));
     d_q1trd_.alloc(3 * size_t(n_lms));
@@ -361,6 +381,9 @@ class Solver final : public rba_solver {
     prm_.dampO = d_dampO_.get();
     prm_.JpS = d_JpS_.get();
     prm_.bmO = d_bmO_.get();
+    prm_.Vh = d_Vh_.get();
+    prm_.tauH = d_tauH_.get();
+    prm_.Zd = d_Zd_.get();
     prm_.cams = d_cams_.get();
     prm_.lms = d_lms_.get();
     prm_.A = d_A_.get();
@@ -577,6 +600,12 @@ class Solver final : public rba_solver {
       ++hx_event_count_;
       HIP_CHECK(hipEventRecord(e0, stream_));
     }
+    if (opt_.implicit_q) {
+      launch_hx_implicit(x, y, done_flag);
+      if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
+      ++hx_calls_;
+      return;
+    }
     // The LDS-staged small-landmark kernel (latency bound) and the register-streaming
     // kernels of the larger classes run concurrently on two streams; both scatter-add
     // into y with atomics, so there is no ordering between them.
@@ -628,6 +657,32 @@ class Solver final : public rba_solver {
     if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_e0_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_, v, y,
                          done_flag);
+  }
+
+  // same operator from the factors (k_hx_implicit); long tracks use the dense kernel
+  void launch_hx_implicit(const S* x, S* y, const int* done_flag) {
+    if (n_big_ > 0)
+      hipLaunchKernelGGL((rba::k_hx_big<S>), dim3(n_big_), dim3(256), size_t(18) * big_kmax_ * sizeof(S),
+                         stream_, prm_, big_begin_, x, y, done_flag);
+    auto go = [&](auto p2_tag, int c) {
+      constexpr int P2 = decltype(p2_tag)::value;
+      const int n = imp_end_[c] - imp_begin_[c];
+      if (n <= 0) return;
+      constexpr int per_block = 4 * (64 / P2);
+      hipLaunchKernelGGL((rba::k_hx_implicit<S, P2>), dim3((n + per_block - 1) / per_block), dim3(256), 0,
+                         stream_, prm_, imp_begin_[c], imp_end_[c], x, y, done_flag);
+    };
+    if (imp_end_[6] > imp_begin_[6])
+      hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 4>), dim3((imp_end_[6] - imp_begin_[6] + 3) / 4),
+                         dim3(256), 0, stream_, prm_, imp_begin_[6], imp_end_[6], x, y, done_flag);
+    if (imp_end_[5] > imp_begin_[5])
+      hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 2>), dim3((imp_end_[5] - imp_begin_[5] + 3) / 4),
+                         dim3(256), 0, stream_, prm_, imp_begin_[5], imp_end_[5], x, y, done_flag);
+    go(std::integral_constant<int, 64>{}, 4);
+    go(std::integral_constant<int, 32>{}, 3);
+    go(std::integral_constant<int, 16>{}, 2);
+    go(std::integral_constant<int, 8>{}, 1);
+    go(std::integral_constant<int, 4>{}, 0);
   }
 
   void right_multiply(const void* x, void* y) override {
@@ -1023,7 +1078,7 @@ class Solver final : public rba_solver {
   }
   void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) override {
     *storage = storage_bytes_;
-    *hx_bytes = hx_bytes_;
+    *hx_bytes = opt_.implicit_q ? hx_implicit_bytes_ : hx_bytes_;
     *hx_flops = hx_flops_;
   }
 
@@ -1073,7 +1128,9 @@ class Solver final : public rba_solver {
   std::vector<int> perm_;
   int cls_begin_[kNumClasses], cls_end_[kNumClasses];
   int big_begin_ = 0, n_big_ = 0, big_kmax_ = 0;
-  int64_t hx_bytes_ = 0, hx_flops_ = 0, storage_bytes_ = 0;
+  static constexpr int kNumImplicit = 7;
+  int imp_begin_[kNumImplicit], imp_end_[kNumImplicit];
+  int64_t hx_bytes_ = 0, hx_flops_ = 0, storage_bytes_ = 0, hx_implicit_bytes_ = 0;
   rba::Params<S> prm_{};
   S pose_damping_ = S(0);
   bool landmark_damping_valid_ = false;
@@ -1082,7 +1139,7 @@ class Solver final : public rba_solver {
   DevBuf<int> d_lm_k_, d_obs_cam_, d_obs_lm_, d_fail_;
   DevBuf<int64_t> d_lm_obs_, d_lm_blk_, d_cam_off_;
   DevBuf<int> d_cam_obs_;
-  DevBuf<S> d_dampO_, d_JpS_, d_bmO_;
+  DevBuf<S> d_dampO_, d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_;
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
   DevBuf<S> d_A_, d_top0_, d_topd_, d_qtr_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;
   DevBuf<S> d_jp_diag2_, d_pose_scaling_, d_mid_, d_bb_, d_inv_;
@@ -1157,6 +1214,7 @@ void rba_default_options(rba_options* o) {
   o->vee_factor = 2.0;
   o->optimized_cost = 0;
   o->staged_execution = 1;
+  o->implicit_q = 0;
 }
 
 const char* rba_last_error(void) { return g_last_error.c_str(); }

@@ -33,7 +33,8 @@ def _pair(prob, dtype, **kw):
     from oracle import oracle as O
     from rootba_amd import _lib as L
     from rootba_amd.linearizor import LinearizorHIP
-    return LinearizorHIP(prob, dtype, _opts(L, **kw)), O.Oracle(prob, dtype, _opts(O, **kw))
+    okw = {k: v for k, v in kw.items() if k != "implicit_q"}  # product-only switch
+    return LinearizorHIP(prob, dtype, _opts(L, **kw)), O.Oracle(prob, dtype, _opts(O, **okw))
 
 
 @pytest.fixture(scope="module")
@@ -182,6 +183,44 @@ def test_power_series_preconditioner(ladybug_far, dtype):
     c2 = min(r.cost for r in g2.optimize_lm()[0] if r.step_is_successful)
     c3 = min(r.cost for r in g3.optimize_lm()[0] if r.step_is_successful)
     assert abs(c2 - c3) / c3 < (5e-6 if dtype == np.float32 else 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("which", ["small", "mixed", "long"])
+def test_implicit_q_operator(small_problem, mixed_k_problem, long_track_problem, dtype, which):
+    """implicit_q = 1: H*x evaluated from the factors (Jp, reflectors, damping map Z)
+    is the same operator as the dense Q2^T Jp product (and as the oracle's)."""
+    prob = {"small": small_problem, "mixed": mixed_k_problem, "long": long_track_problem}[which]
+    tol = TOL[dtype]
+    gi, o = _pair(prob, dtype, implicit_q=1)
+    gd, _ = _pair(prob, dtype)
+    assert gi.linearize() == 0 and gd.linearize() == 0 and o.linearize() == 0
+    rng = np.random.default_rng(0)
+    for lam in (LAMBDA, 0.0, 1e-6):
+        o.set_pose_damping(lam)
+        o.stage2(lam, o.pose_scaling() if lam == LAMBDA else None)
+        gi.stage2(lam)
+        gd.stage2(lam)
+        x = rng.uniform(-1, 1, 9 * prob.n_cams).astype(dtype)
+        h_o, h_i, h_d = o.right_multiply(x), gi.right_multiply(x), gd.right_multiply(x)
+        assert rel_err(h_i, h_o) < tol and rel_err(h_i, h_d) < tol
+    # full solve on a fresh pair (the oracle scales Jp inside its first stage 2)
+    gi2, o2 = _pair(prob, dtype, implicit_q=1)
+    assert gi2.linearize() == 0 and o2.linearize() == 0
+    ii, ci = gi2.solve(1e-4)
+    io, co = o2.solve(1e-4)
+    assert abs(ci.num_iterations - co.num_iterations) <= (1 if dtype == np.float32 else 0)
+    if ci.num_iterations == co.num_iterations:
+        assert rel_err(ii, io) < (2e-3 if dtype == np.float32 else 1e-9)
+
+
+def test_implicit_q_lm_run(ladybug_far):
+    gi, o = _pair(ladybug_far, np.float64, implicit_q=1, max_num_iterations=8)
+    li, _ = gi.optimize_lm()
+    lo, _ = o.optimize_lm()
+    assert len(li) == len(lo)
+    assert np.allclose([r.cost for r in li], [r.cost for r in lo], rtol=1e-9)
+    assert [r.cg_iterations for r in li] == [r.cg_iterations for r in lo]
 
 
 def test_operator_is_symmetric_positive(small_problem):
