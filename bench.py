@@ -203,7 +203,7 @@ def main():
         achieved = stats["hx_bytes"] / avg_hx / 1e9 if avg_hx else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hx_traffic.json")
-        if os.path.exists(tpath) and world == 1:
+        if os.path.exists(tpath) and world == 1 and not args.implicit_q:
             try:
                 with open(tpath) as f:
                     traffic = json.load(f).get(args.workload, {}).get("traffic_bytes_per_launch")

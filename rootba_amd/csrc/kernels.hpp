@@ -49,6 +49,14 @@ struct Params {
   S* Vh;        // [2 n_obs][4]  Householder vectors (v0, v1, v2, Q^T r) per block row
   S* tauH;      // [3 n_lms]     their tau
   S* Zd;        // [9 n_lms]     3x3 map of the top rows through damp / drop-Q1 / undamp
+  // wave-tiled copies for k <= 32 (one lane per block row, landmark = aligned group
+  // of P2 lanes, see k_hx_implicit): fully coalesced, no index hops
+  S* JT;                             // [tiles][9][64] scaled Jacobian rows
+  S* VT;                             // [tiles][3][64] reflector entries
+  const int* __restrict__ CT;        // [tiles][64]    camera of the row's observation, -1 = padding
+  const int* __restrict__ lm_tile;   // [n_lms] tile of the landmark (-1: not tiled)
+  const int* __restrict__ lm_lane0;  // [n_lms] first lane of the landmark inside its tile
+  int implicit;                      // write the tiled copies in stage 1
   S* qtr;       // [2 n_obs]
   S* R0;        // [6 n_lms]
   S* Rd;        // [6 n_lms]
@@ -652,6 +660,12 @@ __global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin,
       vh[1] = vm[1][rc];
       vh[2] = vm[2][rc];
       vh[3] = rs[rc];
+      if (p.implicit && p.lm_tile[s] >= 0) {
+        S* vt = p.VT + size_t(p.lm_tile[s]) * 192 + p.lm_lane0[s] + r;
+        vt[0] = vm[0][rc];
+        vt[64] = vm[1][rc];
+        vt[128] = vm[2][rc];
+      }
     }
   }
   if (lane == 0) {
@@ -705,6 +719,11 @@ __global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin,
       p.JpS[(o0 + i) * 18 + comp] = m0;
       p.JpS[(o0 + i) * 18 + 9 + comp] = m1;
       p.bmO[(o0 + i) * 9 + comp] = bm;
+      if (p.implicit && p.lm_tile[s] >= 0) {
+        S* jt = p.JT + (size_t(p.lm_tile[s]) * 9 + comp) * 64 + p.lm_lane0[s] + 2 * i;
+        jt[0] = m0;
+        jt[1] = m1;
+      }
     }
   }
 }
@@ -956,46 +975,50 @@ __device__ __forceinline__ S seg_sum(S v) {
   return v;
 }
 
+struct ImplicitTiles {
+  int tile_begin[6];  // first tile of class c (P2 = 4 << c); [5] = total
+  int lm_begin[5];    // first landmark of class c
+  int lm_end[5];
+};
+
 template <class S, int P2>
-__global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, int lm_begin, int lm_end,
-                                                     const S* __restrict__ x, S* __restrict__ y,
-                                                     const int* __restrict__ done_flag) {
-  constexpr int LPW = 64 / P2;  // landmarks per wavefront
-  __shared__ S ybuf[4][32 * 9 + 8];
-  __shared__ int cbuf[4][32];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, int t_in_class,
+                                                 int lm_begin, int lm_end, const S* __restrict__ x,
+                                                 S* __restrict__ y, S* yb, int* cb, int lane,
+                                                 int done) {
+  constexpr int LPW = 64 / P2;  // landmarks per wavefront (= per tile)
   const int seg = lane / P2, r = lane - P2 * seg;
-  const int s = lm_begin + (blockIdx.x * 4 + wave) * LPW + seg;
-  if (done_flag && *done_flag) return;
-  if (lm_begin + (blockIdx.x * 4 + wave) * LPW >= lm_end) return;  // whole wave idle
+  const int s = lm_begin + t_in_class * LPW + seg;
   const bool lm_ok = s < lm_end;
-  const int k = lm_ok ? p.lm_k[s] : 0;
-  const int64_t o0 = lm_ok ? p.lm_obs[s] : 0;
-  const bool act = r < 2 * k;
-  const int64_t obs = o0 + (r >> 1);
-  S jp[9], xv[9];
-  S v0 = S(0), v1 = S(0), v2 = S(0);
-  int cam = 0;
-  if (act) {
-    cam = p.obs_cam[obs];
-    const S* jrow = p.JpS + obs * 18 + 9 * (r & 1);
-    const S* vh = p.Vh + 4 * (2 * o0 + r);
-    v0 = vh[0];
-    v1 = vh[1];
-    v2 = vh[2];
+  // everything is addressed by (tile, lane) only: no index hops, 256-byte rows
+  const int cam = p.CT[T * 64 + lane];
+  const bool act = cam >= 0;
+  S jp[9];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) jp[c] = jrow[c];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) xv[c] = x[9 * cam + c];
-  } else {
-#pragma unroll
-    for (int c = 0; c < 9; ++c) jp[c] = xv[c] = S(0);
-  }
+  for (int c = 0; c < 9; ++c) jp[c] = p.JT[(T * 9 + c) * 64 + lane];
+  const S v0 = p.VT[(T * 3 + 0) * 64 + lane], v1 = p.VT[(T * 3 + 1) * 64 + lane],
+          v2 = p.VT[(T * 3 + 2) * 64 + lane];
   const S t0 = lm_ok ? p.tauH[3 * s + 0] : S(0), t1 = lm_ok ? p.tauH[3 * s + 1] : S(0),
           t2 = lm_ok ? p.tauH[3 * s + 2] : S(0);
+  // gather x for the 32 observation slots of the tile with 9-lane coalescing
+  // (lanes as (slot, component)), hand it to the row lanes through LDS
+  const int obs_local = lane >> 1;
+  if ((lane & 1) == 0) cb[obs_local] = cam;
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int e = q * 64 + lane;
+    if (e < 288) {
+      const int ol = e / 9, c = e - 9 * ol;
+      const int cc = cb[ol];
+      yb[e] = cc >= 0 ? x[9 * cc + c] : S(0);
+    }
+  }
+  wave_lds_fence();
   S u = S(0);
 #pragma unroll
-  for (int c = 0; c < 9; ++c) u += jp[c] * xv[c];
+  for (int c = 0; c < 9; ++c) u += jp[c] * yb[9 * obs_local + c];
+  wave_lds_fence();
   // W^T: reflectors 0,1,2
   u -= t0 * seg_sum<S, P2>(v0 * u) * v0;
   u -= t1 * seg_sum<S, P2>(v1 * u) * v1;
@@ -1014,27 +1037,53 @@ __global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, int lm_begin, 
   u -= t1 * seg_sum<S, P2>(v1 * u) * v1;
   u -= t0 * seg_sum<S, P2>(v0 * u) * v0;
   // y_obs = Jp_obs^T u_obs: add the two rows of an observation (lanes r, r^1),
-  // transpose through LDS, scatter with 9-lane coalescing
-  S* yb = ybuf[wave];
-  int* cb = cbuf[wave];
-  const int obs_local = lane >> 1;  // 32 observation slots per wavefront
+  // transpose through LDS so that 9 consecutive lanes hold one observation
 #pragma unroll
   for (int c = 0; c < 9; ++c) {
     S v = jp[c] * u;
     v += dpp_mov0<0xb1>(v);  // partner row of the same observation
     if ((lane & 1) == 0) yb[9 * obs_local + c] = act ? v : S(0);
   }
-  if ((lane & 1) == 0) cb[obs_local] = act ? cam : -1;
   wave_lds_fence();
+  // (measured: this scatter is ~100 of the kernel's ~265 us on venice - about 7.5 M
+  //  36-byte requests; pre-aggregating per workgroup after sorting landmarks by camera
+  //  made it worse because same-address atomics serialise)
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     const int e = q * 64 + lane;
     if (e < 288) {
       const int ol = e / 9, c = e - 9 * ol;
       const int cc = cb[ol];
-      if (cc >= 0) atomic_add(y + 9 * cc + c, yb[e]);
+      if (cc >= 0 && !done) atomic_add(y + 9 * cc + c, yb[e]);
     }
   }
+}
+
+// all tiled classes (k <= 32) in ONE launch: wave -> tile -> class
+template <class S>
+__global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, ImplicitTiles it,
+                                                     const S* __restrict__ x, S* __restrict__ y,
+                                                     const int* __restrict__ done_flag) {
+  __shared__ S ybuf[4][32 * 9 + 8];
+  __shared__ int cbuf[4][32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int T = blockIdx.x * 4 + wave;
+  if (T >= it.tile_begin[5]) return;  // whole wave idle
+  // the PCG "done" flag is fetched alongside the data and only gates the scatter, so
+  // it does not add a memory round trip in front of the loads
+  const int done = done_flag ? *done_flag : 0;
+  S* yb = ybuf[wave];
+  int* cb = cbuf[wave];
+  if (T >= it.tile_begin[4])
+    hx_implicit_tile<S, 64>(p, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], x, y, yb, cb, lane, done);
+  else if (T >= it.tile_begin[3])
+    hx_implicit_tile<S, 32>(p, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], x, y, yb, cb, lane, done);
+  else if (T >= it.tile_begin[2])
+    hx_implicit_tile<S, 16>(p, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], x, y, yb, cb, lane, done);
+  else if (T >= it.tile_begin[1])
+    hx_implicit_tile<S, 8>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], x, y, yb, cb, lane, done);
+  else
+    hx_implicit_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], x, y, yb, cb, lane, done);
 }
 
 // rows of one landmark spread over RCH x 64 lanes (32 < k <= 112): one landmark
