@@ -120,6 +120,14 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m rootba_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch ships its own ROCm runtime (libamdhip64.so.7, libhsa-runtime64, librccl.so.1)
+        # under the same SONAMEs as /opt/rocm: whichever is loaded first serves the whole
+        # process. A mixed pair breaks RCCL ("no ROCm-capable device is detected" inside
+        # ncclCommInitRank), so when PyTorch is installed it goes first, as in bench.py.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.rba_last_error.restype = C.c_char_p
     return _lib

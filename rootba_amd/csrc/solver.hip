@@ -315,9 +315,7 @@ class Solver final : public rba_solver {
         int nbatch = kSmallBatchesPerBlock;
         if (const char* ev = std::getenv("RBA_SMALL_NB")) nbatch = std::max(1, std::atoi(ev));
         const int span = gmax * nbatch;
-        const char* only_k = std::getenv("RBA_EXPERIMENT_ONLY_K");  // timing experiments only
         for (int b0 = s; b0 < e; b0 += span) {
-          if (only_k && std::atoi(only_k) != k) break;
           const int count = std::min(span, e - b0);
           const int G = std::min(gmax, count);
           batches.push_back(rba::SmallBatch{b0, G, k, count, lm_blk[b0], lm_obs[b0]});
@@ -473,7 +471,9 @@ class Solver final : public rba_solver {
 
   // ---- multi-GPU ------------------------------------------------------------
   void comm_init(int rank, int nranks, const void* uid) override {
-    if (nranks <= 1) return;
+    // nranks == 1 is allowed on purpose: a one-rank communicator exercises the whole
+    // RCCL call path (dlopen, unique id, every all-reduce site) on a single-GPU box
+    if (nranks < 1) return;
     if (!g_rccl.load()) throw HipError{"cannot load librccl.so", RBA_ERR_COMM};
     Rccl::UniqueId id;
     std::memcpy(&id, uid, sizeof(id));
@@ -493,7 +493,7 @@ class Solver final : public rba_solver {
 
   template <class T>
   void all_reduce(T* buf, size_t count, int op = kNcclSum) {
-    if (nranks_ <= 1) return;
+    if (!comm_ && !cb_fn_) return;
     if (cb_fn_) {
       // caller-provided collective on a host staging buffer (MPI, gloo, ...)
       cb_stage_.resize(count * sizeof(T));
@@ -613,7 +613,7 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_stage2_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
                          lambda);
     launch_cam_stage2(prm_, lambda);
-    if (nranks_ > 1) {
+    if (comm_ || cb_fn_) {
       // every rank added lambda*I and holds only its landmarks' sums: make the
       // diagonal term count once
       all_reduce(d_bb_.get(), size_t(90) * n_cams_);

@@ -95,3 +95,26 @@ def test_two_ranks_one_gpu_match_unsharded(dtype):
     for a, (cost, cgi, ok) in zip(log, r0["lm"]):
         assert a.step_is_successful == ok
         assert abs(a.cost - cost) <= (1e-5 if dtype == np.float32 else 1e-9) * cost
+
+
+def test_rccl_call_path_with_one_rank(ladybug_problem):
+    """A one-rank RCCL communicator: dlopen, ncclGetUniqueId, ncclCommInitRank and
+    every ncclAllReduce site of the library run on this single-GPU box; the
+    results must equal the run without a communicator."""
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    opts = dict(robust_norm=1, max_num_iterations=4)
+    a = LinearizorHIP(ladybug_problem, np.float32, L.default_options(**opts))
+    b = LinearizorHIP(ladybug_problem, np.float32, L.default_options(**opts))
+    uid = LinearizorHIP.comm_unique_id()
+    assert len(uid) == 128
+    b.comm_init(0, 1, uid)
+    assert a.linearize() == 0 and b.linearize() == 0
+    ba, bla = a.stage2(0.1)
+    bb, blb = b.stage2(0.1)
+    assert np.array_equal(ba, bb) and np.array_equal(bla, blb)
+    la, _ = a.optimize_lm()
+    lb, _ = b.optimize_lm()
+    assert len(la) == len(lb)
+    assert np.allclose([r.cost for r in la], [r.cost for r in lb], rtol=1e-6)
