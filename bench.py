@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--steps", type=int, default=18)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="venice-1778")
-    ap.add_argument("--cpu-baseline-iters", type=int, default=2,
+    ap.add_argument("--cpu-baseline-iters", type=int, default=4,
                     help="LM iterations of the CPU oracle timed beside the GPU (0 = skip)")
     ap.add_argument("--translation-sigma", type=float, default=0.5)
     ap.add_argument("--point-sigma", type=float, default=0.5)
