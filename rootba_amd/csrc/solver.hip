@@ -162,6 +162,7 @@ class Solver final : public rba_solver {
     HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     n_obs_ = lm_off[n_lms];
     nvec_ = 9 * n_cams_;
+    if (const char* ev = std::getenv("RBA_HX_SINGLE_STREAM")) hx_single_stream_ = std::atoi(ev) != 0;
 
     // ---- sort landmarks by number of observations (stable) ----------------
     perm_.resize(n_lms);
@@ -654,12 +655,17 @@ class Solver final : public rba_solver {
     // The LDS-staged small-landmark kernel (latency bound) and the register-streaming
     // kernels of the larger classes run concurrently on two streams; both scatter-add
     // into y with atomics, so there is no ordering between them.
-    if (n_small_batches_ > 0) {
+    // (RBA_HX_SINGLE_STREAM=1 serialises them, for per-kernel profiles that add up)
+    const bool two_streams = n_small_batches_ > 0 && !hx_single_stream_;
+    if (two_streams) {
       HIP_CHECK(hipEventRecord(ev_fork_, stream_));
       HIP_CHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
       hipLaunchKernelGGL((rba::k_hx_small<S>), dim3(n_small_batches_), dim3(256), small_lds_bytes_,
                          stream2_, prm_, d_batches_.get(), x, y, done_flag);
       HIP_CHECK(hipEventRecord(ev_join_, stream2_));
+    } else if (n_small_batches_ > 0) {
+      hipLaunchKernelGGL((rba::k_hx_small<S>), dim3(n_small_batches_), dim3(256), small_lds_bytes_,
+                         stream_, prm_, d_batches_.get(), x, y, done_flag);
     }
     if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_hx_big<S>), dim3(n_big_), dim3(256), size_t(18) * big_kmax_ * sizeof(S),
@@ -673,7 +679,7 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_hx<S, CH, U>), dim3((end - begin + 3) / 4), dim3(256), 0,
                          stream_, prm_, begin, end, x, y, done_flag);
     });
-    if (n_small_batches_ > 0) HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
+    if (two_streams) HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
     if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
     ++hx_calls_;
   }
@@ -1198,6 +1204,7 @@ class Solver final : public rba_solver {
   hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
   std::vector<hipEvent_t> hx_events_;
   int hx_event_count_ = 0, hx_calls_ = 0;
+  bool hx_single_stream_ = false;
   // LM state machine
   struct LmState {
     bool active = false, terminated = false, need_linearize = true;
