@@ -1047,7 +1047,10 @@ __device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, i
   wave_lds_fence();
   // (measured: this scatter is ~100 of the kernel's ~265 us on venice - about 7.5 M
   //  36-byte requests; pre-aggregating per workgroup after sorting landmarks by camera
-  //  made it worse because same-address atomics serialise)
+  //  made it worse because same-address atomics serialise; accumulating into a
+  //  workgroup-private 64 KB LDS copy of y with ds_add_f32 from persistent 1024-thread
+  //  workgroups, with or without register prefetch of the next tile, also measured
+  //  slower: 318 us. A flat atomic on an LDS pointer faults on gfx950, by the way.)
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     const int e = q * 64 + lane;
