@@ -42,7 +42,7 @@ def build_app(force: bool = False, verbose: bool = False) -> str:
         os.path.getmtime(os.path.join(CSRC, d)) > os.path.getmtime(APP) for d in HOST_DEPS)
         or os.path.getmtime(LIB) > os.path.getmtime(APP))
     if force or stale:
-        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", os.path.join(CSRC, "host", "bal_qr_hip.cpp"),
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-pthread", os.path.join(CSRC, "host", "bal_qr_hip.cpp"),
                "-o", APP, "-L" + HERE, "-lrootba_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))

@@ -6,18 +6,32 @@
 // normalisation (:428-469), perturbation (:508-554), depth filtering (:471-506),
 // the flat camera state of `Camera::params()` (bal_problem.hpp:84-95) and the
 // load pipeline order of `load_normalized_bal_problem` (:794-832).
-// Own implementation on plain arrays (no Eigen/Sophus); one-off host work,
-// outside the accelerated hot path.
+// Own implementation on plain arrays (no Eigen/Sophus). One-off host work outside
+// the accelerated hot path, but it dominates end-to-end time on the large
+// problems, so the loader is a parallel tokeniser straight into the CSR/SoA
+// layout of the C ABI.
 #pragma once
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <cfloat>
+#include <charconv>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -100,67 +114,272 @@ inline double median_upper(std::vector<double>& v) {
   std::nth_element(v.begin(), mid, v.end());
   return *mid;
 }
+// number of worker threads for the one-off host passes (loader, filter)
+inline int host_threads() {
+  if (const char* e = std::getenv("RBA_HOST_THREADS")) return std::max(1, std::atoi(e));
+  return int(std::max(1u, std::min(64u, std::thread::hardware_concurrency())));
+}
+template <class F>
+inline void parallel_for(size_t n, int threads, F&& f) {  // f(begin, end, thread)
+  threads = int(std::max<size_t>(1, std::min<size_t>(threads, n)));
+  if (threads == 1) return f(size_t(0), n, 0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([&, t] { f(n * t / threads, n * (t + 1) / threads, t); });
+  for (auto& th : pool) th.join();
+}
+inline bool is_space(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; }
+
+// Decimal text -> double, correctly rounded like fscanf("%lf"). Up to 15 significant
+// digits and |exponent| <= 22 the value is m * 10^e with both factors exact in double
+// (one rounding, Clinger's fast path). BAL files carry 17 digits ("%.16e"): up to 19
+// digits and |exponent| <= 27 both factors are exact in the x87 64-bit mantissa, the
+// product has one rounding there, and narrowing it to 53 bits is the correctly rounded
+// result unless the 64-bit value sits next to a rounding midpoint — detected from its low
+// 11 bits, about 3 in 2048 tokens — which, like everything else, goes through strtod.
+// (libstdc++ 11's std::from_chars<double> wraps strtod in newlocale/uselocale, which
+// takes a process-wide lock and does not scale over threads.)
+// Returns the end of the token or nullptr.
+inline const char* parse_double(const char* c, const char* stop, double& out) {
+  static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                    1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const char* const begin = c;
+  bool neg = false;
+  if (c < stop && (*c == '-' || *c == '+')) neg = *c++ == '-';
+  uint64_t m = 0;
+  int sig = 0, exp10 = 0, ndig = 0;
+  for (; c < stop && *c >= '0' && *c <= '9'; ++c, ++ndig) {
+    if (sig > 0 || *c != '0') ++sig;
+    if (sig <= 19) m = m * 10 + uint64_t(*c - '0'); else ++exp10;
+  }
+  if (c < stop && *c == '.') {
+    for (++c; c < stop && *c >= '0' && *c <= '9'; ++c, ++ndig) {
+      if (sig > 0 || *c != '0') ++sig;
+      if (sig <= 19) { m = m * 10 + uint64_t(*c - '0'); --exp10; }
+    }
+  }
+  if (ndig == 0) return nullptr;
+  if (c < stop && (*c == 'e' || *c == 'E')) {
+    const char* e = c + 1;
+    bool eneg = false;
+    if (e < stop && (*e == '-' || *e == '+')) eneg = *e++ == '-';
+    int ev = 0, ed = 0;
+    for (; e < stop && *e >= '0' && *e <= '9'; ++e, ++ed) ev = std::min(ev * 10 + (*e - '0'), 100000);
+    if (ed == 0) return nullptr;
+    exp10 += eneg ? -ev : ev;
+    c = e;
+  }
+  if (sig <= 15 && exp10 >= -22 && exp10 <= 22) {
+    const double v = exp10 < 0 ? double(m) / kPow10[-exp10] : double(m) * kPow10[exp10];
+    out = neg ? -v : v;
+    return c;
+  }
+#if LDBL_MANT_DIG == 64
+  if (sig <= 19 && exp10 >= -27 && exp10 <= 27) {
+    static const struct Pow10L {
+      long double v[28];
+      Pow10L() {
+        v[0] = 1.0L;
+        for (int i = 1; i < 28; ++i) v[i] = v[i - 1] * 10.0L;  // exact: 5^27 < 2^63
+      }
+    } kPow10L;
+    const long double v = exp10 < 0 ? static_cast<long double>(m) / kPow10L.v[-exp10]
+                                    : static_cast<long double>(m) * kPow10L.v[exp10];
+    uint64_t mant;
+    std::memcpy(&mant, &v, sizeof(mant));
+    const unsigned low = unsigned(mant & 0x7FFu);
+    if (low < 0x3FFu || low > 0x401u) {
+      const double d = static_cast<double>(v);
+      out = neg ? -d : d;
+      return c;
+    }
+  }
+#endif
+  // slow path: strtod needs a terminated token
+  const std::string tok(begin, c);
+  char* endp = nullptr;
+  out = std::strtod(tok.c_str(), &endp);
+  return endp == tok.c_str() + tok.size() ? c : nullptr;
+}
+
+// read-only mapping of a whole file
+struct MappedFile {
+  const char* data = nullptr;
+  size_t size = 0;
+  explicit MappedFile(const std::string& path) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("Could not open '" + path + "'");
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || st.st_size <= 0) {
+      ::close(fd);
+      throw std::runtime_error("Failed to parse '" + path + "'");
+    }
+    size = size_t(st.st_size);
+    // MAP_POPULATE: one in-kernel pass instead of a page fault per 4 KB from every parser thread
+    void* m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) throw std::runtime_error("Could not map '" + path + "'");
+    data = static_cast<const char*>(m);
+  }
+  ~MappedFile() {
+    if (data) ::munmap(const_cast<char*>(data), size);
+  }
+  MappedFile(const MappedFile&) = delete;
+  MappedFile& operator=(const MappedFile&) = delete;
+};
 }  // namespace detail
 
+// Flat CSR / SoA storage — the layout `rba_create` takes (include/rootba_hip.h), so
+// loading goes from the text file to the device without a per-landmark container
+// (the reference keeps a std::map per landmark, bal_problem.hpp:117-127).
 template <class Scalar>
 class BalProblem {
  public:
   static constexpr int CAM_STATE_SIZE = 10;  // qx qy qz qw tx ty tz f k1 k2
 
-  struct Observation {
-    int cam;
-    Scalar x, y;
-  };
-  struct Landmark {
-    std::array<Scalar, 3> p_w;
-    std::vector<Observation> obs;  // ascending camera index (std::map order)
-  };
-
   std::vector<std::array<Scalar, 10>> cameras;
-  std::vector<Landmark> landmarks;
+  std::vector<std::array<Scalar, 3>> points;  // landmark positions p_w
+  std::vector<int64_t> lm_off;                // [num_landmarks + 1] observation ranges
+  std::vector<int32_t> obs_cam;               // ascending camera index inside a landmark (std::map order)
+  std::vector<Scalar> obs_xy;                 // 2 per observation
 
   int num_cameras() const { return int(cameras.size()); }
-  int num_landmarks() const { return int(landmarks.size()); }
-  int64_t num_observations() const {
-    int64_t n = 0;
-    for (const auto& l : landmarks) n += int64_t(l.obs.size());
-    return n;
-  }
+  int num_landmarks() const { return int(points.size()); }
+  int64_t num_observations() const { return int64_t(obs_cam.size()); }
 
   // BAL text format: header, observations (cam lm x y), 9 parameters per camera
-  // (Rodrigues, t, f, k1, k2), 3 per landmark. The camera looks down -z with y up
+  // (Rodrigues, t, f, k1, k2), 3 per landmark (reference bal_problem.cpp:190-282, which
+  // reads it with fscanf into a map per landmark). The camera looks down -z with y up
   // in BAL; here +z forward / y down, so y and z axes are flipped on load.
-  void load_bal(const std::string& path) {
-    FILE* f = std::fopen(path.c_str(), "r");
-    if (!f) throw std::runtime_error("Could not open '" + path + "'");
-    auto fail = [&]() {
-      std::fclose(f);
-      throw std::runtime_error("Failed to parse '" + path + "'");
-    };
-    int nc, nl, no;
-    if (std::fscanf(f, "%d %d %d", &nc, &nl, &no) != 3 || nc <= 0 || nl <= 0 || no <= 0) fail();
-    cameras.assign(nc, {});
-    landmarks.assign(nl, {});
-    for (int i = 0; i < no; ++i) {
-      int c, l;
-      double x, y;
-      if (std::fscanf(f, "%d %d %lf %lf", &c, &l, &x, &y) != 4) fail();
-      if (c < 0 || c >= nc || l < 0 || l >= nl) fail();
-      landmarks[l].obs.push_back({c, Scalar(x), Scalar(-y)});
+  // Parallel two-pass tokeniser over the memory-mapped file: pass 1 counts the tokens
+  // of each chunk, pass 2 converts them knowing their global index; observations are
+  // then bucketed by landmark with a counting sort.
+  void load_bal(const std::string& path, int threads = 0) {
+    if (threads <= 0) threads = detail::host_threads();
+    const detail::MappedFile file(path);
+    const char* const base = file.data;
+    const char* const end = base + file.size;
+    auto fail = [&]() -> void { throw std::runtime_error("Failed to parse '" + path + "'"); };
+
+    // header
+    const char* cur = base;
+    long long hdr[3];
+    for (long long& h : hdr) {
+      while (cur < end && detail::is_space(*cur)) ++cur;
+      const auto r = std::from_chars(cur, end, h);
+      if (r.ec != std::errc() || h <= 0) fail();
+      cur = r.ptr;
     }
-    for (auto& lm : landmarks) {
-      std::sort(lm.obs.begin(), lm.obs.end(), [](const Observation& a, const Observation& b) { return a.cam < b.cam; });
-      for (size_t i = 1; i < lm.obs.size(); ++i)
-        if (lm.obs[i].cam == lm.obs[i - 1].cam) {
-          std::fclose(f);
-          throw std::runtime_error("Invalid file '" + path + "'");  // duplicate (camera, landmark)
+    const int64_t nc = hdr[0], nl = hdr[1], no = hdr[2];
+    if (nc > INT32_MAX || nl > INT32_MAX) fail();
+    const int64_t n_tokens = 4 * no + 9 * nc + 3 * nl;
+
+    // chunk boundaries on whitespace
+    const size_t body = size_t(end - cur);
+    const int T = int(std::max<size_t>(1, std::min<size_t>(size_t(threads), body / 4096 + 1)));
+    std::vector<const char*> cut(T + 1);
+    cut[0] = cur;
+    cut[T] = end;
+    for (int t = 1; t < T; ++t) {
+      const char* c = cur + body * t / T;
+      while (c < end && !detail::is_space(*c)) ++c;
+      cut[t] = c;
+    }
+    std::vector<int64_t> first_token(T + 1, 0);
+    detail::parallel_for(size_t(T), T, [&](size_t b, size_t e, int) {
+      for (size_t t = b; t < e; ++t) {
+        int64_t n = 0;
+        bool in_tok = false;
+        for (const char* c = cut[t]; c < cut[t + 1]; ++c) {
+          const bool sp = detail::is_space(*c);
+          n += (!sp && !in_tok);
+          in_tok = !sp;
         }
+        first_token[t + 1] = n;
+      }
+    });
+    for (int t = 0; t < T; ++t) first_token[t + 1] += first_token[t];
+    if (first_token[T] < n_tokens) fail();  // trailing tokens are ignored like fscanf would
+
+    std::vector<int32_t> raw_cam(no), raw_lm(no);
+    std::vector<double> raw_xy(size_t(2) * no), params(size_t(9) * nc + size_t(3) * nl);
+    std::atomic<bool> bad{false};
+    detail::parallel_for(size_t(T), T, [&](size_t b, size_t e, int) {
+      for (size_t t = b; t < e; ++t) {
+        int64_t tok = first_token[t];
+        const char* c = cut[t];
+        const char* const stop = cut[t + 1];
+        while (tok < n_tokens) {
+          while (c < stop && detail::is_space(*c)) ++c;
+          if (c >= stop) break;
+          if (tok < 4 * no) {
+            const int64_t o = tok >> 2;
+            const int field = int(tok & 3);
+            if (field < 2) {
+              long long v = -1;
+              const auto r = std::from_chars(c, stop, v);
+              if (r.ec != std::errc() || v < 0 || v >= (field == 0 ? nc : nl)) return bad.store(true);
+              (field == 0 ? raw_cam : raw_lm)[o] = int32_t(v);
+              c = r.ptr;
+            } else {
+              double v;
+              c = detail::parse_double(c, stop, v);
+              if (!c) return bad.store(true);
+              raw_xy[2 * o + (field - 2)] = field == 3 ? -v : v;
+            }
+          } else {
+            double v;
+            c = detail::parse_double(c, stop, v);
+            if (!c) return bad.store(true);
+            params[tok - 4 * no] = v;
+          }
+          if (c < stop && !detail::is_space(*c)) return bad.store(true);  // e.g. "1.5" where an index belongs
+          ++tok;
+        }
+      }
+    });
+    if (bad.load()) fail();
+
+    // counting sort by landmark (stable in file order), then camera order inside
+    lm_off.assign(nl + 1, 0);
+    for (int64_t o = 0; o < no; ++o) ++lm_off[raw_lm[o] + 1];
+    for (int64_t l = 0; l < nl; ++l) lm_off[l + 1] += lm_off[l];
+    obs_cam.resize(no);
+    obs_xy.resize(size_t(2) * no);
+    {
+      std::vector<int64_t> fill(lm_off.begin(), lm_off.end() - 1);
+      for (int64_t o = 0; o < no; ++o) {
+        const int64_t d = fill[raw_lm[o]]++;
+        obs_cam[d] = raw_cam[o];
+        obs_xy[2 * d] = Scalar(raw_xy[2 * o]);
+        obs_xy[2 * d + 1] = Scalar(raw_xy[2 * o + 1]);
+      }
     }
+    std::atomic<bool> dup{false};
+    detail::parallel_for(size_t(nl), threads, [&](size_t b, size_t e, int) {
+      std::vector<std::pair<int32_t, std::array<Scalar, 2>>> tmp;
+      for (size_t l = b; l < e; ++l) {
+        const int64_t o0 = lm_off[l], o1 = lm_off[l + 1];
+        bool sorted = true;
+        for (int64_t o = o0 + 1; o < o1; ++o) sorted = sorted && obs_cam[o - 1] < obs_cam[o];
+        if (sorted) continue;
+        tmp.clear();
+        for (int64_t o = o0; o < o1; ++o) tmp.push_back({obs_cam[o], {obs_xy[2 * o], obs_xy[2 * o + 1]}});
+        std::sort(tmp.begin(), tmp.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        for (int64_t o = o0; o < o1; ++o) {
+          obs_cam[o] = tmp[o - o0].first;
+          obs_xy[2 * o] = tmp[o - o0].second[0];
+          obs_xy[2 * o + 1] = tmp[o - o0].second[1];
+          if (o > o0 && obs_cam[o] == obs_cam[o - 1]) dup.store(true);
+        }
+      }
+    });
+    if (dup.load()) throw std::runtime_error("Invalid file '" + path + "'");  // duplicate (camera, landmark)
+
     const detail::Mat3 flip = {1, 0, 0, 0, -1, 0, 0, 0, -1};
-    for (int i = 0; i < nc; ++i) {
-      double p[9];
-      for (double& v : p)
-        if (std::fscanf(f, "%lf", &v) != 1) fail();
+    cameras.assign(nc, {});
+    for (int64_t i = 0; i < nc; ++i) {
+      const double* p = params.data() + 9 * i;
       const detail::Mat3 R = detail::mul(flip, detail::so3_exp({p[0], p[1], p[2]}));
       double q[4];
       detail::rot_to_quat(R, q);
@@ -173,31 +392,27 @@ class BalProblem {
       cam[8] = Scalar(p[7]);
       cam[9] = Scalar(p[8]);
     }
-    for (int i = 0; i < nl; ++i) {
-      double p[3];
-      for (double& v : p)
-        if (std::fscanf(f, "%lf", &v) != 1) fail();
-      landmarks[i].p_w = {Scalar(p[0]), Scalar(p[1]), Scalar(p[2])};
-    }
-    std::fclose(f);
+    points.resize(nl);
+    const double* pp = params.data() + 9 * nc;
+    for (int64_t i = 0; i < nl; ++i) points[i] = {Scalar(pp[3 * i]), Scalar(pp[3 * i + 1]), Scalar(pp[3 * i + 2])};
   }
 
   // X <- s (X - median), camera centres likewise; s = new_scale / MAD(L1)
   void normalize(double new_scale) {
-    const size_t n = landmarks.size();
+    const size_t n = points.size();
     std::vector<double> tmp(n);
     detail::Vec3 med;
     for (int j = 0; j < 3; ++j) {
-      for (size_t i = 0; i < n; ++i) tmp[i] = landmarks[i].p_w[j];
+      for (size_t i = 0; i < n; ++i) tmp[i] = points[i][j];
       med[j] = detail::median_upper(tmp);
     }
     for (size_t i = 0; i < n; ++i) {
-      const auto& p = landmarks[i].p_w;
+      const auto& p = points[i];
       tmp[i] = std::abs(p[0] - med[0]) + std::abs(p[1] - med[1]) + std::abs(p[2] - med[2]);
     }
     const double scale = new_scale / detail::median_upper(tmp);
-    for (auto& lm : landmarks)
-      for (int j = 0; j < 3; ++j) lm.p_w[j] = Scalar(scale * (lm.p_w[j] - med[j]));
+    for (auto& p : points)
+      for (int j = 0; j < 3; ++j) p[j] = Scalar(scale * (p[j] - med[j]));
     for (auto& cam : cameras) {
       double q[4] = {double(cam[0]), double(cam[1]), double(cam[2]), double(cam[3])};
       const detail::Mat3 R = detail::quat_to_rot(q);
@@ -235,28 +450,57 @@ class BalProblem {
       }
     }
     if (landmark_sigma > 0)
-      for (auto& lm : landmarks) {
+      for (auto& p : points) {
         const detail::Vec3 d = noise(landmark_sigma);
-        for (int j = 0; j < 3; ++j) lm.p_w[j] += Scalar(d[j]);
+        for (int j = 0; j < 3; ++j) p[j] += Scalar(d[j]);
       }
   }
 
   // drop observations with depth < threshold, then landmarks with < 2 observations
-  void filter_obs(double threshold) {
+  void filter_obs(double threshold, int threads = 0) {
     if (threshold <= 0) return;
-    for (auto& lm : landmarks) {
-      auto bad = [&](const Observation& o) {
-        const auto& cam = cameras[o.cam];
-        double q[4] = {double(cam[0]), double(cam[1]), double(cam[2]), double(cam[3])};
-        const detail::Mat3 R = detail::quat_to_rot(q);
-        const double z = R[6] * lm.p_w[0] + R[7] * lm.p_w[1] + R[8] * lm.p_w[2] + cam[6];
-        return z < threshold;
-      };
-      lm.obs.erase(std::remove_if(lm.obs.begin(), lm.obs.end(), bad), lm.obs.end());
+    if (threads <= 0) threads = detail::host_threads();
+    const int64_t nl = num_landmarks();
+    std::vector<std::array<double, 4>> row2(cameras.size());  // third row of R and t_z
+    for (size_t i = 0; i < cameras.size(); ++i) {
+      const auto& cam = cameras[i];
+      double q[4] = {double(cam[0]), double(cam[1]), double(cam[2]), double(cam[3])};
+      const detail::Mat3 R = detail::quat_to_rot(q);
+      row2[i] = {R[6], R[7], R[8], double(cam[6])};
     }
-    landmarks.erase(std::remove_if(landmarks.begin(), landmarks.end(),
-                                   [](const Landmark& l) { return l.obs.size() < 2; }),
-                    landmarks.end());
+    std::vector<uint8_t> keep(obs_cam.size());
+    std::vector<int64_t> kept(nl + 1, 0);
+    detail::parallel_for(size_t(nl), threads, [&](size_t b, size_t e, int) {
+      for (size_t l = b; l < e; ++l) {
+        const auto& p = points[l];
+        int64_t n = 0;
+        for (int64_t o = lm_off[l]; o < lm_off[l + 1]; ++o) {
+          const auto& r = row2[obs_cam[o]];
+          keep[o] = !(r[0] * p[0] + r[1] * p[1] + r[2] * p[2] + r[3] < threshold);
+          n += keep[o];
+        }
+        kept[l + 1] = n >= 2 ? n : 0;
+      }
+    });
+    int64_t w_lm = 0, w_obs = 0;
+    const std::vector<int64_t> old_off = lm_off;  // compaction below overwrites lm_off in place
+    for (int64_t l = 0; l < nl; ++l) {
+      const int64_t o0 = old_off[l], o1 = old_off[l + 1];
+      if (kept[l + 1] == 0) continue;
+      for (int64_t o = o0; o < o1; ++o)
+        if (keep[o]) {
+          obs_cam[w_obs] = obs_cam[o];
+          obs_xy[2 * w_obs] = obs_xy[2 * o];
+          obs_xy[2 * w_obs + 1] = obs_xy[2 * o + 1];
+          ++w_obs;
+        }
+      points[w_lm] = points[l];
+      lm_off[++w_lm] = w_obs;
+    }
+    points.resize(w_lm);
+    lm_off.resize(w_lm + 1);
+    obs_cam.resize(w_obs);
+    obs_xy.resize(size_t(2) * w_obs);
   }
 
   template <class S2>
@@ -265,37 +509,25 @@ class BalProblem {
     out.cameras.resize(cameras.size());
     for (size_t i = 0; i < cameras.size(); ++i)
       for (int j = 0; j < 10; ++j) out.cameras[i][j] = S2(cameras[i][j]);
-    out.landmarks.resize(landmarks.size());
-    for (size_t i = 0; i < landmarks.size(); ++i) {
-      for (int j = 0; j < 3; ++j) out.landmarks[i].p_w[j] = S2(landmarks[i].p_w[j]);
-      for (const auto& o : landmarks[i].obs) out.landmarks[i].obs.push_back({o.cam, S2(o.x), S2(o.y)});
-    }
+    out.points.resize(points.size());
+    for (size_t i = 0; i < points.size(); ++i)
+      for (int j = 0; j < 3; ++j) out.points[i][j] = S2(points[i][j]);
+    out.lm_off = lm_off;
+    out.obs_cam = obs_cam;
+    out.obs_xy.assign(obs_xy.begin(), obs_xy.end());
     return out;
   }
 
   // flat views consumed by the C ABI
-  void to_csr(std::vector<int64_t>& off, std::vector<int32_t>& cam, std::vector<Scalar>& xy) const {
-    off.assign(1, 0);
-    cam.clear();
-    xy.clear();
-    for (const auto& lm : landmarks) {
-      for (const auto& o : lm.obs) {
-        cam.push_back(o.cam);
-        xy.push_back(o.x);
-        xy.push_back(o.y);
-      }
-      off.push_back(int64_t(cam.size()));
-    }
-  }
   void copy_to_state(std::vector<Scalar>& cams, std::vector<Scalar>& lms) const {
     cams.resize(10 * cameras.size());
-    lms.resize(3 * landmarks.size());
+    lms.resize(3 * points.size());
     for (size_t i = 0; i < cameras.size(); ++i) std::copy(cameras[i].begin(), cameras[i].end(), cams.begin() + 10 * i);
-    for (size_t i = 0; i < landmarks.size(); ++i) std::copy(landmarks[i].p_w.begin(), landmarks[i].p_w.end(), lms.begin() + 3 * i);
+    for (size_t i = 0; i < points.size(); ++i) std::copy(points[i].begin(), points[i].end(), lms.begin() + 3 * i);
   }
   void copy_from_state(const std::vector<Scalar>& cams, const std::vector<Scalar>& lms) {
     for (size_t i = 0; i < cameras.size(); ++i) std::copy(cams.begin() + 10 * i, cams.begin() + 10 * i + 10, cameras[i].begin());
-    for (size_t i = 0; i < landmarks.size(); ++i) std::copy(lms.begin() + 3 * i, lms.begin() + 3 * i + 3, landmarks[i].p_w.begin());
+    for (size_t i = 0; i < points.size(); ++i) std::copy(lms.begin() + 3 * i, lms.begin() + 3 * i + 3, points[i].begin());
   }
 };
 

@@ -4,10 +4,13 @@
 // ba_log.json. Flags keep the reference's names (docs/Configuration.md:45-259),
 // restricted to the ones that reach the hot path; the TOML/clipp machinery of
 // the reference is out of scope.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <fstream>
+#include <random>
 #include <string>
 
 #include "linearizor_hip.hpp"
@@ -36,19 +39,28 @@ void usage() {
 
 template <class Scalar>
 int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string& log_path, bool dry_run, int device) {
+  const auto t_load = std::chrono::steady_clock::now();
   auto prob = load_normalized_bal_problem<Scalar>(ds);
+  const double load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load).count();
   double sx = 0, sy = 0, sz = 0;
-  for (const auto& l : prob.landmarks) {
-    sx += l.p_w[0];
-    sy += l.p_w[1];
-    sz += l.p_w[2];
+  for (const auto& p : prob.points) {
+    sx += p[0];
+    sy += p[1];
+    sz += p[2];
   }
-  std::printf("Loaded BAL problem (%d cams, %d lms, %lld obs) from '%s'\n", prob.num_cameras(), prob.num_landmarks(),
-              static_cast<long long>(prob.num_observations()), ds.input.c_str());
+  // order-sensitive inside a landmark (position weight), so it also pins the camera order
+  double obs_checksum = 0;
+  for (int l = 0; l < prob.num_landmarks(); ++l)
+    for (int64_t o = prob.lm_off[l]; o < prob.lm_off[l + 1]; ++o)
+      obs_checksum += double(o - prob.lm_off[l] + 1) * (double(prob.obs_cam[o] + 1) * double(prob.obs_xy[2 * o]) + double(prob.obs_xy[2 * o + 1]));
+  std::printf("Loaded BAL problem (%d cams, %d lms, %lld obs) from '%s' in %.3fs\n", prob.num_cameras(),
+              prob.num_landmarks(), static_cast<long long>(prob.num_observations()), ds.input.c_str(), load_seconds);
   if (dry_run) {
-    std::printf("{\"num_cameras\": %d, \"num_landmarks\": %d, \"num_observations\": %lld, "
+    std::printf("{\"num_cameras\": %d, \"num_landmarks\": %d, \"num_observations\": %lld, \"load_seconds\": %.6f, "
+                "\"obs_checksum\": %.12e, "
                 "\"landmark_sum\": [%.12e, %.12e, %.12e], \"cam0\": [%.12e, %.12e, %.12e, %.12e, %.12e, %.12e, %.12e]}\n",
-                prob.num_cameras(), prob.num_landmarks(), static_cast<long long>(prob.num_observations()), sx, sy, sz,
+                prob.num_cameras(), prob.num_landmarks(), static_cast<long long>(prob.num_observations()), load_seconds,
+                obs_checksum, sx, sy, sz,
                 double(prob.cameras[0][0]), double(prob.cameras[0][1]), double(prob.cameras[0][2]),
                 double(prob.cameras[0][3]), double(prob.cameras[0][4]), double(prob.cameras[0][5]),
                 double(prob.cameras[0][6]));
@@ -86,6 +98,45 @@ int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string&
   return 0;
 }
 }  // namespace
+
+// parse_double against strtod on random doubles printed in the formats BAL writers use
+static int self_test_parser(long n) {
+  std::mt19937_64 rng(38401);
+  long bad = 0, tokens = 0;
+  char buf[512];
+  const char* fmts[] = {"%.16e", "%.17g", "%.9e", "%.6f", "%.18e", "%.15e", "%g", "%+.16e"};
+  for (long it = 0; it < n; ++it) {
+    const uint64_t bits = rng();
+    double x;
+    if (it % 3 == 0) {
+      std::memcpy(&x, &bits, 8);
+      if (!std::isfinite(x)) continue;
+    } else {
+      x = std::ldexp(double(int64_t(bits)), -int(rng() % 90));
+    }
+    for (const char* f : fmts) {
+      const int len = std::snprintf(buf, sizeof buf, f, x);
+      if (len <= 0 || len >= int(sizeof buf)) continue;
+      double got = 0;
+      const double ref = std::strtod(buf, nullptr);
+      const char* e = rootba_hip::detail::parse_double(buf, buf + len, got);
+      ++tokens;
+      if (e != buf + len || std::memcmp(&ref, &got, 8) != 0) {
+        if (bad++ < 5) std::fprintf(stderr, "MISMATCH '%s': strtod %.17g parse_double %.17g\n", buf, ref, got);
+      }
+    }
+  }
+  for (const char* b : {"", "-", ".", "1e", "abc", "1.5x", "e5"}) {
+    double g;
+    const char* e = rootba_hip::detail::parse_double(b, b + std::strlen(b), g);
+    if (e == b + std::strlen(b)) {
+      std::fprintf(stderr, "accepted malformed token '%s'\n", b);
+      ++bad;
+    }
+  }
+  std::printf("{\"tokens\": %ld, \"mismatches\": %ld}\n", tokens, bad);
+  return bad == 0 ? 0 : 3;
+}
 
 int main(int argc, char** argv) {
   BalDatasetOptions ds;
@@ -137,6 +188,7 @@ int main(int argc, char** argv) {
     else if (a == "--log-path") log_path = val();
     else if (a == "--device") device = std::stoi(val());
     else if (a == "--dry-run") dry_run = true;
+    else if (a == "--self-test-parser") return self_test_parser(std::stol(val()));
     else if (a == "--implicit-q") so.implicit_q = true;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 1; }
   }

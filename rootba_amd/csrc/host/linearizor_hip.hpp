@@ -174,13 +174,11 @@ class LinearizorHIP {
  private:
   LinearizorHIP(BalProblem<Scalar>& bal_problem, const SolverOptions& options, SolverSummary* summary, int device)
       : bal_problem_(bal_problem), options_(options), summary_(summary) {
-    std::vector<int64_t> off;
-    std::vector<int32_t> cam;
-    VecX xy;
-    bal_problem.to_csr(off, cam, xy);
     const rba_options o = options.to_rba();
+    // BalProblem already stores the CSR topology the C ABI takes
     check_rba(rba_create(std::is_same<Scalar, float>::value ? RBA_F32 : RBA_F64, device, bal_problem.num_cameras(),
-                         bal_problem.num_landmarks(), off.data(), cam.data(), xy.data(), &o, &h_),
+                         bal_problem.num_landmarks(), bal_problem.lm_off.data(), bal_problem.obs_cam.data(),
+                         bal_problem.obs_xy.data(), &o, &h_),
               "rba_create");
     VecX cams, lms;
     bal_problem.copy_to_state(cams, lms);

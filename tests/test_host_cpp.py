@@ -46,6 +46,84 @@ def test_cpp_loader_and_preprocessing_match_numpy_mirror(app, bal_file):
     assert np.allclose(info["cam0"][4:], ref.cams[0, 4:7], rtol=1e-9, atol=1e-7)
 
 
+def test_number_parser_matches_strtod(app):
+    """The loader's own decimal parser (Clinger / x87 fast paths, strtod otherwise) is bit-exact
+    against strtod, i.e. reads what the reference's fscanf("%lf") reads."""
+    out = subprocess.run([app, "--self-test-parser", "200000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["tokens"] > 1_000_000 and info["mismatches"] == 0
+
+
+def _dry(app, path, *extra):
+    return subprocess.run([app, "--input", path, "--dry-run", "--no-normalize", *extra], capture_output=True, text=True)
+
+
+def _obs_checksum(p):
+    off = p.lm_obs_offsets
+    pos = np.arange(p.n_obs) - np.repeat(off[:-1], np.diff(off)) + 1
+    return float(np.sum(pos * ((p.obs_cam_idx + 1.0) * p.obs_xy[:, 0] + p.obs_xy[:, 1])))
+
+
+def test_loader_any_observation_order_and_thread_count(app, bal_file, tmp_path):
+    """Observations may come in any order in the file (the reference buckets them in a std::map per
+    landmark): shuffled lines load to the same CSR as the sorted file, for any number of parser threads."""
+    path, raw = bal_file
+    ref = P.read_bal(path)
+    lines = open(path).read().split("\n")
+    n_obs = raw.n_obs
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(n_obs)
+    shuffled = str(tmp_path / "shuffled.txt")
+    with open(shuffled, "w") as f:
+        # also exercise tabs, CRLF and several tokens per line in the parameter section
+        f.write(lines[0] + "\r\n")
+        f.write("\n".join(lines[1 + i].replace(" ", "\t") for i in perm) + "\n")
+        f.write(" ".join(lines[1 + n_obs:]) + "\n")
+    want = _obs_checksum(ref)
+    for threads in ("1", "3", "8"):
+        for fpath in (path, shuffled):
+            env = dict(os.environ, RBA_HOST_THREADS=threads)
+            out = subprocess.run([app, "--input", fpath, "--dry-run", "--no-normalize"], capture_output=True,
+                                 text=True, env=env)
+            assert out.returncode == 0, out.stderr
+            info = json.loads(out.stdout.strip().splitlines()[-1])
+            assert (info["num_cameras"], info["num_landmarks"], info["num_observations"]) == (ref.n_cams, ref.n_lms, ref.n_obs)
+            assert np.isclose(info["obs_checksum"], want, rtol=1e-12)
+            assert np.allclose(info["landmark_sum"], ref.lms.sum(0), rtol=1e-12)
+
+
+def test_loader_rejects_malformed_files(app, bal_file, tmp_path):
+    """Duplicate (camera, landmark) pairs, out-of-range indices, non-numeric and missing tokens are
+    fatal like in the reference (bal_problem.cpp:229-230, :199-205)."""
+    path, raw = bal_file
+    lines = open(path).read().split("\n")
+
+    def variant(name, edit):
+        ls = list(lines)
+        edit(ls)
+        fpath = str(tmp_path / name)
+        open(fpath, "w").write("\n".join(ls))
+        return fpath
+
+    def dup(ls):
+        ls[2] = ls[1]
+    def bad_cam(ls):
+        ls[1] = "9999 " + ls[1].split(" ", 1)[1]
+    def bad_token(ls):
+        ls[5] = ls[5].replace(ls[5].split()[2], "1.2.3")
+    def float_index(ls):
+        ls[3] = "0.5 " + ls[3].split(" ", 1)[1]
+    def truncated(ls):
+        del ls[-5:]
+
+    for name, edit in (("dup", dup), ("bad_cam", bad_cam), ("bad_token", bad_token), ("float_index", float_index),
+                       ("truncated", truncated)):
+        out = _dry(app, variant(name, edit))
+        assert out.returncode == 2, (name, out.stdout, out.stderr)
+        assert "FATAL" in out.stderr
+
+
 def test_cli_rejects_bad_input(app, tmp_path):
     assert subprocess.run([app, "--input", str(tmp_path / "missing.txt")], capture_output=True).returncode == 2
     assert subprocess.run([app, "--input", "x", "--preconditioner-type", "POWER_VARIABLE_PROJECTION"],
