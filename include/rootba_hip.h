@@ -128,6 +128,10 @@ typedef struct rba_lm_iteration {
   double iteration_time;
   double stage1_time, stage2_time, precond_time, pcg_time, backsub_time,
       residual_time;
+  /* ResidualInfo of the evaluated state (what BaLog::BaIteration derives
+   * num_obs*, residual_block_*mean from, ba_log_utils.cpp:100-118) */
+  int num_obs, num_obs_valid;
+  double residual_sum, residual_sum_valid;
 } rba_lm_iteration;
 
 typedef struct rba_solver* rba_handle;

@@ -23,7 +23,7 @@ def needs_build() -> bool:
 
 
 APP = os.path.join(HERE, "bal_qr_hip")
-HOST_DEPS = [os.path.join("host", f) for f in ("bal_qr_hip.cpp", "linearizor_hip.hpp", "bal_problem.hpp")]
+HOST_DEPS = [os.path.join("host", f) for f in ("bal_qr_hip.cpp", "linearizor_hip.hpp", "bal_problem.hpp", "ba_log.hpp")]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -22,6 +22,7 @@
 #include <atomic>
 #include <cfloat>
 #include <charconv>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -531,15 +532,22 @@ class BalProblem {
   }
 };
 
-// load (double) -> normalize -> perturb -> filter -> cast
+// load (double) -> normalize -> perturb -> filter -> cast; optional wall times of the two halves
 template <class Scalar>
-BalProblem<Scalar> load_normalized_bal_problem(const BalDatasetOptions& o) {
+BalProblem<Scalar> load_normalized_bal_problem(const BalDatasetOptions& o, double* load_seconds = nullptr,
+                                               double* preprocess_seconds = nullptr) {
+  const auto t0 = std::chrono::steady_clock::now();
   BalProblem<double> p;
   p.load_bal(o.input);
+  const auto t1 = std::chrono::steady_clock::now();
   if (o.normalize) p.normalize(o.normalization_scale);
   p.perturb(o.rotation_sigma, o.translation_sigma, o.point_sigma, o.random_seed);
   p.filter_obs(o.init_depth_threshold);
-  return p.template copy_cast<Scalar>();
+  auto out = p.template copy_cast<Scalar>();
+  const auto t2 = std::chrono::steady_clock::now();
+  if (load_seconds) *load_seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (preprocess_seconds) *preprocess_seconds = std::chrono::duration<double>(t2 - t1).count();
+  return out;
 }
 
 }  // namespace rootba_hip

@@ -13,6 +13,7 @@
 #include <random>
 #include <string>
 
+#include "ba_log.hpp"
 #include "linearizor_hip.hpp"
 
 using namespace rootba_hip;
@@ -40,7 +41,8 @@ void usage() {
 template <class Scalar>
 int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string& log_path, bool dry_run, int device) {
   const auto t_load = std::chrono::steady_clock::now();
-  auto prob = load_normalized_bal_problem<Scalar>(ds);
+  double load_only_seconds = 0, preprocess_seconds = 0;
+  auto prob = load_normalized_bal_problem<Scalar>(ds, &load_only_seconds, &preprocess_seconds);
   const double load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load).count();
   double sx = 0, sy = 0, sz = 0;
   for (const auto& p : prob.points) {
@@ -67,34 +69,17 @@ int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string&
     return 0;
   }
   SolverSummary summary;
+  const auto t_opt = std::chrono::steady_clock::now();
   bundle_adjust_manual(prob, so, &summary, device);
-  // ba_log.json: flat object, one array per iteration field (reference
-  // src/rootba/bal/ba_log.cpp:62-149), restricted to the fields produced here
-  std::ofstream f(log_path);
-  auto arr = [&](const char* name, auto getter, bool last = false) {
-    f << "  \"" << name << "\": [";
-    for (size_t i = 0; i < summary.iterations.size(); ++i) f << (i ? ", " : "") << getter(summary.iterations[i]);
-    f << "]" << (last ? "\n" : ",\n");
-  };
-  f.precision(17);
-  f << "{\n  \"_type\": \"rootba\",\n  \"_static\": {\"solver\": {\"solver_type\": \"bal_qr_hip\", \"message\": \""
-    << summary.message << "\", \"initial_cost\": " << summary.initial_cost << ", \"final_cost\": " << summary.final_cost
-    << "}},\n";
-  arr("iteration", [](const IterationSummary& s) { return s.iteration; });
-  arr("cost_all_error", [](const IterationSummary& s) { return s.cost.all.error; });
-  arr("cost_valid_error", [](const IterationSummary& s) { return s.cost.valid.error; });
-  arr("step_is_successful", [](const IterationSummary& s) { return int(s.step_is_successful); });
-  arr("step_is_valid", [](const IterationSummary& s) { return int(s.step_is_valid); });
-  arr("linear_solver_iterations", [](const IterationSummary& s) { return s.linear_solver_iterations; });
-  arr("trust_region_radius", [](const IterationSummary& s) { return s.trust_region_radius; });
-  arr("iteration_time_in_seconds", [](const IterationSummary& s) { return s.iteration_time_in_seconds; });
-  arr("stage1_time_in_seconds", [](const IterationSummary& s) { return s.stage1_time_in_seconds; });
-  arr("stage2_time_in_seconds", [](const IterationSummary& s) { return s.stage2_time_in_seconds; });
-  arr("solve_reduced_system_time_in_seconds",
-      [](const IterationSummary& s) { return s.solve_reduced_system_time_in_seconds; });
-  arr("back_substitution_time_in_seconds", [](const IterationSummary& s) { return s.back_substitution_time_in_seconds; },
-      true);
-  f << "}\n";
+  PipelineTimingSummary timing;
+  timing.load_time = load_only_seconds;
+  timing.preprocess_time = preprocess_seconds;
+  timing.optimize_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_opt).count();
+  // ba_log.json in the reference's layout (src/rootba/bal/ba_log.cpp:62-149)
+  if (!save_ba_log_json(log_path, summary, summarize_dataset(prob, ds.input), timing)) {
+    std::fprintf(stderr, "Could not save BA log to %s.\n", log_path.c_str());
+    return 2;
+  }
   return 0;
 }
 }  // namespace
@@ -136,6 +121,46 @@ static int self_test_parser(long n) {
   }
   std::printf("{\"tokens\": %ld, \"mismatches\": %ld}\n", tokens, bad);
   return bad == 0 ? 0 : 3;
+}
+
+// ba_log.json writer on a hand-made summary (success, reject, success): no GPU needed
+static int self_test_log(const std::string& path) {
+  SolverSummary summary;
+  summary.message = "Solver did not converge after maximum number of iterations";
+  const double costs[4] = {100.0, 60.0, 75.0, 50.0};
+  const bool ok[4] = {true, true, false, true};
+  for (int i = 0; i < 4; ++i) {
+    IterationSummary it;
+    it.iteration = i;
+    it.step_is_valid = true;
+    it.step_is_successful = ok[i];
+    it.cost.all = {1000, costs[i], 2000.0 + i};
+    it.cost.valid = {990 + i, costs[i] - 1.0, 1900.0 + i};
+    if (i > 0) it.prev_cost = summary.iterations.back().cost;
+    it.step_norm = 0.5 * i;
+    it.relative_decrease = ok[i] ? 0.9 : -0.3;
+    it.trust_region_radius = 1e4 * (i + 1);
+    it.linear_solver_iterations = 10 * i;
+    it.iteration_time_in_seconds = 0.01;
+    it.cumulative_time_in_seconds = 0.01 * (i + 1);
+    it.stage1_time_in_seconds = 0.001;
+    it.stage2_time_in_seconds = 0.002;
+    it.solve_reduced_system_time_in_seconds = 0.003;
+    it.back_substitution_time_in_seconds = 0.004;
+    summary.iterations.push_back(it);
+  }
+  summary.initial_cost = costs[0];
+  summary.final_cost = costs[3];
+  DatasetSummary dataset;
+  dataset.input_path = "self \"test\"";
+  dataset.num_cameras = 3;
+  dataset.num_landmarks = 5;
+  dataset.num_observations = 12;
+  PipelineTimingSummary timing;
+  timing.load_time = 1;
+  timing.preprocess_time = 2;
+  timing.optimize_time = 3;
+  return save_ba_log_json(path, summary, dataset, timing) ? 0 : 2;
 }
 
 int main(int argc, char** argv) {
@@ -189,6 +214,7 @@ int main(int argc, char** argv) {
     else if (a == "--device") device = std::stoi(val());
     else if (a == "--dry-run") dry_run = true;
     else if (a == "--self-test-parser") return self_test_parser(std::stol(val()));
+    else if (a == "--self-test-log") return self_test_log(val());
     else if (a == "--implicit-q") so.implicit_q = true;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 1; }
   }

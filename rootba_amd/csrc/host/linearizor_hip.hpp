@@ -13,6 +13,9 @@
 #pragma once
 
 #include <cmath>
+#include <sys/resource.h>
+
+#include <chrono>
 #include <cstdio>
 #include <limits>
 #include <memory>
@@ -103,17 +106,23 @@ struct IterationSummary {  // subset of reference solver_summary.hpp:99-204
   int iteration = 0;
   bool step_is_valid = false, step_is_successful = false;
   ResidualInfo cost;
-  double relative_decrease = 0, trust_region_radius = 0;
+  ResidualInfo prev_cost;  // cost of the previous summary (the reference stores cost_change = cost - that)
+  double relative_decrease = 0, trust_region_radius = 0, step_norm = 0;
   int linear_solver_iterations = 0;
-  double iteration_time_in_seconds = 0, stage1_time_in_seconds = 0, stage2_time_in_seconds = 0,
-         compute_preconditioner_time_in_seconds = 0, solve_reduced_system_time_in_seconds = 0,
-         back_substitution_time_in_seconds = 0, residual_evaluation_time_in_seconds = 0;
+  double iteration_time_in_seconds = 0, cumulative_time_in_seconds = 0, stage1_time_in_seconds = 0,
+         stage2_time_in_seconds = 0, compute_preconditioner_time_in_seconds = 0,
+         solve_reduced_system_time_in_seconds = 0, back_substitution_time_in_seconds = 0,
+         residual_evaluation_time_in_seconds = 0;
+  uint64_t resident_memory_peak = 0;
 };
 struct SolverSummary {
   std::vector<IterationSummary> iterations;
+  std::string solver_type = "bal_qr_hip";  // the reference's names are bal_qr / bal_sc / bal_power_sc
   std::string message;
   int termination_type = 0;  // 0 NO_CONVERGENCE, 1 CONVERGENCE
   double initial_cost = 0, final_cost = 0;
+  double preprocessor_time_in_seconds = 0, minimizer_time_in_seconds = 0, postprocessor_time_in_seconds = 0,
+         total_time_in_seconds = 0;
 };
 
 inline void check_rba(int status, const char* what) {
@@ -200,7 +209,14 @@ void bundle_adjust_manual(BalProblem<Scalar>& bal_problem, const SolverOptions& 
   SolverSummary local;
   SolverSummary& summary = summary_out ? *summary_out : local;
   summary = SolverSummary();
+  const auto t_total = std::chrono::steady_clock::now();
+  auto seconds_since = [](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
+  // preprocessor = building the linearizor: device allocation, topology and state upload
   auto lin = LinearizorHIP<Scalar>::create(bal_problem, options, &summary, device);
+  summary.preprocessor_time_in_seconds = seconds_since(t_total);
+  const auto t_minimizer = std::chrono::steady_clock::now();
   check_rba(rba_lm_begin(lin->handle()), "rba_lm_begin");
   for (;;) {
     rba_lm_iteration row;
@@ -214,8 +230,15 @@ void bundle_adjust_manual(BalProblem<Scalar>& bal_problem, const SolverOptions& 
     it.iteration = row.iteration;
     it.step_is_valid = row.step_is_valid;
     it.step_is_successful = row.step_is_successful;
-    it.cost.all.error = row.cost;
-    it.cost.valid.error = row.cost_valid;
+    it.cost.all = {row.num_obs, row.cost, row.residual_sum};
+    it.cost.valid = {row.num_obs_valid, row.cost_valid, row.residual_sum_valid};
+    if (!summary.iterations.empty()) it.prev_cost = summary.iterations.back().cost;
+    it.step_norm = row.inc_norm;
+    it.cumulative_time_in_seconds = seconds_since(t_minimizer);
+    {
+      struct rusage ru;
+      if (getrusage(RUSAGE_SELF, &ru) == 0) it.resident_memory_peak = uint64_t(ru.ru_maxrss) * 1024u;
+    }
     it.relative_decrease = row.relative_decrease;
     it.trust_region_radius = row.lambda > 0 ? 1.0 / row.lambda : 0.0;
     it.linear_solver_iterations = row.cg_iterations;
@@ -255,7 +278,11 @@ void bundle_adjust_manual(BalProblem<Scalar>& bal_problem, const SolverOptions& 
         break;
       }
   }
+  summary.minimizer_time_in_seconds = seconds_since(t_minimizer);
+  const auto t_post = std::chrono::steady_clock::now();
   lin->download();
+  summary.postprocessor_time_in_seconds = seconds_since(t_post);
+  summary.total_time_in_seconds = seconds_since(t_total);
   if (options.verbosity_level >= 1)
     std::printf("Final Cost: %.4e\n%s: %s\n", summary.final_cost,
                 summary.termination_type ? "CONVERGENCE" : "NO_CONVERGENCE", summary.message.c_str());

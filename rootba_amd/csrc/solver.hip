@@ -949,6 +949,10 @@ class Solver final : public rba_solver {
       // iteration 0 is evaluation only (bal_bundle_adjustment.cpp:311-322)
       row.cost = lm_.ri.all_error;
       row.cost_valid = lm_.ri.valid_error;
+      row.num_obs = int(lm_.ri.all_num_obs);
+      row.num_obs_valid = int(lm_.ri.valid_num_obs);
+      row.residual_sum = lm_.ri.all_residual_sum;
+      row.residual_sum_valid = lm_.ri.valid_residual_sum;
       row.lambda = lm_.lambda;
       row.step_is_successful = row.step_is_valid = 1;
       lm_.prev_all = lm_.ri.all_error;
@@ -996,6 +1000,10 @@ class Solver final : public rba_solver {
     compute_error(&ri2);
     row.cost = ri2.all_error;
     row.cost_valid = ri2.valid_error;
+    row.num_obs = int(ri2.all_num_obs);
+    row.num_obs_valid = int(ri2.valid_num_obs);
+    row.residual_sum = ri2.all_residual_sum;
+    row.residual_sum_valid = ri2.valid_residual_sum;
     row.l_diff = l_diff;
     if (!std::isfinite(l_diff) || !ri2.is_numerically_valid) {
       row.step_is_valid = row.step_is_successful = 0;

@@ -124,6 +124,60 @@ def test_loader_rejects_malformed_files(app, bal_file, tmp_path):
         assert "FATAL" in out.stderr
 
 
+# BaLog::BaIteration members, reference src/rootba/bal/ba_log.hpp:139-237 (one array each in ba_log.json)
+BA_ITERATION_KEYS = """iteration linear_solver_type step_is_valid step_is_nonmonotonic step_is_successful num_obs
+num_obs_valid num_obs_valid_change cost cost_change cost_valid cost_valid_change cost_avg_valid cost_avg_valid_change
+grad_projected_norm grad_projected_max_norm grad_norm grad_max_norm residual_block_mean residual_block_valid_mean
+step_norm relative_decrease trust_region_radius linear_solver_iterations iteration_time cumulative_time logging_time
+step_solver_time residual_evaluation_time jacobian_evaluation_time scale_landmark_jacobian_time perform_qr_time
+stage1_time scale_pose_jacobian_time landmark_damping_time compute_preconditioner_time compute_gradient_time
+stage2_time prepare_time solve_reduced_system_time back_substitution_time update_cameras_time resident_memory
+resident_memory_peak""".split()
+# BaLog::BaSolver / ProblemInfo / PipelineTiming members (ba_log.hpp:45-137)
+BA_SOLVER_KEYS = """solver_type termination_type message num_successful_steps num_unsuccessful_steps
+logging_time_in_seconds preprocessor_time_in_seconds minimizer_time_in_seconds postprocessor_time_in_seconds
+total_time_in_seconds linear_solver_time_in_seconds num_linear_solves residual_evaluation_time_in_seconds
+num_residual_evaluations jacobian_evaluation_time_in_seconds num_jacobian_evaluations num_threads_given
+num_threads_used num_threads_available resident_memory_peak""".split()
+BA_PROBLEM_KEYS = "type input_path num_cameras num_landmarks num_observations rcs_sparsity per_lm_obs per_host_lms".split()
+
+
+def check_ba_log_layout(log):
+    """The flat layout of reference ba_log.cpp:62-149 that python/rootba/log.py + plot_logs.py consume."""
+    assert log["_type"] == "rootba"
+    n = len(log["iteration"])
+    for k in BA_ITERATION_KEYS:
+        assert k in log and len(log[k]) == n, k
+    assert set(log) == set(BA_ITERATION_KEYS) | {"_type", "_static"}
+    st = log["_static"]
+    assert set(st) == {"problem_info", "timing", "solver"}
+    assert set(BA_SOLVER_KEYS) <= set(st["solver"])
+    assert set(st["problem_info"]) == set(BA_PROBLEM_KEYS)
+    assert set(st["problem_info"]["per_lm_obs"]) == {"mean", "min", "max", "stddev"}
+    assert set(st["timing"]) == {"total", "load", "preprocess", "optimize", "postprocess"}
+    assert not st["solver"]["solver_type"].endswith("_ceres")
+    assert all(isinstance(v, bool) for v in log["step_is_successful"])
+
+
+def test_ba_log_layout_and_rejected_step_rows(app, tmp_path):
+    path = str(tmp_path / "ba_log.json")
+    assert subprocess.run([app, "--self-test-log", path]).returncode == 0
+    log = json.load(open(path))
+    check_ba_log_layout(log)
+    # rejected step (iteration 2) repeats the previous row's cost columns (ba_log_utils.cpp:119-137)
+    assert log["cost"] == [100.0, 60.0, 60.0, 50.0]
+    assert log["cost_change"] == [0.0, -40.0, 0.0, -25.0]      # w.r.t. the previous summary, 75 -> 50
+    assert log["step_is_successful"] == [True, True, False, True]
+    assert log["step_norm"][2] == 0 and log["relative_decrease"][2] == 0
+    assert log["num_obs_valid"] == [990, 991, 991, 993] and log["num_obs_valid_change"] == [0, 1, 0, 1]
+    assert np.allclose(log["residual_block_mean"], [2.0, 2.001, 2.001, 2.003])
+    assert np.allclose(log["step_solver_time"], 0.009)
+    s = log["_static"]
+    assert s["solver"]["num_successful_steps"] == 2 and s["solver"]["num_unsuccessful_steps"] == 1
+    assert s["solver"]["num_linear_solves"] == 3 and s["timing"]["total"] == 6
+    assert s["problem_info"]["input_path"] == 'self "test"'
+
+
 def test_cli_rejects_bad_input(app, tmp_path):
     assert subprocess.run([app, "--input", str(tmp_path / "missing.txt")], capture_output=True).returncode == 2
     assert subprocess.run([app, "--input", "x", "--preconditioner-type", "POWER_VARIABLE_PROJECTION"],
@@ -143,10 +197,18 @@ def test_bal_qr_hip_end_to_end(app, bal_file, tmp_path):
     assert out.returncode == 0, out.stderr
     assert "Final Cost" in out.stdout and "Iteration 1" in out.stdout
     log = json.load(open(log_path))
-    assert log["_type"] == "rootba" and log["iteration"][0] == 0
+    check_ba_log_layout(log)
+    assert log["iteration"][0] == 0
     prob = P.normalize(P.read_bal(path), 100.0)
     g = LinearizorHIP(prob, np.float64, L.default_options(robust_norm=1, max_num_iterations=6))
     rows, _ = g.optimize_lm()
     assert len(rows) == len(log["iteration"])
-    assert np.allclose([r.cost for r in rows], log["cost_all_error"], rtol=1e-7)
+    # rejected steps repeat the previous cost in the log (monotonic plots)
+    want, last = [], None
+    for r in rows:
+        last = r.cost if (r.step_is_successful or last is None) else last
+        want.append(last)
+    assert np.allclose(want, log["cost"], rtol=1e-7)
     assert [r.cg_iterations for r in rows] == log["linear_solver_iterations"]
+    assert log["num_obs"][0] == prob.n_obs and log["_static"]["problem_info"]["num_observations"] == prob.n_obs
+    assert np.isclose(log["cumulative_time"][-1], log["_static"]["solver"]["minimizer_time_in_seconds"], rtol=0.2)
