@@ -80,6 +80,10 @@ class LmIteration(C.Structure):
         ("pcg_time", C.c_double),
         ("backsub_time", C.c_double),
         ("residual_time", C.c_double),
+        ("num_obs", C.c_int),
+        ("num_obs_valid", C.c_int),
+        ("residual_sum", C.c_double),
+        ("residual_sum_valid", C.c_double),
     ]
 
 

@@ -112,6 +112,9 @@ struct LmIteration {
   double iteration_time = 0;
   double stage1_time = 0, stage2_time = 0, precond_time = 0, pcg_time = 0,
          backsub_time = 0, residual_time = 0;
+  // ResidualInfo of the evaluated state (solver_summary.hpp cost.{all,valid})
+  int num_obs = 0, num_obs_valid = 0;
+  double residual_sum = 0, residual_sum_valid = 0;
 };
 
 // Sophus::Constants<Scalar>::epsilonSqrt() (upstream Sophus: epsilon = 1e-10
@@ -1305,6 +1308,10 @@ class Oracle {
       if (it == 0) {
         row.cost = ri.all.error;
         row.cost_valid = ri.valid.error;
+        row.num_obs = ri.all.num_obs;
+        row.num_obs_valid = ri.valid.num_obs;
+        row.residual_sum = ri.all.residual_sum;
+        row.residual_sum_valid = ri.valid.residual_sum;
         row.lambda = lambda;
         row.step_is_successful = 1;
         row.step_is_valid = 1;
@@ -1359,6 +1366,10 @@ class Oracle {
         }
         row.cost = ri2.all.error;
         row.cost_valid = ri2.valid.error;
+        row.num_obs = ri2.all.num_obs;
+        row.num_obs_valid = ri2.valid.num_obs;
+        row.residual_sum = ri2.all.residual_sum;
+        row.residual_sum_valid = ri2.valid.residual_sum;
         row.l_diff = l_diff;
         if (!std::isfinite(l_diff)) {
           row.step_is_valid = 0;
