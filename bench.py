@@ -116,8 +116,9 @@ def main():
     ap.add_argument("--workload", default="venice-1778")
     ap.add_argument("--cpu-baseline-iters", type=int, default=4,
                     help="LM iterations of the CPU oracle timed beside the GPU (0 = skip)")
-    ap.add_argument("--translation-sigma", type=float, default=0.5)
-    ap.add_argument("--point-sigma", type=float, default=0.5)
+    ap.add_argument("--translation-sigma", type=float, default=0.01,
+                    help="camera-centre perturbation (SURVEY.md 8d / CVPR'21 common settings: 0.01)")
+    ap.add_argument("--point-sigma", type=float, default=0.01)
     ap.add_argument("--rotation-sigma", type=float, default=0.0)
     ap.add_argument("--preconditioner", choices=sorted(PRECOND), default="SCHUR_JACOBI",
                     help="reference default: SCHUR_JACOBI")

@@ -1,0 +1,10 @@
+set -x
+mkdir -p gpurun_out/r1b
+python bench.py > gpurun_out/r1b/venice.json 2> gpurun_out/r1b/venice.log
+python bench.py --implicit-q --cpu-baseline-iters 0 > gpurun_out/r1b/venice_implicit.json 2> gpurun_out/r1b/venice_implicit.log
+python bench.py --workload trafalgar-257 > gpurun_out/r1b/trafalgar.json 2> gpurun_out/r1b/trafalgar.log
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r1b/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --cpu-baseline-iters 0 > $GRAFT_REPO_ROOT/gpurun_out/r1b/prof.json 2> $GRAFT_REPO_ROOT/gpurun_out/r1b/prof.log
+cd $GRAFT_REPO_ROOT
+python bench.py --workload final-13682 --cpu-baseline-iters 0 > gpurun_out/r1b/final.json 2> gpurun_out/r1b/final.log
+tail -c 600 gpurun_out/r1b/venice.json
