@@ -1607,6 +1607,10 @@ __global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ in
 //   k_pcg_c1 : (refresh) r = b - H x, partial of Q
 // One workgroup cannot pull the 81 n_c preconditioner through a single CU fast
 // enough (H*x evicts it from L2 every iteration), hence kPcgBlocks workgroups.
+// (Measured alternative: the five kernels fused into one launch with software grid
+//  barriers between the phases. Same 0.65 ms per CG iteration on venice — with one L2
+//  per XCD an agent-scope release/acquire pair is an L2 write-back + invalidate, i.e.
+//  as expensive as the ~5.6 us kernel boundary it replaces — so the simpler form stays.)
 // All scalars stay on the device in `CgState` (double, as in the reference);
 // kernels are no-ops once `done`; the host only polls the state. Every reduction
 // has a fixed order, so all ranks of a multi-GPU run compute bit-identical
