@@ -107,8 +107,10 @@ typedef struct rba_iter_timings {
   double solve_reduced_system_time;
   double back_substitution_time;
   double update_cameras_time;
-  double hx_time;      /* sum over right_multiply launches of the last solve */
-  int hx_calls;        /* number of right_multiply calls in the last solve  */
+  double hx_time;      /* sum over the TIMED right_multiply launches of the last solve:
+                          every 8th product (calls 1, 9, 17, ...; env RBA_HX_TIMING_STRIDE,
+                          1 = all, 0 = none) is bracketed by HIP events               */
+  int hx_calls;        /* number of launches hx_time sums over                        */
 } rba_iter_timings;
 
 /* One row of the LM log: subset of IterationSummary

@@ -163,6 +163,7 @@ class Solver final : public rba_solver {
     n_obs_ = lm_off[n_lms];
     nvec_ = 9 * n_cams_;
     if (const char* ev = std::getenv("RBA_HX_SINGLE_STREAM")) hx_single_stream_ = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
 
     // ---- sort landmarks by number of observations (stable) ----------------
     perm_.resize(n_lms);
@@ -403,6 +404,7 @@ class Solver final : public rba_solver {
     HIP_CHECK(hipEventCreate(&ev_a_));
     HIP_CHECK(hipEventCreate(&ev_b_));
     hx_events_.resize(2 * kMaxHxEvents);
+    hx_event_call_.resize(kMaxHxEvents);
     for (auto& e : hx_events_) HIP_CHECK(hipEventCreate(&e));
     HIP_CHECK(hipStreamSynchronize(stream_));
 
@@ -640,9 +642,13 @@ class Solver final : public rba_solver {
   // y += sum_l A_l^T A_l x_l over the local landmarks (no pose damping term)
   void launch_hx(const S* x, S* y, const int* done_flag = nullptr) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hx_event_count_ < kMaxHxEvents) {
+    // every hx_timing_stride_-th product is bracketed by HIP events (each event is a
+    // marker packet on the queue: timing all of them costs ~15 us per PCG iteration)
+    if (hx_timing_stride_ > 0 && hx_calls_ % hx_timing_stride_ == (hx_timing_stride_ > 1 ? 1 : 0) &&
+        hx_event_count_ < kMaxHxEvents) {
       e0 = hx_events_[2 * hx_event_count_];
       e1 = hx_events_[2 * hx_event_count_ + 1];
+      hx_event_call_[hx_event_count_] = hx_calls_;
       ++hx_event_count_;
       HIP_CHECK(hipEventRecord(e0, stream_));
     }
@@ -769,15 +775,18 @@ class Solver final : public rba_solver {
     timings_.solve_reduced_system_time = time_end();
     // H*x launches that did real work: one per PCG iteration plus the residual
     // refreshes; launches queued after termination are no-ops and are excluded
-    const int real_hx = std::min(hx_event_count_, cg.num_iterations + cg.num_iterations / 10);
+    const int real_hx = cg.num_iterations + cg.num_iterations / 10;
     double hx_ms = 0;
-    for (int i = 0; i < real_hx; ++i) {
+    int timed = 0;
+    for (int i = 0; i < hx_event_count_; ++i) {
+      if (hx_event_call_[i] >= real_hx) break;
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, hx_events_[2 * i], hx_events_[2 * i + 1]));
       hx_ms += ms;
+      ++timed;
     }
-    timings_.hx_time = hx_ms * 1e-3;
-    timings_.hx_calls = real_hx;
+    timings_.hx_time = hx_ms * 1e-3;  // sum over the TIMED products
+    timings_.hx_calls = timed;
     if (cg_out) *cg_out = cg;
     return RBA_OK;
   }
@@ -1211,8 +1220,10 @@ class Solver final : public rba_solver {
   char* h_pinned_ = nullptr;
   hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
   std::vector<hipEvent_t> hx_events_;
+  std::vector<int> hx_event_call_;  // which H*x call of the solve each event pair brackets
   int hx_event_count_ = 0, hx_calls_ = 0;
   bool hx_single_stream_ = false;
+  int hx_timing_stride_ = 8;  // HIP events around every n-th H*x (rba_iter_timings.hx_time); 0 = off
   // LM state machine
   struct LmState {
     bool active = false, terminated = false, need_linearize = true;
