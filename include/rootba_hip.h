@@ -78,6 +78,9 @@ typedef struct rba_options {
   int implicit_q;                 /* 0 (default): H*x streams the dense Q2^T Jp blocks the
                                      reference materialises; 1: same operator evaluated from
                                      the factors (Jp, Householder vectors, damping rotations) */
+  int solver_type;                /* SolverOptions::SolverType: 0 SQUARE_ROOT (default, LinearizorQR),
+                                     1 SCHUR_COMPLEMENT (LinearizorSC, linearizor_sc.cpp:70-211:
+                                     explicit block-sparse reduced camera matrix + SpMV)        */
 } rba_options;
 
 /* ResidualInfo (src/rootba/bal/residual_info.hpp:57-96), sums in double */

@@ -41,6 +41,7 @@ class Options(C.Structure):
         ("optimized_cost", C.c_int),
         ("staged_execution", C.c_int),
         ("implicit_q", C.c_int),  # product-only switch; the oracle has one operator
+        ("solver_type", C.c_int),  # 0 SQUARE_ROOT, 1 SCHUR_COMPLEMENT
     ]
 
 

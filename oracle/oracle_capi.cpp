@@ -33,6 +33,7 @@ struct orc_options {
   int optimized_cost;
   int staged_execution;
   int implicit_q;  // product-only switch (ignored here)
+  int solver_type;
 };
 
 struct orc_residual_info {
@@ -75,6 +76,7 @@ void orc_default_options(orc_options* o) {
   o->optimized_cost = d.optimized_cost;
   o->staged_execution = d.staged_execution;
   o->implicit_q = 0;
+  o->solver_type = d.solver_type;
 }
 
 int orc_sizeof_lm_iteration() { return int(sizeof(orc::LmIteration)); }
@@ -111,6 +113,7 @@ static Options to_options(const orc_options* o) {
   d.vee_factor = o->vee_factor;
   d.optimized_cost = o->optimized_cost;
   d.staged_execution = o->staged_execution;
+  d.solver_type = o->solver_type;
   return d;
 }
 

@@ -75,6 +75,10 @@ struct Options {
   double vee_factor = 2.0;
   int optimized_cost = 0;  // 0 ERROR, 1 ERROR_VALID, 2 ERROR_VALID_AVG
   int staged_execution = 1;
+  // SolverOptions::SolverType (solver_options.hpp): 0 SQUARE_ROOT (LinearizorQR),
+  // 1 SCHUR_COMPLEMENT (LinearizorSC, src/rootba/solver/linearizor_sc.cpp:70-211; the
+  // reduced matrix is kept DENSE here, i.e. small problems only)
+  int solver_type = 0;
 };
 
 // src/rootba/bal/residual_info.hpp:57-96
@@ -944,6 +948,18 @@ class Oracle {
   // (linearization_qr.hpp:406-429, 821-825)
   void right_multiply(const S* x, S* y) const {
     const size_t n = size_t(P) * n_cams_;
+    if (opt_.solver_type == 1) {
+      // BlockSparseMatrix::right_multiply on H_pp (block_sparse_matrix.hpp); H already
+      // holds the pose damping (linearization_sc.hpp:323-327)
+#pragma omp parallel for num_threads(n_threads_) schedule(static)
+      for (int64_t i = 0; i < int64_t(n); ++i) {
+        S v = 0;
+        const S* row = &sc_H_[size_t(i) * n];
+        for (size_t j = 0; j < n; ++j) v += row[j] * x[j];
+        y[i] = v;
+      }
+      return;
+    }
     std::vector<std::vector<S>> acc(n_threads_);
 #pragma omp parallel num_threads(n_threads_)
     {
@@ -1195,6 +1211,27 @@ class Oracle {
   // (reference CHECK-aborts, :121-122).
   bool linearize(LmIteration* it = nullptr) {
     const double t0 = now_seconds();
+    if (opt_.solver_type == 1) {
+      // LinearizorSC::linearize (linearizor_sc.cpp:70-99): linearize_problem, get_Jp_diag2,
+      // scale_Jl_cols, pose scaling from the UNSCALED Jp column norms
+      const size_t n = size_t(P) * n_cams_;
+      jp_diag2_.assign(n, S(0));
+      bool ok = true;
+      for (int l = 0; l < n_lms_; ++l) {
+        const int K = k(l);
+        std::vector<S> Jp(size_t(2 * K) * P), Jl(size_t(2 * K) * 3), r(2 * K);
+        sc_linearize(l, nullptr, Jp, Jl, r, jp_diag2_.data(), nullptr);
+        for (S v : Jp) ok = ok && std::isfinite(v);
+        for (S v : Jl) ok = ok && std::isfinite(v);
+        for (S v : r) ok = ok && std::isfinite(v);
+      }
+      if (!ok) return false;
+      pose_scaling_.resize(n);
+      for (size_t i = 0; i < n; ++i) pose_scaling_[i] = S(1) / (eps_ + std::sqrt(jp_diag2_[i]));
+      new_linearization_point_ = true;
+      if (it) it->stage1_time = now_seconds() - t0;
+      return true;
+    }
     const bool use_jacobi = opt_.preconditioner_type == 0;
     const bool ok =
         get_stage1(jp_diag2_, use_jacobi ? &precond_blocks_ : nullptr);
@@ -1213,6 +1250,32 @@ class Oracle {
   std::vector<S> solve(S lambda, CgSummary* cg_out = nullptr,
                        LmIteration* it = nullptr) {
     double t0 = now_seconds();
+    if (opt_.solver_type == 1) {
+      // LinearizorSC::solve (linearizor_sc.cpp:101-186): H_pp, b_p with pose + landmark
+      // damping lambda, SCHUR_JACOBI = inverted diagonal blocks of H_pp, PCG
+      const size_t n = size_t(P) * n_cams_;
+      sc_lambda_ = lambda;
+      std::vector<S> b;
+      sc_build(lambda, lambda, pose_scaling_.data(), &sc_H_, b, nullptr);
+      b_ = b;
+      if (it) it->stage2_time = now_seconds() - t0;
+      t0 = now_seconds();
+      precond_blocks_.assign(size_t(81) * n_cams_, S(0));
+      for (int c = 0; c < n_cams_; ++c)
+        for (int a = 0; a < P; ++a)
+          for (int bb = 0; bb < P; ++bb)
+            precond_blocks_[size_t(81) * c + a * P + bb] = sc_H_[(size_t(P) * c + a) * n + P * c + bb];
+      build_preconditioner(precond_blocks_, nullptr);
+      if (it) it->precond_time = now_seconds() - t0;
+      t0 = now_seconds();
+      std::vector<S> inc(n, S(0));
+      CgSummary cg = pcg(b, inc);
+      for (size_t i = 0; i < n; ++i) inc[i] = -inc[i];
+      if (it) it->pcg_time = now_seconds() - t0;
+      if (cg_out) *cg_out = cg;
+      new_linearization_point_ = false;
+      return inc;
+    }
     const bool use_schur_jacobi = opt_.preconditioner_type == 1;
     set_pose_damping(lambda);
     std::vector<S> b;
@@ -1255,7 +1318,9 @@ class Oracle {
   S apply(std::vector<S> inc, LmIteration* it = nullptr) {
     const double t0 = now_seconds();
     bool ok = true;
-    const S l_diff = back_substitute_all(inc.data(), &ok);
+    const S l_diff = opt_.solver_type == 1
+                         ? sc_back_substitute(sc_lambda_, pose_scaling_.data(), inc.data())
+                         : back_substitute_all(inc.data(), &ok);
     if (it) it->backsub_time = now_seconds() - t0;
     if (!std::isfinite(l_diff) || !ok)
       return std::numeric_limits<S>::quiet_NaN();
@@ -1623,6 +1688,8 @@ class Oracle {
   S pose_damping_ = 0;
   std::vector<S> jp_diag2_, pose_scaling_, precond_blocks_, inv_blocks_, b_;
   std::vector<S> pw_Jp_, pw_Jl_, pw_Hll_inv_;
+  mutable std::vector<S> sc_H_;  // dense reduced camera matrix of the SC solver mode
+  S sc_lambda_ = 0;
   bool new_linearization_point_ = false;
 };
 

@@ -42,6 +42,7 @@ class RbaOptions(C.Structure):
         ("optimized_cost", C.c_int),
         ("staged_execution", C.c_int),
         ("implicit_q", C.c_int),
+        ("solver_type", C.c_int),  # 0 SQUARE_ROOT, 1 SCHUR_COMPLEMENT
     ]
 
 

@@ -1,0 +1,333 @@
+// kernels_sc.hpp — explicit Schur-complement backend (solver_type = SCHUR_COMPLEMENT).
+//
+// What the reference's LinearizorSC / LinearizationSC / LandmarkBlockSC compute
+// (src/rootba/solver/linearizor_sc.cpp:70-211, src/rootba/sc/linearization_sc.hpp:55-359,
+// src/rootba/sc/landmark_block.hpp:127-446), laid out for the GPU instead of one
+// (2k x 16) Eigen matrix per landmark + a concurrent hash map of 9x9 blocks:
+//
+//   linearize   per OBSERVATION (one thread each): sqrt(w) Jp D_p (18), sqrt(w) Jl (6),
+//               sqrt(w) r (2), obs-major SoA records; per LANDMARK (one thread each,
+//               fixed order): M = Jl^T Jl (6 unique), v = Jl^T r, column scale of Jl.
+//   prepare(l)  per landmark: H_ll^-1 = (S M S + lambda I)^-1, H_ll^-1 b_l;
+//               per observation: W = Jp^T Jl (9x3), T = W H_ll^-1, and the gradient
+//               record Jp^T (r - Jl H_ll^-1 b_l); gradient summed camera-major (fixed order).
+//   assemble    one wavefront per landmark over its k^2 x 81 block entries:
+//               S(ci, cj) -= T_i W_j^T  (+ Jp_i^T Jp_i on the diagonal), scatter-added
+//               into a block-CSR matrix whose structure (all co-observing camera pairs)
+//               is fixed at construction; slot lookup through a dense n_c x n_c table.
+//   S x         block-CSR SpMV, one workgroup per block row, no atomics.
+//   back-sub    one thread per landmark (fixed order): delta = -H_ll^-1 Jl^T (r + Jp x),
+//               l_diff -= J_inc^T (J_inc / 2 + r), p_w += delta o scale.
+// The 81-float blocks are contiguous ([slot][a][b]) so that both the scatter-add and the
+// SpMV stream whole cache lines. The only nondeterministic order is the scatter-add of
+// the block entries.
+#pragma once
+
+#include "kernels.hpp"
+
+namespace rba {
+
+template <class S>
+struct ScParams {
+  int n_cams, n_lms;
+  int64_t n_obs;
+  // topology (shared with the square-root path)
+  const int* lm_k;
+  const int64_t* lm_obs;
+  const int* obs_cam;
+  const int* obs_lm;
+  const S* obs_xy;
+  const int64_t* cam_obs_off;
+  const int* cam_obs;
+  // state
+  S* cams;
+  S* lms;
+  const S* pose_scaling;
+  // linearisation records
+  S* JpS;   // [obs][18]  sqrt(w) Jp D_p
+  S* JlS;   // [obs][6]   sqrt(w) Jl (column scale applied on use)
+  S* rS;    // [obs][2]
+  S* M;     // [lm][6]    Jl^T Jl: 00 01 02 11 12 22
+  S* v;     // [lm][3]    Jl^T r
+  S* scale; // [lm][3]    1 / (eps + |Jl col|)
+  S* Hinv;  // [lm][9]
+  S* hb;    // [lm][3]    H_ll^-1 b_l
+  S* W;     // [obs][27]  Jp^T Jl
+  S* T;     // [obs][27]  W H_ll^-1
+  S* bO;    // [obs][9]
+  // reduced system
+  const int* slot_of;  // [n_cams * n_cams] block slot or -1
+  const int* row_ptr;  // [n_cams + 1] first slot of each block row
+  const int* cols;     // [nnz] column camera of each slot
+  const int* diag_slot;  // [n_cams]
+  S* vals;             // [nnz][81]
+  S* b;                // [9 n_cams]
+  S* blocks;           // [n_cams][81] diagonal blocks (preconditioner input)
+  int* fail_flag;
+  double* lm_ldiff;
+  int robust_norm, valid_only;
+  S huber, eps;
+};
+
+// ---- linearize ----------------------------------------------------------------
+// linearize_landmark + scale_Jp_cols (sc/landmark_block.hpp:127-176, 200-213), one
+// thread per observation
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_linearize_obs(ScParams<S> p) {
+  const int64_t o = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (o >= p.n_obs) return;
+  const int c = p.obs_cam[o], l = p.obs_lm[o];
+  S cam[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) cam[i] = p.cams[10 * c + i];
+  S res[2], Jp[18], Jl[6];
+  const bool valid = linearize_obs<S>(cam, p.lms[3 * l], p.lms[3 * l + 1], p.lms[3 * l + 2],
+                                      p.obs_xy[2 * o], p.obs_xy[2 * o + 1], res, Jp, Jl);
+  S sw = S(0);
+  if (!p.valid_only || valid) {
+    bool fin = is_finite(res[0]) && is_finite(res[1]);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) fin = fin && is_finite(Jp[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fin = fin && is_finite(Jl[i]);
+    if (!fin) atomicOr(p.fail_flag, 1);
+    S err, w;
+    error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
+    sw = sqrt(w);
+  }
+  // invalid projections keep zero rows (storage_.setZero + skipped assignment)
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+      p.JpS[18 * o + 9 * r + a] = sw == S(0) ? S(0) : sw * Jp[9 * r + a] * p.pose_scaling[9 * c + a];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) p.JlS[6 * o + i] = sw == S(0) ? S(0) : sw * Jl[i];
+  p.rS[2 * o] = sw == S(0) ? S(0) : sw * res[0];
+  p.rS[2 * o + 1] = sw == S(0) ? S(0) : sw * res[1];
+}
+
+// Jl^T Jl, Jl^T r and scale_Jl_cols (landmark_block.hpp:188-198), one thread per landmark
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_landmark_moments(ScParams<S> p) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= p.n_lms) return;
+  S m[6] = {0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0};
+  for (int64_t o = p.lm_obs[l]; o < p.lm_obs[l + 1]; ++o) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const S j0 = p.JlS[6 * o + 3 * r], j1 = p.JlS[6 * o + 3 * r + 1], j2 = p.JlS[6 * o + 3 * r + 2];
+      const S rr = p.rS[2 * o + r];
+      m[0] += j0 * j0;
+      m[1] += j0 * j1;
+      m[2] += j0 * j2;
+      m[3] += j1 * j1;
+      m[4] += j1 * j2;
+      m[5] += j2 * j2;
+      v[0] += j0 * rr;
+      v[1] += j1 * rr;
+      v[2] += j2 * rr;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) p.M[6 * l + i] = m[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p.v[3 * l + i] = v[i];
+  p.scale[3 * l + 0] = S(1) / (p.eps + sqrt(m[0]));
+  p.scale[3 * l + 1] = S(1) / (p.eps + sqrt(m[3]));
+  p.scale[3 * l + 2] = S(1) / (p.eps + sqrt(m[5]));
+}
+
+// ---- prepare(lambda) ------------------------------------------------------------
+// H_ll^-1 and H_ll^-1 b_l (add_Hb, landmark_block.hpp:222-232), one thread per landmark
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_landmark_inverse(ScParams<S> p, S lambda) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= p.n_lms) return;
+  const S s0 = p.scale[3 * l], s1 = p.scale[3 * l + 1], s2 = p.scale[3 * l + 2];
+  const S* m = p.M + 6 * l;
+  const S a00 = s0 * s0 * m[0] + lambda, a01 = s0 * s1 * m[1], a02 = s0 * s2 * m[2];
+  const S a11 = s1 * s1 * m[3] + lambda, a12 = s1 * s2 * m[4], a22 = s2 * s2 * m[5] + lambda;
+  // general 3x3 inverse by cofactors (Eigen's Matrix3::inverse())
+  const S c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+  const S det = a00 * c00 + a01 * c01 + a02 * c02;
+  const S id = S(1) / det;
+  S h[9];
+  h[0] = c00 * id;
+  h[1] = c01 * id;
+  h[2] = c02 * id;
+  h[3] = h[1];
+  h[4] = (a00 * a22 - a02 * a02) * id;
+  h[5] = (a01 * a02 - a00 * a12) * id;
+  h[6] = h[2];
+  h[7] = h[5];
+  h[8] = (a00 * a11 - a01 * a01) * id;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) p.Hinv[9 * l + i] = h[i];
+  const S v0 = s0 * p.v[3 * l], v1 = s1 * p.v[3 * l + 1], v2 = s2 * p.v[3 * l + 2];
+  p.hb[3 * l + 0] = h[0] * v0 + h[1] * v1 + h[2] * v2;
+  p.hb[3 * l + 1] = h[3] * v0 + h[4] * v1 + h[5] * v2;
+  p.hb[3 * l + 2] = h[6] * v0 + h[7] * v1 + h[8] * v2;
+}
+
+// W = Jp^T Jl, T = W H_ll^-1, gradient record Jp^T (r - Jl H_ll^-1 b_l); thread per observation
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_obs_products(ScParams<S> p) {
+  const int64_t o = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (o >= p.n_obs) return;
+  const int l = p.obs_lm[o];
+  S jp[18], jl[6], h[9];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) jp[i] = p.JpS[18 * o + i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) jl[i] = p.JlS[6 * o + i] * p.scale[3 * l + (i % 3)];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) h[i] = p.Hinv[9 * l + i];
+  const S hb0 = p.hb[3 * l], hb1 = p.hb[3 * l + 1], hb2 = p.hb[3 * l + 2];
+  const S t0 = p.rS[2 * o] - (jl[0] * hb0 + jl[1] * hb1 + jl[2] * hb2);
+  const S t1 = p.rS[2 * o + 1] - (jl[3] * hb0 + jl[4] * hb1 + jl[5] * hb2);
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+    const S w0 = jp[a] * jl[0] + jp[9 + a] * jl[3];
+    const S w1 = jp[a] * jl[1] + jp[9 + a] * jl[4];
+    const S w2 = jp[a] * jl[2] + jp[9 + a] * jl[5];
+    p.W[27 * o + 3 * a + 0] = w0;
+    p.W[27 * o + 3 * a + 1] = w1;
+    p.W[27 * o + 3 * a + 2] = w2;
+    p.T[27 * o + 3 * a + 0] = w0 * h[0] + w1 * h[3] + w2 * h[6];
+    p.T[27 * o + 3 * a + 1] = w0 * h[1] + w1 * h[4] + w2 * h[7];
+    p.T[27 * o + 3 * a + 2] = w0 * h[2] + w1 * h[5] + w2 * h[8];
+    p.bO[9 * o + a] = jp[a] * t0 + jp[9 + a] * t1;
+  }
+}
+
+// b[c] = sum over the camera's observations (fixed order), one workgroup per camera
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_cam_gradient(ScParams<S> p) {
+  __shared__ double sm4[4];
+  const int c = blockIdx.x;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t t = p.cam_obs_off[c] + threadIdx.x; t < p.cam_obs_off[c + 1]; t += 256) {
+    const int64_t o = p.cam_obs[t];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) acc[a] += double(p.bO[9 * o + a]);
+  }
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+    const double t = block_sum_256(acc[a], sm4);
+    if (threadIdx.x == 0) p.b[9 * c + a] = S(t);
+  }
+}
+
+// add_Hb (landmark_block.hpp:234-262): one wavefront per landmark, lanes over the
+// k^2 x 81 entries of its camera-pair blocks
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_assemble(ScParams<S> p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l = blockIdx.x * 4 + wave;
+  if (l >= p.n_lms) return;
+  const int k = p.lm_k[l];
+  const int64_t o0 = p.lm_obs[l];
+  const int total = k * k * 81;
+  for (int e = lane; e < total; e += 64) {
+    const int pr = e / 81, rem = e - 81 * pr;
+    const int i = pr / k, j = pr - k * i;
+    const int a = rem / 9, bb = rem - 9 * a;
+    const int64_t oi = o0 + i, oj = o0 + j;
+    const S* t = p.T + 27 * oi + 3 * a;
+    const S* w = p.W + 27 * oj + 3 * bb;
+    S val = -(t[0] * w[0] + t[1] * w[1] + t[2] * w[2]);
+    if (i == j) val += p.JpS[18 * oi + a] * p.JpS[18 * oi + bb] + p.JpS[18 * oi + 9 + a] * p.JpS[18 * oi + 9 + bb];
+    const int slot = p.slot_of[size_t(p.obs_cam[oi]) * p.n_cams + p.obs_cam[oj]];
+    atomic_add(p.vals + size_t(81) * slot + rem, val);
+  }
+}
+
+// pose damping on the diagonal blocks (linearization_sc.hpp:323-327) and a copy of the
+// diagonal blocks for the SCHUR_JACOBI preconditioner (linearizor_sc.cpp:134-137)
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_damp_and_extract_diag(ScParams<S> p, S lambda) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 81 * p.n_cams) return;
+  const int c = i / 81, e = i - 81 * c;
+  S* blk = p.vals + size_t(81) * p.diag_slot[c];
+  S v = blk[e];
+  if (e % 10 == 0) {
+    v += lambda;
+    blk[e] = v;
+  }
+  p.blocks[i] = v;
+}
+
+// ---- S x ------------------------------------------------------------------------
+// BlockSparseMatrix::right_multiply: one workgroup per block row, threads over the
+// row's contiguous 81 nnz_i entries; the 9 row sums are selected by predication
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_spmv(ScParams<S> p, const S* __restrict__ x, S* __restrict__ y,
+                                                 const int* __restrict__ done_flag) {
+  __shared__ double sm4[4];
+  if (done_flag && *done_flag) return;
+  const int c = blockIdx.x;
+  const int s0 = p.row_ptr[c], s1 = p.row_ptr[c + 1];
+  const S* __restrict__ vals = p.vals + size_t(81) * s0;
+  const int total = 81 * (s1 - s0);
+  S acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int t = e / 81, rem = e - 81 * t;
+    const int a = rem / 9, bb = rem - 9 * a;
+    const S prod = vals[e] * x[9 * p.cols[s0 + t] + bb];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[q] += (q == a) ? prod : S(0);
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const double t = block_sum_256(double(acc[q]), sm4);
+    if (threadIdx.x == 0) y[9 * c + q] = S(t);
+  }
+}
+
+// ---- back-substitution (landmark_block.hpp:409-446), one thread per landmark -----
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_back_substitute(ScParams<S> p, const S* __restrict__ x) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= p.n_lms) return;
+  const S s0 = p.scale[3 * l], s1 = p.scale[3 * l + 1], s2 = p.scale[3 * l + 2];
+  const int64_t ob = p.lm_obs[l], oe = p.lm_obs[l + 1];
+  S tmp[3] = {0, 0, 0};
+  for (int64_t o = ob; o < oe; ++o) {
+    const int c = p.obs_cam[o];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      S jp_inc = S(0);
+#pragma unroll
+      for (int a = 0; a < 9; ++a) jp_inc += p.JpS[18 * o + 9 * r + a] * x[9 * c + a];
+      const S t = p.rS[2 * o + r] + jp_inc;
+      tmp[0] += p.JlS[6 * o + 3 * r] * s0 * t;
+      tmp[1] += p.JlS[6 * o + 3 * r + 1] * s1 * t;
+      tmp[2] += p.JlS[6 * o + 3 * r + 2] * s2 * t;
+    }
+  }
+  const S* h = p.Hinv + 9 * l;
+  const S d0 = -(h[0] * tmp[0] + h[1] * tmp[1] + h[2] * tmp[2]);
+  const S d1 = -(h[3] * tmp[0] + h[4] * tmp[1] + h[5] * tmp[2]);
+  const S d2 = -(h[6] * tmp[0] + h[7] * tmp[1] + h[8] * tmp[2]);
+  S acc = S(0);
+  for (int64_t o = ob; o < oe; ++o) {
+    const int c = p.obs_cam[o];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      S j_inc = S(0);
+#pragma unroll
+      for (int a = 0; a < 9; ++a) j_inc += p.JpS[18 * o + 9 * r + a] * x[9 * c + a];
+      j_inc += p.JlS[6 * o + 3 * r] * s0 * d0 + p.JlS[6 * o + 3 * r + 1] * s1 * d1 + p.JlS[6 * o + 3 * r + 2] * s2 * d2;
+      acc += j_inc * (S(0.5) * j_inc + p.rS[2 * o + r]);
+    }
+  }
+  p.lm_ldiff[l] = -double(acc);
+  if (!is_finite(acc)) atomicOr(p.fail_flag, 2);
+  p.lms[3 * l + 0] += d0 * s0;
+  p.lms[3 * l + 1] += d1 * s1;
+  p.lms[3 * l + 2] += d2 * s2;
+}
+
+}  // namespace rba

@@ -24,6 +24,7 @@
 #include "../../include/rootba_hip.h"
 #include "kernels.hpp"
 #include "kernels_big.hpp"
+#include "kernels_sc.hpp"
 
 namespace {
 
@@ -353,14 +354,21 @@ class Solver final : public rba_solver {
     d_lms_.alloc(3 * size_t(n_lms));
     d_cams_bak_.alloc(10 * size_t(n_cams));
     d_lms_bak_.alloc(3 * size_t(n_lms));
-    d_A_.alloc(size_t(blk));
-    d_top0_.alloc(27 * size_t(n_obs_));
-    d_topd_.alloc(27 * size_t(n_obs_));
-    d_qtr_.alloc(2 * size_t(n_obs_));
-    d_dampO_.alloc(27 * size_t(n_obs_));
+    sc_ = opt_.solver_type == 1;
+    if (sc_ && opt_.preconditioner_type != 1)
+      throw HipError{"SCHUR_COMPLEMENT solver: only the SCHUR_JACOBI preconditioner is implemented",
+                     RBA_ERR_UNSUPPORTED};
+    // the dense landmark blocks and the QR by-products exist only for the square-root solver
+    const size_t qr_obs = sc_ ? 0 : size_t(n_obs_);
+    d_A_.alloc(sc_ ? 0 : size_t(blk));
+    d_top0_.alloc(27 * qr_obs);
+    d_topd_.alloc(27 * qr_obs);
+    d_qtr_.alloc(2 * qr_obs);
+    d_dampO_.alloc(27 * qr_obs);
     d_JpS_.alloc(18 * size_t(n_obs_));
-    d_bmO_.alloc(9 * size_t(n_obs_));
-    d_Vh_.alloc(8 * size_t(n_obs_));
+    d_bmO_.alloc(9 * qr_obs);
+    d_Vh_.alloc(8 * qr_obs);
+    if (sc_) build_sc_structure(lm_k, lm_obs, s_obs_cam);
     d_tauH_.alloc(3 * size_t(n_lms));
     d_Zd_.alloc(9 * size_t(n_lms));
     d_Zd_.zero(stream_);
@@ -455,6 +463,97 @@ class Solver final : public rba_solver {
     prm_.jacobi = opt_.preconditioner_type == 0 || opt_.preconditioner_type == 2;
     prm_.huber = S(opt_.huber_parameter);
     prm_.eps = opt_.jacobi_scaling_eps > 0 ? S(opt_.jacobi_scaling_eps) : rba::Eps<S>::eps_sqrt;
+    if (sc_) {
+      scp_.n_cams = n_cams;
+      scp_.n_lms = n_lms;
+      scp_.n_obs = n_obs_;
+      scp_.lm_k = prm_.lm_k;
+      scp_.lm_obs = prm_.lm_obs;
+      scp_.obs_cam = prm_.obs_cam;
+      scp_.obs_lm = prm_.obs_lm;
+      scp_.obs_xy = prm_.obs_xy;
+      scp_.cam_obs_off = prm_.cam_obs_off;
+      scp_.cam_obs = prm_.cam_obs;
+      scp_.cams = prm_.cams;
+      scp_.lms = prm_.lms;
+      scp_.pose_scaling = prm_.pose_scaling;
+      scp_.JpS = prm_.JpS;
+      scp_.JlS = d_sc_JlS_.get();
+      scp_.rS = d_sc_rS_.get();
+      scp_.M = d_sc_M_.get();
+      scp_.v = d_sc_v_.get();
+      scp_.scale = prm_.jl_scale;
+      scp_.Hinv = d_sc_Hinv_.get();
+      scp_.hb = d_sc_hb_.get();
+      scp_.W = d_sc_W_.get();
+      scp_.T = d_sc_T_.get();
+      scp_.bO = d_sc_bO_.get();
+      scp_.slot_of = d_sc_slot_.get();
+      scp_.row_ptr = d_sc_rowptr_.get();
+      scp_.cols = d_sc_cols_.get();
+      scp_.diag_slot = d_sc_diag_.get();
+      scp_.vals = d_sc_vals_.get();
+      scp_.b = prm_.b;
+      scp_.blocks = prm_.blocks;
+      scp_.fail_flag = prm_.fail_flag;
+      scp_.lm_ldiff = prm_.lm_ldiff;
+      scp_.robust_norm = prm_.robust_norm;
+      scp_.valid_only = prm_.valid_only;
+      scp_.huber = prm_.huber;
+      scp_.eps = prm_.eps;
+    }
+  }
+
+  // Block structure of the reduced camera matrix: every ordered pair of cameras that
+  // observe a common landmark (what BlockSparseMatrix::add ends up holding,
+  // block_sparse_matrix.hpp), as block-CSR + a dense (camera, camera) -> slot table.
+  void build_sc_structure(const std::vector<int>& lm_k, const std::vector<int64_t>& lm_obs,
+                          const std::vector<int>& s_obs_cam) {
+    const size_t nc = size_t(n_cams_);
+    std::vector<int> slot(nc * nc, -1);
+    for (int l = 0; l < n_lms_; ++l) {
+      const int64_t o0 = lm_obs[l];
+      for (int i = 0; i < lm_k[l]; ++i) {
+        int* row = slot.data() + size_t(s_obs_cam[o0 + i]) * nc;
+        for (int j = 0; j < lm_k[l]; ++j) row[s_obs_cam[o0 + j]] = 0;
+      }
+    }
+    for (size_t c = 0; c < nc; ++c) slot[c * nc + c] = 0;  // diagonal always present (pose damping)
+    std::vector<int> row_ptr(nc + 1, 0), cols, diag(nc);
+    int nnz = 0;
+    for (size_t c = 0; c < nc; ++c) {
+      row_ptr[c] = nnz;
+      for (size_t d = 0; d < nc; ++d)
+        if (slot[c * nc + d] == 0) {
+          if (d == c) diag[c] = nnz;
+          slot[c * nc + d] = nnz++;
+          cols.push_back(int(d));
+        }
+    }
+    row_ptr[nc] = nnz;
+    sc_nnz_ = nnz;
+    d_sc_slot_.alloc(slot.size());
+    d_sc_rowptr_.alloc(row_ptr.size());
+    d_sc_cols_.alloc(cols.size());
+    d_sc_diag_.alloc(diag.size());
+    d_sc_slot_.upload(slot.data(), slot.size(), stream_);
+    d_sc_rowptr_.upload(row_ptr.data(), row_ptr.size(), stream_);
+    d_sc_cols_.upload(cols.data(), cols.size(), stream_);
+    d_sc_diag_.upload(diag.data(), diag.size(), stream_);
+    d_sc_vals_.alloc(size_t(81) * nnz);
+    d_sc_JlS_.alloc(6 * size_t(n_obs_));
+    d_sc_rS_.alloc(2 * size_t(n_obs_));
+    d_sc_M_.alloc(6 * size_t(n_lms_));
+    d_sc_v_.alloc(3 * size_t(n_lms_));
+    d_sc_Hinv_.alloc(9 * size_t(n_lms_));
+    d_sc_hb_.alloc(3 * size_t(n_lms_));
+    d_sc_W_.alloc(27 * size_t(n_obs_));
+    d_sc_T_.alloc(27 * size_t(n_obs_));
+    d_sc_bO_.alloc(9 * size_t(n_obs_));
+    HIP_CHECK(hipStreamSynchronize(stream_));  // the host vectors above go out of scope
+    // algorithmic traffic of one S x: the blocks, their column indices, x and y
+    hx_bytes_ = int64_t(sizeof(S)) * 81 * nnz + int64_t(4) * nnz + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
+    hx_flops_ = int64_t(162) * nnz;
   }
 
   ~Solver() override {
@@ -477,6 +576,9 @@ class Solver final : public rba_solver {
     // nranks == 1 is allowed on purpose: a one-rank communicator exercises the whole
     // RCCL call path (dlopen, unique id, every all-reduce site) on a single-GPU box
     if (nranks < 1) return;
+    if (sc_ && nranks > 1)
+      throw HipError{"SCHUR_COMPLEMENT solver: landmark sharding is not implemented (single GPU only)",
+                     RBA_ERR_UNSUPPORTED};
     if (!g_rccl.load()) throw HipError{"cannot load librccl.so", RBA_ERR_COMM};
     Rccl::UniqueId id;
     std::memcpy(&id, uid, sizeof(id));
@@ -488,6 +590,9 @@ class Solver final : public rba_solver {
   }
 
   void comm_init_callback(int rank, int nranks, rba_allreduce_fn fn, void* ctx) override {
+    if (sc_ && nranks > 1)
+      throw HipError{"SCHUR_COMPLEMENT solver: landmark sharding is not implemented (single GPU only)",
+                     RBA_ERR_UNSUPPORTED};
     rank_ = rank;
     nranks_ = nranks;
     cb_fn_ = fn;
@@ -585,16 +690,24 @@ class Solver final : public rba_solver {
     all_reduce(d_fail_.get(), 1, kNcclMax);
     hipLaunchKernelGGL((rba::k_pose_scaling<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                        d_jp_diag2_.get(), d_pose_scaling_.get(), prm_.eps, nvec_);
-    for_each_class([&](auto ch_tag, int begin, int end) {
-      constexpr int CH = decltype(ch_tag)::value;
-      const size_t lds = 4 * size_t(rba::ClassCfg<CH>::WAVE_LDS) * sizeof(S);
-      hipLaunchKernelGGL((rba::k_linearize_qr<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
-                         lds, stream_, prm_, begin, end);
-    });
-    if (n_big_ > 0)
-      hipLaunchKernelGGL((rba::k_linearize_qr_big<S>), dim3(n_big_), dim3(256),
-                         size_t(16) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_);
-    launch_cam_stage1(prm_);
+    if (sc_) {
+      // LinearizorSC::linearize (linearizor_sc.cpp:70-99)
+      hipLaunchKernelGGL((rba::k_sc_linearize_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0,
+                         stream_, scp_);
+      hipLaunchKernelGGL((rba::k_sc_landmark_moments<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_,
+                         scp_);
+    } else {
+      for_each_class([&](auto ch_tag, int begin, int end) {
+        constexpr int CH = decltype(ch_tag)::value;
+        const size_t lds = 4 * size_t(rba::ClassCfg<CH>::WAVE_LDS) * sizeof(S);
+        hipLaunchKernelGGL((rba::k_linearize_qr<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
+                           lds, stream_, prm_, begin, end);
+      });
+      if (n_big_ > 0)
+        hipLaunchKernelGGL((rba::k_linearize_qr_big<S>), dim3(n_big_), dim3(256),
+                           size_t(16) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_);
+      launch_cam_stage1(prm_);
+    }
     HIP_CHECK(hipGetLastError());
     int fail = 0;
     HIP_CHECK(hipMemcpyAsync(&fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -607,6 +720,21 @@ class Solver final : public rba_solver {
 
   // ---- stage 2 ------------------------------------------------------------------
   void run_stage2(S lambda) {
+    if (sc_) {
+      // set_landmark_damping + get_Hb + block-diagonal copy (linearizor_sc.cpp:101-140)
+      hipLaunchKernelGGL((rba::k_sc_landmark_inverse<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_,
+                         scp_, lambda);
+      hipLaunchKernelGGL((rba::k_sc_obs_products<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0,
+                         stream_, scp_);
+      d_sc_vals_.zero(stream_);
+      hipLaunchKernelGGL((rba::k_sc_assemble<S>), dim3((n_lms_ + 3) / 4), dim3(256), 0, stream_, scp_);
+      hipLaunchKernelGGL((rba::k_sc_cam_gradient<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_);
+      hipLaunchKernelGGL((rba::k_sc_damp_and_extract_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0,
+                         stream_, scp_, lambda);
+      pose_damping_ = lambda;
+      landmark_damping_valid_ = true;
+      return;
+    }
     for_each_class([&](auto ch_tag, int begin, int end) {
       constexpr int CH = decltype(ch_tag)::value;
       hipLaunchKernelGGL((rba::k_stage2<S, CH>), dim3((end - begin + 3) / 4), dim3(256), 0,
@@ -651,6 +779,13 @@ class Solver final : public rba_solver {
       hx_event_call_[hx_event_count_] = hx_calls_;
       ++hx_event_count_;
       HIP_CHECK(hipEventRecord(e0, stream_));
+    }
+    if (sc_) {
+      // y = S x (pose damping is part of S); overwrites y
+      hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_, x, y, done_flag);
+      if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
+      ++hx_calls_;
+      return;
     }
     if (opt_.implicit_q) {
       launch_hx_implicit(x, y, done_flag);
@@ -747,7 +882,7 @@ class Solver final : public rba_solver {
     launch_hx(d_vin_.get(), d_tmp_.get());
     all_reduce(d_tmp_.get(), nvec_);
     hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
-                       d_vin_.get(), d_tmp_.get(), pose_damping_, nvec_);
+                       d_vin_.get(), d_tmp_.get(), sc_ ? S(0) : pose_damping_, nvec_);
     d_tmp_.download(static_cast<S*>(y), nvec_, stream_);
     sync();
   }
@@ -768,7 +903,7 @@ class Solver final : public rba_solver {
     time_begin();
     hx_event_count_ = 0;
     hx_calls_ = 0;
-    rba_cg_summary cg = pcg(lambda);
+    rba_cg_summary cg = pcg(sc_ ? S(0) : lambda);  // SC: the damping is inside the matrix
     hipLaunchKernelGGL((rba::k_negate<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                        d_x_.get(), nvec_);
     d_x_.download(static_cast<S*>(inc_out), nvec_, stream_);
@@ -870,14 +1005,19 @@ class Solver final : public rba_solver {
     time_begin();
     d_inc_.upload(static_cast<const S*>(inc), nvec_, stream_);
     HIP_CHECK(hipMemsetAsync(d_fail_.get(), 0, sizeof(int), stream_));
-    for_each_class([&](auto ch_tag, int begin, int end) {
-      constexpr int CH = decltype(ch_tag)::value;
-      hipLaunchKernelGGL((rba::k_back_substitute<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
-                         0, stream_, prm_, begin, end, d_inc_.get());
-    });
-    if (n_big_ > 0)
-      hipLaunchKernelGGL((rba::k_back_substitute_big<S>), dim3(n_big_), dim3(256),
-                         size_t(9) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_, d_inc_.get());
+    if (sc_) {
+      hipLaunchKernelGGL((rba::k_sc_back_substitute<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_,
+                         scp_, d_inc_.get());
+    } else {
+      for_each_class([&](auto ch_tag, int begin, int end) {
+        constexpr int CH = decltype(ch_tag)::value;
+        hipLaunchKernelGGL((rba::k_back_substitute<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
+                           0, stream_, prm_, begin, end, d_inc_.get());
+      });
+      if (n_big_ > 0)
+        hipLaunchKernelGGL((rba::k_back_substitute_big<S>), dim3(n_big_), dim3(256),
+                           size_t(9) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_, d_inc_.get());
+    }
     const int blocks = std::min(kReduceBlocks, (n_lms_ + 255) / 256);
     hipLaunchKernelGGL((rba::k_sum_ldiff), dim3(blocks), dim3(256), 0, stream_,
                        d_lm_ldiff_.get(), n_lms_, d_partials_.get());
@@ -1088,6 +1228,7 @@ class Solver final : public rba_solver {
   // ---- misc -----------------------------------------------------------------------------
   // PMC calibration helper: stream the block storage once; returns bytes read
   int64_t debug_read_A(int vec) override {
+    if (sc_) throw HipError{"the SCHUR_COMPLEMENT solver has no dense landmark blocks", RBA_ERR_UNSUPPORTED};
     use_device();
     const size_t n = d_A_.size() * sizeof(S) / sizeof(float);
     const float* src = reinterpret_cast<const float*>(d_A_.get());
@@ -1119,6 +1260,7 @@ class Solver final : public rba_solver {
     sync();
   }
   void get_landmark_R(int damped, void* R6, void* q3) override {
+    if (sc_) throw HipError{"the SCHUR_COMPLEMENT solver has no triangular factors", RBA_ERR_UNSUPPORTED};
     use_device();
     std::vector<S> R(6 * size_t(n_lms_)), q(3 * size_t(n_lms_));
     if (damped) {
@@ -1223,6 +1365,12 @@ class Solver final : public rba_solver {
   std::vector<int> hx_event_call_;  // which H*x call of the solve each event pair brackets
   int hx_event_count_ = 0, hx_calls_ = 0;
   bool hx_single_stream_ = false;
+  // explicit Schur-complement backend (solver_type = 1)
+  bool sc_ = false;
+  int sc_nnz_ = 0;
+  rba::ScParams<S> scp_{};
+  DevBuf<S> d_sc_JlS_, d_sc_rS_, d_sc_M_, d_sc_v_, d_sc_Hinv_, d_sc_hb_, d_sc_W_, d_sc_T_, d_sc_bO_, d_sc_vals_;
+  DevBuf<int> d_sc_slot_, d_sc_rowptr_, d_sc_cols_, d_sc_diag_;
   int hx_timing_stride_ = 8;  // HIP events around every n-th H*x (rba_iter_timings.hx_time); 0 = off
   // LM state machine
   struct LmState {
@@ -1286,6 +1434,7 @@ void rba_default_options(rba_options* o) {
   o->optimized_cost = 0;
   o->staged_execution = 1;
   o->implicit_q = 0;
+  o->solver_type = 0;
 }
 
 const char* rba_last_error(void) { return g_last_error.c_str(); }
