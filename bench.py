@@ -125,9 +125,11 @@ def main():
     ap.add_argument("--power-order", type=int, default=10)
     ap.add_argument("--implicit-q", action="store_true",
                     help="H*x from the QR factors (SURVEY.md 8f #1) instead of the dense blocks")
+    ap.add_argument("--solver-type", choices=["SQUARE_ROOT", "SCHUR_COMPLEMENT"], default="SQUARE_ROOT",
+                    help="SCHUR_COMPLEMENT: explicit reduced camera matrix + SpMV (SURVEY.md 8f #4), 1 GPU")
     args = ap.parse_args()
     _SOLVER_KW.update(preconditioner_type=PRECOND[args.preconditioner], power_order=args.power_order)
-    _GPU_KW.update(implicit_q=int(args.implicit_q))
+    _GPU_KW.update(implicit_q=int(args.implicit_q), solver_type=int(args.solver_type == "SCHUR_COMPLEMENT"))
 
     import torch
     import torch.distributed as dist
@@ -204,7 +206,7 @@ def main():
         achieved = stats["hx_bytes"] / avg_hx / 1e9 if avg_hx else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hx_traffic.json")
-        if os.path.exists(tpath) and world == 1 and not args.implicit_q:
+        if os.path.exists(tpath) and world == 1 and not args.implicit_q and args.solver_type == "SQUARE_ROOT":
             try:
                 with open(tpath) as f:
                     traffic = json.load(f).get(args.workload, {}).get("traffic_bytes_per_launch")
@@ -225,7 +227,7 @@ def main():
             "data": data,
             "config": {
                 "workload": f"BAL {args.workload} ({data}): {prob.n_cams} cams, {prob.n_lms} lms, {prob.n_obs} obs, "
-                            f"solver=SQUARE_ROOT, {args.preconditioner}, Huber(1), float32",
+                            f"solver={args.solver_type}, {args.preconditioner}, Huber(1), float32",
                 "parallelism": f"landmarks sharded over {world} GPU(s), RCCL all-reduce of camera vectors",
                 "cg_iterations_per_step": sum(r.cg_iterations for r in timed) / max(1, len(timed)),
                 "successful_steps": sum(r.step_is_successful for r in timed),
@@ -233,7 +235,9 @@ def main():
                 "final_cost": [r.cost for r in rows if r.step_is_successful][-1],
             },
             "roofline": {
-                "kernel": ("k_hx_implicit (H*x from the QR factors; algorithmic bytes = SURVEY.md 8d implicit-Q formula)"
+                "kernel": ("k_sc_spmv (S*x on the explicit block-CSR reduced camera matrix; algorithmic bytes = "
+                           "81 s + 4 per block + 2 x 9 n_c s)" if args.solver_type == "SCHUR_COMPLEMENT" else
+                           "k_hx_implicit (H*x from the QR factors; algorithmic bytes = SURVEY.md 8d implicit-Q formula)"
                            if args.implicit_q else
                            "k_hx (H*x = sum_l A_l^T A_l x, all k-classes of one right_multiply)"),
                 "bound": "hbm",

@@ -11,16 +11,16 @@
 //   prepare(l)  per landmark: H_ll^-1 = (S M S + lambda I)^-1, H_ll^-1 b_l;
 //               per observation: W = Jp^T Jl (9x3), T = W H_ll^-1, and the gradient
 //               record Jp^T (r - Jl H_ll^-1 b_l); gradient summed camera-major (fixed order).
-//   assemble    one wavefront per landmark over its k^2 x 81 block entries:
-//               S(ci, cj) -= T_i W_j^T  (+ Jp_i^T Jp_i on the diagonal), scatter-added
-//               into a block-CSR matrix whose structure (all co-observing camera pairs)
-//               is fixed at construction; slot lookup through a dense n_c x n_c table.
+//   assemble    one wavefront per 9x9 block of the reduced matrix: S(ci, cj) = - sum over the
+//               landmarks seen by both cameras of T_i W_j^T  (+ Jp_i^T Jp_i on the diagonal),
+//               gathered through a per-block list of observation pairs; the block-CSR
+//               structure (all co-observing camera pairs) and the lists are fixed at
+//               construction (dense n_c x n_c slot table on the host).
 //   S x         block-CSR SpMV, one workgroup per block row, no atomics.
 //   back-sub    one thread per landmark (fixed order): delta = -H_ll^-1 Jl^T (r + Jp x),
 //               l_diff -= J_inc^T (J_inc / 2 + r), p_w += delta o scale.
-// The 81-float blocks are contiguous ([slot][a][b]) so that both the scatter-add and the
-// SpMV stream whole cache lines. The only nondeterministic order is the scatter-add of
-// the block entries.
+// The 81-float blocks are contiguous ([slot][a][b]); every reduction has a fixed order,
+// the backend uses no atomics at all.
 #pragma once
 
 #include "kernels.hpp"
@@ -56,7 +56,6 @@ struct ScParams {
   S* T;     // [obs][27]  W H_ll^-1
   S* bO;    // [obs][9]
   // reduced system
-  const int* slot_of;  // [n_cams * n_cams] block slot or -1
   const int* row_ptr;  // [n_cams + 1] first slot of each block row
   const int* cols;     // [nnz] column camera of each slot
   const int* diag_slot;  // [n_cams]
@@ -219,27 +218,93 @@ __global__ __launch_bounds__(256) void k_sc_cam_gradient(ScParams<S> p) {
   }
 }
 
-// add_Hb (landmark_block.hpp:234-262): one wavefront per landmark, lanes over the
-// k^2 x 81 entries of its camera-pair blocks
+// add_Hb (landmark_block.hpp:234-262), block-major: one workgroup per 9x9 block (ci <= cj)
+// of the reduced matrix sums the contributions -T_i W_j^T of all landmarks seen by both
+// cameras (plus Jp_i^T Jp_i on the diagonal) from a per-block list of observation pairs
+// built at construction, and also writes the transposed block (cj, ci). Fixed order, no
+// atomics, no zero fill; lane e owns entry e of the block, lanes 0..16 also entry 64 + e.
+// The four wavefronts take interleaved chunks of kScUnroll pairs (the lists of a camera's
+// own block and of neighbouring cameras are thousands long: one wavefront per block leaves
+// a latency-bound tail), walk them with wave-uniform (scalar) index loads so that the
+// 108-byte gathers of several pairs are in flight together, and are summed in wave order.
+constexpr int kScUnroll = 4;
+// three consecutive scalars with ONE load instruction (global_load_dwordx3 / 3 x dwordx2):
+// the gathers are bound by the number of vector memory instructions, not by bytes
 template <class S>
-__global__ __launch_bounds__(256) void k_sc_assemble(ScParams<S> p) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int l = blockIdx.x * 4 + wave;
-  if (l >= p.n_lms) return;
-  const int k = p.lm_k[l];
-  const int64_t o0 = p.lm_obs[l];
-  const int total = k * k * 81;
-  for (int e = lane; e < total; e += 64) {
-    const int pr = e / 81, rem = e - 81 * pr;
-    const int i = pr / k, j = pr - k * i;
-    const int a = rem / 9, bb = rem - 9 * a;
-    const int64_t oi = o0 + i, oj = o0 + j;
-    const S* t = p.T + 27 * oi + 3 * a;
-    const S* w = p.W + 27 * oj + 3 * bb;
-    S val = -(t[0] * w[0] + t[1] * w[1] + t[2] * w[2]);
-    if (i == j) val += p.JpS[18 * oi + a] * p.JpS[18 * oi + bb] + p.JpS[18 * oi + 9 + a] * p.JpS[18 * oi + 9 + bb];
-    const int slot = p.slot_of[size_t(p.obs_cam[oi]) * p.n_cams + p.obs_cam[oj]];
-    atomic_add(p.vals + size_t(81) * slot + rem, val);
+struct __attribute__((packed, aligned(sizeof(S)))) Triple {
+  S v[3];
+};
+template <class S>
+__device__ __forceinline__ void load3(const S* __restrict__ src, S out[3]) {
+  const Triple<S> t = *reinterpret_cast<const Triple<S>*>(src);
+  out[0] = t.v[0];
+  out[1] = t.v[1];
+  out[2] = t.v[2];
+}
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_assemble(ScParams<S> p, const int* __restrict__ upper_slot,
+                                                     const int* __restrict__ mirror_slot,
+                                                     const int64_t* __restrict__ pair_ptr,
+                                                     const int* __restrict__ pair_oi,
+                                                     const int* __restrict__ pair_oj, int n_upper) {
+  __shared__ S part[3][81];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = blockIdx.x;
+  const int a0 = lane / 9, b0 = lane - 9 * a0;  // entry lane       (a0 <= 7)
+  const int e1 = 64 + lane;                      // entry 64 + lane  (lanes 0..16)
+  const bool has1 = e1 < 81;
+  const int a1 = has1 ? e1 / 9 : 0, b1 = has1 ? e1 - 9 * a1 : 0;
+  S acc0 = S(0), acc1 = S(0);
+  const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
+  for (int64_t q = q0 + wave * kScUnroll; q < q1; q += 4 * kScUnroll) {
+    int oi[kScUnroll], oj[kScUnroll];
+    S t0[kScUnroll][3], w0[kScUnroll][3], t1[kScUnroll][3], w1[kScUnroll][3];
+#pragma unroll
+    for (int r = 0; r < kScUnroll; ++r) {
+      const bool ok = q + r < q1;
+      oi[r] = ok ? pair_oi[q + r] : -1;
+      oj[r] = ok ? pair_oj[q + r] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < kScUnroll; ++r) {
+      const bool ok = oi[r] >= 0;
+      const S* __restrict__ T = p.T + 27 * int64_t(ok ? oi[r] : 0);
+      const S* __restrict__ W = p.W + 27 * int64_t(ok ? oj[r] : 0);
+      load3(T + 3 * a0, t0[r]);
+      load3(W + 3 * b0, w0[r]);
+      load3(T + 3 * a1, t1[r]);
+      load3(W + 3 * b1, w1[r]);
+      if (!ok) t0[r][0] = t0[r][1] = t0[r][2] = S(0);
+      if (!ok || !has1) t1[r][0] = t1[r][1] = t1[r][2] = S(0);
+    }
+#pragma unroll
+    for (int r = 0; r < kScUnroll; ++r) {
+      acc0 -= t0[r][0] * w0[r][0] + t0[r][1] * w0[r][1] + t0[r][2] * w0[r][2];
+      acc1 -= t1[r][0] * w1[r][0] + t1[r][1] * w1[r][1] + t1[r][2] * w1[r][2];
+      if (oi[r] >= 0 && oi[r] == oj[r]) {  // wave-uniform: diagonal blocks only
+        const S* __restrict__ J = p.JpS + 18 * int64_t(oi[r]);
+        acc0 += J[a0] * J[b0] + J[9 + a0] * J[9 + b0];
+        if (has1) acc1 += J[a1] * J[b1] + J[9 + a1] * J[9 + b1];
+      }
+    }
+  }
+  if (wave > 0) {
+    part[wave - 1][lane] = acc0;
+    if (has1) part[wave - 1][e1] = acc1;
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  acc0 = ((acc0 + part[0][lane]) + part[1][lane]) + part[2][lane];
+  if (has1) acc1 = ((acc1 + part[0][e1]) + part[1][e1]) + part[2][e1];
+  S* out = p.vals + size_t(81) * upper_slot[u];
+  out[lane] = acc0;
+  if (has1) out[e1] = acc1;
+  const int m = mirror_slot[u];
+  if (m >= 0) {
+    S* outT = p.vals + size_t(81) * m;
+    outT[9 * b0 + a0] = acc0;
+    if (has1) outT[9 * b1 + a1] = acc1;
   }
 }
 

@@ -488,7 +488,6 @@ class Solver final : public rba_solver {
       scp_.W = d_sc_W_.get();
       scp_.T = d_sc_T_.get();
       scp_.bO = d_sc_bO_.get();
-      scp_.slot_of = d_sc_slot_.get();
       scp_.row_ptr = d_sc_rowptr_.get();
       scp_.cols = d_sc_cols_.get();
       scp_.diag_slot = d_sc_diag_.get();
@@ -532,11 +531,57 @@ class Solver final : public rba_solver {
     }
     row_ptr[nc] = nnz;
     sc_nnz_ = nnz;
-    d_sc_slot_.alloc(slot.size());
+    // upper blocks (ci <= cj; cameras ascend inside a landmark, so i <= j) and, per upper
+    // block, the list of contributing observation pairs (counting sort, landmark order)
+    std::vector<int> upper_of(size_t(nnz), -1), upper_slot, mirror_slot;
+    for (size_t c = 0; c < nc; ++c)
+      for (size_t d = c; d < nc; ++d)
+        if (slot[c * nc + d] >= 0) {
+          upper_of[slot[c * nc + d]] = int(upper_slot.size());
+          upper_slot.push_back(slot[c * nc + d]);
+          mirror_slot.push_back(d == c ? -1 : slot[d * nc + c]);
+        }
+    const int n_upper = int(upper_slot.size());
+    sc_n_upper_ = n_upper;
+    std::vector<int64_t> pair_ptr(size_t(n_upper) + 1, 0);
+    for (int l = 0; l < n_lms_; ++l) {
+      const int64_t o0 = lm_obs[l];
+      for (int i = 0; i < lm_k[l]; ++i) {
+        const int* row = slot.data() + size_t(s_obs_cam[o0 + i]) * nc;
+        for (int j = i; j < lm_k[l]; ++j) ++pair_ptr[size_t(upper_of[row[s_obs_cam[o0 + j]]]) + 1];
+      }
+    }
+    for (int t = 0; t < n_upper; ++t) pair_ptr[t + 1] += pair_ptr[t];
+    const int64_t n_pairs = pair_ptr[n_upper];
+    std::vector<int> pair_oi(n_pairs), pair_oj(n_pairs);
+    {
+      std::vector<int64_t> fill(pair_ptr.begin(), pair_ptr.end() - 1);
+      for (int l = 0; l < n_lms_; ++l) {
+        const int64_t o0 = lm_obs[l];
+        for (int i = 0; i < lm_k[l]; ++i) {
+          const int* row = slot.data() + size_t(s_obs_cam[o0 + i]) * nc;
+          for (int j = i; j < lm_k[l]; ++j) {
+            const int64_t d = fill[upper_of[row[s_obs_cam[o0 + j]]]]++;
+            pair_oi[d] = int(o0 + i);
+            pair_oj[d] = int(o0 + j);
+          }
+        }
+      }
+    }
+    d_sc_upper_.alloc(n_upper);
+    d_sc_mirror_.alloc(n_upper);
+    d_sc_upper_.upload(upper_slot.data(), n_upper, stream_);
+    d_sc_mirror_.upload(mirror_slot.data(), n_upper, stream_);
+    d_sc_pair_ptr_.alloc(pair_ptr.size());
+    d_sc_pair_oi_.alloc(n_pairs);
+    d_sc_pair_oj_.alloc(n_pairs);
+    d_sc_pair_ptr_.upload(pair_ptr.data(), pair_ptr.size(), stream_);
+    d_sc_pair_oi_.upload(pair_oi.data(), n_pairs, stream_);
+    d_sc_pair_oj_.upload(pair_oj.data(), n_pairs, stream_);
+    sc_assemble_bytes_ = n_pairs * int64_t(8 + 54 * sizeof(S)) + int64_t(81) * nnz * sizeof(S);
     d_sc_rowptr_.alloc(row_ptr.size());
     d_sc_cols_.alloc(cols.size());
     d_sc_diag_.alloc(diag.size());
-    d_sc_slot_.upload(slot.data(), slot.size(), stream_);
     d_sc_rowptr_.upload(row_ptr.data(), row_ptr.size(), stream_);
     d_sc_cols_.upload(cols.data(), cols.size(), stream_);
     d_sc_diag_.upload(diag.data(), diag.size(), stream_);
@@ -726,8 +771,9 @@ class Solver final : public rba_solver {
                          scp_, lambda);
       hipLaunchKernelGGL((rba::k_sc_obs_products<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0,
                          stream_, scp_);
-      d_sc_vals_.zero(stream_);
-      hipLaunchKernelGGL((rba::k_sc_assemble<S>), dim3((n_lms_ + 3) / 4), dim3(256), 0, stream_, scp_);
+      hipLaunchKernelGGL((rba::k_sc_assemble<S>), dim3(sc_n_upper_), dim3(256), 0, stream_, scp_,
+                         d_sc_upper_.get(), d_sc_mirror_.get(), d_sc_pair_ptr_.get(), d_sc_pair_oi_.get(),
+                         d_sc_pair_oj_.get(), sc_n_upper_);
       hipLaunchKernelGGL((rba::k_sc_cam_gradient<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_);
       hipLaunchKernelGGL((rba::k_sc_damp_and_extract_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0,
                          stream_, scp_, lambda);
@@ -1370,7 +1416,10 @@ class Solver final : public rba_solver {
   int sc_nnz_ = 0;
   rba::ScParams<S> scp_{};
   DevBuf<S> d_sc_JlS_, d_sc_rS_, d_sc_M_, d_sc_v_, d_sc_Hinv_, d_sc_hb_, d_sc_W_, d_sc_T_, d_sc_bO_, d_sc_vals_;
-  DevBuf<int> d_sc_slot_, d_sc_rowptr_, d_sc_cols_, d_sc_diag_;
+  DevBuf<int> d_sc_rowptr_, d_sc_cols_, d_sc_diag_, d_sc_pair_oi_, d_sc_pair_oj_, d_sc_upper_, d_sc_mirror_;
+  int sc_n_upper_ = 0;
+  DevBuf<int64_t> d_sc_pair_ptr_;
+  int64_t sc_assemble_bytes_ = 0;
   int hx_timing_stride_ = 8;  // HIP events around every n-th H*x (rba_iter_timings.hx_time); 0 = off
   // LM state machine
   struct LmState {
