@@ -75,7 +75,7 @@ struct Options {
   double vee_factor = 2.0;
   int optimized_cost = 0;  // 0 ERROR, 1 ERROR_VALID, 2 ERROR_VALID_AVG
   int staged_execution = 1;
-  // SolverOptions::SolverType (solver_options.hpp): 0 SQUARE_ROOT (LinearizorQR),
+  // SolverOptions::SolverType (src/rootba/bal/solver_options.hpp:58-62): 0 SQUARE_ROOT (LinearizorQR),
   // 1 SCHUR_COMPLEMENT (LinearizorSC, src/rootba/solver/linearizor_sc.cpp:70-211; the
   // reduced matrix is kept DENSE here, i.e. small problems only)
   int solver_type = 0;

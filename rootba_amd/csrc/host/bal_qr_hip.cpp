@@ -34,6 +34,7 @@ void usage() {
       "  --optimized-cost ERROR|ERROR_VALID|ERROR_VALID_AVG\n"
       "  --eta <e> --max-linear-solver-iterations <n> --function-tolerance <t>\n"
       "  --jacobi-scaling-epsilon <e> --log-path <ba_log.json> --device <n>\n"
+      "  --solver-type SQUARE_ROOT|SCHUR_COMPLEMENT   (default SQUARE_ROOT)\n"
       "  --implicit-q                           evaluate H*x from the QR factors instead of the dense blocks\n"
       "  --dry-run                              load + preprocess only, print problem statistics");
 }
@@ -197,6 +198,11 @@ int main(int argc, char** argv) {
       else if (v == "SCHUR_JACOBI") so.preconditioner_type = SolverOptions::PreconditionerType::SCHUR_JACOBI;
       else if (v == "POWER_SCHUR_COMPLEMENT") so.preconditioner_type = SolverOptions::PreconditionerType::POWER_SCHUR_COMPLEMENT;
       else { std::fprintf(stderr, "preconditioner %s not implemented\n", v.c_str()); return 1; }
+    } else if (a == "--solver-type") {
+      const std::string v = val();
+      if (v == "SQUARE_ROOT") so.solver_type = SolverOptions::SolverType::SQUARE_ROOT;
+      else if (v == "SCHUR_COMPLEMENT") so.solver_type = SolverOptions::SolverType::SCHUR_COMPLEMENT;
+      else { std::fprintf(stderr, "solver type %s not implemented\n", v.c_str()); return 1; }
     } else if (a == "--robust-norm") {
       const std::string v = val();
       so.residual.robust_norm = v == "HUBER" ? BalResidualOptions::RobustNorm::HUBER : BalResidualOptions::RobustNorm::NONE;

@@ -36,6 +36,10 @@ struct BalResidualOptions {
 };
 
 struct SolverOptions {
+  // reference src/rootba/bal/solver_options.hpp:58-62, 89-90: SQUARE_ROOT (default), SCHUR_COMPLEMENT; POWER_SCHUR_COMPLEMENT
+  // (LinearizorPowerSC) is not built here
+  enum class SolverType { SQUARE_ROOT, SCHUR_COMPLEMENT };
+  SolverType solver_type = SolverType::SQUARE_ROOT;
   enum class PreconditionerType { JACOBI, SCHUR_JACOBI, POWER_SCHUR_COMPLEMENT };
   enum class OptimizedCost { ERROR, ERROR_VALID, ERROR_VALID_AVG };
   int verbosity_level = 2;
@@ -88,6 +92,7 @@ struct SolverOptions {
     o.optimized_cost = int(optimized_cost);
     o.staged_execution = staged_execution;
     o.implicit_q = implicit_q;
+    o.solver_type = solver_type == SolverType::SCHUR_COMPLEMENT ? 1 : 0;
     return o;
   }
 };
@@ -117,7 +122,7 @@ struct IterationSummary {  // subset of reference solver_summary.hpp:99-204
 };
 struct SolverSummary {
   std::vector<IterationSummary> iterations;
-  std::string solver_type = "bal_qr_hip";  // the reference's names are bal_qr / bal_sc / bal_power_sc
+  std::string solver_type = "bal_qr_hip";  // bal_sc_hip for the SC backend (reference: bal_qr / bal_sc / bal_power_sc)
   std::string message;
   int termination_type = 0;  // 0 NO_CONVERGENCE, 1 CONVERGENCE
   double initial_cost = 0, final_cost = 0;
@@ -209,6 +214,7 @@ void bundle_adjust_manual(BalProblem<Scalar>& bal_problem, const SolverOptions& 
   SolverSummary local;
   SolverSummary& summary = summary_out ? *summary_out : local;
   summary = SolverSummary();
+  if (options.solver_type == SolverOptions::SolverType::SCHUR_COMPLEMENT) summary.solver_type = "bal_sc_hip";
   const auto t_total = std::chrono::steady_clock::now();
   auto seconds_since = [](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
