@@ -395,4 +395,111 @@ __global__ __launch_bounds__(256) void k_sc_back_substitute(ScParams<S> p, const
   p.lms[3 * l + 2] += d2 * s2;
 }
 
+// ===========================================================================
+// Explicit reduced camera matrix of the SQUARE-ROOT solver:
+//   S = sum_l A_l^T A_l,  A_l = (Q2^T Jp)_l  (the 2k x 9k blocks H*x streams),
+// in the same block-CSR layout as above, for long PCG solves (solver.hip: pcg()).
+// With Q = [Q1 Q2] orthogonal and Jp block diagonal per observation,
+//   A_l^T A_l = Jp^T Jp - (Q1^T Jp)^T (Q1^T Jp),
+// so an OFF-DIAGONAL block (ci != cj) is exactly  - topd_i^T topd_j : a rank-3 product
+// of the damped top rows that stage 2 produced with orthogonal transformations only
+// (no H_ll^-1, nothing to cancel) — gathered block-major like the SC assembly.
+// The DIAGONAL blocks are accumulated as Gram matrices of A_l's own column blocks
+// (sums of squares; the subtraction form would cancel).
+// ===========================================================================
+// topd [obs][3][9] -> [obs][9][3] so that a lane's three factors are one 12-byte load
+template <class S>
+__global__ __launch_bounds__(256) void k_topd_transpose(const S* __restrict__ topd, S* __restrict__ topdT,
+                                                        int64_t n) {
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int64_t o = t / 27;
+  const int e = int(t - 27 * o), m = e / 9, c = e - 9 * m;
+  topdT[27 * o + 3 * c + m] = topd[t];
+}
+
+// strictly upper blocks: one workgroup per block, fixed order, mirrored write
+template <class S>
+__global__ __launch_bounds__(256) void k_ex_offdiag(const S* __restrict__ topdT, S* __restrict__ vals,
+                                                    const int* __restrict__ upper_slot,
+                                                    const int* __restrict__ mirror_slot,
+                                                    const int64_t* __restrict__ pair_ptr,
+                                                    const int* __restrict__ pair_oi,
+                                                    const int* __restrict__ pair_oj) {
+  __shared__ S part[3][81];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = blockIdx.x;
+  const int a0 = lane / 9, b0 = lane - 9 * a0;
+  const int e1 = 64 + lane;
+  const bool has1 = e1 < 81;
+  const int a1 = has1 ? e1 / 9 : 0, b1 = has1 ? e1 - 9 * a1 : 0;
+  S acc0 = S(0), acc1 = S(0);
+  const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
+  for (int64_t q = q0 + wave * kScUnroll; q < q1; q += 4 * kScUnroll) {
+    int oi[kScUnroll], oj[kScUnroll];
+    S t0[kScUnroll][3], w0[kScUnroll][3], t1[kScUnroll][3], w1[kScUnroll][3];
+#pragma unroll
+    for (int r = 0; r < kScUnroll; ++r) {
+      const bool ok = q + r < q1;
+      oi[r] = ok ? pair_oi[q + r] : -1;
+      oj[r] = ok ? pair_oj[q + r] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < kScUnroll; ++r) {
+      const bool ok = oi[r] >= 0;
+      const S* __restrict__ T = topdT + 27 * int64_t(ok ? oi[r] : 0);
+      const S* __restrict__ W = topdT + 27 * int64_t(ok ? oj[r] : 0);
+      load3(T + 3 * a0, t0[r]);
+      load3(W + 3 * b0, w0[r]);
+      load3(T + 3 * a1, t1[r]);
+      load3(W + 3 * b1, w1[r]);
+      if (!ok) t0[r][0] = t0[r][1] = t0[r][2] = S(0);
+      if (!ok || !has1) t1[r][0] = t1[r][1] = t1[r][2] = S(0);
+    }
+#pragma unroll
+    for (int r = 0; r < kScUnroll; ++r) {
+      acc0 -= t0[r][0] * w0[r][0] + t0[r][1] * w0[r][1] + t0[r][2] * w0[r][2];
+      acc1 -= t1[r][0] * w1[r][0] + t1[r][1] * w1[r][1] + t1[r][2] * w1[r][2];
+    }
+  }
+  if (wave > 0) {
+    part[wave - 1][lane] = acc0;
+    if (has1) part[wave - 1][e1] = acc1;
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  acc0 = ((acc0 + part[0][lane]) + part[1][lane]) + part[2][lane];
+  if (has1) acc1 = ((acc1 + part[0][e1]) + part[1][e1]) + part[2][e1];
+  S* out = vals + size_t(81) * upper_slot[u];
+  out[lane] = acc0;
+  if (has1) out[e1] = acc1;
+  S* outT = vals + size_t(81) * mirror_slot[u];
+  outT[9 * b0 + a0] = acc0;
+  if (has1) outT[9 * b1 + a1] = acc1;
+}
+
+// diagonal blocks: one wavefront per landmark, per observation the 9x9 Gram matrix of its
+// column block of A_l, scatter-added into the camera's diagonal block (zeroed before)
+template <class S>
+__global__ __launch_bounds__(256) void k_ex_diag(Params<S> p, const int* __restrict__ diag_slot,
+                                                 S* __restrict__ vals, int lm_begin, int lm_end) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;
+  const int k = p.lm_k[s];
+  const int64_t o0 = p.lm_obs[s];
+  const int nrows = 2 * k, ncols = 9 * k;
+  const S* __restrict__ A = p.A + p.lm_blk[s];
+  for (int e = lane; e < 81 * k; e += 64) {
+    const int i = e / 81, rem = e - 81 * i;
+    const int a = rem / 9, b = rem - 9 * a;
+    const S* __restrict__ ca = A + 9 * i + a;
+    const S* __restrict__ cb = A + 9 * i + b;
+    S acc = S(0);
+    for (int r = 0; r < nrows; ++r) acc += ca[size_t(r) * ncols] * cb[size_t(r) * ncols];
+    atomic_add(vals + size_t(81) * diag_slot[p.obs_cam[o0 + i]] + rem, acc);
+  }
+}
+
 }  // namespace rba

@@ -369,6 +369,21 @@ class Solver final : public rba_solver {
     d_bmO_.alloc(9 * qr_obs);
     d_Vh_.alloc(8 * qr_obs);
     if (sc_) build_sc_structure(lm_k, lm_obs, s_obs_cam);
+    // square-root solver: explicit reduced matrix for long PCG solves (see pcg())
+    if (const char* ev = std::getenv("RBA_EXPLICIT_AFTER")) explicit_after_ = std::atoi(ev);
+    if (!sc_ && !opt_.implicit_q && explicit_after_ > 0 && size_t(n_cams_) * n_cams_ <= (size_t(1) << 31)) {
+      h_lm_obs_ = lm_obs;
+      h_obs_cam_ = s_obs_cam;
+      pair_mark_.assign(size_t(n_cams_) * n_cams_, 0);
+      for (int l = 0; l < n_lms; ++l) {
+        const int64_t o0 = lm_obs[l];
+        for (int i = 0; i < lm_k[l]; ++i) {
+          uint8_t* row = pair_mark_.data() + size_t(s_obs_cam[o0 + i]) * n_cams_;
+          for (int j = 0; j < lm_k[l]; ++j) row[s_obs_cam[o0 + j]] = 1;
+        }
+      }
+      build_explicit_structure();
+    }
     d_tauH_.alloc(3 * size_t(n_lms));
     d_Zd_.alloc(9 * size_t(n_lms));
     d_Zd_.zero(stream_);
@@ -503,6 +518,109 @@ class Solver final : public rba_solver {
     }
   }
 
+  // Block-CSR structure for the explicit reduced matrix of the square-root solver, from the
+  // co-observation marks (the union over ranks when landmarks are sharded), and the per-block
+  // lists of the LOCAL observation pairs (i < j) that contribute to each strictly upper block
+  void build_explicit_structure() {
+    const size_t nc = size_t(n_cams_);
+    std::vector<int> slot(nc * nc, -1), row_ptr(nc + 1, 0), cols, diag(nc), upper_slot, mirror_slot;
+    int nnz = 0;
+    for (size_t c = 0; c < nc; ++c) {
+      row_ptr[c] = nnz;
+      for (size_t d = 0; d < nc; ++d)
+        if (pair_mark_[c * nc + d] || c == d) {
+          if (c == d) diag[c] = nnz;
+          slot[c * nc + d] = nnz++;
+          cols.push_back(int(d));
+        }
+    }
+    row_ptr[nc] = nnz;
+    std::vector<int> upper_of(size_t(nnz), -1);
+    for (size_t c = 0; c < nc; ++c)
+      for (size_t d = c + 1; d < nc; ++d)
+        if (slot[c * nc + d] >= 0) {
+          upper_of[slot[c * nc + d]] = int(upper_slot.size());
+          upper_slot.push_back(slot[c * nc + d]);
+          mirror_slot.push_back(slot[d * nc + c]);
+        }
+    const int n_upper = int(upper_slot.size());
+    std::vector<int64_t> pair_ptr(size_t(n_upper) + 1, 0);
+    for (int l = 0; l < n_lms_; ++l) {
+      const int64_t o0 = h_lm_obs_[l];
+      const int k = int(h_lm_obs_[l + 1] - o0);
+      for (int i = 0; i < k; ++i) {
+        const int* row = slot.data() + size_t(h_obs_cam_[o0 + i]) * nc;
+        for (int j = i + 1; j < k; ++j) ++pair_ptr[size_t(upper_of[row[h_obs_cam_[o0 + j]]]) + 1];
+      }
+    }
+    for (int t = 0; t < n_upper; ++t) pair_ptr[t + 1] += pair_ptr[t];
+    const int64_t n_pairs = pair_ptr[n_upper];
+    std::vector<int> pair_oi(n_pairs), pair_oj(n_pairs);
+    {
+      std::vector<int64_t> fill(pair_ptr.begin(), pair_ptr.end() - 1);
+      for (int l = 0; l < n_lms_; ++l) {
+        const int64_t o0 = h_lm_obs_[l];
+        const int k = int(h_lm_obs_[l + 1] - o0);
+        for (int i = 0; i < k; ++i) {
+          const int* row = slot.data() + size_t(h_obs_cam_[o0 + i]) * nc;
+          for (int j = i + 1; j < k; ++j) {
+            const int64_t d = fill[upper_of[row[h_obs_cam_[o0 + j]]]]++;
+            pair_oi[d] = int(o0 + i);
+            pair_oj[d] = int(o0 + j);
+          }
+        }
+      }
+    }
+    ex_nnz_ = nnz;
+    ex_n_upper_ = n_upper;
+    d_ex_rowptr_.alloc(row_ptr.size());
+    d_ex_cols_.alloc(cols.size());
+    d_ex_diag_.alloc(diag.size());
+    d_ex_upper_.alloc(upper_slot.size());
+    d_ex_mirror_.alloc(mirror_slot.size());
+    d_ex_pair_ptr_.alloc(pair_ptr.size());
+    d_ex_pair_oi_.alloc(n_pairs);
+    d_ex_pair_oj_.alloc(n_pairs);
+    d_ex_vals_.alloc(size_t(81) * nnz);
+    d_ex_topdT_.alloc(27 * size_t(n_obs_));
+    d_ex_rowptr_.upload(row_ptr.data(), row_ptr.size(), stream_);
+    d_ex_cols_.upload(cols.data(), cols.size(), stream_);
+    d_ex_diag_.upload(diag.data(), diag.size(), stream_);
+    d_ex_upper_.upload(upper_slot.data(), upper_slot.size(), stream_);
+    d_ex_mirror_.upload(mirror_slot.data(), mirror_slot.size(), stream_);
+    d_ex_pair_ptr_.upload(pair_ptr.data(), pair_ptr.size(), stream_);
+    d_ex_pair_oi_.upload(pair_oi.data(), n_pairs, stream_);
+    d_ex_pair_oj_.upload(pair_oj.data(), n_pairs, stream_);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    exp_ = rba::ScParams<S>{};
+    exp_.n_cams = n_cams_;
+    exp_.row_ptr = d_ex_rowptr_.get();
+    exp_.cols = d_ex_cols_.get();
+    exp_.vals = d_ex_vals_.get();
+    ex_ready_ = true;
+  }
+
+  // S = sum_l A_l^T A_l of the CURRENT damped blocks (valid until the next stage 2)
+  void assemble_explicit() {
+    d_ex_vals_.zero(stream_);  // diagonal blocks are accumulated; blocks without local pairs stay 0
+    const int64_t n27 = 27 * int64_t(n_obs_);
+    hipLaunchKernelGGL((rba::k_topd_transpose<S>), dim3(unsigned((n27 + 255) / 256)), dim3(256), 0, stream_,
+                       prm_.topd, d_ex_topdT_.get(), n27);
+    if (ex_n_upper_ > 0)
+      hipLaunchKernelGGL((rba::k_ex_offdiag<S>), dim3(ex_n_upper_), dim3(256), 0, stream_, d_ex_topdT_.get(),
+                         d_ex_vals_.get(), d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(),
+                         d_ex_pair_oi_.get(), d_ex_pair_oj_.get());
+    for_each_class([&](auto, int begin, int end) {
+      hipLaunchKernelGGL((rba::k_ex_diag<S>), dim3((end - begin + 3) / 4), dim3(256), 0, stream_, prm_,
+                         d_ex_diag_.get(), d_ex_vals_.get(), begin, end);
+    });
+    if (n_big_ > 0)
+      hipLaunchKernelGGL((rba::k_ex_diag<S>), dim3((n_big_ + 3) / 4), dim3(256), 0, stream_, prm_,
+                         d_ex_diag_.get(), d_ex_vals_.get(), big_begin_, big_begin_ + n_big_);
+    all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
+    ex_valid_ = true;
+  }
+
   // Block structure of the reduced camera matrix: every ordered pair of cameras that
   // observe a common landmark (what BlockSparseMatrix::add ends up holding,
   // block_sparse_matrix.hpp), as block-CSR + a dense (camera, camera) -> slot table.
@@ -632,6 +750,22 @@ class Solver final : public rba_solver {
     if (rc != 0) throw HipError{"ncclCommInitRank failed: " + std::to_string(rc), RBA_ERR_COMM};
     rank_ = rank;
     nranks_ = nranks;
+    union_structure_over_ranks();
+  }
+
+  // every rank must hold the SAME block structure for the explicit reduced matrix: union of
+  // the co-observation marks of all landmark shards
+  void union_structure_over_ranks() {
+    if (!ex_ready_ || nranks_ <= 1) return;
+    std::vector<int> marks(pair_mark_.begin(), pair_mark_.end());
+    DevBuf<int> d;
+    d.alloc(marks.size());
+    d.upload(marks.data(), marks.size(), stream_);
+    all_reduce(d.get(), marks.size(), kNcclMax);
+    d.download(marks.data(), marks.size(), stream_);
+    sync();
+    for (size_t i = 0; i < marks.size(); ++i) pair_mark_[i] = uint8_t(marks[i] != 0);
+    build_explicit_structure();
   }
 
   void comm_init_callback(int rank, int nranks, rba_allreduce_fn fn, void* ctx) override {
@@ -642,6 +776,7 @@ class Solver final : public rba_solver {
     nranks_ = nranks;
     cb_fn_ = fn;
     cb_ctx_ = ctx;
+    union_structure_over_ranks();
   }
 
   template <class T>
@@ -760,6 +895,7 @@ class Solver final : public rba_solver {
     timings_.stage1_time = time_end();
     pose_damping_ = S(0);
     landmark_damping_valid_ = false;
+    ex_valid_ = false;
     return (fail & 1) ? RBA_NUMERICAL_FAILURE : RBA_OK;
   }
 
@@ -799,6 +935,7 @@ class Solver final : public rba_solver {
     }
     pose_damping_ = lambda;
     landmark_damping_valid_ = true;
+    ex_valid_ = false;
   }
 
   int stage2(double lambda, void* b_out, void* blocks_out) override {
@@ -825,6 +962,13 @@ class Solver final : public rba_solver {
       hx_event_call_[hx_event_count_] = hx_calls_;
       ++hx_event_count_;
       HIP_CHECK(hipEventRecord(e0, stream_));
+    }
+    if (ex_active_) {
+      // y = (sum_l A_l^T A_l) x from the assembled matrix; overwrites y (y was zero)
+      hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, exp_, x, y, done_flag);
+      if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
+      ++hx_calls_;
+      return;
     }
     if (sc_) {
       // y = S x (pose damping is part of S); overwrites y
@@ -990,7 +1134,15 @@ class Solver final : public rba_solver {
     // The host polls the device state lazily: every iteration at first (many
     // solves need 2-3 iterations), every 4th later; kernels queued past the end
     // are no-ops (`done`).
+    ex_active_ = false;
     for (int it = 1; it <= max_it; ++it) {
+      // Long solve: from here on the product is an SpMV with the explicitly assembled
+      // S = sum_l A_l^T A_l (one assembly ~ 16 matrix-free products on venice; S is all-reduced
+      // once, after which the iterations need no collective at all)
+      if (ex_ready_ && !ex_active_ && it > explicit_after_) {
+        if (!ex_valid_) assemble_explicit();
+        ex_active_ = true;
+      }
       if (opt_.preconditioner_type == 2) {
         // z = sum_{i=0..order} (Hpp^-1 E0)^i Hpp^-1 r   (PowerSCPreconditioner::solve_assign,
         // preconditioner.hpp:180-192); d_inv_ holds Hpp^-1
@@ -1016,7 +1168,7 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_pcg_a2<S>), dim3(NB), dim3(T), 0, stream_, d_z_.get(), d_p_.get(),
                          d_q_.get(), n, st, part_rho);
       launch_hx(d_p_.get(), d_q_.get(), done);
-      all_reduce(d_q_.get(), n);
+      if (!ex_active_) all_reduce(d_q_.get(), n);
       hipLaunchKernelGGL((rba::k_pcg_b1<S>), dim3(NB), dim3(T), 0, stream_, d_p_.get(), d_q_.get(),
                          lambda, n, st, part_pq);
       hipLaunchKernelGGL((rba::k_pcg_b2<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
@@ -1024,7 +1176,7 @@ class Solver final : public rba_solver {
       if (it % 10 == 0) {
         // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
         launch_hx(d_x_.get(), d_tmp_.get(), done);
-        all_reduce(d_tmp_.get(), n);
+        if (!ex_active_) all_reduce(d_tmp_.get(), n);
         hipLaunchKernelGGL((rba::k_pcg_c1<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
                            d_r_.get(), d_tmp_.get(), lambda, n, st, part_q1);
         hipLaunchKernelGGL((rba::k_pcg_fin), dim3(1), dim3(1), 0, stream_, st, part_q1, 1, eta, min_it,
@@ -1039,6 +1191,7 @@ class Solver final : public rba_solver {
         if (hst->done) break;
       }
     }
+    ex_active_ = false;
     summary.termination_type = hst->termination;
     summary.num_iterations = hst->iter;
     return summary;
@@ -1411,6 +1564,17 @@ class Solver final : public rba_solver {
   std::vector<int> hx_event_call_;  // which H*x call of the solve each event pair brackets
   int hx_event_count_ = 0, hx_calls_ = 0;
   bool hx_single_stream_ = false;
+  // explicit reduced matrix of the square-root solver (adaptive, see pcg())
+  int explicit_after_ = 24;  // matrix-free products before a solve switches to S x; 0 = never
+  bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;
+  int ex_nnz_ = 0, ex_n_upper_ = 0;
+  std::vector<uint8_t> pair_mark_;
+  rba::ScParams<S> exp_{};
+  std::vector<int64_t> h_lm_obs_;  // host copies of the (sorted) topology for the pair lists
+  std::vector<int> h_obs_cam_;
+  DevBuf<int> d_ex_rowptr_, d_ex_cols_, d_ex_diag_, d_ex_upper_, d_ex_mirror_, d_ex_pair_oi_, d_ex_pair_oj_;
+  DevBuf<int64_t> d_ex_pair_ptr_;
+  DevBuf<S> d_ex_vals_, d_ex_topdT_;
   // explicit Schur-complement backend (solver_type = 1)
   bool sc_ = false;
   int sc_nnz_ = 0;
