@@ -81,6 +81,9 @@ typedef struct rba_options {
   int solver_type;                /* SolverOptions::SolverType: 0 SQUARE_ROOT (default, LinearizorQR),
                                      1 SCHUR_COMPLEMENT (LinearizorSC, linearizor_sc.cpp:70-211:
                                      explicit block-sparse reduced camera matrix + SpMV)        */
+  int explicit_after;             /* square-root solver with SCHUR_JACOBI: after this many matrix-free
+                                     products a PCG solve assembles S = sum_l A_l^T A_l explicitly
+                                     (block-CSR) and continues with S x; 0 = never. Default 6. */
 } rba_options;
 
 /* ResidualInfo (src/rootba/bal/residual_info.hpp:57-96), sums in double */
@@ -197,6 +200,9 @@ int rba_solve(rba_handle h, double lambda, void* inc_out, rba_cg_summary* cg);
  * blocks 81*n_cams, nullable) and right_multiply (linearization_qr.hpp:821-825). */
 int rba_stage2(rba_handle h, double lambda, void* b_out, void* blocks_out);
 int rba_right_multiply(rba_handle h, const void* x, void* y);
+/* The same product through the explicitly assembled reduced matrix (see
+ * rba_options.explicit_after); for tests. Needs rba_stage2 / rba_solve first. */
+int rba_right_multiply_explicit(rba_handle h, const void* x, void* y);
 
 /* LinearizorQR::apply (linearizor_qr.cpp:268-291): back_substitute
  * (linearization_qr.hpp:165-179, landmark_block_base.ipp:212-284), un-scale,

@@ -42,6 +42,7 @@ class Options(C.Structure):
         ("staged_execution", C.c_int),
         ("implicit_q", C.c_int),  # product-only switch; the oracle has one operator
         ("solver_type", C.c_int),  # 0 SQUARE_ROOT, 1 SCHUR_COMPLEMENT
+        ("explicit_after", C.c_int),  # product-only
     ]
 
 

@@ -34,6 +34,7 @@ struct orc_options {
   int staged_execution;
   int implicit_q;  // product-only switch (ignored here)
   int solver_type;
+  int explicit_after;  // product-only switch (ignored here)
 };
 
 struct orc_residual_info {
@@ -77,6 +78,7 @@ void orc_default_options(orc_options* o) {
   o->staged_execution = d.staged_execution;
   o->implicit_q = 0;
   o->solver_type = d.solver_type;
+  o->explicit_after = 0;
 }
 
 int orc_sizeof_lm_iteration() { return int(sizeof(orc::LmIteration)); }

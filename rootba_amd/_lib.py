@@ -43,6 +43,7 @@ class RbaOptions(C.Structure):
         ("staged_execution", C.c_int),
         ("implicit_q", C.c_int),
         ("solver_type", C.c_int),  # 0 SQUARE_ROOT, 1 SCHUR_COMPLEMENT
+        ("explicit_after", C.c_int),
     ]
 
 
@@ -110,7 +111,7 @@ EXPORTS = [
     "rba_default_options", "rba_last_error", "rba_device_count", "rba_create", "rba_destroy",
     "rba_comm_unique_id", "rba_comm_init", "rba_comm_init_callback", "rba_set_state", "rba_get_state", "rba_backup",
     "rba_restore", "rba_compute_error", "rba_linearize", "rba_solve", "rba_stage2",
-    "rba_right_multiply", "rba_apply", "rba_back_substitute", "rba_optimize_lm", "rba_lm_begin", "rba_lm_step", "rba_lm_termination", "rba_synchronize",
+    "rba_right_multiply", "rba_right_multiply_explicit", "rba_apply", "rba_back_substitute", "rba_optimize_lm", "rba_lm_begin", "rba_lm_step", "rba_lm_termination", "rba_synchronize",
     "rba_get_timings", "rba_debug_read_blocks",
     "rba_get_jl_col_scale", "rba_get_pose_scaling", "rba_get_landmark_R", "rba_get_problem_stats",
 ]

@@ -65,6 +65,7 @@ struct SolverOptions {
   double initial_vee = 2.0;
   double vee_factor = 2.0;
   bool implicit_q = false;  // not in the reference: evaluate H*x from the QR factors
+  int explicit_after = 6;   // not in the reference: rba_options.explicit_after
   bool use_projection_validity_check() const { return optimized_cost != OptimizedCost::ERROR; }
 
   rba_options to_rba() const {
@@ -92,6 +93,7 @@ struct SolverOptions {
     o.optimized_cost = int(optimized_cost);
     o.staged_execution = staged_execution;
     o.implicit_q = implicit_q;
+    o.explicit_after = explicit_after;
     o.solver_type = solver_type == SolverType::SCHUR_COMPLEMENT ? 1 : 0;
     return o;
   }

@@ -404,8 +404,10 @@ __global__ __launch_bounds__(256) void k_sc_back_substitute(ScParams<S> p, const
 // so an OFF-DIAGONAL block (ci != cj) is exactly  - topd_i^T topd_j : a rank-3 product
 // of the damped top rows that stage 2 produced with orthogonal transformations only
 // (no H_ll^-1, nothing to cancel) — gathered block-major like the SC assembly.
-// The DIAGONAL blocks are accumulated as Gram matrices of A_l's own column blocks
-// (sums of squares; the subtraction form would cancel).
+// The DIAGONAL blocks are the ones stage 2 computes for the SCHUR_JACOBI preconditioner
+// (sum over the camera's observations of Jp^T Jp - top^T top plus the damping rows;
+// both sums have thousands of terms, the rounding error of the difference is of the
+// same order, eps sqrt(n), as that of accumulating Gram blocks).
 // ===========================================================================
 // topd [obs][3][9] -> [obs][9][3] so that a lane's three factors are one 12-byte load
 template <class S>
@@ -479,27 +481,15 @@ __global__ __launch_bounds__(256) void k_ex_offdiag(const S* __restrict__ topdT,
   if (has1) outT[9 * b1 + a1] = acc1;
 }
 
-// diagonal blocks: one wavefront per landmark, per observation the 9x9 Gram matrix of its
-// column block of A_l, scatter-added into the camera's diagonal block (zeroed before)
+// diagonal blocks: stage 2 already holds them (+ lambda I) as the SCHUR_JACOBI
+// preconditioner input, summed camera-major on the matrix cores and all-reduced
 template <class S>
-__global__ __launch_bounds__(256) void k_ex_diag(Params<S> p, const int* __restrict__ diag_slot,
-                                                 S* __restrict__ vals, int lm_begin, int lm_end) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s = lm_begin + blockIdx.x * 4 + wave;
-  if (s >= lm_end) return;
-  const int k = p.lm_k[s];
-  const int64_t o0 = p.lm_obs[s];
-  const int nrows = 2 * k, ncols = 9 * k;
-  const S* __restrict__ A = p.A + p.lm_blk[s];
-  for (int e = lane; e < 81 * k; e += 64) {
-    const int i = e / 81, rem = e - 81 * i;
-    const int a = rem / 9, b = rem - 9 * a;
-    const S* __restrict__ ca = A + 9 * i + a;
-    const S* __restrict__ cb = A + 9 * i + b;
-    S acc = S(0);
-    for (int r = 0; r < nrows; ++r) acc += ca[size_t(r) * ncols] * cb[size_t(r) * ncols];
-    atomic_add(vals + size_t(81) * diag_slot[p.obs_cam[o0 + i]] + rem, acc);
-  }
+__global__ __launch_bounds__(256) void k_ex_set_diag(const S* __restrict__ blocks, const int* __restrict__ diag_slot,
+                                                     S* __restrict__ vals, S lambda, int n_cams) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 81 * n_cams) return;
+  const int c = t / 81, e = t - 81 * c;
+  vals[size_t(81) * diag_slot[c] + e] = blocks[t] - (e % 10 == 0 ? lambda : S(0));
 }
 
 }  // namespace rba

@@ -131,6 +131,7 @@ struct rba_solver {
   virtual int solve(double lambda, void* inc_out, rba_cg_summary* cg) = 0;
   virtual int stage2(double lambda, void* b_out, void* blocks_out) = 0;
   virtual void right_multiply(const void* x, void* y) = 0;
+  virtual void right_multiply_explicit(const void* x, void* y) = 0;
   virtual int apply(const void* inc, double* l_diff, bool update_cams) = 0;
   virtual int optimize_lm(rba_lm_iteration* log, int max_rows, int* n_rows, int* term) = 0;
   virtual void lm_begin() = 0;
@@ -370,8 +371,12 @@ class Solver final : public rba_solver {
     d_Vh_.alloc(8 * qr_obs);
     if (sc_) build_sc_structure(lm_k, lm_obs, s_obs_cam);
     // square-root solver: explicit reduced matrix for long PCG solves (see pcg())
+    explicit_after_ = opt_.explicit_after;
     if (const char* ev = std::getenv("RBA_EXPLICIT_AFTER")) explicit_after_ = std::atoi(ev);
-    if (!sc_ && !opt_.implicit_q && explicit_after_ > 0 && size_t(n_cams_) * n_cams_ <= (size_t(1) << 31)) {
+    // (needs the SCHUR_JACOBI blocks of stage 2 as its diagonal; the dense n_c x n_c slot table
+    //  bounds the camera count)
+    if (!sc_ && !opt_.implicit_q && opt_.preconditioner_type == 1 && explicit_after_ > 0 &&
+        size_t(n_cams_) * n_cams_ <= (size_t(1) << 31)) {
       h_lm_obs_ = lm_obs;
       h_obs_cam_ = s_obs_cam;
       pair_mark_.assign(size_t(n_cams_) * n_cams_, 0);
@@ -602,7 +607,7 @@ class Solver final : public rba_solver {
 
   // S = sum_l A_l^T A_l of the CURRENT damped blocks (valid until the next stage 2)
   void assemble_explicit() {
-    d_ex_vals_.zero(stream_);  // diagonal blocks are accumulated; blocks without local pairs stay 0
+    if (comm_ || cb_fn_) d_ex_vals_.zero(stream_);  // sharded: blocks without local pairs must be 0
     const int64_t n27 = 27 * int64_t(n_obs_);
     hipLaunchKernelGGL((rba::k_topd_transpose<S>), dim3(unsigned((n27 + 255) / 256)), dim3(256), 0, stream_,
                        prm_.topd, d_ex_topdT_.get(), n27);
@@ -610,14 +615,10 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_ex_offdiag<S>), dim3(ex_n_upper_), dim3(256), 0, stream_, d_ex_topdT_.get(),
                          d_ex_vals_.get(), d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(),
                          d_ex_pair_oi_.get(), d_ex_pair_oj_.get());
-    for_each_class([&](auto, int begin, int end) {
-      hipLaunchKernelGGL((rba::k_ex_diag<S>), dim3((end - begin + 3) / 4), dim3(256), 0, stream_, prm_,
-                         d_ex_diag_.get(), d_ex_vals_.get(), begin, end);
-    });
-    if (n_big_ > 0)
-      hipLaunchKernelGGL((rba::k_ex_diag<S>), dim3((n_big_ + 3) / 4), dim3(256), 0, stream_, prm_,
-                         d_ex_diag_.get(), d_ex_vals_.get(), big_begin_, big_begin_ + n_big_);
     all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
+    // (the diagonal blocks were all-reduced by stage 2 already)
+    hipLaunchKernelGGL((rba::k_ex_set_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
+                       prm_.blocks, d_ex_diag_.get(), d_ex_vals_.get(), pose_damping_, n_cams_);
     ex_valid_ = true;
   }
 
@@ -955,8 +956,9 @@ class Solver final : public rba_solver {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // every hx_timing_stride_-th product is bracketed by HIP events (each event is a
     // marker packet on the queue: timing all of them costs ~15 us per PCG iteration)
-    if (hx_timing_stride_ > 0 && hx_calls_ % hx_timing_stride_ == (hx_timing_stride_ > 1 ? 1 : 0) &&
-        hx_event_count_ < kMaxHxEvents) {
+    // (only the matrix-free product is timed: rba_iter_timings.hx_time is its roofline input)
+    if (!ex_active_ && hx_timing_stride_ > 0 &&
+        hx_calls_ % hx_timing_stride_ == (hx_timing_stride_ > 1 ? 1 : 0) && hx_event_count_ < kMaxHxEvents) {
       e0 = hx_events_[2 * hx_event_count_];
       e1 = hx_events_[2 * hx_event_count_ + 1];
       hx_event_call_[hx_event_count_] = hx_calls_;
@@ -1073,6 +1075,21 @@ class Solver final : public rba_solver {
     all_reduce(d_tmp_.get(), nvec_);
     hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                        d_vin_.get(), d_tmp_.get(), sc_ ? S(0) : pose_damping_, nvec_);
+    d_tmp_.download(static_cast<S*>(y), nvec_, stream_);
+    sync();
+  }
+
+  // y = (S + lambda I) x through the explicitly assembled reduced matrix (tests)
+  void right_multiply_explicit(const void* x, void* y) override {
+    if (!ex_ready_) throw HipError{"the explicit reduced matrix is not enabled for this configuration", RBA_ERR_UNSUPPORTED};
+    use_device();
+    if (!landmark_damping_valid_) throw HipError{"right_multiply_explicit needs a stage 2 first", RBA_ERR_INVALID_ARGUMENT};
+    if (!ex_valid_) assemble_explicit();
+    d_vin_.upload(static_cast<const S*>(x), nvec_, stream_);
+    hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, exp_, d_vin_.get(),
+                       d_tmp_.get(), static_cast<const int*>(nullptr));
+    hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
+                       d_vin_.get(), d_tmp_.get(), pose_damping_, nvec_);
     d_tmp_.download(static_cast<S*>(y), nvec_, stream_);
     sync();
   }
@@ -1565,7 +1582,7 @@ class Solver final : public rba_solver {
   int hx_event_count_ = 0, hx_calls_ = 0;
   bool hx_single_stream_ = false;
   // explicit reduced matrix of the square-root solver (adaptive, see pcg())
-  int explicit_after_ = 24;  // matrix-free products before a solve switches to S x; 0 = never
+  int explicit_after_ = 0;  // matrix-free products before a solve switches to S x; 0 = never
   bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;
   int ex_nnz_ = 0, ex_n_upper_ = 0;
   std::vector<uint8_t> pair_mark_;
@@ -1648,6 +1665,7 @@ void rba_default_options(rba_options* o) {
   o->staged_execution = 1;
   o->implicit_q = 0;
   o->solver_type = 0;
+  o->explicit_after = 6;
 }
 
 const char* rba_last_error(void) { return g_last_error.c_str(); }
@@ -1787,6 +1805,13 @@ int rba_stage2(rba_handle h, double lambda, void* b_out, void* blocks_out) {
 int rba_right_multiply(rba_handle h, const void* x, void* y) {
   return guarded([&]() -> int {
     h->right_multiply(x, y);
+    return RBA_OK;
+  });
+}
+
+int rba_right_multiply_explicit(rba_handle h, const void* x, void* y) {
+  return guarded([&]() -> int {
+    h->right_multiply_explicit(x, y);
     return RBA_OK;
   });
 }

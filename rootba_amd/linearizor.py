@@ -165,6 +165,13 @@ class LinearizorHIP:
         L.check(self.lib.rba_right_multiply(self.h, _ptr(xi), _ptr(y)), "rba_right_multiply")
         return y
 
+    def right_multiply_explicit(self, x):
+        """The same product through the explicitly assembled reduced matrix (`explicit_after`)."""
+        xi = self._in(x, 9 * self.n_cams)
+        y = self._vec(9 * self.n_cams)
+        L.check(self.lib.rba_right_multiply_explicit(self.h, _ptr(xi), _ptr(y)), "rba_right_multiply_explicit")
+        return y
+
     def back_substitute(self, inc) -> float:
         x = self._in(inc, 9 * self.n_cams)
         l_diff = C.c_double(0)

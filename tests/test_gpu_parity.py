@@ -33,7 +33,7 @@ def _pair(prob, dtype, **kw):
     from oracle import oracle as O
     from rootba_amd import _lib as L
     from rootba_amd.linearizor import LinearizorHIP
-    okw = {k: v for k, v in kw.items() if k != "implicit_q"}  # product-only switch
+    okw = {k: v for k, v in kw.items() if k not in ("implicit_q", "explicit_after")}  # product-only switches
     return LinearizorHIP(prob, dtype, _opts(L, **kw)), O.Oracle(prob, dtype, _opts(O, **okw))
 
 
@@ -259,7 +259,9 @@ def test_lm_trajectory_matches_oracle(ladybug_far, dtype):
     for a, b in zip(lg[:5], lo[:5]):
         assert a.step_is_successful == b.step_is_successful
         assert abs(a.cg_iterations - b.cg_iterations) <= (1 if dtype == np.float32 else 0)
-        assert abs(a.inc_norm - b.inc_norm) <= (1e-3 if dtype == np.float32 else 1e-8) * b.inc_norm + 1e-12
+        # f32: the PCG stops on the Q-model test (eta = 0.1), i.e. far from converged; the GPU's
+        # rounding (atomics order, assembled matrix after 6 products) moves the truncated iterate
+        assert abs(a.inc_norm - b.inc_norm) <= (3e-3 if dtype == np.float32 else 1e-8) * b.inc_norm + 1e-12
         assert abs(a.cost - b.cost) <= (1e-5 if dtype == np.float32 else 1e-10) * b.cost
         assert abs(a.lambda_ - b.lambda_) <= 1e-3 * b.lambda_
     if dtype == np.float64:
@@ -287,9 +289,11 @@ def test_per_iteration_increment_lockstep(ladybug_far, dtype):
     f64: 1e-10. f32: 1e-4 while the truncated PCG runs a handful
     of iterations; with 20+ PCG iterations float32 rounding is amplified in BOTH
     implementations, so there the bound is accuracy parity: the GPU increment is
-    as close to the float64 solution as the float32 oracle's is."""
+    as close to the float64 solution as the float32 oracle's is.
+    (explicit_after=0: the matrix-free product in every PCG iteration, i.e. the reference's
+    algorithm step by step; the switch to the assembled matrix has its own tests below.)"""
     from oracle import oracle as O
-    g, o = _pair(ladybug_far, dtype)
+    g, o = _pair(ladybug_far, dtype, explicit_after=0)
     o64 = O.Oracle(ladybug_far, np.float64, _opts(O))
     lam = 1e-4
     for it in range(5):
@@ -547,3 +551,44 @@ def test_schur_complement_unsupported_combinations(small_problem):
     g = LinearizorHIP(small_problem, np.float32, L.default_options(solver_type=1))
     with pytest.raises(RuntimeError, match="single GPU"):
         g.comm_init_callback(0, 2, lambda *a: None)
+
+
+# ---- explicit reduced matrix of the square-root solver (rba_options.explicit_after) -------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("which", ["small", "mixed", "long"])
+def test_explicit_reduced_matrix_is_the_same_operator(small_problem, mixed_k_problem, long_track_problem, dtype, which):
+    """S = sum_l A_l^T A_l assembled block-wise (off-diagonal blocks from the damped top rows,
+    diagonal blocks from stage 2) applies like the matrix-free product and like the oracle."""
+    prob = {"small": small_problem, "mixed": mixed_k_problem, "long": long_track_problem}[which]
+    tol = TOL[dtype]
+    g, o = _pair(prob, dtype)
+    assert g.linearize() == 0 and o.linearize() == 0
+    rng = np.random.default_rng(3)
+    for lam in (LAMBDA, 1e-6):
+        o.set_pose_damping(lam)
+        o.stage2(lam, o.pose_scaling() if lam == LAMBDA else None)
+        g.stage2(lam)
+        for _ in range(2):
+            x = rng.uniform(-1, 1, 9 * prob.n_cams).astype(dtype)
+            ye, ym, yo = g.right_multiply_explicit(x), g.right_multiply(x), o.right_multiply(x)
+            assert rel_err(ye, ym) < 3 * tol and rel_err(ye, yo) < 3 * tol
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_explicit_switch_inside_pcg(ladybug_far, dtype):
+    """Switching to S x after 1 / 6 / never matrix-free products gives the same PCG solution
+    and the same LM run (tolerances of the other trajectory tests)."""
+    incs, runs = [], []
+    for after in (1, 6, 0):
+        g, _ = _pair(ladybug_far, dtype, explicit_after=after, max_num_iterations=6, eta=1e-5)
+        assert g.linearize() == 0
+        inc, cg = g.solve(1e-5)  # tight eta: the solve runs well past the switch
+        assert cg.termination_type == 1 and cg.num_iterations > 8
+        incs.append(inc)
+        g2, _ = _pair(ladybug_far, dtype, explicit_after=after, max_num_iterations=6)
+        runs.append(g2.optimize_lm()[0])
+    tol = 1e-9 if dtype == np.float64 else 2e-3
+    assert rel_err(incs[0], incs[2]) < tol and rel_err(incs[1], incs[2]) < tol
+    ctol = 1e-9 if dtype == np.float64 else 2e-5
+    for a, b, c in zip(*runs):
+        assert abs(a.cost - c.cost) <= ctol * c.cost and abs(b.cost - c.cost) <= ctol * c.cost
