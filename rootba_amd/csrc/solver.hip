@@ -388,6 +388,8 @@ class Solver final : public rba_solver {
         }
       }
       build_explicit_structure();
+      // only the first explicit_after products of a solve are matrix-free: sample them densely
+      if (!std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = 2;
     }
     d_tauH_.alloc(3 * size_t(n_lms));
     d_Zd_.alloc(9 * size_t(n_lms));
