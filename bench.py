@@ -161,7 +161,10 @@ def main():
     gpu_opts = solver_options(L, max(n_iter, 1))
     for key, val in _GPU_KW.items():
         setattr(gpu_opts, key, val)
+    t0 = time.perf_counter()
     lin = LinearizorHIP(local, np.float32, gpu_opts, device=local_rank)
+    log(f"[rank {rank}] solver set up in {time.perf_counter() - t0:.2f}s (rba_create: sort by track length, "
+        f"CSC index, block structure of the reduced matrix, device allocation)")
     if world > 1:
         uid = [LinearizorHIP.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -229,6 +232,7 @@ def main():
                 "workload": f"BAL {args.workload} ({data}): {prob.n_cams} cams, {prob.n_lms} lms, {prob.n_obs} obs, "
                             f"solver={args.solver_type}, {args.preconditioner}, Huber(1), float32",
                 "parallelism": f"landmarks sharded over {world} GPU(s), RCCL all-reduce of camera vectors",
+                "explicit_after": int(os.environ.get("RBA_EXPLICIT_AFTER", gpu_opts.explicit_after)),
                 "cg_iterations_per_step": sum(r.cg_iterations for r in timed) / max(1, len(timed)),
                 "successful_steps": sum(r.step_is_successful for r in timed),
                 "initial_cost": rows[0].cost,
