@@ -76,6 +76,14 @@ __global__ __launch_bounds__(256) void k_linearize_qr_big(Params<S> p, int lm_be
     if (tid == 0) p.jl_scale[3 * s + c] = sc;
     __syncthreads();
   }
+  // raw (weighted, column-scaled) Jl rows and residual for the back-substitution's l_diff
+  for (int r = tid; r < nrows; r += 256) {
+    S* dst = p.JlS + 3 * (2 * o0 + r);
+    dst[0] = V[4 * r + 0];
+    dst[1] = V[4 * r + 1];
+    dst[2] = V[4 * r + 2];
+    p.rS[2 * o0 + r] = V[4 * r + 3];
+  }
   // Householder QR of Jl, applied to the remaining columns and to the residual
   S tau[3];
   for (int m = 0; m < 3; ++m) {
@@ -334,68 +342,5 @@ __global__ __launch_bounds__(256) void k_e0_big(Params<S> p, int lm_begin, const
   }
 }
 
-// back-substitution (same outputs as k_back_substitute)
-template <class S>
-__global__ __launch_bounds__(256) void k_back_substitute_big(Params<S> p, int lm_begin,
-                                                             const S* __restrict__ x) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  __shared__ S sm[4];
-  const int tid = threadIdx.x;
-  const int s = lm_begin + blockIdx.x;
-  const int k = p.lm_k[s];
-  const int64_t o0 = p.lm_obs[s];
-  const int nrows = 2 * k, ncols = 9 * k;
-  const S* __restrict__ Ablk = p.A + p.lm_blk[s];
-  const S* __restrict__ T0 = p.top0 + 27 * o0;
-  const S* __restrict__ Td = p.topd + 27 * o0;
-  S* xs = reinterpret_cast<S*>(smem_raw);
-  for (int j = tid; j < ncols; j += 256) {
-    const int i = j / 9;
-    xs[j] = x[9 * p.obs_cam[o0 + i] + (j - 9 * i)];
-  }
-  __syncthreads();
-  S u[3], g0[3];
-  for (int m = 0; m < 3; ++m) {
-    S d = S(0), e = S(0);
-    for (int j = tid; j < ncols; j += 256) {
-      const int i = j / 9, comp = j - 9 * i;
-      d += Td[27 * i + 9 * m + comp] * xs[j];
-      e += T0[27 * i + 9 * m + comp] * xs[j];
-    }
-    u[m] = big_block_sum(d, sm);
-    g0[m] = big_block_sum(e, sm);
-  }
-  const S* Rd = p.Rd + 6 * s;
-  const S* R0 = p.R0 + 6 * s;
-  S rhs[3], inc[3];
-  for (int m = 0; m < 3; ++m) rhs[m] = p.q1trd[3 * s + m] + u[m];
-  inc[2] = rhs[2] / Rd[5];
-  inc[1] = (rhs[1] - Rd[4] * inc[2]) / Rd[3];
-  inc[0] = (rhs[0] - Rd[1] * inc[1] - Rd[2] * inc[2]) / Rd[0];
-  for (int m = 0; m < 3; ++m) inc[m] = -inc[m];
-  g0[0] += R0[0] * inc[0] + R0[1] * inc[1] + R0[2] * inc[2];
-  g0[1] += R0[3] * inc[1] + R0[4] * inc[2];
-  g0[2] += R0[5] * inc[2];
-  const S* __restrict__ qtr = p.qtr + 2 * o0;
-  S acc = S(0);
-  for (int m = 0; m < 3; ++m) acc += g0[m] * (S(0.5) * g0[m] + qtr[m]);
-  for (int r = 0; r < nrows - 3; ++r) {
-    const S* row = Ablk + size_t(r) * ncols;
-    S d = S(0);
-    for (int j = tid; j < ncols; j += 256) d += row[j] * xs[j];
-    const S g = big_block_sum(d, sm);
-    acc += g * (S(0.5) * g + qtr[3 + r]);
-  }
-  if (tid == 0) {
-    p.lm_ldiff[s] = -double(acc);
-    const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) &&
-                     is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) &&
-                     is_finite(p.lms[3 * s + 2]);
-    if (!fin) atomicOr(p.fail_flag, 2);
-    p.lms[3 * s + 0] += inc[0] * p.jl_scale[3 * s + 0];
-    p.lms[3 * s + 1] += inc[1] * p.jl_scale[3 * s + 1];
-    p.lms[3 * s + 2] += inc[2] * p.jl_scale[3 * s + 2];
-  }
-}
 
 }  // namespace rba

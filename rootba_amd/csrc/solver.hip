@@ -296,8 +296,6 @@ class Solver final : public rba_solver {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_big<S>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_back_substitute_big<S>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
       }
     }
 
@@ -367,6 +365,9 @@ class Solver final : public rba_solver {
     d_qtr_.alloc(2 * qr_obs);
     d_dampO_.alloc(27 * qr_obs);
     d_JpS_.alloc(18 * size_t(n_obs_));
+    d_JlS_.alloc(6 * qr_obs);
+    d_rS_.alloc(2 * qr_obs);
+    d_bsO_.alloc(5 * qr_obs);
     d_bmO_.alloc(9 * qr_obs);
     d_Vh_.alloc(8 * qr_obs);
     if (sc_) build_sc_structure(lm_k, lm_obs, s_obs_cam);
@@ -450,6 +451,9 @@ class Solver final : public rba_solver {
     prm_.cam_obs = d_cam_obs_.get();
     prm_.dampO = d_dampO_.get();
     prm_.JpS = d_JpS_.get();
+    prm_.JlS = d_JlS_.get();
+    prm_.rS = d_rS_.get();
+    prm_.bsO = d_bsO_.get();
     prm_.bmO = d_bmO_.get();
     prm_.Vh = d_Vh_.get();
     prm_.tauH = d_tauH_.get();
@@ -1227,14 +1231,9 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_sc_back_substitute<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_,
                          scp_, d_inc_.get());
     } else {
-      for_each_class([&](auto ch_tag, int begin, int end) {
-        constexpr int CH = decltype(ch_tag)::value;
-        hipLaunchKernelGGL((rba::k_back_substitute<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
-                           0, stream_, prm_, begin, end, d_inc_.get());
-      });
-      if (n_big_ > 0)
-        hipLaunchKernelGGL((rba::k_back_substitute_big<S>), dim3(n_big_), dim3(256),
-                           size_t(9) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_, d_inc_.get());
+      hipLaunchKernelGGL((rba::k_bs_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0, stream_, prm_,
+                         d_inc_.get(), int64_t(n_obs_));
+      hipLaunchKernelGGL((rba::k_bs_landmark<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_, prm_);
     }
     const int blocks = std::min(kReduceBlocks, (n_lms_ + 255) / 256);
     hipLaunchKernelGGL((rba::k_sum_ldiff), dim3(blocks), dim3(256), 0, stream_,
@@ -1565,7 +1564,7 @@ class Solver final : public rba_solver {
   DevBuf<int> d_lm_k_, d_obs_cam_, d_obs_lm_, d_fail_;
   DevBuf<int64_t> d_lm_obs_, d_lm_blk_, d_cam_off_;
   DevBuf<int> d_cam_obs_;
-  DevBuf<S> d_dampO_, d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_JT_, d_VT_;
+  DevBuf<S> d_dampO_, d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_JT_, d_VT_, d_JlS_, d_rS_, d_bsO_;
   DevBuf<int> d_CT_, d_lm_tile_, d_lm_lane0_;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
