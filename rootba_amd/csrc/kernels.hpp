@@ -61,6 +61,7 @@ struct Params {
   S* JlS;       // [n_obs][2][3]  sqrt(w) Jl D_l before the QR (back-substitution)
   S* rS;        // [n_obs][2]     sqrt(w) r
   S* bsO;       // [n_obs][5]     back-substitution scratch: topd x (3), Jp x (2)
+  S* givens;    // [n_lms][12]    the 6 damping rotations of stage 2: c[6], s[6]
   S* R0;        // [6 n_lms]
   S* Rd;        // [6 n_lms]
   S* q1trd;     // [3 n_lms]
@@ -745,24 +746,24 @@ __global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin,
 
 // ===========================================================================
 // Stage 2: landmark damping by 6 Givens rotations against the stored undamped
-// top rows, plus the damping rows' contribution to b and to the block diagonal
-// (set_landmark_damping ipp:165-210; add_Q2TJp_T_Q2Tr ipp:443-466 and
-//  add_Q2TJp_T_Q2TJp_blockdiag ipp:520-552, last three rows).
-// Nothing is "undone": the damped rows are always rebuilt from top0/R0. The
-// camera-indexed sums of the damping rows are taken by k_cam_stage2 from the
-// observation-major copy dampO written here.
+// top rows (set_landmark_damping, ipp:149-210). Because the linearisation is
+// kept undamped (top0, R0, Q1^T r), changing lambda needs no "undo" pass; the
+// rotations only touch the three top rows and the three extra rows, which is
+// exactly what gets recomputed here.
+// (get_Q2TJp_T_Q2Tr / get_Q2TJp_T_Q2TJp_blockdiag: see k_cam_stage2.)
+// Two fully occupied passes instead of one wavefront per landmark (which runs at 30 %
+// lane utilisation for the 2-3 observation landmarks that dominate BAL problems):
+//   k_stage2_landmark  one thread per landmark: the 6 rotations from R0, damped R / Q1^T r,
+//                      damping-row residual, Z for the implicit-Q operator
+//   k_stage2_cols      one thread per (observation, pose component): rotates the stored top0
+//                      column into topd / dampO and the three damping rows of the dense block
 // ===========================================================================
-template <class S, int CH>
-__global__ __launch_bounds__(256) void k_stage2(Params<S> p, int lm_begin, int lm_end, S lambda) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s = lm_begin + blockIdx.x * 4 + wave;
-  if (s >= lm_end) return;
-  const int k = p.lm_k[s];
+template <class S>
+__global__ __launch_bounds__(256) void k_stage2_landmark(Params<S> p, S lambda) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= p.n_lms) return;
   const int64_t o0 = p.lm_obs[s];
-  const int nrows = 2 * k, ncols = 9 * k;
-
-  // small part, computed redundantly by every lane: [R | q] rows 0..2 and the
-  // damping rows [sqrt(lambda) I | 0]
+  // [R | q] rows 0..2 and the damping rows [sqrt(lambda) I | 0]
   S T[3][4], D[3][4];
   {
     const S* R = p.R0 + 6 * s;
@@ -805,97 +806,99 @@ __global__ __launch_bounds__(256) void k_stage2(Params<S> p, int lm_begin, int l
       }
     }
   }
-  if (lane == 0) {
-    S* R = p.Rd + 6 * s;
-    R[0] = T[0][0];
-    R[1] = T[0][1];
-    R[2] = T[0][2];
-    R[3] = T[1][1];
-    R[4] = T[1][2];
-    R[5] = T[2][2];
-    p.q1trd[3 * s + 0] = T[0][3];
-    p.q1trd[3 * s + 1] = T[1][3];
-    p.q1trd[3 * s + 2] = T[2][3];
-    p.damp_r[3 * s + 0] = D[0][3];
-    p.damp_r[3 * s + 1] = D[1][3];
-    p.damp_r[3 * s + 2] = D[2][3];
-    // Z: what "apply the 6 damping rotations, drop the three Q1 rows, rotate back"
-    // does to the top three entries of a vector (the three extra rows start at 0
-    // and are discarded afterwards). Used by the implicit-Q operator.
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      S u[3] = {S(0), S(0), S(0)}, e[3] = {S(0), S(0), S(0)};
-      u[j] = S(1);
-      int idx = 0;
-#pragma unroll
-      for (int n = 0; n < 3; ++n) {
-#pragma unroll
-        for (int m = 0; m <= n; ++m) {
-          const S x = e[n - m], y = u[n];
-          e[n - m] = gc[idx] * x + gs[idx] * y;
-          u[n] = -gs[idx] * x + gc[idx] * y;
-          ++idx;
-        }
-      }
-      u[0] = u[1] = u[2] = S(0);
-#pragma unroll
-      for (int n = 2; n >= 0; --n) {
-#pragma unroll
-        for (int m = n; m >= 0; --m) {
-          --idx;
-          const S x = e[n - m], y = u[n];
-          e[n - m] = gc[idx] * x - gs[idx] * y;
-          u[n] = gs[idx] * x + gc[idx] * y;
-        }
-      }
-      p.Zd[9 * s + 0 + j] = u[0];
-      p.Zd[9 * s + 3 + j] = u[1];
-      p.Zd[9 * s + 6 + j] = u[2];
-    }
+  for (int i = 0; i < 6; ++i) {
+    p.givens[12 * size_t(s) + i] = gc[i];
+    p.givens[12 * size_t(s) + 6 + i] = gs[i];
   }
+  S* R = p.Rd + 6 * s;
+  R[0] = T[0][0];
+  R[1] = T[0][1];
+  R[2] = T[0][2];
+  R[3] = T[1][1];
+  R[4] = T[1][2];
+  R[5] = T[2][2];
+  p.q1trd[3 * s + 0] = T[0][3];
+  p.q1trd[3 * s + 1] = T[1][3];
+  p.q1trd[3 * s + 2] = T[2][3];
+  p.damp_r[3 * s + 0] = D[0][3];
+  p.damp_r[3 * s + 1] = D[1][3];
+  p.damp_r[3 * s + 2] = D[2][3];
+  if (!p.implicit) return;
+  // Z: what "apply the 6 damping rotations, drop the three Q1 rows, rotate back"
+  // does to the top three entries of a vector (the three extra rows start at 0
+  // and are discarded afterwards). Used by the implicit-Q operator.
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    S u[3] = {S(0), S(0), S(0)}, e[3] = {S(0), S(0), S(0)};
+    u[j] = S(1);
+    int idx = 0;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+#pragma unroll
+      for (int m = 0; m <= n; ++m) {
+        const S x = e[n - m], y = u[n];
+        e[n - m] = gc[idx] * x + gs[idx] * y;
+        u[n] = -gs[idx] * x + gc[idx] * y;
+        ++idx;
+      }
+    }
+    u[0] = u[1] = u[2] = S(0);
+#pragma unroll
+    for (int n = 2; n >= 0; --n) {
+#pragma unroll
+      for (int m = n; m >= 0; --m) {
+        --idx;
+        const S x = e[n - m], y = u[n];
+        e[n - m] = gc[idx] * x - gs[idx] * y;
+        u[n] = gs[idx] * x + gc[idx] * y;
+      }
+    }
+    p.Zd[9 * s + 0 + j] = u[0];
+    p.Zd[9 * s + 3 + j] = u[1];
+    p.Zd[9 * s + 6 + j] = u[2];
+  }
+}
 
-  S* Ablk = p.A + p.lm_blk[s];
-  const S* T0 = p.top0 + 27 * o0;
-  S* Td = p.topd + 27 * o0;
-  S* DO = p.dampO + 27 * o0;
-  const int lane9 = lane / 9, comp = lane - 9 * lane9;
-#pragma unroll 1
-  for (int ch = 0; ch < CH; ++ch) {
-    const int islot = 7 * ch + lane9;
-    const bool act = lane < 63 && islot < k;
-    const int i = act ? islot : 0;
-    const int j = 9 * i + comp;
-    S t[3] = {S(0), S(0), S(0)}, d[3] = {S(0), S(0), S(0)};
-    if (act) {
-      t[0] = T0[27 * i + comp];
-      t[1] = T0[27 * i + 9 + comp];
-      t[2] = T0[27 * i + 18 + comp];
-    }
-    {
-      int idx = 0;
+template <class S>
+__global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t n_obs) {
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= 9 * n_obs) return;
+  const int64_t o = t / 9;
+  const int comp = int(t - 9 * o);
+  const int s = p.obs_lm[o];
+  const S* __restrict__ g = p.givens + 12 * size_t(s);
+  const S* __restrict__ T0 = p.top0 + 27 * o;
+  S tt[3] = {T0[comp], T0[9 + comp], T0[18 + comp]}, d[3] = {S(0), S(0), S(0)};
+  {
+    int idx = 0;
 #pragma unroll
-      for (int n = 0; n < 3; ++n) {
+    for (int n = 0; n < 3; ++n) {
 #pragma unroll
-        for (int m = 0; m <= n; ++m) {
-          const S x = d[n - m], y = t[n];
-          d[n - m] = gc[idx] * x + gs[idx] * y;
-          t[n] = -gs[idx] * x + gc[idx] * y;
-          ++idx;
-        }
+      for (int m = 0; m <= n; ++m) {
+        const S c = g[idx], sn = g[6 + idx];
+        const S x = d[n - m], y = tt[n];
+        d[n - m] = c * x + sn * y;
+        tt[n] = -sn * x + c * y;
+        ++idx;
       }
     }
-    if (act) {
-      Td[27 * i + comp] = t[0];
-      Td[27 * i + 9 + comp] = t[1];
-      Td[27 * i + 18 + comp] = t[2];
-      DO[27 * i + comp] = d[0];
-      DO[27 * i + 9 + comp] = d[1];
-      DO[27 * i + 18 + comp] = d[2];
-      Ablk[size_t(nrows - 3) * ncols + j] = d[0];
-      Ablk[size_t(nrows - 2) * ncols + j] = d[1];
-      Ablk[size_t(nrows - 1) * ncols + j] = d[2];
-    }
   }
+  S* Td = p.topd + 27 * o;
+  S* DO = p.dampO + 27 * o;
+  Td[comp] = tt[0];
+  Td[9 + comp] = tt[1];
+  Td[18 + comp] = tt[2];
+  DO[comp] = d[0];
+  DO[9 + comp] = d[1];
+  DO[18 + comp] = d[2];
+  const int k = p.lm_k[s];
+  const int nrows = 2 * k, ncols = 9 * k;
+  S* Ablk = p.A + p.lm_blk[s];
+  const int j = 9 * int(o - p.lm_obs[s]) + comp;
+  Ablk[size_t(nrows - 3) * ncols + j] = d[0];
+  Ablk[size_t(nrows - 2) * ncols + j] = d[1];
+  Ablk[size_t(nrows - 1) * ncols + j] = d[2];
 }
 
 // ===========================================================================

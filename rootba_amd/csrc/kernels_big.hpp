@@ -190,91 +190,6 @@ __global__ __launch_bounds__(256) void k_linearize_qr_big(Params<S> p, int lm_be
   }
 }
 
-// ---------------------------------------------------------------------------
-// stage 2 (same outputs as k_stage2)
-// ---------------------------------------------------------------------------
-template <class S>
-__global__ __launch_bounds__(256) void k_stage2_big(Params<S> p, int lm_begin, S lambda) {
-  const int tid = threadIdx.x;
-  const int s = lm_begin + blockIdx.x;
-  const int k = p.lm_k[s];
-  const int64_t o0 = p.lm_obs[s];
-  const int nrows = 2 * k, ncols = 9 * k;
-  S T[3][4], D[3][4];
-  {
-    const S* R = p.R0 + 6 * s;
-    T[0][0] = R[0]; T[0][1] = R[1]; T[0][2] = R[2];
-    T[1][0] = S(0); T[1][1] = R[3]; T[1][2] = R[4];
-    T[2][0] = S(0); T[2][1] = S(0); T[2][2] = R[5];
-    T[0][3] = p.qtr[2 * o0 + 0];
-    T[1][3] = p.qtr[2 * o0 + 1];
-    T[2][3] = p.qtr[2 * o0 + 2];
-  }
-  const S sl = sqrt(lambda);
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) D[a][b] = (a == b) ? sl : S(0);
-  S gc[6], gs[6];
-  {
-    int idx = 0;
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-#pragma unroll
-      for (int m = 0; m <= n; ++m) {
-        S c = S(1), sn = S(0);
-        if (lambda != S(0)) make_givens<S>(T[n][n], D[n - m][n], c, sn);
-        gc[idx] = c;
-        gs[idx] = sn;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const S x = D[n - m][b], y = T[n][b];
-          D[n - m][b] = c * x + sn * y;
-          T[n][b] = -sn * x + c * y;
-        }
-        ++idx;
-      }
-    }
-  }
-  if (tid == 0) {
-    S* R = p.Rd + 6 * s;
-    R[0] = T[0][0]; R[1] = T[0][1]; R[2] = T[0][2];
-    R[3] = T[1][1]; R[4] = T[1][2]; R[5] = T[2][2];
-    for (int m = 0; m < 3; ++m) {
-      p.q1trd[3 * s + m] = T[m][3];
-      p.damp_r[3 * s + m] = D[m][3];
-    }
-  }
-  S* Ablk = p.A + p.lm_blk[s];
-  const S* T0 = p.top0 + 27 * o0;
-  S* Td = p.topd + 27 * o0;
-  S* DO = p.dampO + 27 * o0;
-  const int cam28 = tid / 9, comp = tid - 9 * cam28;
-  for (int pass = 0; pass * 28 < k; ++pass) {
-    const int i = pass * 28 + cam28;
-    if (!(tid < 252 && i < k)) continue;
-    const int j = 9 * i + comp;
-    S t[3] = {T0[27 * i + comp], T0[27 * i + 9 + comp], T0[27 * i + 18 + comp]};
-    S d[3] = {S(0), S(0), S(0)};
-    int idx = 0;
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-#pragma unroll
-      for (int m = 0; m <= n; ++m) {
-        const S x = d[n - m], y = t[n];
-        d[n - m] = gc[idx] * x + gs[idx] * y;
-        t[n] = -gs[idx] * x + gc[idx] * y;
-        ++idx;
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      Td[27 * i + 9 * m + comp] = t[m];
-      DO[27 * i + 9 * m + comp] = d[m];
-      Ablk[size_t(nrows - 3 + m) * ncols + j] = d[m];
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------
 // H*x (same result as k_hx): x and y of the landmark live in LDS

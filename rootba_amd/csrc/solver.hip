@@ -368,6 +368,7 @@ class Solver final : public rba_solver {
     d_JlS_.alloc(6 * qr_obs);
     d_rS_.alloc(2 * qr_obs);
     d_bsO_.alloc(5 * qr_obs);
+    d_givens_.alloc(sc_ ? 0 : 12 * size_t(n_lms));
     d_bmO_.alloc(9 * qr_obs);
     d_Vh_.alloc(8 * qr_obs);
     if (sc_) build_sc_structure(lm_k, lm_obs, s_obs_cam);
@@ -454,6 +455,7 @@ class Solver final : public rba_solver {
     prm_.JlS = d_JlS_.get();
     prm_.rS = d_rS_.get();
     prm_.bsO = d_bsO_.get();
+    prm_.givens = d_givens_.get();
     prm_.bmO = d_bmO_.get();
     prm_.Vh = d_Vh_.get();
     prm_.tauH = d_tauH_.get();
@@ -924,14 +926,10 @@ class Solver final : public rba_solver {
       landmark_damping_valid_ = true;
       return;
     }
-    for_each_class([&](auto ch_tag, int begin, int end) {
-      constexpr int CH = decltype(ch_tag)::value;
-      hipLaunchKernelGGL((rba::k_stage2<S, CH>), dim3((end - begin + 3) / 4), dim3(256), 0,
-                         stream_, prm_, begin, end, lambda);
-    });
-    if (n_big_ > 0)
-      hipLaunchKernelGGL((rba::k_stage2_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
-                         lambda);
+    hipLaunchKernelGGL((rba::k_stage2_landmark<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_, prm_,
+                       lambda);
+    hipLaunchKernelGGL((rba::k_stage2_cols<S>), dim3(unsigned((9 * int64_t(n_obs_) + 255) / 256)), dim3(256), 0,
+                       stream_, prm_, int64_t(n_obs_));
     launch_cam_stage2(prm_, lambda);
     if (comm_ || cb_fn_) {
       // every rank added lambda*I and holds only its landmarks' sums: make the
@@ -1564,7 +1562,7 @@ class Solver final : public rba_solver {
   DevBuf<int> d_lm_k_, d_obs_cam_, d_obs_lm_, d_fail_;
   DevBuf<int64_t> d_lm_obs_, d_lm_blk_, d_cam_off_;
   DevBuf<int> d_cam_obs_;
-  DevBuf<S> d_dampO_, d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_JT_, d_VT_, d_JlS_, d_rS_, d_bsO_;
+  DevBuf<S> d_dampO_, d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_JT_, d_VT_, d_JlS_, d_rS_, d_bsO_, d_givens_;
   DevBuf<int> d_CT_, d_lm_tile_, d_lm_lane0_;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
