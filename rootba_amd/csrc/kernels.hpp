@@ -1596,7 +1596,10 @@ __global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ in
 // (Measured alternative: the five kernels fused into one launch with software grid
 //  barriers between the phases. Same 0.65 ms per CG iteration on venice — with one L2
 //  per XCD an agent-scope release/acquire pair is an L2 write-back + invalidate, i.e.
-//  as expensive as the ~5.6 us kernel boundary it replaces — so the simpler form stays.)
+//  as expensive as the ~5.6 us kernel boundary it replaces — so the simpler form stays.
+//  Likewise measured and dropped: the termination test in the last-arriving workgroup of
+//  k_pcg_b2 (threadfence + atomic counter) and k_pcg_b1 folded into the SpMV: slower, for
+//  the same reason; operand loads hoisted above the `done` test: +1 %, not worth the code.)
 // All scalars stay on the device in `CgState` (double, as in the reference);
 // kernels are no-ops once `done`; the host only polls the state. Every reduction
 // has a fixed order, so all ranks of a multi-GPU run compute bit-identical
