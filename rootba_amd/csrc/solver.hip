@@ -634,6 +634,9 @@ class Solver final : public rba_solver {
   // block_sparse_matrix.hpp), as block-CSR + a dense (camera, camera) -> slot table.
   void build_sc_structure(const std::vector<int>& lm_k, const std::vector<int64_t>& lm_obs,
                           const std::vector<int>& s_obs_cam) {
+    if (n_cams_ > 20000)
+      throw HipError{"SCHUR_COMPLEMENT solver: more than 20000 cameras (dense camera-pair table on the host)",
+                     RBA_ERR_UNSUPPORTED};
     const size_t nc = size_t(n_cams_);
     std::vector<int> slot(nc * nc, -1);
     for (int l = 0; l < n_lms_; ++l) {
