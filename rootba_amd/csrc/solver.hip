@@ -377,7 +377,7 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_EXPLICIT_AFTER")) explicit_after_ = std::atoi(ev);
     // (needs the SCHUR_JACOBI blocks of stage 2 as its diagonal; the dense n_c x n_c host tables used
     //  to build the structure bound the camera count: 20000 cameras = 0.4 GB of marks + 1.6 GB transient)
-    if (!sc_ && !opt_.implicit_q && opt_.preconditioner_type == 1 && explicit_after_ > 0 && n_cams_ <= 20000) {
+    if (!sc_ && opt_.preconditioner_type == 1 && explicit_after_ > 0 && n_cams_ <= 20000) {
       h_lm_obs_ = lm_obs;
       h_obs_cam_ = s_obs_cam;
       pair_mark_.assign(size_t(n_cams_) * n_cams_, 0);
