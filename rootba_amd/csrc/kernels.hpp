@@ -62,6 +62,7 @@ struct Params {
   S* rS;        // [n_obs][2]     sqrt(w) r
   S* bsO;       // [n_obs][5]     back-substitution scratch: topd x (3), Jp x (2)
   S* givens;    // [n_lms][12]    the 6 damping rotations of stage 2: c[6], s[6]
+  S* bdO;       // [n_obs][9]     damping rows' part of b per observation
   S* R0;        // [6 n_lms]
   S* Rd;        // [6 n_lms]
   S* q1trd;     // [3 n_lms]
@@ -328,12 +329,7 @@ __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float 
   if (tid < 252) {
     const int g = tid / 9, a = tid - 9 * g;
     double accb = 0;
-    if (damped)
-      accb = cam_sum9(p.cam_obs, t0, t1, g, [&](int o) {
-        const float* d = p.dampO + int64_t(o) * 27;
-        const float* dr = p.damp_r + 3 * int64_t(p.obs_lm[o]);
-        return d[a] * dr[0] + d[9 + a] * dr[1] + d[18 + a] * dr[2];
-      });
+    if (damped) accb = cam_sum9(p.cam_obs, t0, t1, g, [&](int o) { return p.bdO[int64_t(o) * 9 + a]; });
     bsum[g][a] = accb;
   }
   __syncthreads();
@@ -892,6 +888,9 @@ __global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t n_obs)
   DO[comp] = d[0];
   DO[9 + comp] = d[1];
   DO[18 + comp] = d[2];
+  // the damping rows' part of b (add_Q2TJp_T_Q2Tr on rows 2k-3..2k-1), summed camera-major later
+  const S* __restrict__ dr = p.damp_r + 3 * size_t(s);
+  p.bdO[9 * o + comp] = d[0] * dr[0] + d[1] * dr[1] + d[2] * dr[2];
   const int k = p.lm_k[s];
   const int nrows = 2 * k, ncols = 9 * k;
   S* Ablk = p.A + p.lm_blk[s];

@@ -369,6 +369,7 @@ class Solver final : public rba_solver {
     d_rS_.alloc(2 * qr_obs);
     d_bsO_.alloc(5 * qr_obs);
     d_givens_.alloc(sc_ ? 0 : 12 * size_t(n_lms));
+    d_bdO_.alloc(9 * qr_obs);
     d_bmO_.alloc(9 * qr_obs);
     d_Vh_.alloc(8 * qr_obs);
     if (sc_) build_sc_structure(lm_k, lm_obs, s_obs_cam);
@@ -455,6 +456,7 @@ class Solver final : public rba_solver {
     prm_.rS = d_rS_.get();
     prm_.bsO = d_bsO_.get();
     prm_.givens = d_givens_.get();
+    prm_.bdO = d_bdO_.get();
     prm_.bmO = d_bmO_.get();
     prm_.Vh = d_Vh_.get();
     prm_.tauH = d_tauH_.get();
@@ -1564,7 +1566,7 @@ class Solver final : public rba_solver {
   DevBuf<int> d_lm_k_, d_obs_cam_, d_obs_lm_, d_fail_;
   DevBuf<int64_t> d_lm_obs_, d_lm_blk_, d_cam_off_;
   DevBuf<int> d_cam_obs_;
-  DevBuf<S> d_dampO_, d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_JT_, d_VT_, d_JlS_, d_rS_, d_bsO_, d_givens_;
+  DevBuf<S> d_dampO_, d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_JT_, d_VT_, d_JlS_, d_rS_, d_bsO_, d_givens_, d_bdO_;
   DevBuf<int> d_CT_, d_lm_tile_, d_lm_lane0_;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
