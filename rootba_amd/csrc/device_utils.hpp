@@ -50,6 +50,17 @@ __device__ __forceinline__ double read_lane(double v, int lane) {
                               static_cast<unsigned int>(lo));
 }
 
+// sum over the 16 lanes of a DPP row (the first four steps of wave_sum); every lane of
+// the row receives it
+template <class S>
+__device__ __forceinline__ S row_sum(S v) {
+  v += dpp_mov0<0xb1>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_mov0<0x4e>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_mov0<0x124>(v);  // row_ror:4
+  v += dpp_mov0<0x128>(v);  // row_ror:8
+  return v;
+}
+
 template <class S>
 __device__ __forceinline__ S wave_sum(S v) {
   v += dpp_mov0<0xb1>(v);   // quad_perm:[1,0,3,2]

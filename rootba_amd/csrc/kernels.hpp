@@ -740,6 +740,208 @@ __global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin,
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same for the smallest landmarks (k <= 7, 2k <= 14 rows): FOUR landmarks per
+// wavefront in the geometry and Householder phases, one per 16-lane DPP row, so that the
+// reductions are row-local (4 DPP steps) and the ~800 instructions of those phases are
+// shared by four landmarks; the column phase then runs once per landmark as above.
+// (One wavefront per 2-3 observation landmark executes at 5-20 % lane utilisation.)
+// ---------------------------------------------------------------------------
+template <class S>
+__global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm_begin, int lm_end) {
+  using Cfg = ClassCfg<1>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, sl = lane & 15, row_base = lane & 48;
+  const int s_first = lm_begin + (blockIdx.x * 4 + wave) * 4;
+  if (s_first >= lm_end) return;  // whole wave exits; no block-level barriers below
+  const int s = s_first + g;
+  const bool lm_ok = s < lm_end;
+  S* JpL = reinterpret_cast<S*>(smem_raw) + size_t(wave * 4 + g) * Cfg::WAVE_LDS;
+  S* V = JpL + 18 * Cfg::KMAX;  // [2k][4]
+
+  const int k = lm_ok ? p.lm_k[s] : 0;
+  const int64_t o0 = lm_ok ? p.lm_obs[s] : 0;
+  const int nrows = 2 * k;
+
+  // ---- geometry: lane sl of the row = observation sl ----------------------------
+  if (sl < k) {
+    const S pwx = p.lms[3 * s], pwy = p.lms[3 * s + 1], pwz = p.lms[3 * s + 2];
+    const int i = sl;
+    const int64_t o = o0 + i;
+    const int cam = p.obs_cam[o];
+    S res[2], Jp[18], Jl[6];
+    const bool valid = linearize_obs<S>(p.cams + 10 * cam, pwx, pwy, pwz, p.obs_xy[2 * o],
+                                        p.obs_xy[2 * o + 1], res, Jp, Jl);
+    S sw = S(0);
+    if (!p.valid_only || valid) {
+      S err, w;
+      error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
+      sw = sqrt(w);
+    }
+#pragma unroll
+    for (int c = 0; c < 18; ++c) JpL[18 * i + c] = sw * Jp[c];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      V[4 * (2 * i + r) + 0] = sw * Jl[3 * r + 0];
+      V[4 * (2 * i + r) + 1] = sw * Jl[3 * r + 1];
+      V[4 * (2 * i + r) + 2] = sw * Jl[3 * r + 2];
+      V[4 * (2 * i + r) + 3] = sw * res[r];
+    }
+  }
+  wave_lds_fence();
+
+  // ---- row lanes: lane sl of the row = block row sl ------------------------------
+  const bool rvalid = sl < nrows;
+  const int r = sl;
+  S jl[3], rs;
+  jl[0] = rvalid ? V[4 * r + 0] : S(0);
+  jl[1] = rvalid ? V[4 * r + 1] : S(0);
+  jl[2] = rvalid ? V[4 * r + 2] : S(0);
+  rs = rvalid ? V[4 * r + 3] : S(0);
+  wave_lds_fence();
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const S ss = row_sum(jl[c] * jl[c]);
+    const S sc = S(1) / (p.eps + sqrt(ss));
+    jl[c] *= sc;
+    if (sl == 0 && lm_ok) p.jl_scale[3 * s + c] = sc;
+  }
+  if (rvalid) {
+    S* dst = p.JlS + 3 * (2 * o0 + r);
+    dst[0] = jl[0];
+    dst[1] = jl[1];
+    dst[2] = jl[2];
+    p.rS[2 * o0 + r] = rs;
+  }
+  S vm[3], tau[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const S c0 = __shfl(jl[m], row_base + m);
+    const S tail = row_sum((r > m && rvalid) ? jl[m] * jl[m] : S(0));
+    S beta, inv;
+    if (tail <= Eps<S>::tiny) {
+      tau[m] = S(0);
+      beta = c0;
+      inv = S(0);
+    } else {
+      beta = sqrt(c0 * c0 + tail);
+      if (c0 >= S(0)) beta = -beta;
+      inv = S(1) / (c0 - beta);
+      tau[m] = (beta - c0) / beta;
+    }
+    vm[m] = (r == m) ? S(1) : ((r > m && rvalid) ? jl[m] * inv : S(0));
+#pragma unroll
+    for (int c2 = m + 1; c2 < 3; ++c2) {
+      const S d = tau[m] * row_sum(vm[m] * jl[c2]);
+      jl[c2] -= d * vm[m];
+    }
+    {
+      const S d = tau[m] * row_sum(vm[m] * rs);
+      rs -= d * vm[m];
+    }
+    if (r == m) jl[m] = beta;
+    if (r > m) jl[m] = S(0);
+  }
+  const S g10 = row_sum(vm[1] * vm[0]), g20 = row_sum(vm[2] * vm[0]), g21 = row_sum(vm[2] * vm[1]);
+  {
+    const S r00 = __shfl(jl[0], row_base), r01 = __shfl(jl[1], row_base), r02 = __shfl(jl[2], row_base),
+            r11 = __shfl(jl[1], row_base + 1), r12 = __shfl(jl[2], row_base + 1),
+            r22 = __shfl(jl[2], row_base + 2);
+    if (sl == 0 && lm_ok) {
+      S* R = p.R0 + 6 * s;
+      R[0] = r00;
+      R[1] = r01;
+      R[2] = r02;
+      R[3] = r11;
+      R[4] = r12;
+      R[5] = r22;
+      p.tauH[3 * s + 0] = tau[0];
+      p.tauH[3 * s + 1] = tau[1];
+      p.tauH[3 * s + 2] = tau[2];
+    }
+  }
+  if (rvalid) {
+    V[4 * r + 0] = vm[0];
+    V[4 * r + 1] = vm[1];
+    V[4 * r + 2] = vm[2];
+    V[4 * r + 3] = rs;
+    p.qtr[2 * o0 + r] = rs;
+    S* vh = p.Vh + 4 * (2 * o0 + r);
+    vh[0] = vm[0];
+    vh[1] = vm[1];
+    vh[2] = vm[2];
+    vh[3] = rs;
+    if (p.implicit && p.lm_tile[s] >= 0) {
+      S* vt = p.VT + size_t(p.lm_tile[s]) * 192 + p.lm_lane0[s] + r;
+      vt[0] = vm[0];
+      vt[64] = vm[1];
+      vt[128] = vm[2];
+    }
+  }
+  wave_lds_fence();
+
+  // ---- column lanes, one landmark of the wave after the other ---------------------
+  const int lane9 = lane / 9, comp = lane - 9 * lane9;
+#pragma unroll
+  for (int gg = 0; gg < 4; ++gg) {
+    const int s2 = s_first + gg;
+    if (s2 >= lm_end) break;  // wave-uniform
+    const int k2 = p.lm_k[s2];
+    const int64_t o2 = p.lm_obs[s2];
+    const int nrows2 = 2 * k2, ncols2 = 9 * k2;
+    const S t0 = read_lane(tau[0], 16 * gg), t1 = read_lane(tau[1], 16 * gg), t2 = read_lane(tau[2], 16 * gg);
+    const S h10 = read_lane(g10, 16 * gg), h20 = read_lane(g20, 16 * gg), h21 = read_lane(g21, 16 * gg);
+    const S* JpL2 = reinterpret_cast<S*>(smem_raw) + size_t(wave * 4 + gg) * Cfg::WAVE_LDS;
+    const S* V2 = JpL2 + 18 * Cfg::KMAX;
+    S* Ablk = p.A + p.lm_blk[s2];
+    S* T0 = p.top0 + 27 * o2;
+    const int islot = lane9;
+    const bool act = lane < 63 && islot < k2;
+    const int i = act ? islot : 0;
+    const int j = 9 * i + comp;
+    const int cam = act ? p.obs_cam[o2 + i] : 0;
+    S m0 = S(0), m1 = S(0);
+    if (act) {
+      const S d = p.pose_scaling[9 * cam + comp];
+      m0 = JpL2[18 * i + comp] * d;
+      m1 = JpL2[18 * i + 9 + comp] * d;
+    }
+    const S va0 = V2[4 * (2 * i) + 0], va1 = V2[4 * (2 * i) + 1], va2 = V2[4 * (2 * i) + 2];
+    const S vb0 = V2[4 * (2 * i + 1) + 0], vb1 = V2[4 * (2 * i + 1) + 1], vb2 = V2[4 * (2 * i + 1) + 2];
+    const S c0 = t0 * (va0 * m0 + vb0 * m1);
+    const S c1 = t1 * (va1 * m0 + vb1 * m1 - c0 * h10);
+    const S c2 = t2 * (va2 * m0 + vb2 * m1 - c0 * h20 - c1 * h21);
+    S bm = S(0);
+    for (int rr = 0; rr < nrows2; ++rr) {
+      const S w0 = V2[4 * rr + 0], w1 = V2[4 * rr + 1], w2 = V2[4 * rr + 2], cr = V2[4 * rr + 3];
+      S val = -(c0 * w0 + c1 * w1 + c2 * w2);
+      if (rr == 2 * i) val += m0;
+      if (rr == 2 * i + 1) val += m1;
+      if (rr < 3) {
+        if (act) T0[27 * i + 9 * rr + comp] = val;  // [i][r][comp]
+      } else {
+        if (act) Ablk[size_t(rr - 3) * ncols2 + j] = val;
+        bm += val * cr;
+      }
+    }
+    if (act) {
+      // landmark-damping rows start out as zeros
+      Ablk[size_t(nrows2 - 3) * ncols2 + j] = S(0);
+      Ablk[size_t(nrows2 - 2) * ncols2 + j] = S(0);
+      Ablk[size_t(nrows2 - 1) * ncols2 + j] = S(0);
+      p.JpS[(o2 + i) * 18 + comp] = m0;
+      p.JpS[(o2 + i) * 18 + 9 + comp] = m1;
+      p.bmO[(o2 + i) * 9 + comp] = bm;
+      if (p.implicit && p.lm_tile[s2] >= 0) {
+        S* jt = p.JT + (size_t(p.lm_tile[s2]) * 9 + comp) * 64 + p.lm_lane0[s2] + 2 * i;
+        jt[0] = m0;
+        jt[1] = m1;
+      }
+    }
+  }
+}
+
 // ===========================================================================
 // Stage 2: landmark damping by 6 Givens rotations against the stored undamped
 // top rows (set_landmark_damping, ipp:149-210). Because the linearisation is

@@ -165,6 +165,7 @@ class Solver final : public rba_solver {
     n_obs_ = lm_off[n_lms];
     nvec_ = 9 * n_cams_;
     if (const char* ev = std::getenv("RBA_HX_SINGLE_STREAM")) hx_single_stream_ = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("RBA_QR_UNPACKED")) qr_unpacked_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
 
     // ---- sort landmarks by number of observations (stable) ----------------
@@ -893,8 +894,12 @@ class Solver final : public rba_solver {
       for_each_class([&](auto ch_tag, int begin, int end) {
         constexpr int CH = decltype(ch_tag)::value;
         const size_t lds = 4 * size_t(rba::ClassCfg<CH>::WAVE_LDS) * sizeof(S);
-        hipLaunchKernelGGL((rba::k_linearize_qr<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
-                           lds, stream_, prm_, begin, end);
+        if (CH == 1 && !qr_unpacked_)  // k <= 7: four landmarks per wavefront in the QR phases
+          hipLaunchKernelGGL((rba::k_linearize_qr_packed<S>), dim3((end - begin + 15) / 16), dim3(256),
+                             4 * lds, stream_, prm_, begin, end);
+        else
+          hipLaunchKernelGGL((rba::k_linearize_qr<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
+                             lds, stream_, prm_, begin, end);
       });
       if (n_big_ > 0)
         hipLaunchKernelGGL((rba::k_linearize_qr_big<S>), dim3(n_big_), dim3(256),
@@ -1584,6 +1589,7 @@ class Solver final : public rba_solver {
   std::vector<int> hx_event_call_;  // which H*x call of the solve each event pair brackets
   int hx_event_count_ = 0, hx_calls_ = 0;
   bool hx_single_stream_ = false;
+  bool qr_unpacked_ = false;  // RBA_QR_UNPACKED=1: one wavefront per landmark also for k <= 7
   // explicit reduced matrix of the square-root solver (adaptive, see pcg())
   int explicit_after_ = 0;  // matrix-free products before a solve switches to S x; 0 = never
   bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;

@@ -117,4 +117,6 @@ def test_rccl_call_path_with_one_rank(ladybug_problem):
     la, _ = a.optimize_lm()
     lb, _ = b.optimize_lm()
     assert len(la) == len(lb)
-    assert np.allclose([r.cost for r in la], [r.cost for r in lb], rtol=1e-6)
+    # two float32 runs differ by the order of the atomic scatter-adds: cost resolution ~1e-6 (see
+    # test_lm_trajectory_matches_oracle)
+    assert np.allclose([r.cost for r in la], [r.cost for r in lb], rtol=3e-6)
