@@ -719,15 +719,18 @@ __global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin,
       if (r < 3) {
         if (act) T0[27 * i + 9 * r + comp] = val;  // [i][r][comp]
       } else {
-        if (act) Ablk[size_t(r - 3) * ncols + j] = val;
+        if (act && !p.implicit) Ablk[size_t(r - 3) * ncols + j] = val;
         bm += val * cr;
       }
     }
     if (act) {
-      // landmark-damping rows start out as zeros
-      Ablk[size_t(nrows - 3) * ncols + j] = S(0);
-      Ablk[size_t(nrows - 2) * ncols + j] = S(0);
-      Ablk[size_t(nrows - 1) * ncols + j] = S(0);
+      // landmark-damping rows start out as zeros (the implicit-Q operator never reads the
+      // dense block of a k <= 112 landmark: it is not written then)
+      if (!p.implicit) {
+        Ablk[size_t(nrows - 3) * ncols + j] = S(0);
+        Ablk[size_t(nrows - 2) * ncols + j] = S(0);
+        Ablk[size_t(nrows - 1) * ncols + j] = S(0);
+      }
       p.JpS[(o0 + i) * 18 + comp] = m0;
       p.JpS[(o0 + i) * 18 + 9 + comp] = m1;
       p.bmO[(o0 + i) * 9 + comp] = bm;
@@ -921,15 +924,16 @@ __global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm
       if (rr < 3) {
         if (act) T0[27 * i + 9 * rr + comp] = val;  // [i][r][comp]
       } else {
-        if (act) Ablk[size_t(rr - 3) * ncols2 + j] = val;
+        if (act && !p.implicit) Ablk[size_t(rr - 3) * ncols2 + j] = val;
         bm += val * cr;
       }
     }
     if (act) {
-      // landmark-damping rows start out as zeros
-      Ablk[size_t(nrows2 - 3) * ncols2 + j] = S(0);
-      Ablk[size_t(nrows2 - 2) * ncols2 + j] = S(0);
-      Ablk[size_t(nrows2 - 1) * ncols2 + j] = S(0);
+      if (!p.implicit) {  // landmark-damping rows start out as zeros
+        Ablk[size_t(nrows2 - 3) * ncols2 + j] = S(0);
+        Ablk[size_t(nrows2 - 2) * ncols2 + j] = S(0);
+        Ablk[size_t(nrows2 - 1) * ncols2 + j] = S(0);
+      }
       p.JpS[(o2 + i) * 18 + comp] = m0;
       p.JpS[(o2 + i) * 18 + 9 + comp] = m1;
       p.bmO[(o2 + i) * 9 + comp] = bm;
@@ -1094,6 +1098,7 @@ __global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t n_obs)
   const S* __restrict__ dr = p.damp_r + 3 * size_t(s);
   p.bdO[9 * o + comp] = d[0] * dr[0] + d[1] * dr[1] + d[2] * dr[2];
   const int k = p.lm_k[s];
+  if (p.implicit && k <= 112) return;  // dense block unused (only the k > 112 kernels read it)
   const int nrows = 2 * k, ncols = 9 * k;
   S* Ablk = p.A + p.lm_blk[s];
   const int j = 9 * int(o - p.lm_obs[s]) + comp;
