@@ -123,11 +123,14 @@ def main():
     ap.add_argument("--preconditioner", choices=sorted(PRECOND), default="SCHUR_JACOBI",
                     help="reference default: SCHUR_JACOBI")
     ap.add_argument("--power-order", type=int, default=10)
-    ap.add_argument("--implicit-q", action="store_true",
-                    help="H*x from the QR factors (SURVEY.md 8f #1) instead of the dense blocks")
+    ap.add_argument("--dense-blocks", action="store_true",
+                    help="matrix-free products on the dense Q2^T Jp blocks (what the reference materialises) "
+                         "instead of the default evaluation from the QR factors (implicit-Q, SURVEY.md 8f #1)")
+    ap.add_argument("--implicit-q", action="store_true", help="(default since round 1; kept for old command lines)")
     ap.add_argument("--solver-type", choices=["SQUARE_ROOT", "SCHUR_COMPLEMENT"], default="SQUARE_ROOT",
                     help="SCHUR_COMPLEMENT: explicit reduced camera matrix + SpMV (SURVEY.md 8f #4), 1 GPU")
     args = ap.parse_args()
+    args.implicit_q = not args.dense_blocks
     _SOLVER_KW.update(preconditioner_type=PRECOND[args.preconditioner], power_order=args.power_order)
     _GPU_KW.update(implicit_q=int(args.implicit_q), solver_type=int(args.solver_type == "SCHUR_COMPLEMENT"))
 
@@ -209,10 +212,11 @@ def main():
         achieved = stats["hx_bytes"] / avg_hx / 1e9 if avg_hx else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hx_traffic.json")
-        if os.path.exists(tpath) and world == 1 and not args.implicit_q and args.solver_type == "SQUARE_ROOT":
+        if os.path.exists(tpath) and world == 1 and args.solver_type == "SQUARE_ROOT":
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get(args.workload, {}).get("traffic_bytes_per_launch")
+                    key = args.workload + ("/implicit_q" if args.implicit_q else "")
+                    traffic = json.load(f).get(key, {}).get("traffic_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

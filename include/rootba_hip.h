@@ -75,9 +75,10 @@ typedef struct rba_options {
   double vee_factor;
   int optimized_cost;             /* 0 ERROR, 1 ERROR_VALID, 2 ERROR_VALID_AVG    */
   int staged_execution;           /* accepted; execution is always staged         */
-  int implicit_q;                 /* 0 (default): H*x streams the dense Q2^T Jp blocks the
-                                     reference materialises; 1: same operator evaluated from
-                                     the factors (Jp, Householder vectors, damping rotations) */
+  int implicit_q;                 /* matrix-free products H*x: 1 (default) evaluated from the factors
+                                     (Jp, Householder vectors, damping rotations); the dense blocks of
+                                     landmarks with <= 112 observations are then never written.
+                                     0: stream the dense Q2^T Jp blocks the reference materialises */
   int solver_type;                /* SolverOptions::SolverType: 0 SQUARE_ROOT (default, LinearizorQR),
                                      1 SCHUR_COMPLEMENT (LinearizorSC, linearizor_sc.cpp:70-211:
                                      explicit block-sparse reduced camera matrix + SpMV)        */

@@ -35,7 +35,7 @@ void usage() {
       "  --eta <e> --max-linear-solver-iterations <n> --function-tolerance <t>\n"
       "  --jacobi-scaling-epsilon <e> --log-path <ba_log.json> --device <n>\n"
       "  --solver-type SQUARE_ROOT|SCHUR_COMPLEMENT   (default SQUARE_ROOT)\n"
-      "  --implicit-q                           evaluate H*x from the QR factors instead of the dense blocks\n"
+      "  --dense-blocks                         matrix-free products on the dense Q2^T Jp blocks (default: from the QR factors)\n"
       "  --dry-run                              load + preprocess only, print problem statistics");
 }
 
@@ -222,6 +222,7 @@ int main(int argc, char** argv) {
     else if (a == "--self-test-parser") return self_test_parser(std::stol(val()));
     else if (a == "--self-test-log") return self_test_log(val());
     else if (a == "--implicit-q") so.implicit_q = true;
+    else if (a == "--dense-blocks") so.implicit_q = false;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 1; }
   }
   if (ds.input.empty()) { usage(); return 1; }

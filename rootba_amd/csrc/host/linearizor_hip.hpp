@@ -64,7 +64,7 @@ struct SolverOptions {
   int power_order = 10;
   double initial_vee = 2.0;
   double vee_factor = 2.0;
-  bool implicit_q = false;  // not in the reference: evaluate H*x from the QR factors
+  bool implicit_q = true;   // not in the reference: matrix-free products from the QR factors (false: dense blocks)
   int explicit_after = 6;   // not in the reference: rba_options.explicit_after
   bool use_projection_validity_check() const { return optimized_cost != OptimizedCost::ERROR; }
 

@@ -1672,7 +1672,7 @@ void rba_default_options(rba_options* o) {
   o->vee_factor = 2.0;
   o->optimized_cost = 0;
   o->staged_execution = 1;
-  o->implicit_q = 0;
+  o->implicit_q = 1;
   o->solver_type = 0;
   o->explicit_after = 6;
 }

@@ -4,7 +4,8 @@
     python scripts/pmc_traffic.py parse <fetch_dir> <write_dir> <out.json>
 
 `run` executes, on venice-1778: stage 1 + stage 2, then 3 x (calibration read of
-the block storage with 4-byte loads, the same with 16-byte loads, one H*x).
+the block storage with 4-byte loads, the same with 16-byte loads, one H*x) with the dense
+blocks, then 3 x one H*x with the implicit-Q operator.
 FETCH_SIZE / WRITE_SIZE are collected in SEPARATE rocprofv3 passes
 (MI355X_MICROARCH.md: FETCH_SIZE needs 3 of 4 TCC slots, WRITE_SIZE 2) with
 --kernel-trace only. Units: KiB. gfx950 correction: FETCH_SIZE under-reports wide
@@ -30,16 +31,25 @@ def run():
     from rootba_amd import problem as P
     from rootba_amd.linearizor import LinearizorHIP
     prob = P.preprocess(P.named_synthetic("venice-1778"), translation_sigma=0.5, point_sigma=0.5)
-    g = LinearizorHIP(prob, np.float32, L.default_options(robust_norm=1))
-    assert g.linearize() == 0
-    g.stage2(1e-4)
     x = np.random.default_rng(0).normal(size=9 * prob.n_cams).astype(np.float32)
-    nbytes = C.c_int64(0)
-    for _ in range(3):
-        L.check(g.lib.rba_debug_read_blocks(g.h, 1, C.byref(nbytes)), "calib1")
-        L.check(g.lib.rba_debug_read_blocks(g.h, 4, C.byref(nbytes)), "calib4")
-        g.right_multiply(x)
-    print(json.dumps({"calib_bytes": nbytes.value, **g.problem_stats()}))
+    meta = {}
+    # dense blocks first (its kernels k_hx<..>, k_hx_small), then the implicit-Q operator (k_hx_implicit*)
+    for mode, iq in (("dense", 0), ("implicit_q", 1)):
+        g = LinearizorHIP(prob, np.float32, L.default_options(robust_norm=1, implicit_q=iq))
+        assert g.linearize() == 0
+        g.stage2(1e-4)
+        nbytes = C.c_int64(0)
+        for _ in range(3):
+            if not iq:
+                L.check(g.lib.rba_debug_read_blocks(g.h, 1, C.byref(nbytes)), "calib1")
+                L.check(g.lib.rba_debug_read_blocks(g.h, 4, C.byref(nbytes)), "calib4")
+            g.right_multiply(x)
+        if not iq:
+            meta["calib_bytes"] = nbytes.value
+        meta["hx_bytes_" + mode] = g.problem_stats()["hx_bytes"]
+        g.close()
+    meta["hx_bytes"] = meta["hx_bytes_dense"]
+    print(json.dumps(meta))
 
 
 def _counter_rows(d, counter):
@@ -51,14 +61,15 @@ def _counter_rows(d, counter):
     return out
 
 
-def parse(fetch_dir, write_dir, out_path, calib_bytes, hx_bytes):
+def parse(fetch_dir, write_dir, out_path, calib_bytes, hx_bytes, hx_bytes_implicit=None):
     res = {}
     for name, d, counter in (("fetch", fetch_dir, "FETCH_SIZE"), ("write", write_dir, "WRITE_SIZE")):
         rows = _counter_rows(d, counter)
         agg = {}
         for k, v in rows:
             key = ("calib1" if "k_calib_read<1>" in k else "calib4" if "k_calib_read<4>" in k else
-                   "hx_small" if "k_hx_small" in k else "hx" if "k_hx<" in k else None)
+                   "hx_small" if "k_hx_small" in k else "hx" if "k_hx<" in k else
+                   "hx_implicit" if "k_hx_implicit" in k else None)
             if key:
                 agg.setdefault(key, []).append(v)
         res[name] = {k: sum(v) / 3.0 * 1024.0 for k, v in agg.items()}  # KiB -> bytes, per repetition
@@ -75,6 +86,15 @@ def parse(fetch_dir, write_dir, out_path, calib_bytes, hx_bytes):
         "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, --kernel-trace; KiB*1024; "
                   "FETCH_SIZE corrected by factors calibrated on streaming reads of the block storage",
     }}
+    if hx_bytes_implicit and "hx_implicit" in f:
+        # k_hx_implicit reads its tiles with 4-byte-per-lane coalesced loads (factor c1)
+        out["venice-1778/implicit_q"] = {
+            "traffic_bytes_per_launch": f["hx_implicit"] * c1 + res["write"].get("hx_implicit", 0),
+            "algorithmic_bytes_per_launch": hx_bytes_implicit,
+            "fetch_raw_bytes": f["hx_implicit"], "write_raw_bytes": res["write"].get("hx_implicit", 0),
+            "fetch_correction_4B_loads": c1,
+            "method": out["venice-1778"]["method"],
+        }
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
@@ -84,4 +104,5 @@ if __name__ == "__main__":
         run()
     else:
         meta = json.load(open(sys.argv[5]))
-        parse(sys.argv[2], sys.argv[3], sys.argv[4], meta["calib_bytes"], meta["hx_bytes"])
+        parse(sys.argv[2], sys.argv[3], sys.argv[4], meta["calib_bytes"], meta["hx_bytes"],
+              meta.get("hx_bytes_implicit_q"))

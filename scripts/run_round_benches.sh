@@ -4,7 +4,8 @@ set -x
 mkdir -p gpurun_out/r1b
 python bench.py > gpurun_out/r1b/venice.json 2> gpurun_out/r1b/venice.log
 RBA_EXPLICIT_AFTER=0 python bench.py --cpu-baseline-iters 0 > gpurun_out/r1b/venice_matrix_free.json 2> gpurun_out/r1b/venice_matrix_free.log
-python bench.py --implicit-q --cpu-baseline-iters 0 > gpurun_out/r1b/venice_implicit.json 2> gpurun_out/r1b/venice_implicit.log
+python bench.py --dense-blocks --cpu-baseline-iters 0 > gpurun_out/r1b/venice_dense.json 2> gpurun_out/r1b/venice_dense.log
+RBA_EXPLICIT_AFTER=0 python bench.py --dense-blocks --cpu-baseline-iters 0 > gpurun_out/r1b/venice_dense_matrix_free.json 2> gpurun_out/r1b/venice_dense_matrix_free.log
 python bench.py --solver-type SCHUR_COMPLEMENT --cpu-baseline-iters 0 > gpurun_out/r1b/venice_sc.json 2> gpurun_out/r1b/venice_sc.log
 python bench.py --workload trafalgar-257 > gpurun_out/r1b/trafalgar.json 2> gpurun_out/r1b/trafalgar.log
 cd /tmp && export TMPDIR=/tmp

@@ -100,10 +100,11 @@ def test_compute_error(small_problem, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("which", ["small", "mixed"])
-def test_linearization_stage2_operator_backsub(small_problem, mixed_k_problem, dtype, which):
+@pytest.mark.parametrize("implicit_q", [1, 0])  # products from the QR factors (default) / dense blocks
+def test_linearization_stage2_operator_backsub(small_problem, mixed_k_problem, dtype, which, implicit_q):
     prob = small_problem if which == "small" else mixed_k_problem
     tol = TOL[dtype]
-    g, o = _pair(prob, dtype)
+    g, o = _pair(prob, dtype, implicit_q=implicit_q)
     st, d2 = g.linearize(want_jp_diag2=True)
     assert st == 0 and o.linearize() == 0
     assert rel_err(g.pose_scaling(), o.pose_scaling()) < tol
@@ -137,9 +138,10 @@ def test_linearization_stage2_operator_backsub(small_problem, mixed_k_problem, d
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("precond", [0, 1])
-def test_solve_and_apply(small_problem, dtype, precond):
+@pytest.mark.parametrize("implicit_q", [1, 0])
+def test_solve_and_apply(small_problem, dtype, precond, implicit_q):
     tol = TOL[dtype]
-    g, o = _pair(small_problem, dtype, preconditioner_type=precond)
+    g, o = _pair(small_problem, dtype, preconditioner_type=precond, implicit_q=implicit_q)
     assert g.linearize() == 0 and o.linearize() == 0
     ig, cg = g.solve(1e-4)
     io, co = o.solve(1e-4)
@@ -244,7 +246,8 @@ def ladybug_far():
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_lm_trajectory_matches_oracle(ladybug_far, dtype):
+@pytest.mark.parametrize("implicit_q", [1, 0])
+def test_lm_trajectory_matches_oracle(ladybug_far, dtype, implicit_q):
     """Whole LM runs: same accept/reject decisions, CG iteration counts and costs
     while the steps are large, and the SAME FINAL COST within 1e-6 relative
     (north_star). Both sides run a fixed 12 iterations (function_tolerance = 0):
@@ -253,7 +256,7 @@ def test_lm_trajectory_matches_oracle(ladybug_far, dtype):
     different summation orders drift apart at the 1e-3 level in the late, tiny
     increments (truncated CG, eta = 0.1); increments are therefore compared in
     lock-step in the next test."""
-    g, o = _pair(ladybug_far, dtype, max_num_iterations=12, function_tolerance=0.0)
+    g, o = _pair(ladybug_far, dtype, max_num_iterations=12, function_tolerance=0.0, implicit_q=implicit_q)
     lg, tg = g.optimize_lm()
     lo, to = o.optimize_lm()
     for a, b in zip(lg[:5], lo[:5]):
@@ -439,15 +442,20 @@ def test_numerical_failure_is_reported_not_fatal(small_problem):
 # ---------------------------------------------------------------------------
 # BASELINE.json's full size: size-independent properties on venice-1778
 # ---------------------------------------------------------------------------
-def test_full_size_venice_properties():
+@pytest.mark.parametrize("implicit_q", [1, 0])
+def test_full_size_venice_properties(implicit_q):
     import torch  # noqa: F401
     from rootba_amd import _lib as L
     from rootba_amd import problem as P
     from rootba_amd.linearizor import LinearizorHIP
     prob = P.preprocess(P.named_synthetic("venice-1778"), translation_sigma=0.5, point_sigma=0.5)
-    g = LinearizorHIP(prob, np.float32, _opts(L, max_num_iterations=3))
+    g = LinearizorHIP(prob, np.float32, _opts(L, max_num_iterations=3, implicit_q=implicit_q))
     stats = g.problem_stats()
-    assert stats == {k: prob.block_stats()[k] for k in stats}
+    want = {k: prob.block_stats()[k] for k in stats}
+    if implicit_q:  # s * sum_l (2k (9 + 3) + 3 (2k + 3) + 12) + camera indices + x and y
+        k = prob.obs_per_lm().astype(np.int64)
+        want["hx_bytes"] = int(4 * (2 * k * 12 + 3 * (2 * k + 3) + 12).sum() + 4 * prob.n_obs + 4 * 18 * prob.n_cams)
+    assert stats == want
     e0 = g.compute_error()
     assert e0.all_num_obs == prob.n_obs and e0.is_numerically_valid
     c0, l0 = g.get_state()
@@ -556,12 +564,14 @@ def test_schur_complement_unsupported_combinations(small_problem):
 # ---- explicit reduced matrix of the square-root solver (rba_options.explicit_after) -------------
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("which", ["small", "mixed", "long"])
-def test_explicit_reduced_matrix_is_the_same_operator(small_problem, mixed_k_problem, long_track_problem, dtype, which):
+@pytest.mark.parametrize("implicit_q", [1, 0])
+def test_explicit_reduced_matrix_is_the_same_operator(small_problem, mixed_k_problem, long_track_problem, dtype, which,
+                                                      implicit_q):
     """S = sum_l A_l^T A_l assembled block-wise (off-diagonal blocks from the damped top rows,
     diagonal blocks from stage 2) applies like the matrix-free product and like the oracle."""
     prob = {"small": small_problem, "mixed": mixed_k_problem, "long": long_track_problem}[which]
     tol = TOL[dtype]
-    g, o = _pair(prob, dtype)
+    g, o = _pair(prob, dtype, implicit_q=implicit_q)
     assert g.linearize() == 0 and o.linearize() == 0
     rng = np.random.default_rng(3)
     for lam in (LAMBDA, 1e-6):
