@@ -1510,7 +1510,7 @@ class Solver final : public rba_solver {
   }
   void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) override {
     *storage = storage_bytes_;
-    *hx_bytes = opt_.implicit_q ? hx_implicit_bytes_ : hx_bytes_;
+    *hx_bytes = (opt_.implicit_q && !sc_) ? hx_implicit_bytes_ : hx_bytes_;
     *hx_flops = hx_flops_;
   }
 
