@@ -84,7 +84,9 @@ typedef struct rba_options {
                                      explicit block-sparse reduced camera matrix + SpMV)        */
   int explicit_after;             /* square-root solver with SCHUR_JACOBI: after this many matrix-free
                                      products a PCG solve assembles S = sum_l A_l^T A_l explicitly
-                                     (block-CSR) and continues with S x; 0 = never. Default 6. */
+                                     (block-CSR) and continues with S x; 0 = never; -1 (default) = 6 for
+                                     the first long solve, then the measured break-even
+                                     (assembly time / product time, clamped to 2..32)           */
 } rba_options;
 
 /* ResidualInfo (src/rootba/bal/residual_info.hpp:57-96), sums in double */

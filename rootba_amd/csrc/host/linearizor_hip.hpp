@@ -65,7 +65,7 @@ struct SolverOptions {
   double initial_vee = 2.0;
   double vee_factor = 2.0;
   bool implicit_q = true;   // not in the reference: matrix-free products from the QR factors (false: dense blocks)
-  int explicit_after = 6;   // not in the reference: rba_options.explicit_after
+  int explicit_after = -1;  // not in the reference: rba_options.explicit_after (-1 = measured break-even)
   bool use_projection_validity_check() const { return optimized_cost != OptimizedCost::ERROR; }
 
   rba_options to_rba() const {

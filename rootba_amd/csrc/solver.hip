@@ -377,6 +377,10 @@ class Solver final : public rba_solver {
     // square-root solver: explicit reduced matrix for long PCG solves (see pcg())
     explicit_after_ = opt_.explicit_after;
     if (const char* ev = std::getenv("RBA_EXPLICIT_AFTER")) explicit_after_ = std::atoi(ev);
+    if (explicit_after_ < 0) {  // auto: start with 6, then the measured break-even (see solve())
+      explicit_auto_ = true;
+      explicit_after_ = 6;
+    }
     // (needs the SCHUR_JACOBI blocks of stage 2 as its diagonal; the dense n_c x n_c host tables used
     //  to build the structure bound the camera count: 20000 cameras = 0.4 GB of marks + 1.6 GB transient)
     if (!sc_ && opt_.preconditioner_type == 1 && explicit_after_ > 0 && n_cams_ <= 20000) {
@@ -435,6 +439,9 @@ class Solver final : public rba_solver {
     d_partials_.zero(stream_);
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 4096));
     HIP_CHECK(hipEventCreate(&ev_a_));
+    HIP_CHECK(hipEventCreate(&ev_asm0_));
+    HIP_CHECK(hipEventCreate(&ev_asm1_));
+    d_scratch_int_.alloc(1);
     HIP_CHECK(hipEventCreate(&ev_b_));
     hx_events_.resize(2 * kMaxHxEvents);
     hx_event_call_.resize(kMaxHxEvents);
@@ -617,6 +624,8 @@ class Solver final : public rba_solver {
 
   // S = sum_l A_l^T A_l of the CURRENT damped blocks (valid until the next stage 2)
   void assemble_explicit() {
+    const bool measure = explicit_auto_ && !asm_measured_ && !asm_pending_;
+    if (measure) HIP_CHECK(hipEventRecord(ev_asm0_, stream_));
     if (comm_ || cb_fn_) d_ex_vals_.zero(stream_);  // sharded: blocks without local pairs must be 0
     const int64_t n27 = 27 * int64_t(n_obs_);
     hipLaunchKernelGGL((rba::k_topd_transpose<S>), dim3(unsigned((n27 + 255) / 256)), dim3(256), 0, stream_,
@@ -629,6 +638,10 @@ class Solver final : public rba_solver {
     // (the diagonal blocks were all-reduced by stage 2 already)
     hipLaunchKernelGGL((rba::k_ex_set_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
                        prm_.blocks, d_ex_diag_.get(), d_ex_vals_.get(), pose_damping_, n_cams_);
+    if (measure) {
+      HIP_CHECK(hipEventRecord(ev_asm1_, stream_));
+      asm_pending_ = true;
+    }
     ex_valid_ = true;
   }
 
@@ -740,6 +753,8 @@ class Solver final : public rba_solver {
     if (comm_ && g_rccl.CommDestroy) g_rccl.CommDestroy(comm_);
     for (auto& e : hx_events_) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ev_a_);
+    (void)hipEventDestroy(ev_asm0_);
+    (void)hipEventDestroy(ev_asm1_);
     (void)hipEventDestroy(ev_b_);
     if (h_pinned_) (void)hipHostFree(h_pinned_);
     (void)hipEventDestroy(ev_fork_);
@@ -1142,6 +1157,27 @@ class Solver final : public rba_solver {
     }
     timings_.hx_time = hx_ms * 1e-3;  // sum over the TIMED products
     timings_.hx_calls = timed;
+    if (asm_pending_ && timed > 0) {
+      // break-even of the switch (ski rental): as many matrix-free products as one assembly costs.
+      // Identical on all ranks? No - timings differ, so rank 0's value is broadcast (max is enough:
+      // every rank must switch in the same iteration).
+      float asm_ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&asm_ms, ev_asm0_, ev_asm1_));
+      int t = int(std::lround(double(asm_ms) / (hx_ms / timed)));
+      t = std::max(2, std::min(32, t));
+      if (comm_ || cb_fn_) {
+        d_scratch_int_.upload(&t, 1, stream_);
+        all_reduce(d_scratch_int_.get(), 1, kNcclMax);
+        d_scratch_int_.download(&t, 1, stream_);
+        sync();
+      }
+      if (std::getenv("RBA_VERBOSE"))
+        std::fprintf(stderr, "[rootba_hip] assembly %.3f ms, matrix-free product %.3f ms -> explicit_after = %d\n",
+                     double(asm_ms), hx_ms / timed, t);
+      explicit_after_ = t;
+      asm_pending_ = false;
+      asm_measured_ = true;
+    }
     if (cg_out) *cg_out = cg;
     return RBA_OK;
   }
@@ -1593,6 +1629,9 @@ class Solver final : public rba_solver {
   // explicit reduced matrix of the square-root solver (adaptive, see pcg())
   int explicit_after_ = 0;  // matrix-free products before a solve switches to S x; 0 = never
   bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;
+  bool explicit_auto_ = false, asm_measured_ = false, asm_pending_ = false;
+  hipEvent_t ev_asm0_ = nullptr, ev_asm1_ = nullptr;
+  DevBuf<int> d_scratch_int_;
   int ex_nnz_ = 0, ex_n_upper_ = 0;
   std::vector<uint8_t> pair_mark_;
   rba::ScParams<S> exp_{};
@@ -1674,7 +1713,7 @@ void rba_default_options(rba_options* o) {
   o->staged_execution = 1;
   o->implicit_q = 1;
   o->solver_type = 0;
-  o->explicit_after = 6;
+  o->explicit_after = -1;
 }
 
 const char* rba_last_error(void) { return g_last_error.c_str(); }
