@@ -1805,7 +1805,11 @@ __global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ in
 //  as expensive as the ~5.6 us kernel boundary it replaces — so the simpler form stays.
 //  Likewise measured and dropped: the termination test in the last-arriving workgroup of
 //  k_pcg_b2 (threadfence + atomic counter) and k_pcg_b1 folded into the SpMV: slower, for
-//  the same reason; operand loads hoisted above the `done` test: +1 %, not worth the code.)
+//  the same reason; operand loads hoisted above the `done` test: +1 %, not worth the code;
+//  all vector work of an iteration in ONE 1024-thread workgroup (no grid synchronisation at
+//  all): 50 us instead of 5 x 4.8 us — a single CU cannot stream 0.9 MB of vectors and
+//  preconditioner blocks fast enough; only b1 + b2 + the termination test in one workgroup:
+//  still 10 us per iteration slower.)
 // All scalars stay on the device in `CgState` (double, as in the reference);
 // kernels are no-ops once `done`; the host only polls the state. Every reduction
 // has a fixed order, so all ranks of a multi-GPU run compute bit-identical
