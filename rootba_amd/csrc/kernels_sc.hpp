@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_sc_damp_and_extract_diag(ScParams<S> p,
 template <class S>
 __global__ __launch_bounds__(256) void k_sc_spmv(ScParams<S> p, const S* __restrict__ x, S* __restrict__ y,
                                                  const int* __restrict__ done_flag) {
-  __shared__ double sm4[4];
+  __shared__ double part[4][9];
   if (done_flag && *done_flag) return;
   const int c = blockIdx.x;
   const int s0 = p.row_ptr[c], s1 = p.row_ptr[c + 1];
@@ -344,11 +344,17 @@ __global__ __launch_bounds__(256) void k_sc_spmv(ScParams<S> p, const S* __restr
 #pragma unroll
     for (int q = 0; q < 9; ++q) acc[q] += (q == a) ? prod : S(0);
   }
+  // nine row sums: wave reductions, then one barrier and a fixed-order sum over the four waves
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
-    const double t = block_sum_256(double(acc[q]), sm4);
-    if (threadIdx.x == 0) y[9 * c + q] = S(t);
+    const double t = wave_sum(double(acc[q]));
+    if (lane == 0) part[wave][q] = t;
   }
+  __syncthreads();
+  if (threadIdx.x < 9)
+    y[9 * c + threadIdx.x] =
+        S((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
 // ---- back-substitution (landmark_block.hpp:409-446), one thread per landmark -----
