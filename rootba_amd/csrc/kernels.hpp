@@ -1531,11 +1531,7 @@ __device__ __forceinline__ void hx_small_body(const Params<S>& p, const SmallBat
       S acc = S(0);
 #pragma unroll
       for (int i = 0; i < NR; ++i) acc += col[i * NC] * tv[i];
-#ifdef RBA_EXPERIMENT_NO_ATOMIC
-      y[yidx[e]] = acc;
-#else
       atomic_add(y + yidx[e], acc);
-#endif
     }
     __syncthreads();
   }
