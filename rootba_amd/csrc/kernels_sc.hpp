@@ -487,6 +487,59 @@ __global__ __launch_bounds__(256) void k_ex_offdiag(const S* __restrict__ topdT,
   if (has1) outT[9 * b1 + a1] = acc1;
 }
 
+// float version on the matrix cores: the block is the GEMM  - [T_1 T_2 ...] [W_1 W_2 ...]^T
+// (9 x 3P)(3P x 9) over the P pairs of its list. v_mfma_f32_16x16x4_f32 consumes 4 of the 3P
+// inner indices per instruction with ONE 4-byte gather per lane and operand, i.e. 6 vector
+// memory instructions per 4 pairs instead of 16 — the kernel is bound by the number of
+// memory instructions (address processing of 64-lane gathers), not by bytes or flops.
+// Reads the damped top rows in their native [obs][3][9] layout (single-float gathers, the nine
+// components of a factor column are contiguous).
+__global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const float* __restrict__ topd, float* __restrict__ vals,
+                                                         const int* __restrict__ upper_slot,
+                                                         const int* __restrict__ mirror_slot,
+                                                         const int64_t* __restrict__ pair_ptr,
+                                                         const int* __restrict__ pair_oi,
+                                                         const int* __restrict__ pair_oj) {
+  __shared__ float tile[4][16][16];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = blockIdx.x;
+  const int i = lane & 15, kk = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
+  for (int64_t q = q0 + wave * 4; q < q1; q += 16) {
+    int oi[4], oj[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = q + r < q1;
+      oi[r] = ok ? pair_oi[q + r] : -1;
+      oj[r] = ok ? pair_oj[q + r] : -1;
+    }
+    float av[3], bv[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int g = 4 * m + kk;          // inner index 0..11 = (pair, factor column)
+      const int pp = g / 3, c = g - 3 * pp;
+      const int o_i = pp == 0 ? oi[0] : pp == 1 ? oi[1] : pp == 2 ? oi[2] : oi[3];
+      const int o_j = pp == 0 ? oj[0] : pp == 1 ? oj[1] : pp == 2 ? oj[2] : oj[3];
+      const bool ok = i < 9 && o_i >= 0;
+      av[m] = ok ? topd[27 * int64_t(o_i) + 9 * c + i] : 0.f;
+      bv[m] = ok ? topd[27 * int64_t(o_j) + 9 * c + i] : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[m], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[wave][kk * 4 + r][i] = acc[r];
+  __syncthreads();
+  if (threadIdx.x < 81) {
+    const int a = threadIdx.x / 9, b = threadIdx.x - 9 * a;
+    const float v = -(((tile[0][a][b] + tile[1][a][b]) + tile[2][a][b]) + tile[3][a][b]);
+    vals[size_t(81) * upper_slot[u] + threadIdx.x] = v;
+    vals[size_t(81) * mirror_slot[u] + 9 * b + a] = v;
+  }
+}
+
 // diagonal blocks: stage 2 already holds them (+ lambda I) as the SCHUR_JACOBI
 // preconditioner input, summed camera-major on the matrix cores and all-reduced
 template <class S>

@@ -604,7 +604,7 @@ class Solver final : public rba_solver {
     d_ex_pair_oi_.alloc(n_pairs);
     d_ex_pair_oj_.alloc(n_pairs);
     d_ex_vals_.alloc(size_t(81) * nnz);
-    d_ex_topdT_.alloc(27 * size_t(n_obs_));
+    d_ex_topdT_.alloc(sizeof(S) == 8 ? 27 * size_t(n_obs_) : 0);
     d_ex_rowptr_.upload(row_ptr.data(), row_ptr.size(), stream_);
     d_ex_cols_.upload(cols.data(), cols.size(), stream_);
     d_ex_diag_.upload(diag.data(), diag.size(), stream_);
@@ -627,13 +627,7 @@ class Solver final : public rba_solver {
     const bool measure = explicit_auto_ && !asm_measured_ && !asm_pending_;
     if (measure) HIP_CHECK(hipEventRecord(ev_asm0_, stream_));
     if (comm_ || cb_fn_) d_ex_vals_.zero(stream_);  // sharded: blocks without local pairs must be 0
-    const int64_t n27 = 27 * int64_t(n_obs_);
-    hipLaunchKernelGGL((rba::k_topd_transpose<S>), dim3(unsigned((n27 + 255) / 256)), dim3(256), 0, stream_,
-                       prm_.topd, d_ex_topdT_.get(), n27);
-    if (ex_n_upper_ > 0)
-      hipLaunchKernelGGL((rba::k_ex_offdiag<S>), dim3(ex_n_upper_), dim3(256), 0, stream_, d_ex_topdT_.get(),
-                         d_ex_vals_.get(), d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(),
-                         d_ex_pair_oi_.get(), d_ex_pair_oj_.get());
+    if (ex_n_upper_ > 0) launch_offdiag(prm_.topd, d_ex_vals_.get());
     all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
     // (the diagonal blocks were all-reduced by stage 2 already)
     hipLaunchKernelGGL((rba::k_ex_set_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
@@ -1043,6 +1037,22 @@ class Solver final : public rba_solver {
     if (two_streams) HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
     if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
     ++hx_calls_;
+  }
+
+  // off-diagonal blocks of the explicit reduced matrix: matrix cores for float, VALU for double
+  void launch_offdiag(const float* topd, float* vals) {
+    hipLaunchKernelGGL((rba::k_ex_offdiag_mfma), dim3(ex_n_upper_), dim3(256), 0, stream_, topd, vals,
+                       d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(), d_ex_pair_oi_.get(),
+                       d_ex_pair_oj_.get());
+  }
+  void launch_offdiag(const double* topd, double* vals) {
+    // the VALU version takes its factors as 12-byte loads from a [obs][9][3] copy
+    const int64_t n27 = 27 * int64_t(n_obs_);
+    hipLaunchKernelGGL((rba::k_topd_transpose<double>), dim3(unsigned((n27 + 255) / 256)), dim3(256), 0, stream_,
+                       topd, d_ex_topdT_.get(), n27);
+    hipLaunchKernelGGL((rba::k_ex_offdiag<double>), dim3(ex_n_upper_), dim3(256), 0, stream_, d_ex_topdT_.get(), vals,
+                       d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(), d_ex_pair_oi_.get(),
+                       d_ex_pair_oj_.get());
   }
 
   // camera-major 9x9 contractions: matrix cores for float, VALU (double accumulators) for double
