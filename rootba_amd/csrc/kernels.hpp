@@ -18,6 +18,8 @@
 // parts. See DESIGN.md for bytes per kernel.
 #pragma once
 
+#include <type_traits>
+
 #include "device_utils.hpp"
 
 namespace rba {
@@ -61,7 +63,7 @@ struct Params {
   S* JlS;       // [n_obs][2][3]  sqrt(w) Jl D_l before the QR (back-substitution)
   S* rS;        // [n_obs][2]     sqrt(w) r
   S* bsO;       // [n_obs][5]     back-substitution scratch: topd x (3), Jp x (2)
-  S* givens;    // [n_lms][12]    the 6 damping rotations of stage 2: c[6], s[6]
+  S* givens;    // [n_lms][16]    the 6 damping rotations of stage 2: c[6], s[6], damping-row residual[3], pad
   S* bdO;       // [n_obs][9]     damping rows' part of b per observation
   S* R0;        // [6 n_lms]
   S* Rd;        // [6 n_lms]
@@ -1008,10 +1010,18 @@ __global__ __launch_bounds__(256) void k_stage2_landmark(Params<S> p, S lambda) 
       }
     }
   }
+  {
+    // one 64-byte record per landmark for the column pass: c[6], s[6], damping-row residual[3]
+    S* grec = p.givens + 16 * size_t(s);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    p.givens[12 * size_t(s) + i] = gc[i];
-    p.givens[12 * size_t(s) + 6 + i] = gs[i];
+    for (int i = 0; i < 6; ++i) {
+      grec[i] = gc[i];
+      grec[6 + i] = gs[i];
+    }
+    grec[12] = D[0][3];
+    grec[13] = D[1][3];
+    grec[14] = D[2][3];
+    grec[15] = S(0);
   }
   S* R = p.Rd + 6 * s;
   R[0] = T[0][0];
@@ -1069,7 +1079,21 @@ __global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t n_obs)
   const int64_t o = t / 9;
   const int comp = int(t - 9 * o);
   const int s = p.obs_lm[o];
-  const S* __restrict__ g = p.givens + 12 * size_t(s);
+  // the landmark's record as four 16-byte loads (the pass is bound by the number of vector
+  // memory instructions, not by bytes)
+  S g[16];
+  {
+    using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+    const V4* __restrict__ src = reinterpret_cast<const V4*>(p.givens + 16 * size_t(s));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const V4 v = src[q];
+      g[4 * q] = v.x;
+      g[4 * q + 1] = v.y;
+      g[4 * q + 2] = v.z;
+      g[4 * q + 3] = v.w;
+    }
+  }
   const S* __restrict__ T0 = p.top0 + 27 * o;
   S tt[3] = {T0[comp], T0[9 + comp], T0[18 + comp]}, d[3] = {S(0), S(0), S(0)};
   {
@@ -1095,8 +1119,7 @@ __global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t n_obs)
   DO[9 + comp] = d[1];
   DO[18 + comp] = d[2];
   // the damping rows' part of b (add_Q2TJp_T_Q2Tr on rows 2k-3..2k-1), summed camera-major later
-  const S* __restrict__ dr = p.damp_r + 3 * size_t(s);
-  p.bdO[9 * o + comp] = d[0] * dr[0] + d[1] * dr[1] + d[2] * dr[2];
+  p.bdO[9 * o + comp] = d[0] * g[12] + d[1] * g[13] + d[2] * g[14];
   const int k = p.lm_k[s];
   if (p.implicit && k <= 112) return;  // dense block unused (only the k > 112 kernels read it)
   const int nrows = 2 * k, ncols = 9 * k;

@@ -369,7 +369,7 @@ class Solver final : public rba_solver {
     d_JlS_.alloc(6 * qr_obs);
     d_rS_.alloc(2 * qr_obs);
     d_bsO_.alloc(5 * qr_obs);
-    d_givens_.alloc(sc_ ? 0 : 12 * size_t(n_lms));
+    d_givens_.alloc(sc_ ? 0 : 16 * size_t(n_lms));
     d_bdO_.alloc(9 * qr_obs);
     d_bmO_.alloc(9 * qr_obs);
     d_Vh_.alloc(8 * qr_obs);
