@@ -44,7 +44,6 @@ struct Params {
   S* A;
   S* top0;      // [n_obs][3][9] Q1^T Jp, undamped (observation-major)
   S* topd;      // [n_obs][3][9] with landmark damping
-  S* dampO;     // [n_obs][3][9] copy of the damping rows (observation-major)
   S* JpS;       // [n_obs][2][9] weighted, column-scaled pose Jacobian
   S* bmO;       // [n_obs][9]    per-observation part of b from the Q2 rows
   // implicit-Q operator (k_hx_implicit): the factors instead of the product
@@ -209,10 +208,9 @@ __global__ __launch_bounds__(256) void k_cam_jp_diag2(Params<S> p) {
 
 // Stage 1, camera-major part: damping-independent terms of the preconditioner
 // and of the gradient,
-//   B_mid[c] = sum_obs ( JpS^T JpS - top0^T top0 )   (== sum over the Q2 rows of
-//              (Q2^T Jp)_c^T (Q2^T Jp)_c, because Q is orthogonal;
-//              add_Q2TJp_T_Q2TJp_blockdiag ipp:520-552 without the damping rows;
-//              JACOBI: JpS^T JpS only, add_Jp_T_Jp_blockdiag ipp:554-569)
+//   B_mid[c] = sum_obs JpS^T JpS    (H_pp diagonal block; JACOBI: add_Jp_T_Jp_blockdiag
+//              ipp:554-569. SCHUR_JACOBI subtracts the Gram matrix of the damped top rows in
+//              stage 2: add_Q2TJp_T_Q2TJp_blockdiag ipp:520-552 through orthogonality)
 //   b_mid[c] = sum_obs bmO                           (add_Q2TJp_T_Q2Tr ipp:443-466)
 // Threads 0..242: 3 observation groups x 81 block entries; 243..251: b.
 // ---------------------------------------------------------------------------
@@ -283,19 +281,15 @@ __device__ __forceinline__ double cam_sum9(const int* __restrict__ cam_obs, int6
 
 // float: matrix-core version
 __global__ __launch_bounds__(256) void k_cam_stage1_mfma(Params<float> p) {
-  __shared__ float tile[2][4][16][16];
+  __shared__ float tile[4][16][16];
   __shared__ double bsum[28][9];
   const int c = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  f32x4 accJ = {0.f, 0.f, 0.f, 0.f}, accT = {0.f, 0.f, 0.f, 0.f};
+  f32x4 accJ = {0.f, 0.f, 0.f, 0.f};
   accJ = mfma_xtx<2>(p.JpS, 18, p.cam_obs, t0, t1, wave, lane, accJ);
-  if (!p.jacobi) accT = mfma_xtx<3>(p.top0, 27, p.cam_obs, t0, t1, wave, lane, accT);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    tile[0][wave][(lane >> 4) * 4 + r][lane & 15] = accJ[r];
-    tile[1][wave][(lane >> 4) * 4 + r][lane & 15] = accT[r];
-  }
+  for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = accJ[r];
   // b_mid: 28 groups x 9 components on the VALU, double
   if (tid < 252) {
     const int g = tid / 9, a = tid - 9 * g;
@@ -306,7 +300,7 @@ __global__ __launch_bounds__(256) void k_cam_stage1_mfma(Params<float> p) {
     const int i = tid / 9, j = tid - 9 * i;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += tile[0][w][i][j] - tile[1][w][i][j];
+    for (int w = 0; w < 4; ++w) v += tile[w][i][j];
     p.B_mid[81 * c + tid] = v;
   }
   if (tid >= 128 && tid < 137) {
@@ -325,7 +319,7 @@ __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float 
   const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const bool damped = lambda != 0.f;
-  if (damped && !p.jacobi) acc = mfma_xtx<3>(p.dampO, 27, p.cam_obs, t0, t1, wave, lane, acc);
+  if (!p.jacobi) acc = mfma_xtx<3>(p.topd, 27, p.cam_obs, t0, t1, wave, lane, acc);
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
   if (tid < 252) {
@@ -337,10 +331,10 @@ __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float 
   __syncthreads();
   if (tid < 81) {
     const int i = tid / 9, j = tid - 9 * i;
-    float v = p.B_mid[81 * c + tid] + (i == j ? lambda : 0.f);
+    float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += tile[w][i][j];
-    p.blocks[81 * c + tid] = v;
+    for (int w = 0; w < 4; ++w) t += tile[w][i][j];
+    p.blocks[81 * c + tid] = (p.B_mid[81 * c + tid] - t) + (i == j ? lambda : 0.f);
   }
   if (tid >= 128 && tid < 137) {
     const int a = tid - 128;
@@ -352,8 +346,8 @@ __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float 
 
 template <class S>
 __global__ __launch_bounds__(256) void k_cam_stage1(Params<S> p) {
-  constexpr int TILE = 64, W = 54, NLD = (TILE * W + 255) / 256;
-  __shared__ S rec[TILE][W];  // [JpS 18 | top0 27 | bmO 9]
+  constexpr int TILE = 64, W = 27, NLD = (TILE * W + 255) / 256;
+  __shared__ S rec[TILE][W];  // [JpS 18 | bmO 9]
   __shared__ int olist[TILE];
   __shared__ double red[3][81];
   const int c = blockIdx.x;
@@ -375,7 +369,7 @@ __global__ __launch_bounds__(256) void k_cam_stage1(Params<S> p) {
       if (idx < n * W) {
         const int q = idx / W, f = idx - W * q;
         const int64_t o = olist[q];
-        v[u] = f < 18 ? p.JpS[o * 18 + f] : (f < 45 ? p.top0[o * 27 + (f - 18)] : p.bmO[o * 9 + (f - 45)]);
+        v[u] = f < 18 ? p.JpS[o * 18 + f] : p.bmO[o * 9 + (f - 18)];
       }
     }
 #pragma unroll
@@ -387,14 +381,11 @@ __global__ __launch_bounds__(256) void k_cam_stage1(Params<S> p) {
     if (grp < 3) {
       for (int q = grp; q < n; q += 3) {
         const S* r = rec[q];
-        S t = r[ea] * r[eb] + r[9 + ea] * r[9 + eb];
-        if (!p.jacobi)
-          t -= r[18 + ea] * r[18 + eb] + r[27 + ea] * r[27 + eb] + r[36 + ea] * r[36 + eb];
-        acc += double(t);
+        acc += double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb]);
       }
     } else if (tid < 252) {
       const int a = tid - 243;
-      for (int q = 0; q < n; ++q) acc += double(rec[q][45 + a]);
+      for (int q = 0; q < n; ++q) acc += double(rec[q][18 + a]);
     }
   }
   if (grp < 3) red[grp][e] = acc;
@@ -404,31 +395,29 @@ __global__ __launch_bounds__(256) void k_cam_stage1(Params<S> p) {
 }
 
 // Stage 2, camera-major part:
-//   blocks[c] = B_mid[c] + lambda I + sum_obs dampO^T dampO
-//   b[c]      = b_mid[c] + sum_obs dampO^T damp_r[landmark]
+//   blocks[c] = B_mid[c] - sum_obs topd^T topd + lambda I      (B_mid = sum_obs Jp^T Jp)
+//   b[c]      = b_mid[c] + sum_obs bdO        (bdO = damping rows^T damping-row residual)
+// With Q orthogonal for the damped system, sum over the kept rows of A^T A equals
+// Jp^T Jp minus the Gram matrix of the (damped) top rows.
 // (last three rows of add_Q2TJp_T_Q2TJp_blockdiag / add_Q2TJp_T_Q2Tr; pose
 //  damping on the preconditioner: linearization_qr.hpp:796-802, JACOBI:
 //  linearizor_qr.cpp:227-232)
 template <class S>
 __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
-  constexpr int TILE = 64, W = 30, NLD = (TILE * W + 255) / 256;
-  __shared__ S rec[TILE][W];  // [dampO 27 | damp_r 3]
-  __shared__ int olist[TILE], llist[TILE];
+  constexpr int TILE = 64, W = 36, NLD = (TILE * W + 255) / 256;
+  __shared__ S rec[TILE][W];  // [topd 27 | bdO 9]
+  __shared__ int olist[TILE];
   __shared__ double red[3][81];
   const int c = blockIdx.x;
   const int tid = threadIdx.x;
   const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
   double acc = 0;
-  if (lambda != S(0)) {
+  {
     const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
     for (int64_t base = t0; base < t1; base += TILE) {
       const int n = int(min<int64_t>(TILE, t1 - base));
       __syncthreads();
-      if (tid < n) {
-        const int o = p.cam_obs[base + tid];
-        olist[tid] = o;
-        llist[tid] = p.obs_lm[o];
-      }
+      if (tid < n) olist[tid] = p.cam_obs[base + tid];
       __syncthreads();
       S v[NLD];
 #pragma unroll
@@ -437,7 +426,7 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
         v[u] = S(0);
         if (idx < n * W) {
           const int q = idx / W, f = idx - W * q;
-          v[u] = f < 27 ? p.dampO[int64_t(olist[q]) * 27 + f] : p.damp_r[3 * int64_t(llist[q]) + (f - 27)];
+          v[u] = f < 27 ? p.topd[int64_t(olist[q]) * 27 + f] : p.bdO[int64_t(olist[q]) * 9 + (f - 27)];
         }
       }
 #pragma unroll
@@ -450,15 +439,13 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
         if (!p.jacobi) {
           for (int q = grp; q < n; q += 3) {
             const S* r = rec[q];
-            acc += double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb] + r[18 + ea] * r[18 + eb]);
+            acc -= double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb] + r[18 + ea] * r[18 + eb]);
           }
         }
       } else if (tid < 252) {
         const int a = tid - 243;
-        for (int q = 0; q < n; ++q) {
-          const S* r = rec[q];
-          acc += double(r[a] * r[27] + r[9 + a] * r[28] + r[18 + a] * r[29]);
-        }
+        if (lambda != S(0))
+          for (int q = 0; q < n; ++q) acc += double(rec[q][27 + a]);
       }
     }
   }
@@ -960,7 +947,7 @@ __global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm
 //   k_stage2_landmark  one thread per landmark: the 6 rotations from R0, damped R / Q1^T r,
 //                      damping-row residual, Z for the implicit-Q operator
 //   k_stage2_cols      one thread per (observation, pose component): rotates the stored top0
-//                      column into topd / dampO and the three damping rows of the dense block
+//                      column into topd, the three damping rows of the dense block and their part of b
 // ===========================================================================
 template <class S>
 __global__ __launch_bounds__(256) void k_stage2_landmark(Params<S> p, S lambda) {
@@ -1111,13 +1098,9 @@ __global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t n_obs)
     }
   }
   S* Td = p.topd + 27 * o;
-  S* DO = p.dampO + 27 * o;
   Td[comp] = tt[0];
   Td[9 + comp] = tt[1];
   Td[18 + comp] = tt[2];
-  DO[comp] = d[0];
-  DO[9 + comp] = d[1];
-  DO[18 + comp] = d[2];
   // the damping rows' part of b (add_Q2TJp_T_Q2Tr on rows 2k-3..2k-1), summed camera-major later
   p.bdO[9 * o + comp] = d[0] * g[12] + d[1] * g[13] + d[2] * g[14];
   const int k = p.lm_k[s];

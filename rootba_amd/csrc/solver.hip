@@ -364,7 +364,6 @@ class Solver final : public rba_solver {
     d_top0_.alloc(27 * qr_obs);
     d_topd_.alloc(27 * qr_obs);
     d_qtr_.alloc(2 * qr_obs);
-    d_dampO_.alloc(27 * qr_obs);
     d_JpS_.alloc(18 * size_t(n_obs_));
     d_JlS_.alloc(6 * qr_obs);
     d_rS_.alloc(2 * qr_obs);
@@ -433,7 +432,6 @@ class Solver final : public rba_solver {
     d_A_.zero(stream_);
     d_top0_.zero(stream_);
     d_topd_.zero(stream_);
-    d_dampO_.zero(stream_);
     d_pose_scaling_.zero(stream_);
     d_fail_.zero(stream_);
     d_partials_.zero(stream_);
@@ -458,7 +456,6 @@ class Solver final : public rba_solver {
     prm_.obs_xy = d_obs_xy_.get();
     prm_.cam_obs_off = d_cam_off_.get();
     prm_.cam_obs = d_cam_obs_.get();
-    prm_.dampO = d_dampO_.get();
     prm_.JpS = d_JpS_.get();
     prm_.JlS = d_JlS_.get();
     prm_.rS = d_rS_.get();
@@ -1617,7 +1614,7 @@ class Solver final : public rba_solver {
   DevBuf<int> d_lm_k_, d_obs_cam_, d_obs_lm_, d_fail_;
   DevBuf<int64_t> d_lm_obs_, d_lm_blk_, d_cam_off_;
   DevBuf<int> d_cam_obs_;
-  DevBuf<S> d_dampO_, d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_JT_, d_VT_, d_JlS_, d_rS_, d_bsO_, d_givens_, d_bdO_;
+  DevBuf<S> d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_JT_, d_VT_, d_JlS_, d_rS_, d_bsO_, d_givens_, d_bdO_;
   DevBuf<int> d_CT_, d_lm_tile_, d_lm_lane0_;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
