@@ -733,23 +733,33 @@ __global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin,
 }
 
 // ---------------------------------------------------------------------------
-// The same for the smallest landmarks (k <= 7, 2k <= 14 rows): FOUR landmarks per
-// wavefront in the geometry and Householder phases, one per 16-lane DPP row, so that the
-// reductions are row-local (4 DPP steps) and the ~800 instructions of those phases are
+// The same for small landmarks: k <= 7 (2k <= 14 rows): FOUR landmarks per wavefront in the
+// geometry and Householder phases, one per 16-lane DPP row, so that the reductions are
+// row-local (4 DPP steps); k <= 14: TWO landmarks, 32 lanes each (one more step); and the ~800 instructions of those phases are
 // shared by four landmarks; the column phase then runs once per landmark as above.
 // (One wavefront per 2-3 observation landmark executes at 5-20 % lane utilisation.)
 // ---------------------------------------------------------------------------
-template <class S>
+// sum over an aligned group of SEG lanes (16: one DPP row; 32: two rows)
+template <class S, int SEG>
+__device__ __forceinline__ S seg_row_sum(S v) {
+  v = row_sum(v);
+  if (SEG == 32) v += __shfl_xor(v, 16);
+  return v;
+}
+
+template <class S, int CH>
 __global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm_begin, int lm_end) {
-  using Cfg = ClassCfg<1>;
+  static_assert(CH == 1 || CH == 2, "k <= 7: four landmarks per wavefront, k <= 14: two");
+  using Cfg = ClassCfg<CH>;
+  constexpr int SEG = 16 * CH, P = 64 / SEG;  // lanes per landmark, landmarks per wavefront
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int g = lane >> 4, sl = lane & 15, row_base = lane & 48;
-  const int s_first = lm_begin + (blockIdx.x * 4 + wave) * 4;
+  const int g = lane / SEG, sl = lane & (SEG - 1), row_base = lane & ~(SEG - 1);
+  const int s_first = lm_begin + (blockIdx.x * 4 + wave) * P;
   if (s_first >= lm_end) return;  // whole wave exits; no block-level barriers below
   const int s = s_first + g;
   const bool lm_ok = s < lm_end;
-  S* JpL = reinterpret_cast<S*>(smem_raw) + size_t(wave * 4 + g) * Cfg::WAVE_LDS;
+  S* JpL = reinterpret_cast<S*>(smem_raw) + size_t(wave * P + g) * Cfg::WAVE_LDS;
   S* V = JpL + 18 * Cfg::KMAX;  // [2k][4]
 
   const int k = lm_ok ? p.lm_k[s] : 0;
@@ -794,7 +804,7 @@ __global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm
   wave_lds_fence();
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const S ss = row_sum(jl[c] * jl[c]);
+    const S ss = seg_row_sum<S, SEG>(jl[c] * jl[c]);
     const S sc = S(1) / (p.eps + sqrt(ss));
     jl[c] *= sc;
     if (sl == 0 && lm_ok) p.jl_scale[3 * s + c] = sc;
@@ -810,7 +820,7 @@ __global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
     const S c0 = __shfl(jl[m], row_base + m);
-    const S tail = row_sum((r > m && rvalid) ? jl[m] * jl[m] : S(0));
+    const S tail = seg_row_sum<S, SEG>((r > m && rvalid) ? jl[m] * jl[m] : S(0));
     S beta, inv;
     if (tail <= Eps<S>::tiny) {
       tau[m] = S(0);
@@ -825,17 +835,17 @@ __global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm
     vm[m] = (r == m) ? S(1) : ((r > m && rvalid) ? jl[m] * inv : S(0));
 #pragma unroll
     for (int c2 = m + 1; c2 < 3; ++c2) {
-      const S d = tau[m] * row_sum(vm[m] * jl[c2]);
+      const S d = tau[m] * seg_row_sum<S, SEG>(vm[m] * jl[c2]);
       jl[c2] -= d * vm[m];
     }
     {
-      const S d = tau[m] * row_sum(vm[m] * rs);
+      const S d = tau[m] * seg_row_sum<S, SEG>(vm[m] * rs);
       rs -= d * vm[m];
     }
     if (r == m) jl[m] = beta;
     if (r > m) jl[m] = S(0);
   }
-  const S g10 = row_sum(vm[1] * vm[0]), g20 = row_sum(vm[2] * vm[0]), g21 = row_sum(vm[2] * vm[1]);
+  const S g10 = seg_row_sum<S, SEG>(vm[1] * vm[0]), g20 = seg_row_sum<S, SEG>(vm[2] * vm[0]), g21 = seg_row_sum<S, SEG>(vm[2] * vm[1]);
   {
     const S r00 = __shfl(jl[0], row_base), r01 = __shfl(jl[1], row_base), r02 = __shfl(jl[2], row_base),
             r11 = __shfl(jl[1], row_base + 1), r12 = __shfl(jl[2], row_base + 1),
@@ -876,19 +886,21 @@ __global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm
   // ---- column lanes, one landmark of the wave after the other ---------------------
   const int lane9 = lane / 9, comp = lane - 9 * lane9;
 #pragma unroll
-  for (int gg = 0; gg < 4; ++gg) {
+  for (int gg = 0; gg < P; ++gg) {
     const int s2 = s_first + gg;
     if (s2 >= lm_end) break;  // wave-uniform
     const int k2 = p.lm_k[s2];
     const int64_t o2 = p.lm_obs[s2];
     const int nrows2 = 2 * k2, ncols2 = 9 * k2;
-    const S t0 = read_lane(tau[0], 16 * gg), t1 = read_lane(tau[1], 16 * gg), t2 = read_lane(tau[2], 16 * gg);
-    const S h10 = read_lane(g10, 16 * gg), h20 = read_lane(g20, 16 * gg), h21 = read_lane(g21, 16 * gg);
-    const S* JpL2 = reinterpret_cast<S*>(smem_raw) + size_t(wave * 4 + gg) * Cfg::WAVE_LDS;
+    const S t0 = read_lane(tau[0], SEG * gg), t1 = read_lane(tau[1], SEG * gg), t2 = read_lane(tau[2], SEG * gg);
+    const S h10 = read_lane(g10, SEG * gg), h20 = read_lane(g20, SEG * gg), h21 = read_lane(g21, SEG * gg);
+    const S* JpL2 = reinterpret_cast<S*>(smem_raw) + size_t(wave * P + gg) * Cfg::WAVE_LDS;
     const S* V2 = JpL2 + 18 * Cfg::KMAX;
     S* Ablk = p.A + p.lm_blk[s2];
     S* T0 = p.top0 + 27 * o2;
-    const int islot = lane9;
+#pragma unroll 1
+    for (int ch = 0; ch < CH; ++ch) {
+    const int islot = 7 * ch + lane9;
     const bool act = lane < 63 && islot < k2;
     const int i = act ? islot : 0;
     const int j = 9 * i + comp;
@@ -932,6 +944,7 @@ __global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm
         jt[1] = m1;
       }
     }
+    }  // ch
   }
 }
 

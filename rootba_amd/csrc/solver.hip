@@ -900,9 +900,12 @@ class Solver final : public rba_solver {
       for_each_class([&](auto ch_tag, int begin, int end) {
         constexpr int CH = decltype(ch_tag)::value;
         const size_t lds = 4 * size_t(rba::ClassCfg<CH>::WAVE_LDS) * sizeof(S);
-        if (CH == 1 && !qr_unpacked_)  // k <= 7: four landmarks per wavefront in the QR phases
-          hipLaunchKernelGGL((rba::k_linearize_qr_packed<S>), dim3((end - begin + 15) / 16), dim3(256),
-                             4 * lds, stream_, prm_, begin, end);
+        if (CH <= 2 && !qr_unpacked_) {
+          // k <= 7 / k <= 14: four / two landmarks per wavefront in the QR phases
+          constexpr int PCH = CH <= 2 ? CH : 1, P = 4 / PCH;
+          hipLaunchKernelGGL((rba::k_linearize_qr_packed<S, PCH>), dim3((end - begin + 4 * P - 1) / (4 * P)),
+                             dim3(256), P * lds, stream_, prm_, begin, end);
+        }
         else
           hipLaunchKernelGGL((rba::k_linearize_qr<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
                              lds, stream_, prm_, begin, end);
