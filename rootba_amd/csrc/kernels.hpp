@@ -1824,7 +1824,10 @@ __global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ in
 //  all vector work of an iteration in ONE 1024-thread workgroup (no grid synchronisation at
 //  all): 50 us instead of 5 x 4.8 us — a single CU cannot stream 0.9 MB of vectors and
 //  preconditioner blocks fast enough; only b1 + b2 + the termination test in one workgroup:
-//  still 10 us per iteration slower.)
+//  still 10 us per iteration slower; three regrouped multi-workgroup launches per iteration
+//  (direction + ping-ponged scalar state | S p with p.q | update + preconditioner per owned
+//  cameras): 48 us instead of 44 us. The iteration is a chain of ~25 dependent memory round
+//  trips through caches that every launch starts cold, not a count of launches.)
 // All scalars stay on the device in `CgState` (double, as in the reference);
 // kernels are no-ops once `done`; the host only polls the state. Every reduction
 // has a fixed order, so all ranks of a multi-GPU run compute bit-identical
