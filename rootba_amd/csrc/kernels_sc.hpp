@@ -1,5 +1,8 @@
-// kernels_sc.hpp — explicit Schur-complement backend (solver_type = SCHUR_COMPLEMENT).
+// kernels_sc.hpp — block-CSR reduced camera matrix: (1) the explicit Schur-complement backend
+// (solver_type = SCHUR_COMPLEMENT), (2) further down, the explicitly assembled matrix of the
+// SQUARE-ROOT solver for long PCG solves, and the SpMV both share.
 //
+// (1) Schur-complement backend.
 // What the reference's LinearizorSC / LinearizationSC / LandmarkBlockSC compute
 // (src/rootba/solver/linearizor_sc.cpp:70-211, src/rootba/sc/linearization_sc.hpp:55-359,
 // src/rootba/sc/landmark_block.hpp:127-446), laid out for the GPU instead of one
