@@ -38,7 +38,7 @@ struct DatasetSummary {  // reference bal_dataset_summary / BaLog::ProblemInfo
   std::string type = "bal", input_path;
   int num_cameras = 0, num_landmarks = 0;
   int64_t num_observations = 0;
-  double rcs_sparsity = 0;  // not computed here (needs the camera co-visibility graph)
+  double rcs_sparsity = 0;
   DatasetStats per_lm_obs, per_host_lms;
 };
 
@@ -67,6 +67,7 @@ DatasetSummary summarize_dataset(const BalProblem<Scalar>& p, const std::string&
   std::vector<int64_t> per_lm(p.num_landmarks()), per_cam(p.num_cameras(), 0);
   for (int l = 0; l < p.num_landmarks(); ++l) per_lm[l] = p.lm_off[l + 1] - p.lm_off[l];
   for (int32_t c : p.obs_cam) ++per_cam[c];
+  s.rcs_sparsity = p.num_cameras() <= 20000 ? p.compute_rcs_sparsity() : 0.0;  // n_c^2 byte mask
   s.per_lm_obs = stats(per_lm);
   s.per_host_lms = stats(per_cam);  // landmarks observed per camera
   return s;

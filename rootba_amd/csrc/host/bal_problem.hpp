@@ -504,6 +504,19 @@ class BalProblem {
     obs_xy.resize(size_t(2) * w_obs);
   }
 
+  // 1 - (non-zero 9x9 blocks of the reduced camera system) / n_c^2: cameras are coupled when they
+  // observe a common landmark (reference bal_problem.cpp:647-712; byte mask instead of atomics)
+  double compute_rcs_sparsity() const {
+    const size_t nc = cameras.size();
+    std::vector<uint8_t> mask(nc * nc, 0);
+    for (int l = 0; l < num_landmarks(); ++l)
+      for (int64_t i = lm_off[l]; i < lm_off[l + 1]; ++i)
+        for (int64_t j = lm_off[l]; j < i; ++j) mask[size_t(obs_cam[i]) * nc + obs_cam[j]] = 1;  // cam_j < cam_i
+    size_t lower = 0;
+    for (uint8_t m : mask) lower += m;
+    return 1.0 - double(nc + 2 * lower) / double(nc * nc);
+  }
+
   template <class S2>
   BalProblem<S2> copy_cast() const {
     BalProblem<S2> out;

@@ -60,10 +60,10 @@ int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string&
               prob.num_landmarks(), static_cast<long long>(prob.num_observations()), ds.input.c_str(), load_seconds);
   if (dry_run) {
     std::printf("{\"num_cameras\": %d, \"num_landmarks\": %d, \"num_observations\": %lld, \"load_seconds\": %.6f, "
-                "\"obs_checksum\": %.12e, "
+                "\"rcs_sparsity\": %.12e, \"obs_checksum\": %.12e, "
                 "\"landmark_sum\": [%.12e, %.12e, %.12e], \"cam0\": [%.12e, %.12e, %.12e, %.12e, %.12e, %.12e, %.12e]}\n",
                 prob.num_cameras(), prob.num_landmarks(), static_cast<long long>(prob.num_observations()), load_seconds,
-                obs_checksum, sx, sy, sz,
+                prob.compute_rcs_sparsity(), obs_checksum, sx, sy, sz,
                 double(prob.cameras[0][0]), double(prob.cameras[0][1]), double(prob.cameras[0][2]),
                 double(prob.cameras[0][3]), double(prob.cameras[0][4]), double(prob.cameras[0][5]),
                 double(prob.cameras[0][6]));

@@ -41,6 +41,14 @@ def test_cpp_loader_and_preprocessing_match_numpy_mirror(app, bal_file):
     assert ref.n_obs < raw.n_obs
     assert (info["num_cameras"], info["num_landmarks"], info["num_observations"]) == (ref.n_cams, ref.n_lms, ref.n_obs)
     assert np.allclose(info["landmark_sum"], ref.lms.sum(0), rtol=1e-9, atol=1e-6)
+    # reduced-camera-system sparsity (reference bal_problem.cpp:647-712)
+    mask = np.zeros((ref.n_cams, ref.n_cams), bool)
+    off = ref.lm_obs_offsets
+    for l in range(ref.n_lms):
+        c = ref.obs_cam_idx[off[l]:off[l + 1]]
+        mask[np.ix_(c, c)] = True
+    np.fill_diagonal(mask, True)
+    assert np.isclose(info["rcs_sparsity"], 1.0 - mask.sum() / ref.n_cams ** 2, atol=1e-12)
     q = np.array(info["cam0"][:4])
     assert np.allclose(P.quat_to_rot(q), P.quat_to_rot(ref.cams[0, :4]), atol=1e-9)
     assert np.allclose(info["cam0"][4:], ref.cams[0, 4:7], rtol=1e-9, atol=1e-7)
