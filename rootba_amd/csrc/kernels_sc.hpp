@@ -311,6 +311,67 @@ __global__ __launch_bounds__(256) void k_sc_assemble(ScParams<S> p, const int* _
   }
 }
 
+// float version on the matrix cores (see k_ex_offdiag_mfma below for the reasoning): the block
+// is  sum_pairs ( [i == j] Jp_i^T Jp_i - T_i W_j^T ),  two GEMMs over the pair list with one
+// 4-byte gather per lane and operand per v_mfma_f32_16x16x4_f32.
+__global__ __launch_bounds__(256) void k_sc_assemble_mfma(ScParams<float> p, const int* __restrict__ upper_slot,
+                                                          const int* __restrict__ mirror_slot,
+                                                          const int64_t* __restrict__ pair_ptr,
+                                                          const int* __restrict__ pair_oi,
+                                                          const int* __restrict__ pair_oj) {
+  __shared__ float tile[4][16][16];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = blockIdx.x;
+  const int i = lane & 15, kk = lane >> 4;
+  const bool diagonal = mirror_slot[u] < 0;  // every pair of a diagonal block is (o, o)
+  f32x4 accN = {0.f, 0.f, 0.f, 0.f}, accP = {0.f, 0.f, 0.f, 0.f};
+  const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
+  for (int64_t q = q0 + wave * 4; q < q1; q += 16) {
+    int oi[4], oj[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = q + r < q1;
+      oi[r] = ok ? pair_oi[q + r] : -1;
+      oj[r] = ok ? pair_oj[q + r] : -1;
+    }
+    float av[3], bv[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int g = 4 * m + kk;  // inner index 0..11 = (pair, factor column)
+      const int pp = g / 3, c = g - 3 * pp;
+      const int o_i = pp == 0 ? oi[0] : pp == 1 ? oi[1] : pp == 2 ? oi[2] : oi[3];
+      const int o_j = pp == 0 ? oj[0] : pp == 1 ? oj[1] : pp == 2 ? oj[2] : oj[3];
+      const bool ok = i < 9 && o_i >= 0;
+      av[m] = ok ? p.T[27 * int64_t(o_i) + 3 * i + c] : 0.f;
+      bv[m] = ok ? p.W[27 * int64_t(o_j) + 3 * i + c] : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) accN = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[m], accN, 0, 0, 0);
+    if (diagonal) {
+      // Jp^T Jp of the four observations: inner index = (pair, Jacobian row), two instructions
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int g = 4 * m + kk;  // 0..7
+        const int pp = g >> 1, row = g & 1;
+        const int o = pp == 0 ? oi[0] : pp == 1 ? oi[1] : pp == 2 ? oi[2] : oi[3];
+        const float v = (i < 9 && o >= 0) ? p.JpS[18 * int64_t(o) + 9 * row + i] : 0.f;
+        accP = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, accP, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[wave][kk * 4 + r][i] = accP[r] - accN[r];
+  __syncthreads();
+  if (threadIdx.x < 81) {
+    const int a = threadIdx.x / 9, b = threadIdx.x - 9 * a;
+    const float v = ((tile[0][a][b] + tile[1][a][b]) + tile[2][a][b]) + tile[3][a][b];
+    p.vals[size_t(81) * upper_slot[u] + threadIdx.x] = v;
+    const int m = mirror_slot[u];
+    if (m >= 0) p.vals[size_t(81) * m + 9 * b + a] = v;
+  }
+}
+
 // pose damping on the diagonal blocks (linearization_sc.hpp:323-327) and a copy of the
 // diagonal blocks for the SCHUR_JACOBI preconditioner (linearizor_sc.cpp:134-137)
 template <class S>

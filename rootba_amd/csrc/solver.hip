@@ -934,9 +934,7 @@ class Solver final : public rba_solver {
                          scp_, lambda);
       hipLaunchKernelGGL((rba::k_sc_obs_products<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0,
                          stream_, scp_);
-      hipLaunchKernelGGL((rba::k_sc_assemble<S>), dim3(sc_n_upper_), dim3(256), 0, stream_, scp_,
-                         d_sc_upper_.get(), d_sc_mirror_.get(), d_sc_pair_ptr_.get(), d_sc_pair_oi_.get(),
-                         d_sc_pair_oj_.get(), sc_n_upper_);
+      launch_sc_assemble(scp_);
       hipLaunchKernelGGL((rba::k_sc_cam_gradient<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_);
       hipLaunchKernelGGL((rba::k_sc_damp_and_extract_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0,
                          stream_, scp_, lambda);
@@ -1037,6 +1035,17 @@ class Solver final : public rba_solver {
     if (two_streams) HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
     if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
     ++hx_calls_;
+  }
+
+  // SC backend assembly: matrix cores for float, VALU for double
+  void launch_sc_assemble(const rba::ScParams<float>& sp) {
+    hipLaunchKernelGGL((rba::k_sc_assemble_mfma), dim3(sc_n_upper_), dim3(256), 0, stream_, sp, d_sc_upper_.get(),
+                       d_sc_mirror_.get(), d_sc_pair_ptr_.get(), d_sc_pair_oi_.get(), d_sc_pair_oj_.get());
+  }
+  void launch_sc_assemble(const rba::ScParams<double>& sp) {
+    hipLaunchKernelGGL((rba::k_sc_assemble<double>), dim3(sc_n_upper_), dim3(256), 0, stream_, sp,
+                       d_sc_upper_.get(), d_sc_mirror_.get(), d_sc_pair_ptr_.get(), d_sc_pair_oi_.get(),
+                       d_sc_pair_oj_.get(), sc_n_upper_);
   }
 
   // off-diagonal blocks of the explicit reduced matrix: matrix cores for float, VALU for double
