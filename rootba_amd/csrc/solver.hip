@@ -1365,7 +1365,9 @@ class Solver final : public rba_solver {
       if (lm_.it > max_lm_iter) lm_.terminated = true;
       return (keep_going && !lm_.terminated) ? 1 : 0;
     };
-    if (lm_.it == 0 || lm_.need_linearize) {
+    // (the reference re-evaluates the error at every outer iteration, bal_bundle_adjustment.cpp:297-301,
+    //  with a TODO to avoid it; after an accepted step the state is the one ri2 was computed for)
+    if (lm_.it == 0 || (lm_.need_linearize && !lm_.ri_is_current)) {
       compute_error(&lm_.ri);
       if (!lm_.ri.is_numerically_valid) {
         lm_.terminated = true;
@@ -1387,6 +1389,7 @@ class Solver final : public rba_solver {
       lm_.prev_valid = lm_.ri.valid_error;
       lm_.it = 1;
       lm_.need_linearize = true;
+      lm_.ri_is_current = true;
       return finish(true);
     }
     if (lm_.need_linearize) {
@@ -1470,6 +1473,8 @@ class Solver final : public rba_solver {
         lm_.termination = 1;
       }
       lm_.need_linearize = true;
+      lm_.ri = ri2;
+      lm_.ri_is_current = true;
       return finish(true);
     }
     lm_.lambda = lm_.lambda_vee * lm_.lambda;
@@ -1672,6 +1677,7 @@ class Solver final : public rba_solver {
   // LM state machine
   struct LmState {
     bool active = false, terminated = false, need_linearize = true;
+    bool ri_is_current = false;  // `ri` belongs to the current state (set after an accepted step)
     int it = 0, termination = 0;
     S lambda = S(0), lambda_vee = S(0);
     double prev_all = 0, prev_valid = 0;
