@@ -28,6 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DTYPE = np.float32
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -87,7 +88,7 @@ def cpu_baseline(prob, n_iter: int, gpu_rows):
     the first `n_iter` LM iterations of the same problem, all host cores."""
     from oracle import oracle as O
     t0 = time.perf_counter()
-    o = O.Oracle(prob, np.float32, solver_options(O, n_iter))
+    o = O.Oracle(prob, DTYPE, solver_options(O, n_iter))
     log(f"[cpu_baseline] oracle set up in {time.perf_counter() - t0:.1f}s, threads={o.num_threads()}")
     rows, _ = o.optimize_lm()
     its = [r for r in rows if r.iteration >= 1]
@@ -129,7 +130,10 @@ def main():
     ap.add_argument("--implicit-q", action="store_true", help="(default since round 1; kept for old command lines)")
     ap.add_argument("--solver-type", choices=["SQUARE_ROOT", "SCHUR_COMPLEMENT"], default="SQUARE_ROOT",
                     help="SCHUR_COMPLEMENT: explicit reduced camera matrix + SpMV (SURVEY.md 8f #4), 1 GPU")
+    ap.add_argument("--use-double", action="store_true", help="float64 (BASELINE metric is float32)")
     args = ap.parse_args()
+    global DTYPE
+    DTYPE = np.float64 if args.use_double else np.float32
     args.implicit_q = not args.dense_blocks
     _SOLVER_KW.update(preconditioner_type=PRECOND[args.preconditioner], power_order=args.power_order)
     _GPU_KW.update(implicit_q=int(args.implicit_q), solver_type=int(args.solver_type == "SCHUR_COMPLEMENT"))
@@ -165,7 +169,7 @@ def main():
     for key, val in _GPU_KW.items():
         setattr(gpu_opts, key, val)
     t0 = time.perf_counter()
-    lin = LinearizorHIP(local, np.float32, gpu_opts, device=local_rank)
+    lin = LinearizorHIP(local, DTYPE, gpu_opts, device=local_rank)
     log(f"[rank {rank}] solver set up in {time.perf_counter() - t0:.2f}s (rba_create: sort by track length, "
         f"CSC index, block structure of the reduced matrix, device allocation)")
     if world > 1:
@@ -230,11 +234,11 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f64" if DTYPE == np.float64 else "f32",
             "data": data,
             "config": {
                 "workload": f"BAL {args.workload} ({data}): {prob.n_cams} cams, {prob.n_lms} lms, {prob.n_obs} obs, "
-                            f"solver={args.solver_type}, {args.preconditioner}, Huber(1), float32",
+                            f"solver={args.solver_type}, {args.preconditioner}, Huber(1), {'float64' if DTYPE == np.float64 else 'float32'}",
                 "parallelism": f"landmarks sharded over {world} GPU(s), RCCL all-reduce of camera vectors",
                 "explicit_after": int(os.environ.get("RBA_EXPLICIT_AFTER", gpu_opts.explicit_after)),
                 "cg_iterations_per_step": sum(r.cg_iterations for r in timed) / max(1, len(timed)),

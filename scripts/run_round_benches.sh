@@ -13,3 +13,5 @@ rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r1b/prof -o benc
 cd $GRAFT_REPO_ROOT
 python bench.py --workload final-13682 --cpu-baseline-iters 0 > gpurun_out/r1b/final.json 2> gpurun_out/r1b/final.log
 tail -c 400 gpurun_out/r1b/venice.json
+python bench.py --use-double --cpu-baseline-iters 0 > gpurun_out/r1b/venice_f64.json 2> gpurun_out/r1b/venice_f64.log
+python bench.py --use-double --solver-type SCHUR_COMPLEMENT --cpu-baseline-iters 0 > gpurun_out/r1b/venice_f64_sc.json 2> gpurun_out/r1b/venice_f64_sc.log
