@@ -172,10 +172,36 @@ def main():
     lin = LinearizorHIP(local, DTYPE, gpu_opts, device=local_rank)
     log(f"[rank {rank}] solver set up in {time.perf_counter() - t0:.2f}s (rba_create: sort by track length, "
         f"CSC index, block structure of the reduced matrix, device allocation)")
+    transport = "RCCL all-reduce of camera vectors"
     if world > 1:
-        uid = [LinearizorHIP.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        lin.comm_init(rank, world, uid[0])
+        ok = 1
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [LinearizorHIP.comm_unique_id()]
+            except Exception as e:  # librccl could not be loaded by the library
+                log(f"[rank 0] rba_comm_unique_id failed: {e!r}")
+        dist.broadcast_object_list(uid, src=0)  # every rank takes part, whatever happened on rank 0
+        if uid[0] is None:
+            ok = 0
+        else:
+            try:
+                lin.comm_init(rank, world, uid[0])
+            except Exception as e:  # the library's own communicator cannot be created on this node
+                log(f"[rank {rank}] rba_comm_init failed: {e!r}")
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            # safety net: the library's callback transport, backed by torch.distributed (host staging)
+            def allreduce(arr, op):
+                t = torch.from_numpy(arr).cuda()
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+                arr[...] = t.cpu().numpy()
+
+            lin.comm_init_callback(rank, world, allreduce)
+            transport = "torch.distributed all-reduce through the callback transport (rba_comm_init failed)"
+            log(f"[rank {rank}] using the callback transport")
     stats = lin.problem_stats()
 
     def barrier():
@@ -239,7 +265,7 @@ def main():
             "config": {
                 "workload": f"BAL {args.workload} ({data}): {prob.n_cams} cams, {prob.n_lms} lms, {prob.n_obs} obs, "
                             f"solver={args.solver_type}, {args.preconditioner}, Huber(1), {'float64' if DTYPE == np.float64 else 'float32'}",
-                "parallelism": f"landmarks sharded over {world} GPU(s), RCCL all-reduce of camera vectors",
+                "parallelism": f"landmarks sharded over {world} GPU(s), {transport}",
                 "explicit_after": int(os.environ.get("RBA_EXPLICIT_AFTER", gpu_opts.explicit_after)),
                 "cg_iterations_per_step": sum(r.cg_iterations for r in timed) / max(1, len(timed)),
                 "successful_steps": sum(r.step_is_successful for r in timed),
