@@ -157,6 +157,30 @@ class Solver final : public rba_solver {
   Solver(int device, int n_cams, int n_lms, const int64_t* lm_off, const int32_t* obs_cam,
          const S* obs_xy, const rba_options& opt)
       : device_(device), n_cams_(n_cams), n_lms_(n_lms), opt_(opt) {
+    // input validation first: nothing to release if it throws
+    for (int l = 0; l < n_lms; ++l) {
+      const int64_t k = lm_off[l + 1] - lm_off[l];
+      if (k < 2)
+        throw HipError{"every landmark needs >= 2 observations (landmark " + std::to_string(l) + ")",
+                       RBA_ERR_INVALID_ARGUMENT};
+      for (int64_t q = lm_off[l]; q < lm_off[l + 1]; ++q) {
+        if (obs_cam[q] < 0 || obs_cam[q] >= n_cams)
+          throw HipError{"camera index out of range", RBA_ERR_INVALID_ARGUMENT};
+        if (q > lm_off[l] && obs_cam[q] <= obs_cam[q - 1])
+          throw HipError{"camera indices must be strictly ascending inside a landmark",
+                         RBA_ERR_INVALID_ARGUMENT};
+      }
+    }
+    try {
+      construct(lm_off, obs_cam, obs_xy);
+    } catch (...) {
+      release_resources();  // the destructor does not run for a throwing constructor
+      throw;
+    }
+  }
+
+  void construct(const int64_t* lm_off, const int32_t* obs_cam, const S* obs_xy) {
+    const int n_cams = n_cams_, n_lms = n_lms_;
     HIP_CHECK(hipSetDevice(device_));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
@@ -189,20 +213,12 @@ class Solver final : public rba_solver {
     for (int s = 0; s < n_lms; ++s) {
       const int l = perm_[s];
       const int k = int(lm_off[l + 1] - lm_off[l]);
-      if (k < 2)
-        throw HipError{"every landmark needs >= 2 observations (landmark " + std::to_string(l) + ")",
-                       RBA_ERR_INVALID_ARGUMENT};
       lm_k[s] = k;
       lm_obs[s] = o;
       lm_blk[s] = blk;
       kmax = std::max(kmax, k);
       for (int i = 0; i < k; ++i) {
         const int64_t src = lm_off[l] + i;
-        if (obs_cam[src] < 0 || obs_cam[src] >= n_cams)
-          throw HipError{"camera index out of range", RBA_ERR_INVALID_ARGUMENT};
-        if (i > 0 && obs_cam[src] <= obs_cam[src - 1])
-          throw HipError{"camera indices must be strictly ascending inside a landmark",
-                         RBA_ERR_INVALID_ARGUMENT};
         s_obs_cam[o] = obs_cam[src];
         s_obs_lm[o] = s;
         s_obs_xy[2 * o] = obs_xy[2 * src];
@@ -441,7 +457,7 @@ class Solver final : public rba_solver {
     HIP_CHECK(hipEventCreate(&ev_asm1_));
     d_scratch_int_.alloc(1);
     HIP_CHECK(hipEventCreate(&ev_b_));
-    hx_events_.resize(2 * kMaxHxEvents);
+    hx_events_.assign(2 * kMaxHxEvents, nullptr);
     hx_event_call_.resize(kMaxHxEvents);
     for (auto& e : hx_events_) HIP_CHECK(hipEventCreate(&e));
     HIP_CHECK(hipStreamSynchronize(stream_));
@@ -737,21 +753,28 @@ class Solver final : public rba_solver {
     hx_flops_ = int64_t(162) * nnz;
   }
 
-  ~Solver() override {
+  ~Solver() override { release_resources(); }
+
+  // streams, events, pinned memory, communicator (device buffers are DevBuf members);
+  // safe on a partially constructed object
+  void release_resources() {
     (void)hipSetDevice(device_);
-    (void)hipStreamSynchronize(stream_);
-    (void)hipStreamSynchronize(stream2_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (stream2_) (void)hipStreamSynchronize(stream2_);
     if (comm_ && g_rccl.CommDestroy) g_rccl.CommDestroy(comm_);
-    for (auto& e : hx_events_) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(ev_a_);
-    (void)hipEventDestroy(ev_asm0_);
-    (void)hipEventDestroy(ev_asm1_);
-    (void)hipEventDestroy(ev_b_);
+    comm_ = nullptr;
+    for (auto& e : hx_events_)
+      if (e) (void)hipEventDestroy(e);
+    hx_events_.clear();
+    for (hipEvent_t* e : {&ev_a_, &ev_b_, &ev_asm0_, &ev_asm1_, &ev_fork_, &ev_join_}) {
+      if (*e) (void)hipEventDestroy(*e);
+      *e = nullptr;
+    }
     if (h_pinned_) (void)hipHostFree(h_pinned_);
-    (void)hipEventDestroy(ev_fork_);
-    (void)hipEventDestroy(ev_join_);
-    (void)hipStreamDestroy(stream2_);
-    (void)hipStreamDestroy(stream_);
+    h_pinned_ = nullptr;
+    if (stream2_) (void)hipStreamDestroy(stream2_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+    stream_ = stream2_ = nullptr;
   }
 
   // ---- multi-GPU ------------------------------------------------------------
@@ -1770,6 +1793,28 @@ int rba_create(int dtype, int device, int32_t n_cams, int32_t n_lms,
       // combination of BASELINE.json config 5
       g_last_error = "preconditioner_type must be JACOBI (0), SCHUR_JACOBI (1) or POWER_SCHUR_COMPLEMENT (2)";
       return RBA_ERR_UNSUPPORTED;
+    }
+    {
+      const rba_options& o = *options;
+      const char* bad = nullptr;
+      if (o.max_cg_it < 1) bad = "max_cg_it (max_linear_solver_iterations) must be >= 1";
+      else if (o.min_cg_it < 0 || o.min_cg_it > o.max_cg_it) bad = "0 <= min_cg_it <= max_cg_it required";
+      else if (!(o.eta >= 0.0)) bad = "eta must be >= 0";
+      else if (o.power_order < 0) bad = "power_order must be >= 0";
+      else if (!(o.min_trust_region_radius > 0.0) || !(o.initial_trust_region_radius >= o.min_trust_region_radius) ||
+               !(o.max_trust_region_radius >= o.initial_trust_region_radius))
+        bad = "0 < min_trust_region_radius <= initial_trust_region_radius <= max_trust_region_radius required";
+      else if (o.max_num_iterations < 0) bad = "max_num_iterations must be >= 0";
+      else if (!(o.initial_vee > 0.0) || !(o.vee_factor > 0.0)) bad = "initial_vee and vee_factor must be > 0";
+      else if (o.robust_norm < 0 || o.robust_norm > 1) bad = "robust_norm must be NONE (0) or HUBER (1)";
+      else if (o.robust_norm == 1 && !(o.huber_parameter > 0.0)) bad = "huber_parameter must be > 0";
+      else if (o.optimized_cost < 0 || o.optimized_cost > 2) bad = "optimized_cost must be 0, 1 or 2";
+      else if (o.solver_type < 0 || o.solver_type > 1) bad = "solver_type must be SQUARE_ROOT (0) or SCHUR_COMPLEMENT (1)";
+      else if (!(o.jacobi_scaling_eps >= 0.0)) bad = "jacobi_scaling_eps must be >= 0";
+      if (bad) {
+        g_last_error = std::string("rba_create: ") + bad;
+        return RBA_ERR_INVALID_ARGUMENT;
+      }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {

@@ -1,0 +1,112 @@
+"""GPU-vs-oracle comparisons at BASELINE.json's own single-GPU configurations (synthetic stand-ins of
+the same size; the real BAL files when present):
+
+  config 2  ladybug-49     f32  per-landmark QR invariants vs the CPU oracle
+  config 3  trafalgar-257  f32  full LM run (QR + PCG pipeline) in lock-step with the oracle
+  config 4  venice-1778    f32  first four LM iterations in lock-step (cost, CG count, |inc|)
+  (config 1, ladybug-49 f64 "plumbing", is tests/test_gpu_parity.py::test_lm_trajectory_matches_oracle)
+
+Tolerances: SURVEY.md §8c — 1e-4 (f32) on per-iteration vectors while the truncated PCG is short,
+1e-6 relative on the final cost (north_star). The oracle runs on the GPU box's host cores
+(trafalgar ~1.4 LM it/s, venice ~20 s for four iterations).
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _opts(mod, **kw):
+    return mod.default_options(robust_norm=1, huber_parameter=1.0, **kw)
+
+
+def _bench_problem(name):
+    """Exactly bench.py's workload (CVPR'21 common settings)."""
+    import types
+
+    import bench
+    args = types.SimpleNamespace(translation_sigma=0.01, point_sigma=0.01, rotation_sigma=0.0)
+    return bench.make_problem(name, args)[0]
+
+
+def _pair(prob, dtype, **kw):
+    import torch  # noqa: F401
+    from oracle import oracle as O
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    return LinearizorHIP(prob, dtype, _opts(L, **kw)), O.Oracle(prob, dtype, _opts(O, **kw))
+
+
+def test_config2_ladybug49_f32_landmark_qr_vs_cpu():
+    """BASELINE config 2: the per-landmark QR kernel alone, float32, against the CPU oracle."""
+    prob = _bench_problem("ladybug-49")
+    g, o = _pair(prob, np.float32)
+    rc, d2, _ = o.stage1()
+    st, d2g = g.linearize(want_jp_diag2=True)
+    assert rc == 0 and st == 0
+    assert rel_err(d2g, d2) < 1e-5
+    assert rel_err(g.jl_col_scale(), o.jl_col_scale()) < 1e-5
+    # R^T R and |Q1^T r| per landmark are invariant to the reflector signs
+    Rg, qg = g.landmark_R(damped=False)
+    k = prob.obs_per_lm()
+    from oracle import oracle as O
+    o64 = O.Oracle(prob, np.float64, _opts(O))
+    assert o64.stage1()[0] == 0
+    eg = eo = 0.0
+    for l in np.random.default_rng(0).choice(prob.n_lms, 200, replace=False):
+        blk, li = o.block(int(l))
+        Ro = np.triu(blk[:3, li:li + 3].astype(np.float64))
+        R = np.zeros((3, 3))
+        R[np.triu_indices(3)] = Rg[l]
+        assert rel_err(R.T @ R, Ro.T @ Ro) < 1e-4
+        assert blk.shape[0] == 2 * k[l] + 3
+        # |Q1^T r|: the residuals are ~0.5 px differences of ~1e3 px projections near the optimum, so
+        # float32 itself carries ~1e-4 relative error there - accuracy parity w.r.t. the float64 oracle
+        b64, _ = o64.block(int(l))
+        n64 = np.linalg.norm(b64[:3, li + 3])
+        eg = max(eg, abs(np.linalg.norm(qg[l].astype(np.float64)) - n64) / (1e-3 + n64))
+        eo = max(eo, abs(np.linalg.norm(blk[:3, li + 3].astype(np.float64)) - n64) / (1e-3 + n64))
+    assert eg < 2e-3 and eg <= 3 * eo + 1e-5, (eg, eo)
+
+
+def test_config3_trafalgar257_f32_full_lm_run():
+    """BASELINE config 3: full QR + PCG pipeline, float32, 12 LM iterations against the oracle."""
+    prob = _bench_problem("trafalgar-257")
+    kw = dict(max_num_iterations=12, function_tolerance=0.0)
+    g, o = _pair(prob, np.float32, **kw)
+    lg, tg = g.optimize_lm()
+    lo, to = o.optimize_lm()
+    assert lg[0].cost == pytest.approx(lo[0].cost, rel=2e-6)
+    for a, b in zip(lg[1:6], lo[1:6]):
+        assert a.step_is_successful == b.step_is_successful == 1
+        # long float32 PCG solves end on the Q-model test within rounding noise: 15 % on the count
+        assert abs(a.cg_iterations - b.cg_iterations) <= max(1, (15 * b.cg_iterations) // 100)
+        assert abs(a.cost - b.cost) <= 1e-5 * b.cost
+        assert abs(a.inc_norm - b.inc_norm) <= 1e-2 * b.inc_norm
+        assert abs(a.lambda_ - b.lambda_) <= 1e-2 * b.lambda_
+    fg = min(r.cost for r in lg if r.step_is_successful)
+    fo = min(r.cost for r in lo if r.step_is_successful)
+    assert abs(fg - fo) / fo < 1e-6  # north_star: same final cost within 1e-6 relative
+
+
+def test_config4_venice1778_f32_lockstep_four_iterations():
+    """BASELINE config 4 (single GPU): the headline workload, iterations 1..4 against the oracle."""
+    prob = _bench_problem("venice-1778")
+    kw = dict(max_num_iterations=4, function_tolerance=0.0)
+    g, o = _pair(prob, np.float32, **kw)
+    lg, _ = g.optimize_lm()
+    lo, _ = o.optimize_lm()
+    assert len(lg) == len(lo) == 5
+    # 5e6 float32 residuals: the cost itself resolves to ~1e-6 relative
+    assert lg[0].cost == pytest.approx(lo[0].cost, rel=2e-6)
+    for a, b in zip(lg[1:], lo[1:]):
+        assert a.step_is_successful == b.step_is_successful == 1
+        assert abs(a.cg_iterations - b.cg_iterations) <= max(1, (15 * b.cg_iterations) // 100)
+        assert abs(a.cost - b.cost) <= 2e-6 * b.cost
+        assert abs(a.inc_norm - b.inc_norm) <= 1e-2 * b.inc_norm
+        assert abs(a.lambda_ - b.lambda_) <= 1e-2 * b.lambda_
+    # size-independent properties at full size: states agree after the four accepted steps
+    (cg_, lg_), (co_, lo_) = g.get_state(), o.get_state()
+    assert rel_err(cg_, co_) < 1e-4 and rel_err(lg_, lo_) < 1e-4
