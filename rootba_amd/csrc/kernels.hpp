@@ -1834,13 +1834,22 @@ __global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ in
 // scalars from the (identical) all-reduced vectors.
 // ===========================================================================
 struct CgState {
-  double rho_hist[2];  // rho of iteration i lives in rho_hist[i & 1]
-  double pq, q0, q1, norm_b2;
+  double rho_hist[2];  // rho of iteration i (0-based) lives in rho_hist[i & 1]
+  double q_hist[2];    // Q after i completed iterations lives in q_hist[i & 1] (Q_0 = 0)
+  double pq, norm_b2;
   double alpha, beta;
-  int iter;         // iterations completed
+  int iter;         // iterations completed (written by k_pcg_fin / k_pcgs_update only)
+  int cur;          // iteration in progress, 1-based (written by k_pcgs_spmv only)
+  int need_test;    // k_pcgs_update left Q partials of iteration `iter` for the termination test
   int done;         // 0 running, 1 finished
   int termination;  // 0 NO_CONVERGENCE, 1 SUCCESS, 2 FAILURE
+  int result_iter;  // num_iterations of the summary (valid once done)
+  int indefinite;   // terminated on p.q <= 0 ("Matrix is indefinite")
   int refresh;      // the current iteration recomputes r from scratch
+  // per-solve parameters of the fused PCG (kernels_pcg.hpp), set by k_pcgs_begin: device-side so
+  // that the captured launch graphs are independent of them
+  int pswap;        // direction of `it` completed iterations lives in buffer (it + pswap) & 1
+  double lambda;    // pose damping added to the product (0 when the matrix contains it)
 };
 
 constexpr int kPcgBlocks = 64;  // workgroups of the PCG vector kernels
@@ -1883,11 +1892,14 @@ __global__ __launch_bounds__(1024) void k_pcg_init(const S* __restrict__ bvec, S
     for (int w = 0; w < int(blockDim.x >> 6); ++w) nb2 += sm[w];
     st->rho_hist[0] = st->rho_hist[1] = 1.0;
     st->pq = 0;
-    st->q0 = 0;  // -x.(b + r) with x = 0
-    st->q1 = 0;
+    st->q_hist[0] = st->q_hist[1] = 0;  // -x.(b + r) with x = 0
     st->norm_b2 = nb2;
     st->alpha = st->beta = 0;
     st->iter = 0;
+    st->cur = 0;
+    st->need_test = 0;
+    st->result_iter = 0;
+    st->indefinite = 0;
     st->refresh = 0;
     st->termination = nb2 == 0.0 ? 1 : 0;  // "Convergence. |b| = 0."
     st->done = nb2 == 0.0 ? 1 : 0;
@@ -1978,6 +1990,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_a2(const S* __restrict__ z,
       st->termination = 2;  // "Numerical failure. rho / beta"
       st->done = 1;
       st->iter = iter + 1;
+      st->result_iter = iter + 1;
     } else {
       st->rho_hist[iter & 1] = rho;
       st->beta = beta;
@@ -2036,8 +2049,10 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_b2(const S* __restrict__ bv
     st->refresh = refresh;
     if (stop) {
       st->termination = term;
+      st->indefinite = term == 0 ? 1 : 0;
       st->done = 1;
       st->iter = iter + 1;
+      st->result_iter = iter + 1;
     }
   }
   if (stop) return;
@@ -2085,18 +2100,19 @@ __global__ void k_pcg_fin(CgState* st, const double* __restrict__ partial_q1, in
   if (phase == 0 && st->refresh) return;
   if (phase == 1 && !st->refresh) return;
   const double q1 = pcg_sum_partials(partial_q1);
-  st->q1 = q1;
   st->refresh = 0;
-  st->iter += 1;
-  const double zeta = st->iter * (q1 - st->q0) / q1;
-  if (zeta < q_tolerance && st->iter >= min_it) {
+  const int it = st->iter + 1;
+  st->iter = it;
+  st->result_iter = it;
+  const double zeta = it * (q1 - st->q_hist[(it + 1) & 1]) / q1;
+  st->q_hist[it & 1] = q1;
+  if (zeta < q_tolerance && it >= min_it) {
     st->termination = 1;
     st->done = 1;
     return;
   }
-  st->q0 = q1;
   // residual-based termination is off (r_tolerance = -1, linearizor_base.cpp:91)
-  if (st->iter >= max_it) {
+  if (it >= max_it) {
     st->termination = 0;
     st->done = 1;
   }

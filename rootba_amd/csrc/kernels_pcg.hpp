@@ -45,7 +45,8 @@ struct SpmvItem {
   int row;    // camera (block row)
   int slot0;  // first block slot of the item
   int slot1;  // one past the last
-  int first;  // 1: first item of its row (adds lambda p_c, publishes p_new[c])
+  int extra;  // -1: first item of its row (writes q[9 row ..], adds lambda p_c, publishes p_new[c]);
+              // >= 0: further item of a long row, writes its partial sums to qextra[9 extra ..]
 };
 
 // vector of 16 bytes of scalars
@@ -67,156 +68,207 @@ constexpr size_t spmv_lds_bytes() {
   return (size_t(64) * 81 + Vec16<S>::N) * sizeof(S);
 }
 
-// y[0..8] (all lanes) += S_row,chunk * v for the blocks [slot0, slot1) of one row; v is read by
-// the callback (lane j gets the 9 entries of column block j)
-template <class S, class XF>
-__device__ __forceinline__ void spmv_item_accumulate(const int* __restrict__ cols, const S* __restrict__ vals,
-                                                     int slot0, int slot1, S* lds, int lane, double acc[9],
-                                                     XF&& load_x) {
+constexpr int kSpmvPass = 21;  // 16-byte loads in flight per lane (float: a whole 64-block chunk)
+
+// One 64-block chunk of a row strip: the chunk's scalars [81 chunk, 81 (chunk + nb)) are copied to
+// LDS at the same 16-byte phase with fully coalesced 16-byte loads (kSpmvPass per lane in flight).
+template <class S>
+struct ChunkStage {
   using V = typename Vec16<S>::type;
-  constexpr int N = Vec16<S>::N;
-  constexpr int PASS = 21;  // 16-byte loads in flight per lane
-  for (int chunk = slot0; chunk < slot1; chunk += 64) {
-    const int nb = min(64, slot1 - chunk);
-    const bool act = lane < nb;
-    const int col = act ? cols[chunk + lane] : 0;
-    S xv[9];
-    load_x(col, act, xv);
-    // the chunk's scalars [g0, g0 + 81 nb) -> LDS at the same 16-byte phase
+  static constexpr int N = Vec16<S>::N;
+  const V* __restrict__ src;
+  int off, nvec;
+  __device__ __forceinline__ void setup(const S* __restrict__ vals, int chunk, int nb) {
     const int64_t g0 = int64_t(81) * chunk;
     const int64_t base = g0 & ~int64_t(N - 1);
-    const int off = int(g0 - base);
-    const int nvec = (off + 81 * nb + N - 1) / N;
-    const V* __restrict__ src = reinterpret_cast<const V*>(vals + base);
+    off = int(g0 - base);
+    nvec = (off + 81 * nb + N - 1) / N;
+    src = reinterpret_cast<const V*>(vals + base);
+  }
+  __device__ __forceinline__ void issue(int v0, int lane, V tmp[kSpmvPass]) const {
+    // (index clamped instead of predicated: no exec-mask branch per load; surplus lanes re-read
+    //  the last vector, the store below is predicated)
+#pragma unroll
+    for (int u = 0; u < kSpmvPass; ++u) tmp[u] = src[min(v0 + u * 64 + lane, nvec - 1)];
+  }
+  __device__ __forceinline__ void store(int v0, int lane, const V tmp[kSpmvPass], S* lds) const {
     V* dst = reinterpret_cast<V*>(lds);
-    for (int v0 = 0; v0 < nvec; v0 += 64 * PASS) {
-      V tmp[PASS];
 #pragma unroll
-      for (int u = 0; u < PASS; ++u) {
-        const int i = v0 + u * 64 + lane;
-        if (i < nvec) tmp[u] = src[i];
-      }
-#pragma unroll
-      for (int u = 0; u < PASS; ++u) {
-        const int i = v0 + u * 64 + lane;
-        if (i < nvec) dst[i] = tmp[u];
-      }
+    for (int u = 0; u < kSpmvPass; ++u) {
+      const int i = v0 + u * 64 + lane;
+      if (i < nvec) dst[i] = tmp[u];
     }
-    __syncthreads();
-    if (act) {
-      const S* blk = lds + off + 81 * lane;
+  }
+};
+
+// lane j multiplies ITS block out of LDS (lane stride 81 words: conflict-free)
+template <class S>
+__device__ __forceinline__ void spmv_block_times(const S* lds, int off, int lane, bool act, const S xv[9],
+                                                 double acc[9]) {
+  if (act) {
+    const S* blk = lds + off + 81 * lane;
 #pragma unroll
-      for (int a = 0; a < 9; ++a) {
-        S t = S(0);
+    for (int a = 0; a < 9; ++a) {
+      S t = S(0);
 #pragma unroll
-        for (int b = 0; b < 9; ++b) t += blk[9 * a + b] * xv[b];
-        acc[a] += double(t);
-      }
+      for (int b = 0; b < 9; ++b) t += blk[9 * a + b] * xv[b];
+      acc[a] += double(t);
     }
-    __syncthreads();  // the next chunk overwrites the staging buffer
   }
 }
 
 // MODE 0: direction update + product + p.q partial.   MODE 1: refresh product S x (+ lambda x).
+// Load schedule (the kernel is a chain of memory round trips, not a bandwidth problem):
+//   round 1  the item descriptor
+//   round 2  the first chunk's matrix vectors, its column indices, the 2 x 64 reduction partials and
+//            the PCG state - all independent, all issued before anything is waited for
+//   round 3  the gathers of z / p (need the column indices)
+// The termination decision is evaluated while rounds 2/3 are in flight.
 template <class S, int MODE>
 __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, const S* __restrict__ vals,
                                                   const SpmvItem* __restrict__ items, const S* __restrict__ z,
                                                   S* pbuf0, S* pbuf1, const S* __restrict__ xvec,
-                                                  S* __restrict__ qpart, S lambda, CgState* st,
-                                                  const double* __restrict__ part_rho,
+                                                  S* __restrict__ qmain, S* __restrict__ qextra, CgState* st, const double* __restrict__ part_rho,
                                                   const double* __restrict__ part_q,
                                                   double* __restrict__ part_pq, double q_tolerance, int min_it,
                                                   int max_it, int period, int* host_progress) {
+  using V = typename Vec16<S>::type;
   extern __shared__ __attribute__((aligned(16))) char smem_pcgs[];
   S* lds = reinterpret_cast<S*>(smem_pcgs);
   const int lane = threadIdx.x;
-  if (st->done) return;
   const SpmvItem item = items[blockIdx.x];
   const int c = item.row;
-  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-  if (MODE == 1) {
-    if (st->cur % period != 0) return;
-    spmv_item_accumulate<S>(cols, vals, item.slot0, item.slot1, lds, lane, acc,
-                            [&](int col, bool act, S xv[9]) {
-#pragma unroll
-                              for (int t = 0; t < 9; ++t) xv[t] = act ? xvec[9 * col + t] : S(0);
-                            });
-    S mine = S(0);
-#pragma unroll
-    for (int a = 0; a < 9; ++a) {
-      const double tot = wave_sum(acc[a]);
-      if (lane == a) mine = S(tot);
-    }
-    if (lane < 9) {
-      if (item.first) mine += lambda * xvec[9 * c + lane];
-      qpart[9 * blockIdx.x + lane] = mine;
-    }
-    return;
+  // ---- round 2: everything that depends on the item only. vmcnt retires in order: what the
+  //      next round needs (column indices, partials) is requested BEFORE the 21 matrix vectors
+  ChunkStage<S> cs;
+  const int nb0 = min(64, item.slot1 - item.slot0);
+  const bool act0 = lane < nb0;
+  const int col0 = cols[item.slot0 + min(lane, nb0 - 1)];
+  double prho = 0, pq1 = 0;
+  if (MODE == 0) {
+    prho = part_rho[lane];
+    pq1 = part_q[lane];
   }
-
-  // ---- prologue: termination test of the previous iteration, rho, beta ------------
-  const int it = st->iter;  // iterations completed
-  const double rho = wave_sum(part_rho[lane]);
-  const double q1 = wave_sum(part_q[lane]);
-  const int need_test = st->need_test;
-  int stop = 0, term = 0, res_it = it;
-  if (need_test) {
-    // Q-model test (conjugate_gradient.hpp:239-276); residual-based test is off (r_tolerance = -1)
-    const double zeta = it * (q1 - st->q_hist[(it + 1) & 1]) / q1;
-    if (zeta < q_tolerance && it >= min_it) {
-      stop = 1;
-      term = 1;
-    } else if (it >= max_it) {
-      stop = 1;
-      term = 0;
+  const int done = st->done, it = st->iter, cur_st = st->cur, need_test = st->need_test, pswap = st->pswap;
+  const double q_prev = st->q_hist[(it + 1) & 1], rho_prev = st->rho_hist[(it + 1) & 1];
+  const S lambda = S(st->lambda);
+  cs.setup(vals, item.slot0, nb0);
+  V tmp[kSpmvPass];
+  cs.issue(0, lane, tmp);
+  // ---- round 3: the operand of the first chunk ---------------------------------------------
+  const S* __restrict__ p_old = ((it + pswap) & 1) ? pbuf1 : pbuf0;
+  S* __restrict__ p_new = ((it + pswap) & 1) ? pbuf0 : pbuf1;
+  const bool first_it = it == 0;
+  S za[9], pa[9];
+  // (unpredicated: col0 is a valid column for every lane; idle lanes are masked at the product)
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (MODE == 0) {
+      za[t] = z[9 * col0 + t];
+      pa[t] = p_old[9 * col0 + t];
+    } else {
+      za[t] = xvec[9 * col0 + t];
     }
   }
-  double beta = 0.0;
-  if (!stop) {
-    if (rho == 0.0 || isinf(rho)) {
-      stop = 1;
-      term = 2;  // "Numerical failure. rho / beta"
-      res_it = it + 1;
-    } else if (it > 0) {
-      beta = rho / st->rho_hist[(it + 1) & 1];
-      if (beta == 0.0 || isinf(beta)) {
-        stop = 1;
-        term = 2;
-        res_it = it + 1;
+  const int lc = min(lane, 8);
+  const S zc = MODE == 0 ? z[9 * c + lc] : xvec[9 * c + lc];
+  const S pcold = MODE == 0 ? p_old[9 * c + lc] : S(0);
+
+  // ---- decisions (while the loads are in flight) ---------------------------------------------
+  int stop = done, term = 0, res_it = it, own_stop = 0;
+  double beta = 0.0, rho = 0.0, q1 = 0.0;
+  if (MODE == 0) {
+    rho = wave_sum(prho);
+    q1 = wave_sum(pq1);
+    if (!done) {
+      if (need_test) {
+        // Q-model test (conjugate_gradient.hpp:239-276); residual-based test is off (r_tolerance = -1)
+        const double zeta = it * (q1 - q_prev) / q1;
+        if (zeta < q_tolerance && it >= min_it) {
+          own_stop = 1;
+          term = 1;
+        } else if (it >= max_it) {
+          own_stop = 1;
+          term = 0;
+        }
+      }
+      if (!own_stop) {
+        if (rho == 0.0 || isinf(rho)) {
+          own_stop = 1;
+          term = 2;  // "Numerical failure. rho / beta"
+          res_it = it + 1;
+        } else if (it > 0) {
+          beta = rho / rho_prev;
+          if (beta == 0.0 || isinf(beta)) {
+            own_stop = 1;
+            term = 2;
+            res_it = it + 1;
+          }
+        }
       }
     }
-  }
-  if (blockIdx.x == 0 && lane == 0) {
-    if (need_test) st->q_hist[it & 1] = q1;
-    if (stop) {
-      st->termination = term;
-      st->result_iter = res_it;
-      st->done = 1;
-      if (host_progress) __hip_atomic_store(host_progress + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else {
-      st->rho_hist[it & 1] = rho;
-      st->beta = beta;
-      st->cur = it + 1;
-      if (host_progress) __hip_atomic_store(host_progress, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    stop = done | own_stop;
+    if (blockIdx.x == 0 && lane == 0) {
+      if (done) {
+        // (the host's run-ahead throttle must learn about a termination the round-1 kernels detected)
+        if (host_progress) __hip_atomic_store(host_progress + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        if (need_test) st->q_hist[it & 1] = q1;
+        if (own_stop) {
+          st->termination = term;
+          st->result_iter = res_it;
+          st->done = 1;
+          if (host_progress) __hip_atomic_store(host_progress + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+          st->rho_hist[it & 1] = rho;
+          st->beta = beta;
+          st->cur = it + 1;
+          if (host_progress) __hip_atomic_store(host_progress, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
     }
+  } else {
+    stop = done | (cur_st % period != 0 ? 1 : 0);
   }
   if (stop) return;
 
-  // ---- q_c = sum_j S_cj (z_j + beta p_j) ---------------------------------------------
-  const S* __restrict__ p_old = (it & 1) ? pbuf1 : pbuf0;
-  S* __restrict__ p_new = (it & 1) ? pbuf0 : pbuf1;
+  // ---- q_c = sum_j S_cj v_j,  v = z + beta p (MODE 0) or x (MODE 1) ---------------------------
   const S bs = S(beta);
-  const bool first_it = it == 0;
-  spmv_item_accumulate<S>(cols, vals, item.slot0, item.slot1, lds, lane, acc,
-                          [&](int col, bool act, S xv[9]) {
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  S xv[9];
 #pragma unroll
-                            for (int t = 0; t < 9; ++t) {
-                              const S zz = act ? z[9 * col + t] : S(0);
-                              const S pp = (act && !first_it) ? p_old[9 * col + t] : S(0);
-                              xv[t] = first_it ? zz : zz + bs * pp;
-                            }
-                          });
+  for (int t = 0; t < 9; ++t) xv[t] = (MODE == 0 && !first_it) ? za[t] + bs * pa[t] : za[t];
+  (void)pa;
+  cs.store(0, lane, tmp, lds);
+  for (int v0 = 64 * kSpmvPass; v0 < cs.nvec; v0 += 64 * kSpmvPass) {  // double: second half of the chunk
+    cs.issue(v0, lane, tmp);
+    cs.store(v0, lane, tmp, lds);
+  }
+  __syncthreads();
+  spmv_block_times<S>(lds, cs.off, lane, act0, xv, acc);
+  for (int chunk = item.slot0 + 64; chunk < item.slot1; chunk += 64) {  // long rows only
+    __syncthreads();  // the staging buffer is overwritten
+    const int nb = min(64, item.slot1 - chunk);
+    const bool act = lane < nb;
+    const int col = act ? cols[chunk + lane] : 0;
+    cs.setup(vals, chunk, nb);
+    for (int v0 = 0; v0 < cs.nvec; v0 += 64 * kSpmvPass) {
+      cs.issue(v0, lane, tmp);
+      cs.store(v0, lane, tmp, lds);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (MODE == 0) {
+        const S zz = act ? z[9 * col + t] : S(0);
+        const S pp = (act && !first_it) ? p_old[9 * col + t] : S(0);
+        xv[t] = first_it ? zz : zz + bs * pp;
+      } else {
+        xv[t] = act ? xvec[9 * col + t] : S(0);
+      }
+    }
+    __syncthreads();
+    spmv_block_times<S>(lds, cs.off, lane, act, xv, acc);
+  }
   S mine = S(0);
 #pragma unroll
   for (int a = 0; a < 9; ++a) {
@@ -225,55 +277,108 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
   }
   double pq = 0.0;
   if (lane < 9) {
-    const S zz = z[9 * c + lane];
-    const S pc = first_it ? zz : zz + bs * p_old[9 * c + lane];
-    if (item.first) {
+    const S pc = (MODE == 0 && !first_it) ? zc + bs * pcold : zc;  // p_c (MODE 0) / x_c (MODE 1)
+    if (item.extra < 0) {
       mine += lambda * pc;  // pose damping term of right_multiply
-      p_new[9 * c + lane] = pc;
+      if (MODE == 0) p_new[9 * c + lane] = pc;
+      qmain[9 * c + lane] = mine;
+    } else {
+      qextra[9 * item.extra + lane] = mine;
     }
-    qpart[9 * blockIdx.x + lane] = mine;
     pq = double(pc) * double(mine);
   }
-  pq = wave_sum(pq);
-  if (lane == 0) part_pq[blockIdx.x] = pq;
+  if (MODE == 0) {
+    pq = wave_sum(pq);
+    if (lane == 0) part_pq[blockIdx.x] = pq;
+  }
 }
 
-// phase 0: after the direction product; phase 1: after the refresh product
+// q_i = first item's sum + the extra items of a long row (fixed order)
+template <class S>
+__device__ __forceinline__ S pcgs_gather_q(S qm, const S* __restrict__ qextra, int e0, int e1, int row) {
+  for (int q = e0; q < e1; ++q) qm += qextra[9 * q + row];
+  return qm;
+}
+
+// phase 0: after the direction product; phase 1: after the refresh product.
+// All operands of the first tile are requested before the p.q reduction is waited for.
 template <class S>
 __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, const S* __restrict__ bvec,
                                                      S* __restrict__ x, S* __restrict__ r, S* __restrict__ z,
-                                                     const S* pbuf0, const S* pbuf1, const S* __restrict__ qpart,
-                                                     const int* __restrict__ item_ptr, int n_items, int n_cams,
+                                                     const S* pbuf0, const S* pbuf1, const S* __restrict__ qmain,
+                                                     const S* __restrict__ qextra,
+                                                     const int* __restrict__ extra_ptr, int n_items, int n_cams,
                                                      CgState* st, const double* __restrict__ part_pq,
                                                      double* __restrict__ part_rho, double* __restrict__ part_q,
                                                      int phase, int period, int* host_progress) {
-  __shared__ double sm[4];
+  __shared__ double sm[4][2];
   __shared__ S rl[252];
-  if (st->done) return;
   const int tid = threadIdx.x;
-  const int cur = st->cur;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int n_tiles = (n_cams + 27) / 28;
+  // ---- loads first --------------------------------------------------------------------------
+  double accp = 0;
+  if (phase == 0) {
+    // eight independent loads per thread and batch (a serial strided loop would be eight memory
+    // round trips); fixed summation order
+    for (int base = 0; base < n_items; base += 2048) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        v[u] = part_pq[min(idx, n_items - 1)];
+        if (idx >= n_items) v[u] = 0.0;
+      }
+      accp += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+  }
+  const int done = st->done, cur = st->cur, pswap = st->pswap;
+  const double rho0 = st->rho_hist[0], rho1 = st->rho_hist[1];
+  int tile = blockIdx.x;
+  int i = 252 * tile + tid;
+  bool act = tile < n_tiles && tid < 252 && i < 9 * n_cams;
+  int c = act ? i / 9 : 0, row = act ? i - 9 * c : 0;
+  S xo = S(0), ro = S(0), bo = S(0), po0 = S(0), po1 = S(0), qm = S(0), Mrow[9];
+  int e0 = 0, e1 = 0;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) Mrow[j] = S(0);
+  if (act) {
+    xo = x[i];
+    ro = r[i];
+    bo = bvec[i];
+    po0 = pbuf0[i];
+    po1 = pbuf1[i];
+    qm = qmain[i];
+    e0 = extra_ptr[c];
+    e1 = extra_ptr[c + 1];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) Mrow[j] = inv[81 * c + 9 * row + j];
+  }
+  // ---- p.q, alpha ---------------------------------------------------------------------------
   const bool refresh = (cur % period) == 0;
-  if (phase == 1 && !refresh) return;
+  int stop = done | ((phase == 1 && !refresh) ? 1 : 0);
   S a = S(0);
   if (phase == 0) {
-    double acc = 0;
-    for (int i = tid; i < n_items; i += 256) acc += part_pq[i];
-    const double pq = pcg_block_sum(acc, sm);
-    int stop = 0, term = 0;
+    const double t = wave_sum(accp);
+    if (lane == 0) sm[wave][0] = t;
+    __syncthreads();
+    const double pq = (sm[0][0] + sm[1][0]) + (sm[2][0] + sm[3][0]);
+    __syncthreads();
+    int own_stop = 0, term = 0;
     double alpha = 0;
     if (pq <= 0.0 || isinf(pq)) {
-      stop = 1;  // "Matrix is indefinite, no more progress can be made." -> NO_CONVERGENCE
+      own_stop = 1;  // "Matrix is indefinite, no more progress can be made." -> NO_CONVERGENCE
     } else {
-      alpha = st->rho_hist[(cur + 1) & 1] / pq;
+      alpha = ((cur + 1) & 1 ? rho1 : rho0) / pq;
       if (isinf(alpha)) {
-        stop = 1;
+        own_stop = 1;
         term = 2;
       }
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if (!done && blockIdx.x == 0 && tid == 0) {
       st->pq = pq;
       st->alpha = alpha;
-      if (stop) {
+      if (own_stop) {
         st->termination = term;
         st->indefinite = term == 0 ? 1 : 0;
         st->result_iter = cur;
@@ -281,30 +386,45 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
         if (host_progress) __hip_atomic_store(host_progress + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
-    if (stop) return;
+    stop |= own_stop;
     a = S(alpha);
   }
-  const S* __restrict__ p = (cur & 1) ? pbuf1 : pbuf0;
+  if (stop) return;
+  const bool odd = (cur + pswap) & 1;
+  const S* __restrict__ p = odd ? pbuf1 : pbuf0;
   double acc_rho = 0, acc_q = 0;
-  const int n_tiles = (n_cams + 27) / 28;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int i = 252 * tile + tid;
-    const bool act = tid < 252 && i < 9 * n_cams;
-    const int c = act ? i / 9 : 0, row = act ? i - 9 * c : 0;
+  for (; tile < n_tiles; tile += gridDim.x) {
+    if (tile != int(blockIdx.x)) {  // further tiles (n_cams > 28 * gridDim.x)
+      i = 252 * tile + tid;
+      act = tid < 252 && i < 9 * n_cams;
+      c = act ? i / 9 : 0;
+      row = act ? i - 9 * c : 0;
+      if (act) {
+        xo = x[i];
+        ro = r[i];
+        bo = bvec[i];
+        po0 = p[i];
+        po1 = po0;
+        qm = qmain[i];
+        e0 = extra_ptr[c];
+        e1 = extra_ptr[c + 1];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) Mrow[j] = inv[81 * c + 9 * row + j];
+      }
+    }
     S xn = S(0), rn = S(0);
     if (act) {
-      S qv = S(0);
-      for (int q = item_ptr[c]; q < item_ptr[c + 1]; ++q) qv += qpart[9 * q + row];
+      const S qv = pcgs_gather_q(qm, qextra, e0, e1, row);
       if (phase == 0) {
-        xn = x[i] + a * p[i];
+        xn = xo + a * (odd ? po1 : po0);
         x[i] = xn;
         if (!refresh) {
-          rn = r[i] - a * qv;
+          rn = ro - a * qv;
           r[i] = rn;
         }
       } else {
-        xn = x[i];
-        rn = bvec[i] - qv;  // qv = (S x + lambda x)_i
+        xn = xo;
+        rn = bo - qv;  // qv = (S x + lambda x)_i
         r[i] = rn;
       }
     }
@@ -313,22 +433,25 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
     if (tid < 252) rl[tid] = rn;
     __syncthreads();
     if (act) {
-      const S* M = inv + 81 * c + 9 * row;
       const S* rc = rl + 9 * (tid / 9);
       S zc = S(0);
 #pragma unroll
-      for (int j = 0; j < 9; ++j) zc += M[j] * rc[j];
+      for (int j = 0; j < 9; ++j) zc += Mrow[j] * rc[j];
       z[i] = zc;
       acc_rho += double(rn) * double(zc);
-      acc_q -= double(xn) * double(bvec[i] + rn);
+      acc_q -= double(xn) * double(bo + rn);
     }
   }
   if (phase == 0 && refresh) return;
-  const double rho_p = pcg_block_sum(acc_rho, sm);
-  const double q_p = pcg_block_sum(acc_q, sm);
+  const double t0 = wave_sum(acc_rho), t1 = wave_sum(acc_q);
+  if (lane == 0) {
+    sm[wave][0] = t0;
+    sm[wave][1] = t1;
+  }
+  __syncthreads();
   if (tid == 0) {
-    part_rho[blockIdx.x] = rho_p;
-    part_q[blockIdx.x] = q_p;
+    part_rho[blockIdx.x] = (sm[0][0] + sm[1][0]) + (sm[2][0] + sm[3][0]);
+    part_q[blockIdx.x] = (sm[0][1] + sm[1][1]) + (sm[2][1] + sm[3][1]);
     if (blockIdx.x == 0) {
       st->iter = cur;
       st->need_test = 1;
@@ -336,19 +459,34 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
   }
 }
 
-// r = b - (S x + lambda x) from the item partials of a refresh product (operator switch inside a solve)
+// per-solve parameters (see CgState)
+__global__ void k_pcgs_begin(CgState* st, double lambda, int pswap) {
+  st->lambda = lambda;
+  st->pswap = pswap;
+}
+
+// y = q (+ the extra items of long rows)   (tests: rba_right_multiply_explicit)
+template <class S>
+__global__ __launch_bounds__(256) void k_pcgs_collect(S* __restrict__ y, const S* __restrict__ qmain,
+                                                      const S* __restrict__ qextra,
+                                                      const int* __restrict__ extra_ptr, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = i / 9, row = i - 9 * c;
+  y[i] = pcgs_gather_q(qmain[i], qextra, extra_ptr[c], extra_ptr[c + 1], row);
+}
+
+// r = b - (S x + lambda x) from a refresh product (operator switch inside a solve)
 template <class S>
 __global__ __launch_bounds__(256) void k_pcgs_residual(const S* __restrict__ bvec, S* __restrict__ r,
-                                                       const S* __restrict__ qpart,
-                                                       const int* __restrict__ item_ptr, int n,
+                                                       const S* __restrict__ qmain, const S* __restrict__ qextra,
+                                                       const int* __restrict__ extra_ptr, int n,
                                                        const CgState* st) {
   if (st->done) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int c = i / 9, row = i - 9 * c;
-  S qv = S(0);
-  for (int q = item_ptr[c]; q < item_ptr[c + 1]; ++q) qv += qpart[9 * q + row];
-  r[i] = bvec[i] - qv;
+  r[i] = bvec[i] - pcgs_gather_q(qmain[i], qextra, extra_ptr[c], extra_ptr[c + 1], row);
 }
 
 }  // namespace rba

@@ -25,6 +25,7 @@
 #include "kernels.hpp"
 #include "kernels_big.hpp"
 #include "kernels_sc.hpp"
+#include "kernels_pcg.hpp"
 
 namespace {
 
@@ -451,7 +452,13 @@ class Solver final : public rba_solver {
     d_pose_scaling_.zero(stream_);
     d_fail_.zero(stream_);
     d_partials_.zero(stream_);
+    d_p2_.alloc(nvec_);
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 4096));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_progress_), 64));
+    h_progress_[0] = h_progress_[1] = 0;
+    if (const char* ev = std::getenv("RBA_FUSED_PCG")) fused_pcg_ = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("RBA_PCG_RUN_AHEAD")) pcg_run_ahead_ = std::max(1, std::atoi(ev));
+    if (const char* ev = std::getenv("RBA_PCG_GRAPHS")) use_pcg_graphs_ = std::atoi(ev) != 0;
     HIP_CHECK(hipEventCreate(&ev_a_));
     HIP_CHECK(hipEventCreate(&ev_asm0_));
     HIP_CHECK(hipEventCreate(&ev_asm1_));
@@ -608,6 +615,7 @@ class Solver final : public rba_solver {
     }
     ex_nnz_ = nnz;
     ex_n_upper_ = n_upper;
+    build_spmv_items(row_ptr);
     d_ex_rowptr_.alloc(row_ptr.size());
     d_ex_cols_.alloc(cols.size());
     d_ex_diag_.alloc(diag.size());
@@ -616,7 +624,7 @@ class Solver final : public rba_solver {
     d_ex_pair_ptr_.alloc(pair_ptr.size());
     d_ex_pair_oi_.alloc(n_pairs);
     d_ex_pair_oj_.alloc(n_pairs);
-    d_ex_vals_.alloc(size_t(81) * nnz);
+    d_ex_vals_.alloc(size_t(81) * nnz + 4);  // + 4: the SpMV's last 16-byte load may run past the end
     d_ex_topdT_.alloc(sizeof(S) == 8 ? 27 * size_t(n_obs_) : 0);
     d_ex_rowptr_.upload(row_ptr.data(), row_ptr.size(), stream_);
     d_ex_cols_.upload(cols.data(), cols.size(), stream_);
@@ -633,6 +641,38 @@ class Solver final : public rba_solver {
     exp_.cols = d_ex_cols_.get();
     exp_.vals = d_ex_vals_.get();
     ex_ready_ = true;
+  }
+
+  // work items of the fused PCG's SpMV (kernels_pcg.hpp): one wavefront per block row, rows with
+  // more than 64 * kSpmvChunksPerItem blocks are split (their partial sums are added in item order)
+  void build_spmv_items(const std::vector<int>& row_ptr) {
+    destroy_pcg_graphs();  // they hold the addresses of the buffers (re)allocated here
+    std::vector<rba::SpmvItem> items;
+    std::vector<int> extra_ptr(size_t(n_cams_) + 1, 0);
+    const int span = 64 * rba::kSpmvChunksPerItem;
+    int n_extra = 0;
+    for (int c = 0; c < n_cams_; ++c) {
+      extra_ptr[c] = n_extra;
+      items.push_back(rba::SpmvItem{c, row_ptr[c], std::min(row_ptr[c] + span, row_ptr[c + 1]), -1});
+      for (int s0 = row_ptr[c] + span; s0 < row_ptr[c + 1]; s0 += span)
+        items.push_back(rba::SpmvItem{c, s0, std::min(s0 + span, row_ptr[c + 1]), n_extra++});
+    }
+    extra_ptr[n_cams_] = n_extra;
+    n_items_ = int(items.size());
+    d_items_.alloc(items.size());
+    d_item_ptr_.alloc(extra_ptr.size());
+    d_items_.upload(items.data(), items.size(), stream_);
+    d_item_ptr_.upload(extra_ptr.data(), extra_ptr.size(), stream_);
+    d_qpart_.alloc(size_t(9) * std::max(1, n_extra));
+    d_qmain_.alloc(nvec_);
+    d_pcgs_pq_.alloc(n_items_);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    if (rba::spmv_lds_bytes<S>() > 48 * 1024) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_pcgs_spmv<S, 0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(rba::spmv_lds_bytes<S>())));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_pcgs_spmv<S, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(rba::spmv_lds_bytes<S>())));
+    }
   }
 
   // S = sum_l A_l^T A_l of the CURRENT damped blocks (valid until the next stage 2)
@@ -683,6 +723,7 @@ class Solver final : public rba_solver {
     }
     row_ptr[nc] = nnz;
     sc_nnz_ = nnz;
+    build_spmv_items(row_ptr);
     // upper blocks (ci <= cj; cameras ascend inside a landmark, so i <= j) and, per upper
     // block, the list of contributing observation pairs (counting sort, landmark order)
     std::vector<int> upper_of(size_t(nnz), -1), upper_slot, mirror_slot;
@@ -737,7 +778,7 @@ class Solver final : public rba_solver {
     d_sc_rowptr_.upload(row_ptr.data(), row_ptr.size(), stream_);
     d_sc_cols_.upload(cols.data(), cols.size(), stream_);
     d_sc_diag_.upload(diag.data(), diag.size(), stream_);
-    d_sc_vals_.alloc(size_t(81) * nnz);
+    d_sc_vals_.alloc(size_t(81) * nnz + 4);
     d_sc_JlS_.alloc(6 * size_t(n_obs_));
     d_sc_rS_.alloc(2 * size_t(n_obs_));
     d_sc_M_.alloc(6 * size_t(n_lms_));
@@ -759,6 +800,7 @@ class Solver final : public rba_solver {
   // safe on a partially constructed object
   void release_resources() {
     (void)hipSetDevice(device_);
+    destroy_pcg_graphs();
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (stream2_) (void)hipStreamSynchronize(stream2_);
     if (comm_ && g_rccl.CommDestroy) g_rccl.CommDestroy(comm_);
@@ -772,6 +814,8 @@ class Solver final : public rba_solver {
     }
     if (h_pinned_) (void)hipHostFree(h_pinned_);
     h_pinned_ = nullptr;
+    if (h_progress_) (void)hipHostFree(h_progress_);
+    h_progress_ = nullptr;
     if (stream2_) (void)hipStreamDestroy(stream2_);
     if (stream_) (void)hipStreamDestroy(stream_);
     stream_ = stream2_ = nullptr;
@@ -1156,12 +1200,139 @@ class Solver final : public rba_solver {
     if (!landmark_damping_valid_) throw HipError{"right_multiply_explicit needs a stage 2 first", RBA_ERR_INVALID_ARGUMENT};
     if (!ex_valid_) assemble_explicit();
     d_vin_.upload(static_cast<const S*>(x), nvec_, stream_);
-    hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, exp_, d_vin_.get(),
-                       d_tmp_.get(), static_cast<const int*>(nullptr));
-    hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
-                       d_vin_.get(), d_tmp_.get(), pose_damping_, nvec_);
+    if (fused_pcg_) {
+      // the SpMV of the fused PCG (kernels_pcg.hpp), refresh-product mode, on a cleared state
+      HIP_CHECK(hipMemsetAsync(d_cg_.get(), 0, sizeof(rba::CgState), stream_));
+      hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, d_cg_.get(), double(pose_damping_), 0);
+      launch_pcgs_product(exp_, d_vin_.get(), /*period=*/1);
+      hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, d_tmp_.get(),
+                         d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), nvec_);
+    } else {
+      hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, exp_, d_vin_.get(),
+                         d_tmp_.get(), static_cast<const int*>(nullptr));
+      hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
+                         d_vin_.get(), d_tmp_.get(), pose_damping_, nvec_);
+    }
     d_tmp_.download(static_cast<S*>(y), nvec_, stream_);
     sync();
+  }
+
+  // q = M x + lambda x   (k_pcgs_spmv, refresh-product mode; lambda from the device state)
+  void launch_pcgs_product(const rba::ScParams<S>& M, const S* x, int period) {
+    hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 1>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
+                       M.cols, M.vals, d_items_.get(), static_cast<const S*>(nullptr), static_cast<S*>(nullptr),
+                       static_cast<S*>(nullptr), x, d_qmain_.get(), d_qpart_.get(), d_cg_.get(),
+                       static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
+                       static_cast<double*>(nullptr), 0.0, 0, 0, period, static_cast<int*>(nullptr));
+  }
+
+  static constexpr int kPcgPeriod = 10;  // residual_reset_period (conjugate_gradient.hpp:86-88)
+  static constexpr int kPcgBlock = 5;    // iterations per captured launch graph
+
+  // one PCG iteration of the fused path: product + update (+ the residual refresh)
+  void enqueue_pcgs_iteration(const rba::ScParams<S>& M, bool with_refresh) {
+    constexpr int NB = rba::kPcgBlocks;
+    rba::CgState* st = d_cg_.get();
+    double* part_rho = d_pcg_partials_.get();
+    double* part_q = part_rho + 2 * NB;
+    hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 0>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
+                       M.cols, M.vals, d_items_.get(), d_z_.get(), d_p_.get(), d_p2_.get(),
+                       static_cast<const S*>(nullptr), d_qmain_.get(), d_qpart_.get(), st, part_rho, part_q,
+                       d_pcgs_pq_.get(), opt_.eta, opt_.min_cg_it, opt_.max_cg_it, kPcgPeriod, h_progress_);
+    hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), prm_.b,
+                       d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), d_qmain_.get(),
+                       d_qpart_.get(), d_item_ptr_.get(), n_items_, n_cams_, st, d_pcgs_pq_.get(), part_rho,
+                       part_q, 0, kPcgPeriod, h_progress_);
+    if (with_refresh) {
+      // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
+      launch_pcgs_product(M, d_x_.get(), kPcgPeriod);
+      hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), prm_.b,
+                         d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), d_qmain_.get(),
+                         d_qpart_.get(), d_item_ptr_.get(), n_items_, n_cams_, st, d_pcgs_pq_.get(), part_rho,
+                         part_q, 1, kPcgPeriod, h_progress_);
+    }
+  }
+
+  // the termination test of the last iteration lives in the next product's prologue
+  void enqueue_pcgs_final_test(const rba::ScParams<S>& M) {
+    constexpr int NB = rba::kPcgBlocks;
+    double* part_rho = d_pcg_partials_.get();
+    hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 0>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
+                       M.cols, M.vals, d_items_.get(), d_z_.get(), d_p_.get(), d_p2_.get(),
+                       static_cast<const S*>(nullptr), d_qmain_.get(), d_qpart_.get(), d_cg_.get(), part_rho,
+                       part_rho + 2 * NB, d_pcgs_pq_.get(), opt_.eta, opt_.min_cg_it, opt_.max_cg_it, kPcgPeriod,
+                       h_progress_);
+  }
+
+  // Launch graphs of kPcgBlock iterations (the host cannot issue two launches per 13 us iteration
+  // eagerly): [0] plain, [1] with the residual refresh after the block's last iteration. All
+  // per-solve parameters live in the device state, so the graphs are captured once.
+  void destroy_pcg_graphs() {
+    for (auto& g : pcg_graph_exec_) {
+      if (g) (void)hipGraphExecDestroy(g);
+      g = nullptr;
+    }
+  }
+  void build_pcg_graphs(const rba::ScParams<S>& M) {
+    for (int v = 0; v < 2; ++v) {
+      hipGraph_t graph = nullptr;
+      HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      for (int i = 0; i < kPcgBlock; ++i) enqueue_pcgs_iteration(M, v == 1 && i == kPcgBlock - 1);
+      HIP_CHECK(hipStreamEndCapture(stream_, &graph));
+      HIP_CHECK(hipGraphInstantiate(&pcg_graph_exec_[v], graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+    }
+  }
+
+  // The PCG from iteration `it_start` on, on the assembled matrix M, two launches per iteration
+  // (kernels_pcg.hpp). State (x, r, p, rho/Q history, iteration counter) is taken over from the
+  // round-1 kernels when a solve switches operators mid-way.
+  void pcg_fused(const rba::ScParams<S>& M, S lambda, int it_start) {
+    const int n = nvec_, max_it = opt_.max_cg_it;
+    constexpr int NB = rba::kPcgBlocks, T = rba::kPcgThreads;
+    static_assert(kPcgPeriod % kPcgBlock == 0, "graph blocks must tile the refresh period");
+    rba::CgState* st = d_cg_.get();
+    double* part_rho = d_pcg_partials_.get();
+    // the device reads the direction of `it` completed iterations from P[(it + pswap) & 1]; it is in d_p_ now
+    hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, st, double(lambda), (it_start - 1) & 1);
+    if (it_start > 1) {
+      // operator switch inside a running solve: the residual is recomputed with the operator used
+      // from here on, r = b - (S + lambda I) x, exactly like the periodic refresh
+      launch_pcgs_product(M, d_x_.get(), 1);
+      hipLaunchKernelGGL((rba::k_pcgs_residual<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, prm_.b,
+                         d_r_.get(), d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), n, st);
+    }
+    hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(), d_z_.get(),
+                       n, st, part_rho);
+    if (use_pcg_graphs_ && !pcg_graph_exec_[0]) build_pcg_graphs(M);
+    volatile int* hp = h_progress_;
+    hp[0] = it_start - 1;
+    hp[1] = 0;
+    // run-ahead throttle: the device publishes the iteration it has started; launches queued
+    // after the termination are no-ops
+    auto wait_for = [&](int it, int ahead) {
+      long spins = 0;
+      while (!hp[1] && it - hp[0] > ahead)
+        if ((++spins & 0x3fff) == 0 && hipStreamQuery(stream_) == hipSuccess) break;  // nothing left in flight
+      return hp[1] == 0;
+    };
+    int it = it_start;
+    bool running = true;
+    while (running && it <= max_it) {
+      const bool aligned = (it - 1) % kPcgBlock == 0;
+      if (use_pcg_graphs_ && aligned && it + kPcgBlock - 1 <= max_it) {
+        if (!(running = wait_for(it, kPcgBlock))) break;  // at most one block queued behind the running one
+        const bool refresh = (it + kPcgBlock - 1) % kPcgPeriod == 0;
+        HIP_CHECK(hipGraphLaunch(pcg_graph_exec_[refresh ? 1 : 0], stream_));
+        it += kPcgBlock;
+      } else {
+        if (!(running = wait_for(it, pcg_run_ahead_))) break;
+        enqueue_pcgs_iteration(M, it % kPcgPeriod == 0);
+        ++it;
+      }
+    }
+    if (running && wait_for(it, pcg_run_ahead_)) enqueue_pcgs_final_test(M);
+    HIP_CHECK(hipGetLastError());
   }
 
   // ---- solve = stage 2 + preconditioner + PCG ------------------------------------
@@ -1181,6 +1352,15 @@ class Solver final : public rba_solver {
     hx_event_count_ = 0;
     hx_calls_ = 0;
     rba_cg_summary cg = pcg(sc_ ? S(0) : lambda);  // SC: the damping is inside the matrix
+    if (pcg_used_explicit_ && !sc_ && (cg.termination_type == 2 || pcg_indefinite_)) {
+      // The assembled operator is S + E with |E| ~ eps |S|: unlike the square-root product
+      // (p.q = |A p|^2 + lambda |p|^2 >= 0 by construction) it can lose definiteness when
+      // lambda < eps |S|. The reference's operator cannot - repeat this solve matrix-free.
+      explicit_off_for_solve_ = true;
+      ++explicit_fallbacks_;
+      cg = pcg(lambda);
+      explicit_off_for_solve_ = false;
+    }
     hipLaunchKernelGGL((rba::k_negate<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                        d_x_.get(), nvec_);
     d_x_.download(static_cast<S*>(inc_out), nvec_, stream_);
@@ -1243,13 +1423,22 @@ class Solver final : public rba_solver {
     // solves need 2-3 iterations), every 4th later; kernels queued past the end
     // are no-ops (`done`).
     ex_active_ = false;
-    for (int it = 1; it <= max_it; ++it) {
+    pcg_used_explicit_ = false;
+    const bool fused = fused_pcg_ && n_items_ > 0 && opt_.preconditioner_type == 1;
+    bool go_fused = sc_ && fused;  // explicit Schur-complement backend: the matrix exists from the start
+    int it = 1;
+    for (; it <= max_it && !go_fused; ++it) {
       // Long solve: from here on the product is an SpMV with the explicitly assembled
       // S = sum_l A_l^T A_l (one assembly ~ 16 matrix-free products on venice; S is all-reduced
       // once, after which the iterations need no collective at all)
-      if (ex_ready_ && !ex_active_ && it > explicit_after_) {
+      if (ex_ready_ && !ex_active_ && !explicit_off_for_solve_ && it > explicit_after_) {
         if (!ex_valid_) assemble_explicit();
         ex_active_ = true;
+        pcg_used_explicit_ = true;
+        if (fused) {
+          go_fused = true;
+          break;
+        }
       }
       if (opt_.preconditioner_type == 2) {
         // z = sum_{i=0..order} (Hpp^-1 E0)^i Hpp^-1 r   (PowerSCPreconditioner::solve_assign,
@@ -1299,9 +1488,15 @@ class Solver final : public rba_solver {
         if (hst->done) break;
       }
     }
+    if (go_fused) {
+      pcg_fused(sc_ ? scp_ : exp_, lambda, it);
+      HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
+      sync();
+    }
     ex_active_ = false;
     summary.termination_type = hst->termination;
-    summary.num_iterations = hst->iter;
+    summary.num_iterations = hst->result_iter;
+    pcg_indefinite_ = hst->indefinite != 0;
     return summary;
   }
 
@@ -1687,6 +1882,19 @@ class Solver final : public rba_solver {
   DevBuf<int> d_ex_rowptr_, d_ex_cols_, d_ex_diag_, d_ex_upper_, d_ex_mirror_, d_ex_pair_oi_, d_ex_pair_oj_;
   DevBuf<int64_t> d_ex_pair_ptr_;
   DevBuf<S> d_ex_vals_, d_ex_topdT_;
+  // fused PCG on the assembled matrix (kernels_pcg.hpp)
+  DevBuf<rba::SpmvItem> d_items_;
+  DevBuf<int> d_item_ptr_;
+  DevBuf<S> d_qpart_, d_qmain_, d_p2_;  // extra-item partials, q, second direction buffer
+  DevBuf<double> d_pcgs_pq_;
+  int n_items_ = 0;
+  int* h_progress_ = nullptr;  // pinned: [0] iteration started on the device, [1] done
+  bool pcg_used_explicit_ = false, pcg_indefinite_ = false, explicit_off_for_solve_ = false;
+  int explicit_fallbacks_ = 0;  // solves repeated matrix-free after the assembled operator broke down
+  hipGraphExec_t pcg_graph_exec_[2] = {nullptr, nullptr};
+  bool use_pcg_graphs_ = true;  // RBA_PCG_GRAPHS=0: eager launches
+  bool fused_pcg_ = true;      // RBA_FUSED_PCG=0: the seven-launch iteration of round 1
+  int pcg_run_ahead_ = 6;      // iterations the host may queue ahead of the device
   // explicit Schur-complement backend (solver_type = 1)
   bool sc_ = false;
   int sc_nnz_ = 0;
