@@ -459,6 +459,7 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_FUSED_PCG")) fused_pcg_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_PCG_RUN_AHEAD")) pcg_run_ahead_ = std::max(1, std::atoi(ev));
     if (const char* ev = std::getenv("RBA_PCG_GRAPHS")) use_pcg_graphs_ = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("RBA_SWITCH_REFRESH")) switch_refresh_ = std::atoi(ev) != 0;
     HIP_CHECK(hipEventCreate(&ev_a_));
     HIP_CHECK(hipEventCreate(&ev_asm0_));
     HIP_CHECK(hipEventCreate(&ev_asm1_));
@@ -1295,7 +1296,7 @@ class Solver final : public rba_solver {
     double* part_rho = d_pcg_partials_.get();
     // the device reads the direction of `it` completed iterations from P[(it + pswap) & 1]; it is in d_p_ now
     hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, st, double(lambda), (it_start - 1) & 1);
-    if (it_start > 1) {
+    if (it_start > 1 && switch_refresh_) {
       // operator switch inside a running solve: the residual is recomputed with the operator used
       // from here on, r = b - (S + lambda I) x, exactly like the periodic refresh
       launch_pcgs_product(M, d_x_.get(), 1);
@@ -1893,6 +1894,7 @@ class Solver final : public rba_solver {
   int explicit_fallbacks_ = 0;  // solves repeated matrix-free after the assembled operator broke down
   hipGraphExec_t pcg_graph_exec_[2] = {nullptr, nullptr};
   bool use_pcg_graphs_ = true;  // RBA_PCG_GRAPHS=0: eager launches
+  bool switch_refresh_ = true;  // RBA_SWITCH_REFRESH=0: keep the recursive residual across the operator switch
   bool fused_pcg_ = true;      // RBA_FUSED_PCG=0: the seven-launch iteration of round 1
   int pcg_run_ahead_ = 6;      // iterations the host may queue ahead of the device
   // explicit Schur-complement backend (solver_type = 1)
