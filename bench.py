@@ -9,17 +9,20 @@ stage 1 (when the linearisation point moved), stage 2 + preconditioner + PCG,
 back-substitution + camera update, compute_error.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 shards the landmarks of the SAME problem over the ranks (strong scaling);
-the camera-sized vectors are all-reduced with RCCL inside the library.
-Rank 0 prints one JSON line.
+N > 1 shards the landmarks of the SAME problem over N ranks (strong scaling); the
+camera-sized vectors are all-reduced with RCCL inside the library. When WORLD_SIZE is
+not set and N > 1 the script launches its N ranks itself (torch.distributed.run on
+127.0.0.1); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+it runs as one of them. Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,11 +40,14 @@ def log(*a):
 
 
 def shard_ranges(k: np.ndarray, n: int):
-    """Contiguous landmark ranges balanced by sum(k^2) (bytes of the blocks)."""
+    """Contiguous landmark ranges balanced by sum(k^2) (bytes of the blocks); every rank gets >= 1 landmark."""
+    if k.size < n:
+        raise SystemExit(f"cannot shard {k.size} landmarks over {n} ranks")
     w = np.cumsum(k.astype(np.float64) ** 2)
     cuts = [0]
     for r in range(1, n):
-        cuts.append(int(np.searchsorted(w, w[-1] * r / n)))
+        c = int(np.searchsorted(w, w[-1] * r / n))
+        cuts.append(min(max(c, cuts[-1] + 1), k.size - (n - r)))
     cuts.append(k.size)
     return [(cuts[i], cuts[i + 1]) for i in range(n)]
 
@@ -54,14 +60,18 @@ def take_landmarks(prob, lo: int, hi: int):
                       prob.obs_cam_idx[o0:o1].copy(), prob.obs_xy[o0:o1].copy(), prob.name)
 
 
+REAL_FILES = {
+    "venice-1778": ("venice", "problem-1778-993923-pre.txt"),
+    "ladybug-49": ("ladybug", "problem-49-7776-pre.txt"),
+    "trafalgar-257": ("trafalgar", "problem-257-65132-pre.txt"),
+    "final-13682": ("final", "problem-13682-4456117-pre.txt"),
+}
+
+
 def make_problem(workload: str, args):
     from rootba_amd import problem as P
-    real = os.path.join(ROOT, "..", "rootba_data", "bal", *{
-        "venice-1778": ("venice", "problem-1778-993923-pre.txt"),
-        "ladybug-49": ("ladybug", "problem-49-7776-pre.txt"),
-        "trafalgar-257": ("trafalgar", "problem-257-65132-pre.txt"),
-        "final-13682": ("final", "problem-13682-4456117-pre.txt"),
-    }[workload])
+    base = workload.split("+")[0]
+    real = os.path.join(ROOT, "..", "rootba_data", "bal", *REAL_FILES.get(base, ("none", "none")))
     if os.path.exists(real):
         raw, data = P.read_bal(real), "real"
     else:
@@ -76,11 +86,11 @@ _SOLVER_KW = {}
 _GPU_KW = {}  # switches that exist only in the HIP library
 
 
-def solver_options(mod, n_iter: int):
-    # reference defaults + CVPR'21 common settings (Huber 1.0); no early stop so
-    # that exactly warmup+steps LM iterations are executed
+def solver_options(mod, n_iter: int, function_tolerance: float = 0.0):
+    # reference defaults + CVPR'21 common settings (Huber 1.0); function_tolerance = 0 so that
+    # exactly warmup+steps LM iterations are executed in the timed run
     return mod.default_options(robust_norm=1, huber_parameter=1.0, max_num_iterations=n_iter,
-                               function_tolerance=0.0, **_SOLVER_KW)
+                               function_tolerance=function_tolerance, **_SOLVER_KW)
 
 
 def cpu_baseline(prob, n_iter: int, gpu_rows):
@@ -97,16 +107,65 @@ def cpu_baseline(prob, n_iter: int, gpu_rows):
     tg = sum(r.iteration_time for r in g)
     for r in its:
         log(f"[cpu_baseline] it {r.iteration} cg {r.cg_iterations} cost {r.cost:.6e} t {r.iteration_time:.2f}s")
+    n_cg = sum(r.cg_iterations for r in its)
+    t_pcg = sum(r.pcg_time for r in its)
+    hx_gb = getattr(cpu_baseline, "dense_hx_bytes", 0) / 1e9
     return {
         "value": len(its) / t if t > 0 else None,
         "unit": "LM iterations/s",
         "cores": o.num_threads(),
         "kind": "port",
-        "sample": (f"LM iterations 1..{n_iter} of the same problem, f32, "
-                   f"{sum(r.cg_iterations for r in its)} CG iterations in total; "
+        "sample": (f"LM iterations 1..{n_iter} of the same problem, {np.dtype(DTYPE).name}, "
+                   f"{n_cg} CG iterations in total; "
                    f"the GPU path runs the same {n_iter} iterations at {len(g) / tg if tg > 0 else 0:.1f} it/s"),
+        "product_GBps": ((n_cg + n_cg // 10) * hx_gb / t_pcg) if t_pcg > 0 and hx_gb > 0 else None,
         "final_cost_rel_diff_vs_gpu": (abs(its[-1].cost - g[-1].cost) / its[-1].cost) if g and its else None,
     }
+
+
+def self_launch(args_list, n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks on this node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *args_list]
+    log(f"[bench] WORLD_SIZE is not set: launching {n} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def reference_semantics_run(local, prob_name, rank, world, local_rank, comm_setup):
+    """The same LM run with the reference's own stopping rule (function_tolerance = 1e-6,
+    bal_bundle_adjustment.cpp:174-201, 476-481): it/s over iterations 1..(iteration where it fires)."""
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    opts = solver_options(L, 50, function_tolerance=1e-6)
+    for key, val in _GPU_KW.items():
+        setattr(opts, key, val)
+    lin = LinearizorHIP(local, DTYPE, opts, device=local_rank)
+    comm_setup(lin)
+    lin.lm_begin()
+    lin.lm_step()  # iteration 0: evaluation only
+    lin.synchronize()
+    t0 = time.perf_counter()
+    n, cg, more, cost = 0, 0, True, None
+    while more:
+        row, more = lin.lm_step()
+        n += 1
+        cg += row.cg_iterations
+        if row.step_is_successful:
+            cost = row.cost
+    lin.synchronize()
+    t = time.perf_counter() - t0
+    term = lin.lm_termination()
+    lin.close()
+    return {"value": n / t, "unit": "LM iterations/s", "iterations": n, "seconds": t, "cg_iterations": cg,
+            "termination": {0: "NO_CONVERGENCE", 1: "CONVERGED", -1: "FAILURE"}.get(term, str(term)),
+            "final_cost": cost,
+            "rule": "iterations 1..k, k = first iteration with |cost change| <= 1e-6 cost (the reference's "
+                    "function_tolerance); the headline `value` runs exactly --steps iterations with the rule off"}
 
 
 def main():
@@ -131,7 +190,11 @@ def main():
     ap.add_argument("--solver-type", choices=["SQUARE_ROOT", "SCHUR_COMPLEMENT"], default="SQUARE_ROOT",
                     help="SCHUR_COMPLEMENT: explicit reduced camera matrix + SpMV (SURVEY.md 8f #4), 1 GPU")
     ap.add_argument("--use-double", action="store_true", help="float64 (BASELINE metric is float32)")
+    ap.add_argument("--no-reference-semantics", action="store_true",
+                    help="skip the second run with the reference's function_tolerance stopping rule")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
     global DTYPE
     DTYPE = np.float64 if args.use_double else np.float32
     args.implicit_q = not args.dense_blocks
@@ -145,9 +208,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong "
+                         f"number of ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the solver has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -171,38 +237,45 @@ def main():
     t0 = time.perf_counter()
     lin = LinearizorHIP(local, DTYPE, gpu_opts, device=local_rank)
     log(f"[rank {rank}] solver set up in {time.perf_counter() - t0:.2f}s (rba_create: sort by track length, "
-        f"CSC index, block structure of the reduced matrix, device allocation)")
-    transport = "RCCL all-reduce of camera vectors"
+        f"CSC index, block structure of the reduced matrix, launch graphs, device allocation)")
+
+    # ---- transport: decided COLLECTIVELY before anybody enters ncclCommInitRank ------------------
+    use_callback = [False]
     if world > 1:
-        ok = 1
-        uid = [None]
-        if rank == 0:
-            try:
-                uid = [LinearizorHIP.comm_unique_id()]
-            except Exception as e:  # librccl could not be loaded by the library
-                log(f"[rank 0] rba_comm_unique_id failed: {e!r}")
-        dist.broadcast_object_list(uid, src=0)  # every rank takes part, whatever happened on rank 0
-        if uid[0] is None:
-            ok = 0
-        else:
-            try:
-                lin.comm_init(rank, world, uid[0])
-            except Exception as e:  # the library's own communicator cannot be created on this node
-                log(f"[rank {rank}] rba_comm_init failed: {e!r}")
-                ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        probe = 1
+        try:
+            LinearizorHIP.comm_unique_id()  # can this rank load librccl and talk to it at all?
+        except Exception as e:
+            log(f"[rank {rank}] RCCL probe failed: {e!r}")
+            probe = 0
+        flag = torch.tensor([probe], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            # safety net: the library's callback transport, backed by torch.distributed (host staging)
+        use_callback[0] = int(flag.item()) == 0
+        if use_callback[0]:
+            log(f"[rank {rank}] RCCL is not usable on every rank: ALL ranks use the callback transport "
+                f"(torch.distributed all-reduce, host staging)")
+
+    def comm_setup(solver):
+        if world == 1:
+            return
+        if use_callback[0]:
             def allreduce(arr, op):
                 t = torch.from_numpy(arr).cuda()
                 dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
                 arr[...] = t.cpu().numpy()
+            solver.comm_init_callback(rank, world, allreduce)
+        else:
+            uid = [LinearizorHIP.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            solver.comm_init(rank, world, uid[0])  # a failure here is fatal (no silent fallback)
+        info = solver.comm_info()
+        if info["nranks"] != world or info["rank"] != rank:
+            raise SystemExit(f"rank {rank}: the library's communicator reports {info}, expected {world} ranks")
 
-            lin.comm_init_callback(rank, world, allreduce)
-            transport = "torch.distributed all-reduce through the callback transport (rba_comm_init failed)"
-            log(f"[rank {rank}] using the callback transport")
+    comm_setup(lin)
+    info = lin.comm_info()
     stats = lin.problem_stats()
+    bytes_model = lin.byte_model()
 
     def barrier():
         if world > 1:
@@ -212,24 +285,36 @@ def main():
     rows, hx_time, hx_calls = [], 0.0, 0
     lin.lm_begin()
     for _ in range(args.warmup):
-        row, _more = lin.lm_step()
+        row, more = lin.lm_step()
         rows.append(row)
+        if not more:
+            raise SystemExit(f"the LM loop terminated during warm-up (iteration {row.iteration}): no valid measurement")
     lin.synchronize()
+    comm0 = lin.comm_stats()
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        row, _more = lin.lm_step()
+    for s_ in range(args.steps):
+        row, more = lin.lm_step()
         rows.append(row)
         tm = lin.timings()
         hx_time += tm.hx_time
         hx_calls += tm.hx_calls
+        if not more and s_ + 1 < args.steps:
+            raise SystemExit(f"the LM loop terminated after {s_ + 1} of {args.steps} timed steps (iteration "
+                             f"{row.iteration}, lambda {row.lambda_:.2e}): refusing to count no-op steps")
     lin.synchronize()
     barrier()
     elapsed = time.perf_counter() - t_start
+    comm1 = lin.comm_stats()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    lin.close()
+
+    ref_sem = None
+    if not args.no_reference_semantics:
+        ref_sem = reference_semantics_run(local, prob.name, rank, world, local_rank, comm_setup)
 
     if rank == 0:
         timed = rows[args.warmup:]
@@ -238,17 +323,50 @@ def main():
                 f"lambda {r.lambda_:.2e} t {r.iteration_time * 1e3:8.2f} ms (s1 {r.stage1_time * 1e3:.2f} "
                 f"s2 {r.stage2_time * 1e3:.2f} pcg {r.pcg_time * 1e3:.2f} bs {r.backsub_time * 1e3:.2f} "
                 f"err {r.residual_time * 1e3:.2f})")
+        sc = args.solver_type == "SCHUR_COMPLEMENT"
         avg_hx = hx_time / hx_calls if hx_calls else None
         achieved = stats["hx_bytes"] / avg_hx / 1e9 if avg_hx else None
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hx_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.solver_type == "SQUARE_ROOT":
+        if os.path.exists(tpath) and world == 1 and not sc:
             try:
                 with open(tpath) as f:
                     key = args.workload + ("/implicit_q" if args.implicit_q else "")
                     traffic = json.load(f).get(key, {}).get("traffic_bytes_per_launch")
+                traffic_source = ("profiles/hx_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  "scripts/run_pmc_traffic.sh on this kernel and workload; not measured in this run)")
             except Exception:
                 traffic = None
+
+        # per-stage and whole-iteration rooflines from the HIP-event stage timers of the timed rows and
+        # the library's byte model (include/rootba_hip.h: rba_byte_model)
+        def frac(nbytes, secs):
+            return nbytes / secs / 1e9 / HBM_PEAK_GBS if secs > 0 else None
+        n_t = max(1, len(timed))
+        n_lin = sum(1 for r in timed if r.stage1_time > 0)
+        t_s1 = sum(r.stage1_time for r in timed)
+        t_s2 = sum(r.stage2_time for r in timed)
+        t_bs = sum(r.backsub_time for r in timed)
+        t_err = sum(r.residual_time for r in timed)
+        t_pcg = sum(r.pcg_time for r in timed)
+        n_cg = sum(r.cg_iterations for r in timed)
+        n_err = sum(2 if r.stage1_time > 0 else 1 for r in timed)
+        b_iter = (bytes_model["stage1"] * n_lin + bytes_model["stage2"] * n_t + bytes_model["back_substitution"] * n_t +
+                  bytes_model["compute_error"] * n_err)
+        stages = {
+            "stage1": {"bytes_per_launch": bytes_model["stage1"], "ms": 1e3 * t_s1 / max(1, n_lin),
+                       "frac": frac(bytes_model["stage1"] * n_lin, t_s1)},
+            "stage2": {"bytes_per_launch": bytes_model["stage2"], "ms": 1e3 * t_s2 / n_t,
+                       "frac": frac(bytes_model["stage2"] * n_t, t_s2)},
+            "back_substitution": {"bytes_per_launch": bytes_model["back_substitution"], "ms": 1e3 * t_bs / n_t,
+                                  "frac": frac(bytes_model["back_substitution"] * n_t, t_bs)},
+            "compute_error": {"bytes_per_launch": bytes_model["compute_error"], "ms": 1e3 * t_err / max(1, n_err),
+                              "frac": frac(bytes_model["compute_error"] * n_err, t_err)},
+            "pcg": {"ms_per_step": 1e3 * t_pcg / n_t, "cg_iterations": n_cg,
+                    "bytes_per_matrix_free_product": bytes_model["product_matrix_free"],
+                    "bytes_per_assembled_product": bytes_model["product_assembled"],
+                    "bytes_per_assembly": bytes_model["assembly"]},
+        }
         out = {
             "metric": "LM iterations/sec (linearize+QR+PCG+back-sub) on BAL venice-1778",
             "value": args.steps / elapsed,
@@ -265,16 +383,25 @@ def main():
             "config": {
                 "workload": f"BAL {args.workload} ({data}): {prob.n_cams} cams, {prob.n_lms} lms, {prob.n_obs} obs, "
                             f"solver={args.solver_type}, {args.preconditioner}, Huber(1), {'float64' if DTYPE == np.float64 else 'float32'}",
-                "parallelism": f"landmarks sharded over {world} GPU(s), {transport}",
+                "parallelism": (f"landmarks sharded over {world} GPU(s); library communicator: transport="
+                                f"{info['transport']}, nranks={info['nranks']}"
+                                + ("" if world == 1 else "; all-reduce of camera-sized vectors / the assembled matrix")),
+                "comm_per_step": None if world == 1 else {
+                    "all_reduces": (comm1["calls"] - comm0["calls"]) / args.steps,
+                    "bytes": (comm1["bytes"] - comm0["bytes"]) / args.steps,
+                    "ms": 1e3 * (comm1["seconds"] - comm0["seconds"]) / args.steps},
                 "explicit_after": int(os.environ.get("RBA_EXPLICIT_AFTER", gpu_opts.explicit_after)),
+                "function_tolerance": 0.0,
+                "compute_error_per_iteration": "2 (start of every outer iteration + after the step, as the reference)",
                 "cg_iterations_per_step": sum(r.cg_iterations for r in timed) / max(1, len(timed)),
                 "successful_steps": sum(r.step_is_successful for r in timed),
                 "initial_cost": rows[0].cost,
                 "final_cost": [r.cost for r in rows if r.step_is_successful][-1],
+                "value_reference_semantics": ref_sem,
             },
             "roofline": {
-                "kernel": ("k_sc_spmv (S*x on the explicit block-CSR reduced camera matrix; algorithmic bytes = "
-                           "81 s + 4 per block + 2 x 9 n_c s)" if args.solver_type == "SCHUR_COMPLEMENT" else
+                "kernel": ("k_pcgs_spmv (S*x on the explicit block-CSR reduced camera matrix; algorithmic bytes = "
+                           "81 s + 4 per block + 2 x 9 n_c s)" if sc else
                            "k_hx_implicit (H*x from the QR factors; algorithmic bytes = SURVEY.md 8d implicit-Q formula)"
                            if args.implicit_q else
                            "k_hx (H*x = sum_l A_l^T A_l x, all k-classes of one right_multiply)"),
@@ -284,19 +411,28 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": stats["hx_bytes"],
                 "avg_launch_ms": avg_hx * 1e3 if avg_hx else None,
                 "launches_timed": hx_calls,
+                "whole_iteration": {
+                    "what": "sum over the stage kernels (stage 1, stage 2, back-substitution, cost evaluations; "
+                            "the PCG is reported separately) of the bytes each must move in this layout / "
+                            "their summed HIP-event times / 8 TB/s",
+                    "frac": frac(b_iter, t_s1 + t_s2 + t_bs + t_err),
+                    "bytes_per_step": b_iter / n_t,
+                },
+                "stages": stages,
             },
         }
         if world == 1 and args.cpu_baseline_iters > 0:
             try:
+                cpu_baseline.dense_hx_bytes = 0
                 out["cpu_baseline"] = cpu_baseline(prob, args.cpu_baseline_iters, rows)
             except Exception as e:  # the baseline must never take the GPU number down
                 log(f"[cpu_baseline] failed: {e!r}")
                 out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    lin.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -53,7 +53,9 @@ extern "C" {
  *  src/rootba/solver/linearizor_qr.cpp:58-68, linearizor_base.cpp:87-93,
  *  bal_bundle_adjustment.cpp:264-272). Field names follow SolverOptions. */
 typedef struct rba_options {
-  int use_householder;            /* use_householder_marginalization (only 1 supported) */
+  int use_householder;            /* use_householder_marginalization; 0 (Givens, ipp:700-715) is accepted and
+                                     executed with Householder reflectors: every consumer of the block is
+                                     invariant to the choice of the orthogonal factor */
   int use_valid_projections_only; /* = use_projection_validity_check()            */
   int robust_norm;                /* 0 NONE, 1 HUBER (bal_residual_options.hpp)   */
   double huber_parameter;
@@ -174,6 +176,16 @@ int rba_comm_init(rba_handle h, int rank, int nranks, const void* unique_id128);
 typedef int (*rba_allreduce_fn)(void* ctx, void* host_buf, int64_t count, int dtype, int op);
 int rba_comm_init_callback(rba_handle h, int rank, int nranks, rba_allreduce_fn fn, void* ctx);
 
+/* What the handle's communicator looks like: *transport_out = 0 none (single GPU), 1 RCCL, 2 caller
+ * callback; *nranks_out = number of ranks (for RCCL: as reported by ncclCommCount on the live
+ * communicator, not the value passed in). */
+int rba_comm_info(rba_handle h, int* rank_out, int* nranks_out, int* transport_out);
+/* All-reduce traffic since rba_create: number of collectives, payload bytes, and device seconds
+ * (HIP events around every collective on the solver stream; the callback transport reports host
+ * wall time). Five call sites, SURVEY.md 8e: Jp_diag2 (+ failure flag), [b | block diagonal],
+ * every matrix-free product, the assembled matrix (once per assembly), residual sums / l_diff. */
+int rba_get_comm_stats(rba_handle h, int64_t* calls_out, int64_t* bytes_out, double* seconds_out);
+
 /* BalProblem state upload/download (Camera::params()/from_params(),
  * bal_problem.hpp:84-95; copy_to/from_camera_state, bal_problem.cpp:570-588). */
 int rba_set_state(rba_handle h, const void* cams10, const void* lms3);
@@ -248,6 +260,21 @@ int rba_get_landmark_R(rba_handle h, int damped, void* R6_per_lm,
 /* Algorithmic byte/flop counts of the resident topology. */
 int rba_get_problem_stats(rba_handle h, int64_t* block_storage_bytes,
                           int64_t* hx_algorithmic_bytes, int64_t* hx_flops);
+
+/* Bytes that one launch group must move through HBM in THIS library's data layout (DESIGN.md 2-3;
+ * compulsory traffic: every record read or written once, camera-sized vectors once per kernel).
+ * bench.py divides them by the measured stage times for the per-stage and whole-iteration rooflines. */
+typedef struct rba_byte_model {
+  int64_t compute_error;       /* one cost evaluation                                        */
+  int64_t stage1;              /* one linearisation: geometry, landmark QR, camera-major sums */
+  int64_t stage2;              /* landmark damping + per-observation rotation + camera-major sums */
+  int64_t product_matrix_free; /* one H x from the QR factors (implicit_q) / the dense blocks */
+  int64_t product_assembled;   /* one S x on the assembled block-CSR matrix                   */
+  int64_t assembly;            /* one assembly of the reduced camera matrix                   */
+  int64_t pcg_vectors;         /* vector / preconditioner work of one PCG iteration           */
+  int64_t back_substitution;   /* back-substitution + landmark update                         */
+} rba_byte_model;
+int rba_get_byte_model(rba_handle h, rba_byte_model* out);
 
 #ifdef __cplusplus
 }

@@ -109,12 +109,19 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, 
 # every symbol include/rootba_hip.h declares
 EXPORTS = [
     "rba_default_options", "rba_last_error", "rba_device_count", "rba_create", "rba_destroy",
-    "rba_comm_unique_id", "rba_comm_init", "rba_comm_init_callback", "rba_set_state", "rba_get_state", "rba_backup",
+    "rba_comm_unique_id", "rba_comm_init", "rba_comm_init_callback", "rba_comm_info", "rba_get_comm_stats",
+    "rba_set_state", "rba_get_state", "rba_backup",
     "rba_restore", "rba_compute_error", "rba_linearize", "rba_solve", "rba_stage2",
     "rba_right_multiply", "rba_right_multiply_explicit", "rba_apply", "rba_back_substitute", "rba_optimize_lm", "rba_lm_begin", "rba_lm_step", "rba_lm_termination", "rba_synchronize",
     "rba_get_timings", "rba_debug_read_blocks",
     "rba_get_jl_col_scale", "rba_get_pose_scaling", "rba_get_landmark_R", "rba_get_problem_stats",
+    "rba_get_byte_model",
 ]
+
+
+class RbaByteModel(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("compute_error", "stage1", "stage2", "product_matrix_free",
+                                         "product_assembled", "assembly", "pcg_vectors", "back_substitution")]
 
 _lib = None
 

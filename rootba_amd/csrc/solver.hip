@@ -94,6 +94,7 @@ struct Rccl {
   int (*GetUniqueId)(UniqueId*) = nullptr;
   int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool load() {
@@ -104,6 +105,7 @@ struct Rccl {
     GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
     return GetUniqueId && CommInitRank && CommDestroy && AllReduce;
@@ -123,6 +125,8 @@ struct rba_solver {
   virtual ~rba_solver() = default;
   virtual void comm_init(int rank, int nranks, const void* uid) = 0;
   virtual void comm_init_callback(int rank, int nranks, rba_allreduce_fn fn, void* ctx) = 0;
+  virtual void comm_info(int* rank, int* nranks, int* transport) = 0;
+  virtual void comm_stats(int64_t* calls, int64_t* bytes, double* seconds) = 0;
   virtual void set_state(const void* cams, const void* lms) = 0;
   virtual void get_state(void* cams, void* lms) = 0;
   virtual void backup() = 0;
@@ -145,6 +149,7 @@ struct rba_solver {
   virtual void get_pose_scaling(void* out) = 0;
   virtual void get_landmark_R(int damped, void* R6, void* q3) = 0;
   virtual void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) = 0;
+  virtual void get_byte_model(rba_byte_model* out) = 0;
 };
 
 namespace {
@@ -238,6 +243,7 @@ class Solver final : public rba_solver {
     }
     lm_obs[n_lms] = o;
     lm_blk[n_lms] = blk;
+    storage_dense_bytes_ = int64_t(sizeof(S)) * blk;
     // CSC index camera -> observations (sorted-observation numbering), used by
     // the camera-major reductions
     std::vector<int64_t> cam_off(n_cams + 1, 0);
@@ -559,6 +565,9 @@ class Solver final : public rba_solver {
       scp_.huber = prm_.huber;
       scp_.eps = prm_.eps;
     }
+    // capture the launch graphs of the fused PCG now (one-off cost, not part of an LM iteration)
+    if (fused_pcg_ && use_pcg_graphs_ && n_items_ > 0 && opt_.preconditioner_type == 1 && (sc_ || ex_ready_))
+      build_pcg_graphs(sc_ ? scp_ : exp_);
   }
 
   // Block-CSR structure for the explicit reduced matrix of the square-root solver, from the
@@ -598,6 +607,7 @@ class Solver final : public rba_solver {
     }
     for (int t = 0; t < n_upper; ++t) pair_ptr[t + 1] += pair_ptr[t];
     const int64_t n_pairs = pair_ptr[n_upper];
+    ex_pairs_ = n_pairs;
     std::vector<int> pair_oi(n_pairs), pair_oj(n_pairs);
     {
       std::vector<int64_t> fill(pair_ptr.begin(), pair_ptr.end() - 1);
@@ -809,6 +819,9 @@ class Solver final : public rba_solver {
     for (auto& e : hx_events_)
       if (e) (void)hipEventDestroy(e);
     hx_events_.clear();
+    for (auto& e : comm_events_)
+      if (e) (void)hipEventDestroy(e);
+    comm_events_.clear();
     for (hipEvent_t* e : {&ev_a_, &ev_b_, &ev_asm0_, &ev_asm1_, &ev_fork_, &ev_join_}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
@@ -867,10 +880,63 @@ class Solver final : public rba_solver {
     union_structure_over_ranks();
   }
 
+  void comm_info(int* rank, int* nranks, int* transport) override {
+    *rank = rank_;
+    *transport = comm_ ? 1 : (cb_fn_ ? 2 : 0);
+    *nranks = nranks_;
+    if (comm_ && g_rccl.CommCount) {
+      int n = 0;
+      if (g_rccl.CommCount(comm_, &n) == 0) *nranks = n;
+    }
+  }
+  void comm_stats(int64_t* calls, int64_t* bytes, double* seconds) override {
+    use_device();
+    flush_comm_events(true);
+    *calls = comm_calls_;
+    *bytes = comm_bytes_;
+    *seconds = comm_seconds_;
+  }
+  // elapsed time of the recorded collectives (event pairs are recycled)
+  void flush_comm_events(bool wait) {
+    if (comm_ev_used_ == 0) return;
+    if (wait) sync();
+    for (int i = 0; i < comm_ev_used_; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, comm_events_[2 * i], comm_events_[2 * i + 1]) == hipSuccess)
+        comm_seconds_ += double(ms) * 1e-3;
+    }
+    comm_ev_used_ = 0;
+  }
+
   template <class T>
   void all_reduce(T* buf, size_t count, int op = kNcclSum) {
     if (!comm_ && !cb_fn_) return;
+    ++comm_calls_;
+    comm_bytes_ += int64_t(count * sizeof(T));
     if (cb_fn_) {
+      const double t0 = wall_seconds();
+      all_reduce_callback(buf, count, op);
+      comm_seconds_ += wall_seconds() - t0;
+      return;
+    }
+    if (comm_ev_used_ == kCommEvents) flush_comm_events(true);
+    if (comm_events_.empty()) {
+      comm_events_.assign(2 * kCommEvents, nullptr);
+      for (auto& e : comm_events_) HIP_CHECK(hipEventCreate(&e));
+    }
+    HIP_CHECK(hipEventRecord(comm_events_[2 * comm_ev_used_], stream_));
+    const int dt = std::is_same<T, float>::value    ? kNcclFloat32
+                   : std::is_same<T, double>::value ? kNcclFloat64
+                                                    : kNcclInt32;
+    const int rc = g_rccl.AllReduce(buf, buf, count, dt, op, comm_, stream_);
+    if (rc != 0) throw HipError{"ncclAllReduce failed: " + std::to_string(rc), RBA_ERR_COMM};
+    HIP_CHECK(hipEventRecord(comm_events_[2 * comm_ev_used_ + 1], stream_));
+    ++comm_ev_used_;
+  }
+
+  template <class T>
+  void all_reduce_callback(T* buf, size_t count, int op) {
+    {
       // caller-provided collective on a host staging buffer (MPI, gloo, ...)
       cb_stage_.resize(count * sizeof(T));
       HIP_CHECK(hipMemcpyAsync(cb_stage_.data(), buf, count * sizeof(T), hipMemcpyDeviceToHost, stream_));
@@ -880,13 +946,7 @@ class Solver final : public rba_solver {
       if (rc != 0) throw HipError{"all-reduce callback failed: " + std::to_string(rc), RBA_ERR_COMM};
       HIP_CHECK(hipMemcpyAsync(buf, cb_stage_.data(), count * sizeof(T), hipMemcpyHostToDevice, stream_));
       sync();
-      return;
     }
-    const int dt = std::is_same<T, float>::value    ? kNcclFloat32
-                   : std::is_same<T, double>::value ? kNcclFloat64
-                                                    : kNcclInt32;
-    const int rc = g_rccl.AllReduce(buf, buf, count, dt, op, comm_, stream_);
-    if (rc != 0) throw HipError{"ncclAllReduce failed: " + std::to_string(rc), RBA_ERR_COMM};
   }
 
   // ---- state ------------------------------------------------------------------
@@ -1584,9 +1644,9 @@ class Solver final : public rba_solver {
       if (lm_.it > max_lm_iter) lm_.terminated = true;
       return (keep_going && !lm_.terminated) ? 1 : 0;
     };
-    // (the reference re-evaluates the error at every outer iteration, bal_bundle_adjustment.cpp:297-301,
-    //  with a TODO to avoid it; after an accepted step the state is the one ri2 was computed for)
-    if (lm_.it == 0 || (lm_.need_linearize && !lm_.ri_is_current)) {
+    // the reference re-evaluates the error at every outer iteration (bal_bundle_adjustment.cpp:297-301,
+    // with a TODO to avoid it); so does this loop - the metric of SURVEY.md 8d includes both evaluations
+    if (lm_.it == 0 || lm_.need_linearize) {
       compute_error(&lm_.ri);
       if (!lm_.ri.is_numerically_valid) {
         lm_.terminated = true;
@@ -1787,6 +1847,30 @@ class Solver final : public rba_solver {
       for (int c = 0; c < 3; ++c) qo[3 * size_t(perm_[s]) + c] = q[3 * size_t(s) + c];
     }
   }
+  // compulsory HBM bytes per launch group in this layout (include/rootba_hip.h: rba_byte_model)
+  void get_byte_model(rba_byte_model* m) override {
+    const int64_t s = sizeof(S), no = n_obs_, nl = n_lms_, nc = n_cams_;
+    const int64_t geometry_in = no * (2 * s + 8) + nl * (3 * s + 12) + nc * 10 * s;  // obs, indices, points, cameras
+    m->compute_error = geometry_in;
+    if (sc_) {
+      m->stage1 = 2 * geometry_in + no * (26 * s) + nl * 12 * s + nc * 9 * s;
+      m->stage2 = nl * 21 * s + no * (26 + 63) * s + sc_assemble_bytes_ + nc * 90 * s;
+      m->back_substitution = no * (26 * s + 4) + nl * 18 * s;
+      m->product_matrix_free = 0;
+    } else {
+      // per observation written by stage 1: top0 27, JpS 18, bmO 9, qtr 2, JlS 6, rS 2, Vh 8 (+ JT 18, VT 6 tiles)
+      const int64_t rec = (27 + 18 + 9 + 2 + 6 + 2 + 8 + (opt_.implicit_q ? 24 : 0)) * s;
+      m->stage1 = 2 * geometry_in + no * 4 /* CSC */ + no * rec + nl * 12 * s + (opt_.implicit_q ? 0 : storage_dense_bytes_) +
+                  no * (27 * s + 4) /* camera-major read of JpS, bmO */ + nc * (9 + 90) * s;
+      m->stage2 = nl * (6 + 3 + 16 + 6 + 3 + 3 + 9) * s + no * (27 + 27 + 9) * s + no * ((27 + 9) * s + 4) + nc * 180 * s;
+      m->back_substitution = no * (18 + 27 + 5 + 4) * s + no * (5 + 6 + 2 + 2) * s + nl * (6 + 3 + 3 + 3 + 3 + 8) * s;
+      m->product_matrix_free = opt_.implicit_q ? no * (24 * s + 8) + nl * 12 * s + nc * 18 * s : hx_bytes_;
+    }
+    const int64_t nnz = sc_ ? sc_nnz_ : ex_nnz_;
+    m->product_assembled = nnz * (81 * s + 4) + nc * 18 * s;
+    m->assembly = sc_ ? sc_assemble_bytes_ : ex_pairs_ * (8 + 54 * s) + nnz * 81 * s;
+    m->pcg_vectors = nc * (81 + 10 * 9) * s;
+  }
   void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) override {
     *storage = storage_bytes_;
     *hx_bytes = (opt_.implicit_q && !sc_) ? hx_implicit_bytes_ : hx_bytes_;
@@ -1842,6 +1926,7 @@ class Solver final : public rba_solver {
   static constexpr int kNumImplicit = 7;
   int imp_begin_[kNumImplicit], imp_end_[kNumImplicit];
   int64_t hx_bytes_ = 0, hx_flops_ = 0, storage_bytes_ = 0, hx_implicit_bytes_ = 0;
+  int64_t storage_dense_bytes_ = 0, ex_pairs_ = 0;
   rba::Params<S> prm_{};
   S pose_damping_ = S(0);
   bool landmark_damping_valid_ = false;
@@ -1924,6 +2009,11 @@ class Solver final : public rba_solver {
   rba_allreduce_fn cb_fn_ = nullptr;
   void* cb_ctx_ = nullptr;
   std::vector<char> cb_stage_;
+  static constexpr int kCommEvents = 64;
+  std::vector<hipEvent_t> comm_events_;
+  int comm_ev_used_ = 0;
+  int64_t comm_calls_ = 0, comm_bytes_ = 0;
+  double comm_seconds_ = 0;
 };
 
 template <class F>
@@ -2091,6 +2181,19 @@ int rba_comm_init_callback(rba_handle h, int rank, int nranks, rba_allreduce_fn 
   });
 }
 
+int rba_comm_info(rba_handle h, int* rank_out, int* nranks_out, int* transport_out) {
+  return guarded([&]() -> int {
+    h->comm_info(rank_out, nranks_out, transport_out);
+    return RBA_OK;
+  });
+}
+int rba_get_comm_stats(rba_handle h, int64_t* calls_out, int64_t* bytes_out, double* seconds_out) {
+  return guarded([&]() -> int {
+    h->comm_stats(calls_out, bytes_out, seconds_out);
+    return RBA_OK;
+  });
+}
+
 int rba_set_state(rba_handle h, const void* cams, const void* lms) {
   return guarded([&]() -> int {
     h->set_state(cams, lms);
@@ -2205,6 +2308,12 @@ int rba_get_pose_scaling(rba_handle h, void* out) {
 int rba_get_landmark_R(rba_handle h, int damped, void* R6, void* q3) {
   return guarded([&]() -> int {
     h->get_landmark_R(damped, R6, q3);
+    return RBA_OK;
+  });
+}
+int rba_get_byte_model(rba_handle h, rba_byte_model* out) {
+  return guarded([&]() -> int {
+    h->get_byte_model(out);
     return RBA_OK;
   });
 }

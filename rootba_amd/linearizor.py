@@ -103,6 +103,16 @@ class LinearizorHIP:
         L.check(self.lib.rba_comm_init_callback(self.h, C.c_int(rank), C.c_int(nranks), self._allreduce_cb,
                                                 None), "rba_comm_init_callback")
 
+    def comm_info(self) -> dict:
+        r, n, t = C.c_int(0), C.c_int(0), C.c_int(0)
+        L.check(self.lib.rba_comm_info(self.h, C.byref(r), C.byref(n), C.byref(t)), "rba_comm_info")
+        return {"rank": r.value, "nranks": n.value, "transport": ("none", "rccl", "callback")[t.value]}
+
+    def comm_stats(self) -> dict:
+        c, b, s = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        L.check(self.lib.rba_get_comm_stats(self.h, C.byref(c), C.byref(b), C.byref(s)), "rba_get_comm_stats")
+        return {"calls": c.value, "bytes": b.value, "seconds": s.value}
+
     # -- BalProblem state -----------------------------------------------------------
     def set_state(self, cams, lms):
         c, l = self._in(cams, 10 * self.n_cams), self._in(lms, 3 * self.n_lms)
@@ -225,6 +235,11 @@ class LinearizorHIP:
         L.check(self.lib.rba_get_landmark_R(self.h, C.c_int(int(damped)), _ptr(R), _ptr(q)),
                 "rba_get_landmark_R")
         return R.reshape(-1, 6), q.reshape(-1, 3)
+
+    def byte_model(self) -> dict:
+        m = L.RbaByteModel()
+        L.check(self.lib.rba_get_byte_model(self.h, C.byref(m)), "rba_get_byte_model")
+        return {n: getattr(m, n) for n, _ in L.RbaByteModel._fields_}
 
     def problem_stats(self) -> dict:
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)

@@ -110,3 +110,22 @@ def test_shard_ranges_balance_bytes():
         assert r[0][0] == 0 and r[-1][1] == k.size and all(a[1] == b[0] for a, b in zip(r, r[1:]))
         w = np.array([(k[a:b].astype(float) ** 2).sum() for a, b in r])
         assert w.max() / w.mean() < 1.05
+
+
+def test_shard_ranges_never_empty():
+    sys.path.insert(0, ROOT)
+    from bench import shard_ranges
+    k = np.array([2, 2, 2, 2000, 2, 2, 2, 2])  # one landmark holds almost all the bytes
+    r = shard_ranges(k, 8)
+    assert all(b > a for a, b in r) and r[0][0] == 0 and r[-1][1] == k.size
+    with pytest.raises(SystemExit):
+        shard_ranges(k[:3], 8)
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """`bench.py --gpus N` must never print a line for a different number of ranks."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and p.stdout.strip() == ""
