@@ -47,18 +47,15 @@ struct Params {
   S* JpS;       // [n_obs][2][9] weighted, column-scaled pose Jacobian
   S* bmO;       // [n_obs][9]    per-observation part of b from the Q2 rows
   // implicit-Q operator (k_hx_implicit): the factors instead of the product
-  S* Vh;        // [2 n_obs][4]  Householder vectors (v0, v1, v2, Q^T r) per block row
+  S* Vh;        // [2 n_obs][4]  per block row: Householder vectors v0, v1, v2 and (Q^T r)[row]
   S* tauH;      // [3 n_lms]     their tau
   S* Zd;        // [9 n_lms]     3x3 map of the top rows through damp / drop-Q1 / undamp
-  // wave-tiled copies for k <= 32 (one lane per block row, landmark = aligned group
-  // of P2 lanes, see k_hx_implicit): fully coalesced, no index hops
-  S* JT;                             // [tiles][9][64] scaled Jacobian rows
-  S* VT;                             // [tiles][3][64] reflector entries
-  const int* __restrict__ CT;        // [tiles][64]    camera of the row's observation, -1 = padding
-  const int* __restrict__ lm_tile;   // [n_lms] tile of the landmark (-1: not tiled)
-  const int* __restrict__ lm_lane0;  // [n_lms] first lane of the landmark inside its tile
-  int implicit;                      // write the tiled copies in stage 1
-  S* qtr;       // [2 n_obs]
+  S* LQ;        // [n_lms][12]   tau[3], reflector cross products g10 g20 g21, d[3] (kernels_s1.hpp)
+  // wave tiles for k <= 32 (one lane per block row, landmark = aligned group of P2 lanes, see
+  // k_hx_implicit / k_s1_qr_tile): static maps lane -> camera / block row, -1 = padding
+  const int* __restrict__ CT;        // [tiles][64] camera of the row's observation
+  const int* __restrict__ RT;        // [tiles][64] global block row 2 o + r
+  int implicit;                      // products from the factors: the dense blocks of k <= 112 are not written
   S* JlS;       // [n_obs][2][3]  sqrt(w) Jl D_l before the QR (back-substitution)
   S* rS;        // [n_obs][2]     sqrt(w) r
   S* bsO;       // [n_obs][5]     back-substitution scratch: topd x (3), Jp x (2)
@@ -655,18 +652,11 @@ __global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin,
       V[4 * r + 1] = vm[1][rc];
       V[4 * r + 2] = vm[2][rc];
       V[4 * r + 3] = rs[rc];
-      p.qtr[2 * o0 + r] = rs[rc];
       S* vh = p.Vh + 4 * (2 * o0 + r);
       vh[0] = vm[0][rc];
       vh[1] = vm[1][rc];
       vh[2] = vm[2][rc];
       vh[3] = rs[rc];
-      if (p.implicit && p.lm_tile[s] >= 0) {
-        S* vt = p.VT + size_t(p.lm_tile[s]) * 192 + p.lm_lane0[s] + r;
-        vt[0] = vm[0][rc];
-        vt[64] = vm[1][rc];
-        vt[128] = vm[2][rc];
-      }
     }
   }
   if (lane == 0) {
@@ -723,11 +713,6 @@ __global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin,
       p.JpS[(o0 + i) * 18 + comp] = m0;
       p.JpS[(o0 + i) * 18 + 9 + comp] = m1;
       p.bmO[(o0 + i) * 9 + comp] = bm;
-      if (p.implicit && p.lm_tile[s] >= 0) {
-        S* jt = p.JT + (size_t(p.lm_tile[s]) * 9 + comp) * 64 + p.lm_lane0[s] + 2 * i;
-        jt[0] = m0;
-        jt[1] = m1;
-      }
     }
   }
 }
@@ -868,18 +853,11 @@ __global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm
     V[4 * r + 1] = vm[1];
     V[4 * r + 2] = vm[2];
     V[4 * r + 3] = rs;
-    p.qtr[2 * o0 + r] = rs;
     S* vh = p.Vh + 4 * (2 * o0 + r);
     vh[0] = vm[0];
     vh[1] = vm[1];
     vh[2] = vm[2];
     vh[3] = rs;
-    if (p.implicit && p.lm_tile[s] >= 0) {
-      S* vt = p.VT + size_t(p.lm_tile[s]) * 192 + p.lm_lane0[s] + r;
-      vt[0] = vm[0];
-      vt[64] = vm[1];
-      vt[128] = vm[2];
-    }
   }
   wave_lds_fence();
 
@@ -938,11 +916,6 @@ __global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm
       p.JpS[(o2 + i) * 18 + comp] = m0;
       p.JpS[(o2 + i) * 18 + 9 + comp] = m1;
       p.bmO[(o2 + i) * 9 + comp] = bm;
-      if (p.implicit && p.lm_tile[s2] >= 0) {
-        S* jt = p.JT + (size_t(p.lm_tile[s2]) * 9 + comp) * 64 + p.lm_lane0[s2] + 2 * i;
-        jt[0] = m0;
-        jt[1] = m1;
-      }
     }
     }  // ch
   }
@@ -980,9 +953,9 @@ __global__ __launch_bounds__(256) void k_stage2_landmark(Params<S> p, S lambda) 
     T[2][0] = S(0);
     T[2][1] = S(0);
     T[2][2] = R[5];
-    T[0][3] = p.qtr[2 * o0 + 0];
-    T[1][3] = p.qtr[2 * o0 + 1];
-    T[2][3] = p.qtr[2 * o0 + 2];
+    T[0][3] = p.Vh[4 * (2 * o0 + 0) + 3];  // Q1^T r = first three entries of Q^T r
+    T[1][3] = p.Vh[4 * (2 * o0 + 1) + 3];
+    T[2][3] = p.Vh[4 * (2 * o0 + 2) + 3];
   }
   const S sl = sqrt(lambda);
 #pragma unroll
@@ -1233,14 +1206,26 @@ __device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, i
   const int seg = lane / P2, r = lane - P2 * seg;
   const int s = lm_begin + t_in_class * LPW + seg;
   const bool lm_ok = s < lm_end;
-  // everything is addressed by (tile, lane) only: no index hops, 256-byte rows
+  // static lane maps (tile, lane) -> camera / block row; the Jacobian row (36 bytes) and the
+  // reflector entries (16 bytes) are read straight from the stage-1 records: consecutive lanes
+  // are consecutive rows, so a wave reads one contiguous 2.3 KB / 1 KB span
   const int cam = p.CT[T * 64 + lane];
+  const int row = p.RT[T * 64 + lane];
   const bool act = cam >= 0;
   S jp[9];
+  {
+    const S* __restrict__ jrow = p.JpS + 9 * int64_t(act ? row : 0);
 #pragma unroll
-  for (int c = 0; c < 9; ++c) jp[c] = p.JT[(T * 9 + c) * 64 + lane];
-  const S v0 = p.VT[(T * 3 + 0) * 64 + lane], v1 = p.VT[(T * 3 + 1) * 64 + lane],
-          v2 = p.VT[(T * 3 + 2) * 64 + lane];
+    for (int c = 0; c < 9; ++c) jp[c] = act ? jrow[c] : S(0);
+  }
+  S v0 = S(0), v1 = S(0), v2 = S(0);
+  if (act) {
+    using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+    const V4 vv = reinterpret_cast<const V4*>(p.Vh)[row];
+    v0 = vv.x;
+    v1 = vv.y;
+    v2 = vv.z;
+  }
   const S t0 = lm_ok ? p.tauH[3 * s + 0] : S(0), t1 = lm_ok ? p.tauH[3 * s + 1] : S(0),
           t2 = lm_ok ? p.tauH[3 * s + 2] : S(0);
   // gather x for the 32 observation slots of the tile with 9-lane coalescing

@@ -138,7 +138,6 @@ __global__ __launch_bounds__(256) void k_linearize_qr_big(Params<S> p, int lm_be
     R[5] = V[8 + 2];
   }
   for (int r = tid; r < nrows; r += 256) {
-    p.qtr[2 * o0 + r] = V[4 * r + 3];
     S* vh = p.Vh + 4 * (2 * o0 + r);
     vh[0] = W[4 * r + 0];
     vh[1] = W[4 * r + 1];

@@ -1,0 +1,574 @@
+// kernels_s1.hpp — stage 1 (linearise + marginalise, LinearizationQR::get_stage1,
+// src/rootba/qr/linearization_qr.hpp:634-712) staged BY PARALLELISM for the implicit-Q
+// configuration (the dense 2k x 9k block of a landmark is never materialised there).
+//
+// Round 1 ran geometry, Householder QR and the column pass inside ONE wavefront-per-landmark(s)
+// kernel: 86 % VALU-busy (profiles/r2_pmc_stage1.csv) at 5-40 % lane utilisation, 1.5 ms on
+// venice-1778 — geometry with one lane per observation of a 2-7 observation landmark, a column
+// pass that walks all 2k rows per column. Here every pass runs at the parallelism its work has:
+//
+//   k_s1_geometry   one THREAD per observation: projection, analytic Jacobians, Huber weight
+//                   (linearize_landmark, landmark_block_base.ipp:88-147). Writes the weighted pose
+//                   Jacobian rows (JpS, still unscaled) and the rows [sqrt(w) Jl | sqrt(w) r] (Vh),
+//                   transposed through LDS so that both stores are contiguous 16-byte streams.
+//   k_cam_gram      one WORKGROUP per camera (camera-major, fixed order): G_c = sum_obs Jp^T Jp.
+//                   Its diagonal is Jp_diag2 (add_Jp_diag2, ipp:493-518; double accumulation), and
+//                   D_c G_c D_c is the JACOBI block / the minuend of the SCHUR_JACOBI block
+//                   (add_Jp_T_Jp_blockdiag, ipp:554-569): one gather pass over the records instead of a
+//                   second geometry evaluation per observation plus a separate Gram pass.
+//   k_s1_qr_tile    one LANE per block row, a landmark = an aligned group of 4..64 lanes (the wave
+//                   tiles of the implicit-Q operator): Jl column scaling (scale_Jl_cols, ipp:571-587),
+//                   Householder QR of the 2k x 3 Jl (perform_qr_householder, ipp:717-743), Q^T r, and the
+//                   per-landmark scalars of the compact reflector application. Only the 4 columns
+//                   [Jl | r] are transformed here - Q depends on Jl alone.
+//   k_s1_cols       one THREAD per (observation, pose component): column scaling (scale_Jp_cols,
+//                   ipp:589-614, commutes with Q^T), the three top rows Q1^T Jp and the Q2 part of b
+//                   in CLOSED FORM: with Q^T Jp[:, j] = Jp[:, j] - sum_m c_m v_m (three reflectors,
+//                   c_m from two FMAs each because column j has two non-zero rows),
+//                     b_j = sum_{r >= 3} (Q^T Jp)[r, j] (Q^T r)[r]
+//                         = m0 q[2i] + m1 q[2i+1] (rows >= 3 only) - sum_m c_m d_m,   d_m = sum_{r>=3} v_m[r] q[r]
+//                   — the same products as the row-by-row sum, associated per reflector, O(1) per
+//                   column instead of O(2k).
+//   k_cam_bmid      camera-major sum of the per-observation parts of b (add_Q2TJp_T_Q2Tr, ipp:443-466).
+// Landmarks with more than 112 observations keep the workgroup-per-landmark kernel (kernels_big.hpp),
+// the dense-block configuration (implicit_q = 0) the round-1 kernels (kernels.hpp).
+#pragma once
+
+#include "kernels.hpp"
+
+namespace rba {
+
+// ---------------------------------------------------------------------------
+// pass G
+// ---------------------------------------------------------------------------
+template <class S>
+__global__ __launch_bounds__(256) void k_s1_geometry(Params<S> p, int64_t n_obs) {
+  extern __shared__ __attribute__((aligned(16))) char smem_s1[];
+  S* sj = reinterpret_cast<S*>(smem_s1);  // [256][18]
+  S* sv = sj + 256 * 18;                  // [256][8]
+  const int tid = threadIdx.x;
+  const int64_t o_base = int64_t(blockIdx.x) * 256;
+  const int64_t o = o_base + tid;
+  const int n_here = int(min<int64_t>(256, n_obs - o_base));
+  if (tid < n_here) {
+    const int cam = p.obs_cam[o];
+    const int l = p.obs_lm[o];
+    S res[2], Jp[18], Jl[6];
+    const bool valid = linearize_obs<S>(p.cams + 10 * cam, p.lms[3 * l], p.lms[3 * l + 1], p.lms[3 * l + 2],
+                                        p.obs_xy[2 * o], p.obs_xy[2 * o + 1], res, Jp, Jl);
+    S sw = S(0);
+    if (!p.valid_only || valid) {
+      bool fin = is_finite(res[0]) && is_finite(res[1]);
+#pragma unroll
+      for (int i = 0; i < 18; ++i) fin = fin && is_finite(Jp[i]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) fin = fin && is_finite(Jl[i]);
+      if (!fin) atomicOr(p.fail_flag, 1);  // non-finite check of linearize_landmark (ipp:123-146)
+      S err, w;
+      error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
+      sw = sqrt(w);
+    }
+#pragma unroll
+    for (int c = 0; c < 18; ++c) sj[18 * tid + c] = sw * Jp[c];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      sv[8 * tid + 4 * r + 0] = sw * Jl[3 * r + 0];
+      sv[8 * tid + 4 * r + 1] = sw * Jl[3 * r + 1];
+      sv[8 * tid + 4 * r + 2] = sw * Jl[3 * r + 2];
+      sv[8 * tid + 4 * r + 3] = sw * res[r];
+    }
+  }
+  __syncthreads();
+  // contiguous copy-out (observations of a workgroup are consecutive)
+  using V = typename std::conditional<sizeof(S) == 4, float4, double2>::type;
+  constexpr int N = 16 / int(sizeof(S));
+  {
+    S* dst = p.JpS + 18 * o_base;
+    const int total = 18 * n_here, nvec = total / N;
+    for (int i = tid; i < nvec; i += 256) reinterpret_cast<V*>(dst)[i] = reinterpret_cast<const V*>(sj)[i];
+    for (int i = nvec * N + tid; i < total; i += 256) dst[i] = sj[i];
+  }
+  {
+    S* dst = p.Vh + 8 * o_base;
+    const int nvec = 8 * n_here / N;
+    for (int i = tid; i < nvec; i += 256) reinterpret_cast<V*>(dst)[i] = reinterpret_cast<const V*>(sv)[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// camera-major Gram pass on the UNSCALED records
+// ---------------------------------------------------------------------------
+// Jp_diag2 in double, fixed order: thread = (group of 28, component)
+template <class S>
+__device__ __forceinline__ void cam_diag2(const Params<S>& p, int c, int64_t t0, int64_t t1, double (*bsum)[9]) {
+  const int tid = threadIdx.x;
+  if (tid < 252) {
+    const int g = tid / 9, a = tid - 9 * g;
+    double acc = 0;
+    int64_t t = t0 + g;
+    for (; t + 3 * 28 < t1; t += 4 * 28) {
+      const int o0 = p.cam_obs[t], o1 = p.cam_obs[t + 28], o2 = p.cam_obs[t + 56], o3 = p.cam_obs[t + 84];
+      const S a0 = p.JpS[int64_t(o0) * 18 + a], b0 = p.JpS[int64_t(o0) * 18 + 9 + a];
+      const S a1 = p.JpS[int64_t(o1) * 18 + a], b1 = p.JpS[int64_t(o1) * 18 + 9 + a];
+      const S a2 = p.JpS[int64_t(o2) * 18 + a], b2 = p.JpS[int64_t(o2) * 18 + 9 + a];
+      const S a3 = p.JpS[int64_t(o3) * 18 + a], b3 = p.JpS[int64_t(o3) * 18 + 9 + a];
+      acc += (double(a0 * a0 + b0 * b0) + double(a1 * a1 + b1 * b1)) +
+             (double(a2 * a2 + b2 * b2) + double(a3 * a3 + b3 * b3));
+    }
+    for (; t < t1; t += 28) {
+      const int o = p.cam_obs[t];
+      const S a0 = p.JpS[int64_t(o) * 18 + a], b0 = p.JpS[int64_t(o) * 18 + 9 + a];
+      acc += double(a0 * a0 + b0 * b0);
+    }
+    bsum[g][a] = acc;
+  }
+}
+
+// float: Gram tile on the matrix cores (exact f32 fmaf chains, see mfma_xtx)
+__global__ __launch_bounds__(256) void k_cam_gram_mfma(Params<float> p) {
+  __shared__ float tile[4][16][16];
+  __shared__ double bsum[28][9];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = mfma_xtx<2>(p.JpS, 18, p.cam_obs, t0, t1, wave, lane, acc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+  cam_diag2<float>(p, c, t0, t1, bsum);
+  __syncthreads();
+  if (tid < 81) {
+    const int i = tid / 9, j = tid - 9 * i;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += tile[w][i][j];
+    p.B_mid[81 * c + tid] = v;
+  }
+  if (tid >= 128 && tid < 137) {
+    const int a = tid - 128;
+    double s = 0;
+    for (int g = 0; g < 28; ++g) s += bsum[g][a];
+    p.jp_diag2[9 * c + a] = float(s);
+  }
+}
+
+// generic (double): LDS-staged records, double accumulators
+template <class S>
+__global__ __launch_bounds__(256) void k_cam_gram(Params<S> p) {
+  constexpr int TILE = 64, W = 18, NLD = (TILE * W + 255) / 256;
+  __shared__ S rec[TILE][W];
+  __shared__ int olist[TILE];
+  __shared__ double red[3][81];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
+  double acc = 0;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  for (int64_t base = t0; base < t1; base += TILE) {
+    const int n = int(min<int64_t>(TILE, t1 - base));
+    __syncthreads();
+    if (tid < n) olist[tid] = p.cam_obs[base + tid];
+    __syncthreads();
+    S v[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = u * 256 + tid;
+      v[u] = S(0);
+      if (idx < n * W) {
+        const int q = idx / W, f = idx - W * q;
+        v[u] = p.JpS[int64_t(olist[q]) * 18 + f];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = u * 256 + tid;
+      if (idx < n * W) rec[idx / W][idx % W] = v[u];
+    }
+    __syncthreads();
+    if (grp < 3) {
+      for (int q = grp; q < n; q += 3) {
+        const S* r = rec[q];
+        acc += double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb]);
+      }
+    }
+  }
+  if (grp < 3) red[grp][e] = acc;
+  __syncthreads();
+  if (tid < 81) {
+    const double v = red[0][tid] + red[1][tid] + red[2][tid];
+    p.B_mid[81 * c + tid] = S(v);
+    if (tid / 9 == tid % 9) p.jp_diag2[9 * c + tid / 9] = S(v);
+  }
+}
+
+// B_mid = D G D once the (all-reduced) column scaling is known
+template <class S>
+__global__ void k_scale_gram(Params<S> p) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 81 * p.n_cams) return;
+  const int c = t / 81, e = t - 81 * c, a = e / 9, b = e - 9 * a;
+  p.B_mid[t] *= p.pose_scaling[9 * c + a] * p.pose_scaling[9 * c + b];
+}
+
+// ---------------------------------------------------------------------------
+// pass Q: Householder QR of [Jl | r], lane per block row
+// ---------------------------------------------------------------------------
+// per-landmark scalars handed to the column pass: LQ[s][12] = tau[3], g10 g20 g21, d[3], pad
+template <class S, int P2>
+__device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_in_class, int lm_begin, int lm_end,
+                                           int lane) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  constexpr int LPW = 64 / P2;
+  const int seg = lane / P2, r = lane - P2 * seg, base = lane - r;
+  const int s = lm_begin + t_in_class * LPW + seg;
+  const bool lm_ok = s < lm_end;
+  const int64_t row = p.RT[T * 64 + lane];  // -1: padding lane
+  const bool rvalid = row >= 0;
+  S jl[3] = {S(0), S(0), S(0)}, rs = S(0);
+  if (rvalid) {
+    const V4 v = reinterpret_cast<const V4*>(p.Vh)[row];
+    jl[0] = v.x;
+    jl[1] = v.y;
+    jl[2] = v.z;
+    rs = v.w;
+  }
+  // scale_Jl_cols
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const S ss = seg_sum<S, P2>(jl[c] * jl[c]);
+    const S sc = S(1) / (p.eps + sqrt(ss));
+    jl[c] *= sc;
+    if (r == 0 && lm_ok) p.jl_scale[3 * s + c] = sc;
+  }
+  if (rvalid) {
+    S* dst = p.JlS + 3 * row;
+    dst[0] = jl[0];
+    dst[1] = jl[1];
+    dst[2] = jl[2];
+    p.rS[row] = rs;
+  }
+  S vm[3], tau[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const S c0 = __shfl(jl[m], base + m);
+    const S tail = seg_sum<S, P2>((r > m && rvalid) ? jl[m] * jl[m] : S(0));
+    S beta, inv;
+    if (tail <= Eps<S>::tiny) {
+      tau[m] = S(0);
+      beta = c0;
+      inv = S(0);
+    } else {
+      beta = sqrt(c0 * c0 + tail);
+      if (c0 >= S(0)) beta = -beta;
+      inv = S(1) / (c0 - beta);
+      tau[m] = (beta - c0) / beta;
+    }
+    vm[m] = (r == m) ? S(1) : ((r > m && rvalid) ? jl[m] * inv : S(0));
+#pragma unroll
+    for (int c2 = m + 1; c2 < 3; ++c2) {
+      const S d = tau[m] * seg_sum<S, P2>(vm[m] * jl[c2]);
+      jl[c2] -= d * vm[m];
+    }
+    {
+      const S d = tau[m] * seg_sum<S, P2>(vm[m] * rs);
+      rs -= d * vm[m];
+    }
+    if (r == m) jl[m] = beta;
+    if (r > m) jl[m] = S(0);
+  }
+  const S g10 = seg_sum<S, P2>(vm[1] * vm[0]), g20 = seg_sum<S, P2>(vm[2] * vm[0]),
+          g21 = seg_sum<S, P2>(vm[2] * vm[1]);
+  const bool low = r >= 3 && rvalid;
+  const S d0 = seg_sum<S, P2>(low ? vm[0] * rs : S(0)), d1 = seg_sum<S, P2>(low ? vm[1] * rs : S(0)),
+          d2 = seg_sum<S, P2>(low ? vm[2] * rs : S(0));
+  const S r00 = __shfl(jl[0], base), r01 = __shfl(jl[1], base), r02 = __shfl(jl[2], base),
+          r11 = __shfl(jl[1], base + 1), r12 = __shfl(jl[2], base + 1), r22 = __shfl(jl[2], base + 2);
+  if (r == 0 && lm_ok) {
+    S* R = p.R0 + 6 * s;
+    R[0] = r00;
+    R[1] = r01;
+    R[2] = r02;
+    R[3] = r11;
+    R[4] = r12;
+    R[5] = r22;
+    p.tauH[3 * s + 0] = tau[0];
+    p.tauH[3 * s + 1] = tau[1];
+    p.tauH[3 * s + 2] = tau[2];
+    V4* lq = reinterpret_cast<V4*>(p.LQ + 12 * size_t(s));
+    lq[0] = V4{tau[0], tau[1], tau[2], g10};
+    lq[1] = V4{g20, g21, d0, d1};
+    lq[2] = V4{d2, S(0), S(0), S(0)};
+  }
+  if (rvalid) reinterpret_cast<V4*>(p.Vh)[row] = V4{vm[0], vm[1], vm[2], rs};
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void k_s1_qr_tile(Params<S> p, ImplicitTiles it) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int T = blockIdx.x * 4 + wave;
+  if (T >= it.tile_begin[5]) return;
+  if (T >= it.tile_begin[4])
+    s1_qr_tile<S, 64>(p, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], lane);
+  else if (T >= it.tile_begin[3])
+    s1_qr_tile<S, 32>(p, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], lane);
+  else if (T >= it.tile_begin[2])
+    s1_qr_tile<S, 16>(p, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], lane);
+  else if (T >= it.tile_begin[1])
+    s1_qr_tile<S, 8>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], lane);
+  else
+    s1_qr_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], lane);
+}
+
+// 32 < k <= 112: one landmark per wavefront, rows rc * 64 + lane
+template <class S, int RCH>
+__global__ __launch_bounds__(256) void k_s1_qr_wide(Params<S> p, int lm_begin, int lm_end) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;
+  const int k = p.lm_k[s];
+  const int64_t row0 = 2 * p.lm_obs[s];
+  const int nrows = 2 * k;
+  S jl[RCH][3], rs[RCH], vm[3][RCH], tau[3];
+  bool rvalid[RCH];
+#pragma unroll
+  for (int rc = 0; rc < RCH; ++rc) {
+    const int r = rc * 64 + lane;
+    rvalid[rc] = r < nrows;
+    jl[rc][0] = jl[rc][1] = jl[rc][2] = rs[rc] = S(0);
+    if (rvalid[rc]) {
+      const V4 v = reinterpret_cast<const V4*>(p.Vh)[row0 + r];
+      jl[rc][0] = v.x;
+      jl[rc][1] = v.y;
+      jl[rc][2] = v.z;
+      rs[rc] = v.w;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    S ss = S(0);
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) ss += jl[rc][c] * jl[rc][c];
+    ss = wave_sum(ss);
+    const S sc = S(1) / (p.eps + sqrt(ss));
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) jl[rc][c] *= sc;
+    if (lane == 0) p.jl_scale[3 * s + c] = sc;
+  }
+#pragma unroll
+  for (int rc = 0; rc < RCH; ++rc) {
+    const int r = rc * 64 + lane;
+    if (rvalid[rc]) {
+      S* dst = p.JlS + 3 * (row0 + r);
+      dst[0] = jl[rc][0];
+      dst[1] = jl[rc][1];
+      dst[2] = jl[rc][2];
+      p.rS[row0 + r] = rs[rc];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const S c0 = read_lane(jl[0][m], m);
+    S tail = S(0);
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) {
+      const int r = rc * 64 + lane;
+      tail += (r > m && rvalid[rc]) ? jl[rc][m] * jl[rc][m] : S(0);
+    }
+    tail = wave_sum(tail);
+    S beta, inv;
+    if (tail <= Eps<S>::tiny) {
+      tau[m] = S(0);
+      beta = c0;
+      inv = S(0);
+    } else {
+      beta = sqrt(c0 * c0 + tail);
+      if (c0 >= S(0)) beta = -beta;
+      inv = S(1) / (c0 - beta);
+      tau[m] = (beta - c0) / beta;
+    }
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) {
+      const int r = rc * 64 + lane;
+      vm[m][rc] = (r == m) ? S(1) : ((r > m && rvalid[rc]) ? jl[rc][m] * inv : S(0));
+    }
+#pragma unroll
+    for (int c2 = m + 1; c2 < 3; ++c2) {
+      S d = S(0);
+#pragma unroll
+      for (int rc = 0; rc < RCH; ++rc) d += vm[m][rc] * jl[rc][c2];
+      d = tau[m] * wave_sum(d);
+#pragma unroll
+      for (int rc = 0; rc < RCH; ++rc) jl[rc][c2] -= d * vm[m][rc];
+    }
+    {
+      S d = S(0);
+#pragma unroll
+      for (int rc = 0; rc < RCH; ++rc) d += vm[m][rc] * rs[rc];
+      d = tau[m] * wave_sum(d);
+#pragma unroll
+      for (int rc = 0; rc < RCH; ++rc) rs[rc] -= d * vm[m][rc];
+    }
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc) {
+      const int r = rc * 64 + lane;
+      if (r == m) jl[rc][m] = beta;
+      if (r > m) jl[rc][m] = S(0);
+    }
+  }
+  S g10 = S(0), g20 = S(0), g21 = S(0), d0 = S(0), d1 = S(0), d2 = S(0);
+#pragma unroll
+  for (int rc = 0; rc < RCH; ++rc) {
+    g10 += vm[1][rc] * vm[0][rc];
+    g20 += vm[2][rc] * vm[0][rc];
+    g21 += vm[2][rc] * vm[1][rc];
+    const bool low = rc * 64 + lane >= 3 && rvalid[rc];
+    d0 += low ? vm[0][rc] * rs[rc] : S(0);
+    d1 += low ? vm[1][rc] * rs[rc] : S(0);
+    d2 += low ? vm[2][rc] * rs[rc] : S(0);
+  }
+  g10 = wave_sum(g10);
+  g20 = wave_sum(g20);
+  g21 = wave_sum(g21);
+  d0 = wave_sum(d0);
+  d1 = wave_sum(d1);
+  d2 = wave_sum(d2);
+  const S r00 = read_lane(jl[0][0], 0), r01 = read_lane(jl[0][1], 0), r02 = read_lane(jl[0][2], 0),
+          r11 = read_lane(jl[0][1], 1), r12 = read_lane(jl[0][2], 1), r22 = read_lane(jl[0][2], 2);
+  if (lane == 0) {
+    S* R = p.R0 + 6 * s;
+    R[0] = r00;
+    R[1] = r01;
+    R[2] = r02;
+    R[3] = r11;
+    R[4] = r12;
+    R[5] = r22;
+    p.tauH[3 * s + 0] = tau[0];
+    p.tauH[3 * s + 1] = tau[1];
+    p.tauH[3 * s + 2] = tau[2];
+    V4* lq = reinterpret_cast<V4*>(p.LQ + 12 * size_t(s));
+    lq[0] = V4{tau[0], tau[1], tau[2], g10};
+    lq[1] = V4{g20, g21, d0, d1};
+    lq[2] = V4{d2, S(0), S(0), S(0)};
+  }
+#pragma unroll
+  for (int rc = 0; rc < RCH; ++rc) {
+    const int r = rc * 64 + lane;
+    if (rvalid[rc]) reinterpret_cast<V4*>(p.Vh)[row0 + r] = V4{vm[0][rc], vm[1][rc], vm[2][rc], rs[rc]};
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass C: one thread per observation (nine columns in registers); the three output records of the
+// workgroup's 128 consecutive observations are contiguous in HBM, so they are staged in LDS and
+// written as full 16-byte streams (the thread-per-(observation, component) form of this pass issued
+// nineteen vector memory instructions per 4-byte result and ran at 2 TB/s)
+// ---------------------------------------------------------------------------
+constexpr int kS1ColsThreads = 128;
+
+template <class S>
+__global__ __launch_bounds__(kS1ColsThreads) void k_s1_cols(Params<S> p, int64_t n_obs) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  using V = typename std::conditional<sizeof(S) == 4, float4, double2>::type;
+  constexpr int N = 16 / int(sizeof(S)), NT = kS1ColsThreads;
+  extern __shared__ __attribute__((aligned(16))) char smem_s1c[];
+  S* sJ = reinterpret_cast<S*>(smem_s1c);  // [NT][18]  in: unscaled rows, out: scaled rows
+  S* sT = sJ + NT * 18;                    // [NT][27]  Q1^T Jp
+  S* sB = sT + NT * 27;                    // [NT][9]   Q2 part of b
+  const int tid = threadIdx.x;
+  const int64_t o_base = int64_t(blockIdx.x) * NT;
+  const int n_here = int(min<int64_t>(NT, n_obs - o_base));
+  const int64_t o = o_base + tid;
+  const bool act = tid < n_here;
+  // ---- independent loads first ----
+  {
+    const S* src = p.JpS + 18 * o_base;
+    const int total = 18 * n_here, nvec = total / N;
+    for (int i = tid; i < nvec; i += NT) reinterpret_cast<V*>(sJ)[i] = reinterpret_cast<const V*>(src)[i];
+    for (int i = nvec * N + tid; i < total; i += NT) sJ[i] = src[i];
+  }
+  const int64_t oc = act ? o : o_base;
+  const int s = p.obs_lm[oc];
+  const int cam = p.obs_cam[oc];
+  const V4* __restrict__ vh = reinterpret_cast<const V4*>(p.Vh);
+  const V4 va = vh[2 * oc], vb = vh[2 * oc + 1];
+  S dsc[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) dsc[c] = p.pose_scaling[9 * cam + c];
+  const int64_t o0 = p.lm_obs[s];
+  const V4* __restrict__ lq = reinterpret_cast<const V4*>(p.LQ + 12 * size_t(s));
+  const V4 q0 = lq[0], q1 = lq[1], q2 = lq[2];
+  const V4 w0 = vh[2 * o0], w1 = vh[2 * o0 + 1], w2 = vh[2 * o0 + 2];
+  const int i = int(oc - o0);
+  __syncthreads();
+  if (act) {
+    const S tau0 = q0.x, tau1 = q0.y, tau2 = q0.z, g10 = q0.w, g20 = q1.x, g21 = q1.y, d0 = q1.z, d1 = q1.w,
+            d2 = q2.x;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const S m0 = sJ[18 * tid + c] * dsc[c], m1 = sJ[18 * tid + 9 + c] * dsc[c];
+      const S c0 = tau0 * (va.x * m0 + vb.x * m1);
+      const S c1 = tau1 * (va.y * m0 + vb.y * m1 - c0 * g10);
+      const S c2 = tau2 * (va.z * m0 + vb.z * m1 - c0 * g20 - c1 * g21);
+      // rows 0..2 of Q^T Jp (column j): Q1^T Jp
+      S t0 = -(c0 * w0.x + c1 * w0.y + c2 * w0.z);
+      S t1 = -(c0 * w1.x + c1 * w1.y + c2 * w1.z);
+      S t2 = -(c0 * w2.x + c1 * w2.y + c2 * w2.z);
+      S bm = -(c0 * d0 + c1 * d1 + c2 * d2);
+      if (i == 0) {
+        t0 += m0;
+        t1 += m1;
+      } else if (i == 1) {
+        t2 += m0;
+        bm += m1 * vb.w;
+      } else {
+        bm += m0 * va.w + m1 * vb.w;
+      }
+      sT[27 * tid + c] = t0;
+      sT[27 * tid + 9 + c] = t1;
+      sT[27 * tid + 18 + c] = t2;
+      sJ[18 * tid + c] = m0;
+      sJ[18 * tid + 9 + c] = m1;
+      sB[9 * tid + c] = bm;
+    }
+  }
+  __syncthreads();
+  auto copy_out = [&](S* dst, const S* src, int total) {
+    const int nvec = total / N;
+    for (int q = tid; q < nvec; q += NT) reinterpret_cast<V*>(dst)[q] = reinterpret_cast<const V*>(src)[q];
+    for (int q = nvec * N + tid; q < total; q += NT) dst[q] = src[q];
+  };
+  // (16-byte alignment of the three destinations: o_base is a multiple of 128)
+  copy_out(p.top0 + 27 * o_base, sT, 27 * n_here);
+  copy_out(p.JpS + 18 * o_base, sJ, 18 * n_here);
+  copy_out(p.bmO + 9 * o_base, sB, 9 * n_here);
+}
+
+// b_mid[c] = sum over the camera's observations of bmO (fixed order, double)
+template <class S>
+__global__ __launch_bounds__(256) void k_cam_bmid(Params<S> p) {
+  __shared__ double bsum[28][9];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  if (tid < 252) {
+    const int g = tid / 9, a = tid - 9 * g;
+    double acc = 0;
+    int64_t t = t0 + g;
+    for (; t + 3 * 28 < t1; t += 4 * 28) {
+      const int o0 = p.cam_obs[t], o1 = p.cam_obs[t + 28], o2 = p.cam_obs[t + 56], o3 = p.cam_obs[t + 84];
+      const S v0 = p.bmO[int64_t(o0) * 9 + a], v1 = p.bmO[int64_t(o1) * 9 + a], v2 = p.bmO[int64_t(o2) * 9 + a],
+              v3 = p.bmO[int64_t(o3) * 9 + a];
+      acc += (double(v0) + double(v1)) + (double(v2) + double(v3));
+    }
+    for (; t < t1; t += 28) acc += double(p.bmO[int64_t(p.cam_obs[t]) * 9 + a]);
+    bsum[g][a] = acc;
+  }
+  __syncthreads();
+  if (tid < 9) {
+    double s = 0;
+    for (int g = 0; g < 28; ++g) s += bsum[g][tid];
+    p.b_mid[9 * c + tid] = S(s);
+  }
+}
+
+}  // namespace rba

@@ -24,6 +24,7 @@
 #include "../../include/rootba_hip.h"
 #include "kernels.hpp"
 #include "kernels_big.hpp"
+#include "kernels_s1.hpp"
 #include "kernels_sc.hpp"
 #include "kernels_pcg.hpp"
 
@@ -196,6 +197,7 @@ class Solver final : public rba_solver {
     nvec_ = 9 * n_cams_;
     if (const char* ev = std::getenv("RBA_HX_SINGLE_STREAM")) hx_single_stream_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_QR_UNPACKED")) qr_unpacked_ = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("RBA_S1_FUSED")) s1_fused_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
 
     // ---- sort landmarks by number of observations (stable) ----------------
@@ -204,8 +206,12 @@ class Solver final : public rba_solver {
     // NOTE: a secondary sort by first camera was tried and REJECTED: neighbouring lanes
     // then scatter-add to the same addresses, the atomics serialise, and H*x got 20 %
     // slower (dense 538 -> 660 us on venice). The input order spreads cameras evenly.
+    int sort_by_camera = 0;
+    if (const char* ev = std::getenv("RBA_SORT_BY_CAMERA")) sort_by_camera = std::atoi(ev);
     std::stable_sort(perm_.begin(), perm_.end(), [&](int a, int b) {
-      return (lm_off[a + 1] - lm_off[a]) < (lm_off[b + 1] - lm_off[b]);
+      const int64_t ka = lm_off[a + 1] - lm_off[a], kb = lm_off[b + 1] - lm_off[b];
+      if (ka != kb) return ka < kb;
+      return sort_by_camera ? obs_cam[lm_off[a]] < obs_cam[lm_off[b]] : false;
     });
     std::vector<int> lm_k(n_lms);
     std::vector<int64_t> lm_obs(n_lms + 1), lm_blk(n_lms + 1);
@@ -283,7 +289,7 @@ class Solver final : public rba_solver {
       }
     }
     // wave tiles of the implicit-Q operator for k <= 32 (classes 0..4)
-    std::vector<int> lm_tile(n_lms, -1), lm_lane0(n_lms, 0), tile_cam;
+    std::vector<int> lm_tile(n_lms, -1), lm_lane0(n_lms, 0), tile_cam, tile_row;
     {
       const int p2_of[5] = {4, 8, 16, 32, 64};
       int tiles = 0;
@@ -300,11 +306,16 @@ class Solver final : public rba_solver {
       }
       n_tiles_ = opt_.implicit_q ? tiles : 0;
       tile_cam.assign(size_t(n_tiles_) * 64, -1);
+      tile_row.assign(size_t(n_tiles_) * 64, -1);
+      if (2 * n_obs_ > int64_t(std::numeric_limits<int>::max()))
+        throw HipError{"more than 2^30 observations: block-row indices exceed 32 bits", RBA_ERR_UNSUPPORTED};
       if (opt_.implicit_q)
         for (int s2 = 0; s2 < n_lms; ++s2)
           if (lm_tile[s2] >= 0)
-            for (int rr = 0; rr < 2 * lm_k[s2]; ++rr)
+            for (int rr = 0; rr < 2 * lm_k[s2]; ++rr) {
               tile_cam[size_t(lm_tile[s2]) * 64 + lm_lane0[s2] + rr] = s_obs_cam[lm_obs[s2] + rr / 2];
+              tile_row[size_t(lm_tile[s2]) * 64 + lm_lane0[s2] + rr] = int(2 * lm_obs[s2] + rr);
+            }
     }
     // everything beyond k = 112: one workgroup per landmark (kernels_big.hpp)
     big_begin_ = begin;
@@ -386,7 +397,6 @@ class Solver final : public rba_solver {
     d_A_.alloc(sc_ ? 0 : size_t(blk));
     d_top0_.alloc(27 * qr_obs);
     d_topd_.alloc(27 * qr_obs);
-    d_qtr_.alloc(2 * qr_obs);
     d_JpS_.alloc(18 * size_t(n_obs_));
     d_JlS_.alloc(6 * qr_obs);
     d_rS_.alloc(2 * qr_obs);
@@ -423,18 +433,14 @@ class Solver final : public rba_solver {
     d_tauH_.alloc(3 * size_t(n_lms));
     d_Zd_.alloc(9 * size_t(n_lms));
     d_Zd_.zero(stream_);
-    d_lm_tile_.alloc(n_lms);
-    d_lm_lane0_.alloc(n_lms);
-    d_lm_tile_.upload(lm_tile.data(), n_lms, stream_);
-    d_lm_lane0_.upload(lm_lane0.data(), n_lms, stream_);
+    d_LQ_.alloc(sc_ ? 0 : 12 * size_t(n_lms));
     if (n_tiles_ > 0) {
-      d_JT_.alloc(size_t(n_tiles_) * 9 * 64);
-      d_VT_.alloc(size_t(n_tiles_) * 3 * 64);
       d_CT_.alloc(size_t(n_tiles_) * 64);
-      d_JT_.zero(stream_);
-      d_VT_.zero(stream_);
+      d_RT_.alloc(size_t(n_tiles_) * 64);
       d_CT_.upload(tile_cam.data(), tile_cam.size(), stream_);
+      d_RT_.upload(tile_row.data(), tile_row.size(), stream_);
     }
+    n_obs_small_ = lm_obs[big_begin_];  // observations of the landmarks with k <= 112 (sorted first)
     d_R0_.alloc(6 * size_t(n_lms));
     d_Rd_.alloc(6 * size_t(n_lms));
     d_q1trd_.alloc(3 * size_t(n_lms));
@@ -496,18 +502,15 @@ class Solver final : public rba_solver {
     prm_.Vh = d_Vh_.get();
     prm_.tauH = d_tauH_.get();
     prm_.Zd = d_Zd_.get();
-    prm_.JT = d_JT_.get();
-    prm_.VT = d_VT_.get();
+    prm_.LQ = d_LQ_.get();
     prm_.CT = d_CT_.get();
-    prm_.lm_tile = d_lm_tile_.get();
-    prm_.lm_lane0 = d_lm_lane0_.get();
+    prm_.RT = d_RT_.get();
     prm_.implicit = opt_.implicit_q ? 1 : 0;
     prm_.cams = d_cams_.get();
     prm_.lms = d_lms_.get();
     prm_.A = d_A_.get();
     prm_.top0 = d_top0_.get();
     prm_.topd = d_topd_.get();
-    prm_.qtr = d_qtr_.get();
     prm_.R0 = d_R0_.get();
     prm_.Rd = d_Rd_.get();
     prm_.q1trd = d_q1trd_.get();
@@ -1013,12 +1016,47 @@ class Solver final : public rba_solver {
     use_device();
     time_begin();
     d_fail_.zero(stream_);
-    hipLaunchKernelGGL((rba::k_cam_jp_diag2<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
+    const bool staged = !sc_ && opt_.implicit_q && !s1_fused_;  // kernels_s1.hpp
+    if (staged) {
+      // geometry once per observation; Jp_diag2 falls out of the camera-major Gram pass
+      hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256),
+                         256 * 26 * sizeof(S), stream_, prm_, int64_t(n_obs_));
+      launch_cam_gram(prm_);
+    } else {
+      hipLaunchKernelGGL((rba::k_cam_jp_diag2<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
+    }
     all_reduce(d_jp_diag2_.get(), nvec_);
     all_reduce(d_fail_.get(), 1, kNcclMax);
     hipLaunchKernelGGL((rba::k_pose_scaling<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                        d_jp_diag2_.get(), d_pose_scaling_.get(), prm_.eps, nvec_);
-    if (sc_) {
+    if (staged) {
+      hipLaunchKernelGGL((rba::k_scale_gram<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_, prm_);
+      if (n_tiles_ > 0) {
+        rba::ImplicitTiles it;
+        for (int c = 0; c < 5; ++c) {
+          it.tile_begin[c] = imp_tile_begin_[c];
+          it.lm_begin[c] = imp_begin_[c];
+          it.lm_end[c] = imp_end_[c];
+        }
+        it.tile_begin[5] = n_tiles_;
+        hipLaunchKernelGGL((rba::k_s1_qr_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, it);
+      }
+      if (imp_end_[5] > imp_begin_[5])
+        hipLaunchKernelGGL((rba::k_s1_qr_wide<S, 2>), dim3((imp_end_[5] - imp_begin_[5] + 3) / 4), dim3(256), 0,
+                           stream_, prm_, imp_begin_[5], imp_end_[5]);
+      if (imp_end_[6] > imp_begin_[6])
+        hipLaunchKernelGGL((rba::k_s1_qr_wide<S, 4>), dim3((imp_end_[6] - imp_begin_[6] + 3) / 4), dim3(256), 0,
+                           stream_, prm_, imp_begin_[6], imp_end_[6]);
+      if (n_obs_small_ > 0)
+        hipLaunchKernelGGL((rba::k_s1_cols<S>),
+                           dim3(unsigned((n_obs_small_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
+                           dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * 54 * sizeof(S), stream_, prm_,
+                           int64_t(n_obs_small_));
+      if (n_big_ > 0)
+        hipLaunchKernelGGL((rba::k_linearize_qr_big<S>), dim3(n_big_), dim3(256),
+                           size_t(16) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_);
+      hipLaunchKernelGGL((rba::k_cam_bmid<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
+    } else if (sc_) {
       // LinearizorSC::linearize (linearizor_sc.cpp:70-99)
       hipLaunchKernelGGL((rba::k_sc_linearize_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0,
                          stream_, scp_);
@@ -1198,6 +1236,12 @@ class Solver final : public rba_solver {
   }
   void launch_cam_stage1(const rba::Params<double>& prm) {
     hipLaunchKernelGGL((rba::k_cam_stage1<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
+  }
+  void launch_cam_gram(const rba::Params<float>& prm) {
+    hipLaunchKernelGGL((rba::k_cam_gram_mfma), dim3(n_cams_), dim3(256), 0, stream_, prm);
+  }
+  void launch_cam_gram(const rba::Params<double>& prm) {
+    hipLaunchKernelGGL((rba::k_cam_gram<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
   }
   void launch_cam_stage2(const rba::Params<float>& prm, float lambda) {
     hipLaunchKernelGGL((rba::k_cam_stage2_mfma), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
@@ -1832,13 +1876,13 @@ class Solver final : public rba_solver {
       sync();
     } else {
       d_R0_.download(R.data(), R.size(), stream_);
-      std::vector<S> qtr(2 * size_t(n_obs_));
+      std::vector<S> vh(8 * size_t(n_obs_));  // (v0, v1, v2, Q^T r) per block row
       std::vector<int64_t> lm_obs(n_lms_ + 1);
-      d_qtr_.download(qtr.data(), qtr.size(), stream_);
+      d_Vh_.download(vh.data(), vh.size(), stream_);
       d_lm_obs_.download(lm_obs.data(), lm_obs.size(), stream_);
       sync();
       for (int s = 0; s < n_lms_; ++s)
-        for (int c = 0; c < 3; ++c) q[3 * size_t(s) + c] = qtr[2 * lm_obs[s] + c];
+        for (int c = 0; c < 3; ++c) q[3 * size_t(s) + c] = vh[4 * (2 * lm_obs[s] + c) + 3];
     }
     S* Ro = static_cast<S*>(R6);
     S* qo = static_cast<S*>(q3);
@@ -1858,13 +1902,21 @@ class Solver final : public rba_solver {
       m->back_substitution = no * (26 * s + 4) + nl * 18 * s;
       m->product_matrix_free = 0;
     } else {
-      // per observation written by stage 1: top0 27, JpS 18, bmO 9, qtr 2, JlS 6, rS 2, Vh 8 (+ JT 18, VT 6 tiles)
-      const int64_t rec = (27 + 18 + 9 + 2 + 6 + 2 + 8 + (opt_.implicit_q ? 24 : 0)) * s;
-      m->stage1 = 2 * geometry_in + no * 4 /* CSC */ + no * rec + nl * 12 * s + (opt_.implicit_q ? 0 : storage_dense_bytes_) +
-                  no * (27 * s + 4) /* camera-major read of JpS, bmO */ + nc * (9 + 90) * s;
+      if (opt_.implicit_q) {
+        // kernels_s1.hpp: geometry writes JpS 18 + Vh 8; Gram pass reads JpS 18 (+ CSC index); QR pass reads
+        // Vh 8, writes Vh 8 + JlS 6 + rS 2; column pass reads JpS 18 + Vh 8 + indices, writes top0 27 + JpS 18
+        // + bmO 9; b pass reads bmO 9 (+ CSC index)
+        m->stage1 = geometry_in + no * ((18 + 8) + 18 + (8 + 8 + 6 + 2) + (18 + 8) + (27 + 18 + 9) + 9) * s +
+                    no * (4 + 8 + 8 + 4) + nl * (12 + 12 + 12) * s + nc * (9 + 81 + 81 + 9 + 9) * s;
+      } else {
+        // round-1 kernels: top0 27, JpS 18, bmO 9, JlS 6, rS 2, Vh 8 and the dense blocks
+        m->stage1 = 2 * geometry_in + no * 4 /* CSC */ + no * (27 + 18 + 9 + 6 + 2 + 8) * s + nl * 12 * s +
+                    storage_dense_bytes_ + no * (27 * s + 4) /* camera-major read of JpS, bmO */ + nc * (9 + 90) * s;
+      }
       m->stage2 = nl * (6 + 3 + 16 + 6 + 3 + 3 + 9) * s + no * (27 + 27 + 9) * s + no * ((27 + 9) * s + 4) + nc * 180 * s;
       m->back_substitution = no * (18 + 27 + 5 + 4) * s + no * (5 + 6 + 2 + 2) * s + nl * (6 + 3 + 3 + 3 + 3 + 8) * s;
-      m->product_matrix_free = opt_.implicit_q ? no * (24 * s + 8) + nl * 12 * s + nc * 18 * s : hx_bytes_;
+      // implicit-Q product: JpS row 9 + Vh row 4 per block row, camera / row maps, tau + Z per landmark
+      m->product_matrix_free = opt_.implicit_q ? no * (26 * s + 16) + nl * 12 * s + nc * 18 * s : hx_bytes_;
     }
     const int64_t nnz = sc_ ? sc_nnz_ : ex_nnz_;
     m->product_assembled = nnz * (81 * s + 4) + nc * 18 * s;
@@ -1935,11 +1987,12 @@ class Solver final : public rba_solver {
   DevBuf<int> d_lm_k_, d_obs_cam_, d_obs_lm_, d_fail_;
   DevBuf<int64_t> d_lm_obs_, d_lm_blk_, d_cam_off_;
   DevBuf<int> d_cam_obs_;
-  DevBuf<S> d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_JT_, d_VT_, d_JlS_, d_rS_, d_bsO_, d_givens_, d_bdO_;
-  DevBuf<int> d_CT_, d_lm_tile_, d_lm_lane0_;
+  DevBuf<S> d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_LQ_, d_JlS_, d_rS_, d_bsO_, d_givens_, d_bdO_;
+  DevBuf<int> d_CT_, d_RT_;
+  int64_t n_obs_small_ = 0;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
-  DevBuf<S> d_A_, d_top0_, d_topd_, d_qtr_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;
+  DevBuf<S> d_A_, d_top0_, d_topd_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;
   DevBuf<S> d_jp_diag2_, d_pose_scaling_, d_mid_, d_bb_, d_inv_;
   DevBuf<S> d_x_, d_r_, d_p_, d_z_, d_q_, d_tmp_, d_inc_, d_vin_, d_pw_t_, d_pw_e_;
   DevBuf<double> d_lm_ldiff_, d_partials_, d_pcg_partials_;
@@ -1954,6 +2007,7 @@ class Solver final : public rba_solver {
   int hx_event_count_ = 0, hx_calls_ = 0;
   bool hx_single_stream_ = false;
   bool qr_unpacked_ = false;  // RBA_QR_UNPACKED=1: one wavefront per landmark also for k <= 7
+  bool s1_fused_ = false;     // RBA_S1_FUSED=1: round-1 stage 1 (geometry + QR + columns in one kernel)
   // explicit reduced matrix of the square-root solver (adaptive, see pcg())
   int explicit_after_ = 0;  // matrix-free products before a solve switches to S x; 0 = never
   bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;
