@@ -61,6 +61,8 @@ struct Params {
   S* bsO;       // [n_obs][5]     back-substitution scratch: topd x (3), Jp x (2)
   S* givens;    // [n_lms][16]    the 6 damping rotations of stage 2: c[6], s[6], damping-row residual[3], pad
   S* bdO;       // [n_obs][9]     damping rows' part of b per observation
+  S* bO;        // [n_obs][9]     staged path (kernels_s1.hpp): Q2 part + damping rows' part of b per observation
+  int b_from_records;  // b = sum_obs bO (staged path) instead of b_mid + sum_obs bdO
   S* R0;        // [6 n_lms]
   S* Rd;        // [6 n_lms]
   S* q1trd;     // [3 n_lms]
@@ -322,7 +324,10 @@ __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float 
   if (tid < 252) {
     const int g = tid / 9, a = tid - 9 * g;
     double accb = 0;
-    if (damped) accb = cam_sum9(p.cam_obs, t0, t1, g, [&](int o) { return p.bdO[int64_t(o) * 9 + a]; });
+    if (p.b_from_records)
+      accb = cam_sum9(p.cam_obs, t0, t1, g, [&](int o) { return p.bO[int64_t(o) * 9 + a]; });
+    else if (damped)
+      accb = cam_sum9(p.cam_obs, t0, t1, g, [&](int o) { return p.bdO[int64_t(o) * 9 + a]; });
     bsum[g][a] = accb;
   }
   __syncthreads();
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float 
   }
   if (tid >= 128 && tid < 137) {
     const int a = tid - 128;
-    double accb = double(p.b_mid[9 * c + a]);
+    double accb = p.b_from_records ? 0.0 : double(p.b_mid[9 * c + a]);
     for (int g = 0; g < 28; ++g) accb += bsum[g][a];
     p.b[9 * c + a] = float(accb);
   }
@@ -423,7 +428,8 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
         v[u] = S(0);
         if (idx < n * W) {
           const int q = idx / W, f = idx - W * q;
-          v[u] = f < 27 ? p.topd[int64_t(olist[q]) * 27 + f] : p.bdO[int64_t(olist[q]) * 9 + (f - 27)];
+          v[u] = f < 27 ? p.topd[int64_t(olist[q]) * 27 + f]
+                        : (p.b_from_records ? p.bO : p.bdO)[int64_t(olist[q]) * 9 + (f - 27)];
         }
       }
 #pragma unroll
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
         }
       } else if (tid < 252) {
         const int a = tid - 243;
-        if (lambda != S(0))
+        if (lambda != S(0) || p.b_from_records)
           for (int q = 0; q < n; ++q) acc += double(rec[q][27 + a]);
       }
     }
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
     p.blocks[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + red[0][tid] + red[1][tid] +
                                red[2][tid] + ((tid / 9 == tid % 9) ? double(lambda) : 0.0));
   if (tid >= 243 && tid < 252)
-    p.b[9 * c + (tid - 243)] = S(double(p.b_mid[9 * c + (tid - 243)]) + acc);
+    p.b[9 * c + (tid - 243)] = S((p.b_from_records ? 0.0 : double(p.b_mid[9 * c + (tid - 243)])) + acc);
 }
 
 // pose_jacobian_scaling = 1 / (eps + sqrt(Jp_diag2))   (linearizor_qr.cpp:130-132)
@@ -1046,8 +1052,8 @@ __global__ __launch_bounds__(256) void k_stage2_landmark(Params<S> p, S lambda) 
 }
 
 template <class S>
-__global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t n_obs) {
-  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t o_begin, int64_t n_obs) {
+  const int64_t t = 9 * o_begin + int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (t >= 9 * n_obs) return;
   const int64_t o = t / 9;
   const int comp = int(t - 9 * o);
@@ -1088,7 +1094,11 @@ __global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t n_obs)
   Td[9 + comp] = tt[1];
   Td[18 + comp] = tt[2];
   // the damping rows' part of b (add_Q2TJp_T_Q2Tr on rows 2k-3..2k-1), summed camera-major later
-  p.bdO[9 * o + comp] = d[0] * g[12] + d[1] * g[13] + d[2] * g[14];
+  const S bd = d[0] * g[12] + d[1] * g[13] + d[2] * g[14];
+  if (p.b_from_records)
+    p.bO[9 * o + comp] = p.bmO[9 * o + comp] + bd;
+  else
+    p.bdO[9 * o + comp] = bd;
   const int k = p.lm_k[s];
   if (p.implicit && k <= 112) return;  // dense block unused (only the k > 112 kernels read it)
   const int nrows = 2 * k, ncols = 9 * k;

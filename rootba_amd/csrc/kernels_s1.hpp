@@ -21,15 +21,16 @@
 //                   Householder QR of the 2k x 3 Jl (perform_qr_householder, ipp:717-743), Q^T r, and the
 //                   per-landmark scalars of the compact reflector application. Only the 4 columns
 //                   [Jl | r] are transformed here - Q depends on Jl alone.
-//   k_s1_cols       one THREAD per (observation, pose component): column scaling (scale_Jp_cols,
-//                   ipp:589-614, commutes with Q^T), the three top rows Q1^T Jp and the Q2 part of b
-//                   in CLOSED FORM: with Q^T Jp[:, j] = Jp[:, j] - sum_m c_m v_m (three reflectors,
+//   k_s12_cols      one THREAD per observation, run inside the first stage 2 of the linearisation point
+//                   (fused with the landmark-damping rotation of the top rows): column scaling
+//                   (scale_Jp_cols, ipp:589-614, commutes with Q^T), the three top rows Q1^T Jp and the
+//                   Q2 part of b in CLOSED FORM: with Q^T Jp[:, j] = Jp[:, j] - sum_m c_m v_m (three reflectors,
 //                   c_m from two FMAs each because column j has two non-zero rows),
 //                     b_j = sum_{r >= 3} (Q^T Jp)[r, j] (Q^T r)[r]
 //                         = m0 q[2i] + m1 q[2i+1] (rows >= 3 only) - sum_m c_m d_m,   d_m = sum_{r>=3} v_m[r] q[r]
 //                   — the same products as the row-by-row sum, associated per reflector, O(1) per
 //                   column instead of O(2k).
-//   k_cam_bmid      camera-major sum of the per-observation parts of b (add_Q2TJp_T_Q2Tr, ipp:443-466).
+//                   The camera-major sum of the b records happens in stage 2's camera pass.
 // Landmarks with more than 112 observations keep the workgroup-per-landmark kernel (kernels_big.hpp),
 // the dense-block configuration (implicit_q = 0) the round-1 kernels (kernels.hpp).
 #pragma once
@@ -459,22 +460,28 @@ __global__ __launch_bounds__(256) void k_s1_qr_wide(Params<S> p, int lm_begin, i
 }
 
 // ---------------------------------------------------------------------------
-// pass C: one thread per observation (nine columns in registers); the three output records of the
-// workgroup's 128 consecutive observations are contiguous in HBM, so they are staged in LDS and
-// written as full 16-byte streams (the thread-per-(observation, component) form of this pass issued
-// nineteen vector memory instructions per 4-byte result and ran at 2 TB/s)
+// pass C + stage 2 columns, fused: one thread per observation (nine columns in registers).
+// The column pass needs the pose scaling, the first stage 2 after a linearisation needs the column
+// pass's top rows and the damping: like the reference, which scales the block lazily inside the
+// first stage 2 (linearizor_qr.cpp:189-191), the column pass runs THERE and rotates its three top
+// rows straight into the damped ones (set_landmark_damping, ipp:165-210, six Givens rotations per
+// landmark from k_stage2_landmark) - the undamped top rows are never stored. A later stage 2 of the
+// same linearisation point (rejected step, new lambda) re-runs the pass on the already scaled rows.
+// Outputs per observation: topd [3][9] (damped Q1^T Jp), bO [9] (Q2 part + damping rows' part of b),
+// JpS [2][9] (scaled rows, first pass only). The workgroup's 128 observations are consecutive, so
+// the records are staged in LDS and move as contiguous 16-byte streams.
 // ---------------------------------------------------------------------------
 constexpr int kS1ColsThreads = 128;
 
 template <class S>
-__global__ __launch_bounds__(kS1ColsThreads) void k_s1_cols(Params<S> p, int64_t n_obs) {
+__global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_t n_obs, int scaled_input) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
   using V = typename std::conditional<sizeof(S) == 4, float4, double2>::type;
   constexpr int N = 16 / int(sizeof(S)), NT = kS1ColsThreads;
   extern __shared__ __attribute__((aligned(16))) char smem_s1c[];
-  S* sJ = reinterpret_cast<S*>(smem_s1c);  // [NT][18]  in: unscaled rows, out: scaled rows
-  S* sT = sJ + NT * 18;                    // [NT][27]  Q1^T Jp
-  S* sB = sT + NT * 27;                    // [NT][9]   Q2 part of b
+  S* sJ = reinterpret_cast<S*>(smem_s1c);  // [NT][18]  in: Jacobian rows, out: scaled rows
+  S* sT = sJ + NT * 18;                    // [NT][27]  damped Q1^T Jp
+  S* sB = sT + NT * 27;                    // [NT][9]   b record
   const int tid = threadIdx.x;
   const int64_t o_base = int64_t(blockIdx.x) * NT;
   const int n_here = int(min<int64_t>(NT, n_obs - o_base));
@@ -494,11 +501,23 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s1_cols(Params<S> p, int64_t
   const V4 va = vh[2 * oc], vb = vh[2 * oc + 1];
   S dsc[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) dsc[c] = p.pose_scaling[9 * cam + c];
+  for (int c = 0; c < 9; ++c) dsc[c] = scaled_input ? S(1) : p.pose_scaling[9 * cam + c];
   const int64_t o0 = p.lm_obs[s];
   const V4* __restrict__ lq = reinterpret_cast<const V4*>(p.LQ + 12 * size_t(s));
   const V4 q0 = lq[0], q1 = lq[1], q2 = lq[2];
   const V4 w0 = vh[2 * o0], w1 = vh[2 * o0 + 1], w2 = vh[2 * o0 + 2];
+  S g[16];  // the landmark's damping record: c[6], s[6], damping-row residual[3]
+  {
+    const V4* __restrict__ src = reinterpret_cast<const V4*>(p.givens + 16 * size_t(s));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const V4 v = src[q];
+      g[4 * q] = v.x;
+      g[4 * q + 1] = v.y;
+      g[4 * q + 2] = v.z;
+      g[4 * q + 3] = v.w;
+    }
+  }
   const int i = int(oc - o0);
   __syncthreads();
   if (act) {
@@ -511,25 +530,41 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s1_cols(Params<S> p, int64_t
       const S c1 = tau1 * (va.y * m0 + vb.y * m1 - c0 * g10);
       const S c2 = tau2 * (va.z * m0 + vb.z * m1 - c0 * g20 - c1 * g21);
       // rows 0..2 of Q^T Jp (column j): Q1^T Jp
-      S t0 = -(c0 * w0.x + c1 * w0.y + c2 * w0.z);
-      S t1 = -(c0 * w1.x + c1 * w1.y + c2 * w1.z);
-      S t2 = -(c0 * w2.x + c1 * w2.y + c2 * w2.z);
+      S tt[3] = {-(c0 * w0.x + c1 * w0.y + c2 * w0.z), -(c0 * w1.x + c1 * w1.y + c2 * w1.z),
+                 -(c0 * w2.x + c1 * w2.y + c2 * w2.z)};
       S bm = -(c0 * d0 + c1 * d1 + c2 * d2);
       if (i == 0) {
-        t0 += m0;
-        t1 += m1;
+        tt[0] += m0;
+        tt[1] += m1;
       } else if (i == 1) {
-        t2 += m0;
+        tt[2] += m0;
         bm += m1 * vb.w;
       } else {
         bm += m0 * va.w + m1 * vb.w;
       }
-      sT[27 * tid + c] = t0;
-      sT[27 * tid + 9 + c] = t1;
-      sT[27 * tid + 18 + c] = t2;
+      // landmark damping: rotate the top rows against the three damping rows (start at zero)
+      S d[3] = {S(0), S(0), S(0)};
+      {
+        int idx = 0;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+#pragma unroll
+          for (int m = 0; m <= n; ++m) {
+            const S cc = g[idx], sn = g[6 + idx];
+            const S x = d[n - m], y = tt[n];
+            d[n - m] = cc * x + sn * y;
+            tt[n] = -sn * x + cc * y;
+            ++idx;
+          }
+        }
+      }
+      sT[27 * tid + c] = tt[0];
+      sT[27 * tid + 9 + c] = tt[1];
+      sT[27 * tid + 18 + c] = tt[2];
       sJ[18 * tid + c] = m0;
       sJ[18 * tid + 9 + c] = m1;
-      sB[9 * tid + c] = bm;
+      // Q2 rows' part of b (add_Q2TJp_T_Q2Tr) + the damping rows' part
+      sB[9 * tid + c] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
     }
   }
   __syncthreads();
@@ -538,10 +573,10 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s1_cols(Params<S> p, int64_t
     for (int q = tid; q < nvec; q += NT) reinterpret_cast<V*>(dst)[q] = reinterpret_cast<const V*>(src)[q];
     for (int q = nvec * N + tid; q < total; q += NT) dst[q] = src[q];
   };
-  // (16-byte alignment of the three destinations: o_base is a multiple of 128)
-  copy_out(p.top0 + 27 * o_base, sT, 27 * n_here);
-  copy_out(p.JpS + 18 * o_base, sJ, 18 * n_here);
-  copy_out(p.bmO + 9 * o_base, sB, 9 * n_here);
+  // (16-byte alignment of the destinations: o_base is a multiple of 128)
+  copy_out(p.topd + 27 * o_base, sT, 27 * n_here);
+  if (!scaled_input) copy_out(p.JpS + 18 * o_base, sJ, 18 * n_here);
+  copy_out(p.bO + 9 * o_base, sB, 9 * n_here);
 }
 
 // b_mid[c] = sum over the camera's observations of bmO (fixed order, double)

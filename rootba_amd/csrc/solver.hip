@@ -395,15 +395,20 @@ class Solver final : public rba_solver {
     // the dense landmark blocks and the QR by-products exist only for the square-root solver
     const size_t qr_obs = sc_ ? 0 : size_t(n_obs_);
     d_A_.alloc(sc_ ? 0 : size_t(blk));
-    d_top0_.alloc(27 * qr_obs);
+    staged_ = !sc_ && opt_.implicit_q && !s1_fused_;
+    // staged path: the undamped top rows / separate b parts exist only for the k > 112 landmarks
+    // (full-size buffers then, indexed by observation as everywhere else)
+    const size_t legacy_obs = (staged_ && n_big_ == 0) ? 0 : qr_obs;
+    d_top0_.alloc(27 * legacy_obs);
     d_topd_.alloc(27 * qr_obs);
+    d_bO_.alloc(staged_ ? 9 * qr_obs : 0);
     d_JpS_.alloc(18 * size_t(n_obs_));
     d_JlS_.alloc(6 * qr_obs);
     d_rS_.alloc(2 * qr_obs);
     d_bsO_.alloc(5 * qr_obs);
     d_givens_.alloc(sc_ ? 0 : 16 * size_t(n_lms));
-    d_bdO_.alloc(9 * qr_obs);
-    d_bmO_.alloc(9 * qr_obs);
+    d_bdO_.alloc(staged_ ? 0 : 9 * qr_obs);
+    d_bmO_.alloc(9 * legacy_obs);
     d_Vh_.alloc(8 * qr_obs);
     if (sc_) build_sc_structure(lm_k, lm_obs, s_obs_cam);
     // square-root solver: explicit reduced matrix for long PCG solves (see pcg())
@@ -498,6 +503,8 @@ class Solver final : public rba_solver {
     prm_.bsO = d_bsO_.get();
     prm_.givens = d_givens_.get();
     prm_.bdO = d_bdO_.get();
+    prm_.bO = d_bO_.get();
+    prm_.b_from_records = staged_ ? 1 : 0;
     prm_.bmO = d_bmO_.get();
     prm_.Vh = d_Vh_.get();
     prm_.tauH = d_tauH_.get();
@@ -1016,7 +1023,7 @@ class Solver final : public rba_solver {
     use_device();
     time_begin();
     d_fail_.zero(stream_);
-    const bool staged = !sc_ && opt_.implicit_q && !s1_fused_;  // kernels_s1.hpp
+    const bool staged = staged_;  // kernels_s1.hpp
     if (staged) {
       // geometry once per observation; Jp_diag2 falls out of the camera-major Gram pass
       hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256),
@@ -1047,15 +1054,11 @@ class Solver final : public rba_solver {
       if (imp_end_[6] > imp_begin_[6])
         hipLaunchKernelGGL((rba::k_s1_qr_wide<S, 4>), dim3((imp_end_[6] - imp_begin_[6] + 3) / 4), dim3(256), 0,
                            stream_, prm_, imp_begin_[6], imp_end_[6]);
-      if (n_obs_small_ > 0)
-        hipLaunchKernelGGL((rba::k_s1_cols<S>),
-                           dim3(unsigned((n_obs_small_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
-                           dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * 54 * sizeof(S), stream_, prm_,
-                           int64_t(n_obs_small_));
+      // the column pass (scaled rows, top rows, b records) runs inside the first stage 2 (k_s12_cols)
+      cols_pending_ = true;
       if (n_big_ > 0)
         hipLaunchKernelGGL((rba::k_linearize_qr_big<S>), dim3(n_big_), dim3(256),
                            size_t(16) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_);
-      hipLaunchKernelGGL((rba::k_cam_bmid<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
     } else if (sc_) {
       // LinearizorSC::linearize (linearizor_sc.cpp:70-99)
       hipLaunchKernelGGL((rba::k_sc_linearize_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0,
@@ -1110,8 +1113,23 @@ class Solver final : public rba_solver {
     }
     hipLaunchKernelGGL((rba::k_stage2_landmark<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_, prm_,
                        lambda);
-    hipLaunchKernelGGL((rba::k_stage2_cols<S>), dim3(unsigned((9 * int64_t(n_obs_) + 255) / 256)), dim3(256), 0,
-                       stream_, prm_, int64_t(n_obs_));
+    if (staged_) {
+      // column pass + rotation of the top rows, fused (kernels_s1.hpp); landmarks with k > 112 keep
+      // their stored undamped top rows and the round-1 rotation pass
+      if (n_obs_small_ > 0)
+        hipLaunchKernelGGL((rba::k_s12_cols<S>),
+                           dim3(unsigned((n_obs_small_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
+                           dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * 54 * sizeof(S), stream_, prm_,
+                           int64_t(n_obs_small_), cols_pending_ ? 0 : 1);
+      cols_pending_ = false;
+      if (n_obs_ > n_obs_small_)
+        hipLaunchKernelGGL((rba::k_stage2_cols<S>),
+                           dim3(unsigned((9 * (int64_t(n_obs_) - n_obs_small_) + 255) / 256)), dim3(256), 0, stream_,
+                           prm_, int64_t(n_obs_small_), int64_t(n_obs_));
+    } else {
+      hipLaunchKernelGGL((rba::k_stage2_cols<S>), dim3(unsigned((9 * int64_t(n_obs_) + 255) / 256)), dim3(256), 0,
+                         stream_, prm_, int64_t(0), int64_t(n_obs_));
+    }
     launch_cam_stage2(prm_, lambda);
     if (comm_ || cb_fn_) {
       // every rank added lambda*I and holds only its landmarks' sums: make the
@@ -1288,6 +1306,7 @@ class Solver final : public rba_solver {
 
   void right_multiply(const void* x, void* y) override {
     use_device();
+    if (cols_pending_) run_stage2(S(0));  // the operator needs the scaled rows of the column pass
     d_vin_.upload(static_cast<const S*>(x), nvec_, stream_);
     d_tmp_.zero(stream_);
     launch_hx(d_vin_.get(), d_tmp_.get());
@@ -1904,16 +1923,19 @@ class Solver final : public rba_solver {
     } else {
       if (opt_.implicit_q) {
         // kernels_s1.hpp: geometry writes JpS 18 + Vh 8; Gram pass reads JpS 18 (+ CSC index); QR pass reads
-        // Vh 8, writes Vh 8 + JlS 6 + rS 2; column pass reads JpS 18 + Vh 8 + indices, writes top0 27 + JpS 18
-        // + bmO 9; b pass reads bmO 9 (+ CSC index)
-        m->stage1 = geometry_in + no * ((18 + 8) + 18 + (8 + 8 + 6 + 2) + (18 + 8) + (27 + 18 + 9) + 9) * s +
-                    no * (4 + 8 + 8 + 4) + nl * (12 + 12 + 12) * s + nc * (9 + 81 + 81 + 9 + 9) * s;
+        // Vh 8, writes Vh 8 + JlS 6 + rS 2 (the column pass belongs to stage 2 here)
+        m->stage1 = geometry_in + no * ((18 + 8) + 18 + (8 + 8 + 6 + 2)) * s + no * (4 + 8) + nl * (12 + 12) * s +
+                    nc * (9 + 81 + 81 + 9) * s;
       } else {
         // round-1 kernels: top0 27, JpS 18, bmO 9, JlS 6, rS 2, Vh 8 and the dense blocks
         m->stage1 = 2 * geometry_in + no * 4 /* CSC */ + no * (27 + 18 + 9 + 6 + 2 + 8) * s + nl * 12 * s +
                     storage_dense_bytes_ + no * (27 * s + 4) /* camera-major read of JpS, bmO */ + nc * (9 + 90) * s;
       }
-      m->stage2 = nl * (6 + 3 + 16 + 6 + 3 + 3 + 9) * s + no * (27 + 27 + 9) * s + no * ((27 + 9) * s + 4) + nc * 180 * s;
+      if (opt_.implicit_q)  // landmark records; fused column pass: JpS 18 + Vh 8 in, topd 27 + JpS 18 + bO 9 out; camera pass
+        m->stage2 = nl * (6 + 3 + 16 + 6 + 3 + 3 + 9 + 12) * s + no * ((18 + 8) + (27 + 18 + 9)) * s + no * 8 +
+                    no * ((27 + 9) * s + 4) + nc * 180 * s;
+      else
+        m->stage2 = nl * (6 + 3 + 16 + 6 + 3 + 3 + 9) * s + no * (27 + 27 + 9) * s + no * ((27 + 9) * s + 4) + nc * 180 * s;
       m->back_substitution = no * (18 + 27 + 5 + 4) * s + no * (5 + 6 + 2 + 2) * s + nl * (6 + 3 + 3 + 3 + 3 + 8) * s;
       // implicit-Q product: JpS row 9 + Vh row 4 per block row, camera / row maps, tau + Z per landmark
       m->product_matrix_free = opt_.implicit_q ? no * (26 * s + 16) + nl * 12 * s + nc * 18 * s : hx_bytes_;
@@ -1987,7 +2009,7 @@ class Solver final : public rba_solver {
   DevBuf<int> d_lm_k_, d_obs_cam_, d_obs_lm_, d_fail_;
   DevBuf<int64_t> d_lm_obs_, d_lm_blk_, d_cam_off_;
   DevBuf<int> d_cam_obs_;
-  DevBuf<S> d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_LQ_, d_JlS_, d_rS_, d_bsO_, d_givens_, d_bdO_;
+  DevBuf<S> d_JpS_, d_bmO_, d_bO_, d_Vh_, d_tauH_, d_Zd_, d_LQ_, d_JlS_, d_rS_, d_bsO_, d_givens_, d_bdO_;
   DevBuf<int> d_CT_, d_RT_;
   int64_t n_obs_small_ = 0;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;
@@ -2008,6 +2030,8 @@ class Solver final : public rba_solver {
   bool hx_single_stream_ = false;
   bool qr_unpacked_ = false;  // RBA_QR_UNPACKED=1: one wavefront per landmark also for k <= 7
   bool s1_fused_ = false;     // RBA_S1_FUSED=1: round-1 stage 1 (geometry + QR + columns in one kernel)
+  bool staged_ = false;       // stage 1 staged by parallelism (kernels_s1.hpp): implicit-Q configuration
+  bool cols_pending_ = false; // linearised, column pass not yet run (it runs inside the first stage 2)
   // explicit reduced matrix of the square-root solver (adaptive, see pcg())
   int explicit_after_ = 0;  // matrix-free products before a solve switches to S x; 0 = never
   bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;

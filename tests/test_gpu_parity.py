@@ -559,15 +559,17 @@ def test_schur_complement_solve_apply_and_lm(ladybug_far, small_problem, dtype):
     r_g, _ = g_sc.optimize_lm()
     r_o, _ = o_sc.optimize_lm()
     r_q, _ = g_qr.optimize_lm()
-    assert len(r_g) == len(r_o) == len(r_q)
     if dtype == np.float64:
+        assert len(r_g) == len(r_o) == len(r_q)
         for a, b, c in zip(r_g, r_o, r_q):
             assert abs(a.cost - b.cost) <= 1e-9 * b.cost and abs(a.cost - c.cost) <= 1e-9 * c.cost
             assert a.step_is_successful == b.step_is_successful == c.step_is_successful
         assert [r.cg_iterations for r in r_g] == [r.cg_iterations for r in r_o]
     else:
         # float32: lock-step while the cost still drops by more than its own resolution, then
-        # only the reached optimum is comparable (accept/reject flips at the noise floor)
+        # only the reached optimum is comparable (accept/reject flips at the noise floor, and with
+        # them the iteration at which the function-tolerance rule ends a run)
+        assert abs(len(r_g) - len(r_o)) <= 2 and abs(len(r_g) - len(r_q)) <= 2
         best = [min(r.cost for r in rows if r.step_is_successful) for rows in (r_g, r_o, r_q)]
         assert max(best) - min(best) <= 2e-5 * min(best)
         for a, b, c in zip(r_g[:4], r_o[:4], r_q[:4]):
