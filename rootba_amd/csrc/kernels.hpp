@@ -24,6 +24,10 @@
 
 namespace rba {
 
+// Per-observation record of stage 2: [damped Q1^T Jp 3x9 | b record 9] = 36 scalars (144 B in float:
+// nine 16-byte pieces, so camera-major passes fetch whole records with wide loads).
+constexpr int kTd = 36;
+
 template <class S>
 struct Params {
   int n_cams;
@@ -43,7 +47,8 @@ struct Params {
   // landmark blocks
   S* A;
   S* top0;      // [n_obs][3][9] Q1^T Jp, undamped (observation-major)
-  S* topd;      // [n_obs][3][9] with landmark damping
+  S* topd;      // [n_obs][kTd]  rows 0..26: Q1^T Jp with landmark damping ([3][9]); 27..35: the observation's
+                //               part of b (staged path: Q2 rows + damping rows; round-1 path: damping rows only)
   S* JpS;       // [n_obs][2][9] weighted, column-scaled pose Jacobian
   S* bmO;       // [n_obs][9]    per-observation part of b from the Q2 rows
   // implicit-Q operator (k_hx_implicit): the factors instead of the product
@@ -60,9 +65,7 @@ struct Params {
   S* rS;        // [n_obs][2]     sqrt(w) r
   S* bsO;       // [n_obs][5]     back-substitution scratch: topd x (3), Jp x (2)
   S* givens;    // [n_lms][16]    the 6 damping rotations of stage 2: c[6], s[6], damping-row residual[3], pad
-  S* bdO;       // [n_obs][9]     damping rows' part of b per observation
-  S* bO;        // [n_obs][9]     staged path (kernels_s1.hpp): Q2 part + damping rows' part of b per observation
-  int b_from_records;  // b = sum_obs bO (staged path) instead of b_mid + sum_obs bdO
+  int b_from_records;  // b = sum_obs (b record) (staged path, kernels_s1.hpp) instead of b_mid + sum_obs (b record)
   S* R0;        // [6 n_lms]
   S* Rd;        // [6 n_lms]
   S* q1trd;     // [3 n_lms]
@@ -278,6 +281,71 @@ __device__ __forceinline__ double cam_sum9(const int* __restrict__ cam_obs, int6
   return acc;
 }
 
+// LDS-staged variant: the wave fetches WHOLE records of 32 observations with 8- / 16-byte pieces
+// (nine pieces per record, every lane busy: 5 gather instructions per 32 observations instead of 16-32
+// four-byte ones with 36 of 64 lanes active), then feeds the matrix cores out of LDS. `side(r, rec)` is
+// called per lane group for VALU side sums over the same staged records (no second gather).
+//   W = 18, ROWS = 2: [Jp row 0 | Jp row 1]          (8-byte pieces)
+//   W = 36, ROWS = 3: [top row 0 | 1 | 2 | b record]  (16-byte pieces)
+// Camera-major workgroups are launched as 8 * ceil(n_cams / 8) blocks and mapped so that one XCD
+// (block b runs on XCD b % 8, each with its own L2) walks a CONTIGUOUS range of cameras: the records
+// of a landmark sit next to each other in HBM and belong to cameras that are close in index, so the
+// cache lines one camera's gather touches are shared with the cameras the same XCD works on at the
+// same time instead of being fetched once per XCD.
+__device__ __forceinline__ int xcd_swizzled_camera(int n_cams) {
+  const int per = (n_cams + 7) / 8;
+  return (blockIdx.x % 8) * per + blockIdx.x / 8;
+}
+inline int xcd_swizzled_grid(int n_cams) { return 8 * ((n_cams + 7) / 8); }
+
+constexpr int kCamChunk = 32;
+template <int W, int ROWS, class F>
+__device__ __forceinline__ f32x4 mfma_xtx_staged(const float* __restrict__ rec, const int* __restrict__ cam_obs,
+                                                 int64_t t0, int64_t t1, int wave, int lane, f32x4 acc, float* lds,
+                                                 bool use_mfma, F&& side) {
+  constexpr int PS = W == 18 ? 2 : 4;  // floats per piece
+  constexpr int NP = W / PS;           // 9 pieces per record
+  static_assert(NP == 9, "nine pieces per record");
+  const int i = lane & 15, kk = lane >> 4;
+  for (int64_t base = t0 + kCamChunk * wave; base < t1; base += 4 * kCamChunk) {
+    const int cnt = int(min<int64_t>(kCamChunk, t1 - base));
+    const int idxreg = lane < cnt ? cam_obs[base + lane] : 0;
+#pragma unroll
+    for (int j = 0; j < (kCamChunk * NP + 63) / 64; ++j) {
+      const int q = j * 64 + lane;
+      const int r = q / NP, pc = q - NP * r;
+      const int o = __shfl(idxreg, r & 31);
+      if (q < cnt * NP) {
+        if (PS == 2) {
+          const float2 v = *reinterpret_cast<const float2*>(rec + int64_t(o) * W + 2 * pc);
+          *reinterpret_cast<float2*>(lds + r * W + 2 * pc) = v;
+        } else {
+          const float4 v = *reinterpret_cast<const float4*>(rec + int64_t(o) * W + 4 * pc);
+          *reinterpret_cast<float4*>(lds + r * W + 4 * pc) = v;
+        }
+      }
+    }
+    wave_lds_fence();
+    if (use_mfma) {
+      if (ROWS == 2) {
+        for (int s = 0; s < cnt; s += 2) {
+          const int so = s + (kk >> 1);
+          const float v = (i < 9 && so < cnt) ? lds[so * W + 9 * (kk & 1) + i] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, acc, 0, 0, 0);
+        }
+      } else {
+        for (int s = 0; s < cnt; ++s) {
+          const float v = (i < 9 && kk < 3) ? lds[s * W + 9 * kk + i] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, acc, 0, 0, 0);
+        }
+      }
+    }
+    side(cnt, lds);
+    wave_lds_fence();  // the next chunk overwrites the staging buffer
+  }
+  return acc;
+}
+
 // float: matrix-core version
 __global__ __launch_bounds__(256) void k_cam_stage1_mfma(Params<float> p) {
   __shared__ float tile[4][16][16];
@@ -312,24 +380,26 @@ __global__ __launch_bounds__(256) void k_cam_stage1_mfma(Params<float> p) {
 
 __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float lambda) {
   __shared__ float tile[4][16][16];
-  __shared__ double bsum[28][9];
-  const int c = blockIdx.x;
+  __shared__ double bsum[4][7][9];
+  __shared__ __attribute__((aligned(16))) float stage[4][kCamChunk * kTd];
+  const int c = xcd_swizzled_camera(p.n_cams);
+  if (c >= p.n_cams) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const bool damped = lambda != 0.f;
-  if (!p.jacobi) acc = mfma_xtx<3>(p.topd, 27, p.cam_obs, t0, t1, wave, lane, acc);
+  const bool want_b = p.b_from_records || damped;
+  // b: lane (g, a) of 7 groups x 9 components sums the b records of observations g, g+7, ... (double)
+  const int g = lane / 9, a = lane - 9 * g;
+  double accb = 0;
+  acc = mfma_xtx_staged<kTd, 3>(p.topd, p.cam_obs, t0, t1, wave, lane, acc, stage[wave], !p.jacobi,
+                                [&](int cnt, const float* rec) {
+                                  if (want_b && lane < 63)
+                                    for (int r = g; r < cnt; r += 7) accb += double(rec[r * kTd + 27 + a]);
+                                });
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-  if (tid < 252) {
-    const int g = tid / 9, a = tid - 9 * g;
-    double accb = 0;
-    if (p.b_from_records)
-      accb = cam_sum9(p.cam_obs, t0, t1, g, [&](int o) { return p.bO[int64_t(o) * 9 + a]; });
-    else if (damped)
-      accb = cam_sum9(p.cam_obs, t0, t1, g, [&](int o) { return p.bdO[int64_t(o) * 9 + a]; });
-    bsum[g][a] = accb;
-  }
+  if (lane < 63) bsum[wave][g][a] = accb;
   __syncthreads();
   if (tid < 81) {
     const int i = tid / 9, j = tid - 9 * i;
@@ -339,10 +409,11 @@ __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float 
     p.blocks[81 * c + tid] = (p.B_mid[81 * c + tid] - t) + (i == j ? lambda : 0.f);
   }
   if (tid >= 128 && tid < 137) {
-    const int a = tid - 128;
-    double accb = p.b_from_records ? 0.0 : double(p.b_mid[9 * c + a]);
-    for (int g = 0; g < 28; ++g) accb += bsum[g][a];
-    p.b[9 * c + a] = float(accb);
+    const int aa = tid - 128;
+    double sum = p.b_from_records ? 0.0 : double(p.b_mid[9 * c + aa]);
+    for (int w = 0; w < 4; ++w)
+      for (int gg = 0; gg < 7; ++gg) sum += bsum[w][gg][aa];
+    p.b[9 * c + aa] = float(sum);
   }
 }
 
@@ -428,8 +499,7 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
         v[u] = S(0);
         if (idx < n * W) {
           const int q = idx / W, f = idx - W * q;
-          v[u] = f < 27 ? p.topd[int64_t(olist[q]) * 27 + f]
-                        : (p.b_from_records ? p.bO : p.bdO)[int64_t(olist[q]) * 9 + (f - 27)];
+          v[u] = p.topd[int64_t(olist[q]) * kTd + f];
         }
       }
 #pragma unroll
@@ -1089,16 +1159,13 @@ __global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t o_begi
       }
     }
   }
-  S* Td = p.topd + 27 * o;
+  S* Td = p.topd + kTd * o;
   Td[comp] = tt[0];
   Td[9 + comp] = tt[1];
   Td[18 + comp] = tt[2];
   // the damping rows' part of b (add_Q2TJp_T_Q2Tr on rows 2k-3..2k-1), summed camera-major later
   const S bd = d[0] * g[12] + d[1] * g[13] + d[2] * g[14];
-  if (p.b_from_records)
-    p.bO[9 * o + comp] = p.bmO[9 * o + comp] + bd;
-  else
-    p.bdO[9 * o + comp] = bd;
+  Td[27 + comp] = p.b_from_records ? p.bmO[9 * o + comp] + bd : bd;
   const int k = p.lm_k[s];
   if (p.implicit && k <= 112) return;  // dense block unused (only the k > 112 kernels read it)
   const int nrows = 2 * k, ncols = 9 * k;
@@ -1586,7 +1653,7 @@ __global__ __launch_bounds__(256) void k_e0(Params<S> p, int lm_begin, int lm_en
   if (done_flag && *done_flag) return;
   const int k = p.lm_k[s];
   const int64_t o0 = p.lm_obs[s];
-  const S* __restrict__ Td = p.topd + 27 * o0;
+  const S* __restrict__ Td = p.topd + kTd * o0;
   const int lane9 = lane / 9, comp = lane - 9 * lane9;
   S t[3][CH];
   int yidx[CH];
@@ -1601,7 +1668,7 @@ __global__ __launch_bounds__(256) void k_e0(Params<S> p, int lm_begin, int lm_en
     const S xv = act[ch] ? v[yidx[ch]] : S(0);
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      t[m][ch] = act[ch] ? Td[27 * islot + 9 * m + comp] : S(0);
+      t[m][ch] = act[ch] ? Td[kTd * islot + 9 * m + comp] : S(0);
       w[m] += t[m][ch] * xv;
     }
   }
@@ -1625,11 +1692,12 @@ __global__ __launch_bounds__(256) void k_e0(Params<S> p, int lm_begin, int lm_en
 //   k_bs_landmark one thread per landmark (fixed order): delta, l_diff term, p_w update
 // ===========================================================================
 template <class S>
-__global__ __launch_bounds__(256) void k_bs_obs(Params<S> p, const S* __restrict__ x, int64_t n_obs) {
-  const int64_t o = int64_t(blockIdx.x) * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_bs_obs(Params<S> p, const S* __restrict__ x, int64_t o_begin,
+                                                int64_t n_obs) {
+  const int64_t o = o_begin + int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (o >= n_obs) return;
   const S* __restrict__ xc = x + 9 * p.obs_cam[o];
-  const S* __restrict__ td = p.topd + 27 * o;
+  const S* __restrict__ td = p.topd + kTd * o;
   const S* __restrict__ jp = p.JpS + 18 * o;
   S xv[9];
 #pragma unroll
@@ -1648,8 +1716,8 @@ __global__ __launch_bounds__(256) void k_bs_obs(Params<S> p, const S* __restrict
 }
 
 template <class S>
-__global__ __launch_bounds__(256) void k_bs_landmark(Params<S> p) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_bs_landmark(Params<S> p, int lm_begin) {
+  const int s = lm_begin + blockIdx.x * 256 + threadIdx.x;
   if (s >= p.n_lms) return;
   const int64_t ob = p.lm_obs[s], oe = p.lm_obs[s + 1];
   S rhs[3] = {p.q1trd[3 * s], p.q1trd[3 * s + 1], p.q1trd[3 * s + 2]};
@@ -1681,6 +1749,102 @@ __global__ __launch_bounds__(256) void k_bs_landmark(Params<S> p) {
   p.lms[3 * s + 0] += inc[0] * p.jl_scale[3 * s + 0];
   p.lms[3 * s + 1] += inc[1] * p.jl_scale[3 * s + 1];
   p.lms[3 * s + 2] += inc[2] * p.jl_scale[3 * s + 2];
+}
+
+// The same back-substitution for the tiled landmarks (k <= 32) in ONE pass, lane per block row
+// (the wave tiles of k_hx_implicit): u = Jp x per row; Q^T u by the three reflectors (segmented
+// reductions); its three top entries rotated by the landmark's damping rotations are exactly
+// topd x, so the stored damped top rows are not read at all; delta from the damped triangle; the
+// model-cost term from the undamped rows v = u + Jl delta. Reads 152 bytes per observation
+// (Jacobian rows, reflectors, Jl rows, residual) instead of 268 in the two-kernel form.
+template <class S, int P2>
+__device__ __forceinline__ void bs_tile(const Params<S>& p, size_t T, int t_in_class, int lm_begin, int lm_end,
+                                        const S* __restrict__ x, int lane) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  constexpr int LPW = 64 / P2;
+  const int seg = lane / P2, r = lane - P2 * seg, base = lane - r;
+  const int s = lm_begin + t_in_class * LPW + seg;
+  const bool lm_ok = s < lm_end;
+  const int cam = p.CT[T * 64 + lane];
+  const int row = p.RT[T * 64 + lane];
+  const bool act = cam >= 0;
+  S u = S(0), v0 = S(0), v1 = S(0), v2 = S(0), jl0 = S(0), jl1 = S(0), jl2 = S(0), rs = S(0);
+  if (act) {
+    const S* __restrict__ jrow = p.JpS + 9 * int64_t(row);
+    const S* __restrict__ xc = x + 9 * cam;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) u += jrow[c] * xc[c];
+    const V4 vv = reinterpret_cast<const V4*>(p.Vh)[row];
+    v0 = vv.x;
+    v1 = vv.y;
+    v2 = vv.z;
+    const S* __restrict__ jl = p.JlS + 3 * int64_t(row);
+    jl0 = jl[0];
+    jl1 = jl[1];
+    jl2 = jl[2];
+    rs = p.rS[row];
+  }
+  const int sl = lm_ok ? s : 0;
+  const S t0 = p.tauH[3 * sl + 0], t1 = p.tauH[3 * sl + 1], t2 = p.tauH[3 * sl + 2];
+  S t = u;
+  t -= t0 * seg_sum<S, P2>(v0 * t) * v0;
+  t -= t1 * seg_sum<S, P2>(v1 * t) * v1;
+  t -= t2 * seg_sum<S, P2>(v2 * t) * v2;
+  S tt[3] = {__shfl(t, base), __shfl(t, base + 1), __shfl(t, base + 2)};
+  // landmark damping: the six rotations of stage 2 on (top rows, zero damping rows)
+  {
+    const S* __restrict__ g = p.givens + 16 * size_t(sl);
+    S d[3] = {S(0), S(0), S(0)};
+    int idx = 0;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+#pragma unroll
+      for (int m = 0; m <= n; ++m) {
+        const S cc = g[idx], sn = g[6 + idx];
+        const S xx = d[n - m], yy = tt[n];
+        d[n - m] = cc * xx + sn * yy;
+        tt[n] = -sn * xx + cc * yy;
+        ++idx;
+      }
+    }
+  }
+  const S* __restrict__ Rd = p.Rd + 6 * size_t(sl);
+  const S rhs0 = p.q1trd[3 * sl] + tt[0], rhs1 = p.q1trd[3 * sl + 1] + tt[1], rhs2 = p.q1trd[3 * sl + 2] + tt[2];
+  S inc[3];
+  inc[2] = rhs2 / Rd[5];
+  inc[1] = (rhs1 - Rd[4] * inc[2]) / Rd[3];
+  inc[0] = (rhs0 - Rd[1] * inc[1] - Rd[2] * inc[2]) / Rd[0];
+  inc[0] = -inc[0];
+  inc[1] = -inc[1];
+  inc[2] = -inc[2];
+  const S v = u + jl0 * inc[0] + jl1 * inc[1] + jl2 * inc[2];
+  const S acc = seg_sum<S, P2>(act ? v * (S(0.5) * v + rs) : S(0));
+  if (r == 0 && lm_ok) {
+    p.lm_ldiff[s] = -double(acc);
+    const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) && is_finite(acc) &&
+                     is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) && is_finite(p.lms[3 * s + 2]);
+    if (!fin) atomicOr(p.fail_flag, 2);
+    p.lms[3 * s + 0] += inc[0] * p.jl_scale[3 * s + 0];
+    p.lms[3 * s + 1] += inc[1] * p.jl_scale[3 * s + 1];
+    p.lms[3 * s + 2] += inc[2] * p.jl_scale[3 * s + 2];
+  }
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void k_bs_tile(Params<S> p, ImplicitTiles it, const S* __restrict__ x) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int T = blockIdx.x * 4 + wave;
+  if (T >= it.tile_begin[5]) return;
+  if (T >= it.tile_begin[4])
+    bs_tile<S, 64>(p, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], x, lane);
+  else if (T >= it.tile_begin[3])
+    bs_tile<S, 32>(p, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], x, lane);
+  else if (T >= it.tile_begin[2])
+    bs_tile<S, 16>(p, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], x, lane);
+  else if (T >= it.tile_begin[1])
+    bs_tile<S, 8>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], x, lane);
+  else
+    bs_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], x, lane);
 }
 
 // deterministic sum of the per-landmark model cost changes

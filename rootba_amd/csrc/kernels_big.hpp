@@ -239,19 +239,19 @@ __global__ __launch_bounds__(256) void k_e0_big(Params<S> p, int lm_begin, const
   const int k = p.lm_k[s];
   const int64_t o0 = p.lm_obs[s];
   const int ncols = 9 * k;
-  const S* __restrict__ Td = p.topd + 27 * o0;
+  const S* __restrict__ Td = p.topd + kTd * o0;
   S w[3] = {S(0), S(0), S(0)};
   for (int j = tid; j < ncols; j += 256) {
     const int i = j / 9, comp = j - 9 * i;
     const S xv = v[9 * p.obs_cam[o0 + i] + comp];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) w[m] += Td[27 * i + 9 * m + comp] * xv;
+    for (int m = 0; m < 3; ++m) w[m] += Td[kTd * i + 9 * m + comp] * xv;
   }
 #pragma unroll
   for (int m = 0; m < 3; ++m) w[m] = big_block_sum(w[m], sm);
   for (int j = tid; j < ncols; j += 256) {
     const int i = j / 9, comp = j - 9 * i;
-    const S* t = Td + 27 * i + comp;
+    const S* t = Td + kTd * i + comp;
     atomic_add(y + 9 * p.obs_cam[o0 + i] + comp, t[0] * w[0] + t[9] * w[1] + t[18] * w[2]);
   }
 }

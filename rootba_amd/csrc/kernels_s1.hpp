@@ -125,18 +125,30 @@ __device__ __forceinline__ void cam_diag2(const Params<S>& p, int c, int64_t t0,
   }
 }
 
-// float: Gram tile on the matrix cores (exact f32 fmaf chains, see mfma_xtx)
+// float: Gram tile on the matrix cores (exact f32 fmaf chains) from LDS-staged whole records
+// (mfma_xtx_staged); Jp_diag2 from the same staged records, double accumulation, fixed order
 __global__ __launch_bounds__(256) void k_cam_gram_mfma(Params<float> p) {
   __shared__ float tile[4][16][16];
-  __shared__ double bsum[28][9];
-  const int c = blockIdx.x;
+  __shared__ double dsum[4][7][9];
+  __shared__ __attribute__((aligned(16))) float stage[4][kCamChunk * 18];
+  const int c = xcd_swizzled_camera(p.n_cams);
+  if (c >= p.n_cams) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = mfma_xtx<2>(p.JpS, 18, p.cam_obs, t0, t1, wave, lane, acc);
+  const int g = lane / 9, a = lane - 9 * g;
+  double accd = 0;
+  acc = mfma_xtx_staged<18, 2>(p.JpS, p.cam_obs, t0, t1, wave, lane, acc, stage[wave], true,
+                               [&](int cnt, const float* rec) {
+                                 if (lane < 63)
+                                   for (int r = g; r < cnt; r += 7) {
+                                     const float x0 = rec[r * 18 + a], x1 = rec[r * 18 + 9 + a];
+                                     accd += double(x0 * x0 + x1 * x1);
+                                   }
+                               });
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-  cam_diag2<float>(p, c, t0, t1, bsum);
+  if (lane < 63) dsum[wave][g][a] = accd;
   __syncthreads();
   if (tid < 81) {
     const int i = tid / 9, j = tid - 9 * i;
@@ -146,10 +158,11 @@ __global__ __launch_bounds__(256) void k_cam_gram_mfma(Params<float> p) {
     p.B_mid[81 * c + tid] = v;
   }
   if (tid >= 128 && tid < 137) {
-    const int a = tid - 128;
-    double s = 0;
-    for (int g = 0; g < 28; ++g) s += bsum[g][a];
-    p.jp_diag2[9 * c + a] = float(s);
+    const int aa = tid - 128;
+    double sum = 0;
+    for (int w = 0; w < 4; ++w)
+      for (int gg = 0; gg < 7; ++gg) sum += dsum[w][gg][aa];
+    p.jp_diag2[9 * c + aa] = float(sum);
   }
 }
 
@@ -467,8 +480,8 @@ __global__ __launch_bounds__(256) void k_s1_qr_wide(Params<S> p, int lm_begin, i
 // rows straight into the damped ones (set_landmark_damping, ipp:165-210, six Givens rotations per
 // landmark from k_stage2_landmark) - the undamped top rows are never stored. A later stage 2 of the
 // same linearisation point (rejected step, new lambda) re-runs the pass on the already scaled rows.
-// Outputs per observation: topd [3][9] (damped Q1^T Jp), bO [9] (Q2 part + damping rows' part of b),
-// JpS [2][9] (scaled rows, first pass only). The workgroup's 128 observations are consecutive, so
+// Outputs per observation: the stage-2 record [damped Q1^T Jp 3x9 | Q2 + damping rows' part of b 9] (kTd
+// scalars) and JpS [2][9] (scaled rows, first pass only). The workgroup's 128 observations are consecutive, so
 // the records are staged in LDS and move as contiguous 16-byte streams.
 // ---------------------------------------------------------------------------
 constexpr int kS1ColsThreads = 128;
@@ -480,8 +493,7 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
   constexpr int N = 16 / int(sizeof(S)), NT = kS1ColsThreads;
   extern __shared__ __attribute__((aligned(16))) char smem_s1c[];
   S* sJ = reinterpret_cast<S*>(smem_s1c);  // [NT][18]  in: Jacobian rows, out: scaled rows
-  S* sT = sJ + NT * 18;                    // [NT][27]  damped Q1^T Jp
-  S* sB = sT + NT * 27;                    // [NT][9]   b record
+  S* sT = sJ + NT * 18;                    // [NT][kTd] damped Q1^T Jp (27) | b record (9)
   const int tid = threadIdx.x;
   const int64_t o_base = int64_t(blockIdx.x) * NT;
   const int n_here = int(min<int64_t>(NT, n_obs - o_base));
@@ -558,13 +570,13 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
           }
         }
       }
-      sT[27 * tid + c] = tt[0];
-      sT[27 * tid + 9 + c] = tt[1];
-      sT[27 * tid + 18 + c] = tt[2];
+      sT[kTd * tid + c] = tt[0];
+      sT[kTd * tid + 9 + c] = tt[1];
+      sT[kTd * tid + 18 + c] = tt[2];
       sJ[18 * tid + c] = m0;
       sJ[18 * tid + 9 + c] = m1;
       // Q2 rows' part of b (add_Q2TJp_T_Q2Tr) + the damping rows' part
-      sB[9 * tid + c] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
+      sT[kTd * tid + 27 + c] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
     }
   }
   __syncthreads();
@@ -574,9 +586,8 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
     for (int q = nvec * N + tid; q < total; q += NT) dst[q] = src[q];
   };
   // (16-byte alignment of the destinations: o_base is a multiple of 128)
-  copy_out(p.topd + 27 * o_base, sT, 27 * n_here);
+  copy_out(p.topd + kTd * o_base, sT, kTd * n_here);
   if (!scaled_input) copy_out(p.JpS + 18 * o_base, sJ, 18 * n_here);
-  copy_out(p.bO + 9 * o_base, sB, 9 * n_here);
 }
 
 // b_mid[c] = sum over the camera's observations of bmO (fixed order, double)

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_topd_transpose(const S* __restrict__ to
   if (t >= n) return;
   const int64_t o = t / 27;
   const int e = int(t - 27 * o), m = e / 9, c = e - 9 * m;
-  topdT[27 * o + 3 * c + m] = topd[t];
+  topdT[27 * o + 3 * c + m] = topd[kTd * o + e];
 }
 
 // strictly upper blocks: one workgroup per block, fixed order, mirrored write
@@ -587,8 +587,8 @@ __global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const float* __restrict
       const int o_i = pp == 0 ? oi[0] : pp == 1 ? oi[1] : pp == 2 ? oi[2] : oi[3];
       const int o_j = pp == 0 ? oj[0] : pp == 1 ? oj[1] : pp == 2 ? oj[2] : oj[3];
       const bool ok = i < 9 && o_i >= 0;
-      av[m] = ok ? topd[27 * int64_t(o_i) + 9 * c + i] : 0.f;
-      bv[m] = ok ? topd[27 * int64_t(o_j) + 9 * c + i] : 0.f;
+      av[m] = ok ? topd[kTd * int64_t(o_i) + 9 * c + i] : 0.f;
+      bv[m] = ok ? topd[kTd * int64_t(o_j) + 9 * c + i] : 0.f;
     }
 #pragma unroll
     for (int m = 0; m < 3; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[m], acc, 0, 0, 0);

@@ -198,6 +198,7 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_HX_SINGLE_STREAM")) hx_single_stream_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_QR_UNPACKED")) qr_unpacked_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_S1_FUSED")) s1_fused_ = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("RBA_BS_TWO_PASS")) bs_two_pass_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
 
     // ---- sort landmarks by number of observations (stable) ----------------
@@ -400,14 +401,12 @@ class Solver final : public rba_solver {
     // (full-size buffers then, indexed by observation as everywhere else)
     const size_t legacy_obs = (staged_ && n_big_ == 0) ? 0 : qr_obs;
     d_top0_.alloc(27 * legacy_obs);
-    d_topd_.alloc(27 * qr_obs);
-    d_bO_.alloc(staged_ ? 9 * qr_obs : 0);
+    d_topd_.alloc(rba::kTd * qr_obs);
     d_JpS_.alloc(18 * size_t(n_obs_));
     d_JlS_.alloc(6 * qr_obs);
     d_rS_.alloc(2 * qr_obs);
     d_bsO_.alloc(5 * qr_obs);
     d_givens_.alloc(sc_ ? 0 : 16 * size_t(n_lms));
-    d_bdO_.alloc(staged_ ? 0 : 9 * qr_obs);
     d_bmO_.alloc(9 * legacy_obs);
     d_Vh_.alloc(8 * qr_obs);
     if (sc_) build_sc_structure(lm_k, lm_obs, s_obs_cam);
@@ -446,6 +445,7 @@ class Solver final : public rba_solver {
       d_RT_.upload(tile_row.data(), tile_row.size(), stream_);
     }
     n_obs_small_ = lm_obs[big_begin_];  // observations of the landmarks with k <= 112 (sorted first)
+    n_obs_tiled_ = lm_obs[imp_end_[4]];  // ... with k <= 32 (the wave tiles)
     d_R0_.alloc(6 * size_t(n_lms));
     d_Rd_.alloc(6 * size_t(n_lms));
     d_q1trd_.alloc(3 * size_t(n_lms));
@@ -502,8 +502,6 @@ class Solver final : public rba_solver {
     prm_.rS = d_rS_.get();
     prm_.bsO = d_bsO_.get();
     prm_.givens = d_givens_.get();
-    prm_.bdO = d_bdO_.get();
-    prm_.bO = d_bO_.get();
     prm_.b_from_records = staged_ ? 1 : 0;
     prm_.bmO = d_bmO_.get();
     prm_.Vh = d_Vh_.get();
@@ -1119,7 +1117,7 @@ class Solver final : public rba_solver {
       if (n_obs_small_ > 0)
         hipLaunchKernelGGL((rba::k_s12_cols<S>),
                            dim3(unsigned((n_obs_small_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
-                           dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * 54 * sizeof(S), stream_, prm_,
+                           dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTd) * sizeof(S), stream_, prm_,
                            int64_t(n_obs_small_), cols_pending_ ? 0 : 1);
       cols_pending_ = false;
       if (n_obs_ > n_obs_small_)
@@ -1256,13 +1254,14 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_cam_stage1<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
   }
   void launch_cam_gram(const rba::Params<float>& prm) {
-    hipLaunchKernelGGL((rba::k_cam_gram_mfma), dim3(n_cams_), dim3(256), 0, stream_, prm);
+    hipLaunchKernelGGL((rba::k_cam_gram_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm);
   }
   void launch_cam_gram(const rba::Params<double>& prm) {
     hipLaunchKernelGGL((rba::k_cam_gram<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
   }
   void launch_cam_stage2(const rba::Params<float>& prm, float lambda) {
-    hipLaunchKernelGGL((rba::k_cam_stage2_mfma), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
+    hipLaunchKernelGGL((rba::k_cam_stage2_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
+                       lambda);
   }
   void launch_cam_stage2(const rba::Params<double>& prm, double lambda) {
     hipLaunchKernelGGL((rba::k_cam_stage2<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
@@ -1278,6 +1277,17 @@ class Solver final : public rba_solver {
     if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_e0_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_, v, y,
                          done_flag);
+  }
+
+  rba::ImplicitTiles implicit_tiles() const {
+    rba::ImplicitTiles it;
+    for (int c = 0; c < 5; ++c) {
+      it.tile_begin[c] = imp_tile_begin_[c];
+      it.lm_begin[c] = imp_begin_[c];
+      it.lm_end[c] = imp_end_[c];
+    }
+    it.tile_begin[5] = n_tiles_;
+    return it;
   }
 
   // same operator from the factors (k_hx_implicit); long tracks use the dense kernel
@@ -1635,9 +1645,20 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_sc_back_substitute<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_,
                          scp_, d_inc_.get());
     } else {
-      hipLaunchKernelGGL((rba::k_bs_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0, stream_, prm_,
-                         d_inc_.get(), int64_t(n_obs_));
-      hipLaunchKernelGGL((rba::k_bs_landmark<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_, prm_);
+      // tiled landmarks (k <= 32, implicit-Q configuration): one lane-per-row pass; the rest: two passes
+      int lm0 = 0;
+      int64_t o0 = 0;
+      if (staged_ && n_tiles_ > 0 && !bs_two_pass_) {
+        hipLaunchKernelGGL((rba::k_bs_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, implicit_tiles(),
+                           d_inc_.get());
+        lm0 = imp_end_[4];
+        o0 = n_obs_tiled_;
+      }
+      if (o0 < n_obs_) {
+        hipLaunchKernelGGL((rba::k_bs_obs<S>), dim3(unsigned((n_obs_ - o0 + 255) / 256)), dim3(256), 0, stream_, prm_,
+                           d_inc_.get(), o0, int64_t(n_obs_));
+        hipLaunchKernelGGL((rba::k_bs_landmark<S>), dim3((n_lms_ - lm0 + 255) / 256), dim3(256), 0, stream_, prm_, lm0);
+      }
     }
     const int blocks = std::min(kReduceBlocks, (n_lms_ + 255) / 256);
     hipLaunchKernelGGL((rba::k_sum_ldiff), dim3(blocks), dim3(256), 0, stream_,
@@ -2009,9 +2030,9 @@ class Solver final : public rba_solver {
   DevBuf<int> d_lm_k_, d_obs_cam_, d_obs_lm_, d_fail_;
   DevBuf<int64_t> d_lm_obs_, d_lm_blk_, d_cam_off_;
   DevBuf<int> d_cam_obs_;
-  DevBuf<S> d_JpS_, d_bmO_, d_bO_, d_Vh_, d_tauH_, d_Zd_, d_LQ_, d_JlS_, d_rS_, d_bsO_, d_givens_, d_bdO_;
+  DevBuf<S> d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_LQ_, d_JlS_, d_rS_, d_bsO_, d_givens_;
   DevBuf<int> d_CT_, d_RT_;
-  int64_t n_obs_small_ = 0;
+  int64_t n_obs_small_ = 0, n_obs_tiled_ = 0;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
   DevBuf<S> d_A_, d_top0_, d_topd_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;
@@ -2032,6 +2053,7 @@ class Solver final : public rba_solver {
   bool s1_fused_ = false;     // RBA_S1_FUSED=1: round-1 stage 1 (geometry + QR + columns in one kernel)
   bool staged_ = false;       // stage 1 staged by parallelism (kernels_s1.hpp): implicit-Q configuration
   bool cols_pending_ = false; // linearised, column pass not yet run (it runs inside the first stage 2)
+  bool bs_two_pass_ = false;  // RBA_BS_TWO_PASS=1: round-1 back-substitution kernels for every landmark
   // explicit reduced matrix of the square-root solver (adaptive, see pcg())
   int explicit_after_ = 0;  // matrix-free products before a solve switches to S x; 0 = never
   bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;
