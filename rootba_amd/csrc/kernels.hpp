@@ -66,6 +66,12 @@ struct Params {
   S* bsO;       // [n_obs][5]     back-substitution scratch: topd x (3), Jp x (2)
   S* givens;    // [n_lms][16]    the 6 damping rotations of stage 2: c[6], s[6], damping-row residual[3], pad
   int b_from_records;  // b = sum_obs (b record) (staged path, kernels_s1.hpp) instead of b_mid + sum_obs (b record)
+  // Optional privatised scatter targets: the camera-indexed scatter-adds of the products go to one of
+  // `y_rep` replicas of the 9 n_c vector (chosen by workgroup), summed afterwards. An experiment switch
+  // (RBA_Y_REPLICAS): on venice 4 / 16 / 64 replicas move H*x by < 2 %, i.e. the 7.5 M atomic requests
+  // onto one 64 KB vector are not what bounds the kernel.
+  int y_rep;
+  int64_t y_rep_stride;
   S* R0;        // [6 n_lms]
   S* Rd;        // [6 n_lms]
   S* q1trd;     // [3 n_lms]
@@ -87,6 +93,21 @@ struct Params {
   S huber;
   S eps;  // jacobi scaling epsilon
 };
+
+template <class S>
+__device__ __forceinline__ S* scatter_replica(const Params<S>& p, S* y) {
+  return p.y_rep > 1 ? y + int64_t(blockIdx.x % unsigned(p.y_rep)) * p.y_rep_stride : y;
+}
+
+// y[i] += sum over the replicas
+template <class S>
+__global__ void k_sum_replicas(S* __restrict__ y, const S* __restrict__ rep, int n_rep, int64_t stride, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  S acc = S(0);
+  for (int r = 0; r < n_rep; ++r) acc += rep[r * stride + i];
+  y[i] += acc;
+}
 
 // ===========================================================================
 // compute_error: one thread per observation, per-block partial sums (double)
@@ -1190,6 +1211,7 @@ __global__ __launch_bounds__(256) void k_hx(Params<S> p, int lm_begin, int lm_en
   const int s = lm_begin + blockIdx.x * 4 + wave;
   if (s >= lm_end) return;
   if (done_flag && *done_flag) return;  // PCG already terminated (host polls lazily)
+  y = scatter_replica(p, y);
   const int k = p.lm_k[s];
   const int64_t o0 = p.lm_obs[s];
   const int nrows = 2 * k, ncols = 9 * k;
@@ -1305,25 +1327,16 @@ __device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, i
   }
   const S t0 = lm_ok ? p.tauH[3 * s + 0] : S(0), t1 = lm_ok ? p.tauH[3 * s + 1] : S(0),
           t2 = lm_ok ? p.tauH[3 * s + 2] : S(0);
-  // gather x for the 32 observation slots of the tile with 9-lane coalescing
-  // (lanes as (slot, component)), hand it to the row lanes through LDS
+  // u = Jp_row . x_cam: each row lane reads its camera's nine entries directly (the two rows of an
+  // observation read the same 36 bytes; x is 9 n_c scalars and stays in L1/L2)
   const int obs_local = lane >> 1;
   if ((lane & 1) == 0) cb[obs_local] = cam;
-  wave_lds_fence();
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    const int e = q * 64 + lane;
-    if (e < 288) {
-      const int ol = e / 9, c = e - 9 * ol;
-      const int cc = cb[ol];
-      yb[e] = cc >= 0 ? x[9 * cc + c] : S(0);
-    }
-  }
-  wave_lds_fence();
   S u = S(0);
+  {
+    const S* __restrict__ xc = x + 9 * (act ? cam : 0);
 #pragma unroll
-  for (int c = 0; c < 9; ++c) u += jp[c] * yb[9 * obs_local + c];
-  wave_lds_fence();
+    for (int c = 0; c < 9; ++c) u += jp[c] * xc[c];
+  }
   // W^T: reflectors 0,1,2
   u -= t0 * seg_sum<S, P2>(v0 * u) * v0;
   u -= t1 * seg_sum<S, P2>(v1 * u) * v1;
@@ -1380,6 +1393,7 @@ __global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, ImplicitTiles 
   // the PCG "done" flag is fetched alongside the data and only gates the scatter, so
   // it does not add a memory round trip in front of the loads
   const int done = done_flag ? *done_flag : 0;
+  y = scatter_replica(p, y);
   S* yb = ybuf[wave];
   int* cb = cbuf[wave];
   if (T >= it.tile_begin[4])
@@ -1407,6 +1421,7 @@ __global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_be
   const int s = lm_begin + blockIdx.x * 4 + wave;
   if (s >= lm_end) return;
   if (done_flag && *done_flag) return;
+  y = scatter_replica(p, y);
   const int k = p.lm_k[s];
   const int64_t o0 = p.lm_obs[s];
   S jp[RCH][9], u[RCH], v[3][RCH];
@@ -1624,6 +1639,7 @@ __global__ __launch_bounds__(256) void k_hx_small(Params<S> p, const SmallBatch*
                                                   const int* __restrict__ done_flag) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (done_flag && *done_flag) return;  // PCG already terminated (host polls lazily)
+  y = scatter_replica(p, y);
   const SmallBatch d = batches[blockIdx.x];
   switch (d.K) {
     case 2: hx_small_body<S, 2>(p, d, x, y, smem_raw); break;
@@ -1651,6 +1667,7 @@ __global__ __launch_bounds__(256) void k_e0(Params<S> p, int lm_begin, int lm_en
   const int s = lm_begin + blockIdx.x * 4 + wave;
   if (s >= lm_end) return;
   if (done_flag && *done_flag) return;
+  y = scatter_replica(p, y);
   const int k = p.lm_k[s];
   const int64_t o0 = p.lm_obs[s];
   const S* __restrict__ Td = p.topd + kTd * o0;

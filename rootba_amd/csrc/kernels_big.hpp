@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void k_hx_big(Params<S> p, int lm_begin, const
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ S sm[4];
   if (done_flag && *done_flag) return;
+  y = scatter_replica(p, y);
   const int tid = threadIdx.x;
   const int s = lm_begin + blockIdx.x;
   const int k = p.lm_k[s];
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void k_e0_big(Params<S> p, int lm_begin, const
                                                 const int* __restrict__ done_flag) {
   __shared__ S sm[4];
   if (done_flag && *done_flag) return;
+  y = scatter_replica(p, y);
   const int tid = threadIdx.x;
   const int s = lm_begin + blockIdx.x;
   const int k = p.lm_k[s];

@@ -199,6 +199,7 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_QR_UNPACKED")) qr_unpacked_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_S1_FUSED")) s1_fused_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_BS_TWO_PASS")) bs_two_pass_ = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("RBA_Y_REPLICAS")) y_rep_ = std::max(1, std::min(64, std::atoi(ev)));
     if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
 
     // ---- sort landmarks by number of observations (stable) ----------------
@@ -470,6 +471,9 @@ class Solver final : public rba_solver {
     d_fail_.zero(stream_);
     d_partials_.zero(stream_);
     d_p2_.alloc(nvec_);
+    if (y_rep_ > 1 && !sc_) d_yrep_.alloc(size_t(y_rep_) * nvec_);
+    prm_.y_rep = (y_rep_ > 1 && !sc_) ? y_rep_ : 1;
+    prm_.y_rep_stride = nvec_;
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 4096));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_progress_), 64));
     h_progress_[0] = h_progress_[1] = 0;
@@ -1181,8 +1185,20 @@ class Solver final : public rba_solver {
       ++hx_calls_;
       return;
     }
+    // matrix-free products scatter-add into privatised replicas of y, summed at the end
+    S* const y_out = y;
+    if (prm_.y_rep > 1) {
+      d_yrep_.zero(stream_);
+      y = d_yrep_.get();
+    }
+    auto finish_replicas = [&]() {
+      if (prm_.y_rep > 1)
+        hipLaunchKernelGGL((rba::k_sum_replicas<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y_out,
+                           d_yrep_.get(), prm_.y_rep, int64_t(nvec_), nvec_);
+    };
     if (opt_.implicit_q) {
       launch_hx_implicit(x, y, done_flag);
+      finish_replicas();
       if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
       ++hx_calls_;
       return;
@@ -1215,6 +1231,7 @@ class Solver final : public rba_solver {
                          stream_, prm_, begin, end, x, y, done_flag);
     });
     if (two_streams) HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
+    finish_replicas();
     if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
     ++hx_calls_;
   }
@@ -1269,6 +1286,11 @@ class Solver final : public rba_solver {
 
   // y += E0 v over the local landmarks (power-series preconditioner)
   void launch_e0(const S* v, S* y, const int* done_flag) {
+    S* const y_out = y;
+    if (prm_.y_rep > 1) {
+      d_yrep_.zero(stream_);
+      y = d_yrep_.get();
+    }
     for_each_class([&](auto ch_tag, int begin, int end) {
       constexpr int CH = decltype(ch_tag)::value;
       hipLaunchKernelGGL((rba::k_e0<S, CH>), dim3((end - begin + 3) / 4), dim3(256), 0, stream_,
@@ -1277,6 +1299,9 @@ class Solver final : public rba_solver {
     if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_e0_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_, v, y,
                          done_flag);
+    if (prm_.y_rep > 1)
+      hipLaunchKernelGGL((rba::k_sum_replicas<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y_out,
+                         d_yrep_.get(), prm_.y_rep, int64_t(nvec_), nvec_);
   }
 
   rba::ImplicitTiles implicit_tiles() const {
@@ -2054,6 +2079,10 @@ class Solver final : public rba_solver {
   bool staged_ = false;       // stage 1 staged by parallelism (kernels_s1.hpp): implicit-Q configuration
   bool cols_pending_ = false; // linearised, column pass not yet run (it runs inside the first stage 2)
   bool bs_two_pass_ = false;  // RBA_BS_TWO_PASS=1: round-1 back-substitution kernels for every landmark
+  int y_rep_ = 1;             // RBA_Y_REPLICAS=n: privatised scatter targets of the matrix-free products
+                              // (measured on venice: 4 / 16 / 64 replicas change H*x by < 2 % - the kernel is bound
+                              //  by its 0.96 GB of HBM traffic, not by atomic serialisation; off by default)
+  DevBuf<S> d_yrep_;
   // explicit reduced matrix of the square-root solver (adaptive, see pcg())
   int explicit_after_ = 0;  // matrix-free products before a solve switches to S x; 0 = never
   bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;
