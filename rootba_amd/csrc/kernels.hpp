@@ -1733,9 +1733,9 @@ __global__ __launch_bounds__(256) void k_bs_obs(Params<S> p, const S* __restrict
 }
 
 template <class S>
-__global__ __launch_bounds__(256) void k_bs_landmark(Params<S> p, int lm_begin) {
+__global__ __launch_bounds__(256) void k_bs_landmark(Params<S> p, int lm_begin, int lm_end) {
   const int s = lm_begin + blockIdx.x * 256 + threadIdx.x;
-  if (s >= p.n_lms) return;
+  if (s >= lm_end) return;
   const int64_t ob = p.lm_obs[s], oe = p.lm_obs[s + 1];
   S rhs[3] = {p.q1trd[3 * s], p.q1trd[3 * s + 1], p.q1trd[3 * s + 2]};
   for (int64_t o = ob; o < oe; ++o) {

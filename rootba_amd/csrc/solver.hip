@@ -195,9 +195,11 @@ class Solver final : public rba_solver {
     HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     n_obs_ = lm_off[n_lms];
     nvec_ = 9 * n_cams_;
+    if (const char* ev = std::getenv("RBA_S1_FUSED")) s1_fused_ = std::atoi(ev) != 0;
+    sc_ = opt_.solver_type == 1;
+    staged_ = !sc_ && opt_.implicit_q && !s1_fused_;  // kernels_s1.hpp: no dense blocks at all
     if (const char* ev = std::getenv("RBA_HX_SINGLE_STREAM")) hx_single_stream_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_QR_UNPACKED")) qr_unpacked_ = std::atoi(ev) != 0;
-    if (const char* ev = std::getenv("RBA_S1_FUSED")) s1_fused_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_BS_TWO_PASS")) bs_two_pass_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_Y_REPLICAS")) y_rep_ = std::max(1, std::min(64, std::atoi(ev)));
     if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
@@ -264,7 +266,7 @@ class Solver final : public rba_solver {
     }
     hx_bytes_ += 4 * n_obs_ + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
     hx_implicit_bytes_ += 4 * n_obs_ + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
-    if (kmax > rba::kBigMaxK)
+    if (kmax > rba::kBigMaxK && !staged_)  // (the implicit-Q configuration has no limit)
       throw HipError{"landmark with " + std::to_string(kmax) + " observations: more than " +
                          std::to_string(rba::kBigMaxK) + " is not supported",
                      RBA_ERR_UNSUPPORTED};
@@ -323,8 +325,8 @@ class Solver final : public rba_solver {
     big_begin_ = begin;
     n_big_ = n_lms - begin;
     big_kmax_ = n_big_ > 0 ? kmax : 0;
-    if (n_big_ > 0) {
-      const size_t lds = size_t(18) * big_kmax_ * sizeof(S);  // largest request of the big kernels
+    if (n_big_ > 0 && !staged_) {
+      const size_t lds = size_t(18) * big_kmax_ * sizeof(S);  // largest request of the dense big kernels
       if (lds > 160 * 1024)
         throw HipError{"landmark with " + std::to_string(kmax) + " observations does not fit the 160 KB LDS",
                        RBA_ERR_UNSUPPORTED};
@@ -390,17 +392,23 @@ class Solver final : public rba_solver {
     d_lms_.alloc(3 * size_t(n_lms));
     d_cams_bak_.alloc(10 * size_t(n_cams));
     d_lms_bak_.alloc(3 * size_t(n_lms));
-    sc_ = opt_.solver_type == 1;
     if (sc_ && opt_.preconditioner_type != 1)
       throw HipError{"SCHUR_COMPLEMENT solver: only the SCHUR_JACOBI preconditioner is implemented",
                      RBA_ERR_UNSUPPORTED};
     // the dense landmark blocks and the QR by-products exist only for the square-root solver
     const size_t qr_obs = sc_ ? 0 : size_t(n_obs_);
-    d_A_.alloc(sc_ ? 0 : size_t(blk));
-    staged_ = !sc_ && opt_.implicit_q && !s1_fused_;
-    // staged path: the undamped top rows / separate b parts exist only for the k > 112 landmarks
-    // (full-size buffers then, indexed by observation as everywhere else)
-    const size_t legacy_obs = (staged_ && n_big_ == 0) ? 0 : qr_obs;
+    d_A_.alloc((sc_ || staged_) ? 0 : size_t(blk));
+    // staged path: no dense blocks, no undamped top rows, no separate b parts
+    const size_t legacy_obs = staged_ ? 0 : qr_obs;
+    if (staged_ && n_big_ > 0) {
+      // global scratch of the long-track kernels: 8 scalars per block row (kernels_big.hpp)
+      std::vector<int64_t> off(size_t(n_big_) + 1, 0);
+      for (int q = 0; q < n_big_; ++q) off[q + 1] = off[q] + 2 * int64_t(lm_k[big_begin_ + q]);
+      d_big_off_.alloc(off.size());
+      d_big_off_.upload(off.data(), off.size(), stream_);
+      d_big_scratch_.alloc(size_t(8) * off[n_big_]);
+      HIP_CHECK(hipStreamSynchronize(stream_));
+    }
     d_top0_.alloc(27 * legacy_obs);
     d_topd_.alloc(rba::kTd * qr_obs);
     d_JpS_.alloc(18 * size_t(n_obs_));
@@ -1059,8 +1067,8 @@ class Solver final : public rba_solver {
       // the column pass (scaled rows, top rows, b records) runs inside the first stage 2 (k_s12_cols)
       cols_pending_ = true;
       if (n_big_ > 0)
-        hipLaunchKernelGGL((rba::k_linearize_qr_big<S>), dim3(n_big_), dim3(256),
-                           size_t(16) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_);
+        hipLaunchKernelGGL((rba::k_s1_qr_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
+                           d_big_scratch_.get(), d_big_off_.get());
     } else if (sc_) {
       // LinearizorSC::linearize (linearizor_sc.cpp:70-99)
       hipLaunchKernelGGL((rba::k_sc_linearize_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0,
@@ -1116,18 +1124,12 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_stage2_landmark<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_, prm_,
                        lambda);
     if (staged_) {
-      // column pass + rotation of the top rows, fused (kernels_s1.hpp); landmarks with k > 112 keep
-      // their stored undamped top rows and the round-1 rotation pass
-      if (n_obs_small_ > 0)
-        hipLaunchKernelGGL((rba::k_s12_cols<S>),
-                           dim3(unsigned((n_obs_small_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
-                           dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTd) * sizeof(S), stream_, prm_,
-                           int64_t(n_obs_small_), cols_pending_ ? 0 : 1);
+      // column pass + rotation of the top rows, fused (kernels_s1.hpp), every observation
+      hipLaunchKernelGGL((rba::k_s12_cols<S>),
+                         dim3(unsigned((n_obs_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
+                         dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTd) * sizeof(S), stream_,
+                         prm_, int64_t(n_obs_), cols_pending_ ? 0 : 1);
       cols_pending_ = false;
-      if (n_obs_ > n_obs_small_)
-        hipLaunchKernelGGL((rba::k_stage2_cols<S>),
-                           dim3(unsigned((9 * (int64_t(n_obs_) - n_obs_small_) + 255) / 256)), dim3(256), 0, stream_,
-                           prm_, int64_t(n_obs_small_), int64_t(n_obs_));
     } else {
       hipLaunchKernelGGL((rba::k_stage2_cols<S>), dim3(unsigned((9 * int64_t(n_obs_) + 255) / 256)), dim3(256), 0,
                          stream_, prm_, int64_t(0), int64_t(n_obs_));
@@ -1317,7 +1319,10 @@ class Solver final : public rba_solver {
 
   // same operator from the factors (k_hx_implicit); long tracks use the dense kernel
   void launch_hx_implicit(const S* x, S* y, const int* done_flag) {
-    if (n_big_ > 0)
+    if (n_big_ > 0 && staged_)
+      hipLaunchKernelGGL((rba::k_hx_implicit_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
+                         d_big_scratch_.get(), d_big_off_.get(), x, y, done_flag);
+    else if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_hx_big<S>), dim3(n_big_), dim3(256), size_t(18) * big_kmax_ * sizeof(S),
                          stream_, prm_, big_begin_, x, y, done_flag);
     if (imp_end_[6] > imp_begin_[6])
@@ -1682,7 +1687,11 @@ class Solver final : public rba_solver {
       if (o0 < n_obs_) {
         hipLaunchKernelGGL((rba::k_bs_obs<S>), dim3(unsigned((n_obs_ - o0 + 255) / 256)), dim3(256), 0, stream_, prm_,
                            d_inc_.get(), o0, int64_t(n_obs_));
-        hipLaunchKernelGGL((rba::k_bs_landmark<S>), dim3((n_lms_ - lm0 + 255) / 256), dim3(256), 0, stream_, prm_, lm0);
+        if (big_begin_ > lm0)
+          hipLaunchKernelGGL((rba::k_bs_landmark<S>), dim3((big_begin_ - lm0 + 255) / 256), dim3(256), 0, stream_,
+                             prm_, lm0, big_begin_);
+        if (n_big_ > 0)
+          hipLaunchKernelGGL((rba::k_bs_landmark_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_);
       }
     }
     const int blocks = std::min(kReduceBlocks, (n_lms_ + 255) / 256);
@@ -2058,6 +2067,8 @@ class Solver final : public rba_solver {
   DevBuf<S> d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_LQ_, d_JlS_, d_rS_, d_bsO_, d_givens_;
   DevBuf<int> d_CT_, d_RT_;
   int64_t n_obs_small_ = 0, n_obs_tiled_ = 0;
+  DevBuf<S> d_big_scratch_;
+  DevBuf<int64_t> d_big_off_;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
   DevBuf<S> d_A_, d_top0_, d_topd_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;

@@ -230,6 +230,11 @@ def synthetic_problem(n_cams: int, n_lms: int, n_obs_target: int, seed: int = RA
     for _ in range(100):
         depth = rng.uniform(2, 20, todo.size)
         lateral = rng.uniform(-0.35, 0.35, (todo.size, 2)) * depth[:, None]
+        # long tracks (seen from a large part of the ring): near the centre of the loop, where every
+        # inward-looking camera has them in front
+        wide = k[todo] > max(8, n_cams // 8)
+        depth[wide] = rng.uniform(8, 12, int(wide.sum()))
+        lateral[wide] = rng.uniform(-0.12, 0.12, (int(wide.sum()), 2)) * depth[wide, None]
         p_c = np.concatenate([lateral, depth[:, None]], 1)
         lms[todo] = np.einsum("nij,nj->ni", R_w_c[base[todo]], p_c) + centers[base[todo]]
         sel = np.isin(lm_of_obs, todo) if todo.size < n_lms else slice(None)
@@ -247,9 +252,28 @@ def synthetic_problem(n_cams: int, n_lms: int, n_obs_target: int, seed: int = RA
     return BalProblem(cams, lms, off, cam_idx, obs_xy, name)
 
 
+def heavy_tail_counts(n_cams: int, n_lms: int, n_obs_target: int, seed: int = RANDOM_SEED) -> np.ndarray:
+    """Observation counts with a realistic heavy tail: the geometric bulk of `synthetic_problem` plus
+    max(8, n_lms / 5000) long tracks with a Pareto(alpha = 1) length, P(k > x) = 40 / x, capped at
+    max(120, n_cams / 4) (real BAL tracks: a few landmarks are seen by hundreds of cameras; one seen by
+    EVERY camera would make the reduced camera matrix dense, which is a different workload)."""
+    rng = np.random.default_rng(seed + 1)
+    kbar = n_obs_target / n_lms
+    k = np.minimum(n_cams, 2 + (rng.geometric(1.0 / (kbar - 1.0), size=n_lms) - 1)).astype(np.int64)
+    n_tail = max(8, n_lms // 5000)
+    cap = min(n_cams, max(120, n_cams // 4))
+    tail = np.minimum(cap, (40.0 / rng.uniform(40.0 / (4 * n_cams), 1.0, n_tail)).astype(np.int64))
+    tail[0] = cap
+    k[rng.choice(n_lms, n_tail, replace=False)] = np.maximum(2, tail)
+    return k
+
+
 def named_synthetic(config: str, seed: int = RANDOM_SEED) -> BalProblem:
-    n_c, n_l, n_o = BAL_SIZES[config]
-    return synthetic_problem(n_c, n_l, n_o, seed=seed, name=f"synthetic-{config}")
+    """`<bal size name>` or `<bal size name>+tail` (same sizes, heavy-tailed track lengths)."""
+    base, _, variant = config.partition("+")
+    n_c, n_l, n_o = BAL_SIZES[base]
+    k = heavy_tail_counts(n_c, n_l, n_o, seed) if variant == "tail" else None
+    return synthetic_problem(n_c, n_l, n_o, seed=seed, name=f"synthetic-{config}", k=k)
 
 
 # ---------------------------------------------------------------------------

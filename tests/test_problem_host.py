@@ -68,3 +68,13 @@ def test_duplicate_observation_is_rejected(tmp_path):
         raise AssertionError("expected ValueError")
     except ValueError as e:
         assert "Invalid file" in str(e)  # reference: CHECK(inserted) << "Invalid file" (bal_problem.cpp:229-230)
+
+
+def test_heavy_tail_variant_has_long_tracks():
+    from rootba_amd import problem as P
+    raw = P.named_synthetic("trafalgar-257+tail")
+    k = raw.obs_per_lm()
+    assert (raw.n_cams, raw.n_lms) == (257, 65132)
+    assert k.max() == 120 and (k > 60).sum() >= 5 and k.min() >= 2
+    prob = P.preprocess(raw)  # every observation stays in front of its camera
+    assert prob.obs_per_lm().max() >= 115
