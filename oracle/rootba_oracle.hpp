@@ -39,6 +39,8 @@
 
 #ifdef _OPENMP
 #include <omp.h>
+#include <memory>
+#include <cstdlib>
 #endif
 
 namespace orc {
@@ -461,18 +463,40 @@ class Oracle {
       off += size_t(rows(l)) * cols(l);
     }
     blk_off_[n_lms] = off;
-    storage_.assign(off, S(0));
+#ifdef _OPENMP
+    n_threads_ = opt_.num_threads > 0 ? opt_.num_threads : omp_get_max_threads();
+#else
+    n_threads_ = 1;
+#endif
+    // Block storage is FIRST TOUCHED by the thread that will work on it: every landmark loop below is
+    // an `omp for schedule(static)` over the same range with the same thread count, so a block stays
+    // on the NUMA node of its worker (a zero-filling std::vector would put all of it on the
+    // constructing thread's node - on a two-socket host every product then crosses the socket link).
+    storage_size_ = off;
+    storage_.reset(static_cast<S*>(std::aligned_alloc(64, (off * sizeof(S) + 63) / 64 * 64)));
+    if (!storage_) throw std::bad_alloc();
+#pragma omp parallel for num_threads(n_threads_) schedule(static)
+    for (int l = 0; l < n_lms; ++l)
+      std::fill(storage_.get() + blk_off_[l], storage_.get() + blk_off_[l + 1], S(0));
+    // per-thread accumulators of the camera-sized reductions, allocated (and first touched) once
+    acc_.resize(size_t(n_threads_));
+    xr_.resize(size_t(n_threads_));
+    tmp_.resize(size_t(n_threads_));
+#pragma omp parallel num_threads(n_threads_)
+    {
+#ifdef _OPENMP
+      const int tid = omp_get_thread_num();
+#else
+      const int tid = 0;
+#endif
+      acc_[tid].assign(size_t(P) * n_cams, S(0));
+    }
     jl_col_scale_.assign(size_t(3) * n_lms, S(0));
     rot_.assign(size_t(12) * n_lms, S(0));
     damped_.assign(n_lms, 0);
     failed_.assign(n_lms, 0);
     eps_ = opt_.jacobi_scaling_eps > 0 ? S(opt_.jacobi_scaling_eps)
                                        : epsilon_sqrt<S>();
-#ifdef _OPENMP
-    n_threads_ = opt_.num_threads > 0 ? opt_.num_threads : omp_get_max_threads();
-#else
-    n_threads_ = 1;
-#endif
   }
 
   int n_cams() const { return n_cams_; }
@@ -485,8 +509,8 @@ class Oracle {
   int res_idx(int l) const { return lm_idx(l) + 3; }
   int cols(int l) const { return lm_idx(l) + 4; }
   int rows(int l) const { return 2 * k(l) + 3; }
-  S* block(int l) { return storage_.data() + blk_off_[l]; }
-  const S* block(int l) const { return storage_.data() + blk_off_[l]; }
+  S* block(int l) { return storage_.get() + blk_off_[l]; }
+  const S* block(int l) const { return storage_.get() + blk_off_[l]; }
   std::vector<S>& cams() { return cams_; }
   std::vector<S>& lms() { return lms_; }
   const std::vector<S>& jl_col_scale() const { return jl_col_scale_; }
@@ -960,7 +984,8 @@ class Oracle {
       }
       return;
     }
-    std::vector<std::vector<S>> acc(n_threads_);
+    // reduction_alg = 0 flavour of the reference (per-thread accumulators, linearization_qr.hpp:294-334),
+    // static schedule = the first-touch partition of the block storage, parallel combine
 #pragma omp parallel num_threads(n_threads_)
     {
 #ifdef _OPENMP
@@ -968,19 +993,19 @@ class Oracle {
 #else
       const int tid = 0;
 #endif
-      acc[tid].assign(n, S(0));
-      std::vector<S> xr, tmp;
-#pragma omp for schedule(dynamic, 256)
+      std::fill(acc_[tid].begin(), acc_[tid].end(), S(0));
+      std::vector<S>& xr = xr_scratch(tid);
+      std::vector<S>& tmp = tmp_scratch(tid);
+#pragma omp for schedule(static)
       for (int l = 0; l < n_lms_; ++l)
-        add_Q2TJp_T_Q2TJp_mult_x(l, acc[tid].data(), x, xr, tmp);
+        add_Q2TJp_T_Q2TJp_mult_x(l, acc_[tid].data(), x, xr, tmp);
+#pragma omp for schedule(static)
+      for (int64_t i = 0; i < int64_t(n); ++i) {
+        S v = 0;
+        for (int t = 0; t < n_threads_; ++t) v += acc_[t][i];
+        y[i] = v + (pose_damping_ > 0 ? x[i] * pose_damping_ : S(0));
+      }
     }
-    for (size_t i = 0; i < n; ++i) {
-      S v = 0;
-      for (int t = 0; t < n_threads_; ++t) v += acc[t][i];
-      y[i] = v;
-    }
-    if (pose_damping_ > 0)
-      for (size_t i = 0; i < n; ++i) y[i] += x[i] * pose_damping_;
   }
 
   // LinearizationQR::back_substitute (linearization_qr.hpp:165-179)
@@ -1681,7 +1706,15 @@ class Oracle {
   std::vector<S> obs_xy_;
   std::vector<S> cams_, lms_, cams_bak_, lms_bak_;
   std::vector<size_t> blk_off_;
-  std::vector<S> storage_;
+  struct FreeDeleter {
+    void operator()(S* p) const { std::free(p); }
+  };
+  std::unique_ptr<S[], FreeDeleter> storage_;
+  size_t storage_size_ = 0;
+  mutable std::vector<std::vector<S>> acc_;  // [thread][9 n_c]
+  mutable std::vector<std::vector<S>> xr_, tmp_;  // [thread] gather / row-product scratch (no per-call allocation)
+  std::vector<S>& xr_scratch(int tid) const { return xr_[tid]; }
+  std::vector<S>& tmp_scratch(int tid) const { return tmp_[tid]; }
   std::vector<S> jl_col_scale_;
   std::vector<S> rot_;
   std::vector<char> damped_, failed_;

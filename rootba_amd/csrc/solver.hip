@@ -428,7 +428,20 @@ class Solver final : public rba_solver {
     }
     // (needs the SCHUR_JACOBI blocks of stage 2 as its diagonal; the dense n_c x n_c host tables used
     //  to build the structure bound the camera count: 20000 cameras = 0.4 GB of marks + 1.6 GB transient)
-    if (!sc_ && opt_.preconditioner_type == 1 && explicit_after_ > 0 && n_cams_ <= 20000) {
+    // The assembly gathers over per-block lists of observation pairs: sum_l k_l (k_l - 1) / 2 pairs of
+    // 8 bytes (plus the 81-scalar blocks). Heavy-tailed track lengths make that O(sum k^2); it is
+    // bounded here: above the budget (RBA_EX_PAIR_BUDGET_GB, default 24 GB of the 288) the solver stays
+    // matrix-free, which needs no such lists.
+    int64_t n_pairs_total = 0;
+    for (int l = 0; l < n_lms; ++l) n_pairs_total += int64_t(lm_k[l]) * (lm_k[l] - 1) / 2;
+    ex_pair_bytes_ = 8 * n_pairs_total;
+    double pair_budget_gb = 24.0;
+    if (const char* ev = std::getenv("RBA_EX_PAIR_BUDGET_GB")) pair_budget_gb = std::atof(ev);
+    const bool pairs_fit = double(ex_pair_bytes_) <= pair_budget_gb * 1e9;
+    if (!pairs_fit && std::getenv("RBA_VERBOSE"))
+      std::fprintf(stderr, "[rootba_hip] pair lists of the reduced matrix would take %.1f GB (> %.1f GB): "
+                           "products stay matrix-free\n", ex_pair_bytes_ * 1e-9, pair_budget_gb);
+    if (!sc_ && opt_.preconditioner_type == 1 && explicit_after_ > 0 && n_cams_ <= 20000 && pairs_fit) {
       h_lm_obs_ = lm_obs;
       h_obs_cam_ = s_obs_cam;
       pair_mark_.assign(size_t(n_cams_) * n_cams_, 0);
@@ -2055,7 +2068,7 @@ class Solver final : public rba_solver {
   static constexpr int kNumImplicit = 7;
   int imp_begin_[kNumImplicit], imp_end_[kNumImplicit];
   int64_t hx_bytes_ = 0, hx_flops_ = 0, storage_bytes_ = 0, hx_implicit_bytes_ = 0;
-  int64_t storage_dense_bytes_ = 0, ex_pairs_ = 0;
+  int64_t storage_dense_bytes_ = 0, ex_pairs_ = 0, ex_pair_bytes_ = 0;
   rba::Params<S> prm_{};
   S pose_damping_ = S(0);
   bool landmark_damping_valid_ = false;
