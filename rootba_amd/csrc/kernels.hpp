@@ -66,6 +66,9 @@ struct Params {
   S* bsO;       // [n_obs][5]     back-substitution scratch: topd x (3), Jp x (2)
   S* givens;    // [n_lms][16]    the 6 damping rotations of stage 2: c[6], s[6], damping-row residual[3], pad
   int b_from_records;  // b = sum_obs (b record) (staged path, kernels_s1.hpp) instead of b_mid + sum_obs (b record)
+  S* sdiag;            // [81 n_cams] JACOBI / power-series with the assembled matrix: B_mid - sum topd^T topd, i.e.
+                       // the diagonal blocks of the reduced matrix (the preconditioner blocks are B_mid + lambda I there)
+  int want_sdiag;
   // Optional privatised scatter targets: the camera-indexed scatter-adds of the products go to one of
   // `y_rep` replicas of the 9 n_c vector (chosen by workgroup), summed afterwards. An experiment switch
   // (RBA_Y_REPLICAS): on venice 4 / 16 / 64 replicas move H*x by < 2 %, i.e. the 7.5 M atomic requests
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float 
   // b: lane (g, a) of 7 groups x 9 components sums the b records of observations g, g+7, ... (double)
   const int g = lane / 9, a = lane - 9 * g;
   double accb = 0;
-  acc = mfma_xtx_staged<kTd, 3>(p.topd, p.cam_obs, t0, t1, wave, lane, acc, stage[wave], !p.jacobi,
+  acc = mfma_xtx_staged<kTd, 3>(p.topd, p.cam_obs, t0, t1, wave, lane, acc, stage[wave], !p.jacobi || p.want_sdiag,
                                 [&](int cnt, const float* rec) {
                                   if (want_b && lane < 63)
                                     for (int r = g; r < cnt; r += 7) accb += double(rec[r * kTd + 27 + a]);
@@ -427,7 +430,9 @@ __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float 
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) t += tile[w][i][j];
-    p.blocks[81 * c + tid] = (p.B_mid[81 * c + tid] - t) + (i == j ? lambda : 0.f);
+    const float bm = p.B_mid[81 * c + tid];
+    p.blocks[81 * c + tid] = (p.jacobi ? bm : bm - t) + (i == j ? lambda : 0.f);
+    if (p.want_sdiag) p.sdiag[81 * c + tid] = bm - t;
   }
   if (tid >= 128 && tid < 137) {
     const int aa = tid - 128;
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
       }
       __syncthreads();
       if (grp < 3) {
-        if (!p.jacobi) {
+        if (!p.jacobi || p.want_sdiag) {
           for (int q = grp; q < n; q += 3) {
             const S* r = rec[q];
             acc -= double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb] + r[18 + ea] * r[18 + eb]);
@@ -545,9 +550,12 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
   }
   if (grp < 3) red[grp][e] = acc;
   __syncthreads();
-  if (tid < 81)
-    p.blocks[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + red[0][tid] + red[1][tid] +
-                               red[2][tid] + ((tid / 9 == tid % 9) ? double(lambda) : 0.0));
+  if (tid < 81) {
+    const double gram = red[0][tid] + red[1][tid] + red[2][tid];  // = - sum topd^T topd
+    p.blocks[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + (p.jacobi ? 0.0 : gram) +
+                               ((tid / 9 == tid % 9) ? double(lambda) : 0.0));
+    if (p.want_sdiag) p.sdiag[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + gram);
+  }
   if (tid >= 243 && tid < 252)
     p.b[9 * c + (tid - 243)] = S((p.b_from_records ? 0.0 : double(p.b_mid[9 * c + (tid - 243)])) + acc);
 }
@@ -2127,6 +2135,26 @@ __global__ __launch_bounds__(kPcgThreads) void k_block_apply(const S* __restrict
     // passes a different buffer (ping-pong)
     for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads)
       zero_me[i] = S(0);
+  }
+}
+
+// one term of the power series through the assembled matrix: with E0 = Hpp_damped - (S + lambda I),
+//   (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t);   w = (S + lambda I) t comes from the SpMV
+template <class S>
+__global__ __launch_bounds__(kPcgThreads) void k_series_step(const S* __restrict__ inv, const S* __restrict__ w,
+                                                            S* __restrict__ t, S* __restrict__ z, int n,
+                                                            const CgState* st) {
+  if (st->done) return;
+  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
+    const int c = i / 9, row = i - 9 * c;
+    const S* M = inv + 81 * c + 9 * row;
+    const S* wc = w + 9 * c;
+    S v = S(0);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v += M[j] * wc[j];
+    const S tn = t[i] - v;
+    t[i] = tn;
+    z[i] += tn;
   }
 }
 

@@ -615,4 +615,13 @@ __global__ __launch_bounds__(256) void k_ex_set_diag(const S* __restrict__ block
   vals[size_t(81) * diag_slot[c] + e] = blocks[t] - (e % 10 == 0 ? lambda : S(0));
 }
 
+// the same from a buffer that holds the diagonal blocks themselves (JACOBI / power series)
+template <class S>
+__global__ __launch_bounds__(256) void k_ex_copy_diag(const S* __restrict__ sdiag, const int* __restrict__ diag_slot,
+                                                      S* __restrict__ vals, int n_cams) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 81 * n_cams) return;
+  vals[size_t(81) * diag_slot[t / 81] + t % 81] = sdiag[t];
+}
+
 }  // namespace rba

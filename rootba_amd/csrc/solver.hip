@@ -441,7 +441,7 @@ class Solver final : public rba_solver {
     if (!pairs_fit && std::getenv("RBA_VERBOSE"))
       std::fprintf(stderr, "[rootba_hip] pair lists of the reduced matrix would take %.1f GB (> %.1f GB): "
                            "products stay matrix-free\n", ex_pair_bytes_ * 1e-9, pair_budget_gb);
-    if (!sc_ && opt_.preconditioner_type == 1 && explicit_after_ > 0 && n_cams_ <= 20000 && pairs_fit) {
+    if (!sc_ && explicit_after_ > 0 && n_cams_ <= 20000 && pairs_fit) {
       h_lm_obs_ = lm_obs;
       h_obs_cam_ = s_obs_cam;
       pair_mark_.assign(size_t(n_cams_) * n_cams_, 0);
@@ -476,7 +476,7 @@ class Solver final : public rba_solver {
     d_jp_diag2_.alloc(nvec_);
     d_pose_scaling_.alloc(nvec_);
     d_mid_.alloc(size_t(90) * n_cams);  // [b_mid | B_mid]
-    d_bb_.alloc(size_t(90) * n_cams);   // [b | blocks]
+    d_bb_.alloc(size_t(171) * n_cams);  // [b | blocks | diagonal blocks of the reduced matrix (JACOBI / series)]
     d_inv_.alloc(size_t(81) * n_cams);
     d_fail_.alloc(1);
     d_lm_ldiff_.alloc(n_lms);
@@ -558,6 +558,8 @@ class Solver final : public rba_solver {
     prm_.valid_only = opt_.use_valid_projections_only;
     // JACOBI and the power-series preconditioner both start from Hpp = sum Jp^T Jp
     prm_.jacobi = opt_.preconditioner_type == 0 || opt_.preconditioner_type == 2;
+    prm_.sdiag = d_bb_.get() + size_t(90) * n_cams;
+    prm_.want_sdiag = (prm_.jacobi && ex_ready_) ? 1 : 0;
     prm_.huber = S(opt_.huber_parameter);
     prm_.eps = opt_.jacobi_scaling_eps > 0 ? S(opt_.jacobi_scaling_eps) : rba::Eps<S>::eps_sqrt;
     if (sc_) {
@@ -599,7 +601,7 @@ class Solver final : public rba_solver {
       scp_.eps = prm_.eps;
     }
     // capture the launch graphs of the fused PCG now (one-off cost, not part of an LM iteration)
-    if (fused_pcg_ && use_pcg_graphs_ && n_items_ > 0 && opt_.preconditioner_type == 1 && (sc_ || ex_ready_))
+    if (fused_pcg_ && use_pcg_graphs_ && n_items_ > 0 && opt_.preconditioner_type != 2 && (sc_ || ex_ready_))
       build_pcg_graphs(sc_ ? scp_ : exp_);
   }
 
@@ -727,8 +729,12 @@ class Solver final : public rba_solver {
     if (ex_n_upper_ > 0) launch_offdiag(prm_.topd, d_ex_vals_.get());
     all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
     // (the diagonal blocks were all-reduced by stage 2 already)
-    hipLaunchKernelGGL((rba::k_ex_set_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
-                       prm_.blocks, d_ex_diag_.get(), d_ex_vals_.get(), pose_damping_, n_cams_);
+    if (prm_.want_sdiag)
+      hipLaunchKernelGGL((rba::k_ex_copy_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
+                         prm_.sdiag, d_ex_diag_.get(), d_ex_vals_.get(), n_cams_);
+    else
+      hipLaunchKernelGGL((rba::k_ex_set_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
+                         prm_.blocks, d_ex_diag_.get(), d_ex_vals_.get(), pose_damping_, n_cams_);
     if (measure) {
       HIP_CHECK(hipEventRecord(ev_asm1_, stream_));
       asm_pending_ = true;
@@ -1151,7 +1157,7 @@ class Solver final : public rba_solver {
     if (comm_ || cb_fn_) {
       // every rank added lambda*I and holds only its landmarks' sums: make the
       // diagonal term count once
-      all_reduce(d_bb_.get(), size_t(90) * n_cams_);
+      all_reduce(d_bb_.get(), size_t(prm_.want_sdiag ? 171 : 90) * n_cams_);
       hipLaunchKernelGGL((rba::k_sub_diag<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                          prm_.blocks, S(lambda) * S(nranks_ - 1), n_cams_);
     }
@@ -1601,14 +1607,16 @@ class Solver final : public rba_solver {
     // are no-ops (`done`).
     ex_active_ = false;
     pcg_used_explicit_ = false;
-    const bool fused = fused_pcg_ && n_items_ > 0 && opt_.preconditioner_type == 1;
+    const bool fused = fused_pcg_ && n_items_ > 0 && opt_.preconditioner_type != 2;  // block-diagonal preconditioners
     bool go_fused = sc_ && fused;  // explicit Schur-complement backend: the matrix exists from the start
     int it = 1;
     for (; it <= max_it && !go_fused; ++it) {
       // Long solve: from here on the product is an SpMV with the explicitly assembled
       // S = sum_l A_l^T A_l (one assembly ~ 16 matrix-free products on venice; S is all-reduced
       // once, after which the iterations need no collective at all)
-      if (ex_ready_ && !ex_active_ && !explicit_off_for_solve_ && it > explicit_after_) {
+      // (power series: every iteration costs 1 + power_order products, the assembly pays off at once)
+      if (ex_ready_ && !ex_active_ && !explicit_off_for_solve_ &&
+          it > (opt_.preconditioner_type == 2 ? 0 : explicit_after_)) {
         if (!ex_valid_) assemble_explicit();
         ex_active_ = true;
         pcg_used_explicit_ = true;
@@ -1626,6 +1634,15 @@ class Solver final : public rba_solver {
                            d_r_.get(), t, static_cast<S*>(nullptr), e, n, st);
         HIP_CHECK(hipMemcpyAsync(d_z_.get(), t, n * sizeof(S), hipMemcpyDeviceToDevice, stream_));
         for (int i = 1; i <= opt_.power_order; ++i) {
+          if (ex_active_) {
+            // through the assembled matrix: (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t), no collective
+            hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, exp_, t, e, done);
+            hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, t, e,
+                               lambda, n);
+            hipLaunchKernelGGL((rba::k_series_step<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), e, t,
+                               d_z_.get(), n, st);
+            continue;
+          }
           launch_e0(t, e, done);
           all_reduce(e, n);
           // t = Hpp^-1 e; z += t; (e is re-zeroed by the next round's first kernel)

@@ -138,3 +138,29 @@ def test_config4_venice1778_f32_lockstep_four_iterations():
     # size-independent properties at full size: states agree after the four accepted steps
     (cg_, lg_), (co_, lo_) = g.get_state(), o.get_state()
     assert rel_err(cg_, co_) < 1e-4 and rel_err(lg_, lo_) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_config5_power_series_preconditioner_at_trafalgar_size(dtype):
+    """BASELINE config 5's solver path (square-root operator + PoBA power-series preconditioner,
+    PowerSCPreconditioner::solve_assign, src/rootba/cg/preconditioner.hpp:180-245) at trafalgar-257
+    size: the GPU applies the series through the assembled reduced matrix
+    ((Hpp^-1 E0) t = t - Hpp^-1 (S + lambda I) t), the oracle through the landmark blocks."""
+    prob = _bench_problem("trafalgar-257")
+    kw = dict(max_num_iterations=5, function_tolerance=0.0, preconditioner_type=2, power_order=10)
+    g, o = _pair(prob, dtype, **kw)
+    lg, _ = g.optimize_lm()
+    lo, _ = o.optimize_lm()
+    assert len(lg) == len(lo) == 6
+    ctol = 2e-6 if dtype == np.float32 else 1e-8
+    for a, b in zip(lg[1:], lo[1:]):
+        assert a.step_is_successful == b.step_is_successful == 1
+        assert abs(a.cost - b.cost) <= ctol * b.cost
+        if dtype == np.float64:
+            assert a.cg_iterations == b.cg_iterations
+        elif b.cg_iterations <= 30:
+            assert abs(a.cg_iterations - b.cg_iterations) <= 1
+    # and it does what a better preconditioner should: fewer PCG iterations than SCHUR_JACOBI
+    gj, _ = _pair(prob, dtype, max_num_iterations=5, function_tolerance=0.0)
+    lj, _ = gj.optimize_lm()
+    assert sum(r.cg_iterations for r in lg) < sum(r.cg_iterations for r in lj)

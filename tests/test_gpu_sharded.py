@@ -94,7 +94,9 @@ def test_two_ranks_one_gpu_match_unsharded(dtype):
     assert len(log) == len(r0["lm"])
     for a, (cost, cgi, ok) in zip(log, r0["lm"]):
         assert a.step_is_successful == ok
-        assert abs(a.cost - cost) <= (1e-5 if dtype == np.float32 else 1e-9) * cost
+        # float32: two summation orders (shards, atomics) on truncated PCG solves - the late iterations
+        # agree to the few 1e-5 that separate any two float32 runs of this problem
+        assert abs(a.cost - cost) <= ((1e-5 if a.iteration <= 2 else 5e-5) if dtype == np.float32 else 1e-9) * cost
 
 
 def test_rccl_call_path_with_one_rank(ladybug_problem):
