@@ -323,48 +323,74 @@ __device__ __forceinline__ int xcd_swizzled_camera(int n_cams) {
 inline int xcd_swizzled_grid(int n_cams) { return 8 * ((n_cams + 7) / 8); }
 
 constexpr int kCamChunk = 32;
-template <int W, int ROWS, class F>
+template <int W, int ROWS, bool PREFETCH, class F>
 __device__ __forceinline__ f32x4 mfma_xtx_staged(const float* __restrict__ rec, const int* __restrict__ cam_obs,
                                                  int64_t t0, int64_t t1, int wave, int lane, f32x4 acc, float* lds,
                                                  bool use_mfma, F&& side) {
   constexpr int PS = W == 18 ? 2 : 4;  // floats per piece
   constexpr int NP = W / PS;           // 9 pieces per record
+  constexpr int NJ = (kCamChunk * NP + 63) / 64;
   static_assert(NP == 9, "nine pieces per record");
+  using PV = typename std::conditional<PS == 2, float2, float4>::type;
   const int i = lane & 15, kk = lane >> 4;
-  for (int64_t base = t0 + kCamChunk * wave; base < t1; base += 4 * kCamChunk) {
-    const int cnt = int(min<int64_t>(kCamChunk, t1 - base));
+  // PREFETCH: the records of chunk c + 1 are in flight (in registers) while chunk c is multiplied out of
+  // LDS. Used for the 72-byte Gram records (158 -> 139 us on venice); with the 16-byte pieces of the
+  // 144-byte stage-2 records the compiler moves the register array to scratch (324 -> 513 us), so that
+  // pass loads straight into LDS.
+  PV regs[NJ];
+  auto issue = [&](int64_t base, int cnt) {
     const int idxreg = lane < cnt ? cam_obs[base + lane] : 0;
 #pragma unroll
-    for (int j = 0; j < (kCamChunk * NP + 63) / 64; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int q = j * 64 + lane;
       const int r = q / NP, pc = q - NP * r;
       const int o = __shfl(idxreg, r & 31);
-      if (q < cnt * NP) {
-        if (PS == 2) {
-          const float2 v = *reinterpret_cast<const float2*>(rec + int64_t(o) * W + 2 * pc);
-          *reinterpret_cast<float2*>(lds + r * W + 2 * pc) = v;
-        } else {
-          const float4 v = *reinterpret_cast<const float4*>(rec + int64_t(o) * W + 4 * pc);
-          *reinterpret_cast<float4*>(lds + r * W + 4 * pc) = v;
-        }
+      if (q < cnt * NP) regs[j] = *reinterpret_cast<const PV*>(rec + int64_t(o) * W + PS * pc);
+    }
+  };
+  int64_t base = t0 + kCamChunk * wave;
+  int cnt = base < t1 ? int(min<int64_t>(kCamChunk, t1 - base)) : 0;
+  if (PREFETCH && cnt > 0) issue(base, cnt);
+  while (cnt > 0) {
+    if (PREFETCH) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int q = j * 64 + lane;
+        const int r = q / NP, pc = q - NP * r;
+        if (q < cnt * NP) *reinterpret_cast<PV*>(lds + r * W + PS * pc) = regs[j];
+      }
+    } else {
+      // straight global -> LDS (a register array here ends up in scratch for the 16-byte pieces)
+      const int idxreg = lane < cnt ? cam_obs[base + lane] : 0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int q = j * 64 + lane;
+        const int r = q / NP, pc = q - NP * r;
+        const int o = __shfl(idxreg, r & 31);
+        if (q < cnt * NP)
+          *reinterpret_cast<PV*>(lds + r * W + PS * pc) = *reinterpret_cast<const PV*>(rec + int64_t(o) * W + PS * pc);
       }
     }
     wave_lds_fence();
+    const int cur = cnt;
+    base += 4 * kCamChunk;
+    cnt = base < t1 ? int(min<int64_t>(kCamChunk, t1 - base)) : 0;
+    if (PREFETCH && cnt > 0) issue(base, cnt);
     if (use_mfma) {
       if (ROWS == 2) {
-        for (int s = 0; s < cnt; s += 2) {
+        for (int s = 0; s < cur; s += 2) {
           const int so = s + (kk >> 1);
-          const float v = (i < 9 && so < cnt) ? lds[so * W + 9 * (kk & 1) + i] : 0.f;
+          const float v = (i < 9 && so < cur) ? lds[so * W + 9 * (kk & 1) + i] : 0.f;
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, acc, 0, 0, 0);
         }
       } else {
-        for (int s = 0; s < cnt; ++s) {
+        for (int s = 0; s < cur; ++s) {
           const float v = (i < 9 && kk < 3) ? lds[s * W + 9 * kk + i] : 0.f;
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, acc, 0, 0, 0);
         }
       }
     }
-    side(cnt, lds);
+    side(cur, lds);
     wave_lds_fence();  // the next chunk overwrites the staging buffer
   }
   return acc;
@@ -416,7 +442,7 @@ __global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float 
   // b: lane (g, a) of 7 groups x 9 components sums the b records of observations g, g+7, ... (double)
   const int g = lane / 9, a = lane - 9 * g;
   double accb = 0;
-  acc = mfma_xtx_staged<kTd, 3>(p.topd, p.cam_obs, t0, t1, wave, lane, acc, stage[wave], !p.jacobi || p.want_sdiag,
+  acc = mfma_xtx_staged<kTd, 3, false>(p.topd, p.cam_obs, t0, t1, wave, lane, acc, stage[wave], !p.jacobi || p.want_sdiag,
                                 [&](int cnt, const float* rec) {
                                   if (want_b && lane < 63)
                                     for (int r = g; r < cnt; r += 7) accb += double(rec[r * kTd + 27 + a]);

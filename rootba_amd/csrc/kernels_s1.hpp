@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_cam_gram_mfma(Params<float> p) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int g = lane / 9, a = lane - 9 * g;
   double accd = 0;
-  acc = mfma_xtx_staged<18, 2>(p.JpS, p.cam_obs, t0, t1, wave, lane, acc, stage[wave], true,
+  acc = mfma_xtx_staged<18, 2, true>(p.JpS, p.cam_obs, t0, t1, wave, lane, acc, stage[wave], true,
                                [&](int cnt, const float* rec) {
                                  if (lane < 63)
                                    for (int r = g; r < cnt; r += 7) {

@@ -87,7 +87,7 @@ def parse(fetch_dir, write_dir, out_path, calib_bytes, hx_bytes, hx_bytes_implic
                   "FETCH_SIZE corrected by factors calibrated on streaming reads of the block storage",
     }}
     if hx_bytes_implicit and "hx_implicit" in f:
-        # k_hx_implicit reads its tiles with 4-byte-per-lane coalesced loads (factor c1)
+        # k_hx_implicit reads the stage-1 records with 4- and 16-byte loads (both calibrate to the same factor)
         out["venice-1778/implicit_q"] = {
             "traffic_bytes_per_launch": f["hx_implicit"] * c1 + res["write"].get("hx_implicit", 0),
             "algorithmic_bytes_per_launch": hx_bytes_implicit,
