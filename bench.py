@@ -26,6 +26,10 @@ import subprocess
 import sys
 import time
 
+# CPUs of this process BEFORE any OpenMP runtime starts: with OMP_PLACES set, libgomp binds the main
+# thread to its place as soon as it is loaded (with numpy / torch), and the affinity mask read later
+# would be that single core
+_CPUS_AT_START = len(os.sched_getaffinity(0))
 # the CPU baseline's OpenMP threads stay on their cores / NUMA node (must be set before libgomp starts)
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 os.environ.setdefault("OMP_PLACES", "cores")
@@ -101,7 +105,7 @@ def effective_cpus() -> tuple[int, str]:
     """CPUs this process may actually use: the cgroup CPU quota when there is one (the GPU boxes run the
     container with cpu.max = 16 CPUs on a 256-thread host: more OpenMP threads than that only get throttled
     - measured 37 GB/s with 16 threads, 31 with 128, 8.5 with 256), else the affinity mask."""
-    n = len(os.sched_getaffinity(0))
+    n = _CPUS_AT_START
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
