@@ -84,6 +84,15 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+// the same on an LDS address (ds_add_f32 / ds_add_f64, no return value); the pointer must be
+// derived from a __shared__ object so that the compiler sees the LDS address space
+__device__ __forceinline__ void lds_atomic_add(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_atomic_add(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <class S>
 struct Eps;
 // Sophus::Constants<Scalar>::epsilon() / epsilonSqrt()

@@ -75,6 +75,7 @@ struct Params {
   // onto one 64 KB vector are not what bounds the kernel.
   int y_rep;
   int64_t y_rep_stride;
+  int hx_debug;  // RBA_HX_DEBUG (profiling only, results are wrong): 1 = no scatter, 2 = loads only
   S* R0;        // [6 n_lms]
   S* Rd;        // [6 n_lms]
   S* q1trd;     // [3 n_lms]
@@ -1440,6 +1441,182 @@ __global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, ImplicitTiles 
     hx_implicit_tile<S, 8>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], x, y, yb, cb, lane, done);
   else
     hx_implicit_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], x, y, yb, cb, lane, done);
+}
+
+// ---------------------------------------------------------------------------
+// Tile loads of the persistent, software-pipelined form of the product (k_hx_implicit_lds below):
+//   * every load of a tile is unconditional (clamped indices, zeros selected afterwards), so the nine
+//     entries of a row are two 16-byte loads + one 4-byte load, x likewise (the one-tile-per-wave form
+//     above issues nine exec-masked 4-byte loads);
+//   * the per-landmark scalars (tau, the Z row) travel with the records instead of being fetched in
+//     the middle of the reflector chain;
+//   * a wave walks the tiles T, T + W, T + 2W, ...: the lane maps of tile i+2 and the records of tile
+//     i+1 are in flight while tile i is reduced (registers ping-pong between two sets; the loop is
+//     unrolled by two and no load is conditional, so no load result is ever copied - a copy would wait
+//     for its load right after issuing it).
+// (Measured on venice, float: the same pipeline with device-scope atomics instead of the LDS copy runs at
+//  252 us against 238 us for the one-tile-per-wave form - a wave's loads queue behind its own outstanding
+//  atomics in the in-order vmcnt counter - so that variant is not kept.)
+// ---------------------------------------------------------------------------
+template <class S>
+struct HxTileData {
+  S jp[9], xc[9], v0, v1, v2, t0, t1, t2, z0, z1, z2;
+};
+
+__device__ __forceinline__ int hx_tile_class(const ImplicitTiles& it, int T) {
+  return int(T >= it.tile_begin[1]) + int(T >= it.tile_begin[2]) + int(T >= it.tile_begin[3]) +
+         int(T >= it.tile_begin[4]);
+}
+
+template <class S>
+__device__ __forceinline__ void hx_tile_load(const Params<S>& p, const ImplicitTiles& it, int T, int cam, int row,
+                                             int lane, const S* __restrict__ x, HxTileData<S>& d) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  const int cls = hx_tile_class(it, T);  // wave-uniform
+  const int sh = 2 + cls;                // P2 = 1 << sh lanes per landmark
+  const int seg = lane >> sh, r = lane & ((1 << sh) - 1);
+  const int lb = cls == 0 ? it.lm_begin[0] : cls == 1 ? it.lm_begin[1] : cls == 2 ? it.lm_begin[2]
+               : cls == 3 ? it.lm_begin[3] : it.lm_begin[4];
+  const int le = cls == 0 ? it.lm_end[0] : cls == 1 ? it.lm_end[1] : cls == 2 ? it.lm_end[2]
+               : cls == 3 ? it.lm_end[3] : it.lm_end[4];
+  const int tb = cls == 0 ? it.tile_begin[0] : cls == 1 ? it.tile_begin[1] : cls == 2 ? it.tile_begin[2]
+               : cls == 3 ? it.tile_begin[3] : it.tile_begin[4];
+  const int s = min(lb + ((T - tb) << (6 - sh)) + seg, le - 1);  // clamped: padding segments read a valid landmark
+  const int64_t rw = cam >= 0 ? row : 0;
+  const int cc = cam >= 0 ? cam : 0;
+  const S* __restrict__ jrow = p.JpS + 9 * rw;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) d.jp[c] = jrow[c];
+  const V4 vv = reinterpret_cast<const V4*>(p.Vh)[rw];
+  d.v0 = vv.x;
+  d.v1 = vv.y;
+  d.v2 = vv.z;
+  const S* __restrict__ xc = x + 9 * cc;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) d.xc[c] = xc[c];
+  const S* __restrict__ th = p.tauH + 3 * int64_t(s);
+  d.t0 = th[0];
+  d.t1 = th[1];
+  d.t2 = th[2];
+  const S* __restrict__ Z = p.Zd + 9 * int64_t(s) + 3 * min(r, 2);
+  d.z0 = Z[0];
+  d.z1 = Z[1];
+  d.z2 = Z[2];
+}
+
+// ---------------------------------------------------------------------------
+// The product with a WORKGROUP-PRIVATE copy of y in LDS (used when 9 n_c scalars fit: venice-1778 in
+// float is 64 008 bytes of the CU's 160 KB). The device-scope float atomics of the forms above are
+// fabric transactions (PMC: 0.22 GB of write traffic per product for 0.18 GB of payload, and a wave's
+// loads queue behind its own outstanding atomics in the in-order vmcnt counter); here a tile's
+// contributions are ds_add_f64's into a DOUBLE LDS copy (measured on gfx950, scripts/microbench/lds_atomics.hip:
+// a 64-lane ds_add_f32 with random addresses takes ~80 ns of the CU's LDS, ds_add_f64 ~10 ns, ds_add_u32 ~7 ns -
+// with float accumulators this kernel ran at 265 us, slower than the global atomics) - outside the vector-memory queue - and
+// each of the (one per CU) persistent 1024-thread workgroups flushes its copy once at the end with fully
+// coalesced atomics: 256 x 9 n_c instead of 9 n_obs. The two rows of an observation share the nine adds
+// (row 2i takes components 0,2,4,6,8, row 2i+1 takes 1,3,5,7).
+// ---------------------------------------------------------------------------
+template <class S, int P2>
+__device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int cam, int lane, double* ylds, int dbg) {
+  const int r = lane & (P2 - 1);
+  const bool act = cam >= 0;
+  if (dbg == 2) {
+    S acc = d.v0 + d.v1 + d.v2 + d.t0 + d.t1 + d.t2 + d.z0 + d.z1 + d.z2;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc += d.jp[c] + d.xc[c];
+    if (acc == S(1.2345e30)) ylds[0] = double(acc);
+    return;
+  }
+  S u = S(0);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) u += d.jp[c] * d.xc[c];
+  u = act ? u : S(0);
+  const S v0 = act ? d.v0 : S(0), v1 = act ? d.v1 : S(0), v2 = act ? d.v2 : S(0);
+  u -= d.t0 * seg_sum<S, P2>(v0 * u) * v0;
+  u -= d.t1 * seg_sum<S, P2>(v1 * u) * v1;
+  u -= d.t2 * seg_sum<S, P2>(v2 * u) * v2;
+  {
+    const int base = lane - r;
+    const S u0 = __shfl(u, base), u1 = __shfl(u, base + 1), u2 = __shfl(u, base + 2);
+    if (act && r < 3) u = d.z0 * u0 + d.z1 * u1 + d.z2 * u2;
+  }
+  u -= d.t2 * seg_sum<S, P2>(v2 * u) * v2;
+  u -= d.t1 * seg_sum<S, P2>(v1 * u) * v1;
+  u -= d.t0 * seg_sum<S, P2>(v0 * u) * v0;
+  const int par = lane & 1;
+  double* yc = ylds + 9 * (act ? cam : 0) + par;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    // both rows of the observation receive the pair sums of components 2q and 2q+1; each adds one
+    const S ve = d.jp[2 * q] * u;
+    const S se = ve + dpp_mov0<0xb1>(ve);
+    S mine = se;
+    if (q < 4) {
+      const S vo = d.jp[2 * q + 1] * u;
+      const S so = vo + dpp_mov0<0xb1>(vo);
+      mine = par ? so : se;
+    }
+    if (act && (q < 4 || par == 0) && (dbg == 0 || mine == S(1.2345e30))) lds_atomic_add(yc + 2 * q, double(mine));
+  }
+}
+
+template <class S>
+__global__ __launch_bounds__(1024) void k_hx_implicit_lds(Params<S> p, ImplicitTiles it, const S* __restrict__ x,
+                                                          S* __restrict__ y, const int* __restrict__ done_flag) {
+  extern __shared__ __align__(16) unsigned char hx_lds_raw[];
+  double* ylds = reinterpret_cast<double*>(hx_lds_raw);
+  if (done_flag && *done_flag) return;  // uniform over the grid: nothing is added after the PCG has terminated
+  const int nvec = 9 * p.n_cams;
+  for (int i = threadIdx.x; i < nvec; i += 1024) ylds[i] = 0.0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nT = it.tile_begin[5];
+  const int W = gridDim.x * 16;
+  const int last = nT - 1;
+  int TA = blockIdx.x * 16 + wave;
+  if (TA < nT) {
+    int TB = TA + W;
+    int camA = p.CT[size_t(TA) * 64 + lane], rowA = p.RT[size_t(TA) * 64 + lane];
+    int camB = p.CT[size_t(min(TB, last)) * 64 + lane], rowB = p.RT[size_t(min(TB, last)) * 64 + lane];
+    HxTileData<S> dA, dB;
+    hx_tile_load(p, it, TA, camA, rowA, lane, x, dA);
+    auto compute = [&](int T, const HxTileData<S>& d, int cam) {
+      switch (hx_tile_class(it, T)) {
+        case 0: hx_tile_compute_lds<S, 4>(d, cam, lane, ylds, p.hx_debug); break;
+        case 1: hx_tile_compute_lds<S, 8>(d, cam, lane, ylds, p.hx_debug); break;
+        case 2: hx_tile_compute_lds<S, 16>(d, cam, lane, ylds, p.hx_debug); break;
+        case 3: hx_tile_compute_lds<S, 32>(d, cam, lane, ylds, p.hx_debug); break;
+        default: hx_tile_compute_lds<S, 64>(d, cam, lane, ylds, p.hx_debug); break;
+      }
+    };
+    for (;;) {
+      const int TC = TB + W;
+      const int camC = p.CT[size_t(min(TC, last)) * 64 + lane], rowC = p.RT[size_t(min(TC, last)) * 64 + lane];
+      hx_tile_load(p, it, min(TB, last), camB, rowB, lane, x, dB);
+      compute(TA, dA, camA);
+      if (TB >= nT) break;
+      const int TD = TC + W;
+      const int camD = p.CT[size_t(min(TD, last)) * 64 + lane], rowD = p.RT[size_t(min(TD, last)) * 64 + lane];
+      hx_tile_load(p, it, min(TC, last), camC, rowC, lane, x, dA);
+      compute(TB, dB, camB);
+      if (TC >= nT) break;
+      TA = TC;
+      camA = camC;
+      TB = TD;
+      camB = camD;
+      rowB = rowD;
+    }
+  }
+  __syncthreads();
+  // flush: every workgroup starts at its own offset so that the 256 copies do not hit the same
+  // addresses at the same moment
+  const int start = int((int64_t(blockIdx.x) * nvec) / gridDim.x);
+  for (int i = threadIdx.x; i < nvec; i += 1024) {
+    int j = i + start;
+    j = j >= nvec ? j - nvec : j;
+    const double v = ylds[j];
+    if (v != 0.0) atomic_add(y + j, S(v));
+  }
 }
 
 // rows of one landmark spread over RCH x 64 lanes (32 < k <= 112): one landmark

@@ -203,6 +203,13 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_BS_TWO_PASS")) bs_two_pass_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_Y_REPLICAS")) y_rep_ = std::max(1, std::min(64, std::atoi(ev)));
     if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
+    if (const char* ev = std::getenv("RBA_HX_LDS")) hx_lds_ = std::atoi(ev);
+    {
+      int dev = 0, cus = 0;
+      HIP_CHECK(hipGetDevice(&dev));
+      HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      if (cus > 0) n_cus_ = cus;
+    }
 
     // ---- sort landmarks by number of observations (stable) ----------------
     perm_.resize(n_lms);
@@ -495,6 +502,8 @@ class Solver final : public rba_solver {
     if (y_rep_ > 1 && !sc_) d_yrep_.alloc(size_t(y_rep_) * nvec_);
     prm_.y_rep = (y_rep_ > 1 && !sc_) ? y_rep_ : 1;
     prm_.y_rep_stride = nvec_;
+    prm_.hx_debug = 0;
+    if (const char* ev = std::getenv("RBA_HX_DEBUG")) prm_.hx_debug = std::atoi(ev);
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 4096));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_progress_), 64));
     h_progress_[0] = h_progress_[1] = 0;
@@ -1358,8 +1367,19 @@ class Solver final : public rba_solver {
         it.lm_end[c] = imp_end_[c];
       }
       it.tile_begin[5] = n_tiles_;
-      hipLaunchKernelGGL((rba::k_hx_implicit<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, it,
-                         x, y, done_flag);
+      const int wgs = (n_tiles_ + 3) / 4;
+      const size_t ylds_bytes = size_t(nvec_) * sizeof(double);  // double accumulators (ds_add_f64)
+      if (hx_lds_ && ylds_bytes <= kHxLdsMaxBytes && (hx_lds_ == 2 || n_tiles_ >= 64 * n_cus_)) {
+        // workgroup-private y in LDS, one persistent 1024-thread workgroup per CU
+        if (!hx_lds_attr_set_) {
+          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_implicit_lds<S>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(kHxLdsMaxBytes)));
+          hx_lds_attr_set_ = true;
+        }
+        hipLaunchKernelGGL((rba::k_hx_implicit_lds<S>), dim3(std::min(n_cus_, (n_tiles_ + 15) / 16)), dim3(1024), ylds_bytes, stream_, prm_, it, x, y,
+                           done_flag);
+      } else
+        hipLaunchKernelGGL((rba::k_hx_implicit<S>), dim3(wgs), dim3(256), 0, stream_, prm_, it, x, y, done_flag);
     }
   }
 
@@ -2120,6 +2140,11 @@ class Solver final : public rba_solver {
   bool staged_ = false;       // stage 1 staged by parallelism (kernels_s1.hpp): implicit-Q configuration
   bool cols_pending_ = false; // linearised, column pass not yet run (it runs inside the first stage 2)
   bool bs_two_pass_ = false;  // RBA_BS_TWO_PASS=1: round-1 back-substitution kernels for every landmark
+  int hx_lds_ = 1;            // RBA_HX_LDS=0: never use the LDS-private y copy (k_hx_implicit_lds); 2: whenever y fits
+                              // (default 1: when it fits and every wave gets at least four tiles)
+  bool hx_lds_attr_set_ = false;
+  static constexpr size_t kHxLdsMaxBytes = 152 * 1024;  // of the CU's 160 KB
+  int n_cus_ = 256;
   int y_rep_ = 1;             // RBA_Y_REPLICAS=n: privatised scatter targets of the matrix-free products
                               // (measured on venice: 4 / 16 / 64 replicas change H*x by < 2 % - the kernel is bound
                               //  by its 0.96 GB of HBM traffic, not by atomic serialisation; off by default)
