@@ -40,6 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DTYPE = np.float32
+GPU_DTYPE = np.float32  # what LinearizorHIP is created with: DTYPE, or "mixed" (--mixed: double state and costs,
+                        # float linear algebra; the CPU baseline then runs the float32 oracle)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -119,8 +121,8 @@ def effective_cpus() -> tuple[int, str]:
 
 def cpu_baseline(prob, n_iter: int, gpu_rows):
     """Oracle (CPU restatement of the reference path) on a bounded sample of the same workload: the
-    first `n_iter` LM iterations, all host cores; when that takes less than a third of the 30 s budget
-    the sample is extended to the first 2 * n_iter iterations (the long PCG solves of venice come late)."""
+    first LM iterations, all host cores; the number of iterations is chosen from a one-iteration probe so
+    that the sample stays within about 25 s on any host (at most 2 * n_iter iterations)."""
     from oracle import oracle as O
 
     n_cpu, cpu_note = effective_cpus()
@@ -135,10 +137,29 @@ def cpu_baseline(prob, n_iter: int, gpu_rows):
         its = [r for r in rows if r.iteration >= 1]
         return o.num_threads(), its, sum(r.iteration_time for r in its)
 
-    threads, its, t = run(n_iter)
-    if t < 10.0:
-        n_iter *= 2
-        threads, its, t = run(n_iter)
+    # Bounded sample (about 10-30 s of CPU work whatever the host is): a one-iteration probe gives the
+    # cost of a linearisation and of one CG iteration on this host; the GPU run's CG counts of the same
+    # iterations (the oracle follows the same trajectory) then predict the time of iterations 1..n, and n
+    # is the largest count <= 2 * n_iter whose prediction stays below the budget.
+    budget = 25.0
+    threads, its, t = run(1)
+    if its:
+        cg1 = max(1, its[0].cg_iterations)
+        t_cg = its[0].pcg_time / cg1
+        t_lin = max(0.0, its[0].iteration_time - its[0].pcg_time)
+        pred, n_fit = 0.0, 0
+        for r in [r for r in gpu_rows if r.iteration >= 1][:2 * n_iter]:
+            pred += t_lin + t_cg * r.cg_iterations * (1 + 1.0 / 10)
+            if pred > budget and n_fit >= 1:
+                break
+            n_fit += 1
+        log(f"[cpu_baseline] probe: {t_lin:.2f} s per linearisation + {t_cg:.3f} s per CG iteration -> "
+            f"sampling LM iterations 1..{n_fit}")
+        n_iter = max(1, n_fit)
+        if n_iter > 1:
+            threads, its, t = run(n_iter)
+    else:
+        n_iter = 1
     g = [r for r in gpu_rows if 1 <= r.iteration <= n_iter]
     tg = sum(r.iteration_time for r in g)
     for r in its:
@@ -186,7 +207,7 @@ def reference_semantics_run(local, prob_name, rank, world, local_rank, comm_setu
     opts = solver_options(L, 50, function_tolerance=1e-6)
     for key, val in _GPU_KW.items():
         setattr(opts, key, val)
-    lin = LinearizorHIP(local, DTYPE, opts, device=local_rank)
+    lin = LinearizorHIP(local, GPU_DTYPE, opts, device=local_rank)
     comm_setup(lin)
     lin.lm_begin()
     lin.lm_step()  # iteration 0: evaluation only
@@ -232,13 +253,18 @@ def main():
     ap.add_argument("--solver-type", choices=["SQUARE_ROOT", "SCHUR_COMPLEMENT"], default="SQUARE_ROOT",
                     help="SCHUR_COMPLEMENT: explicit reduced camera matrix + SpMV (SURVEY.md 8f #4), 1 GPU")
     ap.add_argument("--use-double", action="store_true", help="float64 (BASELINE metric is float32)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="RBA_MIXED: double state / observations / costs, float linear algebra (BASELINE config 5)")
     ap.add_argument("--no-reference-semantics", action="store_true",
                     help="skip the second run with the reference's function_tolerance stopping rule")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
-    global DTYPE
+    global DTYPE, GPU_DTYPE
     DTYPE = np.float64 if args.use_double else np.float32
+    GPU_DTYPE = "mixed" if args.mixed else DTYPE
+    if args.mixed and args.use_double:
+        raise SystemExit("--mixed and --use-double exclude each other")
     args.implicit_q = not args.dense_blocks
     _SOLVER_KW.update(preconditioner_type=PRECOND[args.preconditioner], power_order=args.power_order)
     _GPU_KW.update(implicit_q=int(args.implicit_q), solver_type=int(args.solver_type == "SCHUR_COMPLEMENT"))
@@ -277,7 +303,7 @@ def main():
     for key, val in _GPU_KW.items():
         setattr(gpu_opts, key, val)
     t0 = time.perf_counter()
-    lin = LinearizorHIP(local, DTYPE, gpu_opts, device=local_rank)
+    lin = LinearizorHIP(local, GPU_DTYPE, gpu_opts, device=local_rank)
     log(f"[rank {rank}] solver set up in {time.perf_counter() - t0:.2f}s (rba_create: sort by track length, "
         f"CSC index, block structure of the reduced matrix, launch graphs, device allocation)")
 
@@ -420,11 +446,11 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64" if DTYPE == np.float64 else "f32",
+            "dtype": "f32 (state, observations and costs f64)" if args.mixed else "f64" if DTYPE == np.float64 else "f32",
             "data": data,
             "config": {
                 "workload": f"BAL {args.workload} ({data}): {prob.n_cams} cams, {prob.n_lms} lms, {prob.n_obs} obs, "
-                            f"solver={args.solver_type}, {args.preconditioner}, Huber(1), {'float64' if DTYPE == np.float64 else 'float32'}",
+                            f"solver={args.solver_type}, {args.preconditioner}, Huber(1), {'mixed float32/float64' if args.mixed else 'float64' if DTYPE == np.float64 else 'float32'}",
                 "parallelism": (f"landmarks sharded over {world} GPU(s); library communicator: transport="
                                 f"{info['transport']}, nranks={info['nranks']}"
                                 + ("" if world == 1 else "; all-reduce of camera-sized vectors / the assembled matrix")),
@@ -444,7 +470,9 @@ def main():
             "roofline": {
                 "kernel": ("k_pcgs_spmv (S*x on the explicit block-CSR reduced camera matrix; algorithmic bytes = "
                            "81 s + 4 per block + 2 x 9 n_c s)" if sc else
-                           "k_hx_implicit (H*x from the QR factors; algorithmic bytes = SURVEY.md 8d implicit-Q formula)"
+                           "k_hx_implicit_lds (+ k_hx_implicit_wide for 32 < k <= 112): H*x from the QR factors, workgroup-private "
+                           "double y in LDS where 9 n_c doubles fit, else k_hx_implicit; algorithmic bytes = SURVEY.md 8d "
+                           "implicit-Q formula"
                            if args.implicit_q else
                            "k_hx (H*x = sum_l A_l^T A_l x, all k-classes of one right_multiply)"),
                 "bound": "hbm",

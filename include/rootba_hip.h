@@ -47,6 +47,16 @@ extern "C" {
 
 #define RBA_F32 0
 #define RBA_F64 1
+/* Mixed precision (BASELINE config 5; no reference counterpart - the reference is templated on one
+ * Scalar): the optimisation state (cameras, landmarks), the observations and every cost evaluation
+ * are double; linearisation, landmark QR, the reduced camera system, PCG and back-substitution run
+ * in float on the rounded state, with the accumulations the float path already keeps in double
+ * (cost sums, PCG scalars, Jp_diag2, b, H*x partial sums, l_diff). The float increments are applied
+ * to the double state, so rounding does not accumulate from one LM iteration to the next and the
+ * step-quality ratio is computed from double costs.
+ * At the boundary: `obs_xy` of rba_create and the arrays of rba_set_state / rba_get_state are
+ * DOUBLE; every camera-sized vector (increments, b, x, y, blocks, Jp_diag2, scalings) is FLOAT. */
+#define RBA_MIXED 2
 
 /* SolverOptions fields consumed by the hot path
  * (src/rootba/bal/solver_options.hpp:111-281; read at

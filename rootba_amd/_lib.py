@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "librootba_hip.so")
 
 RBA_OK = 0
 RBA_NUMERICAL_FAILURE = 1
-RBA_F32, RBA_F64 = 0, 1
+RBA_F32, RBA_F64, RBA_MIXED = 0, 1, 2
 
 
 class RbaOptions(C.Structure):

@@ -75,6 +75,8 @@ struct Params {
   // onto one 64 KB vector are not what bounds the kernel.
   int y_rep;
   int64_t y_rep_stride;
+  S* lm_inc;     // mixed precision (RBA_MIXED): the back-substitution stores the scaled landmark increments here
+                 // [3 n_lms] instead of adding them to `lms`; they are applied to the double master state
   int hx_debug;  // RBA_HX_DEBUG (profiling only, results are wrong): 1 = no scatter, 2 = loads only
   S* R0;        // [6 n_lms]
   S* Rd;        // [6 n_lms]
@@ -97,6 +99,20 @@ struct Params {
   S huber;
   S eps;  // jacobi scaling epsilon
 };
+
+// landmark update of the back-substitution (ipp:279-283): lms += Jl_col_scale * inc, or - mixed precision - the
+// scaled increment is handed to the double master state (k_mixed_update_landmarks)
+template <class S>
+__device__ __forceinline__ void apply_landmark_increment(const Params<S>& p, int s, const S inc[3]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const S d = inc[j] * p.jl_scale[3 * s + j];
+    if (p.lm_inc)
+      p.lm_inc[3 * s + j] = d;
+    else
+      p.lms[3 * s + j] += d;
+  }
+}
 
 template <class S>
 __device__ __forceinline__ S* scatter_replica(const Params<S>& p, S* y) {
@@ -1974,9 +1990,7 @@ __global__ __launch_bounds__(256) void k_bs_landmark(Params<S> p, int lm_begin, 
   const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) && is_finite(acc) &&
                    is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) && is_finite(p.lms[3 * s + 2]);
   if (!fin) atomicOr(p.fail_flag, 2);
-  p.lms[3 * s + 0] += inc[0] * p.jl_scale[3 * s + 0];
-  p.lms[3 * s + 1] += inc[1] * p.jl_scale[3 * s + 1];
-  p.lms[3 * s + 2] += inc[2] * p.jl_scale[3 * s + 2];
+  apply_landmark_increment(p, s, inc);
 }
 
 // The same back-substitution for the tiled landmarks (k <= 32) in ONE pass, lane per block row
@@ -2052,9 +2066,7 @@ __device__ __forceinline__ void bs_tile(const Params<S>& p, size_t T, int t_in_c
     const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) && is_finite(acc) &&
                      is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) && is_finite(p.lms[3 * s + 2]);
     if (!fin) atomicOr(p.fail_flag, 2);
-    p.lms[3 * s + 0] += inc[0] * p.jl_scale[3 * s + 0];
-    p.lms[3 * s + 1] += inc[1] * p.jl_scale[3 * s + 1];
-    p.lms[3 * s + 2] += inc[2] * p.jl_scale[3 * s + 2];
+    apply_landmark_increment(p, s, inc);
   }
 }
 
@@ -2092,14 +2104,9 @@ __global__ __launch_bounds__(256) void k_sum_ldiff(const double* __restrict__ v,
 // Camera update: inc *= pose_scaling; T <- (exp(w) R, exp(w) t + v);
 // intrinsics += inc[6..8]   (linearizor_qr.cpp:280-287, bal_problem.hpp:97-109)
 // ===========================================================================
+// cam = (q xyzw, t, f, k1, k2); inc = (dt, dphi, dintrinsics), already unscaled
 template <class S>
-__global__ void k_update_cameras(Params<S> p, const S* __restrict__ inc_scaled) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= p.n_cams) return;
-  S inc[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) inc[i] = inc_scaled[9 * c + i] * p.pose_scaling[9 * c + i];
-  S* cam = p.cams + 10 * c;
+__device__ __forceinline__ void retract_camera(S* cam, const S inc[9]) {
   // SO3::exp as a unit quaternion
   const S th2 = inc[3] * inc[3] + inc[4] * inc[4] + inc[5] * inc[5];
   S im, re;
@@ -2132,6 +2139,50 @@ __global__ void k_update_cameras(Params<S> p, const S* __restrict__ inc_scaled) 
   cam[7] += inc[6];
   cam[8] += inc[7];
   cam[9] += inc[8];
+}
+
+template <class S>
+__global__ void k_update_cameras(Params<S> p, const S* __restrict__ inc_scaled) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.n_cams) return;
+  S inc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) inc[i] = inc_scaled[9 * c + i] * p.pose_scaling[9 * c + i];
+  retract_camera<S>(p.cams + 10 * c, inc);
+}
+
+// ---------------------------------------------------------------------------
+// Mixed precision (RBA_MIXED): the optimisation state lives in double ("master" cameras / landmarks),
+// the linear algebra of an LM iteration runs on its float rounding. The float increments are applied to
+// the masters in double and the float state is re-rounded from them, so the state never accumulates
+// float rounding from one iteration to the next, and costs are evaluated in double on the masters.
+// ---------------------------------------------------------------------------
+__global__ void k_mixed_update_cameras(double* __restrict__ cams64, float* __restrict__ cams32,
+                                       const float* __restrict__ inc_scaled, const float* __restrict__ pose_scaling,
+                                       int n_cams) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cams) return;
+  double inc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) inc[i] = double(inc_scaled[9 * c + i]) * double(pose_scaling[9 * c + i]);
+  double* cam = cams64 + 10 * c;
+  retract_camera<double>(cam, inc);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) cams32[10 * c + i] = float(cam[i]);
+}
+
+__global__ void k_mixed_update_landmarks(double* __restrict__ lms64, float* __restrict__ lms32,
+                                         const float* __restrict__ lm_inc, int64_t n) {
+  const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const double v = lms64[i] + double(lm_inc[i]);
+  lms64[i] = v;
+  lms32[i] = float(v);
+}
+
+__global__ void k_mixed_round(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i < n) dst[i] = float(src[i]);
 }
 
 // ===========================================================================

@@ -448,9 +448,7 @@ __global__ __launch_bounds__(256) void k_bs_landmark_big(Params<S> p, int lm_beg
     const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) && is_finite(acc) &&
                      is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) && is_finite(p.lms[3 * s + 2]);
     if (!fin) atomicOr(p.fail_flag, 2);
-    p.lms[3 * s + 0] += inc[0] * p.jl_scale[3 * s + 0];
-    p.lms[3 * s + 1] += inc[1] * p.jl_scale[3 * s + 1];
-    p.lms[3 * s + 2] += inc[2] * p.jl_scale[3 * s + 2];
+    apply_landmark_increment(p, s, inc);
   }
 }
 

@@ -162,8 +162,8 @@ template <class S>
 class Solver final : public rba_solver {
  public:
   Solver(int device, int n_cams, int n_lms, const int64_t* lm_off, const int32_t* obs_cam,
-         const S* obs_xy, const rba_options& opt)
-      : device_(device), n_cams_(n_cams), n_lms_(n_lms), opt_(opt) {
+         const S* obs_xy, const rba_options& opt, const double* obs_xy64 = nullptr)
+      : device_(device), n_cams_(n_cams), n_lms_(n_lms), opt_(opt), mixed_(obs_xy64 != nullptr) {
     // input validation first: nothing to release if it throws
     for (int l = 0; l < n_lms; ++l) {
       const int64_t k = lm_off[l + 1] - lm_off[l];
@@ -179,14 +179,14 @@ class Solver final : public rba_solver {
       }
     }
     try {
-      construct(lm_off, obs_cam, obs_xy);
+      construct(lm_off, obs_cam, obs_xy, obs_xy64);
     } catch (...) {
       release_resources();  // the destructor does not run for a throwing constructor
       throw;
     }
   }
 
-  void construct(const int64_t* lm_off, const int32_t* obs_cam, const S* obs_xy) {
+  void construct(const int64_t* lm_off, const int32_t* obs_cam, const S* obs_xy, const double* obs_xy64) {
     const int n_cams = n_cams_, n_lms = n_lms_;
     HIP_CHECK(hipSetDevice(device_));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -228,6 +228,7 @@ class Solver final : public rba_solver {
     std::vector<int64_t> lm_obs(n_lms + 1), lm_blk(n_lms + 1);
     std::vector<int> s_obs_cam(n_obs_), s_obs_lm(n_obs_);
     std::vector<S> s_obs_xy(2 * size_t(n_obs_));
+    std::vector<double> s_obs_xy64(mixed_ ? 2 * size_t(n_obs_) : 0);
     int64_t o = 0, blk = 0;
     int kmax = 0;
     hx_bytes_ = 0;
@@ -246,6 +247,10 @@ class Solver final : public rba_solver {
         s_obs_lm[o] = s;
         s_obs_xy[2 * o] = obs_xy[2 * src];
         s_obs_xy[2 * o + 1] = obs_xy[2 * src + 1];
+        if (mixed_) {
+          s_obs_xy64[2 * o] = obs_xy64[2 * src];
+          s_obs_xy64[2 * o + 1] = obs_xy64[2 * src + 1];
+        }
         ++o;
       }
       const int64_t elems = int64_t(2 * k) * (9 * k);
@@ -399,6 +404,18 @@ class Solver final : public rba_solver {
     d_lms_.alloc(3 * size_t(n_lms));
     d_cams_bak_.alloc(10 * size_t(n_cams));
     d_lms_bak_.alloc(3 * size_t(n_lms));
+    if (mixed_) {
+      // RBA_MIXED: double master state + double observations for the cost; float everywhere else
+      if (sc_) throw HipError{"RBA_MIXED is implemented for the SQUARE_ROOT solver", RBA_ERR_UNSUPPORTED};
+      d_obs_xy64_.alloc(2 * size_t(n_obs_));
+      d_obs_xy64_.upload(s_obs_xy64.data(), 2 * size_t(n_obs_), stream_);
+      d_cams64_.alloc(10 * size_t(n_cams));
+      d_lms64_.alloc(3 * size_t(n_lms));
+      d_cams64_bak_.alloc(10 * size_t(n_cams));
+      d_lms64_bak_.alloc(3 * size_t(n_lms));
+      d_lm_inc_.alloc(3 * size_t(n_lms));
+      HIP_CHECK(hipStreamSynchronize(stream_));  // s_obs_xy64 is a local
+    }
     if (sc_ && opt_.preconditioner_type != 1)
       throw HipError{"SCHUR_COMPLEMENT solver: only the SCHUR_JACOBI preconditioner is implemented",
                      RBA_ERR_UNSUPPORTED};
@@ -547,6 +564,7 @@ class Solver final : public rba_solver {
     prm_.implicit = opt_.implicit_q ? 1 : 0;
     prm_.cams = d_cams_.get();
     prm_.lms = d_lms_.get();
+    prm_.lm_inc = mixed_ ? d_lm_inc_.get() : nullptr;
     prm_.A = d_A_.get();
     prm_.top0 = d_top0_.get();
     prm_.topd = d_topd_.get();
@@ -571,6 +589,20 @@ class Solver final : public rba_solver {
     prm_.want_sdiag = (prm_.jacobi && ex_ready_) ? 1 : 0;
     prm_.huber = S(opt_.huber_parameter);
     prm_.eps = opt_.jacobi_scaling_eps > 0 ? S(opt_.jacobi_scaling_eps) : rba::Eps<S>::eps_sqrt;
+    if (mixed_) {
+      // what k_compute_error<double> reads: topology, double observations, the double master state
+      prm64_ = rba::Params<double>{};
+      prm64_.n_cams = n_cams;
+      prm64_.n_lms = n_lms;
+      prm64_.obs_cam = prm_.obs_cam;
+      prm64_.obs_lm = prm_.obs_lm;
+      prm64_.obs_xy = d_obs_xy64_.get();
+      prm64_.cams = d_cams64_.get();
+      prm64_.lms = d_lms64_.get();
+      prm64_.robust_norm = opt_.robust_norm;
+      prm64_.valid_only = opt_.use_valid_projections_only;
+      prm64_.huber = opt_.huber_parameter;
+    }
     if (sc_) {
       scp_.n_cams = n_cams;
       scp_.n_lms = n_lms;
@@ -1000,6 +1032,18 @@ class Solver final : public rba_solver {
   // ---- state ------------------------------------------------------------------
   void set_state(const void* cams, const void* lms) override {
     use_device();
+    if (mixed_) {
+      // RBA_MIXED: the state crosses the boundary in double; the float state is its rounding
+      const double* l = static_cast<const double*>(lms);
+      std::vector<double> sorted(3 * size_t(n_lms_));
+      for (int s = 0; s < n_lms_; ++s)
+        for (int c = 0; c < 3; ++c) sorted[3 * size_t(s) + c] = l[3 * size_t(perm_[s]) + c];
+      d_cams64_.upload(static_cast<const double*>(cams), 10 * size_t(n_cams_), stream_);
+      d_lms64_.upload(sorted.data(), sorted.size(), stream_);
+      round_masters();
+      sync();
+      return;
+    }
     const S* l = static_cast<const S*>(lms);
     std::vector<S> sorted(3 * size_t(n_lms_));
     for (int s = 0; s < n_lms_; ++s)
@@ -1010,6 +1054,16 @@ class Solver final : public rba_solver {
   }
   void get_state(void* cams, void* lms) override {
     use_device();
+    if (mixed_) {
+      std::vector<double> sorted(3 * size_t(n_lms_));
+      d_cams64_.download(static_cast<double*>(cams), 10 * size_t(n_cams_), stream_);
+      d_lms64_.download(sorted.data(), sorted.size(), stream_);
+      sync();
+      double* l = static_cast<double*>(lms);
+      for (int s = 0; s < n_lms_; ++s)
+        for (int c = 0; c < 3; ++c) l[3 * size_t(perm_[s]) + c] = sorted[3 * size_t(s) + c];
+      return;
+    }
     std::vector<S> sorted(3 * size_t(n_lms_));
     d_cams_.download(static_cast<S*>(cams), 10 * size_t(n_cams_), stream_);
     d_lms_.download(sorted.data(), sorted.size(), stream_);
@@ -1024,6 +1078,20 @@ class Solver final : public rba_solver {
                              hipMemcpyDeviceToDevice, stream_));
     HIP_CHECK(hipMemcpyAsync(d_lms_bak_.get(), d_lms_.get(), d_lms_.size() * sizeof(S),
                              hipMemcpyDeviceToDevice, stream_));
+    if (mixed_) {
+      HIP_CHECK(hipMemcpyAsync(d_cams64_bak_.get(), d_cams64_.get(), d_cams64_.size() * sizeof(double),
+                               hipMemcpyDeviceToDevice, stream_));
+      HIP_CHECK(hipMemcpyAsync(d_lms64_bak_.get(), d_lms64_.get(), d_lms64_.size() * sizeof(double),
+                               hipMemcpyDeviceToDevice, stream_));
+    }
+  }
+  // float state = rounding of the double masters (RBA_MIXED)
+  void round_masters() {
+    const int64_t nc = 10 * int64_t(n_cams_), nl = 3 * int64_t(n_lms_);
+    hipLaunchKernelGGL(rba::k_mixed_round, dim3(unsigned((nc + 255) / 256)), dim3(256), 0, stream_, d_cams64_.get(),
+                       reinterpret_cast<float*>(d_cams_.get()), nc);
+    hipLaunchKernelGGL(rba::k_mixed_round, dim3(unsigned((nl + 255) / 256)), dim3(256), 0, stream_, d_lms64_.get(),
+                       reinterpret_cast<float*>(d_lms_.get()), nl);
   }
   void restore() override {
     use_device();
@@ -1031,6 +1099,12 @@ class Solver final : public rba_solver {
                              hipMemcpyDeviceToDevice, stream_));
     HIP_CHECK(hipMemcpyAsync(d_lms_.get(), d_lms_bak_.get(), d_lms_.size() * sizeof(S),
                              hipMemcpyDeviceToDevice, stream_));
+    if (mixed_) {
+      HIP_CHECK(hipMemcpyAsync(d_cams64_.get(), d_cams64_bak_.get(), d_cams64_.size() * sizeof(double),
+                               hipMemcpyDeviceToDevice, stream_));
+      HIP_CHECK(hipMemcpyAsync(d_lms64_.get(), d_lms64_bak_.get(), d_lms64_.size() * sizeof(double),
+                               hipMemcpyDeviceToDevice, stream_));
+    }
   }
 
   // ---- compute_error ----------------------------------------------------------
@@ -1038,8 +1112,12 @@ class Solver final : public rba_solver {
     use_device();
     time_begin();
     const int blocks = int(std::min<int64_t>(kReduceBlocks, (n_obs_ + 255) / 256));
-    hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, stream_, prm_,
-                       n_obs_, d_partials_.get());
+    if (mixed_)
+      hipLaunchKernelGGL((rba::k_compute_error<double>), dim3(blocks), dim3(256), 0, stream_, prm64_, n_obs_,
+                         d_partials_.get());
+    else
+      hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, stream_, prm_,
+                         n_obs_, d_partials_.get());
     double* red = d_partials_.get() + size_t(kReduceBlocks) * 8;
     hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, stream_,
                        d_partials_.get(), int64_t(blocks), red);
@@ -1764,10 +1842,23 @@ class Solver final : public rba_solver {
       return RBA_NUMERICAL_FAILURE;
     }
     *l_diff_out = double(S(l_diff));
+    if (mixed_) {
+      // the float landmark increments go to the double masters; the float state is re-rounded from them
+      const int64_t nl = 3 * int64_t(n_lms_);
+      hipLaunchKernelGGL(rba::k_mixed_update_landmarks, dim3(unsigned((nl + 255) / 256)), dim3(256), 0, stream_,
+                         d_lms64_.get(), reinterpret_cast<float*>(d_lms_.get()),
+                         reinterpret_cast<const float*>(d_lm_inc_.get()), nl);
+    }
     if (update_cams) {
       time_begin();
-      hipLaunchKernelGGL((rba::k_update_cameras<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0,
-                         stream_, prm_, d_inc_.get());
+      if (mixed_)
+        hipLaunchKernelGGL(rba::k_mixed_update_cameras, dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_,
+                           d_cams64_.get(), reinterpret_cast<float*>(d_cams_.get()),
+                           reinterpret_cast<const float*>(d_inc_.get()),
+                           reinterpret_cast<const float*>(prm_.pose_scaling), n_cams_);
+      else
+        hipLaunchKernelGGL((rba::k_update_cameras<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0,
+                           stream_, prm_, d_inc_.get());
       timings_.update_cameras_time = time_end();
     }
     return RBA_OK;
@@ -2121,6 +2212,11 @@ class Solver final : public rba_solver {
   DevBuf<int64_t> d_big_off_;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
+  // RBA_MIXED (S = float): double master state, double observations, float landmark increments
+  bool mixed_ = false;
+  DevBuf<double> d_obs_xy64_, d_cams64_, d_lms64_, d_cams64_bak_, d_lms64_bak_;
+  DevBuf<S> d_lm_inc_;
+  rba::Params<double> prm64_{};
   DevBuf<S> d_A_, d_top0_, d_topd_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;
   DevBuf<S> d_jp_diag2_, d_pose_scaling_, d_mid_, d_bb_, d_inv_;
   DevBuf<S> d_x_, d_r_, d_p_, d_z_, d_q_, d_tmp_, d_inc_, d_vin_, d_pw_t_, d_pw_e_;
@@ -2326,8 +2422,13 @@ int rba_create(int dtype, int device, int32_t n_cams, int32_t n_lms,
     else if (dtype == RBA_F64)
       *out = new Solver<double>(device, n_cams, n_lms, lm_obs_offsets, obs_cam_idx,
                                 static_cast<const double*>(obs_xy), *options);
-    else {
-      g_last_error = "dtype must be RBA_F32 or RBA_F64";
+    else if (dtype == RBA_MIXED) {
+      const double* xy64 = static_cast<const double*>(obs_xy);
+      std::vector<float> xy32(size_t(2) * size_t(lm_obs_offsets[n_lms]));
+      for (size_t i = 0; i < xy32.size(); ++i) xy32[i] = float(xy64[i]);
+      *out = new Solver<float>(device, n_cams, n_lms, lm_obs_offsets, obs_cam_idx, xy32.data(), *options, xy64);
+    } else {
+      g_last_error = "dtype must be RBA_F32, RBA_F64 or RBA_MIXED";
       return RBA_ERR_INVALID_ARGUMENT;
     }
     return RBA_OK;

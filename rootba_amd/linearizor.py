@@ -27,9 +27,13 @@ class LinearizorHIP:
 
     def __init__(self, prob: BalProblem, dtype=np.float32, options: L.RbaOptions | None = None,
                  device: int = 0):
-        self.dtype = np.dtype(dtype)
+        # "mixed" (RBA_MIXED): double state / observations / costs, float linear algebra; camera-sized
+        # vectors cross the boundary as float32, the state as float64
+        self.mixed = isinstance(dtype, str) and dtype == "mixed"
+        self.dtype = np.dtype(np.float32 if self.mixed else dtype)
+        self.state_dtype = np.dtype(np.float64) if self.mixed else self.dtype
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
-            raise ValueError("dtype must be float32 or float64")
+            raise ValueError("dtype must be float32, float64 or 'mixed'")
         self.lib = L.lib()
         if L.device_count() <= 0:
             raise RuntimeError("LinearizorHIP needs a HIP device (no CPU fallback): " + L.last_error())
@@ -37,10 +41,11 @@ class LinearizorHIP:
         self.n_cams, self.n_lms, self.n_obs = prob.n_cams, prob.n_lms, prob.n_obs
         off = np.ascontiguousarray(prob.lm_obs_offsets, dtype=np.int64)
         cam = np.ascontiguousarray(prob.obs_cam_idx, dtype=np.int32)
-        xy = np.ascontiguousarray(prob.obs_xy, dtype=self.dtype)
+        xy = np.ascontiguousarray(prob.obs_xy, dtype=self.state_dtype)
         self.h = C.c_void_p()
         L.check(self.lib.rba_create(
-            C.c_int(L.RBA_F32 if self.dtype == np.float32 else L.RBA_F64), C.c_int(device),
+            C.c_int(L.RBA_MIXED if self.mixed else L.RBA_F32 if self.dtype == np.float32 else L.RBA_F64),
+            C.c_int(device),
             C.c_int32(self.n_cams), C.c_int32(self.n_lms), _ptr(off), _ptr(cam), _ptr(xy),
             C.byref(self.options), C.byref(self.h)), "rba_create")
         self.set_state(prob.cams, prob.lms)
@@ -115,11 +120,15 @@ class LinearizorHIP:
 
     # -- BalProblem state -----------------------------------------------------------
     def set_state(self, cams, lms):
-        c, l = self._in(cams, 10 * self.n_cams), self._in(lms, 3 * self.n_lms)
+        c = np.ascontiguousarray(cams, dtype=self.state_dtype).ravel()
+        l = np.ascontiguousarray(lms, dtype=self.state_dtype).ravel()
+        if c.size != 10 * self.n_cams or l.size != 3 * self.n_lms:
+            raise ValueError("state arrays have the wrong size")
         L.check(self.lib.rba_set_state(self.h, _ptr(c), _ptr(l)), "rba_set_state")
 
     def get_state(self):
-        c, l = self._vec(10 * self.n_cams), self._vec(3 * self.n_lms)
+        c = np.zeros(10 * self.n_cams, dtype=self.state_dtype)
+        l = np.zeros(3 * self.n_lms, dtype=self.state_dtype)
         L.check(self.lib.rba_get_state(self.h, _ptr(c), _ptr(l)), "rba_get_state")
         return c.reshape(-1, 10), l.reshape(-1, 3)
 
