@@ -1533,7 +1533,8 @@ __device__ __forceinline__ void hx_tile_load(const Params<S>& p, const ImplicitT
 // (row 2i takes components 0,2,4,6,8, row 2i+1 takes 1,3,5,7).
 // ---------------------------------------------------------------------------
 template <class S, int P2>
-__device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int cam, int lane, double* ylds, int dbg) {
+__device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int cam, int lane, double* ylds, int dbg,
+                                                    int cam_lo, int win, S* __restrict__ y) {
   const int r = lane & (P2 - 1);
   const bool act = cam >= 0;
   if (dbg == 2) {
@@ -1560,7 +1561,12 @@ __device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int 
   u -= d.t1 * seg_sum<S, P2>(v1 * u) * v1;
   u -= d.t0 * seg_sum<S, P2>(v0 * u) * v0;
   const int par = lane & 1;
-  double* yc = ylds + 9 * (act ? cam : 0) + par;
+  // cameras outside the workgroup's window [cam_lo, cam_lo + win) go straight to y (rare: wrap-around
+  // and long tracks when the landmarks are sorted by camera; never when the window holds every camera)
+  const int rel = (act ? cam : cam_lo) - cam_lo;
+  const bool inside = unsigned(rel) < unsigned(win);
+  double* yc = ylds + 9 * (inside ? rel : 0) + par;
+  S* yg = y + 9 * (act ? cam : 0) + par;
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     // both rows of the observation receive the pair sums of components 2q and 2q+1; each adds one
@@ -1572,66 +1578,108 @@ __device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int 
       const S so = vo + dpp_mov0<0xb1>(vo);
       mine = par ? so : se;
     }
-    if (act && (q < 4 || par == 0) && (dbg == 0 || mine == S(1.2345e30))) lds_atomic_add(yc + 2 * q, double(mine));
+    if (act && (q < 4 || par == 0) && (dbg == 0 || mine == S(1.2345e30))) {
+      if (inside)
+        lds_atomic_add(yc + 2 * q, double(mine));
+      else
+        atomic_add(yg + 2 * q, mine);
+    }
   }
 }
 
+// One persistent workgroup's share. With the landmarks sorted by first camera inside each track-length
+// class, the tiles form a few RUNS of ascending first camera; workgroup g takes, from every run, the tiles
+// whose first camera lies in its camera range, so everything it adds lands in a short camera interval
+// starting at `cam_lo` (tracks are local; wrap-around and very long tracks are the exception and go to y
+// directly). When all cameras fit the LDS window the ranges simply split the tiles evenly.
+constexpr int kHxMaxRuns = 16;
+struct HxChunk {
+  int cam_lo, n_ranges;
+  int tile_begin[kHxMaxRuns], tile_end[kHxMaxRuns];
+};
+
+// v-th tile of a chunk (v clamped to the chunk's last tile)
+__device__ __forceinline__ int hx_chunk_tile(const HxChunk& ch, int v, int n_total) {
+  v = min(v, n_total - 1);
+  int T = ch.tile_begin[0];
+  for (int r = 0; r < ch.n_ranges; ++r) {
+    const int len = ch.tile_end[r] - ch.tile_begin[r];
+    if (v < len) {
+      T = ch.tile_begin[r] + v;
+      break;
+    }
+    v -= len;
+  }
+  return T;
+}
+
 template <class S>
-__global__ __launch_bounds__(1024) void k_hx_implicit_lds(Params<S> p, ImplicitTiles it, const S* __restrict__ x,
-                                                          S* __restrict__ y, const int* __restrict__ done_flag) {
+__global__ __launch_bounds__(1024) void k_hx_implicit_lds(Params<S> p, ImplicitTiles it,
+                                                          const HxChunk* __restrict__ chunks, int win,
+                                                          const S* __restrict__ x, S* __restrict__ y,
+                                                          const int* __restrict__ done_flag) {
   extern __shared__ __align__(16) unsigned char hx_lds_raw[];
+  __shared__ HxChunk ch;
   double* ylds = reinterpret_cast<double*>(hx_lds_raw);
   if (done_flag && *done_flag) return;  // uniform over the grid: nothing is added after the PCG has terminated
-  const int nvec = 9 * p.n_cams;
-  for (int i = threadIdx.x; i < nvec; i += 1024) ylds[i] = 0.0;
+  if (threadIdx.x < sizeof(HxChunk) / sizeof(int))
+    reinterpret_cast<int*>(&ch)[threadIdx.x] = reinterpret_cast<const int*>(chunks + blockIdx.x)[threadIdx.x];
+  const int nwin = 9 * win;
+  for (int i = threadIdx.x; i < nwin; i += 1024) ylds[i] = 0.0;
   __syncthreads();
+  const int cam_lo = ch.cam_lo;
+  int nV = 0;
+  for (int r = 0; r < ch.n_ranges; ++r) nV += ch.tile_end[r] - ch.tile_begin[r];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nT = it.tile_begin[5];
-  const int W = gridDim.x * 16;
-  const int last = nT - 1;
-  int TA = blockIdx.x * 16 + wave;
-  if (TA < nT) {
-    int TB = TA + W;
+  constexpr int W = 16;
+  int vA = wave;
+  if (vA < nV) {
+    int vB = vA + W;
+    int TA = hx_chunk_tile(ch, vA, nV), TB = hx_chunk_tile(ch, vB, nV);
     int camA = p.CT[size_t(TA) * 64 + lane], rowA = p.RT[size_t(TA) * 64 + lane];
-    int camB = p.CT[size_t(min(TB, last)) * 64 + lane], rowB = p.RT[size_t(min(TB, last)) * 64 + lane];
+    int camB = p.CT[size_t(TB) * 64 + lane], rowB = p.RT[size_t(TB) * 64 + lane];
     HxTileData<S> dA, dB;
     hx_tile_load(p, it, TA, camA, rowA, lane, x, dA);
     auto compute = [&](int T, const HxTileData<S>& d, int cam) {
       switch (hx_tile_class(it, T)) {
-        case 0: hx_tile_compute_lds<S, 4>(d, cam, lane, ylds, p.hx_debug); break;
-        case 1: hx_tile_compute_lds<S, 8>(d, cam, lane, ylds, p.hx_debug); break;
-        case 2: hx_tile_compute_lds<S, 16>(d, cam, lane, ylds, p.hx_debug); break;
-        case 3: hx_tile_compute_lds<S, 32>(d, cam, lane, ylds, p.hx_debug); break;
-        default: hx_tile_compute_lds<S, 64>(d, cam, lane, ylds, p.hx_debug); break;
+        case 0: hx_tile_compute_lds<S, 4>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y); break;
+        case 1: hx_tile_compute_lds<S, 8>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y); break;
+        case 2: hx_tile_compute_lds<S, 16>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y); break;
+        case 3: hx_tile_compute_lds<S, 32>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y); break;
+        default: hx_tile_compute_lds<S, 64>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y); break;
       }
     };
     for (;;) {
-      const int TC = TB + W;
-      const int camC = p.CT[size_t(min(TC, last)) * 64 + lane], rowC = p.RT[size_t(min(TC, last)) * 64 + lane];
-      hx_tile_load(p, it, min(TB, last), camB, rowB, lane, x, dB);
+      const int vC = vB + W;
+      const int TC = hx_chunk_tile(ch, vC, nV);
+      const int camC = p.CT[size_t(TC) * 64 + lane], rowC = p.RT[size_t(TC) * 64 + lane];
+      hx_tile_load(p, it, TB, camB, rowB, lane, x, dB);
       compute(TA, dA, camA);
-      if (TB >= nT) break;
-      const int TD = TC + W;
-      const int camD = p.CT[size_t(min(TD, last)) * 64 + lane], rowD = p.RT[size_t(min(TD, last)) * 64 + lane];
-      hx_tile_load(p, it, min(TC, last), camC, rowC, lane, x, dA);
+      if (vB >= nV) break;
+      const int vD = vC + W;
+      const int TD = hx_chunk_tile(ch, vD, nV);
+      const int camD = p.CT[size_t(TD) * 64 + lane], rowD = p.RT[size_t(TD) * 64 + lane];
+      hx_tile_load(p, it, TC, camC, rowC, lane, x, dA);
       compute(TB, dB, camB);
-      if (TC >= nT) break;
+      if (vC >= nV) break;
       TA = TC;
       camA = camC;
+      vB = vD;
       TB = TD;
       camB = camD;
       rowB = rowD;
     }
   }
   __syncthreads();
-  // flush: every workgroup starts at its own offset so that the 256 copies do not hit the same
-  // addresses at the same moment
-  const int start = int((int64_t(blockIdx.x) * nvec) / gridDim.x);
-  for (int i = threadIdx.x; i < nvec; i += 1024) {
+  // flush (zeros are skipped: with camera-sorted landmarks a workgroup touches a small part of its window);
+  // every workgroup starts at its own offset so that copies of the same entries do not arrive together
+  const int start = int((int64_t(blockIdx.x) * nwin) / gridDim.x);
+  S* __restrict__ yw = y + 9 * cam_lo;
+  for (int i = threadIdx.x; i < nwin; i += 1024) {
     int j = i + start;
-    j = j >= nvec ? j - nvec : j;
+    j = j >= nwin ? j - nwin : j;
     const double v = ylds[j];
-    if (v != 0.0) atomic_add(y + j, S(v));
+    if (v != 0.0) atomic_add(yw + j, S(v));
   }
 }
 

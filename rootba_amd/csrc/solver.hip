@@ -214,15 +214,32 @@ class Solver final : public rba_solver {
     // ---- sort landmarks by number of observations (stable) ----------------
     perm_.resize(n_lms);
     std::iota(perm_.begin(), perm_.end(), 0);
-    // NOTE: a secondary sort by first camera was tried and REJECTED: neighbouring lanes
-    // then scatter-add to the same addresses, the atomics serialise, and H*x got 20 %
-    // slower (dense 538 -> 660 us on venice). The input order spreads cameras evenly.
-    int sort_by_camera = 0;
+    // (With device-scope atomics a secondary sort by first camera is a loss: neighbouring lanes then
+    //  scatter-add to the same addresses and the atomics serialise - dense blocks 538 -> 660 us, one tile per
+    //  wave from the factors 238 -> 397 us on venice - so the dense-block configuration keeps the input order.)
+    // Secondary key: first camera. With the LDS-private products (k_hx_implicit_lds) neighbouring lanes adding to
+    // the same cameras cost nothing, the camera windows of large problems need this locality, and the
+    // camera-major gathers get slightly faster (venice: stage 1 440 -> 410 us). RBA_SORT_BY_CAMERA=0 keeps the
+    // input order inside a track length.
+    int sort_by_camera = opt_.implicit_q ? 1 : 0;
     if (const char* ev = std::getenv("RBA_SORT_BY_CAMERA")) sort_by_camera = std::atoi(ev);
+    // track-length classes: the common refinement of the wave-tile classes (k <= 2, 4, 8, 16, 32, 64, 112) and
+    // of the dense-block classes (k <= 7, 14, 28, 56, 112): every class range the kernels use stays contiguous
+    auto k_class = [](int64_t k) {
+      static const int bounds[] = {2, 4, 7, 8, 14, 16, 28, 32, 56, 64, 112};
+      int c = 0;
+      for (int b : bounds) c += k > b ? 1 : 0;
+      return c;
+    };
     std::stable_sort(perm_.begin(), perm_.end(), [&](int a, int b) {
       const int64_t ka = lm_off[a + 1] - lm_off[a], kb = lm_off[b + 1] - lm_off[b];
-      if (ka != kb) return ka < kb;
-      return sort_by_camera ? obs_cam[lm_off[a]] < obs_cam[lm_off[b]] : false;
+      if (!sort_by_camera) return ka < kb;
+      // by class, then by first camera (then by k: equal tracks next to each other)
+      const int ca = k_class(ka), cb = k_class(kb);
+      if (ca != cb) return ca < cb;
+      const int fa = obs_cam[lm_off[a]], fb = obs_cam[lm_off[b]];
+      if (fa != fb) return fa < fb;
+      return ka < kb;
     });
     std::vector<int> lm_k(n_lms);
     std::vector<int64_t> lm_obs(n_lms + 1), lm_blk(n_lms + 1);
@@ -332,6 +349,83 @@ class Solver final : public rba_solver {
               tile_cam[size_t(lm_tile[s2]) * 64 + lm_lane0[s2] + rr] = s_obs_cam[lm_obs[s2] + rr / 2];
               tile_row[size_t(lm_tile[s2]) * 64 + lm_lane0[s2] + rr] = int(2 * lm_obs[s2] + rr);
             }
+    }
+    // persistent workgroups of k_hx_implicit_lds (kernels.hpp: HxChunk): camera ranges x tile runs
+    if (n_tiles_ > 0) {
+      const int G = std::max(1, std::min(n_cus_, (n_tiles_ + 15) / 16));
+      hx_win_ = std::min(n_cams, int(kHxLdsMaxBytes / (9 * sizeof(double))));
+      if (const char* ev = std::getenv("RBA_HX_WIN")) hx_win_ = std::max(1, std::min(hx_win_, std::atoi(ev)));  // tests
+      auto first_cam = [&](int T) { return tile_cam[size_t(T) * 64]; };
+      // runs of ascending first camera
+      std::vector<int> run_begin{0};
+      for (int T = 1; T < n_tiles_; ++T)
+        if (first_cam(T) < first_cam(T - 1)) run_begin.push_back(T);
+      run_begin.push_back(n_tiles_);
+      const int n_runs = int(run_begin.size()) - 1;
+      std::vector<rba::HxChunk> chunks(G);
+      const bool windows = hx_win_ < n_cams;
+      if (!windows || n_runs > rba::kHxMaxRuns) {
+        // every camera fits (or the order has no camera locality): even split of the tiles, window from 0
+        for (int g = 0; g < G; ++g) {
+          rba::HxChunk c{};
+          c.cam_lo = 0;
+          c.n_ranges = 1;
+          c.tile_begin[0] = int(int64_t(n_tiles_) * g / G);
+          c.tile_end[0] = int(int64_t(n_tiles_) * (g + 1) / G);
+          chunks[g] = c;
+        }
+      } else {
+        // camera boundaries with equal tile counts, then per run the tiles whose first camera is in range
+        std::vector<int64_t> cnt(size_t(n_cams) + 1, 0);
+        for (int T = 0; T < n_tiles_; ++T) ++cnt[size_t(first_cam(T)) + 1];
+        for (int c = 0; c < n_cams; ++c) cnt[size_t(c) + 1] += cnt[c];
+        std::vector<int> bound(size_t(G) + 1, n_cams);
+        bound[0] = 0;
+        for (int g = 1; g < G; ++g) {
+          const int64_t target = int64_t(n_tiles_) * g / G;
+          bound[g] = int(std::lower_bound(cnt.begin(), cnt.end(), target) - cnt.begin());
+          bound[g] = std::max(bound[g - 1], std::min(bound[g], n_cams));
+        }
+        for (int g = 0; g < G; ++g) {
+          rba::HxChunk c{};
+          c.cam_lo = std::max(0, std::min(bound[g], n_cams - hx_win_));
+          c.n_ranges = 0;
+          for (int r = 0; r < n_runs; ++r) {
+            auto lb = [&](int cam) {  // first tile of run r with first camera >= cam
+              int lo = run_begin[r], hi = run_begin[r + 1];
+              while (lo < hi) {
+                const int mid = (lo + hi) / 2;
+                if (first_cam(mid) < cam) lo = mid + 1; else hi = mid;
+              }
+              return lo;
+            };
+            const int tb = lb(bound[g]), te = lb(bound[g + 1]);
+            if (te > tb) {
+              c.tile_begin[c.n_ranges] = tb;
+              c.tile_end[c.n_ranges] = te;
+              ++c.n_ranges;
+            }
+          }
+          chunks[g] = c;
+        }
+      }
+      // share of the block rows that land inside their workgroup's window
+      int64_t covered = 0, total = 0;
+      for (const auto& c : chunks)
+        for (int r = 0; r < c.n_ranges; ++r)
+          for (size_t q = size_t(c.tile_begin[r]) * 64; q < size_t(c.tile_end[r]) * 64; ++q)
+            if (tile_cam[q] >= 0) {
+              ++total;
+              covered += unsigned(tile_cam[q] - c.cam_lo) < unsigned(hx_win_) ? 1 : 0;
+            }
+      hx_coverage_ = total > 0 ? double(covered) / double(total) : 1.0;
+      d_hx_chunks_.alloc(chunks.size());
+      d_hx_chunks_.upload(chunks.data(), chunks.size(), stream_);
+      HIP_CHECK(hipStreamSynchronize(stream_));  // `chunks` is a local
+      n_hx_chunks_ = G;
+      if (std::getenv("RBA_VERBOSE"))
+        std::fprintf(stderr, "[rootba_hip] H*x: %d persistent workgroups, %d tile runs, window %d of %d cameras, %.2f %% of "
+                     "the block rows inside their window\n", G, n_runs, hx_win_, n_cams, 100.0 * hx_coverage_);
     }
     // everything beyond k = 112: one workgroup per landmark (kernels_big.hpp)
     big_begin_ = begin;
@@ -1446,16 +1540,16 @@ class Solver final : public rba_solver {
       }
       it.tile_begin[5] = n_tiles_;
       const int wgs = (n_tiles_ + 3) / 4;
-      const size_t ylds_bytes = size_t(nvec_) * sizeof(double);  // double accumulators (ds_add_f64)
-      if (hx_lds_ && ylds_bytes <= kHxLdsMaxBytes && (hx_lds_ == 2 || n_tiles_ >= 64 * n_cus_)) {
-        // workgroup-private y in LDS, one persistent 1024-thread workgroup per CU
+      const size_t ylds_bytes = size_t(9) * hx_win_ * sizeof(double);  // double accumulators (ds_add_f64)
+      if (hx_lds_ && (hx_lds_ == 2 || (n_tiles_ >= 16 * n_cus_ && hx_coverage_ >= 0.9))) {
+        // workgroup-private window of y in LDS, one persistent 1024-thread workgroup per CU
         if (!hx_lds_attr_set_) {
           HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_implicit_lds<S>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(kHxLdsMaxBytes)));
           hx_lds_attr_set_ = true;
         }
-        hipLaunchKernelGGL((rba::k_hx_implicit_lds<S>), dim3(std::min(n_cus_, (n_tiles_ + 15) / 16)), dim3(1024), ylds_bytes, stream_, prm_, it, x, y,
-                           done_flag);
+        hipLaunchKernelGGL((rba::k_hx_implicit_lds<S>), dim3(n_hx_chunks_), dim3(1024), ylds_bytes, stream_, prm_, it,
+                           d_hx_chunks_.get(), hx_win_, x, y, done_flag);
       } else
         hipLaunchKernelGGL((rba::k_hx_implicit<S>), dim3(wgs), dim3(256), 0, stream_, prm_, it, x, y, done_flag);
     }
@@ -2239,6 +2333,9 @@ class Solver final : public rba_solver {
   int hx_lds_ = 1;            // RBA_HX_LDS=0: never use the LDS-private y copy (k_hx_implicit_lds); 2: whenever y fits
                               // (default 1: when it fits and every wave gets at least four tiles)
   bool hx_lds_attr_set_ = false;
+  DevBuf<rba::HxChunk> d_hx_chunks_;
+  int n_hx_chunks_ = 0, hx_win_ = 0;
+  double hx_coverage_ = 1.0;  // share of the tiled block rows whose camera lies inside its workgroup's LDS window
   static constexpr size_t kHxLdsMaxBytes = 152 * 1024;  // of the CU's 160 KB
   int n_cus_ = 256;
   int y_rep_ = 1;             // RBA_Y_REPLICAS=n: privatised scatter targets of the matrix-free products
