@@ -86,7 +86,8 @@ typedef struct rba_options {
   double initial_vee;
   double vee_factor;
   int optimized_cost;             /* 0 ERROR, 1 ERROR_VALID, 2 ERROR_VALID_AVG    */
-  int staged_execution;           /* accepted; execution is always staged         */
+  int staged_execution;           /* 1 (default): stage timers only. 0: the reference's unstaged sub-stage timers
+                                     are measured as well (rba_get_substage_timings); same kernels either way */
   int implicit_q;                 /* matrix-free products H*x: 1 (default) evaluated from the factors
                                      (Jp, Householder vectors, damping rotations); the dense blocks of
                                      landmarks with <= 112 observations are then never written.
@@ -133,6 +134,33 @@ typedef struct rba_iter_timings {
                           1 = all, 0 = none) is bracketed by HIP events               */
   int hx_calls;        /* number of launches hx_time sums over                        */
 } rba_iter_timings;
+
+/* Sub-stage timers of the reference's UNSTAGED execution (`staged_execution = false`,
+ * src/rootba/solver/linearizor_qr.cpp:94-112 and 166-187; IterationSummary fields of the same names,
+ * solver_summary.hpp:183-204). With rba_options.staged_execution = 0 the kernel groups of stage 1 and
+ * stage 2 are separated by HIP events and their times are accumulated here per LM iteration (reset with
+ * the other timings); with staged_execution = 1 (default) all fields stay 0, as in the reference.
+ * The kernels are the same in both modes; where this implementation fuses what the reference times
+ * separately the mapping is:
+ *   jacobian_evaluation_time       geometry pass (linearize_problem)
+ *   scale_landmark_jacobian_time   camera-major Gram pass -> Jp_diag2, scaling vector (get_Jp_diag2; the Jl
+ *                                  column scaling itself is part of the QR kernels)
+ *   stage1_preconditioner_time     D G D scaling of the Gram blocks (get_Jp_T_Jp_blockdiag)
+ *   perform_qr_time                Jl column scaling + Householder QR kernels (scale_Jl_cols + perform_qr)
+ *   landmark_damping_time          the six damping rotations per landmark (set_landmark_damping)
+ *   scale_pose_jacobian_time       per-observation column pass: Jp column scaling, Q1^T Jp, rotated top
+ *                                  rows, b records (scale_Jp_cols + the per-column part of the damping)
+ *   stage2_preconditioner_and_gradient_time   camera-major pass: SCHUR_JACOBI blocks and b
+ *                                  (get_Q2TJp_T_Q2TJp_blockdiag + get_Q2TJp_T_Q2Tr, one fused pass) */
+typedef struct rba_substage_timings {
+  double jacobian_evaluation_time;
+  double scale_landmark_jacobian_time;
+  double stage1_preconditioner_time;
+  double perform_qr_time;
+  double landmark_damping_time;
+  double scale_pose_jacobian_time;
+  double stage2_preconditioner_and_gradient_time;
+} rba_substage_timings;
 
 /* One row of the LM log: subset of IterationSummary
  * (src/rootba/solver/solver_summary.hpp:99-204). */
@@ -255,6 +283,7 @@ int rba_lm_termination(rba_handle h, int* termination_out);
 int rba_synchronize(rba_handle h);
 
 int rba_get_timings(rba_handle h, rba_iter_timings* out);
+int rba_get_substage_timings(rba_handle h, rba_substage_timings* out);
 /* Profiling aid: streams the landmark-block storage once with 4-byte
  * (vec_width = 1) or 16-byte (vec_width = 4) loads and reports the bytes read —
  * a known byte count for calibrating rocprofv3's FETCH_SIZE on gfx950. */

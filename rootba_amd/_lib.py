@@ -77,6 +77,13 @@ class RbaIterTimings(C.Structure):
     ]
 
 
+class RbaSubstageTimings(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "jacobian_evaluation_time", "scale_landmark_jacobian_time", "stage1_preconditioner_time",
+        "perform_qr_time", "landmark_damping_time", "scale_pose_jacobian_time",
+        "stage2_preconditioner_and_gradient_time")]
+
+
 class RbaLmIteration(C.Structure):
     _fields_ = [
         ("iteration", C.c_int),
@@ -113,7 +120,7 @@ EXPORTS = [
     "rba_set_state", "rba_get_state", "rba_backup",
     "rba_restore", "rba_compute_error", "rba_linearize", "rba_solve", "rba_stage2",
     "rba_right_multiply", "rba_right_multiply_explicit", "rba_apply", "rba_back_substitute", "rba_optimize_lm", "rba_lm_begin", "rba_lm_step", "rba_lm_termination", "rba_synchronize",
-    "rba_get_timings", "rba_debug_read_blocks",
+    "rba_get_timings", "rba_get_substage_timings", "rba_debug_read_blocks",
     "rba_get_jl_col_scale", "rba_get_pose_scaling", "rba_get_landmark_R", "rba_get_problem_stats",
     "rba_get_byte_model",
 ]

@@ -168,6 +168,12 @@ inline std::vector<BaIteration> to_ba_iterations(const SolverSummary& summary) {
     r.step_solver_time = s.stage2_time_in_seconds + s.solve_reduced_system_time_in_seconds + s.back_substitution_time_in_seconds;
     r.residual_evaluation_time = s.residual_evaluation_time_in_seconds;
     r.stage1_time = s.stage1_time_in_seconds;
+    r.jacobian_evaluation_time = s.jacobian_evaluation_time_in_seconds;
+    r.scale_landmark_jacobian_time = s.scale_landmark_jacobian_time_in_seconds;
+    r.perform_qr_time = s.perform_qr_time_in_seconds;
+    r.scale_pose_jacobian_time = s.scale_pose_jacobian_time_in_seconds;
+    r.landmark_damping_time = s.landmark_damping_time_in_seconds;
+    r.compute_gradient_time = s.compute_gradient_time_in_seconds;
     r.compute_preconditioner_time = s.compute_preconditioner_time_in_seconds;
     r.stage2_time = s.stage2_time_in_seconds;
     r.solve_reduced_system_time = s.solve_reduced_system_time_in_seconds;

@@ -120,6 +120,10 @@ struct IterationSummary {  // subset of reference solver_summary.hpp:99-204
          stage2_time_in_seconds = 0, compute_preconditioner_time_in_seconds = 0,
          solve_reduced_system_time_in_seconds = 0, back_substitution_time_in_seconds = 0,
          residual_evaluation_time_in_seconds = 0;
+  // unstaged execution only (staged_execution = false; rba_substage_timings, include/rootba_hip.h)
+  double jacobian_evaluation_time_in_seconds = 0, scale_landmark_jacobian_time_in_seconds = 0,
+         perform_qr_time_in_seconds = 0, scale_pose_jacobian_time_in_seconds = 0,
+         landmark_damping_time_in_seconds = 0, compute_gradient_time_in_seconds = 0;
   uint64_t resident_memory_peak = 0;
 };
 struct SolverSummary {
@@ -257,6 +261,20 @@ void bundle_adjust_manual(BalProblem<Scalar>& bal_problem, const SolverOptions& 
     it.solve_reduced_system_time_in_seconds = row.pcg_time;
     it.back_substitution_time_in_seconds = row.backsub_time;
     it.residual_evaluation_time_in_seconds = row.residual_time;
+    if (!options.staged_execution) {
+      // the reference's unstaged timers (linearizor_qr.cpp:94-112, 166-187); the fused camera-major pass of
+      // stage 2 (preconditioner blocks + gradient) is filed under compute_preconditioner_time like the
+      // reference's SCHUR_JACOBI branch, compute_gradient_time stays 0
+      rba_substage_timings sub{};
+      check_rba(rba_get_substage_timings(lin->handle(), &sub), "rba_get_substage_timings");
+      it.jacobian_evaluation_time_in_seconds = sub.jacobian_evaluation_time;
+      it.scale_landmark_jacobian_time_in_seconds = sub.scale_landmark_jacobian_time;
+      it.perform_qr_time_in_seconds = sub.perform_qr_time;
+      it.scale_pose_jacobian_time_in_seconds = sub.scale_pose_jacobian_time;
+      it.landmark_damping_time_in_seconds = sub.landmark_damping_time;
+      it.compute_preconditioner_time_in_seconds +=
+          sub.stage1_preconditioner_time + sub.stage2_preconditioner_and_gradient_time;
+    }
     summary.iterations.push_back(it);
     if (options.verbosity_level >= 1) {
       if (row.iteration == 0) {

@@ -146,6 +146,7 @@ struct rba_solver {
   virtual void device_sync() = 0;
   virtual int64_t debug_read_A(int vec) = 0;
   virtual void get_timings(rba_iter_timings* out) = 0;
+  virtual void get_substage_timings(rba_substage_timings* out) = 0;
   virtual void get_jl_col_scale(void* out) = 0;
   virtual void get_pose_scaling(void* out) = 0;
   virtual void get_landmark_R(int damped, void* R6, void* q3) = 0;
@@ -993,6 +994,9 @@ class Solver final : public rba_solver {
     for (auto& e : hx_events_)
       if (e) (void)hipEventDestroy(e);
     hx_events_.clear();
+    for (auto& e : sub_events_)
+      if (e) (void)hipEventDestroy(e);
+    sub_events_.clear();
     for (auto& e : comm_events_)
       if (e) (void)hipEventDestroy(e);
     comm_events_.clear();
@@ -1232,12 +1236,14 @@ class Solver final : public rba_solver {
   int linearize(void* jp_diag2_out) override {
     use_device();
     time_begin();
+    sub_begin();
     d_fail_.zero(stream_);
     const bool staged = staged_;  // kernels_s1.hpp
     if (staged) {
       // geometry once per observation; Jp_diag2 falls out of the camera-major Gram pass
       hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256),
                          256 * 26 * sizeof(S), stream_, prm_, int64_t(n_obs_));
+      sub_mark(&sub_.jacobian_evaluation_time);  // linearize_problem()
       launch_cam_gram(prm_);
     } else {
       hipLaunchKernelGGL((rba::k_cam_jp_diag2<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
@@ -1247,7 +1253,9 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_pose_scaling<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                        d_jp_diag2_.get(), d_pose_scaling_.get(), prm_.eps, nvec_);
     if (staged) {
+      sub_mark(&sub_.scale_landmark_jacobian_time);  // get_Jp_diag2() (+ scale_Jl_cols, done inside the QR kernels)
       hipLaunchKernelGGL((rba::k_scale_gram<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_, prm_);
+      sub_mark(&sub_.stage1_preconditioner_time);  // get_Jp_T_Jp_blockdiag() (JACOBI; minuend of SCHUR_JACOBI)
       if (n_tiles_ > 0) {
         rba::ImplicitTiles it;
         for (int c = 0; c < 5; ++c) {
@@ -1269,6 +1277,7 @@ class Solver final : public rba_solver {
       if (n_big_ > 0)
         hipLaunchKernelGGL((rba::k_s1_qr_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
                            d_big_scratch_.get(), d_big_off_.get());
+      sub_mark(&sub_.perform_qr_time);  // perform_qr()
     } else if (sc_) {
       // LinearizorSC::linearize (linearizor_sc.cpp:70-99)
       hipLaunchKernelGGL((rba::k_sc_linearize_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0,
@@ -1299,6 +1308,7 @@ class Solver final : public rba_solver {
     HIP_CHECK(hipMemcpyAsync(&fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
     if (jp_diag2_out) d_jp_diag2_.download(static_cast<S*>(jp_diag2_out), nvec_, stream_);
     timings_.stage1_time = time_end();
+    sub_collect();
     pose_damping_ = S(0);
     landmark_damping_valid_ = false;
     ex_valid_ = false;
@@ -1321,8 +1331,10 @@ class Solver final : public rba_solver {
       landmark_damping_valid_ = true;
       return;
     }
+    sub_begin();
     hipLaunchKernelGGL((rba::k_stage2_landmark<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_, prm_,
                        lambda);
+    sub_mark(&sub_.landmark_damping_time);  // set_landmark_damping(): the six rotations per landmark
     if (staged_) {
       // column pass + rotation of the top rows, fused (kernels_s1.hpp), every observation
       hipLaunchKernelGGL((rba::k_s12_cols<S>),
@@ -1330,11 +1342,14 @@ class Solver final : public rba_solver {
                          dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTd) * sizeof(S), stream_,
                          prm_, int64_t(n_obs_), cols_pending_ ? 0 : 1);
       cols_pending_ = false;
+      // scale_Jp_cols() + the column part of the damping (top rows of Q^T Jp rotated, b records)
+      sub_mark(&sub_.scale_pose_jacobian_time);
     } else {
       hipLaunchKernelGGL((rba::k_stage2_cols<S>), dim3(unsigned((9 * int64_t(n_obs_) + 255) / 256)), dim3(256), 0,
                          stream_, prm_, int64_t(0), int64_t(n_obs_));
     }
     launch_cam_stage2(prm_, lambda);
+    sub_mark(&sub_.stage2_preconditioner_and_gradient_time);  // get_Q2TJp_T_Q2TJp_blockdiag() + get_Q2TJp_T_Q2Tr()
     if (comm_ || cb_fn_) {
       // every rank added lambda*I and holds only its landmarks' sums: make the
       // diagonal term count once
@@ -1356,6 +1371,7 @@ class Solver final : public rba_solver {
       HIP_CHECK(hipMemcpyAsync(blocks_out, prm_.blocks, size_t(81) * n_cams_ * sizeof(S),
                                hipMemcpyDeviceToHost, stream_));
     timings_.stage2_time = time_end();
+    sub_collect();
     return RBA_OK;
   }
 
@@ -1717,6 +1733,7 @@ class Solver final : public rba_solver {
     time_begin();
     run_stage2(lambda);
     timings_.stage2_time = time_end();
+    sub_collect();
 
     time_begin();
     hipLaunchKernelGGL((rba::k_invert_blocks<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_,
@@ -2161,6 +2178,7 @@ class Solver final : public rba_solver {
     sync();
   }
   void get_timings(rba_iter_timings* out) override { *out = timings_; }
+  void get_substage_timings(rba_substage_timings* out) override { *out = sub_; }
   void get_jl_col_scale(void* out) override {
     use_device();
     std::vector<S> sorted(3 * size_t(n_lms_));
@@ -2257,7 +2275,39 @@ class Solver final : public rba_solver {
     HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
     return double(ms) * 1e-3;
   }
-  void reset_timings() { timings_ = rba_iter_timings{}; }
+  void reset_timings() {
+    timings_ = rba_iter_timings{};
+    sub_ = rba_substage_timings{};
+  }
+  // Sub-stage timers of the reference's UNSTAGED execution (linearizor_qr.cpp:94-112, 166-187): with
+  // staged_execution = 0 the kernel groups of a stage are separated by HIP events (a marker packet each) and the
+  // elapsed times are filed under the reference's IterationSummary fields; the kernels are the same either way.
+  bool sub_timing() const { return !opt_.staged_execution; }
+  void sub_begin() {
+    sub_n_ = 0;
+    if (sub_timing()) sub_mark(nullptr);
+  }
+  void sub_mark(double* field) {
+    if (!sub_timing()) return;
+    if (sub_n_ >= int(sub_events_.size())) {
+      hipEvent_t e = nullptr;
+      HIP_CHECK(hipEventCreate(&e));
+      sub_events_.push_back(e);
+      sub_fields_.push_back(nullptr);
+    }
+    HIP_CHECK(hipEventRecord(sub_events_[sub_n_], stream_));
+    sub_fields_[sub_n_] = field;
+    ++sub_n_;
+  }
+  // after the stage's time_end() (which synchronised): interval i-1 -> i is added to the field of mark i
+  void sub_collect() {
+    for (int i = 1; i < sub_n_; ++i) {
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, sub_events_[i - 1], sub_events_[i]));
+      if (sub_fields_[i]) *sub_fields_[i] += double(ms) * 1e-3;
+    }
+    sub_n_ = 0;
+  }
 
   template <class F>
   void for_each_class(F&& f) {
@@ -2332,6 +2382,10 @@ class Solver final : public rba_solver {
   bool bs_two_pass_ = false;  // RBA_BS_TWO_PASS=1: round-1 back-substitution kernels for every landmark
   int hx_lds_ = 1;            // RBA_HX_LDS=0: never use the LDS-private y copy (k_hx_implicit_lds); 2: whenever y fits
                               // (default 1: when it fits and every wave gets at least four tiles)
+  rba_substage_timings sub_{};
+  std::vector<hipEvent_t> sub_events_;
+  std::vector<double*> sub_fields_;
+  int sub_n_ = 0;
   bool hx_lds_attr_set_ = false;
   DevBuf<rba::HxChunk> d_hx_chunks_;
   int n_hx_chunks_ = 0, hx_win_ = 0;
@@ -2683,6 +2737,13 @@ int rba_debug_read_blocks(rba_handle h, int vec_width, int64_t* bytes_out) {
 int rba_get_timings(rba_handle h, rba_iter_timings* out) {
   return guarded([&]() -> int {
     h->get_timings(out);
+    return RBA_OK;
+  });
+}
+int rba_get_substage_timings(rba_handle h, rba_substage_timings* out) {
+  return guarded([&]() -> int {
+    if (!out) return RBA_ERR_INVALID_ARGUMENT;
+    h->get_substage_timings(out);
     return RBA_OK;
   });
 }

@@ -224,6 +224,12 @@ class LinearizorHIP:
         L.check(self.lib.rba_synchronize(self.h), "rba_synchronize")
 
     # -- introspection ------------------------------------------------------------------------
+    def substage_timings(self) -> L.RbaSubstageTimings:
+        """Sub-stage timers of the reference's unstaged execution (options.staged_execution = 0)."""
+        t = L.RbaSubstageTimings()
+        L.check(self.lib.rba_get_substage_timings(self.h, C.byref(t)), "rba_get_substage_timings")
+        return t
+
     def timings(self) -> L.RbaIterTimings:
         t = L.RbaIterTimings()
         L.check(self.lib.rba_get_timings(self.h, C.byref(t)), "rba_get_timings")

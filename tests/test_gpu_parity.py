@@ -755,3 +755,31 @@ def test_dense_block_configuration_still_limits_track_length(very_long_track_pro
     from rootba_amd.linearizor import LinearizorHIP
     with pytest.raises(RuntimeError, match="not supported|does not fit"):
         LinearizorHIP(very_long_track_problem, np.float32, _opts(L, implicit_q=0))
+
+
+def test_unstaged_substage_timers(small_problem):
+    """staged_execution = 0: the reference's unstaged timers (linearizor_qr.cpp:94-112, 166-187) are measured
+    between the kernel groups of the two stages and add up to (at most) the stage times; staged execution
+    (default) leaves them at zero, as the reference does. Results are identical in both modes."""
+    from rootba_amd import _lib as L
+    names = [n for n, _ in L.RbaSubstageTimings._fields_]
+    incs = []
+    for staged in (0, 1):
+        g, _ = _pair(small_problem, np.float32, staged_execution=staged)
+        assert g.linearize() == 0
+        t1 = g.timings().stage1_time
+        s1 = g.substage_timings()
+        inc, cg = g.solve(1e-4)
+        t2 = g.timings().stage2_time
+        s = g.substage_timings()
+        incs.append(inc)
+        vals = {n: getattr(s, n) for n in names}
+        if staged:
+            assert all(v == 0.0 for v in vals.values()), vals
+        else:
+            assert all(v > 0.0 for v in vals.values()), vals
+            st1 = s1.jacobian_evaluation_time + s1.scale_landmark_jacobian_time + s1.stage1_preconditioner_time + \
+                s1.perform_qr_time
+            st2 = s.landmark_damping_time + s.scale_pose_jacobian_time + s.stage2_preconditioner_and_gradient_time
+            assert 0.3 * t1 < st1 <= 1.05 * t1 + 1e-4 and 0.3 * t2 < st2 <= 1.05 * t2 + 1e-4, (st1, t1, st2, t2)
+    assert rel_err(incs[0], incs[1]) < 1e-5
