@@ -29,6 +29,7 @@ void usage() {
       "  --init-depth-threshold <z>\n"
       "  --max-num-iterations <n>               (default 20)\n"
       "  --[no-]use-double                      (default double)\n"
+      "  --mixed-precision                      (with --use-double: double state and costs, float linear algebra)\n"
       "  --[no-]staged-execution                (default staged; unstaged also measures the sub-stage timers)\n"
       "  --preconditioner-type JACOBI|SCHUR_JACOBI|POWER_SCHUR_COMPLEMENT  --power-order <m>\n"
       "  --robust-norm NONE|HUBER --huber-parameter <t>\n"
@@ -191,6 +192,7 @@ int main(int argc, char** argv) {
     else if (a == "--random-seed") ds.random_seed = std::stoi(val());
     else if (a == "--init-depth-threshold") ds.init_depth_threshold = std::stod(val());
     else if (a == "--max-num-iterations") so.max_num_iterations = std::stoi(val());
+    else if (a == "--mixed-precision") so.mixed_precision = true;
     else if (a == "--staged-execution") so.staged_execution = true;
     else if (a == "--no-staged-execution") so.staged_execution = false;
     else if (a == "--use-double") so.use_double = true;

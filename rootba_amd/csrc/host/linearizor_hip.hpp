@@ -60,6 +60,7 @@ struct SolverOptions {
   bool use_double = true;
   bool use_householder_marginalization = true;
   bool staged_execution = true;
+  bool mixed_precision = false;  // RBA_MIXED (needs use_double: the host problem is double, the device algebra float)
   int reduction_alg = 1;
   int power_order = 10;
   double initial_vee = 2.0;
@@ -170,13 +171,23 @@ class LinearizorHIP {
   VecX solve(Scalar lambda) {
     VecX inc(size_t(9) * bal_problem_.num_cameras());
     rba_cg_summary cg;
+    if (mixed_) {  // camera-sized vectors cross the RBA_MIXED boundary as float
+      std::vector<float> f(inc.size());
+      check_rba(rba_solve(h_, double(lambda), f.data(), &cg), "rba_solve");
+      for (size_t i = 0; i < f.size(); ++i) inc[i] = Scalar(f[i]);
+    } else
     check_rba(rba_solve(h_, double(lambda), inc.data(), &cg), "rba_solve");
     if (it_summary_) it_summary_->linear_solver_iterations = cg.num_iterations;
     return inc;
   }
   Scalar apply(VecX&& inc) {
     double l_diff = 0;
-    const int st = rba_apply(h_, inc.data(), &l_diff);
+    std::vector<float> f;
+    if (mixed_) {
+      f.resize(inc.size());
+      for (size_t i = 0; i < f.size(); ++i) f[i] = float(inc[i]);
+    }
+    const int st = mixed_ ? rba_apply(h_, f.data(), &l_diff) : rba_apply(h_, inc.data(), &l_diff);
     check_rba(st, "rba_apply");
     if (st == RBA_NUMERICAL_FAILURE) return std::numeric_limits<Scalar>::quiet_NaN();
     return Scalar(l_diff);
@@ -193,10 +204,14 @@ class LinearizorHIP {
 
  private:
   LinearizorHIP(BalProblem<Scalar>& bal_problem, const SolverOptions& options, SolverSummary* summary, int device)
-      : bal_problem_(bal_problem), options_(options), summary_(summary) {
+      : bal_problem_(bal_problem), options_(options), summary_(summary),
+        mixed_(options.mixed_precision && std::is_same<Scalar, double>::value) {
+    if (options.mixed_precision && !mixed_)
+      throw std::runtime_error("mixed_precision needs use_double (the host problem is double)");
     const rba_options o = options.to_rba();
     // BalProblem already stores the CSR topology the C ABI takes
-    check_rba(rba_create(std::is_same<Scalar, float>::value ? RBA_F32 : RBA_F64, device, bal_problem.num_cameras(),
+    check_rba(rba_create(mixed_ ? RBA_MIXED : std::is_same<Scalar, float>::value ? RBA_F32 : RBA_F64, device,
+                         bal_problem.num_cameras(),
                          bal_problem.num_landmarks(), bal_problem.lm_off.data(), bal_problem.obs_cam.data(),
                          bal_problem.obs_xy.data(), &o, &h_),
               "rba_create");
@@ -208,6 +223,7 @@ class LinearizorHIP {
   SolverOptions options_;
   SolverSummary* summary_;
   IterationSummary* it_summary_ = nullptr;
+  bool mixed_ = false;
   rba_handle h_ = nullptr;
 };
 

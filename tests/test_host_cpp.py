@@ -220,3 +220,40 @@ def test_bal_qr_hip_end_to_end(app, bal_file, tmp_path):
     assert [r.cg_iterations for r in rows] == log["linear_solver_iterations"]
     assert log["num_obs"][0] == prob.n_obs and log["_static"]["problem_info"]["num_observations"] == prob.n_obs
     assert np.isclose(log["cumulative_time"][-1], log["_static"]["solver"]["minimizer_time_in_seconds"], rtol=0.2)
+
+
+@pytest.mark.gpu
+def test_bal_qr_hip_mixed_precision_and_unstaged_timers(app, bal_file, tmp_path):
+    """`--mixed-precision --no-staged-execution`: the CLI runs RBA_MIXED (same costs as the Python binding's
+    mixed run) and the log carries the reference's unstaged sub-stage timers."""
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    path, _ = bal_file
+    log_path = str(tmp_path / "ba_log.json")
+    out = subprocess.run([app, "--input", path, "--max-num-iterations", "5", "--robust-norm", "HUBER", "--use-double",
+                          "--mixed-precision", "--no-staged-execution", "--log-path", log_path],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    log = json.load(open(log_path))
+    check_ba_log_layout(log)
+    prob = P.normalize(P.read_bal(path), 100.0)
+    g = LinearizorHIP(prob, "mixed", L.default_options(robust_norm=1, max_num_iterations=5))
+    rows, _ = g.optimize_lm()
+    want, last = [], None
+    for r in rows:
+        last = r.cost if (r.step_is_successful or last is None) else last
+        want.append(last)
+    assert len(rows) == len(log["iteration"]) and np.allclose(want, log["cost"], rtol=1e-6)
+    for key in ("jacobian_evaluation_time", "perform_qr_time", "landmark_damping_time", "scale_pose_jacobian_time",
+                "scale_landmark_jacobian_time"):
+        assert all(v > 0 for v in log[key][1:]), key
+    # staged (default) run: the same columns are zero, as in the reference
+    out = subprocess.run([app, "--input", path, "--max-num-iterations", "2", "--log-path", log_path],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    log = json.load(open(log_path))
+    assert all(v == 0 for v in log["perform_qr_time"])
+    # mixed precision without a double host problem is refused
+    out = subprocess.run([app, "--input", path, "--no-use-double", "--mixed-precision"], capture_output=True, text=True)
+    assert out.returncode != 0
