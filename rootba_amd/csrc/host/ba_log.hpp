@@ -7,13 +7,16 @@
 // iteration), plus "_type": "rootba" and "_static": {problem_info, timing, solver}
 // (ba_log.hpp:45-137). How the per-iteration values derive from the iteration
 // summaries follows ba_log_utils.cpp:97-160: a rejected step repeats the previous
-// row's cost columns so that plots stay monotonic. Own writer (no nlohmann/json).
+// row's cost columns so that plots stay monotonic. Own writers (no nlohmann/json): pretty-printed JSON and
+// the UBJSON twin `<log>.ubjson` (SaveLogFlag UBJSON), byte layout of nlohmann::json::to_ubjson.
 #pragma once
 
 #include <sys/resource.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <fstream>
 #include <functional>
 #include <iomanip>
@@ -185,26 +188,150 @@ inline std::vector<BaIteration> to_ba_iterations(const SolverSummary& summary) {
   return rows;
 }
 
-inline bool save_ba_log_json(const std::string& path, const SolverSummary& summary, const DatasetSummary& dataset,
-                             const PipelineTimingSummary& timing) {
+namespace detail {
+// Minimal JSON value (what nlohmann::json holds for the log): objects keep their keys sorted like
+// nlohmann's std::map-based object, so both writers emit the reference's key order.
+struct JValue {
+  enum Kind { Null, Bool, Int, UInt, Float, String, Array, Object } kind = Null;
+  bool b = false;
+  int64_t i = 0;
+  uint64_t u = 0;
+  double d = 0;
+  std::string s;
+  std::vector<JValue> arr;
+  std::vector<std::pair<std::string, JValue>> obj;  // kept sorted by key
+  static JValue boolean(bool v) { JValue j; j.kind = Bool; j.b = v; return j; }
+  static JValue integer(int64_t v) { JValue j; j.kind = Int; j.i = v; return j; }
+  static JValue unsigned_integer(uint64_t v) { JValue j; j.kind = UInt; j.u = v; return j; }
+  static JValue number(double v) { JValue j; j.kind = Float; j.d = v; return j; }
+  static JValue string(const std::string& v) { JValue j; j.kind = String; j.s = v; return j; }
+  static JValue array() { JValue j; j.kind = Array; return j; }
+  static JValue object() { JValue j; j.kind = Object; return j; }
+  JValue& operator[](const std::string& key) {
+    kind = Object;
+    auto it = std::lower_bound(obj.begin(), obj.end(), key,
+                               [](const std::pair<std::string, JValue>& e, const std::string& k) { return e.first < k; });
+    if (it == obj.end() || it->first != key) it = obj.insert(it, {key, JValue()});
+    return it->second;
+  }
+  void push_back(JValue v) {
+    kind = Array;
+    arr.push_back(std::move(v));
+  }
+};
+
+// text, `std::setw(4) << json` style: 4-space indentation, one element per line
+inline void write_json(const JValue& v, std::ostream& os, int indent = 0) {
+  const std::string pad(size_t(indent) + 4, ' '), pad_close(size_t(indent), ' ');
+  switch (v.kind) {
+    case JValue::Null: os << "null"; break;
+    case JValue::Bool: os << (v.b ? "true" : "false"); break;
+    case JValue::Int: os << v.i; break;
+    case JValue::UInt: os << v.u; break;
+    case JValue::Float: os << json_num(v.d); break;
+    case JValue::String: os << '"' << json_escape(v.s) << '"'; break;
+    case JValue::Array:
+      if (v.arr.empty()) {
+        os << "[]";
+        break;
+      }
+      os << "[\n";
+      for (size_t k = 0; k < v.arr.size(); ++k) {
+        os << pad;
+        write_json(v.arr[k], os, indent + 4);
+        os << (k + 1 < v.arr.size() ? ",\n" : "\n");
+      }
+      os << pad_close << "]";
+      break;
+    case JValue::Object:
+      if (v.obj.empty()) {
+        os << "{}";
+        break;
+      }
+      os << "{\n";
+      for (size_t k = 0; k < v.obj.size(); ++k) {
+        os << pad << '"' << json_escape(v.obj[k].first) << "\": ";
+        write_json(v.obj[k].second, os, indent + 4);
+        os << (k + 1 < v.obj.size() ? ",\n" : "\n");
+      }
+      os << pad_close << "}";
+      break;
+  }
+}
+
+// UBJSON as nlohmann::json::to_ubjson(j, os) writes it (no size / type optimisation): the twin file
+// `<log>.ubjson` of the reference (ba_log.cpp:127-145). Integers take the smallest of i/U/I/l/L that
+// holds them, doubles are 'D' + 8 bytes big-endian, object keys are size-prefixed without the 'S' marker.
+inline void ubjson_bytes(std::ostream& os, uint64_t v, int n) {
+  for (int k = n - 1; k >= 0; --k) os.put(char((v >> (8 * k)) & 0xff));
+}
+inline void ubjson_signed(std::ostream& os, int64_t n) {
+  if (n >= -128 && n <= 127) { os.put('i'); ubjson_bytes(os, uint64_t(n), 1); }
+  else if (n >= 0 && n <= 255) { os.put('U'); ubjson_bytes(os, uint64_t(n), 1); }
+  else if (n >= -32768 && n <= 32767) { os.put('I'); ubjson_bytes(os, uint64_t(n), 2); }
+  else if (n >= -2147483648LL && n <= 2147483647LL) { os.put('l'); ubjson_bytes(os, uint64_t(n), 4); }
+  else { os.put('L'); ubjson_bytes(os, uint64_t(n), 8); }
+}
+inline void ubjson_unsigned(std::ostream& os, uint64_t n) {
+  if (n <= 127) { os.put('i'); ubjson_bytes(os, n, 1); }
+  else if (n <= 255) { os.put('U'); ubjson_bytes(os, n, 1); }
+  else if (n <= 32767) { os.put('I'); ubjson_bytes(os, n, 2); }
+  else if (n <= 2147483647ULL) { os.put('l'); ubjson_bytes(os, n, 4); }
+  else { os.put('L'); ubjson_bytes(os, n, 8); }  // (values above INT64_MAX do not occur in the log)
+}
+inline void write_ubjson(const JValue& v, std::ostream& os) {
+  switch (v.kind) {
+    case JValue::Null: os.put('Z'); break;
+    case JValue::Bool: os.put(v.b ? 'T' : 'F'); break;
+    case JValue::Int: ubjson_signed(os, v.i); break;
+    case JValue::UInt: ubjson_unsigned(os, v.u); break;
+    case JValue::Float: {
+      uint64_t bits;
+      static_assert(sizeof(bits) == sizeof(v.d), "IEEE double");
+      std::memcpy(&bits, &v.d, sizeof(bits));
+      os.put('D');
+      ubjson_bytes(os, bits, 8);
+      break;
+    }
+    case JValue::String:
+      os.put('S');
+      ubjson_unsigned(os, v.s.size());
+      os.write(v.s.data(), std::streamsize(v.s.size()));
+      break;
+    case JValue::Array:
+      os.put('[');
+      for (const JValue& e : v.arr) write_ubjson(e, os);
+      os.put(']');
+      break;
+    case JValue::Object:
+      os.put('{');
+      for (const auto& e : v.obj) {
+        ubjson_unsigned(os, e.first.size());
+        os.write(e.first.data(), std::streamsize(e.first.size()));
+        write_ubjson(e.second, os);
+      }
+      os.put('}');
+      break;
+  }
+}
+}  // namespace detail
+
+// the log as one JSON value: an array per BaIteration member, "_type", "_static" (ba_log.cpp:62-115)
+inline detail::JValue ba_log_to_json(const SolverSummary& summary, const DatasetSummary& dataset,
+                                     const PipelineTimingSummary& timing) {
+  using detail::JValue;
   const std::vector<BaIteration> rows = to_ba_iterations(summary);
-  std::ofstream f(path);
-  if (!f.is_open()) return false;
-  using detail::json_num;
-  bool first = true;
-  auto column = [&](const char* name, const std::function<std::string(const BaIteration&)>& get) {
-    f << (first ? "" : ",\n") << "    \"" << name << "\": [";
-    first = false;
-    for (size_t i = 0; i < rows.size(); ++i) f << (i ? ", " : "") << get(rows[i]);
-    f << "]";
-  };
-#define RBA_LOG_NUM(member) column(#member, [](const BaIteration& r) { return json_num(double(r.member)); })
-#define RBA_LOG_INT(member) column(#member, [](const BaIteration& r) { return std::to_string(r.member); })
-#define RBA_LOG_BOOL(member) column(#member, [](const BaIteration& r) { return std::string(r.member ? "true" : "false"); })
-  f << "{\n";
-  // nlohmann::json orders keys alphabetically; readers do not depend on the order
+  JValue j = JValue::object();
+#define RBA_LOG_NUM(member)  { JValue& a = j[#member]; a = JValue::array(); for (const BaIteration& r : rows) a.push_back(JValue::number(double(r.member))); }
+#define RBA_LOG_INT(member)  { JValue& a = j[#member]; a = JValue::array(); for (const BaIteration& r : rows) a.push_back(JValue::integer(int64_t(r.member))); }
+#define RBA_LOG_UINT(member) { JValue& a = j[#member]; a = JValue::array(); for (const BaIteration& r : rows) a.push_back(JValue::unsigned_integer(uint64_t(r.member))); }
+#define RBA_LOG_BOOL(member) { JValue& a = j[#member]; a = JValue::array(); for (const BaIteration& r : rows) a.push_back(JValue::boolean(r.member)); }
   RBA_LOG_INT(iteration);
-  column("linear_solver_type", [](const BaIteration& r) { return "\"" + detail::json_escape(r.linear_solver_type) + "\""; });
+  {
+    JValue& a = j["linear_solver_type"];
+    a = JValue::array();
+    for (const BaIteration& r : rows) a.push_back(JValue::string(r.linear_solver_type));
+  }
   RBA_LOG_BOOL(step_is_valid);
   RBA_LOG_BOOL(step_is_nonmonotonic);
   RBA_LOG_BOOL(step_is_successful);
@@ -245,52 +372,102 @@ inline bool save_ba_log_json(const std::string& path, const SolverSummary& summa
   RBA_LOG_NUM(solve_reduced_system_time);
   RBA_LOG_NUM(back_substitution_time);
   RBA_LOG_NUM(update_cameras_time);
-  RBA_LOG_INT(resident_memory);
-  RBA_LOG_INT(resident_memory_peak);
+  RBA_LOG_UINT(resident_memory);
+  RBA_LOG_UINT(resident_memory_peak);
 #undef RBA_LOG_NUM
 #undef RBA_LOG_INT
+#undef RBA_LOG_UINT
 #undef RBA_LOG_BOOL
-  f << (first ? "" : ",\n") << "    \"_type\": \"rootba\",\n";
+  j["_type"] = JValue::string("rootba");
 
   auto stats = [&](const DatasetStats& s) {
-    return "{\"mean\": " + json_num(s.mean) + ", \"min\": " + json_num(s.min) + ", \"max\": " + json_num(s.max) +
-           ", \"stddev\": " + json_num(s.stddev) + "}";
+    JValue o = JValue::object();
+    o["mean"] = JValue::number(s.mean);
+    o["min"] = JValue::number(s.min);
+    o["max"] = JValue::number(s.max);
+    o["stddev"] = JValue::number(s.stddev);
+    return o;
   };
-  double linear_solver_time = 0, residual_time = 0;
+  double linear_solver_time = 0, residual_time = 0, jacobian_time = 0;
   int successful = -1, unsuccessful = 0;  // iteration 0 counts as successful in the rows, not in the total
   for (const BaIteration& r : rows) {
     linear_solver_time += r.step_solver_time;
     residual_time += r.residual_evaluation_time;
+    jacobian_time += r.jacobian_evaluation_time;
     (r.step_is_successful ? successful : unsuccessful) += 1;
   }
   const double total = timing.load_time + timing.preprocess_time + timing.optimize_time;
   const int n_solves = rows.empty() ? 0 : int(rows.size()) - 1;
-  f << "    \"_static\": {\n"
-    << "        \"problem_info\": {\"type\": \"" << detail::json_escape(dataset.type) << "\", \"input_path\": \""
-    << detail::json_escape(dataset.input_path) << "\", \"num_cameras\": " << dataset.num_cameras
-    << ", \"num_landmarks\": " << dataset.num_landmarks << ", \"num_observations\": " << dataset.num_observations
-    << ", \"rcs_sparsity\": " << json_num(dataset.rcs_sparsity) << ", \"per_lm_obs\": " << stats(dataset.per_lm_obs)
-    << ", \"per_host_lms\": " << stats(dataset.per_host_lms) << "},\n"
-    << "        \"timing\": {\"total\": " << json_num(total) << ", \"load\": " << json_num(timing.load_time)
-    << ", \"preprocess\": " << json_num(timing.preprocess_time) << ", \"optimize\": " << json_num(timing.optimize_time)
-    << ", \"postprocess\": " << json_num(timing.postprocess_time) << "},\n"
-    << "        \"solver\": {\"solver_type\": \"" << detail::json_escape(summary.solver_type)
-    << "\", \"termination_type\": \"" << (summary.termination_type == 1 ? "CONVERGENCE" : "NO_CONVERGENCE")
-    << "\", \"message\": \"" << detail::json_escape(summary.message) << "\", \"num_successful_steps\": "
-    << std::max(successful, 0) << ", \"num_unsuccessful_steps\": " << unsuccessful
-    << ", \"logging_time_in_seconds\": 0.0, \"preprocessor_time_in_seconds\": "
-    << json_num(summary.preprocessor_time_in_seconds) << ", \"minimizer_time_in_seconds\": "
-    << json_num(summary.minimizer_time_in_seconds) << ", \"postprocessor_time_in_seconds\": "
-    << json_num(summary.postprocessor_time_in_seconds) << ", \"total_time_in_seconds\": "
-    << json_num(summary.total_time_in_seconds) << ", \"linear_solver_time_in_seconds\": " << json_num(linear_solver_time)
-    << ", \"num_linear_solves\": " << n_solves << ", \"residual_evaluation_time_in_seconds\": " << json_num(residual_time)
-    << ", \"num_residual_evaluations\": " << int(rows.size()) << ", \"jacobian_evaluation_time_in_seconds\": 0.0"
-    << ", \"num_jacobian_evaluations\": " << std::max(successful, 0) + (rows.empty() ? 0 : 1)
-    << ", \"num_threads_given\": 0, \"num_threads_used\": 1, \"num_threads_available\": "
-    << std::thread::hardware_concurrency() << ", \"resident_memory_peak\": " << resident_memory_peak_bytes()
-    << ", \"initial_cost\": " << json_num(summary.initial_cost) << ", \"final_cost\": " << json_num(summary.final_cost)
-    << "}\n    }\n}\n";
-  return bool(f);
+  JValue& st = j["_static"];
+  st = JValue::object();
+  JValue& pi = st["problem_info"];
+  pi["type"] = JValue::string(dataset.type);
+  pi["input_path"] = JValue::string(dataset.input_path);
+  pi["num_cameras"] = JValue::integer(dataset.num_cameras);
+  pi["num_landmarks"] = JValue::integer(dataset.num_landmarks);
+  pi["num_observations"] = JValue::integer(dataset.num_observations);
+  pi["rcs_sparsity"] = JValue::number(dataset.rcs_sparsity);
+  pi["per_lm_obs"] = stats(dataset.per_lm_obs);
+  pi["per_host_lms"] = stats(dataset.per_host_lms);
+  JValue& tm = st["timing"];
+  tm["total"] = JValue::number(total);
+  tm["load"] = JValue::number(timing.load_time);
+  tm["preprocess"] = JValue::number(timing.preprocess_time);
+  tm["optimize"] = JValue::number(timing.optimize_time);
+  tm["postprocess"] = JValue::number(timing.postprocess_time);
+  JValue& so = st["solver"];
+  so["solver_type"] = JValue::string(summary.solver_type);
+  so["termination_type"] = JValue::string(summary.termination_type == 1 ? "CONVERGENCE" : "NO_CONVERGENCE");
+  so["message"] = JValue::string(summary.message);
+  so["num_successful_steps"] = JValue::integer(std::max(successful, 0));
+  so["num_unsuccessful_steps"] = JValue::integer(unsuccessful);
+  so["logging_time_in_seconds"] = JValue::number(0.0);
+  so["preprocessor_time_in_seconds"] = JValue::number(summary.preprocessor_time_in_seconds);
+  so["minimizer_time_in_seconds"] = JValue::number(summary.minimizer_time_in_seconds);
+  so["postprocessor_time_in_seconds"] = JValue::number(summary.postprocessor_time_in_seconds);
+  so["total_time_in_seconds"] = JValue::number(summary.total_time_in_seconds);
+  so["linear_solver_time_in_seconds"] = JValue::number(linear_solver_time);
+  so["num_linear_solves"] = JValue::integer(n_solves);
+  so["residual_evaluation_time_in_seconds"] = JValue::number(residual_time);
+  so["num_residual_evaluations"] = JValue::integer(int(rows.size()));
+  so["jacobian_evaluation_time_in_seconds"] = JValue::number(jacobian_time);
+  so["num_jacobian_evaluations"] = JValue::integer(std::max(successful, 0) + (rows.empty() ? 0 : 1));
+  so["num_threads_given"] = JValue::integer(0);
+  so["num_threads_used"] = JValue::integer(1);
+  so["num_threads_available"] = JValue::integer(int(std::thread::hardware_concurrency()));
+  so["resident_memory_peak"] = JValue::unsigned_integer(resident_memory_peak_bytes());
+  so["initial_cost"] = JValue::number(summary.initial_cost);
+  so["final_cost"] = JValue::number(summary.final_cost);
+  return j;
+}
+
+// BaLog::save_json (ba_log.cpp:62-149): SaveLogFlag JSON and / or UBJSON (`<path without extension>.ubjson`)
+enum SaveLogFlag { SAVE_LOG_JSON = 1, SAVE_LOG_UBJSON = 2 };
+
+inline bool save_ba_log(const std::string& path, int flags, const SolverSummary& summary,
+                        const DatasetSummary& dataset, const PipelineTimingSummary& timing) {
+  if (flags == 0) return true;
+  const detail::JValue j = ba_log_to_json(summary, dataset, timing);
+  if (flags & SAVE_LOG_JSON) {
+    std::ofstream f(path);
+    if (!f.is_open()) return false;
+    detail::write_json(j, f);
+    f << "\n";
+    if (!f) return false;
+  }
+  if (flags & SAVE_LOG_UBJSON) {
+    const std::string ub = path.substr(0, path.find_last_of('.')) + ".ubjson";
+    std::ofstream f(ub, std::ios_base::binary);
+    if (!f.is_open()) return false;
+    detail::write_ubjson(j, f);
+    if (!f) return false;
+  }
+  return true;
+}
+
+inline bool save_ba_log_json(const std::string& path, const SolverSummary& summary, const DatasetSummary& dataset,
+                             const PipelineTimingSummary& timing) {
+  return save_ba_log(path, SAVE_LOG_JSON, summary, dataset, timing);
 }
 
 }  // namespace rootba_hip

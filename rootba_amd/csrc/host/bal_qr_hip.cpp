@@ -38,8 +38,11 @@ void usage() {
       "  --jacobi-scaling-epsilon <e> --log-path <ba_log.json> --device <n>\n"
       "  --solver-type SQUARE_ROOT|SCHUR_COMPLEMENT   (default SQUARE_ROOT)\n"
       "  --dense-blocks                         matrix-free products on the dense Q2^T Jp blocks (default: from the QR factors)\n"
+      "  --save-log-flags <JSON,UBJSON>         (default JSON; UBJSON writes <log>.ubjson next to it)\n"
       "  --dry-run                              load + preprocess only, print problem statistics");
 }
+
+static int g_save_log_flags = rootba_hip::SAVE_LOG_JSON;  // BaLogOptions::save_log_flags (ba_log_options.hpp:48-50)
 
 template <class Scalar>
 int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string& log_path, bool dry_run, int device) {
@@ -79,7 +82,7 @@ int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string&
   timing.preprocess_time = preprocess_seconds;
   timing.optimize_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_opt).count();
   // ba_log.json in the reference's layout (src/rootba/bal/ba_log.cpp:62-149)
-  if (!save_ba_log_json(log_path, summary, summarize_dataset(prob, ds.input), timing)) {
+  if (!save_ba_log(log_path, g_save_log_flags, summary, summarize_dataset(prob, ds.input), timing)) {
     std::fprintf(stderr, "Could not save BA log to %s.\n", log_path.c_str());
     return 2;
   }
@@ -163,7 +166,7 @@ static int self_test_log(const std::string& path) {
   timing.load_time = 1;
   timing.preprocess_time = 2;
   timing.optimize_time = 3;
-  return save_ba_log_json(path, summary, dataset, timing) ? 0 : 2;
+  return save_ba_log(path, SAVE_LOG_JSON | SAVE_LOG_UBJSON, summary, dataset, timing) ? 0 : 2;
 }
 
 int main(int argc, char** argv) {
@@ -222,6 +225,24 @@ int main(int argc, char** argv) {
     else if (a == "--function-tolerance") so.function_tolerance = std::stod(val());
     else if (a == "--jacobi-scaling-epsilon") so.jacobi_scaling_epsilon = std::stod(val());
     else if (a == "--log-path") log_path = val();
+    else if (a == "--save-log-flags") {
+      // comma-separated subset of JSON, UBJSON (empty string: save nothing)
+      const std::string v = val();
+      g_save_log_flags = 0;
+      size_t p0 = 0;
+      while (p0 <= v.size() && !v.empty()) {
+        const size_t p1 = v.find(',', p0);
+        const std::string t = v.substr(p0, p1 == std::string::npos ? std::string::npos : p1 - p0);
+        if (t == "JSON") g_save_log_flags |= rootba_hip::SAVE_LOG_JSON;
+        else if (t == "UBJSON") g_save_log_flags |= rootba_hip::SAVE_LOG_UBJSON;
+        else {
+          std::fprintf(stderr, "unknown --save-log-flags entry '%s' (JSON, UBJSON)\n", t.c_str());
+          return 1;
+        }
+        if (p1 == std::string::npos) break;
+        p0 = p1 + 1;
+      }
+    }
     else if (a == "--device") device = std::stoi(val());
     else if (a == "--dry-run") dry_run = true;
     else if (a == "--self-test-parser") return self_test_parser(std::stol(val()));

@@ -186,6 +186,75 @@ def test_ba_log_layout_and_rejected_step_rows(app, tmp_path):
     assert s["problem_info"]["input_path"] == 'self "test"'
 
 
+def _ubjson_decode(buf):
+    """Decoder for the subset nlohmann::json::to_ubjson(j) emits without size/type optimisation
+    (UBJSON draft 12): Z T F i U I l L D S [ ] { }; object keys are size-prefixed strings without 'S'."""
+    import struct
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        b = buf[pos:pos + n]
+        assert len(b) == n
+        pos += n
+        return b
+
+    def integer(marker):
+        fmt = {b"i": ">b", b"U": ">B", b"I": ">h", b"l": ">i", b"L": ">q"}[marker]
+        return struct.unpack(fmt, take(struct.calcsize(fmt)))[0]
+
+    def value(marker=None):
+        marker = marker or take(1)
+        if marker == b"Z":
+            return None
+        if marker in (b"T", b"F"):
+            return marker == b"T"
+        if marker in b"iUIlL":
+            return integer(marker)
+        if marker == b"D":
+            return struct.unpack(">d", take(8))[0]
+        if marker == b"S":
+            return take(integer(take(1))).decode()
+        if marker == b"[":
+            out = []
+            while True:
+                m = take(1)
+                if m == b"]":
+                    return out
+                out.append(value(m))
+        if marker == b"{":
+            out = {}
+            while True:
+                m = take(1)
+                if m == b"}":
+                    return out
+                key = take(integer(m)).decode()
+                out[key] = value()
+        raise AssertionError(f"unexpected UBJSON marker {marker!r} at {pos}")
+
+    v = value()
+    assert pos == len(buf)
+    return v
+
+
+def test_ba_log_ubjson_twin(app, tmp_path):
+    """SaveLogFlag::UBJSON (reference ba_log.cpp:127-145): `<log>.ubjson` holds the same object as the JSON file,
+    in nlohmann's to_ubjson byte layout (smallest integer type, big-endian doubles, sorted keys)."""
+    path = str(tmp_path / "ba_log.json")
+    assert subprocess.run([app, "--self-test-log", path]).returncode == 0
+    log = json.load(open(path))
+    raw = open(str(tmp_path / "ba_log.ubjson"), "rb").read()
+    ub = _ubjson_decode(raw)
+    check_ba_log_layout(ub)
+    assert list(ub) == sorted(ub) and list(log) == sorted(log)  # std::map order of nlohmann::json
+    assert ub == log
+    # spot checks of the encoding itself: "_type" is the second key; small ints are int8, doubles 'D'
+    assert raw[:1] == b"{" and raw[-1:] == b"}"
+    assert b"i\x05_typeSi\x06rootba" in raw                      # key: size-prefixed, no 'S'; value: 'S' + size
+    assert b"i\x09iteration[i\x00i\x01i\x02i\x03]" in raw         # small integers as int8
+    assert b"i\x04cost[D" + __import__("struct").pack(">d", 100.0) in raw  # doubles big-endian
+
+
 def test_cli_rejects_bad_input(app, tmp_path):
     assert subprocess.run([app, "--input", str(tmp_path / "missing.txt")], capture_output=True).returncode == 2
     assert subprocess.run([app, "--input", "x", "--preconditioner-type", "POWER_VARIABLE_PROJECTION"],
