@@ -232,16 +232,18 @@ class Solver final : public rba_solver {
       for (int b : bounds) c += k > b ? 1 : 0;
       return c;
     };
-    std::stable_sort(perm_.begin(), perm_.end(), [&](int a, int b) {
-      const int64_t ka = lm_off[a + 1] - lm_off[a], kb = lm_off[b + 1] - lm_off[b];
-      if (!sort_by_camera) return ka < kb;
-      // by class, then by first camera (then by k: equal tracks next to each other)
-      const int ca = k_class(ka), cb = k_class(kb);
-      if (ca != cb) return ca < cb;
-      const int fa = obs_cam[lm_off[a]], fb = obs_cam[lm_off[b]];
-      if (fa != fb) return fa < fb;
-      return ka < kb;
-    });
+    {
+      // one 64-bit key per landmark (a comparator that recomputes it costs seconds at final-13682 size):
+      // unsorted: k; sorted: class | first camera | k (equal tracks next to each other)
+      std::vector<uint64_t> key(n_lms);
+      for (int l = 0; l < n_lms; ++l) {
+        const int64_t k = lm_off[l + 1] - lm_off[l];
+        key[l] = sort_by_camera ? (uint64_t(k_class(k)) << 56) | (uint64_t(uint32_t(obs_cam[lm_off[l]])) << 24) |
+                                      uint64_t(std::min<int64_t>(k, (1 << 24) - 1))
+                                : uint64_t(k);
+      }
+      std::stable_sort(perm_.begin(), perm_.end(), [&](int a, int b) { return key[a] < key[b]; });
+    }
     std::vector<int> lm_k(n_lms);
     std::vector<int64_t> lm_obs(n_lms + 1), lm_blk(n_lms + 1);
     std::vector<int> s_obs_cam(n_obs_), s_obs_lm(n_obs_);
