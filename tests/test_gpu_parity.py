@@ -783,3 +783,29 @@ def test_unstaged_substage_timers(small_problem):
             st2 = s.landmark_damping_time + s.scale_pose_jacobian_time + s.stage2_preconditioner_and_gradient_time
             assert 0.3 * t1 < st1 <= 1.05 * t1 + 1e-4 and 0.3 * t2 < st2 <= 1.05 * t2 + 1e-4, (st1, t1, st2, t2)
     assert rel_err(incs[0], incs[1]) < 1e-5
+
+
+@pytest.mark.parametrize("lam", [1e-7, 1e-10])
+def test_assembled_operator_at_tiny_damping_float32(ladybug_far, lam):
+    """The float32 assembled reduced matrix is S + E with |E| ~ eps |S| (its diagonal is a difference of sums),
+    so with a pose damping far below eps it can lose definiteness where the reference's operator
+    (p.q = |A p|^2 + lambda |p|^2) cannot. A long solve that switches to it after one product must still
+    return a usable increment - through the matrix (residual refreshed at the switch) or, when the PCG
+    meets p.q <= 0 there, through the matrix-free repeat - and be as close to the float64 solution of the
+    same system as the all-matrix-free float32 solve is."""
+    kw = dict(eta=1e-6, max_cg_it=400)
+    g64, _ = _pair(ladybug_far, np.float64, explicit_after=0, **kw)
+    assert g64.linearize() == 0
+    ref, cref = g64.solve(lam)
+    assert cref.termination_type != 2
+    errs = {}
+    for after in (0, 1):
+        g, _ = _pair(ladybug_far, np.float32, explicit_after=after, **kw)
+        assert g.linearize() == 0
+        inc, cg = g.solve(lam)
+        assert cg.termination_type != 2 and np.all(np.isfinite(inc)), (after, cg.termination_type)
+        errs[after] = rel_err(inc, ref)
+        # the increment is a descent direction of the linearised cost: the model cost change is negative
+        l_diff = g.apply(inc)
+        assert np.isfinite(l_diff) and l_diff > 0
+    assert errs[0] < 0.2 and errs[1] <= max(3 * errs[0], 5e-2), errs
