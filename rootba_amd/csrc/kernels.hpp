@@ -75,6 +75,9 @@ struct Params {
   // onto one 64 KB vector are not what bounds the kernel.
   int y_rep;
   int64_t y_rep_stride;
+  S* W8;         // [n_obs][8] compact stage-2 record (kernels_s1.hpp: k_s2_w8): W' (3x2, row-major) | g (2) with
+                 //            damped Q1^T Jp D = W' (Jp D) per observation and b record = (Jp D)^T g; JpS stays UNSCALED
+  int compact;   // 1: stage 2 writes W8 only; D (pose_scaling) is applied where a camera index is at hand
   S* lm_inc;     // mixed precision (RBA_MIXED): the back-substitution stores the scaled landmark increments here
                  // [3 n_lms] instead of adding them to `lms`; they are applied to the double master state
   int hx_debug;  // RBA_HX_DEBUG (profiling only, results are wrong): 1 = no scatter, 2 = loads only
@@ -601,6 +604,142 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
   }
   if (tid >= 243 && tid < 252)
     p.b[9 * c + (tid - 243)] = S((p.b_from_records ? 0.0 : double(p.b_mid[9 * c + (tid - 243)])) + acc);
+}
+
+// ---------------------------------------------------------------------------
+// Compact stage 2 (p.compact): the landmark side hands over EIGHT scalars per observation (W8: the 3x2 map W'
+// and the 2-vector g, kernels_s1.hpp) instead of the 27 + 9 of the stage-2 record, and the Jacobian rows are
+// never rewritten in scaled form. This camera-major pass gathers the unscaled rows (72 B) and W8 (32 B), forms
+// X = W' Jp (3 x 9) in registers and accumulates
+//   T_c = sum X^T X,   t_c = sum Jp^T g        (no camera scaling yet)
+//   blocks[c] = B_mid[c] - D T_c D + lambda I,  b[c] = D t_c           (B_mid = D G D from stage 1)
+// float: X^T X on the matrix cores, both records of 32 observations staged in LDS per wave.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cam_stage2_w8_mfma(Params<float> p, float lambda) {
+  constexpr int RW = 26;  // staged record: [Jp 18 | W' 6 | g 2]
+  __shared__ float tile[4][16][16];
+  __shared__ double bsum[4][7][9];
+  __shared__ __attribute__((aligned(16))) float stage[4][kCamChunk * RW + 6];
+  const int c = xcd_swizzled_camera(p.n_cams);
+  if (c >= p.n_cams) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const bool want_gram = !p.jacobi || p.want_sdiag;
+  const int i = lane & 15, kk = lane >> 4;
+  const int g = lane / 9, a = lane - 9 * g;
+  double accb = 0;
+  float* lds = stage[wave];
+  for (int64_t base = t0 + kCamChunk * wave; base < t1; base += 4 * kCamChunk) {
+    const int cnt = int(min<int64_t>(kCamChunk, t1 - base));
+    const int idxreg = lane < cnt ? p.cam_obs[base + lane] : 0;
+    // Jacobian rows: nine 8-byte pieces per record; W8: two 16-byte pieces (kept at 8-byte granularity in LDS:
+    // the 26-float record stride is not a multiple of 16 bytes)
+#pragma unroll
+    for (int j = 0; j < (kCamChunk * 9 + 63) / 64; ++j) {
+      const int q = j * 64 + lane;
+      const int r = q / 9, pc = q - 9 * r;
+      const int o = __shfl(idxreg, r & 31);
+      if (q < cnt * 9)
+        *reinterpret_cast<float2*>(lds + r * RW + 2 * pc) = *reinterpret_cast<const float2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
+    }
+    {
+      const int r = lane >> 1, h = lane & 1;
+      const int o = __shfl(idxreg, r & 31);
+      if (r < cnt) {
+        const float4 w = *reinterpret_cast<const float4*>(p.W8 + int64_t(o) * 8 + 4 * h);
+        float* d = lds + r * RW + 18 + 4 * h;
+        *reinterpret_cast<float2*>(d) = float2{w.x, w.y};
+        *reinterpret_cast<float2*>(d + 2) = float2{w.z, w.w};
+      }
+    }
+    wave_lds_fence();
+    if (want_gram) {
+      for (int s = 0; s < cnt; ++s) {
+        const float* rec = lds + s * RW;
+        float v = 0.f;
+        if (i < 9 && kk < 3) v = rec[18 + 2 * kk] * rec[i] + rec[19 + 2 * kk] * rec[9 + i];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, acc, 0, 0, 0);
+      }
+    }
+    if (lane < 63)
+      for (int r = g; r < cnt; r += 7) {
+        const float* rec = lds + r * RW;
+        accb += double(rec[a] * rec[24] + rec[9 + a] * rec[25]);
+      }
+    wave_lds_fence();  // the next chunk overwrites the staging buffer
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+  if (lane < 63) bsum[wave][g][a] = accb;
+  __syncthreads();
+  if (tid < 81) {
+    const int ii = tid / 9, jj = tid - 9 * ii;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t += tile[w][ii][jj];
+    t *= p.pose_scaling[9 * c + ii] * p.pose_scaling[9 * c + jj];
+    const float bm = p.B_mid[81 * c + tid];
+    p.blocks[81 * c + tid] = (p.jacobi ? bm : bm - t) + (ii == jj ? lambda : 0.f);
+    if (p.want_sdiag) p.sdiag[81 * c + tid] = bm - t;
+  }
+  if (tid >= 128 && tid < 137) {
+    const int aa = tid - 128;
+    double sum = 0.0;
+    for (int w = 0; w < 4; ++w)
+      for (int gg = 0; gg < 7; ++gg) sum += bsum[w][gg][aa];
+    p.b[9 * c + aa] = float(sum * double(p.pose_scaling[9 * c + aa]));
+  }
+}
+
+// generic (double): records staged per workgroup, double accumulators
+template <class S>
+__global__ __launch_bounds__(256) void k_cam_stage2_w8(Params<S> p, S lambda) {
+  constexpr int TILE = 64, RW = 26;
+  __shared__ S rec[TILE][RW];
+  __shared__ int olist[TILE];
+  __shared__ double red[3][81];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
+  double acc = 0;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  for (int64_t base = t0; base < t1; base += TILE) {
+    const int n = int(min<int64_t>(TILE, t1 - base));
+    __syncthreads();
+    if (tid < n) olist[tid] = p.cam_obs[base + tid];
+    __syncthreads();
+    for (int idx = tid; idx < n * RW; idx += 256) {
+      const int q = idx / RW, f = idx - RW * q;
+      rec[q][f] = f < 18 ? p.JpS[int64_t(olist[q]) * 18 + f] : p.W8[int64_t(olist[q]) * 8 + (f - 18)];
+    }
+    __syncthreads();
+    if (grp < 3) {
+      if (!p.jacobi || p.want_sdiag) {
+        for (int q = grp; q < n; q += 3) {
+          const S* r = rec[q];
+          S t = S(0);
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+            t += (r[18 + 2 * m] * r[ea] + r[19 + 2 * m] * r[9 + ea]) * (r[18 + 2 * m] * r[eb] + r[19 + 2 * m] * r[9 + eb]);
+          acc -= double(t);
+        }
+      }
+    } else if (tid < 252) {
+      const int a = tid - 243;
+      for (int q = 0; q < n; ++q) acc += double(rec[q][a] * rec[q][24] + rec[q][9 + a] * rec[q][25]);
+    }
+  }
+  if (grp < 3) red[grp][e] = acc;
+  __syncthreads();
+  if (tid < 81) {
+    const double gram = (red[0][tid] + red[1][tid] + red[2][tid]) * double(p.pose_scaling[9 * c + tid / 9]) *
+                        double(p.pose_scaling[9 * c + tid % 9]);  // = - D (sum X^T X) D
+    p.blocks[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + (p.jacobi ? 0.0 : gram) +
+                               ((tid / 9 == tid % 9) ? double(lambda) : 0.0));
+    if (p.want_sdiag) p.sdiag[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + gram);
+  }
+  if (tid >= 243 && tid < 252) p.b[9 * c + (tid - 243)] = S(acc * double(p.pose_scaling[9 * c + (tid - 243)]));
 }
 
 // pose_jacobian_scaling = 1 / (eps + sqrt(Jp_diag2))   (linearizor_qr.cpp:130-132)
@@ -1534,7 +1673,8 @@ __device__ __forceinline__ void hx_tile_load(const Params<S>& p, const ImplicitT
 // ---------------------------------------------------------------------------
 template <class S, int P2>
 __device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int cam, int lane, double* ylds, int dbg,
-                                                    int cam_lo, int win, S* __restrict__ y) {
+                                                    int cam_lo, int win, S* __restrict__ y,
+                                                    const S* __restrict__ dout) {
   const int r = lane & (P2 - 1);
   const bool act = cam >= 0;
   if (dbg == 2) {
@@ -1582,7 +1722,7 @@ __device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int 
       if (inside)
         lds_atomic_add(yc + 2 * q, double(mine));
       else
-        atomic_add(yg + 2 * q, mine);
+        atomic_add(yg + 2 * q, dout ? mine * dout[9 * cam + par + 2 * q] : mine);
     }
   }
 }
@@ -1617,7 +1757,10 @@ template <class S>
 __global__ __launch_bounds__(1024) void k_hx_implicit_lds(Params<S> p, ImplicitTiles it,
                                                           const HxChunk* __restrict__ chunks, int win,
                                                           const S* __restrict__ x, S* __restrict__ y,
+                                                          const S* __restrict__ dout,
                                                           const int* __restrict__ done_flag) {
+  // `dout` (compact stage 2: the Jacobian rows are unscaled, x arrives pre-multiplied by the pose scaling D):
+  // the result is multiplied by D where it leaves the workgroup; nullptr = rows already scaled
   extern __shared__ __align__(16) unsigned char hx_lds_raw[];
   __shared__ HxChunk ch;
   double* ylds = reinterpret_cast<double*>(hx_lds_raw);
@@ -1642,11 +1785,11 @@ __global__ __launch_bounds__(1024) void k_hx_implicit_lds(Params<S> p, ImplicitT
     hx_tile_load(p, it, TA, camA, rowA, lane, x, dA);
     auto compute = [&](int T, const HxTileData<S>& d, int cam) {
       switch (hx_tile_class(it, T)) {
-        case 0: hx_tile_compute_lds<S, 4>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y); break;
-        case 1: hx_tile_compute_lds<S, 8>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y); break;
-        case 2: hx_tile_compute_lds<S, 16>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y); break;
-        case 3: hx_tile_compute_lds<S, 32>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y); break;
-        default: hx_tile_compute_lds<S, 64>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y); break;
+        case 0: hx_tile_compute_lds<S, 4>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y, dout); break;
+        case 1: hx_tile_compute_lds<S, 8>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y, dout); break;
+        case 2: hx_tile_compute_lds<S, 16>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y, dout); break;
+        case 3: hx_tile_compute_lds<S, 32>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y, dout); break;
+        default: hx_tile_compute_lds<S, 64>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y, dout); break;
       }
     };
     for (;;) {
@@ -1675,11 +1818,12 @@ __global__ __launch_bounds__(1024) void k_hx_implicit_lds(Params<S> p, ImplicitT
   // every workgroup starts at its own offset so that copies of the same entries do not arrive together
   const int start = int((int64_t(blockIdx.x) * nwin) / gridDim.x);
   S* __restrict__ yw = y + 9 * cam_lo;
+  const S* __restrict__ dw = dout ? dout + 9 * cam_lo : nullptr;
   for (int i = threadIdx.x; i < nwin; i += 1024) {
     int j = i + start;
     j = j >= nwin ? j - nwin : j;
     const double v = ylds[j];
-    if (v != 0.0) atomic_add(yw + j, S(v));
+    if (v != 0.0) atomic_add(yw + j, dw ? S(v * double(dw[j])) : S(v));
   }
 }
 
@@ -1989,19 +2133,32 @@ __global__ __launch_bounds__(256) void k_bs_obs(Params<S> p, const S* __restrict
   const int64_t o = o_begin + int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (o >= n_obs) return;
   const S* __restrict__ xc = x + 9 * p.obs_cam[o];
-  const S* __restrict__ td = p.topd + kTd * o;
   const S* __restrict__ jp = p.JpS + 18 * o;
   S xv[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) xv[c] = xc[c];
   S out[5] = {S(0), S(0), S(0), S(0), S(0)};
+  if (p.compact) {
+    // x arrives pre-multiplied by the pose scaling; topd x = W' (Jp D x)
 #pragma unroll
-  for (int c = 0; c < 9; ++c) {
-    out[0] += td[c] * xv[c];
-    out[1] += td[9 + c] * xv[c];
-    out[2] += td[18 + c] * xv[c];
-    out[3] += jp[c] * xv[c];
-    out[4] += jp[9 + c] * xv[c];
+    for (int c = 0; c < 9; ++c) {
+      out[3] += jp[c] * xv[c];
+      out[4] += jp[9 + c] * xv[c];
+    }
+    const S* __restrict__ w = p.W8 + 8 * o;
+    out[0] = w[0] * out[3] + w[1] * out[4];
+    out[1] = w[2] * out[3] + w[3] * out[4];
+    out[2] = w[4] * out[3] + w[5] * out[4];
+  } else {
+    const S* __restrict__ td = p.topd + kTd * o;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      out[0] += td[c] * xv[c];
+      out[1] += td[9 + c] * xv[c];
+      out[2] += td[18 + c] * xv[c];
+      out[3] += jp[c] * xv[c];
+      out[4] += jp[9 + c] * xv[c];
+    }
   }
 #pragma unroll
   for (int m = 0; m < 5; ++m) p.bsO[5 * o + m] = out[m];
@@ -2648,6 +2805,13 @@ template <class S>
 __global__ void k_sub_diag(S* __restrict__ blocks, S excess, int n_cams) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 9 * n_cams) blocks[81 * (i / 9) + 10 * (i % 9)] -= excess;
+}
+
+// out[i] = d[i] * v[i] (out may alias v): the pose scaling applied to a camera-sized vector (compact stage 2)
+template <class S>
+__global__ void k_scale_vec(const S* __restrict__ v, const S* __restrict__ d, S* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = d[i] * v[i];
 }
 
 template <class S>

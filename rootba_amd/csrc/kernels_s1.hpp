@@ -487,7 +487,8 @@ __global__ __launch_bounds__(256) void k_s1_qr_wide(Params<S> p, int lm_begin, i
 constexpr int kS1ColsThreads = 128;
 
 template <class S>
-__global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_t n_obs, int scaled_input) {
+__global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_t n_obs, int scaled_input,
+                                                             int write_jps) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
   using V = typename std::conditional<sizeof(S) == 4, float4, double2>::type;
   constexpr int N = 16 / int(sizeof(S)), NT = kS1ColsThreads;
@@ -587,7 +588,86 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
   };
   // (16-byte alignment of the destinations: o_base is a multiple of 128)
   copy_out(p.topd + kTd * o_base, sT, kTd * n_here);
-  if (!scaled_input) copy_out(p.JpS + 18 * o_base, sJ, 18 * n_here);
+  // (compact stage 2, p.compact: this kernel only materialises the 27 + 9 record for the assembly of the reduced
+  //  matrix / the matrix-free E0 products, from the UNSCALED rows, which stay as they are: write_jps = 0)
+  if (!scaled_input && write_jps) copy_out(p.JpS + 18 * o_base, sJ, 18 * n_here);
+}
+
+// ---------------------------------------------------------------------------
+// Compact stage 2, landmark side (p.compact): everything the fused pass above computes per observation is LINEAR
+// in the two scaled Jacobian entries (m0, m1) of a column:
+//   damped top rows    tt[n] = W'[n][0] m0 + W'[n][1] m1          (n = 0..2)
+//   b record           bm    = g[0] m0 + g[1] m1
+// so the eight coefficients are all that has to leave the landmark side: W8 = [W' row-major | g], obtained by
+// running the same closed form on the unit inputs (1, 0) and (0, 1) instead of on nine columns. The Jacobian rows
+// are neither read nor rewritten here: 32 bytes written per observation instead of 216.
+// ---------------------------------------------------------------------------
+template <class S>
+__global__ __launch_bounds__(256) void k_s2_w8(Params<S> p, int64_t n_obs) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  const int64_t o = blockIdx.x * int64_t(256) + threadIdx.x;
+  if (o >= n_obs) return;
+  const int s = p.obs_lm[o];
+  const V4* __restrict__ vh = reinterpret_cast<const V4*>(p.Vh);
+  const V4 va = vh[2 * o], vb = vh[2 * o + 1];
+  const int64_t o0 = p.lm_obs[s];
+  const V4* __restrict__ lq = reinterpret_cast<const V4*>(p.LQ + 12 * size_t(s));
+  const V4 q0 = lq[0], q1 = lq[1], q2 = lq[2];
+  const V4 w0 = vh[2 * o0], w1 = vh[2 * o0 + 1], w2 = vh[2 * o0 + 2];
+  S g[16];  // the landmark's damping record: c[6], s[6], damping-row residual[3]
+  {
+    const V4* __restrict__ src = reinterpret_cast<const V4*>(p.givens + 16 * size_t(s));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const V4 v = src[q];
+      g[4 * q] = v.x;
+      g[4 * q + 1] = v.y;
+      g[4 * q + 2] = v.z;
+      g[4 * q + 3] = v.w;
+    }
+  }
+  const int i = int(o - o0);
+  const S tau0 = q0.x, tau1 = q0.y, tau2 = q0.z, g10 = q0.w, g20 = q1.x, g21 = q1.y, d0 = q1.z, d1 = q1.w, d2 = q2.x;
+  S out[2][4];  // [input][tt0 tt1 tt2 bm]
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const S m0 = e == 0 ? S(1) : S(0), m1 = e == 0 ? S(0) : S(1);
+    const S c0 = tau0 * (va.x * m0 + vb.x * m1);
+    const S c1 = tau1 * (va.y * m0 + vb.y * m1 - c0 * g10);
+    const S c2 = tau2 * (va.z * m0 + vb.z * m1 - c0 * g20 - c1 * g21);
+    S tt[3] = {-(c0 * w0.x + c1 * w0.y + c2 * w0.z), -(c0 * w1.x + c1 * w1.y + c2 * w1.z),
+               -(c0 * w2.x + c1 * w2.y + c2 * w2.z)};
+    S bm = -(c0 * d0 + c1 * d1 + c2 * d2);
+    if (i == 0) {
+      tt[0] += m0;
+      tt[1] += m1;
+    } else if (i == 1) {
+      tt[2] += m0;
+      bm += m1 * vb.w;
+    } else {
+      bm += m0 * va.w + m1 * vb.w;
+    }
+    S d[3] = {S(0), S(0), S(0)};
+    int idx = 0;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+#pragma unroll
+      for (int m = 0; m <= n; ++m) {
+        const S cc = g[idx], sn = g[6 + idx];
+        const S x = d[n - m], y = tt[n];
+        d[n - m] = cc * x + sn * y;
+        tt[n] = -sn * x + cc * y;
+        ++idx;
+      }
+    }
+    out[e][0] = tt[0];
+    out[e][1] = tt[1];
+    out[e][2] = tt[2];
+    out[e][3] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
+  }
+  V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * o);
+  dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};
+  dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
 }
 
 // b_mid[c] = sum over the camera's observations of bmO (fixed order, double)

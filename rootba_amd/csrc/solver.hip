@@ -205,6 +205,9 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_Y_REPLICAS")) y_rep_ = std::max(1, std::min(64, std::atoi(ev)));
     if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
     if (const char* ev = std::getenv("RBA_HX_LDS")) hx_lds_ = std::atoi(ev);
+    compact_ = staged_;  // compact stage-2 records (W8) + unscaled Jacobian rows; RBA_S2_COMPACT=0: round-2a records
+    if (const char* ev = std::getenv("RBA_S2_COMPACT")) compact_ = staged_ && std::atoi(ev) != 0;
+    if (compact_) y_rep_ = 1;  // (the replica experiment post-processes y itself)
     {
       int dev = 0, cus = 0;
       HIP_CHECK(hipGetDevice(&dev));
@@ -662,6 +665,12 @@ class Solver final : public rba_solver {
     prm_.cams = d_cams_.get();
     prm_.lms = d_lms_.get();
     prm_.lm_inc = mixed_ ? d_lm_inc_.get() : nullptr;
+    if (compact_) {
+      d_W8_.alloc(size_t(8) * n_obs_);
+      d_xs_.alloc(nvec_);
+    }
+    prm_.W8 = d_W8_.get();
+    prm_.compact = compact_ ? 1 : 0;
     prm_.A = d_A_.get();
     prm_.top0 = d_top0_.get();
     prm_.topd = d_topd_.get();
@@ -864,6 +873,7 @@ class Solver final : public rba_solver {
     const bool measure = explicit_auto_ && !asm_measured_ && !asm_pending_;
     if (measure) HIP_CHECK(hipEventRecord(ev_asm0_, stream_));
     if (comm_ || cb_fn_) d_ex_vals_.zero(stream_);  // sharded: blocks without local pairs must be 0
+    ensure_topd();  // compact stage 2: the off-diagonal blocks are built from the 27-scalar rows
     if (ex_n_upper_ > 0) launch_offdiag(prm_.topd, d_ex_vals_.get());
     all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
     // (the diagonal blocks were all-reduced by stage 2 already)
@@ -1337,12 +1347,19 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_stage2_landmark<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_, prm_,
                        lambda);
     sub_mark(&sub_.landmark_damping_time);  // set_landmark_damping(): the six rotations per landmark
-    if (staged_) {
+    if (compact_) {
+      // eight coefficients per observation; the Jacobian rows are neither read nor rewritten (kernels_s1.hpp)
+      hipLaunchKernelGGL((rba::k_s2_w8<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0, stream_, prm_,
+                         int64_t(n_obs_));
+      cols_pending_ = false;
+      topd_valid_ = false;
+      sub_mark(&sub_.scale_pose_jacobian_time);
+    } else if (staged_) {
       // column pass + rotation of the top rows, fused (kernels_s1.hpp), every observation
       hipLaunchKernelGGL((rba::k_s12_cols<S>),
                          dim3(unsigned((n_obs_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
                          dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTd) * sizeof(S), stream_,
-                         prm_, int64_t(n_obs_), cols_pending_ ? 0 : 1);
+                         prm_, int64_t(n_obs_), cols_pending_ ? 0 : 1, 1);
       cols_pending_ = false;
       // scale_Jp_cols() + the column part of the damping (top rows of Q^T Jp rotated, b records)
       sub_mark(&sub_.scale_pose_jacobian_time);
@@ -1497,15 +1514,40 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_cam_gram<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
   }
   void launch_cam_stage2(const rba::Params<float>& prm, float lambda) {
-    hipLaunchKernelGGL((rba::k_cam_stage2_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
-                       lambda);
+    if (compact_)
+      hipLaunchKernelGGL((rba::k_cam_stage2_w8_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_,
+                         prm, lambda);
+    else
+      hipLaunchKernelGGL((rba::k_cam_stage2_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
+                         lambda);
   }
   void launch_cam_stage2(const rba::Params<double>& prm, double lambda) {
-    hipLaunchKernelGGL((rba::k_cam_stage2<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
+    if (compact_)
+      hipLaunchKernelGGL((rba::k_cam_stage2_w8<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
+    else
+      hipLaunchKernelGGL((rba::k_cam_stage2<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
+  }
+  // compact stage 2: the 27 + 9 records of the current damping, for the consumers that still read them (assembly of
+  // the reduced matrix, matrix-free E0 products): the round-2a column pass on the unscaled rows, nothing rewritten
+  void ensure_topd() {
+    if (!compact_ || topd_valid_) return;
+    hipLaunchKernelGGL((rba::k_s12_cols<S>),
+                       dim3(unsigned((n_obs_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
+                       dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTd) * sizeof(S), stream_,
+                       prm_, int64_t(n_obs_), 0, 0);
+    topd_valid_ = true;
+  }
+  // x -> D x for the kernels that read the unscaled Jacobian rows (compact stage 2)
+  const S* scaled_operand(const S* x) {
+    if (!compact_) return x;
+    hipLaunchKernelGGL((rba::k_scale_vec<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, x, prm_.pose_scaling,
+                       d_xs_.get(), nvec_);
+    return d_xs_.get();
   }
 
   // y += E0 v over the local landmarks (power-series preconditioner)
   void launch_e0(const S* v, S* y, const int* done_flag) {
+    ensure_topd();
     S* const y_out = y;
     if (prm_.y_rep > 1) {
       d_yrep_.zero(stream_);
@@ -1535,41 +1577,52 @@ class Solver final : public rba_solver {
     return it;
   }
 
-  // same operator from the factors (k_hx_implicit); long tracks use the dense kernel
+  // same operator from the factors; long tracks use the workgroup-per-landmark kernels.
+  // y must be ZERO on entry (every caller zeroes its target: right_multiply, k_pcg_a2, k_pcg_b2).
+  // Compact stage 2: the Jacobian rows are unscaled, so the kernels get D x and their sums are multiplied by D -
+  // inside the LDS kernel where the sums leave the workgroup, by one vector kernel for the others.
   void launch_hx_implicit(const S* x, S* y, const int* done_flag) {
-    if (n_big_ > 0 && staged_)
+    const S* xin = scaled_operand(x);
+    const S* dout = compact_ ? prm_.pose_scaling : nullptr;
+    bool unscaled_adds = false;
+    if (n_big_ > 0 && staged_) {
       hipLaunchKernelGGL((rba::k_hx_implicit_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
-                         d_big_scratch_.get(), d_big_off_.get(), x, y, done_flag);
-    else if (n_big_ > 0)
+                         d_big_scratch_.get(), d_big_off_.get(), xin, y, done_flag);
+      unscaled_adds = true;
+    } else if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_hx_big<S>), dim3(n_big_), dim3(256), size_t(18) * big_kmax_ * sizeof(S),
                          stream_, prm_, big_begin_, x, y, done_flag);
-    if (imp_end_[6] > imp_begin_[6])
+    if (imp_end_[6] > imp_begin_[6]) {
       hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 4>), dim3((imp_end_[6] - imp_begin_[6] + 3) / 4),
-                         dim3(256), 0, stream_, prm_, imp_begin_[6], imp_end_[6], x, y, done_flag);
-    if (imp_end_[5] > imp_begin_[5])
+                         dim3(256), 0, stream_, prm_, imp_begin_[6], imp_end_[6], xin, y, done_flag);
+      unscaled_adds = true;
+    }
+    if (imp_end_[5] > imp_begin_[5]) {
       hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 2>), dim3((imp_end_[5] - imp_begin_[5] + 3) / 4),
-                         dim3(256), 0, stream_, prm_, imp_begin_[5], imp_end_[5], x, y, done_flag);
-    if (n_tiles_ > 0) {
-      rba::ImplicitTiles it;
-      for (int c = 0; c < 5; ++c) {
-        it.tile_begin[c] = imp_tile_begin_[c];
-        it.lm_begin[c] = imp_begin_[c];
-        it.lm_end[c] = imp_end_[c];
+                         dim3(256), 0, stream_, prm_, imp_begin_[5], imp_end_[5], xin, y, done_flag);
+      unscaled_adds = true;
+    }
+    const bool use_lds = n_tiles_ > 0 && hx_lds_ && (hx_lds_ == 2 || (n_tiles_ >= 16 * n_cus_ && hx_coverage_ >= 0.9));
+    rba::ImplicitTiles it = implicit_tiles();
+    if (n_tiles_ > 0 && !use_lds) {
+      hipLaunchKernelGGL((rba::k_hx_implicit<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, it, xin, y,
+                         done_flag);
+      unscaled_adds = true;
+    }
+    if (compact_ && unscaled_adds)
+      hipLaunchKernelGGL((rba::k_scale_vec<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y,
+                         prm_.pose_scaling, y, nvec_);
+    if (use_lds) {
+      // workgroup-private window of y in LDS (double accumulators, ds_add_f64), one persistent 1024-thread
+      // workgroup per CU
+      const size_t ylds_bytes = size_t(9) * hx_win_ * sizeof(double);
+      if (!hx_lds_attr_set_) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_implicit_lds<S>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(kHxLdsMaxBytes)));
+        hx_lds_attr_set_ = true;
       }
-      it.tile_begin[5] = n_tiles_;
-      const int wgs = (n_tiles_ + 3) / 4;
-      const size_t ylds_bytes = size_t(9) * hx_win_ * sizeof(double);  // double accumulators (ds_add_f64)
-      if (hx_lds_ && (hx_lds_ == 2 || (n_tiles_ >= 16 * n_cus_ && hx_coverage_ >= 0.9))) {
-        // workgroup-private window of y in LDS, one persistent 1024-thread workgroup per CU
-        if (!hx_lds_attr_set_) {
-          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_implicit_lds<S>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(kHxLdsMaxBytes)));
-          hx_lds_attr_set_ = true;
-        }
-        hipLaunchKernelGGL((rba::k_hx_implicit_lds<S>), dim3(n_hx_chunks_), dim3(1024), ylds_bytes, stream_, prm_, it,
-                           d_hx_chunks_.get(), hx_win_, x, y, done_flag);
-      } else
-        hipLaunchKernelGGL((rba::k_hx_implicit<S>), dim3(wgs), dim3(256), 0, stream_, prm_, it, x, y, done_flag);
+      hipLaunchKernelGGL((rba::k_hx_implicit_lds<S>), dim3(n_hx_chunks_), dim3(1024), ylds_bytes, stream_, prm_, it,
+                         d_hx_chunks_.get(), hx_win_, xin, y, dout, done_flag);
     }
   }
 
@@ -1919,15 +1972,16 @@ class Solver final : public rba_solver {
       // tiled landmarks (k <= 32, implicit-Q configuration): one lane-per-row pass; the rest: two passes
       int lm0 = 0;
       int64_t o0 = 0;
+      const S* xin = scaled_operand(d_inc_.get());  // compact stage 2: D inc for the unscaled Jacobian rows
       if (staged_ && n_tiles_ > 0 && !bs_two_pass_) {
         hipLaunchKernelGGL((rba::k_bs_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, implicit_tiles(),
-                           d_inc_.get());
+                           xin);
         lm0 = imp_end_[4];
         o0 = n_obs_tiled_;
       }
       if (o0 < n_obs_) {
         hipLaunchKernelGGL((rba::k_bs_obs<S>), dim3(unsigned((n_obs_ - o0 + 255) / 256)), dim3(256), 0, stream_, prm_,
-                           d_inc_.get(), o0, int64_t(n_obs_));
+                           xin, o0, int64_t(n_obs_));
         if (big_begin_ > lm0)
           hipLaunchKernelGGL((rba::k_bs_landmark<S>), dim3((big_begin_ - lm0 + 255) / 256), dim3(256), 0, stream_,
                              prm_, lm0, big_begin_);
@@ -2241,7 +2295,10 @@ class Solver final : public rba_solver {
         m->stage1 = 2 * geometry_in + no * 4 /* CSC */ + no * (27 + 18 + 9 + 6 + 2 + 8) * s + nl * 12 * s +
                     storage_dense_bytes_ + no * (27 * s + 4) /* camera-major read of JpS, bmO */ + nc * (9 + 90) * s;
       }
-      if (opt_.implicit_q)  // landmark records; fused column pass: JpS 18 + Vh 8 in, topd 27 + JpS 18 + bO 9 out; camera pass
+      if (compact_)  // landmark records; W8 pass: Vh 8 in, W8 8 out; camera pass: JpS 18 + W8 8 (+ CSC index) in
+        m->stage2 = nl * (6 + 3 + 16 + 6 + 3 + 3 + 9 + 12) * s + no * (8 + 8) * s + no * 8 + no * ((18 + 8) * s + 4) +
+                    nc * 180 * s;
+      else if (opt_.implicit_q)  // landmark records; fused column pass: JpS 18 + Vh 8 in, topd 27 + JpS 18 + bO 9 out; camera pass
         m->stage2 = nl * (6 + 3 + 16 + 6 + 3 + 3 + 9 + 12) * s + no * ((18 + 8) + (27 + 18 + 9)) * s + no * 8 +
                     no * ((27 + 9) * s + 4) + nc * 180 * s;
       else
@@ -2253,6 +2310,8 @@ class Solver final : public rba_solver {
     const int64_t nnz = sc_ ? sc_nnz_ : ex_nnz_;
     m->product_assembled = nnz * (81 * s + 4) + nc * 18 * s;
     m->assembly = sc_ ? sc_assemble_bytes_ : ex_pairs_ * (8 + 54 * s) + nnz * 81 * s;
+    if (compact_ && !sc_)  // + the column pass that materialises the 27 + 9 records: JpS 18 + Vh 8 in, 36 out
+      m->assembly += int64_t(n_obs_) * (18 + 8 + 36) * s;
     m->pcg_vectors = nc * (81 + 10 * 9) * s;
   }
   void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) override {
@@ -2384,6 +2443,9 @@ class Solver final : public rba_solver {
   bool bs_two_pass_ = false;  // RBA_BS_TWO_PASS=1: round-1 back-substitution kernels for every landmark
   int hx_lds_ = 1;            // RBA_HX_LDS=0: never use the LDS-private y copy (k_hx_implicit_lds); 2: whenever y fits
                               // (default 1: when it fits and every wave gets at least four tiles)
+  bool compact_ = false;     // stage 2 hands W8 (8 scalars per observation) to the camera pass, JpS stays unscaled
+  bool topd_valid_ = false;  // compact: the 27 + 9 records exist for the current damping (assembly / E0 products only)
+  DevBuf<S> d_W8_, d_xs_;
   rba_substage_timings sub_{};
   std::vector<hipEvent_t> sub_events_;
   std::vector<double*> sub_fields_;
