@@ -1490,7 +1490,7 @@ template <class S, int P2>
 __device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, int t_in_class,
                                                  int lm_begin, int lm_end, const S* __restrict__ x,
                                                  S* __restrict__ y, S* yb, int* cb, int lane,
-                                                 int done) {
+                                                 int done, const S* __restrict__ dout) {
   constexpr int LPW = 64 / P2;  // landmarks per wavefront (= per tile)
   const int seg = lane / P2, r = lane - P2 * seg;
   const int s = lm_begin + t_in_class * LPW + seg;
@@ -1565,7 +1565,7 @@ __device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, i
     if (e < 288) {
       const int ol = e / 9, c = e - 9 * ol;
       const int cc = cb[ol];
-      if (cc >= 0 && !done) atomic_add(y + 9 * cc + c, yb[e]);
+      if (cc >= 0 && !done) atomic_add(y + 9 * cc + c, dout ? yb[e] * dout[9 * cc + c] : yb[e]);
     }
   }
 }
@@ -1574,6 +1574,7 @@ __device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, i
 template <class S>
 __global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, ImplicitTiles it,
                                                      const S* __restrict__ x, S* __restrict__ y,
+                                                     const S* __restrict__ dout,
                                                      const int* __restrict__ done_flag) {
   __shared__ S ybuf[4][32 * 9 + 8];
   __shared__ int cbuf[4][32];
@@ -1587,15 +1588,15 @@ __global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, ImplicitTiles 
   S* yb = ybuf[wave];
   int* cb = cbuf[wave];
   if (T >= it.tile_begin[4])
-    hx_implicit_tile<S, 64>(p, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], x, y, yb, cb, lane, done);
+    hx_implicit_tile<S, 64>(p, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], x, y, yb, cb, lane, done, dout);
   else if (T >= it.tile_begin[3])
-    hx_implicit_tile<S, 32>(p, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], x, y, yb, cb, lane, done);
+    hx_implicit_tile<S, 32>(p, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], x, y, yb, cb, lane, done, dout);
   else if (T >= it.tile_begin[2])
-    hx_implicit_tile<S, 16>(p, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], x, y, yb, cb, lane, done);
+    hx_implicit_tile<S, 16>(p, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], x, y, yb, cb, lane, done, dout);
   else if (T >= it.tile_begin[1])
-    hx_implicit_tile<S, 8>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], x, y, yb, cb, lane, done);
+    hx_implicit_tile<S, 8>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], x, y, yb, cb, lane, done, dout);
   else
-    hx_implicit_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], x, y, yb, cb, lane, done);
+    hx_implicit_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], x, y, yb, cb, lane, done, dout);
 }
 
 // ---------------------------------------------------------------------------
@@ -1832,7 +1833,7 @@ __global__ __launch_bounds__(1024) void k_hx_implicit_lds(Params<S> p, ImplicitT
 template <class S, int RCH>
 __global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_begin, int lm_end,
                                                           const S* __restrict__ x,
-                                                          S* __restrict__ y,
+                                                          S* __restrict__ y, const S* __restrict__ dout,
                                                           const int* __restrict__ done_flag) {
   __shared__ S ybuf[4][32 * 9 + 8];
   __shared__ int cbuf[4][32];
@@ -1913,7 +1914,7 @@ __global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_be
       if (e < 288) {
         const int ol = e / 9, c = e - 9 * ol;
         const int cc = cb[ol];
-        if (cc >= 0) atomic_add(y + 9 * cc + c, yb[e]);
+        if (cc >= 0) atomic_add(y + 9 * cc + c, dout ? yb[e] * dout[9 * cc + c] : yb[e]);
       }
     }
     wave_lds_fence();
@@ -2196,6 +2197,47 @@ __global__ __launch_bounds__(256) void k_bs_landmark(Params<S> p, int lm_begin, 
                    is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) && is_finite(p.lms[3 * s + 2]);
   if (!fin) atomicOr(p.fail_flag, 2);
   apply_landmark_increment(p, s, inc);
+}
+
+// the same, one WAVEFRONT per landmark (lanes run over the observations): for the few landmarks with 32 < k <= 112
+// of the staged configuration, where a thread per landmark is a handful of workgroups walking ~100 rows serially
+template <class S>
+__global__ __launch_bounds__(256) void k_bs_landmark_wave(Params<S> p, int lm_begin, int lm_end) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;
+  const int64_t ob = p.lm_obs[s], oe = p.lm_obs[s + 1];
+  S r0 = S(0), r1 = S(0), r2 = S(0);
+  for (int64_t o = ob + lane; o < oe; o += 64) {
+    r0 += p.bsO[5 * o];
+    r1 += p.bsO[5 * o + 1];
+    r2 += p.bsO[5 * o + 2];
+  }
+  S rhs[3] = {p.q1trd[3 * s] + wave_sum(r0), p.q1trd[3 * s + 1] + wave_sum(r1), p.q1trd[3 * s + 2] + wave_sum(r2)};
+  const S* Rd = p.Rd + 6 * s;
+  S inc[3];
+  inc[2] = rhs[2] / Rd[5];
+  inc[1] = (rhs[1] - Rd[4] * inc[2]) / Rd[3];
+  inc[0] = (rhs[0] - Rd[1] * inc[1] - Rd[2] * inc[2]) / Rd[0];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) inc[m] = -inc[m];
+  S acc = S(0);
+  for (int64_t o = ob + lane; o < oe; o += 64) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const S* jl = p.JlS + 6 * o + 3 * r;
+      const S v = p.bsO[5 * o + 3 + r] + jl[0] * inc[0] + jl[1] * inc[1] + jl[2] * inc[2];
+      acc += v * (S(0.5) * v + p.rS[2 * o + r]);
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    p.lm_ldiff[s] = -double(acc);
+    const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) && is_finite(acc) &&
+                     is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) && is_finite(p.lms[3 * s + 2]);
+    if (!fin) atomicOr(p.fail_flag, 2);
+    apply_landmark_increment(p, s, inc);
+  }
 }
 
 // The same back-substitution for the tiled landmarks (k <= 32) in ONE pass, lane per block row
@@ -2635,7 +2677,8 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_rho(const S* __restrict__ r
 template <class S>
 __global__ __launch_bounds__(kPcgThreads) void k_pcg_a2(const S* __restrict__ z, S* __restrict__ pvec,
                                                        S* __restrict__ q, int n, CgState* st,
-                                                       const double* __restrict__ partial) {
+                                                       const double* __restrict__ partial,
+                                                       const S* __restrict__ dscale, S* __restrict__ pscaled) {
   if (st->done) return;
   const int iter = st->iter;
   const double rho = pcg_sum_partials(partial);
@@ -2662,7 +2705,9 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_a2(const S* __restrict__ z,
   if (stop) return;
   const S bs = S(beta);
   for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
-    pvec[i] = iter == 0 ? z[i] : z[i] + bs * pvec[i];
+    const S pn = iter == 0 ? z[i] : z[i] + bs * pvec[i];
+    pvec[i] = pn;
+    if (pscaled) pscaled[i] = dscale[i] * pn;  // compact stage 2: the operand of the matrix-free product is D p
     q[i] = S(0);
   }
 }

@@ -459,6 +459,7 @@ template <class S>
 __global__ __launch_bounds__(256) void k_hx_implicit_big(Params<S> p, int lm_begin, S* __restrict__ scratch,
                                                          const int64_t* __restrict__ scratch_off,
                                                          const S* __restrict__ x, S* __restrict__ y,
+                                                         const S* __restrict__ dout,
                                                          const int* __restrict__ done_flag) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
   __shared__ S sm[12];
@@ -520,7 +521,9 @@ __global__ __launch_bounds__(256) void k_hx_implicit_big(Params<S> p, int lm_beg
   for (int j = tid; j < 9 * (nrows / 2); j += 256) {
     const int i = j / 9, c = j - 9 * i;
     const S* __restrict__ jp = p.JpS + 18 * (o0 + i);
-    atomic_add(y + 9 * p.obs_cam[o0 + i] + c, jp[c] * U[2 * i] + jp[9 + c] * U[2 * i + 1]);
+    const int yi = 9 * p.obs_cam[o0 + i] + c;
+    const S w = jp[c] * U[2 * i] + jp[9 + c] * U[2 * i + 1];
+    atomic_add(y + yi, dout ? w * dout[yi] : w);
   }
 }
 

@@ -1540,6 +1540,7 @@ class Solver final : public rba_solver {
   // x -> D x for the kernels that read the unscaled Jacobian rows (compact stage 2)
   const S* scaled_operand(const S* x) {
     if (!compact_) return x;
+    if (operand_prescaled_) return d_xs_.get();  // the producer of x wrote D x already (k_pcg_a2)
     hipLaunchKernelGGL((rba::k_scale_vec<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, x, prm_.pose_scaling,
                        d_xs_.get(), nvec_);
     return d_xs_.get();
@@ -1578,40 +1579,28 @@ class Solver final : public rba_solver {
   }
 
   // same operator from the factors; long tracks use the workgroup-per-landmark kernels.
-  // y must be ZERO on entry (every caller zeroes its target: right_multiply, k_pcg_a2, k_pcg_b2).
-  // Compact stage 2: the Jacobian rows are unscaled, so the kernels get D x and their sums are multiplied by D -
-  // inside the LDS kernel where the sums leave the workgroup, by one vector kernel for the others.
+  // Compact stage 2: the Jacobian rows are unscaled, so the kernels get D x and multiply what they add to y by D
+  // (the LDS kernel where its sums leave the workgroup, the others per scatter-add).
   void launch_hx_implicit(const S* x, S* y, const int* done_flag) {
     const S* xin = scaled_operand(x);
     const S* dout = compact_ ? prm_.pose_scaling : nullptr;
-    bool unscaled_adds = false;
-    if (n_big_ > 0 && staged_) {
+    if (n_big_ > 0 && staged_)
       hipLaunchKernelGGL((rba::k_hx_implicit_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
-                         d_big_scratch_.get(), d_big_off_.get(), xin, y, done_flag);
-      unscaled_adds = true;
-    } else if (n_big_ > 0)
+                         d_big_scratch_.get(), d_big_off_.get(), xin, y, dout, done_flag);
+    else if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_hx_big<S>), dim3(n_big_), dim3(256), size_t(18) * big_kmax_ * sizeof(S),
                          stream_, prm_, big_begin_, x, y, done_flag);
-    if (imp_end_[6] > imp_begin_[6]) {
+    if (imp_end_[6] > imp_begin_[6])
       hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 4>), dim3((imp_end_[6] - imp_begin_[6] + 3) / 4),
-                         dim3(256), 0, stream_, prm_, imp_begin_[6], imp_end_[6], xin, y, done_flag);
-      unscaled_adds = true;
-    }
-    if (imp_end_[5] > imp_begin_[5]) {
+                         dim3(256), 0, stream_, prm_, imp_begin_[6], imp_end_[6], xin, y, dout, done_flag);
+    if (imp_end_[5] > imp_begin_[5])
       hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 2>), dim3((imp_end_[5] - imp_begin_[5] + 3) / 4),
-                         dim3(256), 0, stream_, prm_, imp_begin_[5], imp_end_[5], xin, y, done_flag);
-      unscaled_adds = true;
-    }
+                         dim3(256), 0, stream_, prm_, imp_begin_[5], imp_end_[5], xin, y, dout, done_flag);
     const bool use_lds = n_tiles_ > 0 && hx_lds_ && (hx_lds_ == 2 || (n_tiles_ >= 16 * n_cus_ && hx_coverage_ >= 0.9));
     rba::ImplicitTiles it = implicit_tiles();
-    if (n_tiles_ > 0 && !use_lds) {
+    if (n_tiles_ > 0 && !use_lds)
       hipLaunchKernelGGL((rba::k_hx_implicit<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, it, xin, y,
-                         done_flag);
-      unscaled_adds = true;
-    }
-    if (compact_ && unscaled_adds)
-      hipLaunchKernelGGL((rba::k_scale_vec<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y,
-                         prm_.pose_scaling, y, nvec_);
+                         dout, done_flag);
     if (use_lds) {
       // workgroup-private window of y in LDS (double accumulators, ds_add_f64), one persistent 1024-thread
       // workgroup per CU
@@ -1920,9 +1909,14 @@ class Solver final : public rba_solver {
         hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(),
                            d_r_.get(), d_z_.get(), n, st, part_rho);
       }
+      // (compact stage 2 and a matrix-free product next: the direction update also writes D p for it)
+      const bool pre = compact_ && !ex_active_;
       hipLaunchKernelGGL((rba::k_pcg_a2<S>), dim3(NB), dim3(T), 0, stream_, d_z_.get(), d_p_.get(),
-                         d_q_.get(), n, st, part_rho);
+                         d_q_.get(), n, st, part_rho, static_cast<const S*>(pre ? prm_.pose_scaling : nullptr),
+                         pre ? d_xs_.get() : static_cast<S*>(nullptr));
+      operand_prescaled_ = pre;
       launch_hx(d_p_.get(), d_q_.get(), done);
+      operand_prescaled_ = false;
       if (!ex_active_) all_reduce(d_q_.get(), n);
       hipLaunchKernelGGL((rba::k_pcg_b1<S>), dim3(NB), dim3(T), 0, stream_, d_p_.get(), d_q_.get(),
                          lambda, n, st, part_pq);
@@ -1982,7 +1976,10 @@ class Solver final : public rba_solver {
       if (o0 < n_obs_) {
         hipLaunchKernelGGL((rba::k_bs_obs<S>), dim3(unsigned((n_obs_ - o0 + 255) / 256)), dim3(256), 0, stream_, prm_,
                            xin, o0, int64_t(n_obs_));
-        if (big_begin_ > lm0)
+        if (big_begin_ > lm0 && lm0 > 0)  // only 32 < k <= 112 left: a wavefront per landmark
+          hipLaunchKernelGGL((rba::k_bs_landmark_wave<S>), dim3((big_begin_ - lm0 + 3) / 4), dim3(256), 0, stream_,
+                             prm_, lm0, big_begin_);
+        else if (big_begin_ > lm0)
           hipLaunchKernelGGL((rba::k_bs_landmark<S>), dim3((big_begin_ - lm0 + 255) / 256), dim3(256), 0, stream_,
                              prm_, lm0, big_begin_);
         if (n_big_ > 0)
@@ -2443,6 +2440,7 @@ class Solver final : public rba_solver {
   bool bs_two_pass_ = false;  // RBA_BS_TWO_PASS=1: round-1 back-substitution kernels for every landmark
   int hx_lds_ = 1;            // RBA_HX_LDS=0: never use the LDS-private y copy (k_hx_implicit_lds); 2: whenever y fits
                               // (default 1: when it fits and every wave gets at least four tiles)
+  bool operand_prescaled_ = false;
   bool compact_ = false;     // stage 2 hands W8 (8 scalars per observation) to the camera pass, JpS stays unscaled
   bool topd_valid_ = false;  // compact: the 27 + 9 records exist for the current damping (assembly / E0 products only)
   DevBuf<S> d_W8_, d_xs_;
