@@ -615,20 +615,27 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
 //   blocks[c] = B_mid[c] - D T_c D + lambda I,  b[c] = D t_c           (B_mid = D G D from stage 1)
 // float: X^T X on the matrix cores, both records of 32 observations staged in LDS per wave.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cam_stage2_w8_mfma(Params<float> p, float lambda) {
+// GRAM: the first stage 2 of a linearisation point on one GPU also forms G_c = sum Jp^T Jp from the same staged rows
+// (the stage-1 Gram pass is then skipped - one gather of the Jacobian rows instead of two): Jp_diag2, the pose scaling
+// D = 1 / (eps + sqrt(Jp_diag2)) and B_mid = D G D are written here, before blocks / b use them.
+// (`GRAM` is a run-time flag, not a template parameter: one instruction stream for the shared part, so the fused and
+//  the two-pass form produce bit-identical blocks and b.)
+__global__ __launch_bounds__(256) void k_cam_stage2_w8_mfma(Params<float> p, float lambda, int GRAM) {
   constexpr int RW = 26;  // staged record: [Jp 18 | W' 6 | g 2]
   __shared__ float tile[4][16][16];
   __shared__ double bsum[4][7][9];
+  __shared__ double dsum[4][7][9];
+  __shared__ float dsc[9];
   __shared__ __attribute__((aligned(16))) float stage[4][kCamChunk * RW + 6];
   const int c = xcd_swizzled_camera(p.n_cams);
   if (c >= p.n_cams) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accG = {0.f, 0.f, 0.f, 0.f};
   const bool want_gram = !p.jacobi || p.want_sdiag;
   const int i = lane & 15, kk = lane >> 4;
   const int g = lane / 9, a = lane - 9 * g;
-  double accb = 0;
+  double accb = 0, accd = 0;
   float* lds = stage[wave];
   for (int64_t base = t0 + kCamChunk * wave; base < t1; base += 4 * kCamChunk) {
     const int cnt = int(min<int64_t>(kCamChunk, t1 - base));
@@ -658,51 +665,100 @@ __global__ __launch_bounds__(256) void k_cam_stage2_w8_mfma(Params<float> p, flo
       for (int s = 0; s < cnt; ++s) {
         const float* rec = lds + s * RW;
         float v = 0.f;
-        if (i < 9 && kk < 3) v = rec[18 + 2 * kk] * rec[i] + rec[19 + 2 * kk] * rec[9 + i];
+        // (explicit fma / rounding in this kernel: both instantiations and the two-pass form must agree bit for bit)
+        if (i < 9 && kk < 3) v = fmaf(rec[18 + 2 * kk], rec[i], __fmul_rn(rec[19 + 2 * kk], rec[9 + i]));
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, acc, 0, 0, 0);
+      }
+    }
+    if (GRAM) {
+      for (int s = 0; s < cnt; s += 2) {  // two observations (4 rows) per instruction
+        const int so = s + (kk >> 1);
+        const float v = (i < 9 && so < cnt) ? lds[so * RW + 9 * (kk & 1) + i] : 0.f;
+        accG = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, accG, 0, 0, 0);
       }
     }
     if (lane < 63)
       for (int r = g; r < cnt; r += 7) {
         const float* rec = lds + r * RW;
-        accb += double(rec[a] * rec[24] + rec[9 + a] * rec[25]);
+        accb += double(fmaf(rec[a], rec[24], __fmul_rn(rec[9 + a], rec[25])));
+        if (GRAM) accd += double(fmaf(rec[a], rec[a], __fmul_rn(rec[9 + a], rec[9 + a])));
       }
     wave_lds_fence();  // the next chunk overwrites the staging buffer
   }
+  if (lane < 63) {
+    bsum[wave][g][a] = accb;
+    if (GRAM) dsum[wave][g][a] = accd;
+  }
+  if (GRAM) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = accG[r];
+  }
+  __syncthreads();
+  float gsum = 0.f;
+  if (GRAM) {
+    if (tid < 81) {
+      const int ii = tid / 9, jj = tid - 9 * ii;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) gsum += tile[w][ii][jj];
+    }
+    if (tid >= 128 && tid < 137) {
+      const int aa = tid - 128;
+      double sum = 0;
+      for (int w = 0; w < 4; ++w)
+        for (int gg = 0; gg < 7; ++gg) sum += dsum[w][gg][aa];
+      const float d2 = float(sum);
+      p.jp_diag2[9 * c + aa] = d2;
+      const float sc = 1.f / (p.eps + sqrtf(d2));  // k_pose_scaling
+      p.pose_scaling[9 * c + aa] = sc;
+      dsc[aa] = sc;
+    }
+    __syncthreads();
+  } else if (tid < 9) {
+    dsc[tid] = p.pose_scaling[9 * c + tid];
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-  if (lane < 63) bsum[wave][g][a] = accb;
   __syncthreads();
   if (tid < 81) {
     const int ii = tid / 9, jj = tid - 9 * ii;
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) t += tile[w][ii][jj];
-    t *= p.pose_scaling[9 * c + ii] * p.pose_scaling[9 * c + jj];
-    const float bm = p.B_mid[81 * c + tid];
-    p.blocks[81 * c + tid] = (p.jacobi ? bm : bm - t) + (ii == jj ? lambda : 0.f);
-    if (p.want_sdiag) p.sdiag[81 * c + tid] = bm - t;
+    const float dd = dsc[ii] * dsc[jj];
+    t = __fmul_rn(t, dd);
+    float bm;
+    if (GRAM) {
+      bm = __fmul_rn(gsum, dd);  // k_scale_gram (own rounding: no contraction with the subtraction below, so the
+                                 // result is bit-identical to the two-pass form)
+      p.B_mid[81 * c + tid] = bm;
+    } else {
+      bm = p.B_mid[81 * c + tid];
+    }
+    const float bt = __fsub_rn(bm, t);
+    p.blocks[81 * c + tid] = (p.jacobi ? bm : bt) + (ii == jj ? lambda : 0.f);
+    if (p.want_sdiag) p.sdiag[81 * c + tid] = bt;
   }
   if (tid >= 128 && tid < 137) {
     const int aa = tid - 128;
     double sum = 0.0;
     for (int w = 0; w < 4; ++w)
       for (int gg = 0; gg < 7; ++gg) sum += bsum[w][gg][aa];
-    p.b[9 * c + aa] = float(sum * double(p.pose_scaling[9 * c + aa]));
+    p.b[9 * c + aa] = float(sum * double(dsc[aa]));
   }
 }
 
 // generic (double): records staged per workgroup, double accumulators
 template <class S>
-__global__ __launch_bounds__(256) void k_cam_stage2_w8(Params<S> p, S lambda) {
+__global__ __launch_bounds__(256) void k_cam_stage2_w8(Params<S> p, S lambda, int GRAM) {
   constexpr int TILE = 64, RW = 26;
   __shared__ S rec[TILE][RW];
   __shared__ int olist[TILE];
-  __shared__ double red[3][81];
+  __shared__ double red[3][81], redG[3][81];
+  __shared__ double dsc[9];
   const int c = blockIdx.x;
   const int tid = threadIdx.x;
   const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
-  double acc = 0;
+  double acc = 0, accG = 0;
   const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
   for (int64_t base = t0; base < t1; base += TILE) {
     const int n = int(min<int64_t>(TILE, t1 - base));
@@ -715,31 +771,57 @@ __global__ __launch_bounds__(256) void k_cam_stage2_w8(Params<S> p, S lambda) {
     }
     __syncthreads();
     if (grp < 3) {
-      if (!p.jacobi || p.want_sdiag) {
-        for (int q = grp; q < n; q += 3) {
-          const S* r = rec[q];
+      for (int q = grp; q < n; q += 3) {
+        const S* r = rec[q];
+        if (!p.jacobi || p.want_sdiag) {
           S t = S(0);
 #pragma unroll
           for (int m = 0; m < 3; ++m)
             t += (r[18 + 2 * m] * r[ea] + r[19 + 2 * m] * r[9 + ea]) * (r[18 + 2 * m] * r[eb] + r[19 + 2 * m] * r[9 + eb]);
           acc -= double(t);
         }
+        if (GRAM) accG += double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb]);
       }
     } else if (tid < 252) {
       const int a = tid - 243;
       for (int q = 0; q < n; ++q) acc += double(rec[q][a] * rec[q][24] + rec[q][9 + a] * rec[q][25]);
     }
   }
-  if (grp < 3) red[grp][e] = acc;
+  if (grp < 3) {
+    red[grp][e] = acc;
+    if (GRAM) redG[grp][e] = accG;
+  }
+  __syncthreads();
+  double gsum = 0;
+  if (GRAM) {
+    if (tid < 81) {
+      gsum = redG[0][tid] + redG[1][tid] + redG[2][tid];
+      if (tid / 9 == tid % 9) {
+        const S d2 = S(gsum);
+        p.jp_diag2[9 * c + tid / 9] = d2;
+        const S sc = S(1) / (p.eps + sqrt(d2));
+        p.pose_scaling[9 * c + tid / 9] = sc;
+        dsc[tid / 9] = double(sc);
+      }
+    }
+  } else if (tid < 9) {
+    dsc[tid] = double(p.pose_scaling[9 * c + tid]);
+  }
   __syncthreads();
   if (tid < 81) {
-    const double gram = (red[0][tid] + red[1][tid] + red[2][tid]) * double(p.pose_scaling[9 * c + tid / 9]) *
-                        double(p.pose_scaling[9 * c + tid % 9]);  // = - D (sum X^T X) D
-    p.blocks[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + (p.jacobi ? 0.0 : gram) +
-                               ((tid / 9 == tid % 9) ? double(lambda) : 0.0));
-    if (p.want_sdiag) p.sdiag[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + gram);
+    const double dd = dsc[tid / 9] * dsc[tid % 9];
+    const double gram = (red[0][tid] + red[1][tid] + red[2][tid]) * dd;  // = - D (sum X^T X) D
+    double bm;
+    if (GRAM) {
+      bm = double(S(gsum) * S(dd));  // as k_scale_gram applied to the stored Gram block
+      p.B_mid[81 * c + tid] = S(bm);
+    } else {
+      bm = double(p.B_mid[81 * c + tid]);
+    }
+    p.blocks[81 * c + tid] = S(bm + (p.jacobi ? 0.0 : gram) + ((tid / 9 == tid % 9) ? double(lambda) : 0.0));
+    if (p.want_sdiag) p.sdiag[81 * c + tid] = S(bm + gram);
   }
-  if (tid >= 243 && tid < 252) p.b[9 * c + (tid - 243)] = S(acc * double(p.pose_scaling[9 * c + (tid - 243)]));
+  if (tid >= 243 && tid < 252) p.b[9 * c + (tid - 243)] = S(acc * dsc[tid - 243]);
 }
 
 // pose_jacobian_scaling = 1 / (eps + sqrt(Jp_diag2))   (linearizor_qr.cpp:130-132)

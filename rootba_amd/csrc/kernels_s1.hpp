@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_cam_gram_mfma(Params<float> p) {
                                  if (lane < 63)
                                    for (int r = g; r < cnt; r += 7) {
                                      const float x0 = rec[r * 18 + a], x1 = rec[r * 18 + 9 + a];
-                                     accd += double(x0 * x0 + x1 * x1);
+                                     accd += double(fmaf(x0, x0, __fmul_rn(x1, x1)));  // as in k_cam_stage2_w8_mfma<true>
                                    }
                                });
 #pragma unroll

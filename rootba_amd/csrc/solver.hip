@@ -207,6 +207,7 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_HX_LDS")) hx_lds_ = std::atoi(ev);
     compact_ = staged_;  // compact stage-2 records (W8) + unscaled Jacobian rows; RBA_S2_COMPACT=0: round-2a records
     if (const char* ev = std::getenv("RBA_S2_COMPACT")) compact_ = staged_ && std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("RBA_FUSED_GRAM")) fused_gram_ = std::atoi(ev) != 0;
     if (compact_) y_rep_ = 1;  // (the replica experiment post-processes y itself)
     {
       int dev = 0, cus = 0;
@@ -1256,17 +1257,24 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256),
                          256 * 26 * sizeof(S), stream_, prm_, int64_t(n_obs_));
       sub_mark(&sub_.jacobian_evaluation_time);  // linearize_problem()
-      launch_cam_gram(prm_);
+      // One GPU, compact stage 2: the Gram pass (Jp_diag2, pose scaling, B_mid) is folded into the camera-major
+      // pass of the first stage 2, which gathers the same Jacobian rows anyway (k_cam_stage2_w8*<GRAM>). Not when
+      // the caller wants Jp_diag2 now, with more than one rank (Jp_diag2 is all-reduced before it is used) or
+      // with the unstaged sub-stage timers.
+      gram_pending_ = fused_gram_ && compact_ && !comm_ && !cb_fn_ && !jp_diag2_out && !sub_timing();
+      if (!gram_pending_) launch_cam_gram(prm_);
     } else {
       hipLaunchKernelGGL((rba::k_cam_jp_diag2<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
     }
-    all_reduce(d_jp_diag2_.get(), nvec_);
+    if (!gram_pending_) all_reduce(d_jp_diag2_.get(), nvec_);
     all_reduce(d_fail_.get(), 1, kNcclMax);
-    hipLaunchKernelGGL((rba::k_pose_scaling<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
-                       d_jp_diag2_.get(), d_pose_scaling_.get(), prm_.eps, nvec_);
+    if (!gram_pending_)
+      hipLaunchKernelGGL((rba::k_pose_scaling<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
+                         d_jp_diag2_.get(), d_pose_scaling_.get(), prm_.eps, nvec_);
     if (staged) {
       sub_mark(&sub_.scale_landmark_jacobian_time);  // get_Jp_diag2() (+ scale_Jl_cols, done inside the QR kernels)
-      hipLaunchKernelGGL((rba::k_scale_gram<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_, prm_);
+      if (!gram_pending_)
+        hipLaunchKernelGGL((rba::k_scale_gram<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_, prm_);
       sub_mark(&sub_.stage1_preconditioner_time);  // get_Jp_T_Jp_blockdiag() (JACOBI; minuend of SCHUR_JACOBI)
       if (n_tiles_ > 0) {
         rba::ImplicitTiles it;
@@ -1368,6 +1376,7 @@ class Solver final : public rba_solver {
                          stream_, prm_, int64_t(0), int64_t(n_obs_));
     }
     launch_cam_stage2(prm_, lambda);
+    gram_pending_ = false;
     sub_mark(&sub_.stage2_preconditioner_and_gradient_time);  // get_Q2TJp_T_Q2TJp_blockdiag() + get_Q2TJp_T_Q2Tr()
     if (comm_ || cb_fn_) {
       // every rank added lambda*I and holds only its landmarks' sums: make the
@@ -1516,14 +1525,15 @@ class Solver final : public rba_solver {
   void launch_cam_stage2(const rba::Params<float>& prm, float lambda) {
     if (compact_)
       hipLaunchKernelGGL((rba::k_cam_stage2_w8_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_,
-                         prm, lambda);
+                         prm, lambda, gram_pending_ ? 1 : 0);
     else
       hipLaunchKernelGGL((rba::k_cam_stage2_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
                          lambda);
   }
   void launch_cam_stage2(const rba::Params<double>& prm, double lambda) {
     if (compact_)
-      hipLaunchKernelGGL((rba::k_cam_stage2_w8<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
+      hipLaunchKernelGGL((rba::k_cam_stage2_w8<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda,
+                         gram_pending_ ? 1 : 0);
     else
       hipLaunchKernelGGL((rba::k_cam_stage2<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
   }
@@ -1536,6 +1546,15 @@ class Solver final : public rba_solver {
                        dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTd) * sizeof(S), stream_,
                        prm_, int64_t(n_obs_), 0, 0);
     topd_valid_ = true;
+  }
+  // the stage-1 Gram pass on its own, for callers that read the pose scaling / Jp_diag2 before any stage 2
+  void ensure_gram() {
+    if (!gram_pending_) return;
+    launch_cam_gram(prm_);
+    hipLaunchKernelGGL((rba::k_pose_scaling<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
+                       d_jp_diag2_.get(), d_pose_scaling_.get(), prm_.eps, nvec_);
+    hipLaunchKernelGGL((rba::k_scale_gram<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_, prm_);
+    gram_pending_ = false;
   }
   // x -> D x for the kernels that read the unscaled Jacobian rows (compact stage 2)
   const S* scaled_operand(const S* x) {
@@ -2243,6 +2262,7 @@ class Solver final : public rba_solver {
   }
   void get_pose_scaling(void* out) override {
     use_device();
+    ensure_gram();
     d_pose_scaling_.download(static_cast<S*>(out), nvec_, stream_);
     sync();
   }
@@ -2441,6 +2461,8 @@ class Solver final : public rba_solver {
   int hx_lds_ = 1;            // RBA_HX_LDS=0: never use the LDS-private y copy (k_hx_implicit_lds); 2: whenever y fits
                               // (default 1: when it fits and every wave gets at least four tiles)
   bool operand_prescaled_ = false;
+  bool fused_gram_ = true;     // RBA_FUSED_GRAM=0: always run the stage-1 Gram pass
+  bool gram_pending_ = false;  // linearised without the Gram pass: the first stage 2's camera pass does it
   bool compact_ = false;     // stage 2 hands W8 (8 scalars per observation) to the camera pass, JpS stays unscaled
   bool topd_valid_ = false;  // compact: the 27 + 9 records exist for the current damping (assembly / E0 products only)
   DevBuf<S> d_W8_, d_xs_;
