@@ -118,6 +118,8 @@ __device__ __forceinline__ void spmv_block_times(const S* lds, int off, int lane
 }
 
 // MODE 0: direction update + product + p.q partial.   MODE 1: refresh product S x (+ lambda x).
+// MODE 2: plain product S x + lambda x outside the fused loop (series of the power preconditioner): lambda is
+//         passed in `q_tolerance`, only `done` is read from the state.
 // Load schedule (the kernel is a chain of memory round trips, not a bandwidth problem):
 //   round 1  the item descriptor
 //   round 2  the first chunk's matrix vectors, its column indices, the 2 x 64 reduction partials and
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
   }
   const int done = st->done, it = st->iter, cur_st = st->cur, need_test = st->need_test, pswap = st->pswap;
   const double q_prev = st->q_hist[(it + 1) & 1], rho_prev = st->rho_hist[(it + 1) & 1];
-  const S lambda = S(st->lambda);
+  const S lambda = MODE == 2 ? S(q_tolerance) : S(st->lambda);
   cs.setup(vals, item.slot0, nb0);
   V tmp[kSpmvPass];
   cs.issue(0, lane, tmp);
@@ -227,8 +229,10 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
         }
       }
     }
-  } else {
+  } else if (MODE == 1) {
     stop = done | (cur_st % period != 0 ? 1 : 0);
+  } else {
+    stop = done;
   }
   if (stop) return;
 

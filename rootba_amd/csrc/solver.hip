@@ -866,6 +866,8 @@ class Solver final : public rba_solver {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(rba::spmv_lds_bytes<S>())));
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_pcgs_spmv<S, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(rba::spmv_lds_bytes<S>())));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_pcgs_spmv<S, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(rba::spmv_lds_bytes<S>())));
     }
   }
 
@@ -1807,7 +1809,8 @@ class Solver final : public rba_solver {
     hx_event_count_ = 0;
     hx_calls_ = 0;
     rba_cg_summary cg = pcg(sc_ ? S(0) : lambda);  // SC: the damping is inside the matrix
-    if (pcg_used_explicit_ && !sc_ && (cg.termination_type == 2 || pcg_indefinite_)) {
+    static const bool force_fallback = std::getenv("RBA_FORCE_EXPLICIT_FALLBACK") != nullptr;  // tests
+    if (pcg_used_explicit_ && !sc_ && (cg.termination_type == 2 || pcg_indefinite_ || force_fallback)) {
       // The assembled operator is S + E with |E| ~ eps |S|: unlike the square-root product
       // (p.q = |A p|^2 + lambda |p|^2 >= 0 by construction) it can lose definiteness when
       // lambda < eps |S|. The reference's operator cannot - repeat this solve matrix-free.
@@ -1905,12 +1908,29 @@ class Solver final : public rba_solver {
         hipLaunchKernelGGL((rba::k_block_apply<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(),
                            d_r_.get(), t, static_cast<S*>(nullptr), e, n, st);
         HIP_CHECK(hipMemcpyAsync(d_z_.get(), t, n * sizeof(S), hipMemcpyDeviceToDevice, stream_));
+        // Repeat of a solve whose assembled operator lost definiteness (explicit_off_for_solve_): the PRODUCT is
+        // matrix-free again (p.q = |A p|^2 + lambda |p|^2 cannot turn negative), but the series of the
+        // preconditioner keeps using the assembled matrix, which is still valid for this damping - an approximate
+        // inverse tolerates its eps |S| error, and order m costs m SpMVs instead of m matrix-free E0 products
+        // (final-13682, order 10: 2 ms instead of 25 ms per PCG iteration).
+        const bool series_on_matrix = ex_active_ || (explicit_off_for_solve_ && ex_ready_ && ex_valid_);
         for (int i = 1; i <= opt_.power_order; ++i) {
-          if (ex_active_) {
+          if (series_on_matrix) {
             // through the assembled matrix: (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t), no collective
-            hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, exp_, t, e, done);
-            hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, t, e,
-                               lambda, n);
+            if (n_items_ > 0) {
+              // the row-staged SpMV of the fused PCG (kernels_pcg.hpp, plain-product mode) + its collect
+              hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
+                                 exp_.cols, exp_.vals, d_items_.get(), static_cast<const S*>(nullptr),
+                                 static_cast<S*>(nullptr), static_cast<S*>(nullptr), t, d_qmain_.get(), d_qpart_.get(),
+                                 st, static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
+                                 static_cast<double*>(nullptr), double(lambda), 0, 0, 1, static_cast<int*>(nullptr));
+              hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, e,
+                                 d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), n);
+            } else {
+              hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, exp_, t, e, done);
+              hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, t, e,
+                                 lambda, n);
+            }
             hipLaunchKernelGGL((rba::k_series_step<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), e, t,
                                d_z_.get(), n, st);
             continue;
@@ -2307,6 +2327,9 @@ class Solver final : public rba_solver {
         // Vh 8, writes Vh 8 + JlS 6 + rS 2 (the column pass belongs to stage 2 here)
         m->stage1 = geometry_in + no * ((18 + 8) + 18 + (8 + 8 + 6 + 2)) * s + no * (4 + 8) + nl * (12 + 12) * s +
                     nc * (9 + 81 + 81 + 9) * s;
+        // one GPU, compact stage 2: the Gram pass (JpS 18 + CSC index) is folded into the stage-2 camera pass, which
+        // reads those rows anyway (already counted there)
+        if (compact_ && fused_gram_ && !comm_ && !cb_fn_ && opt_.staged_execution) m->stage1 -= no * (18 * s + 4);
       } else {
         // round-1 kernels: top0 27, JpS 18, bmO 9, JlS 6, rS 2, Vh 8 and the dense blocks
         m->stage1 = 2 * geometry_in + no * 4 /* CSC */ + no * (27 + 18 + 9 + 6 + 2 + 8) * s + nl * 12 * s +

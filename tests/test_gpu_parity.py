@@ -809,3 +809,23 @@ def test_assembled_operator_at_tiny_damping_float32(ladybug_far, lam):
         l_diff = g.apply(inc)
         assert np.isfinite(l_diff) and l_diff > 0
     assert errs[0] < 0.2 and errs[1] <= max(3 * errs[0], 5e-2), errs
+
+
+@pytest.mark.parametrize("precond", [1, 2])
+def test_matrix_free_repeat_after_assembled_operator_breakdown(ladybug_far, precond, monkeypatch):
+    """When the PCG on the assembled float32 matrix breaks down (p.q <= 0) the solve is repeated with matrix-free
+    products; with the power-series preconditioner the series then still runs through the assembled matrix (an
+    approximate inverse tolerates its rounding, and it is an order of magnitude cheaper than matrix-free E0
+    products). The repeat is forced here; its increment must be the all-matrix-free one up to float32 PCG noise
+    and the solve must converge in a comparable number of iterations."""
+    kw = dict(preconditioner_type=precond, power_order=4, eta=1e-3)
+    g0, _ = _pair(ladybug_far, np.float32, explicit_after=0, **kw)
+    assert g0.linearize() == 0
+    ref, c0 = g0.solve(1e-4)
+    monkeypatch.setenv("RBA_FORCE_EXPLICIT_FALLBACK", "1")
+    g1, _ = _pair(ladybug_far, np.float32, explicit_after=1, **kw)
+    assert g1.linearize() == 0
+    inc, c1 = g1.solve(1e-4)
+    assert c0.termination_type == 1 and c1.termination_type == 1
+    assert abs(c1.num_iterations - c0.num_iterations) <= max(2, c0.num_iterations // 5), (c0.num_iterations, c1.num_iterations)
+    assert rel_err(inc, ref) < 2e-2
