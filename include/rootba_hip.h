@@ -94,7 +94,8 @@ typedef struct rba_options {
                                      0: stream the dense Q2^T Jp blocks the reference materialises */
   int solver_type;                /* SolverOptions::SolverType: 0 SQUARE_ROOT (default, LinearizorQR),
                                      1 SCHUR_COMPLEMENT (LinearizorSC, linearizor_sc.cpp:70-211:
-                                     explicit block-sparse reduced camera matrix + SpMV)        */
+                                     explicit block-sparse reduced camera matrix + SpMV; preconditioners
+                                     SCHUR_JACOBI and POWER_SCHUR_COMPLEMENT like the reference, one GPU) */
   int explicit_after;             /* square-root solver with SCHUR_JACOBI: after this many matrix-free
                                      products a PCG solve assembles S = sum_l A_l^T A_l explicitly
                                      (block-CSR) and continues with S x; 0 = never; -1 (default) = 6 for

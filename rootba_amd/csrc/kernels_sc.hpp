@@ -388,6 +388,16 @@ __global__ __launch_bounds__(256) void k_sc_damp_and_extract_diag(ScParams<S> p,
   p.blocks[i] = v;
 }
 
+// blocks = Hpp + lambda I from the (already scaled) Gram blocks: the blocks of the power-series preconditioner
+// on the explicit system (LinearizationSC::get_jacobi, linearizor_sc.cpp:163-170)
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_jacobi_blocks(const S* __restrict__ gram, S lambda, S* __restrict__ blocks,
+                                                          int n_cams) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 81 * n_cams) return;
+  blocks[i] = gram[i] + ((i % 81) % 10 == 0 ? lambda : S(0));
+}
+
 // ---- S x ------------------------------------------------------------------------
 // BlockSparseMatrix::right_multiply: one workgroup per block row, threads over the
 // row's contiguous 81 nnz_i entries; the 9 row sums are selected by predication

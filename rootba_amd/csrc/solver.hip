@@ -517,9 +517,10 @@ class Solver final : public rba_solver {
       d_lm_inc_.alloc(3 * size_t(n_lms));
       HIP_CHECK(hipStreamSynchronize(stream_));  // s_obs_xy64 is a local
     }
-    if (sc_ && opt_.preconditioner_type != 1)
-      throw HipError{"SCHUR_COMPLEMENT solver: only the SCHUR_JACOBI preconditioner is implemented",
-                     RBA_ERR_UNSUPPORTED};
+    // LinearizorSC offers SCHUR_JACOBI and POWER_SCHUR_COMPLEMENT (linearizor_sc.cpp:158-176; JACOBI: LOG(FATAL))
+    if (sc_ && opt_.preconditioner_type == 0)
+      throw HipError{"SCHUR_COMPLEMENT solver: the SCHUR_JACOBI and POWER_SCHUR_COMPLEMENT preconditioners are "
+                     "implemented (the reference's LinearizorSC has no JACOBI either)", RBA_ERR_UNSUPPORTED};
     // the dense landmark blocks and the QR by-products exist only for the square-root solver
     const size_t qr_obs = sc_ ? 0 : size_t(n_obs_);
     d_A_.alloc((sc_ || staged_) ? 0 : size_t(blk));
@@ -1349,6 +1350,17 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_sc_cam_gradient<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_);
       hipLaunchKernelGGL((rba::k_sc_damp_and_extract_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0,
                          stream_, scp_, lambda);
+      if (opt_.preconditioner_type == 2) {
+        // PowerSCPreconditioner on the explicit system (linearizor_sc.cpp:163-170): its blocks are the JACOBI
+        // blocks Hpp = Jp^T Jp (+ pose damping), get_jacobi(); the series (Hpp^-1 E0)^i runs through S = Hpp - E0
+        // (pcg). The scaled rows of the SC path give D G D directly; Jp_diag2 of this pass goes to a scratch vector.
+        rba::Params<S> gp = prm_;
+        gp.JpS = scp_.JpS;
+        gp.jp_diag2 = d_tmp_.get();
+        launch_cam_gram(gp);
+        hipLaunchKernelGGL((rba::k_sc_jacobi_blocks<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
+                           prm_.B_mid, lambda, scp_.blocks, n_cams_);
+      }
       pose_damping_ = lambda;
       landmark_damping_valid_ = true;
       return;
@@ -1913,21 +1925,22 @@ class Solver final : public rba_solver {
         // preconditioner keeps using the assembled matrix, which is still valid for this damping - an approximate
         // inverse tolerates its eps |S| error, and order m costs m SpMVs instead of m matrix-free E0 products
         // (final-13682, order 10: 2 ms instead of 25 ms per PCG iteration).
-        const bool series_on_matrix = ex_active_ || (explicit_off_for_solve_ && ex_ready_ && ex_valid_);
+        const bool series_on_matrix = sc_ || ex_active_ || (explicit_off_for_solve_ && ex_ready_ && ex_valid_);
+        const rba::ScParams<S>& SM = sc_ ? scp_ : exp_;  // (SC backend: the damping is inside the matrix, lambda = 0)
         for (int i = 1; i <= opt_.power_order; ++i) {
           if (series_on_matrix) {
             // through the assembled matrix: (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t), no collective
             if (n_items_ > 0) {
               // the row-staged SpMV of the fused PCG (kernels_pcg.hpp, plain-product mode) + its collect
               hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
-                                 exp_.cols, exp_.vals, d_items_.get(), static_cast<const S*>(nullptr),
+                                 SM.cols, SM.vals, d_items_.get(), static_cast<const S*>(nullptr),
                                  static_cast<S*>(nullptr), static_cast<S*>(nullptr), t, d_qmain_.get(), d_qpart_.get(),
                                  st, static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
                                  static_cast<double*>(nullptr), double(lambda), 0, 0, 1, static_cast<int*>(nullptr));
               hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, e,
                                  d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), n);
             } else {
-              hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, exp_, t, e, done);
+              hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, SM, t, e, done);
               hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, t, e,
                                  lambda, n);
             }

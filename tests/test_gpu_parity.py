@@ -604,6 +604,36 @@ def test_schur_complement_solve_apply_and_lm(ladybug_far, small_problem, dtype):
             assert abs(a.cost - b.cost) <= 1e-4 * b.cost and abs(a.cost - c.cost) <= 1e-4 * c.cost
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_schur_complement_with_power_series_preconditioner(ladybug_far, small_problem, dtype):
+    """LinearizorSC + PowerSCPreconditioner (linearizor_sc.cpp:163-170, preconditioner.hpp:145-254): the explicit
+    backend with the power series is the same preconditioned system as the square-root solver with it (whose
+    series is pinned against the oracle's PowerSCPreconditioner restatement in test_power_series_preconditioner),
+    so solves and LM runs of the two must agree - to 1e-9 in double (same PCG iteration counts), to float
+    tolerance in float32."""
+    kw = dict(preconditioner_type=2, power_order=5)
+    g_sc, _ = _pair(small_problem, dtype, solver_type=1, **kw)
+    g_qr, _ = _pair(small_problem, dtype, explicit_after=0, **kw)
+    assert g_sc.linearize() == 0 and g_qr.linearize() == 0
+    i_sc, c_sc = g_sc.solve(1e-4)
+    i_qr, c_qr = g_qr.solve(1e-4)
+    assert c_sc.termination_type == c_qr.termination_type == 1
+    assert abs(c_sc.num_iterations - c_qr.num_iterations) <= (0 if dtype == np.float64 else 1)
+    assert rel_err(i_sc, i_qr) < (1e-9 if dtype == np.float64 else 5e-3)
+    # fewer iterations than with the block-diagonal preconditioner on the same system
+    g_sj, _ = _pair(small_problem, dtype, solver_type=1)
+    assert g_sj.linearize() == 0
+    assert c_sc.num_iterations <= g_sj.solve(1e-4)[1].num_iterations
+    r_sc, _ = _pair(ladybug_far, dtype, solver_type=1, max_num_iterations=6, **kw)[0].optimize_lm()
+    r_qr, _ = _pair(ladybug_far, dtype, max_num_iterations=6, **kw)[0].optimize_lm()
+    assert len(r_sc) == len(r_qr)
+    for a, b in zip(r_sc, r_qr):
+        assert a.step_is_successful == b.step_is_successful
+        assert abs(a.cost - b.cost) <= (1e-9 if dtype == np.float64 else 1e-4) * b.cost
+    if dtype == np.float64:
+        assert [r.cg_iterations for r in r_sc] == [r.cg_iterations for r in r_qr]
+
+
 def test_schur_complement_unsupported_combinations(small_problem):
     import torch  # noqa: F401
     from rootba_amd import _lib as L
