@@ -326,3 +326,40 @@ def test_bal_qr_hip_mixed_precision_and_unstaged_timers(app, bal_file, tmp_path)
     # mixed precision without a double host problem is refused
     out = subprocess.run([app, "--input", path, "--no-use-double", "--mixed-precision"], capture_output=True, text=True)
     assert out.returncode != 0
+
+
+GOLDEN_BAL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_bal.txt")
+
+
+def test_loaders_against_hand_derived_values(app):
+    """tests/golden/tiny_bal.txt (2 cameras, 3 landmarks, 5 observations in scrambled order) against values derived BY
+    HAND from the reference's conventions (bal_problem.cpp:190-282) - not from either loader: observations grouped by
+    landmark and sorted by camera (std::map order), image y inverted, T_c_w = diag(1,-1,-1) * exp(rodrigues) and
+    diag(1,-1,-1) * t, intrinsics (f, k1, k2) unchanged. Camera 0 has the Rodrigues vector (0, 0, pi/2)."""
+    # --- numpy mirror -------------------------------------------------------------------------
+    p = P.read_bal(GOLDEN_BAL)
+    assert (p.n_cams, p.n_lms, p.n_obs) == (2, 3, 5)
+    assert p.lm_obs_offsets.tolist() == [0, 2, 4, 5]
+    assert p.obs_cam_idx.tolist() == [0, 1, 0, 1, 0]
+    assert np.array_equal(p.obs_xy, [[1.0, -2.0], [10.5, 20.25], [0.25, 0.75], [7.0, -8.0], [-3.5, -4.5]])
+    assert np.array_equal(p.lms, [[1.0, 1.0, 10.0], [-2.0, 0.5, 12.0], [3.0, -1.5, 8.0]])
+    R0 = np.array([[0.0, -1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, -1.0]])  # diag(1,-1,-1) * rot_z(90 deg)
+    R1 = np.diag([1.0, -1.0, -1.0])                                        # zero Rodrigues vector
+    assert np.allclose(P.quat_to_rot(p.cams[0, :4]), R0, atol=1e-15)
+    assert np.allclose(P.quat_to_rot(p.cams[1, :4]), R1, atol=1e-15)
+    assert np.allclose(np.linalg.norm(p.cams[:, :4], axis=1), 1.0, atol=1e-15)
+    assert np.array_equal(p.cams[0, 4:], [1.0, -2.0, -3.0, 500.0, 1e-2, -1e-3])
+    assert np.array_equal(p.cams[1, 4:], [-4.0, -5.0, -6.5, 650.5, 0.0, 2.5e-4])
+    # --- C++ loader (parallel tokeniser + own decimal parser), no normalisation, no filtering --------
+    out = subprocess.run([app, "--input", GOLDEN_BAL, "--dry-run", "--no-normalize", "--init-depth-threshold", "0"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert (info["num_cameras"], info["num_landmarks"], info["num_observations"]) == (2, 3, 5)
+    assert info["landmark_sum"] == [2.0, 0.0, 30.0]
+    # sum over landmarks and their camera-sorted observations i = 1, 2, ... of i * ((cam + 1) * x + y), y inverted:
+    # -1 + 82.5 + 1 + 12 - 8
+    assert info["obs_checksum"] == 86.5
+    assert info["rcs_sparsity"] == 0.0
+    assert np.allclose(P.quat_to_rot(np.array(info["cam0"][:4])), R0, atol=1e-12)
+    assert info["cam0"][4:] == [1.0, -2.0, -3.0]
