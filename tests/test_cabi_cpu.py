@@ -79,3 +79,38 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("oracle/", "").replace("(oracle)", "") or \
                     "never imported" in txt or "test infrastructure" in txt, f
+
+
+def _header_struct_fields(name):
+    """Field names of `typedef struct <name> { ... } <name>;` in the header, in order (comments stripped)."""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\}\s*%s;" % (name, name), src, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, rest = decl.split(None, 1)
+        fields += [(ctype, n.strip()) for n in rest.split(",")]
+    return fields
+
+
+@pytest.mark.parametrize("cname,mirror", [("rba_options", "RbaOptions"), ("rba_residual_info", "RbaResidualInfo"),
+                                          ("rba_cg_summary", "RbaCgSummary"), ("rba_iter_timings", "RbaIterTimings"),
+                                          ("rba_substage_timings", "RbaSubstageTimings"),
+                                          ("rba_lm_iteration", "RbaLmIteration"), ("rba_byte_model", "RbaByteModel")])
+def test_ctypes_mirrors_match_the_header(cname, mirror):
+    """Every POD struct of include/rootba_hip.h against its ctypes mirror: same field order, names and C types."""
+    ctype_of = {"int": C.c_int, "double": C.c_double, "int64_t": C.c_int64}
+    want = _header_struct_fields(cname)
+    got = getattr(L, mirror)._fields_
+    rename = {"lambda": "lambda_"}  # Python keyword
+    assert [rename.get(n, n) for _, n in want] == [f[0] for f in got]
+    assert [ctype_of[t] for t, _ in want] == [f[1] for f in got]
+    assert C.sizeof(getattr(L, mirror)) > 0
+
+
+def test_dtype_constants_match_the_header():
+    src = open(HEADER).read()
+    for name in ("RBA_F32", "RBA_F64", "RBA_MIXED", "RBA_OK", "RBA_NUMERICAL_FAILURE"):
+        assert int(re.search(r"#define %s \(?(-?\d+)\)?" % name, src).group(1)) == getattr(L, name)
