@@ -1,21 +1,25 @@
 // kernels.hpp — hand-written HIP kernels (gfx950) of the square-root BA solver.
 //
-// Mapping used by every landmark kernel: ONE WAVEFRONT PER LANDMARK, lanes run
-// along the 9k pose columns of the landmark's block. A chunk is 7 whole cameras
-// = 63 columns (lane 63 idles), so a camera's 9 columns never straddle chunks:
-// column j = 63*chunk + lane, camera slot i = 7*chunk + lane/9, component
-// lane%9; CH chunks per lane are chosen per k-class (k <= 7*CH). Rows are streamed. Cross-lane sums
-// (one per block row) use the DPP network. Landmarks are sorted by k at setup
-// so that a launch covers one contiguous k-class with a compile-time CH.
-//
-// Device layout per landmark s (k observations, sorted order):
-//   A     [2k x 9k] row-major, dense: rows 0..2k-4 = Q2^T Jp (scaled), rows
-//         2k-3..2k-1 = the three landmark-damping rows      -> operand of H*x
-//   top0  [k][3][9] Q1^T Jp (undamped), observation-major; topd: with damping
-//   qtr   [2k]      Q^T r (first 3 = Q1^T r);   R0 / Rd [6] upper 3x3 of R
-// i.e. the reference's (2k+3) x (9k+pad+4) LandmarkBlock storage
-// (landmark_block_dynamic.hpp:49-69) split into its streamed and its small
-// parts. See DESIGN.md for bytes per kernel.
+// Two generations live here:
+//  * the default configuration (implicit_q = 1, "staged"): work runs at the parallelism it has - thread per
+//    observation (kernels_s1.hpp), lane per block row on WAVE TILES (a landmark = an aligned group of 4..64 lanes,
+//    k_hx_implicit*, k_bs_tile, k_s1_qr_tile), workgroup per camera for the camera-indexed sums
+//    (k_cam_gram_mfma, k_cam_stage2_w8_mfma). Products scatter into workgroup-private double copies of y in LDS
+//    (k_hx_implicit_lds). No dense landmark block exists.
+//  * the dense-block configuration (implicit_q = 0, round 1): ONE WAVEFRONT PER LANDMARK, lanes run along the 9k pose
+//    columns of the landmark's block. A chunk is 7 whole cameras = 63 columns (lane 63 idles), so a camera's 9
+//    columns never straddle chunks: column j = 63*chunk + lane, camera slot i = 7*chunk + lane/9, component lane%9;
+//    CH chunks per lane are chosen per k-class (k <= 7*CH). Rows are streamed. Cross-lane sums (one per block row)
+//    use the DPP network (k_linearize_qr*, k_hx, k_hx_small, k_stage2_cols, k_cam_stage1/2).
+//    Device layout per landmark s (k observations, sorted order):
+//      A     [2k x 9k] row-major, dense: rows 0..2k-4 = Q2^T Jp (scaled), rows
+//            2k-3..2k-1 = the three landmark-damping rows      -> operand of H*x
+//      top0  [k][3][9] Q1^T Jp (undamped), observation-major; topd: with damping
+//      qtr   [2k]      Q^T r (first 3 = Q1^T r);   R0 / Rd [6] upper 3x3 of R
+//    i.e. the reference's (2k+3) x (9k+pad+4) LandmarkBlock storage
+//    (landmark_block_dynamic.hpp:49-69) split into its streamed and its small parts.
+// Landmarks are sorted by track-length class at setup (and by first camera inside a class in the default
+// configuration), so a launch covers one contiguous class. See DESIGN.md for bytes per kernel.
 #pragma once
 
 #include <type_traits>
