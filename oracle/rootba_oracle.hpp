@@ -1285,12 +1285,18 @@ class Oracle {
       b_ = b;
       if (it) it->stage2_time = now_seconds() - t0;
       t0 = now_seconds();
-      precond_blocks_.assign(size_t(81) * n_cams_, S(0));
-      for (int c = 0; c < n_cams_; ++c)
-        for (int a = 0; a < P; ++a)
-          for (int bb = 0; bb < P; ++bb)
-            precond_blocks_[size_t(81) * c + a * P + bb] = sc_H_[(size_t(P) * c + a) * n + P * c + bb];
-      build_preconditioner(precond_blocks_, nullptr);
+      if (opt_.preconditioner_type == 2) {
+        // POWER_SCHUR_COMPLEMENT (linearizor_sc.cpp:163-170): PowerSCPreconditioner on the JACOBI blocks
+        // (get_jacobi) and the landmark blocks; pcg() applies it through power_precond_solve
+        power_precond_prepare(lambda);
+      } else {
+        precond_blocks_.assign(size_t(81) * n_cams_, S(0));
+        for (int c = 0; c < n_cams_; ++c)
+          for (int a = 0; a < P; ++a)
+            for (int bb = 0; bb < P; ++bb)
+              precond_blocks_[size_t(81) * c + a * P + bb] = sc_H_[(size_t(P) * c + a) * n + P * c + bb];
+        build_preconditioner(precond_blocks_, nullptr);
+      }
       if (it) it->precond_time = now_seconds() - t0;
       t0 = now_seconds();
       std::vector<S> inc(n, S(0));

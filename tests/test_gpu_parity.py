@@ -612,11 +612,15 @@ def test_schur_complement_with_power_series_preconditioner(ladybug_far, small_pr
     so solves and LM runs of the two must agree - to 1e-9 in double (same PCG iteration counts), to float
     tolerance in float32."""
     kw = dict(preconditioner_type=2, power_order=5)
-    g_sc, _ = _pair(small_problem, dtype, solver_type=1, **kw)
+    g_sc, o_sc = _pair(small_problem, dtype, solver_type=1, **kw)
     g_qr, _ = _pair(small_problem, dtype, explicit_after=0, **kw)
-    assert g_sc.linearize() == 0 and g_qr.linearize() == 0
+    assert g_sc.linearize() == 0 and g_qr.linearize() == 0 and o_sc.linearize() == 0
     i_sc, c_sc = g_sc.solve(1e-4)
     i_qr, c_qr = g_qr.solve(1e-4)
+    # ... and the oracle's restatement of LinearizorSC with PowerSCPreconditioner
+    i_o, c_o = o_sc.solve(1e-4)
+    assert abs(c_sc.num_iterations - c_o.num_iterations) <= (0 if dtype == np.float64 else 1)
+    assert rel_err(i_sc, i_o) < (1e-9 if dtype == np.float64 else 5e-3)
     assert c_sc.termination_type == c_qr.termination_type == 1
     assert abs(c_sc.num_iterations - c_qr.num_iterations) <= (0 if dtype == np.float64 else 1)
     assert rel_err(i_sc, i_qr) < (1e-9 if dtype == np.float64 else 5e-3)

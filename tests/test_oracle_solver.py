@@ -214,3 +214,26 @@ def test_power_series_preconditioner_matches_its_definition(small_problem):
     inc_j, cg_j = o2.solve(lam)
     assert cg_p.termination_type == 1 and cg_p.num_iterations <= cg_j.num_iterations
     assert rel_err(inc_p, inc_j) < 0.2  # both truncated at eta = 0.1
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_power_series_preconditioner_sc_equals_qr(small_problem, dtype):
+    """POWER_SCHUR_COMPLEMENT with the explicit solver (the reference's wiring, linearizor_sc.cpp:163-170) and with
+    the square-root solver (the new combination of BASELINE config 5) precondition the same system with the same
+    operator: same PCG iteration counts and increments, fewer iterations than SCHUR_JACOBI, and the preconditioned
+    residual reduction of the truncated series is the Neumann one."""
+    kw = dict(preconditioner_type=2, power_order=4)
+    sc = O.Oracle(small_problem, dtype, _opts(solver_type=1, **kw))
+    qr = O.Oracle(small_problem, dtype, _opts(**kw))
+    assert sc.linearize() == 0 and qr.linearize() == 0
+    i_sc, c_sc = sc.solve(1e-4)
+    i_qr, c_qr = qr.solve(1e-4)
+    assert c_sc.termination_type == c_qr.termination_type == 1
+    assert abs(c_sc.num_iterations - c_qr.num_iterations) <= (0 if dtype == np.float64 else 1)
+    assert rel_err(i_sc, i_qr) < (1e-9 if dtype == np.float64 else 2e-3)
+    sj = O.Oracle(small_problem, dtype, _opts(solver_type=1))
+    assert sj.linearize() == 0
+    assert c_sc.num_iterations < sj.solve(1e-4)[1].num_iterations
+    # and both produce the same step
+    l_sc, l_qr = sc.apply(i_qr), qr.apply(i_qr)
+    assert abs(l_sc - l_qr) <= (1e-9 if dtype == np.float64 else 1e-3) * abs(l_qr)
