@@ -227,6 +227,21 @@ class Solver final : public rba_solver {
     // camera-major gathers get slightly faster (venice: stage 1 440 -> 410 us). RBA_SORT_BY_CAMERA=0 keeps the
     // input order inside a track length.
     int sort_by_camera = opt_.implicit_q ? 1 : 0;
+    if (sort_by_camera) {
+      // More cameras than an LDS window holds: the sort only pays if tracks are local in camera index. Without
+      // that locality (e.g. an unordered photo collection) the windows would miss, the products would fall back to
+      // device atomics, and those are fastest on the INPUT order - so it is kept then.
+      const int win = int(kHxLdsMaxBytes / (9 * sizeof(double)));
+      if (n_cams > win) {
+        int64_t local_rows = 0, rows = 0;
+        for (int l = 0; l < n_lms; ++l) {
+          const int64_t k = lm_off[l + 1] - lm_off[l];
+          rows += 2 * k;
+          if (obs_cam[lm_off[l + 1] - 1] - obs_cam[lm_off[l]] < win / 2) local_rows += 2 * k;
+        }
+        if (double(local_rows) < 0.9 * double(rows)) sort_by_camera = 0;
+      }
+    }
     if (const char* ev = std::getenv("RBA_SORT_BY_CAMERA")) sort_by_camera = std::atoi(ev);
     // track-length classes: the common refinement of the wave-tile classes (k <= 2, 4, 8, 16, 32, 64, 112) and
     // of the dense-block classes (k <= 7, 14, 28, 56, 112): every class range the kernels use stays contiguous
