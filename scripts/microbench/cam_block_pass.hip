@@ -1,0 +1,416 @@
+// Prototype of the camera-BLOCK form of the stage-2 camera pass (development harness, not part of the library;
+// DESIGN.md 10 "open", profiles/r2b_microbench_cam_gather.txt). Same arithmetic as k_cam_stage2_w8_mfma<GRAM>:
+// per camera  T = sum X^T X (X = W' Jp, 3 x 9),  G = sum Jp^T Jp,  t = sum Jp^T g,  diag2 = diag G in double,
+// but the observation lists are the merged, sorted lists of blocks of B = 8 consecutive cameras, cut into B
+// segments with one workgroup each: records of a landmark seen by several cameras of the block arrive as one
+// contiguous piece (the gather runs at 4.1 TB/s of needed bytes instead of 2.3). Every workgroup keeps one pair of
+// matrix-core accumulators per camera of its block (wave-uniform switch on the observation's camera), writes its
+// partial sums, and a per-camera epilogue adds the B partials of its block in a fixed order (deterministic).
+// The harness checks the result against a double-precision host reference and times both kernels.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdint>
+#include <random>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int RW = 26, CH = 32, B = 8;
+constexpr int PF = 162;  // floats per (segment, camera): T 81 | G 81
+constexpr int PD = 18;   // doubles per (segment, camera): t 9 | diag2 9
+
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// list entry: observation index | local camera << 28
+__global__ __launch_bounds__(256) void k_cam_block(const float* __restrict__ J, const float* __restrict__ W,
+                                                   const int* __restrict__ list, const int64_t* __restrict__ off,
+                                                   float* __restrict__ part_f, double* __restrict__ part_d, int n_seg) {
+  __shared__ __attribute__((aligned(16))) float stage[4][CH * RW + 6];
+  __shared__ int camid[4][CH];
+  __shared__ float tile[4][2][16][16];
+  __shared__ double dred[4][7][2][9];
+  const int per = (n_seg + 7) / 8;
+  const int sg = (blockIdx.x % 8) * per + blockIdx.x / 8;  // XCD-contiguous segments
+  if (sg >= n_seg) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, kk = lane >> 4;
+  const int g = lane / 9, a = lane - 9 * g;
+  const int64_t t0 = off[sg], t1 = off[sg + 1];
+  float* lds = stage[wave];
+  int* cid = camid[wave];
+  f32x4 accT[B], accG[B];
+  double accb[B], accd[B];
+#pragma unroll
+  for (int c = 0; c < B; ++c) {
+    accT[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accG[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accb[c] = 0.0;
+    accd[c] = 0.0;
+  }
+  for (int64_t base = t0 + CH * wave; base < t1; base += 4 * CH) {
+    const int cnt = int(t1 - base < CH ? t1 - base : CH);
+    const int e = lane < cnt ? list[base + lane] : 0;
+    const int idx = e & ((1 << 28) - 1);
+    if (lane < cnt) cid[lane] = e >> 28;
+#pragma unroll
+    for (int j = 0; j < (CH * 9 + 63) / 64; ++j) {
+      const int q = j * 64 + lane, r = q / 9, pc = q - 9 * r;
+      const int o = __shfl(idx, r & 31);
+      if (q < cnt * 9) *reinterpret_cast<float2*>(lds + r * RW + 2 * pc) = *reinterpret_cast<const float2*>(J + int64_t(o) * 18 + 2 * pc);
+    }
+    {
+      const int r = lane >> 1, h = lane & 1;
+      const int o = __shfl(idx, r & 31);
+      if (r < cnt) {
+        const float4 w = *reinterpret_cast<const float4*>(W + int64_t(o) * 8 + 4 * h);
+        float* d = lds + r * RW + 18 + 4 * h;
+        *reinterpret_cast<float2*>(d) = float2{w.x, w.y};
+        *reinterpret_cast<float2*>(d + 2) = float2{w.z, w.w};
+      }
+    }
+    wave_fence();
+    for (int s = 0; s < cnt; ++s) {
+      const float* rec = lds + s * RW;
+      const int c = __builtin_amdgcn_readfirstlane(cid[s]);
+      float vT = 0.f, vG = 0.f;
+      if (i < 9 && kk < 3) vT = fmaf(rec[18 + 2 * kk], rec[i], __fmul_rn(rec[19 + 2 * kk], rec[9 + i]));
+      if (i < 9 && kk < 2) vG = rec[9 * kk + i];
+      switch (c) {
+#define CASE(n) case n: accT[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vT, vT, accT[n], 0, 0, 0); \
+                        accG[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vG, vG, accG[n], 0, 0, 0); break;
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7)
+#undef CASE
+      }
+    }
+    if (lane < 63)
+      for (int r = g; r < cnt; r += 7) {
+        const float* rec = lds + r * RW;
+        const int c = cid[r];
+        const double vb = double(fmaf(rec[a], rec[24], __fmul_rn(rec[9 + a], rec[25])));
+        const double vd = double(fmaf(rec[a], rec[a], __fmul_rn(rec[9 + a], rec[9 + a])));
+#pragma unroll
+        for (int n = 0; n < B; ++n) {
+          accb[n] += c == n ? vb : 0.0;
+          accd[n] += c == n ? vd : 0.0;
+        }
+      }
+    wave_fence();  // the next chunk overwrites the staging buffer
+  }
+  // per camera of the block: sum the four waves, write the segment's partial
+#pragma unroll
+  for (int c = 0; c < B; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      tile[wave][0][(lane >> 4) * 4 + r][lane & 15] = accT[c][r];
+      tile[wave][1][(lane >> 4) * 4 + r][lane & 15] = accG[c][r];
+    }
+    if (lane < 63) {
+      dred[wave][g][0][a] = accb[c];
+      dred[wave][g][1][a] = accd[c];
+    }
+    __syncthreads();
+    if (tid < 162) {
+      const int m = tid / 81, e = tid - 81 * m, ii = e / 9, jj = e - 9 * ii;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += tile[w][m][ii][jj];
+      part_f[(size_t(sg) * B + c) * PF + tid] = v;
+    }
+    if (tid >= 192 && tid < 192 + 18) {
+      const int q = tid - 192, m = q / 9, aa = q - 9 * m;
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w)
+        for (int gg = 0; gg < 7; ++gg) v += dred[w][gg][m][aa];
+      part_d[(size_t(sg) * B + c) * PD + q] = v;
+    }
+  }
+}
+
+// Variant 2: the workgroup gathers 128 list entries at a time into LDS (all 256 threads), ranks them by camera with
+// ballots (stable, deterministic), and every wave then reduces the records of ITS two cameras of the block (wave w:
+// cameras w and w + 4) with ONE pair of matrix-core accumulators per camera - no per-observation switch, no select
+// chains, 16 + 8 accumulator registers.
+constexpr int WC = 128;  // list entries per workgroup chunk
+__global__ __launch_bounds__(256) void k_cam_block2(const float* __restrict__ J, const float* __restrict__ W,
+                                                    const int* __restrict__ list, const int64_t* __restrict__ off,
+                                                    float* __restrict__ part_f, double* __restrict__ part_d, int n_seg) {
+  __shared__ __attribute__((aligned(16))) float stage[WC * RW + 6];
+  __shared__ int e_idx[WC];
+  __shared__ int perm[B][WC];
+  __shared__ int cnt_c[B];
+  __shared__ int wave_cnt[2][B];
+  __shared__ double dred[4][7][2][9];
+  const int per = (n_seg + 7) / 8;
+  const int sg = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  if (sg >= n_seg) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, kk = lane >> 4;
+  const int g = lane / 9, a = lane - 9 * g;
+  const int64_t t0 = off[sg], t1 = off[sg + 1];
+  f32x4 accT[2], accG[2];
+  double accb[2] = {0.0, 0.0}, accd[2] = {0.0, 0.0};
+  accT[0] = accT[1] = accG[0] = accG[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t base = t0; base < t1; base += WC) {
+    const int cnt = int(t1 - base < WC ? t1 - base : WC);
+    __syncthreads();  // the previous chunk has been consumed
+    int mycam = -1;
+    if (tid < cnt) {
+      const int e = list[base + tid];
+      e_idx[tid] = e & ((1 << 28) - 1);
+      mycam = e >> 28;
+    }
+    // stable rank of every entry inside its camera: ballots of the two waves that hold entries
+    if (wave < 2) {
+#pragma unroll
+      for (int c = 0; c < B; ++c) {
+        const unsigned long long m = __ballot(mycam == c);
+        if (lane == 0) wave_cnt[wave][c] = __popcll(m);
+      }
+    }
+    __syncthreads();
+    if (tid < WC && mycam >= 0) {
+      // recompute the ballot of my camera (cheap) for the rank
+      unsigned long long mm = 0;
+#pragma unroll
+      for (int c = 0; c < B; ++c) {
+        const unsigned long long m = __ballot(mycam == c);
+        if (mycam == c) mm = m;
+      }
+      const int rank = __popcll(mm & ((1ull << lane) - 1)) + (wave == 1 ? wave_cnt[0][mycam] : 0);
+      perm[mycam][rank] = tid;
+    }
+    if (tid < B) cnt_c[tid] = wave_cnt[0][tid] + wave_cnt[1][tid];
+    // gather the records (needs e_idx of all entries: written before the barrier above)
+    for (int q = tid; q < cnt * 9; q += 256) {
+      const int r = q / 9, pc = q - 9 * r;
+      *reinterpret_cast<float2*>(stage + r * RW + 2 * pc) = *reinterpret_cast<const float2*>(J + int64_t(e_idx[r]) * 18 + 2 * pc);
+    }
+    {
+      const int r = tid >> 1, h = tid & 1;
+      if (r < cnt) {
+        const float4 w = *reinterpret_cast<const float4*>(W + int64_t(e_idx[r]) * 8 + 4 * h);
+        float* d = stage + r * RW + 18 + 4 * h;
+        *reinterpret_cast<float2*>(d) = float2{w.x, w.y};
+        *reinterpret_cast<float2*>(d + 2) = float2{w.z, w.w};
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = wave + 4 * u;
+      const int n = cnt_c[c];
+      for (int k = 0; k < n; ++k) {
+        const float* rec = stage + perm[c][k] * RW;
+        float vT = 0.f, vG = 0.f;
+        if (i < 9 && kk < 3) vT = fmaf(rec[18 + 2 * kk], rec[i], __fmul_rn(rec[19 + 2 * kk], rec[9 + i]));
+        if (i < 9 && kk < 2) vG = rec[9 * kk + i];
+        accT[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vT, vT, accT[u], 0, 0, 0);
+        accG[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vG, vG, accG[u], 0, 0, 0);
+      }
+      if (lane < 63)
+        for (int k = g; k < n; k += 7) {
+          const float* rec = stage + perm[c][k] * RW;
+          accb[u] += double(fmaf(rec[a], rec[24], __fmul_rn(rec[9 + a], rec[25])));
+          accd[u] += double(fmaf(rec[a], rec[a], __fmul_rn(rec[9 + a], rec[9 + a])));
+        }
+    }
+  }
+  // every wave owns the final sums of its two cameras
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int c = wave + 4 * u;
+    float* pf = part_f + (size_t(sg) * B + c) * PF;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ii = (lane >> 4) * 4 + r, jj = lane & 15;
+      if (ii < 9 && jj < 9) {
+        pf[9 * ii + jj] = accT[u][r];
+        pf[81 + 9 * ii + jj] = accG[u][r];
+      }
+    }
+    if (lane < 63) {
+      dred[wave][g][0][a] = accb[u];
+      dred[wave][g][1][a] = accd[u];
+    }
+    wave_fence();
+    if (lane < 18) {
+      const int m = lane / 9, aa = lane - 9 * m;
+      double v = 0.0;
+      for (int gg = 0; gg < 7; ++gg) v += dred[wave][gg][m][aa];
+      part_d[(size_t(sg) * B + c) * PD + lane] = v;
+    }
+    wave_fence();
+  }
+}
+
+// per camera: add the partials of its block's segments in a fixed order; D, B_mid, blocks, b
+__global__ __launch_bounds__(128) void k_cam_block_epilogue(const float* __restrict__ part_f, const double* __restrict__ part_d,
+                                                            const int* __restrict__ seg_first, const int* __restrict__ seg_count,
+                                                            float eps, float lambda, float* __restrict__ pose_scaling,
+                                                            float* __restrict__ B_mid, float* __restrict__ blocks,
+                                                            float* __restrict__ bvec, int n_cams) {
+  __shared__ float dsc[9];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int blk = c / B, cl = c - B * blk;
+  const int s0 = seg_first[blk], ns = seg_count[blk];
+  float t = 0.f, gsum = 0.f;
+  if (tid < 81)
+    for (int s = 0; s < ns; ++s) {
+      const float* pf = part_f + (size_t(s0 + s) * B + cl) * PF;
+      t += pf[tid];
+      gsum += pf[81 + tid];
+    }
+  double bt = 0.0;
+  if (tid >= 96 && tid < 105) {
+    const int aa = tid - 96;
+    double d2 = 0.0;
+    for (int s = 0; s < ns; ++s) {
+      const double* pd = part_d + (size_t(s0 + s) * B + cl) * PD;
+      bt += pd[aa];
+      d2 += pd[9 + aa];
+    }
+    const float sc = 1.f / (eps + sqrtf(float(d2)));
+    pose_scaling[9 * c + aa] = sc;
+    dsc[aa] = sc;
+  }
+  __syncthreads();
+  if (tid < 81) {
+    const int ii = tid / 9, jj = tid - 9 * ii;
+    const float dd = dsc[ii] * dsc[jj];
+    const float bm = __fmul_rn(gsum, dd);
+    B_mid[81 * c + tid] = bm;
+    blocks[81 * c + tid] = __fsub_rn(bm, __fmul_rn(t, dd)) + (ii == jj ? lambda : 0.f);
+  }
+  if (tid >= 96 && tid < 105) bvec[9 * c + (tid - 96)] = float(bt * double(dsc[tid - 96]));
+}
+
+int main() {
+  const int n_cams = 1778, K = 5, n_lms = 1000000;
+  const int64_t n_obs = int64_t(n_lms) * K;
+  std::vector<int> obs_cam(n_obs);
+  std::vector<std::vector<int>> cam_list(n_cams);
+  for (int l = 0; l < n_lms; ++l) {
+    const int f = int(int64_t(l) * n_cams / n_lms);
+    for (int i = 0; i < K; ++i) {
+      const int c = (f + i) % n_cams;
+      obs_cam[int64_t(l) * K + i] = c;
+      cam_list[c].push_back(l * K + i);
+    }
+  }
+  std::mt19937 rng(1);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  std::vector<float> hJ(n_obs * 18), hW(n_obs * 8);
+  for (auto& v : hJ) v = U(rng);
+  for (auto& v : hW) v = U(rng);
+  // merged block lists cut into one segment per camera of the block
+  const int n_blocks = (n_cams + B - 1) / B;
+  std::vector<int> list, seg_first(n_blocks), seg_count(n_blocks);
+  std::vector<int64_t> off(1, 0);
+  for (int g = 0; g < n_blocks; ++g) {
+    const int nb = std::min(n_cams, (g + 1) * B) - g * B;
+    std::vector<int> u;
+    for (int c = g * B; c < g * B + nb; ++c) u.insert(u.end(), cam_list[c].begin(), cam_list[c].end());
+    std::sort(u.begin(), u.end());
+    seg_first[g] = int(off.size()) - 1;
+    seg_count[g] = nb;
+    for (int s = 0; s < nb; ++s) {
+      const size_t a = u.size() * s / nb, b = u.size() * (s + 1) / nb;
+      for (size_t q = a; q < b; ++q) list.push_back(u[q] | ((obs_cam[u[q]] - g * B) << 28));
+      off.push_back(int64_t(list.size()));
+    }
+  }
+  const int n_seg = int(off.size()) - 1;
+  float *J, *W, *pf, *ps, *bm, *bl, *bv;
+  double* pd;
+  int *dl, *dsf, *dsc_;
+  int64_t* doff;
+  CK(hipMalloc(&J, hJ.size() * 4)); CK(hipMalloc(&W, hW.size() * 4));
+  CK(hipMemcpy(J, hJ.data(), hJ.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&pf, size_t(n_seg) * B * PF * 4)); CK(hipMalloc(&pd, size_t(n_seg) * B * PD * 8));
+  CK(hipMalloc(&ps, n_cams * 9 * 4)); CK(hipMalloc(&bm, n_cams * 81 * 4)); CK(hipMalloc(&bl, n_cams * 81 * 4));
+  CK(hipMalloc(&bv, n_cams * 9 * 4));
+  CK(hipMalloc(&dl, list.size() * 4)); CK(hipMalloc(&doff, off.size() * 8));
+  CK(hipMalloc(&dsf, n_blocks * 4)); CK(hipMalloc(&dsc_, n_blocks * 4));
+  CK(hipMemcpy(dl, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(doff, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dsf, seg_first.data(), n_blocks * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dsc_, seg_count.data(), n_blocks * 4, hipMemcpyHostToDevice));
+  const float eps = 3.1622776601683794e-3f, lambda = 1e-4f;
+  hipEvent_t e0, e1, e2;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+  for (int variant = 1; variant <= 2; ++variant) {
+  float best1 = 1e9f, best2 = 1e9f;
+  CK(hipMemset(pf, 0, size_t(n_seg) * B * PF * 4)); CK(hipMemset(pd, 0, size_t(n_seg) * B * PD * 8));
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(e0));
+    if (variant == 1)
+      hipLaunchKernelGGL(k_cam_block, dim3(8 * ((n_seg + 7) / 8)), dim3(256), 0, 0, J, W, dl, doff, pf, pd, n_seg);
+    else
+      hipLaunchKernelGGL(k_cam_block2, dim3(8 * ((n_seg + 7) / 8)), dim3(256), 0, 0, J, W, dl, doff, pf, pd, n_seg);
+    CK(hipEventRecord(e1));
+    hipLaunchKernelGGL(k_cam_block_epilogue, dim3(n_cams), dim3(128), 0, 0, pf, pd, dsf, dsc_, eps, lambda, ps, bm, bl, bv, n_cams);
+    CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
+    float m1, m2;
+    CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e1, e2));
+    if (rep > 0) { best1 = std::min(best1, m1); best2 = std::min(best2, m2); }
+  }
+  CK(hipGetLastError());
+  printf("variant %d: k_cam_block %.1f us + epilogue %.1f us (%d segments of blocks of %d cameras; %.0f MB of records)\n", variant, best1 * 1e3,
+         best2 * 1e3, n_seg, B, n_obs * 104.0 * 1e-6);
+  // host reference in double for a sample of cameras
+  std::vector<float> hbl(n_cams * 81), hbv(n_cams * 9), hps(n_cams * 9), hbm(n_cams * 81);
+  CK(hipMemcpy(hbl.data(), bl, hbl.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hbv.data(), bv, hbv.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hps.data(), ps, hps.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hbm.data(), bm, hbm.size() * 4, hipMemcpyDeviceToHost));
+  double worst_bl = 0, worst_b = 0, worst_d = 0, worst_bm = 0;
+  for (int c : {0, 1, 7, 8, 123, 888, 1770, 1777}) {
+    double G[81] = {0}, T[81] = {0}, t9[9] = {0};
+    for (int o : cam_list[c]) {
+      const float* jp = &hJ[size_t(o) * 18];
+      const float* w = &hW[size_t(o) * 8];
+      double X[3][9];
+      for (int m = 0; m < 3; ++m)
+        for (int a = 0; a < 9; ++a) X[m][a] = double(w[2 * m]) * jp[a] + double(w[2 * m + 1]) * jp[9 + a];
+      for (int a = 0; a < 9; ++a) {
+        t9[a] += double(jp[a]) * w[6] + double(jp[9 + a]) * w[7];
+        for (int b = 0; b < 9; ++b) {
+          G[9 * a + b] += double(jp[a]) * jp[b] + double(jp[9 + a]) * jp[9 + b];
+          T[9 * a + b] += X[0][a] * X[0][b] + X[1][a] * X[1][b] + X[2][a] * X[2][b];
+        }
+      }
+    }
+    double D[9];
+    for (int a = 0; a < 9; ++a) {
+      D[a] = 1.0 / (double(eps) + std::sqrt(G[10 * a]));
+      worst_d = std::max(worst_d, std::abs(hps[9 * c + a] - D[a]) / D[a]);
+      worst_b = std::max(worst_b, std::abs(hbv[9 * c + a] - D[a] * t9[a]) / (std::abs(D[a] * t9[a]) + 1e-3));
+    }
+    double nb = 0, nr = 0, nm = 0, nmr = 0;
+    for (int a = 0; a < 9; ++a)
+      for (int b = 0; b < 9; ++b) {
+        const double ref = D[a] * D[b] * (G[9 * a + b] - T[9 * a + b]) + (a == b ? lambda : 0.0);
+        nb += (hbl[81 * c + 9 * a + b] - ref) * (hbl[81 * c + 9 * a + b] - ref);
+        nr += ref * ref;
+        const double rm = D[a] * D[b] * G[9 * a + b];
+        nm += (hbm[81 * c + 9 * a + b] - rm) * (hbm[81 * c + 9 * a + b] - rm);
+        nmr += rm * rm;
+      }
+    worst_bl = std::max(worst_bl, std::sqrt(nb / nr));
+    worst_bm = std::max(worst_bm, std::sqrt(nm / nmr));
+  }
+  printf("against the double reference (8 cameras): pose scaling %.2e, B_mid %.2e, blocks %.2e, b %.2e (relative)\n", worst_d,
+         worst_bm, worst_bl, worst_b);
+  if (!(worst_d < 1e-5 && worst_bm < 1e-5 && worst_bl < 1e-4 && worst_b < 1e-4)) return 1;
+  }
+  return 0;
+}
