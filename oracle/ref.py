@@ -80,8 +80,12 @@ class Reference:
         xy = np.ascontiguousarray(prob.obs_xy, dtype=self.dtype)
         f = self._fn("create")
         f.restype = C.c_void_p
-        self.h = C.c_void_p(f(C.c_int(self.n_cams), C.c_int(self.n_lms), _ptr(off, C.c_int64),
-                              _ptr(cam, C.c_int32), _ptr(xy, self.ct), C.byref(self.options)))
+        h = f(C.c_int(self.n_cams), C.c_int(self.n_lms), _ptr(off, C.c_int64),
+              _ptr(cam, C.c_int32), _ptr(xy, self.ct), C.byref(self.options))
+        if not h:
+            raise ValueError("not a configuration of the reference (use_valid_projections_only must equal "
+                             "optimized_cost != ERROR, linearizor_qr.cpp:58-68)")
+        self.h = C.c_void_p(h)
         self.set_state(prob.cams, prob.lms)
 
     def _fn(self, name):

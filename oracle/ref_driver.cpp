@@ -247,6 +247,13 @@ void blocks_out(const rootba::IndexedBlocks<S>& blocks, int n_cams, S* out) {
 
 template <class S>
 Handle<S>* h_create(int n_cams, int n_lms, const int64_t* off, const int32_t* cam, const S* xy, const ref_options* o) {
+  // the reference has ONE knob: LinearizorQR derives the blocks' use_valid_projections_only from
+  // SolverOptions::use_projection_validity_check(), i.e. from optimized_cost (linearizor_qr.cpp:58-68)
+  if ((o->use_valid_projections_only != 0) != (o->optimized_cost != 0)) {
+    std::cerr << "oracle/_ref: use_valid_projections_only = " << o->use_valid_projections_only
+              << " with optimized_cost = " << o->optimized_cost << " is not a configuration of the reference\n";
+    return nullptr;
+  }
   auto* h = new Handle<S>();
   h->ropt = *o;
   h->sopt = to_solver_options(*o);
