@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg — never by the product package `rootba_amd`.
-See oracle/rootba_oracle.hpp for the parity status ("parity unpinned").
+See oracle/rootba_oracle.hpp for the parity status (pinned against the reference's own code
+through oracle/_ref, see oracle/ref.py; third-party arithmetic unpinned).
 """
 from __future__ import annotations
 

@@ -7,15 +7,22 @@
 // build, link, load or execute anything under oracle/. The product path
 // (rootba_amd/, include/) never calls into it and has no CPU fallback.
 //
-// PARITY STATUS: "parity unpinned".
-// The reference holds no golden vectors for this path (every reference test is
-// an equivalence/property test on a data file that is absent here), and the
-// reference itself cannot be compiled in this environment (Eigen 3.4, Sophus,
-// basalt-headers, TBB headers, glog, fmt are un-vendored submodules; no
-// network). The oracle is therefore validated the same way the reference
-// validates itself (tests/test_oracle_*.py): QR == explicit Schur complement,
-// operator == explicit matrix, analytic == numeric Jacobians, projection ==
-// the in-tree Snavely formula, plus numpy.linalg cross-checks.
+// PARITY STATUS: pinned against the reference's own code, NOT against the
+// arithmetic inside its third-party libraries.
+// The reference holds no golden vectors for this path and cannot be built with
+// its own dependencies here (Eigen 3.4, Sophus, basalt-headers, TBB headers,
+// glog, fmt are un-vendored submodules; no network). oracle/build_ref.sh
+// compiles the reference's hot-path sources unmodified against stand-ins for
+// those libraries (oracle/ref_shims/, oracle/ref_driver.cpp); this restatement
+// agrees with that build to 1e-16..1e-14 (double) / ~1e-6 (float) on every
+// stage, per solver variant and over whole LM runs
+// (tests/test_oracle_vs_reference.py, tests/test_reference_golden.py).
+// Eigen's / Sophus' / basalt's own arithmetic is restated in BOTH places from
+// the published algorithms - that part remains "parity unpinned" and is bounded
+// by the reference's own boundary tests (projection == in-tree Snavely formula,
+// analytic == numeric Jacobians), by an independent autograd / dense-normal-
+// equation derivation (tests/test_oracle_independent.py) and by the property
+// tests the reference uses for itself (tests/test_oracle_*.py).
 //
 // Every function cites the reference file:line (relative to /root/reference)
 // whose behaviour it restates. Third-party arithmetic (Eigen Householder /
