@@ -430,8 +430,16 @@ class BalProblem {
   void perturb(double rotation_sigma, double translation_sigma, double landmark_sigma, int seed) {
     std::default_random_engine eng = seed < 0 ? std::default_random_engine{std::random_device{}()}
                                               : std::default_random_engine{static_cast<unsigned>(seed)};
-    std::normal_distribution<double> normal;
-    auto noise = [&](double sigma) { return detail::Vec3{normal(eng) * sigma, normal(eng) * sigma, normal(eng) * sigma}; };
+    // A FRESH distribution object per 3-vector, as the reference's perturbation<T, N>() has (bal_problem.cpp:105-114):
+    // libstdc++'s normal_distribution produces values in pairs and caches the second one, so a shared object would
+    // consume the engine differently from the fourth draw on (checked against the reference's own loader,
+    // tests/test_oracle_vs_reference.py).
+    auto noise = [&](double sigma) {
+      std::normal_distribution<double> normal;
+      detail::Vec3 v;
+      for (int j = 0; j < 3; ++j) v[j] = normal(eng) * sigma;
+      return v;
+    };
     if (rotation_sigma > 0 || translation_sigma > 0) {
       for (auto& cam : cameras) {
         double q[4] = {double(cam[0]), double(cam[1]), double(cam[2]), double(cam[3])};

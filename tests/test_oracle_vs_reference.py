@@ -445,3 +445,40 @@ def test_extreme_damping(O, R, small_problem):
         first = False
         assert rel_err(b_a, b_b) < 1e-11 and rel_err(s_a, s_b) < 1e-11
         assert rel_err(o.right_multiply(x), r.right_multiply(x)) < 1e-11
+
+
+def test_host_cpp_loader_pipeline_against_the_references(R, tmp_path):
+    """The PRODUCT's C++ host loader (rootba_amd/csrc/host/bal_problem.hpp, through `bal_qr_hip --dry-run`) against
+    load_normalized_bal_problem<double> of the reference (bal_problem.cpp:773-852) on the same file: load, normalise,
+    PERTURB with the same seed (std::default_random_engine + a fresh normal_distribution per 3-vector: the same
+    engine consumption as the reference), depth filter."""
+    import json
+    import subprocess
+    from rootba_amd import build
+    from rootba_amd import problem as P
+    build.build()
+    raw = P.synthetic_problem(16, 150, 600, seed=9)
+    path = str(tmp_path / "problem-16-150-pre.txt")
+    P.write_bal(raw, path)
+    cases = [([], {}),
+             (["--translation-sigma", "0.05", "--point-sigma", "0.02", "--rotation-sigma", "0.01", "--random-seed", "38401"],
+              dict(translation_sigma=0.05, point_sigma=0.02, rotation_sigma=0.01, seed=38401)),
+             (["--point-sigma", "0.5", "--random-seed", "7", "--init-depth-threshold", "60"],
+              dict(point_sigma=0.5, seed=7, init_depth_threshold=60.0)),
+             (["--no-normalize", "--rotation-sigma", "0.02", "--random-seed", "1"],
+              dict(normalize=False, rotation_sigma=0.02, seed=1))]
+    for args, kw in cases:
+        out = subprocess.run([build.APP, "--input", path, "--dry-run", *args], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        info = json.loads(out.stdout.strip().splitlines()[-1])
+        ref = R.load_bal(path, **kw)
+        assert (info["num_cameras"], info["num_landmarks"], info["num_observations"]) == \
+            (ref["cams"].shape[0], ref["lms"].shape[0], ref["obs_cam_idx"].size)
+        assert np.allclose(info["landmark_sum"], ref["lms"].sum(0), rtol=1e-10, atol=1e-8)
+        off = ref["lm_obs_offsets"]
+        pos = np.arange(ref["obs_cam_idx"].size) - np.repeat(off[:-1], np.diff(off)) + 1
+        chk = float(np.sum(pos * ((ref["obs_cam_idx"] + 1.0) * ref["obs_xy"][:, 0] + ref["obs_xy"][:, 1])))
+        assert np.isclose(info["obs_checksum"], chk, rtol=1e-11)
+        q, qr = np.array(info["cam0"][:4]), ref["cams"][0, :4]
+        assert min(np.linalg.norm(q - qr), np.linalg.norm(q + qr)) < 1e-10
+        assert np.allclose(info["cam0"][4:], ref["cams"][0, 4:7], rtol=1e-10, atol=1e-9)
