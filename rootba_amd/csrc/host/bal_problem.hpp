@@ -432,8 +432,7 @@ class BalProblem {
                                               : std::default_random_engine{static_cast<unsigned>(seed)};
     // A FRESH distribution object per 3-vector, as the reference's perturbation<T, N>() has (bal_problem.cpp:105-114):
     // libstdc++'s normal_distribution produces values in pairs and caches the second one, so a shared object would
-    // consume the engine differently from the fourth draw on (checked against the reference's own loader,
-    // tests/test_oracle_vs_reference.py).
+    // consume the engine differently from the fourth draw on (the tests hold this pipeline to the reference's own loader).
     auto noise = [&](double sigma) {
       std::normal_distribution<double> normal;
       detail::Vec3 v;

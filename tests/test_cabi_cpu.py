@@ -46,6 +46,19 @@ def test_default_options_match_reference_defaults(lib):
     assert o.max_trust_region_radius == 1e16 and o.initial_vee == 2.0 and o.vee_factor == 2.0
 
 
+def test_default_options_are_the_reference_builds(lib):
+    """rba_default_options (include/rootba_hip.h) field by field against the defaults of the reference's OWN
+    SolverOptions declaration, read out of the reference build (oracle/_ref, see oracle/ref_driver.cpp)."""
+    from oracle import ref as R
+    if not R.available():
+        pytest.skip("oracle/_ref is not built and /root/reference is not present")
+    a, b = L.default_options(), R.default_options()
+    for name, _ in L.RbaOptions._fields_:
+        if name in ("implicit_q", "explicit_after", "num_threads"):  # product-only switches / host thread count
+            continue
+        assert getattr(a, name) == getattr(b, name), name
+
+
 def test_option_struct_layout_matches_oracle_mirror():
     from oracle import oracle as O
     assert [f[0] for f in L.RbaOptions._fields_] == [f[0] for f in O.Options._fields_]
