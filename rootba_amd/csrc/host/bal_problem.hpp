@@ -33,13 +33,18 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <fstream>
 #include <utility>
 #include <vector>
 
 namespace rootba_hip {
 
 struct BalDatasetOptions {  // reference src/rootba/bal/bal_dataset_options.hpp:40-100
+  enum class DatasetType { AUTO = 0, ROOTBA, BAL };  // (BUNDLER is not read here)
   std::string input;
+  DatasetType input_type = DatasetType::AUTO;
+  bool save_output = false;
+  std::string output_optimized_path = "optimized.cereal";
   bool normalize = true;
   double normalization_scale = 100.0;
   double rotation_sigma = 0.0;
@@ -513,6 +518,221 @@ class BalProblem {
 
   // 1 - (non-zero 9x9 blocks of the reduced camera system) / n_c^2: cameras are coupled when they
   // observe a common landmark (reference bal_problem.cpp:647-712; byte mask instead of atomics)
+  // ---- ".cereal" problem cache (reference BalProblem::save_rootba / load_rootba, bal_problem.cpp:137-181, 406-427) ------
+  // A cereal BinaryOutputArchive of {file_info; cameras; landmarks}, always in double (the reference casts a float
+  // problem to double before saving, :419-427). What fixes the byte layout:
+  //   in the reference tree:  FileInfo = {type = "rootba::BalProblem", version = "1.0"} written first
+  //                           (util/serialization.hpp:51-60, 150-155; bal_problem_io.hpp:48); BalProblem = cameras, landmarks;
+  //                           Camera = T_c_w, intrinsics; Landmark = p_w, obs; Observation = pos (bal_problem_io.hpp:59-81);
+  //   cereal's portable-binary conventions: arithmetic values raw little-endian, std::string / std::vector / std::map
+  //                           preceded by a uint64 element count, a map entry = key then value, name-value wrappers add
+  //                           nothing;
+  //   basalt-headers' serialisers (un-vendored): SE3 as px py pz qx qy qz qw, fixed-size Eigen matrices as
+  //                           raw coefficients, BalCamera as f k1 k2.
+  // The last line cannot be checked against a file written by the reference here, so it is NOT taken on trust by the
+  // reader: load_rootba parses under each plausible variant of it (translation-first or quaternion-first SE3; matrices
+  // with or without an int32 rows/cols prefix, the intrinsics too or not) and accepts the one variant that consumes the
+  // file exactly with unit quaternions, matrix shapes as declared, camera indices in range and strictly ascending inside
+  // every landmark (std::map order). save_rootba writes the first variant.
+  struct CerealLayout {
+    bool translation_first = true;  // SE3: px py pz qx qy qz qw (else qx qy qz qw px py pz)
+    bool matrix_dims = false;       // int32 rows, int32 cols before every Eigen matrix
+    bool intrinsics_dims = false;   // ... also before the camera's parameter vector
+  };
+  static constexpr const char* kFileType = "rootba::BalProblem";
+  static constexpr const char* kFileVersion = "1.0";
+
+  bool save_rootba(const std::string& path, const CerealLayout& lay = CerealLayout()) const {
+    std::string out;
+    auto put = [&](const void* p, size_t n) { out.append(static_cast<const char*>(p), n); };
+    auto put_u64 = [&](uint64_t v) { put(&v, 8); };
+    auto put_f64 = [&](double v) { put(&v, 8); };
+    auto put_str = [&](const std::string& v) {
+      put_u64(v.size());
+      put(v.data(), v.size());
+    };
+    auto put_dims = [&](bool on, int32_t r, int32_t c) {
+      if (on) {
+        put(&r, 4);
+        put(&c, 4);
+      }
+    };
+    put_str(kFileType);
+    put_str(kFileVersion);
+    put_u64(cameras.size());
+    for (const auto& cam : cameras) {
+      if (lay.translation_first) {
+        for (int j = 4; j < 7; ++j) put_f64(double(cam[j]));
+        for (int j = 0; j < 4; ++j) put_f64(double(cam[j]));
+      } else {
+        for (int j = 0; j < 7; ++j) put_f64(double(cam[j]));
+      }
+      put_dims(lay.matrix_dims && lay.intrinsics_dims, 3, 1);
+      for (int j = 7; j < 10; ++j) put_f64(double(cam[j]));
+    }
+    put_u64(points.size());
+    for (size_t l = 0; l < points.size(); ++l) {
+      put_dims(lay.matrix_dims, 3, 1);
+      for (int j = 0; j < 3; ++j) put_f64(double(points[l][j]));
+      put_u64(uint64_t(lm_off[l + 1] - lm_off[l]));
+      for (int64_t o = lm_off[l]; o < lm_off[l + 1]; ++o) {
+        const int32_t c = obs_cam[o];
+        put(&c, 4);
+        put_dims(lay.matrix_dims, 2, 1);
+        put_f64(double(obs_xy[2 * o]));
+        put_f64(double(obs_xy[2 * o + 1]));
+      }
+    }
+    std::ofstream os(path, std::ios::binary);
+    if (!os.is_open()) return false;
+    os.write(out.data(), std::streamsize(out.size()));
+    return bool(os);
+  }
+
+  // returns false (and leaves *this untouched) when the file is not a BalProblem cache in any accepted layout;
+  // `accepted`, if given, receives the layout that validated
+  bool load_rootba(const std::string& path, std::string* error = nullptr, CerealLayout* accepted = nullptr) {
+    const detail::MappedFile file(path);
+    const char* const base = file.data;
+    const size_t size = file.size;
+    auto fail = [&](const std::string& why) {
+      if (error) *error = why;
+      return false;
+    };
+    size_t hdr = 0;
+    auto get_str = [&](std::string& v) {
+      uint64_t n;
+      if (hdr + 8 > size) return false;
+      std::memcpy(&n, base + hdr, 8);
+      hdr += 8;
+      if (n > size - hdr) return false;
+      v.assign(base + hdr, size_t(n));
+      hdr += size_t(n);
+      return true;
+    };
+    std::string type, version;
+    if (!get_str(type) || !get_str(version)) return fail("truncated file_info");
+    if (type != kFileType) return fail("loaded file has different type '" + type + "'");
+    if (version != kFileVersion) return fail("unknown version '" + version + "'");
+    std::string last_why = "no layout matched";
+    for (int v = 0; v < 6; ++v) {
+      CerealLayout lay;
+      lay.translation_first = (v & 1) == 0;
+      lay.matrix_dims = v >= 2;
+      lay.intrinsics_dims = v >= 4;
+      BalProblem<double> p;
+      size_t at = hdr;
+      bool ok = true;
+      std::string why;
+      auto need = [&](size_t n) {
+        if (ok && at + n > size) {
+          ok = false;
+          why = "truncated";
+        }
+        return ok;
+      };
+      auto get_u64 = [&]() {
+        uint64_t x = 0;
+        if (need(8)) {
+          std::memcpy(&x, base + at, 8);
+          at += 8;
+        }
+        return x;
+      };
+      auto get_f64 = [&]() {
+        double x = 0;
+        if (need(8)) {
+          std::memcpy(&x, base + at, 8);
+          at += 8;
+        }
+        return x;
+      };
+      auto get_i32 = [&]() {
+        int32_t x = 0;
+        if (need(4)) {
+          std::memcpy(&x, base + at, 4);
+          at += 4;
+        }
+        return x;
+      };
+      auto dims = [&](bool on, int32_t r, int32_t c) {
+        if (!on) return;
+        const int32_t rr = get_i32(), cc = get_i32();
+        if (ok && (rr != r || cc != c)) {
+          ok = false;
+          why = "matrix shape";
+        }
+      };
+      const uint64_t nc = get_u64();
+      if (ok && (nc == 0 || nc > (size - at) / 80)) {
+        ok = false;
+        why = "camera count";
+      }
+      if (ok) p.cameras.resize(size_t(nc));
+      for (uint64_t i = 0; ok && i < nc; ++i) {
+        auto& cam = p.cameras[size_t(i)];
+        if (lay.translation_first) {
+          for (int j = 4; j < 7; ++j) cam[j] = get_f64();
+          for (int j = 0; j < 4; ++j) cam[j] = get_f64();
+        } else {
+          for (int j = 0; j < 7; ++j) cam[j] = get_f64();
+        }
+        dims(lay.matrix_dims && lay.intrinsics_dims, 3, 1);
+        for (int j = 7; j < 10; ++j) cam[j] = get_f64();
+        const double n2 = cam[0] * cam[0] + cam[1] * cam[1] + cam[2] * cam[2] + cam[3] * cam[3];
+        if (ok && !(std::abs(n2 - 1.0) < 1e-6)) {
+          ok = false;
+          why = "quaternion norm";
+        }
+      }
+      const uint64_t nl = get_u64();
+      if (ok && nl > (size - at) / 32) {
+        ok = false;
+        why = "landmark count";
+      }
+      if (ok) {
+        p.points.resize(size_t(nl));
+        p.lm_off.assign(1, 0);
+        p.lm_off.reserve(size_t(nl) + 1);
+      }
+      for (uint64_t l = 0; ok && l < nl; ++l) {
+        dims(lay.matrix_dims, 3, 1);
+        for (int j = 0; j < 3; ++j) p.points[size_t(l)][j] = get_f64();
+        const uint64_t k = get_u64();
+        if (ok && k > (size - at) / 20) {
+          ok = false;
+          why = "observation count";
+        }
+        int32_t prev = -1;
+        for (uint64_t o = 0; ok && o < k; ++o) {
+          const int32_t c = get_i32();
+          dims(lay.matrix_dims, 2, 1);
+          const double x = get_f64(), y = get_f64();
+          if (ok && (c <= prev || c >= int64_t(nc))) {
+            ok = false;
+            why = "camera index";
+          }
+          prev = c;
+          p.obs_cam.push_back(c);
+          p.obs_xy.push_back(x);
+          p.obs_xy.push_back(y);
+        }
+        p.lm_off.push_back(int64_t(p.obs_cam.size()));
+      }
+      if (ok && at != size) {
+        ok = false;
+        why = "trailing bytes";
+      }
+      if (ok) {
+        *this = p.template copy_cast<Scalar>();
+        if (accepted) *accepted = lay;
+        return true;
+      }
+      last_why = why;
+    }
+    return fail("not a BalProblem cache in any accepted layout (" + last_why + ")");
+  }
+
   double compute_rcs_sparsity() const {
     const size_t nc = cameras.size();
     std::vector<uint8_t> mask(nc * nc, 0);
@@ -558,7 +778,18 @@ BalProblem<Scalar> load_normalized_bal_problem(const BalDatasetOptions& o, doubl
                                                double* preprocess_seconds = nullptr) {
   const auto t0 = std::chrono::steady_clock::now();
   BalProblem<double> p;
-  p.load_bal(o.input);
+  // autodetect_input_type (bal_problem.cpp:122-135): "*.cereal" is the problem cache, everything else BAL text
+  BalDatasetOptions::DatasetType type = o.input_type;
+  if (type == BalDatasetOptions::DatasetType::AUTO) {
+    const bool cereal = o.input.size() >= 7 && o.input.compare(o.input.size() - 7, 7, ".cereal") == 0;
+    type = cereal ? BalDatasetOptions::DatasetType::ROOTBA : BalDatasetOptions::DatasetType::BAL;
+  }
+  if (type == BalDatasetOptions::DatasetType::ROOTBA) {
+    std::string why;
+    if (!p.load_rootba(o.input, &why)) throw std::runtime_error("Failed to load " + o.input + ": " + why);
+  } else {
+    p.load_bal(o.input);
+  }
   const auto t1 = std::chrono::steady_clock::now();
   if (o.normalize) p.normalize(o.normalization_scale);
   p.perturb(o.rotation_sigma, o.translation_sigma, o.point_sigma, o.random_seed);

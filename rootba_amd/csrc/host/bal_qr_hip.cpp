@@ -39,6 +39,8 @@ void usage() {
       "  --solver-type SQUARE_ROOT|SCHUR_COMPLEMENT   (default SQUARE_ROOT)\n"
       "  --dense-blocks                         matrix-free products on the dense Q2^T Jp blocks (default: from the QR factors)\n"
       "  --save-log-flags <JSON,UBJSON>         (default JSON; UBJSON writes <log>.ubjson next to it)\n"
+      "  --input-type <AUTO|ROOTBA|BAL>         AUTO: '*.cereal' is the rootba problem cache, everything else BAL text\n"
+      "  --[no-]save-output, --output-optimized-path <p>   write the optimised problem as a .cereal cache (default optimized.cereal)\n"
       "  --dry-run                              load + preprocess only, print problem statistics");
 }
 
@@ -64,6 +66,11 @@ int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string&
   std::printf("Loaded BAL problem (%d cams, %d lms, %lld obs) from '%s' in %.3fs\n", prob.num_cameras(),
               prob.num_landmarks(), static_cast<long long>(prob.num_observations()), ds.input.c_str(), load_seconds);
   if (dry_run) {
+    // (--dry-run --save-output writes the PREPROCESSED problem: the cache the reference's tools produce)
+    if (ds.save_output && !prob.save_rootba(ds.output_optimized_path)) {
+      std::fprintf(stderr, "Failed to save %s.\n", ds.output_optimized_path.c_str());
+      return 2;
+    }
     std::printf("{\"num_cameras\": %d, \"num_landmarks\": %d, \"num_observations\": %lld, \"load_seconds\": %.6f, "
                 "\"rcs_sparsity\": %.12e, \"obs_checksum\": %.12e, "
                 "\"landmark_sum\": [%.12e, %.12e, %.12e], \"cam0\": [%.12e, %.12e, %.12e, %.12e, %.12e, %.12e, %.12e]}\n",
@@ -81,6 +88,11 @@ int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string&
   timing.load_time = load_only_seconds;
   timing.preprocess_time = preprocess_seconds;
   timing.optimize_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_opt).count();
+  // BalProblem::postprocress (bal_problem.cpp:556-568): the optimised problem as a `.cereal` cache
+  if (ds.save_output && !prob.save_rootba(ds.output_optimized_path)) {
+    std::fprintf(stderr, "Failed to save %s.\n", ds.output_optimized_path.c_str());
+    return 2;
+  }
   // ba_log.json in the reference's layout (src/rootba/bal/ba_log.cpp:62-149)
   if (!save_ba_log(log_path, g_save_log_flags, summary, summarize_dataset(prob, ds.input), timing)) {
     std::fprintf(stderr, "Could not save BA log to %s.\n", log_path.c_str());
@@ -186,6 +198,16 @@ int main(int argc, char** argv) {
     };
     if (a == "--help" || a == "-h") { usage(); return 0; }
     else if (a == "--input") ds.input = val();
+    else if (a == "--input-type") {
+      const std::string v = val();
+      if (v == "AUTO") ds.input_type = BalDatasetOptions::DatasetType::AUTO;
+      else if (v == "ROOTBA") ds.input_type = BalDatasetOptions::DatasetType::ROOTBA;
+      else if (v == "BAL") ds.input_type = BalDatasetOptions::DatasetType::BAL;
+      else { std::fprintf(stderr, "input type %s not implemented (AUTO, ROOTBA, BAL)\n", v.c_str()); return 1; }
+    }
+    else if (a == "--save-output") ds.save_output = true;
+    else if (a == "--no-save-output") ds.save_output = false;
+    else if (a == "--output-optimized-path") ds.output_optimized_path = val();
     else if (a == "--normalize") ds.normalize = true;
     else if (a == "--no-normalize") ds.normalize = false;
     else if (a == "--normalization-scale") ds.normalization_scale = std::stod(val());

@@ -363,3 +363,159 @@ def test_loaders_against_hand_derived_values(app):
     assert info["rcs_sparsity"] == 0.0
     assert np.allclose(P.quat_to_rot(np.array(info["cam0"][:4])), R0, atol=1e-12)
     assert info["cam0"][4:] == [1.0, -2.0, -3.0]
+
+
+# ---- the `.cereal` problem cache (reference BalProblem::save_rootba / load_rootba) ------------------------------
+def _cereal_bytes(prob, translation_first=True, matrix_dims=False, intrinsics_dims=False, ftype=b"rootba::BalProblem",
+                  version=b"1.0"):
+    """The documented layout (rootba_amd/csrc/host/bal_problem.hpp), written independently with struct.pack."""
+    import struct
+    out = [struct.pack("<Q", len(ftype)), ftype, struct.pack("<Q", len(version)), version]
+    dims = lambda on, r, c: struct.pack("<ii", r, c) if on else b""  # noqa: E731
+    out.append(struct.pack("<Q", prob.n_cams))
+    for cam in prob.cams:
+        se3 = list(cam[4:7]) + list(cam[0:4]) if translation_first else list(cam[0:7])
+        out.append(struct.pack("<7d", *se3) + dims(matrix_dims and intrinsics_dims, 3, 1) + struct.pack("<3d", *cam[7:10]))
+    out.append(struct.pack("<Q", prob.n_lms))
+    off = prob.lm_obs_offsets
+    for l in range(prob.n_lms):
+        out.append(dims(matrix_dims, 3, 1) + struct.pack("<3d", *prob.lms[l]) + struct.pack("<Q", off[l + 1] - off[l]))
+        for o in range(off[l], off[l + 1]):
+            out.append(struct.pack("<i", prob.obs_cam_idx[o]) + dims(matrix_dims, 2, 1) + struct.pack("<2d", *prob.obs_xy[o]))
+    return b"".join(out)
+
+
+def _stats(app, path, *extra):
+    out = subprocess.run([app, "--input", path, "--dry-run", "--no-normalize", *extra], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    return {k: info[k] for k in ("num_cameras", "num_landmarks", "num_observations", "obs_checksum", "landmark_sum", "cam0",
+                                 "rcs_sparsity")}
+
+
+def _same(a, b):
+    assert (a["num_cameras"], a["num_landmarks"], a["num_observations"]) == (b["num_cameras"], b["num_landmarks"], b["num_observations"])
+    assert np.isclose(a["obs_checksum"], b["obs_checksum"], rtol=1e-12) and a["rcs_sparsity"] == b["rcs_sparsity"]
+    assert np.allclose(a["landmark_sum"], b["landmark_sum"], rtol=1e-11) and np.allclose(a["cam0"], b["cam0"], rtol=1e-11)
+
+
+def test_cereal_cache_round_trip_and_byte_layout(app, bal_file, tmp_path):
+    """BAL text -> preprocess -> save as .cereal -> load: same problem; the file is byte for byte the documented layout
+    (file_info strings, uint64 counts, SE3 as px py pz qx qy qz qw, raw fixed-size matrices, int32 map keys)."""
+    path, raw = bal_file
+    cache = str(tmp_path / "pre.cereal")
+    first = subprocess.run([app, "--input", path, "--dry-run", "--init-depth-threshold", "60", "--save-output",
+                            "--output-optimized-path", cache], capture_output=True, text=True)
+    assert first.returncode == 0, first.stderr
+    want = json.loads(first.stdout.strip().splitlines()[-1])
+    _same(_stats(app, cache), want)                       # autodetected by the extension
+    other = str(tmp_path / "pre.bin")
+    os.replace(cache, other)
+    _same(_stats(app, other, "--input-type", "ROOTBA"), want)
+    mirror = P.filter_obs(P.normalize(P.read_bal(path), 100.0), 60.0)
+    data = open(other, "rb").read()
+    mine = _cereal_bytes(mirror)
+    assert len(data) == len(mine)
+    assert data[:45] == mine[:45]  # file_info + camera count
+    a, b = np.frombuffer(data[45:45 + 80 * mirror.n_cams], "<f8"), np.frombuffer(mine[45:45 + 80 * mirror.n_cams], "<f8")
+    assert np.allclose(a.reshape(-1, 10)[:, :3], b.reshape(-1, 10)[:, :3], rtol=1e-9, atol=1e-9)    # translations
+    assert np.allclose(a.reshape(-1, 10)[:, 7:], b.reshape(-1, 10)[:, 7:], rtol=0, atol=0)          # intrinsics: untouched
+    for qa, qb in zip(a.reshape(-1, 10)[:, 3:7], b.reshape(-1, 10)[:, 3:7]):
+        assert min(np.linalg.norm(qa - qb), np.linalg.norm(qa + qb)) < 1e-9
+
+
+@pytest.mark.parametrize("variant", [dict(), dict(translation_first=False), dict(matrix_dims=True),
+                                     dict(matrix_dims=True, translation_first=False),
+                                     dict(matrix_dims=True, intrinsics_dims=True),
+                                     dict(matrix_dims=True, intrinsics_dims=True, translation_first=False)],
+                         ids=["t-first", "q-first", "dims", "dims-q-first", "dims+intr", "dims+intr-q-first"])
+def test_cereal_cache_reader_accepts_the_layout_variants(app, bal_file, tmp_path, variant):
+    """The third-party part of the layout (basalt-headers' serialisers) is unpinned here, so the reader tries its
+    plausible variants and takes the one that validates - each variant, written independently, loads to the same problem."""
+    path, raw = bal_file
+    prob = P.read_bal(path)
+    want = _stats(app, path)
+    f = str(tmp_path / "v.cereal")
+    open(f, "wb").write(_cereal_bytes(prob, **variant))
+    _same(_stats(app, f), want)
+
+
+def test_cereal_cache_reader_rejects_what_it_cannot_validate(app, bal_file, tmp_path):
+    path, raw = bal_file
+    prob = P.read_bal(path)
+    good = _cereal_bytes(prob)
+    bad_q = P.BalProblem(prob.cams.copy(), prob.lms, prob.lm_obs_offsets, prob.obs_cam_idx, prob.obs_xy, "bad")
+    bad_q.cams[3, :4] *= 1.5
+    desc = P.BalProblem(prob.cams, prob.lms, prob.lm_obs_offsets, prob.obs_cam_idx.copy(), prob.obs_xy, "desc")
+    o0 = prob.lm_obs_offsets[5]
+    desc.obs_cam_idx[o0], desc.obs_cam_idx[o0 + 1] = desc.obs_cam_idx[o0 + 1], desc.obs_cam_idx[o0]
+    cases = {"type": (_cereal_bytes(prob, ftype=b"rootba::Something"), "different type"),
+             "version": (_cereal_bytes(prob, version=b"2.0"), "unknown version"),
+             "truncated": (good[:-9], "accepted layout"), "trailing": (good + b"\0" * 8, "accepted layout"),
+             "quaternion": (_cereal_bytes(bad_q), "accepted layout"), "order": (_cereal_bytes(desc), "accepted layout"),
+             "empty": (b"", "Failed")}
+    for name, (blob, msg) in cases.items():
+        f = str(tmp_path / (name + ".cereal"))
+        open(f, "wb").write(blob)
+        out = subprocess.run([app, "--input", f, "--dry-run"], capture_output=True, text=True)
+        assert out.returncode != 0 and msg in out.stderr, (name, out.stderr)
+
+
+def _cereal_parse(data):
+    """Inverse of _cereal_bytes for the layout the writer emits."""
+    import struct
+    at = 0
+
+    def take(fmt):
+        nonlocal at
+        v = struct.unpack_from(fmt, data, at)
+        at += struct.calcsize(fmt)
+        return v
+    for want in (b"rootba::BalProblem", b"1.0"):
+        (n,) = take("<Q")
+        assert data[at:at + n] == want
+        at += n
+    (nc,) = take("<Q")
+    cams = np.zeros((nc, 10))
+    for i in range(nc):
+        v = take("<10d")
+        cams[i] = list(v[3:7]) + list(v[0:3]) + list(v[7:10])
+    (nl,) = take("<Q")
+    lms, off, cam, xy = np.zeros((nl, 3)), [0], [], []
+    for l in range(nl):
+        lms[l] = take("<3d")
+        (k,) = take("<Q")
+        for _ in range(k):
+            c, x, y = take("<idd")
+            cam.append(c)
+            xy.append((x, y))
+        off.append(len(cam))
+    assert at == len(data)
+    return P.BalProblem(cams, lms, np.array(off, dtype=np.int64), np.array(cam, dtype=np.int32), np.array(xy), "cereal")
+
+
+@pytest.mark.gpu
+def test_bal_qr_hip_saves_the_optimised_problem(app, bal_file, tmp_path):
+    """`--save-output` (BalProblem::postprocress, bal_problem.cpp:556-568): the `.cereal` file written after the solve
+    holds the optimised state - its cost, evaluated through the Python binding, is the run's final cost."""
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    path, _ = bal_file
+    log_path, cache = str(tmp_path / "ba_log.json"), str(tmp_path / "optimized.cereal")
+    out = subprocess.run([app, "--input", path, "--max-num-iterations", "6", "--robust-norm", "HUBER", "--log-path", log_path,
+                          "--save-output", "--output-optimized-path", cache], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    log = json.load(open(log_path))
+    opt = _cereal_parse(open(cache, "rb").read())
+    start = P.normalize(P.read_bal(path), 100.0)
+    assert (opt.n_cams, opt.n_lms, opt.n_obs) == (start.n_cams, start.n_lms, start.n_obs)
+    assert np.array_equal(opt.obs_cam_idx, start.obs_cam_idx) and np.array_equal(opt.obs_xy, start.obs_xy)
+    assert not np.allclose(opt.lms, start.lms)
+    g = LinearizorHIP(opt, np.float64, L.default_options(robust_norm=1))
+    assert abs(g.compute_error().all_error - log["cost"][-1]) <= 1e-9 * log["cost"][-1]
+    # and the cache is a valid input of the tool itself
+    again = subprocess.run([app, "--input", cache, "--no-normalize", "--max-num-iterations", "1", "--robust-norm", "HUBER",
+                            "--log-path", log_path], capture_output=True, text=True)
+    assert again.returncode == 0, again.stderr
+    assert abs(json.load(open(log_path))["cost"][0] - log["cost"][-1]) <= 1e-9 * log["cost"][-1]
