@@ -482,3 +482,39 @@ def test_host_cpp_loader_pipeline_against_the_references(R, tmp_path):
         q, qr = np.array(info["cam0"][:4]), ref["cams"][0, :4]
         assert min(np.linalg.norm(q - qr), np.linalg.norm(q + qr)) < 1e-10
         assert np.allclose(info["cam0"][4:], ref["cams"][0, 4:7], rtol=1e-10, atol=1e-9)
+
+
+# ---- BASELINE.json configurations -------------------------------------------------------------------------------------
+def test_baseline_config0_ladybug_float64_whole_run(O, R, ladybug_problem):
+    """BASELINE configs[0]: "ladybug problem-49-7776 float64, solver=QR, CPU reference (plumbing, no GPU)" - the
+    reference's own CPU-runnable case, run here by the reference build with the reference's default options
+    (squared norm, 20 iterations, function_tolerance 1e-6) on the synthetic stand-in of that problem (the real file is
+    not in the image): the restated oracle follows it iteration by iteration."""
+    o = O.Oracle(ladybug_problem, np.float64, O.default_options())
+    r = R.Reference(ladybug_problem, np.float64, R.default_options())
+    la, ta = o.optimize_lm()
+    lb, tb = r.optimize_lm()
+    assert ta == tb == 1 and len(la) == len(lb) >= 5  # CONVERGED by the function tolerance
+    for a, b in zip(la, lb):
+        assert (a.iteration, a.step_is_successful, a.cg_iterations) == (b.iteration, b.step_is_successful, b.cg_iterations)
+        assert abs(a.cost - b.cost) <= 1e-12 * b.cost
+    (ca, la_), (cb, lb_) = o.get_state(), r.get_state()
+    assert rel_err(ca, cb) < 1e-12 and rel_err(la_, lb_) < 1e-12
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_baseline_config2_trafalgar_size_one_iteration(O, R, dt):
+    """BASELINE configs[2] size (257 cameras, 65132 landmarks, ~226k observations): one LM iteration, stage by stage."""
+    from rootba_amd import problem as P
+    prob = P.preprocess(P.named_synthetic("trafalgar-257"))
+    o, r = both(O, R, prob, dt)
+    assert o.linearize() == 0 and r.linearize() == 0
+    ia, ca = o.solve(1e-4)
+    ib, cb = r.solve(1e-4)
+    assert abs(ca.num_iterations - cb.num_iterations) <= (0 if np.dtype(dt) == np.float64 else 1)
+    if ca.num_iterations == cb.num_iterations:
+        assert rel_err(ia, ib) < tol(dt, 1e-10, 1e-3)
+    la, lb = o.apply(ib), r.apply(ib)
+    assert abs(la - lb) <= tol(dt, 1e-11, 1e-4) * abs(lb)
+    ea, eb = o.compute_error(), r.compute_error()
+    assert abs(ea.all_error - eb.all_error) <= tol(dt, 1e-12, 1e-4) * eb.all_error
