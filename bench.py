@@ -175,6 +175,9 @@ def cpu_baseline(prob, n_iter: int, gpu_rows):
         "cores": threads,
         "cores_note": cpu_note,
         "kind": "port",
+        "kind_note": "OpenMP restatement (oracle/liboracle.so), pinned against the reference's own sources compiled "
+                     "with third-party stand-ins (oracle/_ref, tests/test_oracle_vs_reference.py); that build is serial "
+                     "and scalar, so it is the checker of this port, not a timing baseline",
         "sample": (f"LM iterations 1..{n_iter} of the same problem, {np.dtype(DTYPE).name}, "
                    f"{n_cg} CG iterations in total, {t:.1f} s; "
                    f"the GPU path runs the same {n_iter} iterations at {len(g) / tg if tg > 0 else 0:.1f} it/s"),
