@@ -518,3 +518,41 @@ def test_baseline_config2_trafalgar_size_one_iteration(O, R, dt):
     assert abs(la - lb) <= tol(dt, 1e-11, 1e-4) * abs(lb)
     ea, eb = o.compute_error(), r.compute_error()
     assert abs(ea.all_error - eb.all_error) <= tol(dt, 1e-12, 1e-4) * eb.all_error
+
+
+@pytest.mark.parametrize("kw", [dict(max_cg_it=2), dict(min_cg_it=12, eta=0.5), dict(eta=1e-3), dict(eta=0.0, max_cg_it=30)],
+                         ids=["max2", "min12", "eta1e-3", "eta0"])
+def test_pcg_iteration_limits_and_forcing_sequence(O, R, small_problem, kw):
+    """ConjugateGradientsSolver options as LinearizorBase::pcg fills them (linearizor_base.cpp:81-103): the iteration
+    cap (termination NO_CONVERGENCE), the minimum iteration count, the forcing-sequence parameter eta."""
+    o, r = both(O, R, small_problem, np.float64, **kw)
+    assert o.linearize() == 0 and r.linearize() == 0
+    for lam in (1e-4, 1e-6):
+        ia, ca = o.solve(lam)
+        ib, cb = r.solve(lam)
+        assert (ca.num_iterations, ca.termination_type) == (cb.num_iterations, cb.termination_type)
+        assert rel_err(ia, ib) < 1e-9
+    if "max_cg_it" in kw:
+        assert cb.num_iterations == kw["max_cg_it"] and cb.termination_type == 0
+    if "min_cg_it" in kw:
+        assert cb.num_iterations >= kw["min_cg_it"]
+
+
+def test_lm_loop_non_default_trust_region_parameters(O, R, small_problem):
+    """min_relative_decrease, initial_vee, vee_factor, trust-region bounds and a loose function tolerance
+    (bal_bundle_adjustment.cpp:264-272, 434-519)."""
+    from rootba_amd import problem as P
+    far = P.preprocess(P.synthetic_problem(20, 150, 600, seed=11), seed=11, translation_sigma=3.0, point_sigma=3.0,
+                       rotation_sigma=0.3)
+    kw = dict(max_num_iterations=15, min_relative_decrease=0.3, initial_vee=3.0, vee_factor=4.0,
+              initial_trust_region_radius=1e9, max_trust_region_radius=1e10, function_tolerance=1e-4)
+    o, r = both(O, R, far, np.float64, **kw)
+    la, ta = o.optimize_lm()
+    lb, tb = r.optimize_lm()
+    assert ta == tb and len(la) == len(lb)
+    assert any(not b.step_is_successful for b in lb[1:])
+    for i, (a, b) in enumerate(zip(la, lb)):
+        assert (a.iteration, a.step_is_successful, a.step_is_valid) == (b.iteration, b.step_is_successful, b.step_is_valid)
+        assert abs(a.cost - b.cost) <= 1e-7 * b.cost
+        if i + 1 < len(la) and i > 0:
+            assert abs(la[i + 1].lambda_ - b.lambda_) <= 1e-6 * b.lambda_  # damping of the next solve
