@@ -214,13 +214,15 @@ def apply_inc_camera(cam, inc9, dtype=np.float64):
 
 
 def load_bal(path, normalize=True, normalization_scale=100.0, rotation_sigma=0.0, translation_sigma=0.0,
-             point_sigma=0.0, seed=-1, init_depth_threshold=0.0):
-    """load_normalized_bal_problem<double> of the reference (BAL text format). Returns a dict of arrays."""
+             point_sigma=0.0, seed=-1, init_depth_threshold=0.0, input_type="BAL"):
+    """load_normalized_bal_problem<double> of the reference (input_type BAL, BUNDLER or AUTO = by file name).
+    Returns a dict of arrays."""
     L = lib()
     L.ref_load_bal.restype = C.c_void_p
     h = L.ref_load_bal(os.fsencode(path), C.c_int(int(normalize)), C.c_double(normalization_scale),
                        C.c_double(rotation_sigma), C.c_double(translation_sigma), C.c_double(point_sigma),
-                       C.c_int(seed), C.c_double(init_depth_threshold))
+                       C.c_int(seed), C.c_double(init_depth_threshold),
+                       C.c_int({"AUTO": 0, "BAL": 2, "BUNDLER": 3}[input_type]))
     if not h:
         raise RuntimeError(f"the reference's loader rejected {path}")
     h = C.c_void_p(h)

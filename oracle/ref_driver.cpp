@@ -551,11 +551,12 @@ REF_API(double, f64)
 
 // BalProblem::load_bal + normalize + perturb + filter_obs through load_normalized_bal_problem<double>
 // (src/rootba/bal/bal_problem.cpp:773-852). seed < 0: no perturbation is requested by the tests then.
+// input_type: 0 AUTO (by file name, autodetect_input_type), 2 BAL, 3 BUNDLER (BalDatasetOptions::DatasetType)
 void* ref_load_bal(const char* path, int normalize, double normalization_scale, double rotation_sigma,
-                   double translation_sigma, double point_sigma, int seed, double init_depth_threshold) {
+                   double translation_sigma, double point_sigma, int seed, double init_depth_threshold, int input_type) {
   rootba::BalDatasetOptions o;
   o.input = path;
-  o.input_type = rootba::BalDatasetOptions::DatasetType::BAL;
+  o.input_type = static_cast<rootba::BalDatasetOptions::DatasetType>(input_type);
   o.normalize = normalize != 0;
   o.normalization_scale = normalization_scale;
   o.rotation_sigma = rotation_sigma;

@@ -40,7 +40,7 @@
 namespace rootba_hip {
 
 struct BalDatasetOptions {  // reference src/rootba/bal/bal_dataset_options.hpp:40-100
-  enum class DatasetType { AUTO = 0, ROOTBA, BAL };  // (BUNDLER is not read here)
+  enum class DatasetType { AUTO = 0, ROOTBA, BAL, BUNDLER };
   std::string input;
   DatasetType input_type = DatasetType::AUTO;
   bool save_output = false;
@@ -401,6 +401,89 @@ class BalProblem {
     points.resize(nl);
     const double* pp = params.data() + 9 * nc;
     for (int64_t i = 0; i < nl; ++i) points[i] = {Scalar(pp[3 * i]), Scalar(pp[3 * i + 1]), Scalar(pp[3 * i + 2])};
+  }
+
+  // Bundler "bundle.out" (reference BalProblem::load_bundler, bal_problem.cpp:284-404): one comment line ('#' first, up to the
+  // end of the line), "num_cameras num_points", per camera 15 numbers (f k1 k2, R row-major 3x3, t), per point its position,
+  // a colour (read and ignored) and a view list: count, then (camera, key, x, y) per view. Cameras with f == 0 are
+  // uninitialised: dropped, later ones renumbered, their views skipped. Same axis convention as load_bal (camera y and z
+  // axes inverted, image y inverted). A serial pass over the memory-mapped file (these files are small next to BAL dumps).
+  void load_bundler(const std::string& path) {
+    const detail::MappedFile file(path);
+    const char* cur = file.data;
+    const char* const end = file.data + file.size;
+    auto fail = [&]() -> void { throw std::runtime_error("Failed to parse '" + path + "'"); };
+    if (cur >= end || *cur != '#') fail();  // "non-comment line; expected comment..."
+    while (cur < end && *cur != '\n') ++cur;
+    if (cur >= end) fail();  // "could not read comment line"
+    ++cur;
+    auto next_int = [&]() {
+      while (cur < end && detail::is_space(*cur)) ++cur;
+      long long v = 0;
+      const auto r = std::from_chars(cur, end, v);
+      if (r.ec != std::errc() || (r.ptr < end && !detail::is_space(*r.ptr))) fail();
+      cur = r.ptr;
+      return v;
+    };
+    auto next_double = [&]() {
+      while (cur < end && detail::is_space(*cur)) ++cur;
+      double v = 0;
+      const char* c = cur < end ? detail::parse_double(cur, end, v) : nullptr;
+      if (!c || (c < end && !detail::is_space(*c))) fail();
+      cur = c;
+      return v;
+    };
+    const long long nc_file = next_int(), nl = next_int();
+    if (nc_file <= 0 || nl <= 0 || nc_file > INT32_MAX || nl > INT32_MAX) fail();
+    const detail::Mat3 flip = {1, 0, 0, 0, -1, 0, 0, 0, -1};
+    std::vector<int32_t> remap(size_t(nc_file), -1);
+    cameras.clear();
+    for (long long i = 0; i < nc_file; ++i) {
+      double p[15];
+      for (double& v : p) v = next_double();
+      if (p[0] == 0) continue;  // focal length 0: uninitialised camera
+      remap[size_t(i)] = int32_t(cameras.size());
+      const detail::Mat3 R = detail::mul(flip, detail::Mat3{p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11]});
+      double q[4];
+      detail::rot_to_quat(R, q);
+      std::array<Scalar, 10> cam;
+      for (int j = 0; j < 4; ++j) cam[j] = Scalar(q[j]);
+      cam[4] = Scalar(p[12]);
+      cam[5] = Scalar(-p[13]);
+      cam[6] = Scalar(-p[14]);
+      cam[7] = Scalar(p[0]);
+      cam[8] = Scalar(p[1]);
+      cam[9] = Scalar(p[2]);
+      cameras.push_back(cam);
+    }
+    points.assign(size_t(nl), {});
+    lm_off.assign(1, 0);
+    obs_cam.clear();
+    obs_xy.clear();
+    std::vector<std::pair<int32_t, std::array<Scalar, 2>>> views;
+    for (long long l = 0; l < nl; ++l) {
+      for (int j = 0; j < 3; ++j) points[size_t(l)][j] = Scalar(next_double());
+      for (int j = 0; j < 3; ++j) (void)next_double();  // colour
+      const long long k = next_int();
+      if (k < 0) fail();
+      views.clear();
+      for (long long v = 0; v < k; ++v) {
+        const long long c = next_int();
+        (void)next_int();  // key (feature) index
+        const double x = next_double(), y = next_double();
+        if (c < 0 || c >= nc_file) continue;     // (the reference's map lookup finds nothing: view skipped)
+        if (remap[size_t(c)] < 0) continue;      // view of an uninitialised camera
+        views.push_back({remap[size_t(c)], {Scalar(x), Scalar(-y)}});
+      }
+      std::stable_sort(views.begin(), views.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      for (size_t v = 0; v < views.size(); ++v) {
+        if (v > 0 && views[v].first == views[v - 1].first) throw std::runtime_error("Invalid file '" + path + "'");
+        obs_cam.push_back(views[v].first);
+        obs_xy.push_back(views[v].second[0]);
+        obs_xy.push_back(views[v].second[1]);
+      }
+      lm_off.push_back(int64_t(obs_cam.size()));
+    }
   }
 
   // X <- s (X - median), camera centres likewise; s = new_scale / MAD(L1)
@@ -778,15 +861,22 @@ BalProblem<Scalar> load_normalized_bal_problem(const BalDatasetOptions& o, doubl
                                                double* preprocess_seconds = nullptr) {
   const auto t0 = std::chrono::steady_clock::now();
   BalProblem<double> p;
-  // autodetect_input_type (bal_problem.cpp:122-135): "*.cereal" is the problem cache, everything else BAL text
+  // autodetect_input_type (bal_problem.cpp:122-135), on the FILE NAME: "*.cereal" is the problem cache, a name containing
+  // "bundle" a Bundler file, everything else BAL text
   BalDatasetOptions::DatasetType type = o.input_type;
   if (type == BalDatasetOptions::DatasetType::AUTO) {
-    const bool cereal = o.input.size() >= 7 && o.input.compare(o.input.size() - 7, 7, ".cereal") == 0;
-    type = cereal ? BalDatasetOptions::DatasetType::ROOTBA : BalDatasetOptions::DatasetType::BAL;
+    const size_t slash = o.input.find_last_of('/');
+    const std::string name = slash == std::string::npos ? o.input : o.input.substr(slash + 1);
+    const bool cereal = name.size() >= 7 && name.compare(name.size() - 7, 7, ".cereal") == 0;
+    type = cereal ? BalDatasetOptions::DatasetType::ROOTBA
+                  : name.find("bundle") != std::string::npos ? BalDatasetOptions::DatasetType::BUNDLER
+                                                             : BalDatasetOptions::DatasetType::BAL;
   }
   if (type == BalDatasetOptions::DatasetType::ROOTBA) {
     std::string why;
     if (!p.load_rootba(o.input, &why)) throw std::runtime_error("Failed to load " + o.input + ": " + why);
+  } else if (type == BalDatasetOptions::DatasetType::BUNDLER) {
+    p.load_bundler(o.input);
   } else {
     p.load_bal(o.input);
   }

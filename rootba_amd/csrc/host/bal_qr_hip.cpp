@@ -39,7 +39,7 @@ void usage() {
       "  --solver-type SQUARE_ROOT|SCHUR_COMPLEMENT   (default SQUARE_ROOT)\n"
       "  --dense-blocks                         matrix-free products on the dense Q2^T Jp blocks (default: from the QR factors)\n"
       "  --save-log-flags <JSON,UBJSON>         (default JSON; UBJSON writes <log>.ubjson next to it)\n"
-      "  --input-type <AUTO|ROOTBA|BAL>         AUTO: '*.cereal' is the rootba problem cache, everything else BAL text\n"
+      "  --input-type <AUTO|ROOTBA|BAL|BUNDLER> AUTO: '*.cereal' = rootba problem cache, '*bundle*' = Bundler, else BAL text\n"
       "  --[no-]save-output, --output-optimized-path <p>   write the optimised problem as a .cereal cache (default optimized.cereal)\n"
       "  --dry-run                              load + preprocess only, print problem statistics");
 }
@@ -203,7 +203,8 @@ int main(int argc, char** argv) {
       if (v == "AUTO") ds.input_type = BalDatasetOptions::DatasetType::AUTO;
       else if (v == "ROOTBA") ds.input_type = BalDatasetOptions::DatasetType::ROOTBA;
       else if (v == "BAL") ds.input_type = BalDatasetOptions::DatasetType::BAL;
-      else { std::fprintf(stderr, "input type %s not implemented (AUTO, ROOTBA, BAL)\n", v.c_str()); return 1; }
+      else if (v == "BUNDLER") ds.input_type = BalDatasetOptions::DatasetType::BUNDLER;
+      else { std::fprintf(stderr, "input type %s not implemented (AUTO, ROOTBA, BAL, BUNDLER)\n", v.c_str()); return 1; }
     }
     else if (a == "--save-output") ds.save_output = true;
     else if (a == "--no-save-output") ds.save_output = false;

@@ -556,3 +556,82 @@ def test_lm_loop_non_default_trust_region_parameters(O, R, small_problem):
         assert abs(a.cost - b.cost) <= 1e-7 * b.cost
         if i + 1 < len(la) and i > 0:
             assert abs(la[i + 1].lambda_ - b.lambda_) <= 1e-6 * b.lambda_  # damping of the next solve
+
+
+def _write_bundler(prob, path, dead_cameras=(2, 9), seed=0):
+    """Bundler v0.3 text from a problem in this repository's convention (z forward, image y down): cameras
+    as f k1 k2 / R row-major / t in the Bundler convention (y, z axes inverted), uninitialised cameras (f = 0)
+    inserted at `dead_cameras` with views that reference them, views of a point in random order."""
+    from rootba_amd import problem as P
+    rng = np.random.default_rng(seed)
+    flip = np.diag([1.0, -1.0, -1.0])
+    n_file = prob.n_cams + len(dead_cameras)
+    file_idx = [i for i in range(n_file) if i not in dead_cameras]  # file index of our camera c
+    lines = ["# Bundle file v0.3", f"{n_file} {prob.n_lms}"]
+    it = iter(range(prob.n_cams))
+    for i in range(n_file):
+        if i in dead_cameras:
+            lines += ["0 0 0", "0 0 0", "0 0 0", "0 0 0", "0 0 0"]
+            continue
+        c = next(it)
+        R = flip @ P.quat_to_rot(prob.cams[c, :4])
+        t = flip @ prob.cams[c, 4:7]
+        lines.append("%.17g %.17g %.17g" % tuple(prob.cams[c, 7:10]))
+        lines += ["%.17g %.17g %.17g" % tuple(row) for row in R]
+        lines.append("%.17g %.17g %.17g" % tuple(t))
+    off = prob.lm_obs_offsets
+    for l in range(prob.n_lms):
+        lines.append("%.17g %.17g %.17g" % tuple(prob.lms[l]))
+        lines.append("%d %d %d" % tuple(rng.integers(0, 256, 3)))
+        views = [(file_idx[prob.obs_cam_idx[o]], prob.obs_xy[o, 0], -prob.obs_xy[o, 1]) for o in range(off[l], off[l + 1])]
+        if l % 7 == 0:
+            views.append((dead_cameras[l % len(dead_cameras)], 1.5, -2.5))  # a view of an uninitialised camera
+        order = rng.permutation(len(views))
+        lines.append(" ".join([str(len(views))] + ["%d %d %.17g %.17g" % (views[j][0], int(rng.integers(0, 9999)), views[j][1], views[j][2])
+                                                    for j in order]))
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+def test_bundler_format_host_loader_against_the_references(R, tmp_path):
+    """BalProblem::load_bundler (bal_problem.cpp:284-404): uninitialised cameras dropped and the rest renumbered, their
+    views skipped, views bucketed in camera order, axis and image-y inversion - the reference's own loader, the
+    product's C++ loader (`--input-type BUNDLER` and the file-name autodetection) and the problem the file was
+    written from."""
+    import json
+    import subprocess
+    from rootba_amd import build
+    from rootba_amd import problem as P
+    build.build()
+    raw = P.synthetic_problem(16, 150, 600, seed=9)
+    path = str(tmp_path / "bundle.out")
+    _write_bundler(raw, path)
+    ref = R.load_bal(path, normalize=False, input_type="AUTO")  # autodetected from the name
+    assert ref["cams"].shape[0] == raw.n_cams and ref["lms"].shape[0] == raw.n_lms
+    assert np.array_equal(ref["lm_obs_offsets"], raw.lm_obs_offsets) and np.array_equal(ref["obs_cam_idx"], raw.obs_cam_idx)
+    assert np.allclose(ref["obs_xy"], raw.obs_xy, rtol=1e-15, atol=0) and np.allclose(ref["lms"], raw.lms, rtol=1e-15, atol=0)
+    assert rel_err(ref["cams"][:, 4:], raw.cams[:, 4:]) < 1e-15
+    for qa, qb in zip(ref["cams"][:, :4], raw.cams[:, :4]):
+        assert min(np.linalg.norm(qa - qb), np.linalg.norm(qa + qb)) < 1e-13
+    for args, kw in (([], dict(input_type="BUNDLER")),
+                     (["--input-type", "BUNDLER", "--no-normalize"], dict(input_type="BUNDLER", normalize=False)),
+                     (["--init-depth-threshold", "60", "--point-sigma", "0.1", "--random-seed", "3"],
+                      dict(input_type="AUTO", init_depth_threshold=60.0, point_sigma=0.1, seed=3))):
+        out = subprocess.run([build.APP, "--input", path, "--dry-run", *args], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        info = json.loads(out.stdout.strip().splitlines()[-1])
+        want = R.load_bal(path, **kw)
+        assert (info["num_cameras"], info["num_landmarks"], info["num_observations"]) == \
+            (want["cams"].shape[0], want["lms"].shape[0], want["obs_cam_idx"].size)
+        assert np.allclose(info["landmark_sum"], want["lms"].sum(0), rtol=1e-10, atol=1e-8)
+        off = want["lm_obs_offsets"]
+        pos = np.arange(want["obs_cam_idx"].size) - np.repeat(off[:-1], np.diff(off)) + 1
+        chk = float(np.sum(pos * ((want["obs_cam_idx"] + 1.0) * want["obs_xy"][:, 0] + want["obs_xy"][:, 1])))
+        assert np.isclose(info["obs_checksum"], chk, rtol=1e-11)
+        q, qr = np.array(info["cam0"][:4]), want["cams"][0, :4]
+        assert min(np.linalg.norm(q - qr), np.linalg.norm(q + qr)) < 1e-10
+        assert np.allclose(info["cam0"][4:], want["cams"][0, 4:7], rtol=1e-10, atol=1e-9)
+    # malformed: no comment line; a duplicate view of one camera
+    txt = open(path).read()
+    bad1 = str(tmp_path / "bundle_nocomment.out")
+    open(bad1, "w").write(txt.split("\n", 1)[1])
+    assert subprocess.run([build.APP, "--input", bad1, "--dry-run"], capture_output=True, text=True).returncode != 0
