@@ -233,5 +233,8 @@ def load_bal(path, normalize=True, normalization_scale=100.0, rotation_sigma=0.0
     xy = np.zeros((no.value, 2))
     L.ref_loaded_get(h, _ptr(cams, C.c_double), _ptr(lms, C.c_double), _ptr(off, C.c_int64),
                      _ptr(cam, C.c_int32), _ptr(xy, C.c_double))
+    sparsity, kmax = C.c_double(), C.c_int()
+    L.ref_loaded_stats(h, C.byref(sparsity), C.byref(kmax))
     L.ref_loaded_destroy(h)
-    return dict(cams=cams, lms=lms, lm_obs_offsets=off, obs_cam_idx=cam, obs_xy=xy)
+    return dict(cams=cams, lms=lms, lm_obs_offsets=off, obs_cam_idx=cam, obs_xy=xy, rcs_sparsity=sparsity.value,
+                max_obs_per_lm=kmax.value)

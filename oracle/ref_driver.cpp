@@ -601,5 +601,11 @@ void ref_loaded_get(void* p, double* cams, double* lms, int64_t* off, int32_t* c
   std::memcpy(cam, L->cam.data(), sizeof(int32_t) * L->cam.size());
   std::memcpy(xy, L->xy.data(), sizeof(double) * L->xy.size());
 }
+// BalProblem::compute_rcs_sparsity / max_num_observations_per_lm (bal_problem.cpp:619-712)
+void ref_loaded_stats(void* p, double* rcs_sparsity, int* max_obs_per_lm) {
+  auto* L = static_cast<Loaded*>(p);
+  *rcs_sparsity = L->problem.compute_rcs_sparsity();
+  *max_obs_per_lm = L->problem.max_num_observations_per_lm();
+}
 void ref_loaded_destroy(void* p) { delete static_cast<Loaded*>(p); }
 }  // extern "C"

@@ -479,6 +479,7 @@ def test_host_cpp_loader_pipeline_against_the_references(R, tmp_path):
         pos = np.arange(ref["obs_cam_idx"].size) - np.repeat(off[:-1], np.diff(off)) + 1
         chk = float(np.sum(pos * ((ref["obs_cam_idx"] + 1.0) * ref["obs_xy"][:, 0] + ref["obs_xy"][:, 1])))
         assert np.isclose(info["obs_checksum"], chk, rtol=1e-11)
+        assert abs(info["rcs_sparsity"] - ref["rcs_sparsity"]) < 1e-12  # BalProblem::compute_rcs_sparsity
         q, qr = np.array(info["cam0"][:4]), ref["cams"][0, :4]
         assert min(np.linalg.norm(q - qr), np.linalg.norm(q + qr)) < 1e-10
         assert np.allclose(info["cam0"][4:], ref["cams"][0, 4:7], rtol=1e-10, atol=1e-9)
