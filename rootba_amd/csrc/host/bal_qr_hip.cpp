@@ -41,7 +41,8 @@ void usage() {
       "  --save-log-flags <JSON,UBJSON>         (default JSON; UBJSON writes <log>.ubjson next to it)\n"
       "  --input-type <AUTO|ROOTBA|BAL|BUNDLER> AUTO: '*.cereal' = rootba problem cache, '*bundle*' = Bundler, else BAL text\n"
       "  --[no-]save-output, --output-optimized-path <p>   write the optimised problem as a .cereal cache (default optimized.cereal)\n"
-      "  --dry-run                              load + preprocess only, print problem statistics");
+      "  --dry-run                              load + preprocess only, print problem statistics\n"
+      "  --dump-options                         print the solver options this command line selects (JSON) and exit");
 }
 
 static int g_save_log_flags = rootba_hip::SAVE_LOG_JSON;  // BaLogOptions::save_log_flags (ba_log_options.hpp:48-50)
@@ -185,7 +186,7 @@ int main(int argc, char** argv) {
   BalDatasetOptions ds;
   SolverOptions so;
   std::string log_path = "ba_log.json";
-  bool dry_run = false;
+  bool dry_run = false, dump_options = false;
   int device = 0;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -268,11 +269,28 @@ int main(int argc, char** argv) {
     }
     else if (a == "--device") device = std::stoi(val());
     else if (a == "--dry-run") dry_run = true;
+    else if (a == "--dump-options") dump_options = true;
     else if (a == "--self-test-parser") return self_test_parser(std::stol(val()));
     else if (a == "--self-test-log") return self_test_log(val());
     else if (a == "--implicit-q") so.implicit_q = true;
     else if (a == "--dense-blocks") so.implicit_q = false;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 1; }
+  }
+  if (dump_options) {
+    // the rba_options this command line hands to rba_create (SolverOptions::to_rba), one JSON object
+    const rba_options o = so.to_rba();
+    std::printf("{\"use_householder\": %d, \"use_valid_projections_only\": %d, \"robust_norm\": %d, \"huber_parameter\": %.17g, "
+                "\"jacobi_scaling_eps\": %.17g, \"preconditioner_type\": %d, \"reduction_alg\": %d, \"power_order\": %d, "
+                "\"min_cg_it\": %d, \"max_cg_it\": %d, \"eta\": %.17g, \"max_num_iterations\": %d, "
+                "\"min_relative_decrease\": %.17g, \"initial_trust_region_radius\": %.17g, \"min_trust_region_radius\": %.17g, "
+                "\"max_trust_region_radius\": %.17g, \"function_tolerance\": %.17g, \"initial_vee\": %.17g, \"vee_factor\": %.17g, "
+                "\"optimized_cost\": %d, \"staged_execution\": %d, \"solver_type\": %d, \"use_double\": %d}\n",
+                o.use_householder, o.use_valid_projections_only, o.robust_norm, o.huber_parameter, o.jacobi_scaling_eps,
+                o.preconditioner_type, o.reduction_alg, o.power_order, o.min_cg_it, o.max_cg_it, o.eta, o.max_num_iterations,
+                o.min_relative_decrease, o.initial_trust_region_radius, o.min_trust_region_radius, o.max_trust_region_radius,
+                o.function_tolerance, o.initial_vee, o.vee_factor, o.optimized_cost, o.staged_execution, o.solver_type,
+                int(so.use_double));
+    return 0;
   }
   if (ds.input.empty()) { usage(); return 1; }
   try {

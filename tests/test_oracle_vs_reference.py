@@ -636,3 +636,35 @@ def test_bundler_format_host_loader_against_the_references(R, tmp_path):
     bad1 = str(tmp_path / "bundle_nocomment.out")
     open(bad1, "w").write(txt.split("\n", 1)[1])
     assert subprocess.run([build.APP, "--input", bad1, "--dry-run"], capture_output=True, text=True).returncode != 0
+
+
+def test_host_cpp_solver_options_defaults_and_mapping(R):
+    """The C++ host layer's SolverOptions (rootba_amd/csrc/host/linearizor_hip.hpp; what `bal_qr_hip` hands to
+    rba_create, printed by --dump-options): defaults equal to the reference's own SolverOptions declaration, the
+    validity flag derived from optimized_cost as LinearizorQR does (linearizor_qr.cpp:58-68), use_double = true."""
+    import json
+    import subprocess
+    from rootba_amd import build
+    build.build()
+
+    def dump(*args):
+        out = subprocess.run([build.APP, "--dump-options", *args], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    d, ref = dump(), R.default_options()
+    for k, v in d.items():
+        if k == "use_double":
+            assert v == 1  # solver_options.hpp:257-259
+        else:
+            assert v == getattr(ref, k), k
+    for cost, idx in (("ERROR", 0), ("ERROR_VALID", 1), ("ERROR_VALID_AVG", 2)):
+        d = dump("--optimized-cost", cost)
+        want = R.default_options(optimized_cost=idx)
+        assert (d["optimized_cost"], d["use_valid_projections_only"]) == (idx, int(idx != 0))
+        assert want.optimized_cost == idx
+    d = dump("--preconditioner-type", "JACOBI", "--robust-norm", "HUBER", "--huber-parameter", "0.5", "--no-staged-execution",
+             "--max-num-iterations", "7", "--eta", "0.01", "--max-linear-solver-iterations", "33", "--function-tolerance", "1e-9",
+             "--jacobi-scaling-epsilon", "1.0", "--solver-type", "SCHUR_COMPLEMENT")
+    assert (d["preconditioner_type"], d["robust_norm"], d["huber_parameter"], d["staged_execution"], d["max_num_iterations"],
+            d["eta"], d["max_cg_it"], d["function_tolerance"], d["jacobi_scaling_eps"], d["solver_type"]) == \
+        (0, 1, 0.5, 0, 7, 0.01, 33, 1e-9, 1.0, 1)
