@@ -1,0 +1,173 @@
+// integration/rootba/solver/linearizor_hip.hpp - THE REFERENCE-SIDE BINDING of librootba_hip.so
+// (as real code): a sixth `Linearizor<Scalar>` for NikolausDemmel/rootba that forwards the five
+// virtual calls of src/rootba/solver/linearizor.hpp:56-82 to the C ABI of include/rootba_hip.h.
+//
+// This file is written against the REFERENCE'S headers (BalProblem, SolverOptions, LinearizorBase, Eigen types); a
+// maintainer drops it into src/rootba/solver/, adds one enum entry + one `case` to the factory
+// (integration/linearizor_factory_hip.cpp shows the case), and links -lrootba_hip. Nothing else in the reference
+// changes: its CLI, loader, options, LM loop (optimize_lm_ours) and logging run as they are.
+//
+// It is compiled and exercised in this repository by oracle/build_ref.sh (against the reference tree + the
+// third-party stand-ins of oracle/ref_shims), see tests/test_reference_binding.py:
+//   on the GPU: the reference's own LM loop drives the HIP library through this class;
+//   on CPU:     the same object code runs against a test double of the C ABI (oracle/mock_rootba_hip.cpp).
+#pragma once
+
+#include <limits>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "rootba/solver/linearizor_base.hpp"
+#include "rootba/util/time_utils.hpp"
+#include "rootba_hip.h"
+
+namespace rootba {
+
+template <class Scalar_>
+class LinearizorHIP : public LinearizorBase<Scalar_> {
+ public:
+  using Scalar = Scalar_;
+  using Base = LinearizorBase<Scalar>;
+  using VecX = typename Base::VecX;
+
+  LinearizorHIP(BalProblem<Scalar>& bal_problem, const SolverOptions& options, SolverSummary* summary = nullptr,
+                int device = 0)
+      : Base(bal_problem, options, summary) {
+    // CSR topology from the std::map of every landmark (ascending camera index = map order,
+    // landmark_block_dynamic.hpp:52-54)
+    std::vector<int64_t> off(1, 0);
+    std::vector<int32_t> cam;
+    std::vector<Scalar> xy;
+    for (const auto& lm : bal_problem.landmarks()) {
+      for (const auto& [cam_idx, obs] : lm.obs) {
+        cam.push_back(cam_idx);
+        xy.push_back(obs.pos(0));
+        xy.push_back(obs.pos(1));
+      }
+      off.push_back(int64_t(cam.size()));
+    }
+    // SolverOptions -> rba_options: the mapping of LinearizorQR's constructor (linearizor_qr.cpp:58-68) and of
+    // LinearizorBase::pcg (linearizor_base.cpp:87-93)
+    rba_options o;
+    rba_default_options(&o);
+    o.use_householder = options.use_householder_marginalization;
+    o.use_valid_projections_only = options.use_projection_validity_check();
+    o.robust_norm = options.residual.robust_norm == BalResidualOptions::RobustNorm::HUBER ? 1 : 0;
+    o.huber_parameter = options.residual.huber_parameter;
+    o.jacobi_scaling_eps = options.jacobi_scaling_epsilon;
+    o.preconditioner_type =
+        options.preconditioner_type == SolverOptions::PreconditionerType::JACOBI         ? 0
+        : options.preconditioner_type == SolverOptions::PreconditionerType::SCHUR_JACOBI ? 1
+                                                                                         : 2;  // power series
+    o.reduction_alg = options.reduction_alg;
+    o.power_order = options.power_order;
+    o.min_cg_it = options.min_linear_solver_iterations;
+    o.max_cg_it = options.max_linear_solver_iterations;
+    o.eta = options.eta;
+    o.optimized_cost = int(options.optimized_cost);
+    o.staged_execution = options.staged_execution;
+    // (the LM-loop fields of rba_options - trust region, vee, tolerances - are used by rba_optimize_lm only; here
+    //  the reference's own loop runs)
+    const int st = rba_create(std::is_same<Scalar, float>::value ? RBA_F32 : RBA_F64, device, bal_problem.num_cameras(),
+                              bal_problem.num_landmarks(), off.data(), cam.data(), xy.data(), &o, &h_);
+    CHECK(st == RBA_OK) << "rba_create: " << rba_last_error();
+    cams_.resize(size_t(10) * bal_problem.num_cameras());
+    lms_.resize(size_t(3) * bal_problem.num_landmarks());
+    upload();
+  }
+  ~LinearizorHIP() override {
+    if (h_) rba_destroy(h_);
+  }
+
+  // LinearizorBase::compute_error (linearizor_base.cpp:60-68)
+  void compute_error(ResidualInfo& ri) override {
+    Timer<> timer;
+    upload();  // BalProblem is the source of truth (the driver may have called restore())
+    rba_residual_info r;
+    CHECK(rba_compute_error(h_, &r) == RBA_OK) << rba_last_error();
+    ri.all.num_obs = r.all_num_obs;
+    ri.all.error = r.all_error;
+    ri.all.residual_sum = r.all_residual_sum;
+    ri.valid.num_obs = r.valid_num_obs;
+    ri.valid.error = r.valid_error;
+    ri.valid.residual_sum = r.valid_residual_sum;
+    ri.is_numerically_valid = r.is_numerically_valid != 0;
+    if (it_summary_) it_summary_->residual_evaluation_time_in_seconds += timer.elapsed();
+    if (summary_) summary_->num_residual_evaluations += 1;
+  }
+
+  // LinearizorQR::linearize (linearizor_qr.cpp:78-138)
+  void linearize() override {
+    Timer<> timer;
+    const int st = rba_linearize(h_, nullptr);
+    CHECK(st == RBA_OK) << "did not expect numerical failure during linearization (" << rba_last_error() << ")";
+    if (it_summary_) it_summary_->stage1_time_in_seconds = timer.elapsed();
+    if (summary_) summary_->num_jacobian_evaluations += 1;
+  }
+
+  // LinearizorQR::solve (linearizor_qr.cpp:141-265)
+  VecX solve(Scalar lambda) override {
+    Timer<> timer;
+    VecX inc(9 * bal_problem_.num_cameras());
+    rba_cg_summary cg;
+    const int st = rba_solve(h_, double(lambda), inc.data(), &cg);
+    CHECK(st >= 0) << rba_last_error();
+    if (it_summary_) {
+      it_summary_->solve_reduced_system_time_in_seconds = timer.elapsed();
+      it_summary_->linear_solver_iterations = cg.num_iterations;
+      it_summary_->linear_solver_message =
+          cg.termination_type == 1 ? "Convergence." : cg.termination_type == 2 ? "Numerical failure." : "No convergence.";
+      it_summary_->linear_solver_type = "bal_qr_hip";
+    }
+    if (summary_) summary_->num_linear_solves += 1;
+    return inc;
+  }
+
+  // LinearizorQR::apply (linearizor_qr.cpp:268-291). The driver has called bal_problem.backup() before and calls
+  // bal_problem.restore() afterwards when it rejects the step: the host problem is the source of truth, so the
+  // state goes up before the update and comes back after it.
+  Scalar apply(VecX&& inc) override {
+    Timer<> timer;
+    upload();
+    double l_diff = 0;
+    const int st = rba_apply(h_, inc.data(), &l_diff);
+    CHECK(st >= 0) << rba_last_error();
+    if (it_summary_) it_summary_->back_substitution_time_in_seconds = timer.elapsed();
+    if (st != RBA_OK) return std::numeric_limits<Scalar>::quiet_NaN();
+    download();
+    return Scalar(l_diff);
+  }
+
+ private:
+  using Base::bal_problem_;
+  using Base::it_summary_;
+  using Base::summary_;
+
+  // Camera::params() (bal_problem.hpp:84-89): qx qy qz qw tx ty tz f k1 k2
+  void upload() {
+    for (int c = 0; c < bal_problem_.num_cameras(); ++c) {
+      const VecX p = bal_problem_.cameras()[c].params();
+      for (int k = 0; k < 10; ++k) cams_[size_t(10) * c + k] = p(k);
+    }
+    for (int l = 0; l < bal_problem_.num_landmarks(); ++l)
+      for (int k = 0; k < 3; ++k) lms_[size_t(3) * l + k] = bal_problem_.landmarks()[l].p_w(k);
+    CHECK(rba_set_state(h_, cams_.data(), lms_.data()) == RBA_OK) << rba_last_error();
+  }
+  // Camera::from_params (bal_problem.hpp:91-95)
+  void download() {
+    CHECK(rba_get_state(h_, cams_.data(), lms_.data()) == RBA_OK) << rba_last_error();
+    VecX p(10);
+    for (int c = 0; c < bal_problem_.num_cameras(); ++c) {
+      for (int k = 0; k < 10; ++k) p(k) = cams_[size_t(10) * c + k];
+      bal_problem_.cameras()[c].from_params(p);
+    }
+    for (int l = 0; l < bal_problem_.num_landmarks(); ++l)
+      for (int k = 0; k < 3; ++k) bal_problem_.landmarks()[l].p_w(k) = lms_[size_t(3) * l + k];
+  }
+
+  rba_handle h_ = nullptr;
+  std::vector<Scalar> cams_, lms_;
+};
+
+}  // namespace rootba

@@ -36,3 +36,18 @@ for p in $pids; do wait "$p"; done
 $CXX $FLAGS -c "$HERE/ref_driver.cpp" -o "$OUT/obj/ref_driver.o"
 $CXX -shared -o "$OUT/librootba_ref.so" $OBJS "$OUT/obj/ref_driver.o"
 echo "built $OUT/librootba_ref.so"
+
+# The same reference objects + the reference-side BINDING of the HIP library (integration/): the factory is wrapped
+# (integration/linearizor_factory_hip.cpp), the rba_* entry points stay undefined and are resolved at load time
+# from whichever provider the test loads first with RTLD_GLOBAL: rootba_amd/librootba_hip.so on a GPU box, or the
+# oracle-backed test double librootba_hip_mock.so on a machine without one (tests/test_reference_binding.py).
+ROOT=$(cd "$HERE/.." && pwd)
+W=_ZN6rootba10LinearizorI
+X=E6createERNS_10BalProblemI
+Y=EERKNS_13SolverOptionsEPNS_13SolverSummaryE
+$CXX $FLAGS -I"$ROOT/integration" -I"$ROOT/include" -c "$ROOT/integration/linearizor_factory_hip.cpp" \
+  -o "$OUT/obj/linearizor_factory_hip.o" -Wno-return-type-c-linkage
+$CXX -shared -o "$OUT/librootba_ref_binding.so" $OBJS "$OUT/obj/ref_driver.o" "$OUT/obj/linearizor_factory_hip.o" \
+  -Wl,--wrap=${W}d${X}d${Y} -Wl,--wrap=${W}f${X}f${Y}
+$CXX -std=c++17 -O2 -march=x86-64-v3 -fPIC -fopenmp -shared "$HERE/mock_rootba_hip.cpp" -o "$OUT/librootba_hip_mock.so"
+echo "built $OUT/librootba_ref_binding.so and $OUT/librootba_hip_mock.so"

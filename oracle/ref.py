@@ -54,6 +54,34 @@ def lib():
     return _lib
 
 
+_binding = {}
+_BINDING_PATH = os.path.join(_HERE, "_ref", "librootba_ref_binding.so")
+_MOCK_PATH = os.path.join(_HERE, "_ref", "librootba_hip_mock.so")
+
+
+def binding_available() -> bool:
+    return build() is not None and os.path.exists(_BINDING_PATH)
+
+
+def binding_lib(provider: str):
+    """oracle/_ref/librootba_ref_binding.so: the reference's sources + the reference-side binding of the HIP
+    library (integration/rootba/solver/linearizor_hip.hpp) behind the wrapped factory. Its rba_* entry points
+    are resolved from `provider`, loaded first with RTLD_GLOBAL:
+      "hip"  - rootba_amd/librootba_hip.so (needs a GPU),
+      "mock" - oracle/_ref/librootba_hip_mock.so, the oracle-backed test double of the C ABI (no GPU).
+    One provider per process (the first global definition of rba_* wins)."""
+    if _binding and provider not in _binding:
+        raise RuntimeError(f"this process already bound the C ABI to {list(_binding)}")
+    if provider not in _binding:
+        build()
+        path = _MOCK_PATH if provider == "mock" else os.path.join(os.path.dirname(_HERE), "rootba_amd", "librootba_hip.so")
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        lib_ = C.CDLL(_BINDING_PATH)
+        assert lib_.ref_sizeof_lm_iteration() == C.sizeof(LmIteration) and lib_.ref_sizeof_options() == C.sizeof(Options)
+        _binding[provider] = lib_
+    return _binding[provider]
+
+
 def default_options(**kw) -> Options:
     """The defaults of the reference's own SolverOptions declaration (src/rootba/bal/solver_options.hpp)."""
     o = Options()
@@ -68,11 +96,11 @@ def default_options(**kw) -> Options:
 class Reference:
     """`Linearizor<Scalar>` / `LinearizationQR<Scalar, 9>` of the reference on one problem."""
 
-    def __init__(self, prob, dtype=np.float32, options: Options | None = None):
+    def __init__(self, prob, dtype=np.float32, options: Options | None = None, library=None):
         self.dtype = np.dtype(dtype)
         self.suf = "f32" if self.dtype == np.float32 else "f64"
         self.ct = C.c_float if self.dtype == np.float32 else C.c_double
-        self.L = lib()
+        self.L = library or lib()
         self.n_cams, self.n_lms, self.n_obs = prob.n_cams, prob.n_lms, prob.n_obs
         self.options = options or default_options()
         off = np.ascontiguousarray(prob.lm_obs_offsets, dtype=np.int64)
@@ -191,6 +219,39 @@ class Reference:
         term = C.c_int(0)
         n = self._fn("optimize_lm")(self.h, log, C.c_int(max_rows), C.byref(term))
         return [log[i] for i in range(min(n, max_rows))], term.value
+
+
+class ReferenceOnHip(Reference):
+    """The REFERENCE'S Linearizor interface and LM loop on top of the C ABI of include/rootba_hip.h: the wrapped
+    factory (integration/linearizor_factory_hip.cpp) returns rootba::LinearizorHIP for the square-root solver while
+    ROOTBA_LINEARIZOR=hip is set. `linearize / solve / apply / compute_error / optimize_lm` then run
+    reference code (Linearizor calls, optimize_lm_ours) -> binding -> rba_* of `provider` ("hip" | "mock")."""
+
+    def __init__(self, prob, dtype=np.float32, options: Options | None = None, provider="hip"):
+        super().__init__(prob, dtype, options, library=binding_lib(provider))
+
+    def _with_hip(self, f, *a):
+        old = os.environ.get("ROOTBA_LINEARIZOR")
+        os.environ["ROOTBA_LINEARIZOR"] = "hip"
+        try:
+            return f(*a)
+        finally:
+            if old is None:
+                del os.environ["ROOTBA_LINEARIZOR"]
+            else:
+                os.environ["ROOTBA_LINEARIZOR"] = old
+
+    def linearize(self):
+        return self._with_hip(super().linearize)  # (creates the linearizor on first use)
+
+    def compute_error(self) -> ResidualInfo:
+        """Linearizor::compute_error of the binding (rba_compute_error on the uploaded host state)."""
+        ri = ResidualInfo()
+        self._with_hip(self._fn("linearizor_compute_error"), self.h, C.byref(ri))
+        return ri
+
+    def optimize_lm(self, max_rows: int = 256):
+        return self._with_hip(super().optimize_lm, max_rows)
 
 
 def linearize_point(obs, p_w, cam, dtype=np.float64, ignore_validity_check=True):

@@ -297,6 +297,13 @@ void h_compute_error(Handle<S>* h, ref_residual_info* out) {
   rootba::BalBundleAdjustmentHelper<S>::compute_error(h->problem, h->sopt, ri);
   fill_ri(ri, out);
 }
+// Linearizor::compute_error of the linearizor the factory returned (LinearizorBase::compute_error, or the binding's)
+template <class S>
+void h_linearizor_compute_error(Handle<S>* h, ref_residual_info* out) {
+  rootba::ResidualInfo ri;
+  h->linearizor().compute_error(ri);
+  fill_ri(ri, out);
+}
 // LinearizationQR::get_stage1 (linearization_qr.hpp:634-712): 1 = numerical failure (empty vector)
 template <class S>
 int h_stage1(Handle<S>* h, S* jp_diag2, S* jacobi_blocks) {
@@ -454,6 +461,9 @@ struct Loaded {
   void ref_restore_##SUF(void* h) { static_cast<Handle<S>*>(h)->problem.restore(); }                               \
   void ref_compute_error_##SUF(void* h, ref_residual_info* out) {                                                  \
     h_compute_error(static_cast<Handle<S>*>(h), out);                                                              \
+  }                                                                                                                \
+  void ref_linearizor_compute_error_##SUF(void* h, ref_residual_info* out) {                                       \
+    h_linearizor_compute_error(static_cast<Handle<S>*>(h), out);                                                   \
   }                                                                                                                \
   int ref_stage1_##SUF(void* h, S* d, S* blocks) { return h_stage1(static_cast<Handle<S>*>(h), d, blocks); }       \
   void ref_set_pose_damping_##SUF(void* h, S lam) { h_set_pose_damping(static_cast<Handle<S>*>(h), lam); }         \
