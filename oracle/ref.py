@@ -18,6 +18,8 @@ from .oracle import CgSummary, LmIteration, Options, ResidualInfo, _ptr
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_ref", "librootba_ref.so")
+_BINDING_PATH = os.path.join(_HERE, "_ref", "librootba_ref_binding.so")
+_MOCK_PATH = os.path.join(_HERE, "_ref", "librootba_hip_mock.so")
 REFERENCE_ROOT = os.environ.get("REF", "/root/reference")
 
 
@@ -25,11 +27,17 @@ def build(force: bool = False) -> str | None:
     """Run oracle/build_ref.sh when the reference tree is present; returns the library path or None."""
     have_ref = os.path.isdir(os.path.join(REFERENCE_ROOT, "src", "rootba"))
     if have_ref:
-        deps = [os.path.join(_HERE, "ref_driver.cpp"), os.path.join(_HERE, "build_ref.sh")]
+        root = os.path.dirname(_HERE)
+        deps = [os.path.join(_HERE, "ref_driver.cpp"), os.path.join(_HERE, "build_ref.sh"),
+                os.path.join(_HERE, "mock_rootba_hip.cpp"), os.path.join(_HERE, "rootba_oracle.hpp"),
+                os.path.join(root, "include", "rootba_hip.h"),
+                os.path.join(root, "integration", "linearizor_factory_hip.cpp"),
+                os.path.join(root, "integration", "rootba", "solver", "linearizor_hip.hpp")]
         for root, _, files in os.walk(os.path.join(_HERE, "ref_shims")):
             deps += [os.path.join(root, f) for f in files]
-        stale = force or not os.path.exists(_LIB_PATH) or any(
-            os.path.getmtime(d) > os.path.getmtime(_LIB_PATH) for d in deps)
+        newest = min((os.path.getmtime(p) for p in (_LIB_PATH, _BINDING_PATH, _MOCK_PATH) if os.path.exists(p)), default=0)
+        stale = force or not all(os.path.exists(p) for p in (_LIB_PATH, _BINDING_PATH, _MOCK_PATH)) or any(
+            os.path.getmtime(d) > newest for d in deps)
         if stale:
             subprocess.check_call(["sh", os.path.join(_HERE, "build_ref.sh")], stdout=subprocess.DEVNULL)
     return _LIB_PATH if os.path.exists(_LIB_PATH) else None
@@ -55,8 +63,6 @@ def lib():
 
 
 _binding = {}
-_BINDING_PATH = os.path.join(_HERE, "_ref", "librootba_ref_binding.so")
-_MOCK_PATH = os.path.join(_HERE, "_ref", "librootba_hip_mock.so")
 
 
 def binding_available() -> bool:
