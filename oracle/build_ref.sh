@@ -49,5 +49,6 @@ $CXX $FLAGS -I"$ROOT/integration" -I"$ROOT/include" -c "$ROOT/integration/linear
   -o "$OUT/obj/linearizor_factory_hip.o" -Wno-return-type-c-linkage
 $CXX -shared -o "$OUT/librootba_ref_binding.so" $OBJS "$OUT/obj/ref_driver.o" "$OUT/obj/linearizor_factory_hip.o" \
   -Wl,--wrap=${W}d${X}d${Y} -Wl,--wrap=${W}f${X}f${Y}
-$CXX -std=c++17 -O2 -march=x86-64-v3 -fPIC -fopenmp -shared "$HERE/mock_rootba_hip.cpp" -o "$OUT/librootba_hip_mock.so"
+$CXX -std=c++17 -O2 -march=x86-64-v3 -fPIC -fopenmp -fvisibility-inlines-hidden -shared -Wl,-Bsymbolic \
+  "$HERE/mock_rootba_hip.cpp" -o "$OUT/librootba_hip_mock.so"
 echo "built $OUT/librootba_ref_binding.so and $OUT/librootba_hip_mock.so"

@@ -9,8 +9,17 @@
 #include <cstring>
 #include <string>
 
+// only the rba_* entry points leave this library (it is loaded with RTLD_GLOBAL): the oracle's own inline /
+// template code must not interpose on oracle/liboracle.so in the same process
+#pragma GCC visibility push(default)
 #include "../include/rootba_hip.h"
+#pragma GCC visibility pop
+#ifdef _OPENMP
+#include <omp.h>  // (declared before the push: the OpenMP runtime's functions are not ours to hide)
+#endif
+#pragma GCC visibility push(hidden)
 #include "rootba_oracle.hpp"
+#pragma GCC visibility pop
 
 namespace {
 thread_local std::string g_err;
