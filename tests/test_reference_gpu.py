@@ -144,3 +144,28 @@ def test_lm_run(R, ladybug_far, dtype):
         r64 = R.Reference(ladybug_far, np.float64, R.default_options(robust_norm=1, huber_parameter=1.0, **kw))
         f64 = min(x.cost for x in r64.optimize_lm()[0] if x.step_is_successful)
         assert abs(fg - f64) / f64 < 2e-6 and abs(fr - f64) / f64 < 2e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_per_landmark_qr_at_ladybug_size(R, ladybug_far, dtype):
+    """BASELINE configs[1]: "ladybug problem-49-7776 float32, per-landmark QR kernel only vs CPU" - the CPU here is the
+    reference's own LandmarkBlock code: Jl column scales, R^T R and |Q1^T r| of every landmark (invariant to the
+    reflector conventions), and the stage-1 output Jp_diag2 through the pose scaling."""
+    if DRY:
+        pytest.skip("the oracle has no landmark_R accessor")
+    tol = TOL[dtype]
+    g, r = _pair(R, ladybug_far, dtype)
+    st, d2 = g.linearize(want_jp_diag2=True)
+    assert st == 0
+    rc, d_ref, _ = r.stage1()
+    assert rc == 0 and rel_err(d2, d_ref) < tol
+    assert rel_err(g.jl_col_scale(), r.jl_col_scale()) < tol
+    Rg, qg = g.landmark_R(damped=False)
+    worst = 0.0
+    for l in range(0, ladybug_far.n_lms, 37):
+        blk, li = r.block(l)
+        Rr = np.triu(blk[:3, li:li + 3].astype(np.float64))
+        Rl = np.zeros((3, 3))
+        Rl[np.triu_indices(3)] = Rg[l]
+        worst = max(worst, rel_err(Rl.T @ Rl, Rr.T @ Rr), rel_err(np.abs(qg[l]), np.abs(blk[:3, li + 3])))
+    assert worst < 10 * tol
