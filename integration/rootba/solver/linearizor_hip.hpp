@@ -8,7 +8,7 @@
 // changes: its CLI, loader, options, LM loop (optimize_lm_ours) and logging run as they are.
 //
 // It is compiled and exercised in this repository by oracle/build_ref.sh (against the reference tree + the
-// third-party stand-ins of oracle/ref_shims), see tests/test_reference_binding.py:
+// third-party stand-ins of oracle/ref_shims), see tests/test_reference_loop_on_hip.py:
 //   on the GPU: the reference's own LM loop drives the HIP library through this class;
 //   on CPU:     the same object code runs against a test double of the C ABI (oracle/mock_rootba_hip.cpp).
 #pragma once

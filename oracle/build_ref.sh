@@ -40,7 +40,7 @@ echo "built $OUT/librootba_ref.so"
 # The same reference objects + the reference-side BINDING of the HIP library (integration/): the factory is wrapped
 # (integration/linearizor_factory_hip.cpp), the rba_* entry points stay undefined and are resolved at load time
 # from whichever provider the test loads first with RTLD_GLOBAL: rootba_amd/librootba_hip.so on a GPU box, or the
-# oracle-backed test double librootba_hip_mock.so on a machine without one (tests/test_reference_binding.py).
+# oracle-backed test double librootba_hip_mock.so on a machine without one (tests/test_reference_loop_on_hip.py).
 ROOT=$(cd "$HERE/.." && pwd)
 W=_ZN6rootba10LinearizorI
 X=E6createERNS_10BalProblemI

@@ -1,7 +1,7 @@
 // oracle/mock_rootba_hip.cpp - a TEST DOUBLE of the C ABI of include/rootba_hip.h, backed by the CPU oracle.
 //
 // TEST INFRASTRUCTURE ONLY. It exists so that the reference-side binding (integration/rootba/solver/linearizor_hip.hpp)
-// can be exercised on a machine WITHOUT a GPU: tests/test_reference_binding.py loads this library in place of
+// can be exercised on a machine WITHOUT a GPU: tests/test_reference_loop_on_hip.py loads this library in place of
 // rootba_amd/librootba_hip.so and lets the reference's own LM loop run through the binding. It is not a fallback of
 // the product: nothing in rootba_amd/ or include/ knows about it, it is built into oracle/_ref/ only, and the real
 // library keeps failing loudly when there is no GPU (tests/test_cabi_cpu.py). Only the entry points the binding calls
