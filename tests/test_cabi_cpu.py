@@ -94,6 +94,28 @@ def test_product_package_never_imports_the_oracle():
                     "never imported" in txt or "test infrastructure" in txt, f
 
 
+def test_nothing_shipped_knows_the_test_double_of_the_c_abi():
+    """oracle/mock_rootba_hip.cpp (the oracle-backed stand-in of the C ABI that lets tests/test_reference_loop_on_hip.py
+    exercise the reference-side binding without a GPU) is reachable from tests/ only: the product package, the public
+    header, the integration sources, bench.py and __graft_entry__.py never name it, and the binding library is not
+    linked against it (its rba_* symbols are unresolved until a test picks the provider)."""
+    import subprocess
+    needles = ("mock_rootba", "librootba_hip_mock", "hip_mock")
+    paths = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for top in ("rootba_amd", "include", "integration"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            paths += [os.path.join(dirpath, f) for f in files if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp"))]
+    for path in paths:
+        txt = open(path).read()
+        if path.endswith(os.path.join("solver", "linearizor_hip.hpp")):
+            txt = txt.replace("oracle/mock_rootba_hip.cpp", "")  # its header comment says where the CPU test lives
+        assert not any(n in txt for n in needles), path
+    binding = os.path.join(ROOT, "oracle", "_ref", "librootba_ref_binding.so")
+    if os.path.exists(binding):
+        needed = subprocess.run(["readelf", "-d", binding], capture_output=True, text=True).stdout
+        assert "mock" not in needed and "librootba_hip" not in needed
+
+
 def _header_struct_fields(name):
     """Field names of `typedef struct <name> { ... } <name>;` in the header, in order (comments stripped)."""
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
