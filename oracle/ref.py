@@ -80,7 +80,11 @@ def binding_lib(provider: str):
         raise RuntimeError(f"this process already bound the C ABI to {list(_binding)}")
     if provider not in _binding:
         build()
-        path = _MOCK_PATH if provider == "mock" else os.path.join(os.path.dirname(_HERE), "rootba_amd", "librootba_hip.so")
+        if provider == "mock":
+            path = _MOCK_PATH
+        else:
+            from rootba_amd import _lib as product  # (test sessions with RBA_EMU=1 point LIB_PATH at the CPU harness build)
+            path = product.LIB_PATH
         C.CDLL(path, mode=C.RTLD_GLOBAL)
         lib_ = C.CDLL(_BINDING_PATH)
         assert lib_.ref_sizeof_lm_iteration() == C.sizeof(LmIteration) and lib_.ref_sizeof_options() == C.sizeof(Options)

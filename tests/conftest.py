@@ -9,6 +9,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+if os.environ.get("RBA_EMU") == "1":
+    # Development tool, NOT a backend: run the product's kernels on the CPU in the execution harness of tests/hipemu
+    # (see tests/hipemu/hip/hip_runtime.h) - e.g. `RBA_EMU=1 python -m pytest tests -m gpu -k small`. The product package
+    # is untouched; only this test session points its loader at the harness build.
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import build_emu  # noqa: E402
+    import rootba_amd._lib as _rba_lib  # noqa: E402
+    _rba_lib.LIB_PATH = build_emu.build()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,0 +1,52 @@
+"""Builds tests/hipemu/_build/librootba_hip_emu.so: the product's solver.hip + kernel headers, UNCHANGED except for one
+textual rewrite (`extern __shared__` -> `extern`: the dynamic-LDS arrays are defined by the harness), compiled as plain
+C++ against tests/hipemu/hip/hip_runtime.h. TEST INFRASTRUCTURE ONLY - see that header.
+
+    python tests/hipemu/build_emu.py
+"""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "librootba_hip_emu.so")
+CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(ROOT, "rootba_amd", "csrc", "*.hpp")) +
+                  glob.glob(os.path.join(ROOT, "rootba_amd", "csrc", "*.hip")))
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    deps = sources() + [os.path.join(ROOT, "include", "rootba_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
+                        os.path.join(HERE, "hipemu_runtime.cpp"), os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+
+
+def build(force: bool = False) -> str:
+    if not (force or stale()):
+        return LIB
+    src_dir = os.path.join(OUT, "rootba_amd", "csrc")
+    os.makedirs(src_dir, exist_ok=True)
+    os.makedirs(os.path.join(OUT, "include"), exist_ok=True)
+    shutil.copy(os.path.join(ROOT, "include", "rootba_hip.h"), os.path.join(OUT, "include", "rootba_hip.h"))
+    for path in sources():
+        txt = open(path).read().replace("extern __shared__", "extern")
+        open(os.path.join(src_dir, os.path.basename(path)), "w").write(txt)
+    cmd = [CXX, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-mavx2", "-mfma", "-ffp-contract=fast",
+           "-Wno-unused-value", "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-DHIPEMU=1",
+           "-I", HERE, os.path.join(src_dir, "solver.hip"), "-x", "c++", os.path.join(HERE, "hipemu_runtime.cpp"),
+           "-o", LIB, "-ldl", "-lpthread"]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

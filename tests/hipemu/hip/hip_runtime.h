@@ -1,0 +1,308 @@
+// tests/hipemu/hip/hip_runtime.h - a CPU EXECUTION HARNESS for the kernels of rootba_amd/csrc (development / test tool).
+//
+// TEST INFRASTRUCTURE ONLY. tests/hipemu/build_emu.py compiles the UNCHANGED product sources (solver.hip + kernels*.hpp)
+// as plain C++ against this header into tests/hipemu/_build/librootba_hip_emu.so: every kernel then runs on the CPU with
+// the gfx950 execution model emulated - a workgroup is a set of cooperative fibers, one per work-item, 64 per wavefront;
+// __syncthreads, the wave-level operations the kernels use (DPP moves, readlane, __shfl, the 16x16x4 f32 matrix-core
+// instruction) and LDS are modelled; workgroups of a grid run one after the other. It exists so that kernel LOGIC can be
+// exercised when no GPU is at hand (GPU time is rationed to minutes per round). It is NOT a backend of the product:
+// nothing under rootba_amd/ or include/ refers to it, the product library still needs a GPU and fails loudly without one,
+// and no parity or performance statement rests on it - rounding differs from the hardware (fma contraction, atomics
+// order) and it is orders of magnitude slower. tests select it with RBA_EMU=1 (tests/conftest.py).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <type_traits>
+
+// ---- qualifiers --------------------------------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __align__(n) __attribute__((aligned(n)))
+// static __shared__ arrays are function-level statics shared by the fibers of the running workgroup (workgroups run one
+// at a time); `extern __shared__` declarations are rewritten to plain `extern` by build_emu.py and defined in the runtime
+#define __shared__ static
+
+// ---- vector types --------------------------------------------------------------------------------------------------
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+struct double4 { double x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct uint3 { unsigned x, y, z; };
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+static inline double4 make_double4(double x, double y, double z, double w) { return double4{x, y, z, w}; }
+
+// ---- runtime types / constants ---------------------------------------------------------------------------------------
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+constexpr hipError_t hipErrorNotReady = 600;
+constexpr hipError_t hipErrorInvalidValue = 1;
+struct hipemu_stream;
+struct hipemu_event;
+struct hipemu_graph;
+typedef hipemu_stream* hipStream_t;
+typedef hipemu_event* hipEvent_t;
+typedef hipemu_graph* hipGraph_t;
+typedef hipemu_graph* hipGraphExec_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0;
+
+namespace hipemu {
+struct Fiber;
+struct Self {
+  uint3 tid, bid;
+  dim3 bdim, gdim;
+  int lane, wave;
+};
+Self* self();                  // the running work-item
+void block_barrier();          // __syncthreads
+void wave_barrier();           // all live lanes of the wavefront
+uint64_t* wave_slots();        // 64 exchange slots of the running wavefront (+ 6 x 64 more for the matrix-core emulation)
+int first_live_lane();         // lowest lane of the wavefront that has not returned
+void launch(dim3 grid, dim3 block, size_t shmem, hipStream_t stream, std::function<void()> body);
+}  // namespace hipemu
+
+#define threadIdx (hipemu::self()->tid)
+#define blockIdx (hipemu::self()->bid)
+#define blockDim (hipemu::self()->bdim)
+#define gridDim (hipemu::self()->gdim)
+constexpr int warpSize = 64;
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  hipemu::launch(dim3(grid), dim3(block), size_t(shmem), stream, [=]() { kernel(__VA_ARGS__); })
+
+// ---- runtime API (tests/hipemu/hipemu_runtime.cpp) -----------------------------------------------------------------------
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int);
+hipError_t hipGetDevice(int*);
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int dev);
+hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipFree(void* p);
+hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
+hipError_t hipHostFree(void* p);
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k, hipStream_t s);
+hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind k);
+hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t s);
+hipError_t hipMemset(void* dst, int v, size_t n);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamCreate(hipStream_t* s);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamQuery(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
+hipError_t hipDeviceSynchronize();
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t);
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s);
+hipError_t hipGraphExecDestroy(hipGraphExec_t e);
+hipError_t hipGraphDestroy(hipGraph_t g);
+hipError_t hipGetLastError();
+const char* hipGetErrorString(hipError_t e);
+template <class F>
+hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) {
+  return hipSuccess;
+}
+
+// ---- device-side functions ---------------------------------------------------------------------------------------------
+static inline void __syncthreads() { hipemu::block_barrier(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+static inline int __float_as_int(float v) { int r; std::memcpy(&r, &v, 4); return r; }
+static inline float __int_as_float(int v) { float r; std::memcpy(&r, &v, 4); return r; }
+static inline unsigned __float_as_uint(float v) { unsigned r; std::memcpy(&r, &v, 4); return r; }
+static inline float __uint_as_float(unsigned v) { float r; std::memcpy(&r, &v, 4); return r; }
+static inline long long __double_as_longlong(double v) { long long r; std::memcpy(&r, &v, 8); return r; }
+static inline double __longlong_as_double(long long v) { double r; std::memcpy(&r, &v, 8); return r; }
+// correctly rounded single operations that must not be contracted into an fma
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+using std::abs;
+using std::fabs;
+using std::fma;
+using std::fmaf;
+using std::isfinite;
+using std::isinf;
+using std::isnan;
+using std::max;
+using std::min;
+using std::sqrt;
+
+static inline int min(int a, unsigned b) { return a < int(b) ? a : int(b); }
+static inline long long min(long long a, int b) { return a < b ? a : b; }
+static inline long long min(int a, long long b) { return a < b ? a : b; }
+static inline long min(long a, int b) { return a < b ? a : b; }
+static inline long min(int a, long b) { return a < b ? a : b; }
+static inline long long max(long long a, int b) { return a > b ? a : b; }
+static inline long max(long a, int b) { return a > b ? a : b; }
+static inline long max(int a, long b) { return a > b ? a : b; }
+static inline float rsqrtf(float v) { return 1.f / std::sqrt(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline int __clz(int v) { return v ? __builtin_clz(unsigned(v)) : 32; }
+
+// atomics: the fibers of a workgroup interleave only at synchronisation points and workgroups run one after the
+// other, so plain read-modify-write is atomic here
+template <class T>
+static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T>
+static inline T unsafeAtomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; *p = o > v ? o : v; return o; }
+static inline int atomicMin(int* p, int v) { int o = *p; *p = o < v ? o : v; return o; }
+static inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
+static inline int atomicCAS(int* p, int c, int v) { int o = *p; if (o == c) *p = v; return o; }
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+template <class T, class V>
+static inline T hipemu_atomic_fetch_add(T* p, V v) { T o = *p; *p = o + T(v); return o; }
+#define __hip_atomic_fetch_add(p, v, order, scope) hipemu_atomic_fetch_add(p, v)
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(p))
+
+// ---- wave-level operations ----------------------------------------------------------------------------------------------
+namespace hipemu {
+template <class T>
+static inline uint64_t bits(T v) {
+  static_assert(sizeof(T) <= 8, "exchange slot");
+  uint64_t r = 0;
+  std::memcpy(&r, &v, sizeof(T));
+  return r;
+}
+template <class T>
+static inline T from_bits(uint64_t b) {
+  T r;
+  std::memcpy(&r, &b, sizeof(T));
+  return r;
+}
+// every live lane deposits `v`, then reads the slot `pick(lane)` chooses (-1: keep `fallback`)
+template <class T, class F>
+static inline T exchange(T v, T fallback, F pick) {
+  uint64_t* s = wave_slots();
+  const int lane = self()->lane;
+  s[lane] = bits(v);
+  wave_barrier();
+  const int src = pick(lane);
+  const T r = src < 0 ? fallback : from_bits<T>(s[src & 63]);
+  wave_barrier();  // the slots are free for the next operation
+  return r;
+}
+// source lane of a DPP control word (quad_perm, row_shl/shr/ror, row_mirror, row_half_mirror, row_bcast15/31);
+// -1: no source (the instruction keeps `old`)
+static inline int dpp_source(int ctrl, int lane) {
+  const int row = lane & ~15, i = lane & 15;
+  if (ctrl <= 0xff) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  if (ctrl >= 0x101 && ctrl <= 0x10f) return i + (ctrl & 15) <= 15 ? lane + (ctrl & 15) : -1;  // row_shl
+  if (ctrl >= 0x111 && ctrl <= 0x11f) return i - (ctrl & 15) >= 0 ? lane - (ctrl & 15) : -1;   // row_shr
+  if (ctrl >= 0x121 && ctrl <= 0x12f) return row | ((i - (ctrl & 15)) & 15);                   // row_ror
+  if (ctrl == 0x140) return row | (15 - i);                                                    // row_mirror
+  if (ctrl == 0x141) return row | (i & 8) | (7 - (i & 7));                                     // row_half_mirror
+  if (ctrl == 0x142) return lane >= 16 ? row - 1 : -1;                                         // row_bcast:15
+  if (ctrl == 0x143) return lane >= 32 ? 31 : -1;                                              // row_bcast:31
+  std::fprintf(stderr, "hipemu: DPP control 0x%x is not modelled\n", ctrl);
+  std::abort();
+}
+}  // namespace hipemu
+
+static inline int hipemu_update_dpp(int old, int src, int ctrl) {
+  return hipemu::exchange<int>(src, old, [ctrl](int lane) { return hipemu::dpp_source(ctrl, lane); });
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl) hipemu_update_dpp(old, src, ctrl)
+#define __builtin_amdgcn_mov_dpp(src, ctrl, row_mask, bank_mask, bound_ctrl) hipemu_update_dpp(0, src, ctrl)
+static inline int hipemu_readlane(int v, int l) {
+  return hipemu::exchange<int>(v, v, [l](int) { return l; });
+}
+static inline int hipemu_readfirstlane(int v) {
+  const int l = hipemu::first_live_lane();
+  return hipemu::exchange<int>(v, v, [l](int) { return l; });
+}
+#define __builtin_amdgcn_readlane(v, l) hipemu_readlane(v, l)
+#define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)
+#define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
+template <class T>
+static inline T __shfl(T v, int src, int width = 64) {
+  return hipemu::exchange<T>(v, v, [src, width](int lane) { return (lane & ~(width - 1)) | (src & (width - 1)); });
+}
+template <class T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+  return hipemu::exchange<T>(v, v, [mask](int lane) { return lane ^ mask; });
+}
+template <class T>
+static inline T __shfl_down(T v, unsigned d, int width = 64) {
+  return hipemu::exchange<T>(v, v, [d, width](int lane) { return (lane & (width - 1)) + int(d) < width ? lane + int(d) : lane; });
+}
+template <class T>
+static inline T __shfl_up(T v, unsigned d, int width = 64) {
+  return hipemu::exchange<T>(v, v, [d, width](int lane) { return (lane & (width - 1)) >= int(d) ? lane - int(d) : lane; });
+}
+static inline unsigned long long __ballot(int pred) {
+  uint64_t* s = hipemu::wave_slots();
+  s[hipemu::self()->lane] = pred ? 1 : 0;
+  hipemu::wave_barrier();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) m |= (unsigned long long)(s[l] & 1) << l;  // (dead lanes left their slot at 0)
+  hipemu::wave_barrier();
+  s[hipemu::self()->lane] = 0;
+  return m;
+}
+
+// v_mfma_f32_16x16x4_f32: D = A (16x4) B (4x16) + C; lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15] and
+// C/D[(l >> 4) * 4 + r][l & 15], r = 0..3 (MI355X_MICROARCH / cdna_hip_programming guides)
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c) {
+  uint64_t* s = hipemu::wave_slots();
+  const int lane = hipemu::self()->lane;
+  s[lane] = hipemu::bits(a);
+  s[64 + lane] = hipemu::bits(b);
+  hipemu::wave_barrier();
+  const int col = lane & 15, rb = (lane >> 4) * 4;
+  hipemu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    float t = c[r];
+    for (int k = 0; k < 4; ++k)
+      t = std::fmaf(hipemu::from_bits<float>(s[k * 16 + rb + r]), hipemu::from_bits<float>(s[64 + k * 16 + col]), t);
+    d[r] = t;
+  }
+  hipemu::wave_barrier();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_f32_16x16x4f32(a, b, c)

@@ -1,0 +1,354 @@
+// tests/hipemu/hipemu_runtime.cpp - scheduler and runtime API of the CPU execution harness (see hip/hip_runtime.h in this
+// directory: TEST INFRASTRUCTURE ONLY).
+//
+// A kernel launch runs its workgroups one after the other on the calling thread. Inside a workgroup every work-item is
+// a fiber (own stack, hand-written context switch); fibers run until they reach a synchronisation point:
+//   block barrier  (__syncthreads)                     - all live work-items of the workgroup
+//   wave barrier   (every wave-level operation)        - all live lanes of the wavefront (64 consecutive work-items)
+// A work-item that returns from the kernel leaves both sets (like a lane whose EXEC bit is off for good). If no fiber can
+// make progress the harness aborts with a diagnostic instead of hanging.
+// Streams execute synchronously; a stream in capture mode records closures, a graph launch replays them.
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "hip/hip_runtime.h"
+
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  subq $8, %rsp
+  stmxcsr (%rsp)
+  fnstcw 4(%rsp)
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  ldmxcsr (%rsp)
+  fldcw 4(%rsp)
+  addq $8, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
+namespace hipemu {
+
+enum Wait { RUN = 0, WAIT_WAVE, WAIT_BLOCK, DONE };
+
+struct Wave {
+  int alive = 0, arrived = 0;
+  uint64_t slots[7 * 64];
+};
+struct Fiber {
+  void* sp = nullptr;
+  Wait wait = RUN;
+  Self self;
+  Wave* wave = nullptr;
+};
+struct Block {
+  std::vector<Fiber> fibers;
+  std::vector<Wave> waves;
+  int alive = 0, arrived = 0;
+  const std::function<void()>* body = nullptr;
+};
+
+static thread_local Block* g_block = nullptr;
+static thread_local Fiber* g_cur = nullptr;
+static thread_local void* g_sched_sp = nullptr;
+static thread_local std::vector<char>* g_stacks = nullptr;
+constexpr size_t kStack = 96 * 1024;
+
+Self* self() { return &g_cur->self; }
+uint64_t* wave_slots() { return g_cur->wave->slots; }
+int first_live_lane() {
+  Block& b = *g_block;
+  const int w = g_cur->self.wave;
+  for (int l = 0; l < 64; ++l) {
+    const size_t t = size_t(w) * 64 + l;
+    if (t < b.fibers.size() && b.fibers[t].wait != DONE) return l;
+  }
+  return 0;
+}
+
+static void yield() { hipemu_switch(&g_cur->sp, g_sched_sp); }
+
+static void release_wave(Block& b, Wave* w) {
+  for (auto& f : b.fibers)
+    if (f.wave == w && f.wait == WAIT_WAVE) f.wait = RUN;
+  w->arrived = 0;
+}
+static void release_block(Block& b) {
+  for (auto& f : b.fibers)
+    if (f.wait == WAIT_BLOCK) f.wait = RUN;
+  b.arrived = 0;
+}
+
+void wave_barrier() {
+  Fiber* f = g_cur;
+  Wave* w = f->wave;
+  if (w->alive <= 1) return;
+  if (++w->arrived == w->alive) {
+    release_wave(*g_block, w);
+    return;
+  }
+  f->wait = WAIT_WAVE;
+  yield();
+}
+void block_barrier() {
+  Fiber* f = g_cur;
+  Block& b = *g_block;
+  if (b.alive <= 1) return;
+  if (++b.arrived == b.alive) {
+    release_block(b);
+    return;
+  }
+  f->wait = WAIT_BLOCK;
+  yield();
+}
+
+static void trampoline() {
+  Fiber* f = g_cur;
+  (*g_block->body)();
+  // the work-item has returned: it leaves the wavefront and the workgroup
+  Block& b = *g_block;
+  f->wait = DONE;
+  --b.alive;
+  --f->wave->alive;
+  if (f->wave->alive > 0 && f->wave->arrived == f->wave->alive) release_wave(b, f->wave);
+  if (b.alive > 0 && b.arrived == b.alive) release_block(b);
+  yield();
+  std::fprintf(stderr, "hipemu: a finished fiber was resumed\n");
+  std::abort();
+}
+
+static void prepare(Fiber& f, char* stack_top) {
+  // layout expected by hipemu_switch when it loads this context: [mxcsr|fpucw][r15][r14][r13][r12][rbx][rbp][ret]
+  uint64_t* sp = reinterpret_cast<uint64_t*>(reinterpret_cast<uintptr_t>(stack_top) & ~uintptr_t(15));
+  *--sp = 0;                                        // fake return address of trampoline (keeps rsp = 8 mod 16 at entry)
+  *--sp = reinterpret_cast<uint64_t>(&trampoline);  // ret target
+  for (int i = 0; i < 6; ++i) *--sp = 0;            // rbp rbx r12 r13 r14 r15
+  --sp;
+  uint32_t* cw = reinterpret_cast<uint32_t*>(sp);
+  cw[0] = 0x1f80;  // MXCSR default
+  cw[1] = 0x037f;  // x87 control word default
+  f.sp = sp;
+}
+
+static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, uint3 bid) {
+  const size_t n = size_t(block.x) * block.y * block.z;
+  Block b;
+  b.body = &body;
+  b.fibers.resize(n);
+  b.waves.resize((n + 63) / 64);
+  b.alive = int(n);
+  if (!g_stacks) g_stacks = new std::vector<char>();
+  if (g_stacks->size() < n * kStack) g_stacks->resize(n * kStack);
+  for (size_t t = 0; t < n; ++t) {
+    Fiber& f = b.fibers[t];
+    f.self.tid = uint3{unsigned(t % block.x), unsigned((t / block.x) % block.y), unsigned(t / (size_t(block.x) * block.y))};
+    f.self.bid = bid;
+    f.self.bdim = block;
+    f.self.gdim = grid;
+    f.self.lane = int(t & 63);
+    f.self.wave = int(t >> 6);
+    f.wave = &b.waves[t >> 6];
+    ++f.wave->alive;
+    std::memset(f.wave->slots, 0, sizeof f.wave->slots);
+    prepare(f, g_stacks->data() + (t + 1) * kStack);
+  }
+  g_block = &b;
+  while (b.alive > 0) {
+    bool progress = false;
+    for (size_t t = 0; t < n; ++t) {
+      Fiber& f = b.fibers[t];
+      if (f.wait != RUN) continue;
+      g_cur = &f;
+      hipemu_switch(&g_sched_sp, f.sp);
+      progress = true;
+    }
+    if (!progress) {
+      int ww = 0, wb = 0;
+      for (auto& f : b.fibers) {
+        ww += f.wait == WAIT_WAVE;
+        wb += f.wait == WAIT_BLOCK;
+      }
+      std::fprintf(stderr,
+                   "hipemu: deadlock in block (%u,%u,%u): %d work-items alive, %d wait at a wave-level operation, %d at "
+                   "__syncthreads (divergent synchronisation?)\n",
+                   bid.x, bid.y, bid.z, b.alive, ww, wb);
+      std::abort();
+    }
+  }
+  g_block = nullptr;
+  g_cur = nullptr;
+}
+
+}  // namespace hipemu
+
+// ---- streams, events, graphs ------------------------------------------------------------------------------------------
+struct hipemu_graph {
+  std::vector<std::function<void()>> nodes;
+};
+struct hipemu_stream {
+  hipemu_graph* capturing = nullptr;
+};
+struct hipemu_event {
+  std::chrono::steady_clock::time_point t;
+};
+static hipemu_stream g_null_stream;
+static hipemu_stream* S(hipStream_t s) { return s ? s : &g_null_stream; }
+
+namespace hipemu {
+static void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
+  for (unsigned z = 0; z < grid.z; ++z)
+    for (unsigned y = 0; y < grid.y; ++y)
+      for (unsigned x = 0; x < grid.x; ++x) run_block(body, grid, block, uint3{x, y, z});
+}
+void launch(dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t stream, std::function<void()> body) {
+  if (S(stream)->capturing) {
+    S(stream)->capturing->nodes.push_back([grid, block, body]() { run_grid(grid, block, body); });
+    return;
+  }
+  run_grid(grid, block, body);
+}
+}  // namespace hipemu
+
+hipError_t hipGetDeviceCount(int* n) {
+  *n = 1;
+  return hipSuccess;
+}
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) {
+  *d = 0;
+  return hipSuccess;
+}
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
+  *v = 4;  // "compute units": keeps the persistent kernels' grids small
+  return hipSuccess;
+}
+hipError_t hipMalloc(void** p, size_t n) {
+  *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+  return *p ? hipSuccess : hipErrorInvalidValue;
+}
+hipError_t hipFree(void* p) {
+  std::free(p);
+  return hipSuccess;
+}
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipHostFree(void* p) { return hipFree(p); }
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k, hipStream_t s) {
+  if (S(s)->capturing) {
+    // (the source of a captured copy is read at replay time, as in a real graph; host staging buffers of the
+    //  callers outlive the graph)
+    S(s)->capturing->nodes.push_back([dst, src, n]() { std::memmove(dst, src, n); });
+    return hipSuccess;
+  }
+  (void)k;
+  std::memmove(dst, src, n);
+  return hipSuccess;
+}
+hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) {
+  std::memmove(dst, src, n);
+  return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t s) {
+  if (S(s)->capturing) {
+    S(s)->capturing->nodes.push_back([dst, v, n]() { std::memset(dst, v, n); });
+    return hipSuccess;
+  }
+  std::memset(dst, v, n);
+  return hipSuccess;
+}
+hipError_t hipMemset(void* dst, int v, size_t n) {
+  std::memset(dst, v, n);
+  return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+  *s = new hipemu_stream();
+  return hipSuccess;
+}
+hipError_t hipStreamCreate(hipStream_t* s) { return hipStreamCreateWithFlags(s, 0); }
+hipError_t hipStreamDestroy(hipStream_t s) {
+  delete s;
+  return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) {
+  *e = new hipemu_event();
+  (*e)->t = std::chrono::steady_clock::now();
+  return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t e) {
+  delete e;
+  return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  if (S(s)->capturing) {
+    S(s)->capturing->nodes.push_back([e]() { e->t = std::chrono::steady_clock::now(); });
+    return hipSuccess;
+  }
+  e->t = std::chrono::steady_clock::now();
+  return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
+  S(s)->capturing = new hipemu_graph();
+  return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) {
+  *g = S(s)->capturing;
+  S(s)->capturing = nullptr;
+  return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) {
+  *e = new hipemu_graph(*g);
+  return hipSuccess;
+}
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s) {
+  if (S(s)->capturing) {  // (a graph launched into a capturing stream becomes part of it)
+    for (auto& n : e->nodes) S(s)->capturing->nodes.push_back(n);
+    return hipSuccess;
+  }
+  for (auto& n : e->nodes) n();
+  return hipSuccess;
+}
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) {
+  delete e;
+  return hipSuccess;
+}
+hipError_t hipGraphDestroy(hipGraph_t g) {
+  delete g;
+  return hipSuccess;
+}
+hipError_t hipGetLastError() { return hipSuccess; }
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+
+// ---- dynamic LDS of the product's kernels (`extern __shared__` declarations, rewritten to `extern` by build_emu.py) ----
+namespace rba {
+alignas(16) char smem_raw[160 * 1024];
+alignas(16) unsigned char hx_lds_raw[160 * 1024];
+alignas(16) char smem_pcgs[160 * 1024];
+alignas(16) char smem_s1[160 * 1024];
+alignas(16) char smem_s1c[160 * 1024];
+}  // namespace rba
