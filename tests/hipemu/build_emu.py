@@ -1,5 +1,5 @@
 """Builds tests/hipemu/_build/librootba_hip_emu.so: the product's solver.hip + kernel headers, UNCHANGED except for one
-textual rewrite (`extern __shared__` -> `extern`: the dynamic-LDS arrays are defined by the harness), compiled as plain
+textual rewrite (`extern __shared__` -> `extern thread_local`: the dynamic-LDS arrays are defined by the harness), compiled as plain
 C++ against tests/hipemu/hip/hip_runtime.h. TEST INFRASTRUCTURE ONLY - see that header.
 
     python tests/hipemu/build_emu.py
@@ -38,7 +38,7 @@ def build(force: bool = False) -> str:
     os.makedirs(os.path.join(OUT, "include"), exist_ok=True)
     shutil.copy(os.path.join(ROOT, "include", "rootba_hip.h"), os.path.join(OUT, "include", "rootba_hip.h"))
     for path in sources():
-        txt = open(path).read().replace("extern __shared__", "extern")
+        txt = open(path).read().replace("extern __shared__", "extern thread_local")
         open(os.path.join(src_dir, os.path.basename(path)), "w").write(txt)
     cmd = [CXX, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-mavx2", "-mfma", "-ffp-contract=fast",
            "-Wno-unused-value", "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-DHIPEMU=1",

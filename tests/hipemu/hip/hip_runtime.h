@@ -28,9 +28,10 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __align__(n) __attribute__((aligned(n)))
-// static __shared__ arrays are function-level statics shared by the fibers of the running workgroup (workgroups run one
-// at a time); `extern __shared__` declarations are rewritten to plain `extern` by build_emu.py and defined in the runtime
-#define __shared__ static
+// static __shared__ arrays are function-level thread-local statics shared by the fibers of the workgroup that runs on this
+// OS thread (one workgroup at a time per thread); `extern __shared__` declarations are rewritten to `extern thread_local`
+// by build_emu.py and defined in the runtime
+#define __shared__ static thread_local
 
 // ---- vector types --------------------------------------------------------------------------------------------------
 struct float2 { float x, y; };
@@ -174,28 +175,51 @@ static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __clz(int v) { return v ? __builtin_clz(unsigned(v)) : 32; }
 
-// atomics: the fibers of a workgroup interleave only at synchronisation points and workgroups run one after the
-// other, so plain read-modify-write is atomic here
+// atomics: workgroups run concurrently on several OS threads, so these are real atomic read-modify-writes
 template <class T>
-static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+static inline T atomicAdd(T* p, T v) {
+  if constexpr (std::is_integral<T>::value) {
+    return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+  } else {
+    T old, want;
+    __atomic_load(p, &old, __ATOMIC_RELAXED);
+    do {
+      want = old + v;
+    } while (!__atomic_compare_exchange(p, &old, &want, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return old;
+  }
+}
 template <class T>
-static inline T unsafeAtomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
-static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
-static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
-static inline int atomicMax(int* p, int v) { int o = *p; *p = o > v ? o : v; return o; }
-static inline int atomicMin(int* p, int v) { int o = *p; *p = o < v ? o : v; return o; }
-static inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
-static inline int atomicCAS(int* p, int c, int v) { int o = *p; if (o == c) *p = v; return o; }
+static inline T unsafeAtomicAdd(T* p, T v) { return atomicAdd(p, v); }
+static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline int atomicMax(int* p, int v) {
+  int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+  return old;
+}
+static inline int atomicMin(int* p, int v) {
+  int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old > v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+  return old;
+}
+static inline int atomicExch(int* p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+static inline int atomicCAS(int* p, int c, int v) {
+  __atomic_compare_exchange_n(p, &c, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+  return c;
+}
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 template <class T, class V>
-static inline T hipemu_atomic_fetch_add(T* p, V v) { T o = *p; *p = o + T(v); return o; }
+static inline T hipemu_atomic_fetch_add(T* p, V v) { return atomicAdd(p, T(v)); }
 #define __hip_atomic_fetch_add(p, v, order, scope) hipemu_atomic_fetch_add(p, v)
-#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
-#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, __ATOMIC_RELAXED)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, __ATOMIC_RELAXED)
 
 // ---- wave-level operations ----------------------------------------------------------------------------------------------
 namespace hipemu {

@@ -1,16 +1,22 @@
 // tests/hipemu/hipemu_runtime.cpp - scheduler and runtime API of the CPU execution harness (see hip/hip_runtime.h in this
 // directory: TEST INFRASTRUCTURE ONLY).
 //
-// A kernel launch runs its workgroups one after the other on the calling thread. Inside a workgroup every work-item is
+// A kernel launch hands its workgroups to a small pool of OS threads (one workgroup at a time per thread). Inside a workgroup every work-item is
 // a fiber (own stack, hand-written context switch); fibers run until they reach a synchronisation point:
 //   block barrier  (__syncthreads)                     - all live work-items of the workgroup
 //   wave barrier   (every wave-level operation)        - all live lanes of the wavefront (64 consecutive work-items)
 // A work-item that returns from the kernel leaves both sets (like a lane whose EXEC bit is off for good). If no fiber can
 // make progress the harness aborts with a diagnostic instead of hanging.
 // Streams execute synchronously; a stream in capture mode records closures, a graph launch replays them.
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <sched.h>
 
 #include "hip/hip_runtime.h"
 
@@ -212,10 +218,91 @@ static hipemu_stream g_null_stream;
 static hipemu_stream* S(hipStream_t s) { return s ? s : &g_null_stream; }
 
 namespace hipemu {
+// workgroups of a grid are independent: a small pool of OS threads takes them from a shared counter
+// (HIPEMU_THREADS, default: the CPUs this process may use, at most 16; 1 = everything on the calling thread)
+struct Pool {
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable cv_job, cv_done;
+  uint64_t generation = 0;
+  int busy = 0;
+  bool stop = false;
+  // the current job
+  const std::function<void()>* body = nullptr;
+  dim3 grid, block;
+  std::atomic<uint64_t> next{0};
+  uint64_t total = 0;
+
+  void work() {
+    for (;;) {
+      const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= total) return;
+      const unsigned x = unsigned(i % grid.x), y = unsigned((i / grid.x) % grid.y), z = unsigned(i / (uint64_t(grid.x) * grid.y));
+      run_block(*body, grid, block, uint3{x, y, z});
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_job.wait(lk, [&] { return stop || generation != seen; });
+        if (stop) return;
+        seen = generation;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--busy == 0) cv_done.notify_all();
+      }
+    }
+  }
+  explicit Pool(int n) {
+    for (int i = 0; i < n; ++i) workers.emplace_back([this] { loop(); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv_job.notify_all();
+    for (auto& w : workers) w.join();
+  }
+  void run(dim3 g, dim3 b, const std::function<void()>& f) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      body = &f;
+      grid = g;
+      block = b;
+      total = uint64_t(g.x) * g.y * g.z;
+      next.store(0);
+      busy = int(workers.size());
+      ++generation;
+    }
+    cv_job.notify_all();
+    work();  // the calling thread takes its share
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return busy == 0; });
+  }
+};
+static int pool_threads() {
+  if (const char* e = std::getenv("HIPEMU_THREADS")) return std::max(1, std::atoi(e));
+  cpu_set_t set;
+  int n = 1;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+  return std::max(1, std::min(16, n));
+}
 static void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
-  for (unsigned z = 0; z < grid.z; ++z)
-    for (unsigned y = 0; y < grid.y; ++y)
-      for (unsigned x = 0; x < grid.x; ++x) run_block(body, grid, block, uint3{x, y, z});
+  static const int threads = pool_threads();
+  const uint64_t total = uint64_t(grid.x) * grid.y * grid.z;
+  if (threads == 1 || total == 1) {
+    for (unsigned z = 0; z < grid.z; ++z)
+      for (unsigned y = 0; y < grid.y; ++y)
+        for (unsigned x = 0; x < grid.x; ++x) run_block(body, grid, block, uint3{x, y, z});
+    return;
+  }
+  static Pool pool(threads - 1);
+  pool.run(grid, block, body);
 }
 void launch(dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t stream, std::function<void()> body) {
   if (S(stream)->capturing) {
@@ -346,9 +433,9 @@ const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSucce
 
 // ---- dynamic LDS of the product's kernels (`extern __shared__` declarations, rewritten to `extern` by build_emu.py) ----
 namespace rba {
-alignas(16) char smem_raw[160 * 1024];
-alignas(16) unsigned char hx_lds_raw[160 * 1024];
-alignas(16) char smem_pcgs[160 * 1024];
-alignas(16) char smem_s1[160 * 1024];
-alignas(16) char smem_s1c[160 * 1024];
+alignas(16) thread_local char smem_raw[160 * 1024];
+alignas(16) thread_local unsigned char hx_lds_raw[160 * 1024];
+alignas(16) thread_local char smem_pcgs[160 * 1024];
+alignas(16) thread_local char smem_s1[160 * 1024];
+alignas(16) thread_local char smem_s1c[160 * 1024];
 }  // namespace rba
