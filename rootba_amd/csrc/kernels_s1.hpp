@@ -670,6 +670,168 @@ __global__ __launch_bounds__(256) void k_s2_w8(Params<S> p, int64_t n_obs) {
   dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
 }
 
+// k_stage2_landmark + k_s2_w8 in ONE pass (RBA_S2_FUSED_LM=1; written in round 2 after the GPU budget was spent,
+// validated on the CPU execution harness of tests/hipemu only, therefore off by default until it has been measured):
+// every observation's work-item evaluates the six damping rotations of ITS landmark from R0, Q1^T r and lambda
+// (the arithmetic of k_stage2_landmark, kernels.hpp, statement for statement - about 250 flops against the ~100
+// bytes the pass moves per observation) instead of loading the 64-byte `givens` record that a separate
+// thread-per-landmark pass wrote; the work-item of a landmark's FIRST observation also writes the landmark's
+// records (givens, damped R, Q1^T r, damping-row residual, Z). One launch and one pass over the per-landmark
+// data less per stage 2.
+template <class S>
+__global__ __launch_bounds__(256) void k_s2_w8_fused(Params<S> p, int64_t n_obs, S lambda) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  const int64_t o = blockIdx.x * int64_t(256) + threadIdx.x;
+  if (o >= n_obs) return;
+  const int s = p.obs_lm[o];
+  const V4* __restrict__ vh = reinterpret_cast<const V4*>(p.Vh);
+  const V4 va = vh[2 * o], vb = vh[2 * o + 1];
+  const int64_t o0 = p.lm_obs[s];
+  const V4* __restrict__ lq = reinterpret_cast<const V4*>(p.LQ + 12 * size_t(s));
+  const V4 q0 = lq[0], q1 = lq[1], q2 = lq[2];
+  const V4 w0 = vh[2 * o0], w1 = vh[2 * o0 + 1], w2 = vh[2 * o0 + 2];
+  const int i = int(o - o0);
+  // ---- the landmark's damping (k_stage2_landmark) -----------------------------------------------------------
+  S T[3][4], D[3][4];
+  {
+    const S* R = p.R0 + 6 * size_t(s);
+    T[0][0] = R[0];
+    T[0][1] = R[1];
+    T[0][2] = R[2];
+    T[1][0] = S(0);
+    T[1][1] = R[3];
+    T[1][2] = R[4];
+    T[2][0] = S(0);
+    T[2][1] = S(0);
+    T[2][2] = R[5];
+    T[0][3] = w0.w;  // Q1^T r = first three entries of Q^T r (Vh[4 (2 o0 + j) + 3])
+    T[1][3] = w1.w;
+    T[2][3] = w2.w;
+  }
+  const S sl = sqrt(lambda);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) D[a][b] = (a == b) ? sl : S(0);
+  S g[16];  // c[6], s[6], damping-row residual[3], 0: the record k_s2_w8 loads
+  {
+    int idx = 0;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+#pragma unroll
+      for (int m = 0; m <= n; ++m) {
+        S c = S(1), sn = S(0);
+        if (lambda != S(0)) make_givens<S>(T[n][n], D[n - m][n], c, sn);
+        g[idx] = c;
+        g[6 + idx] = sn;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const S x = D[n - m][b], y = T[n][b];
+          D[n - m][b] = c * x + sn * y;
+          T[n][b] = -sn * x + c * y;
+        }
+        ++idx;
+      }
+    }
+  }
+  g[12] = D[0][3];
+  g[13] = D[1][3];
+  g[14] = D[2][3];
+  g[15] = S(0);
+  if (i == 0) {
+    S* grec = p.givens + 16 * size_t(s);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) grec[q] = g[q];
+    S* R = p.Rd + 6 * size_t(s);
+    R[0] = T[0][0];
+    R[1] = T[0][1];
+    R[2] = T[0][2];
+    R[3] = T[1][1];
+    R[4] = T[1][2];
+    R[5] = T[2][2];
+    p.q1trd[3 * size_t(s) + 0] = T[0][3];
+    p.q1trd[3 * size_t(s) + 1] = T[1][3];
+    p.q1trd[3 * size_t(s) + 2] = T[2][3];
+    p.damp_r[3 * size_t(s) + 0] = D[0][3];
+    p.damp_r[3 * size_t(s) + 1] = D[1][3];
+    p.damp_r[3 * size_t(s) + 2] = D[2][3];
+    if (p.implicit) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        S u[3] = {S(0), S(0), S(0)}, e[3] = {S(0), S(0), S(0)};
+        u[j] = S(1);
+        int idx = 0;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+#pragma unroll
+          for (int m = 0; m <= n; ++m) {
+            const S x = e[n - m], y = u[n];
+            e[n - m] = g[idx] * x + g[6 + idx] * y;
+            u[n] = -g[6 + idx] * x + g[idx] * y;
+            ++idx;
+          }
+        }
+        u[0] = u[1] = u[2] = S(0);
+#pragma unroll
+        for (int n = 2; n >= 0; --n) {
+#pragma unroll
+          for (int m = n; m >= 0; --m) {
+            --idx;
+            const S x = e[n - m], y = u[n];
+            e[n - m] = g[idx] * x - g[6 + idx] * y;
+            u[n] = g[6 + idx] * x + g[idx] * y;
+          }
+        }
+        p.Zd[9 * size_t(s) + 0 + j] = u[0];
+        p.Zd[9 * size_t(s) + 3 + j] = u[1];
+        p.Zd[9 * size_t(s) + 6 + j] = u[2];
+      }
+    }
+  }
+  // ---- the observation's eight coefficients (k_s2_w8) -------------------------------------------------------
+  const S tau0 = q0.x, tau1 = q0.y, tau2 = q0.z, g10 = q0.w, g20 = q1.x, g21 = q1.y, d0 = q1.z, d1 = q1.w, d2 = q2.x;
+  S out[2][4];  // [input][tt0 tt1 tt2 bm]
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const S m0 = e == 0 ? S(1) : S(0), m1 = e == 0 ? S(0) : S(1);
+    const S c0 = tau0 * (va.x * m0 + vb.x * m1);
+    const S c1 = tau1 * (va.y * m0 + vb.y * m1 - c0 * g10);
+    const S c2 = tau2 * (va.z * m0 + vb.z * m1 - c0 * g20 - c1 * g21);
+    S tt[3] = {-(c0 * w0.x + c1 * w0.y + c2 * w0.z), -(c0 * w1.x + c1 * w1.y + c2 * w1.z),
+               -(c0 * w2.x + c1 * w2.y + c2 * w2.z)};
+    S bm = -(c0 * d0 + c1 * d1 + c2 * d2);
+    if (i == 0) {
+      tt[0] += m0;
+      tt[1] += m1;
+    } else if (i == 1) {
+      tt[2] += m0;
+      bm += m1 * vb.w;
+    } else {
+      bm += m0 * va.w + m1 * vb.w;
+    }
+    S d[3] = {S(0), S(0), S(0)};
+    int idx = 0;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+#pragma unroll
+      for (int m = 0; m <= n; ++m) {
+        const S cc = g[idx], sn = g[6 + idx];
+        const S x = d[n - m], y = tt[n];
+        d[n - m] = cc * x + sn * y;
+        tt[n] = -sn * x + cc * y;
+        ++idx;
+      }
+    }
+    out[e][0] = tt[0];
+    out[e][1] = tt[1];
+    out[e][2] = tt[2];
+    out[e][3] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
+  }
+  V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * o);
+  dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};
+  dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
+}
+
 // b_mid[c] = sum over the camera's observations of bmO (fixed order, double)
 template <class S>
 __global__ __launch_bounds__(256) void k_cam_bmid(Params<S> p) {

@@ -208,6 +208,7 @@ class Solver final : public rba_solver {
     compact_ = staged_;  // compact stage-2 records (W8) + unscaled Jacobian rows; RBA_S2_COMPACT=0: round-2a records
     if (const char* ev = std::getenv("RBA_S2_COMPACT")) compact_ = staged_ && std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_FUSED_GRAM")) fused_gram_ = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("RBA_S2_FUSED_LM")) s2_fused_lm_ = std::atoi(ev) != 0;
     if (compact_) y_rep_ = 1;  // (the replica experiment post-processes y itself)
     {
       int dev = 0, cus = 0;
@@ -1381,10 +1382,18 @@ class Solver final : public rba_solver {
       return;
     }
     sub_begin();
-    hipLaunchKernelGGL((rba::k_stage2_landmark<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_, prm_,
-                       lambda);
+    const bool fused_lm = compact_ && s2_fused_lm_;  // RBA_S2_FUSED_LM=1 (kernels_s1.hpp: k_s2_w8_fused)
+    if (!fused_lm)
+      hipLaunchKernelGGL((rba::k_stage2_landmark<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_, prm_,
+                         lambda);
     sub_mark(&sub_.landmark_damping_time);  // set_landmark_damping(): the six rotations per landmark
-    if (compact_) {
+    if (fused_lm) {
+      hipLaunchKernelGGL((rba::k_s2_w8_fused<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0, stream_, prm_,
+                         int64_t(n_obs_), lambda);
+      cols_pending_ = false;
+      topd_valid_ = false;
+      sub_mark(&sub_.scale_pose_jacobian_time);
+    } else if (compact_) {
       // eight coefficients per observation; the Jacobian rows are neither read nor rewritten (kernels_s1.hpp)
       hipLaunchKernelGGL((rba::k_s2_w8<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0, stream_, prm_,
                          int64_t(n_obs_));
@@ -2513,6 +2522,7 @@ class Solver final : public rba_solver {
                               // (default 1: when it fits and every wave gets at least four tiles)
   bool operand_prescaled_ = false;
   bool fused_gram_ = true;     // RBA_FUSED_GRAM=0: always run the stage-1 Gram pass
+  bool s2_fused_lm_ = false;   // RBA_S2_FUSED_LM=1: landmark damping inside the W8 pass (k_s2_w8_fused; not yet measured)
   bool gram_pending_ = false;  // linearised without the Gram pass: the first stage 2's camera pass does it
   bool compact_ = false;     // stage 2 hands W8 (8 scalars per observation) to the camera pass, JpS stays unscaled
   bool topd_valid_ = false;  // compact: the 27 + 9 records exist for the current damping (assembly / E0 products only)

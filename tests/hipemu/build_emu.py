@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-OUT = os.path.join(HERE, "_build")
+OUT = os.environ.get("HIPEMU_BUILD_DIR", os.path.join(HERE, "_build"))  # (a second build beside a running session)
 LIB = os.path.join(OUT, "librootba_hip_emu.so")
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
