@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <random>
 #include <vector>
@@ -251,6 +252,151 @@ __global__ __launch_bounds__(256) void k_cam_block2(const float* __restrict__ J,
   }
 }
 
+// Variant 3 (written in round 2 without a GPU: correct on the CPU execution harness of tests/hipemu, not yet timed):
+// per-wave chunks as in variant 1, but
+//   * the cameras of the block are walked in a STATIC loop: for camera n the wave takes the ballot of its chunk's
+//     records that belong to n and issues the matrix-core instructions for exactly those records into accT[n] /
+//     accG[n] - statically indexed accumulators, no switch, no dynamic register indexing;
+//   * no per-lane side sums at all: the row g of W8 rides along as a tenth row of the G operand, so the instruction that
+//     accumulates G = sum Jp^T Jp also accumulates t = sum Jp^T g (tenth column of the tile), and diag2 is the
+//     diagonal of G (float accumulation, as the reference's own float reductions);
+//   * G packs two records per instruction (K = 4 full), T one record (K = 3 of 4).
+// 64 accumulator registers + staging. Partials per (segment, camera): T 81 | G 81 | t 9 floats.
+constexpr int PF3 = 171;
+__global__ __launch_bounds__(256) void k_cam_block3(const float* __restrict__ J, const float* __restrict__ W,
+                                                    const int* __restrict__ list, const int64_t* __restrict__ off,
+                                                    float* __restrict__ part_f, int n_seg) {
+  __shared__ __attribute__((aligned(16))) float stage[4][CH * RW + 6];
+  __shared__ float tile[4][2][16][16];
+  const int per = (n_seg + 7) / 8;
+  const int sg = (blockIdx.x % 8) * per + blockIdx.x / 8;  // XCD-contiguous segments
+  if (sg >= n_seg) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t t0 = off[sg], t1 = off[sg + 1];
+  float* lds = stage[wave];
+  f32x4 accT[B], accG[B];
+#pragma unroll
+  for (int c = 0; c < B; ++c) {
+    accT[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accG[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t base = t0 + CH * wave; base < t1; base += 4 * CH) {
+    const int cnt = int(t1 - base < CH ? t1 - base : CH);
+    const int e = lane < cnt ? list[base + lane] : 0;
+    const int idx = e & ((1 << 28) - 1);
+    const int myc = lane < cnt ? (e >> 28) : -1;
+#pragma unroll
+    for (int j = 0; j < (CH * 9 + 63) / 64; ++j) {
+      const int q = j * 64 + lane, r = q / 9, pc = q - 9 * r;
+      const int o = __shfl(idx, r & 31);
+      if (q < cnt * 9) *reinterpret_cast<float2*>(lds + r * RW + 2 * pc) = *reinterpret_cast<const float2*>(J + int64_t(o) * 18 + 2 * pc);
+    }
+    {
+      const int r = lane >> 1, h = lane & 1;
+      const int o = __shfl(idx, r & 31);
+      if (r < cnt) {
+        const float4 w = *reinterpret_cast<const float4*>(W + int64_t(o) * 8 + 4 * h);
+        float* d = lds + r * RW + 18 + 4 * h;
+        *reinterpret_cast<float2*>(d) = float2{w.x, w.y};
+        *reinterpret_cast<float2*>(d + 2) = float2{w.z, w.w};
+      }
+    }
+    wave_fence();
+#pragma unroll
+    for (int n = 0; n < B; ++n) {
+      const unsigned long long m = __ballot(myc == n);
+      for (unsigned long long mm = m; mm;) {  // T: one record per instruction (rows 0..2 of the operand = X = W' Jp)
+        const int s = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        const float* rec = lds + s * RW;
+        float vT = 0.f;
+        if (i < 9 && kk < 3) vT = fmaf(rec[18 + 2 * kk], rec[i], __fmul_rn(rec[19 + 2 * kk], rec[9 + i]));
+        accT[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vT, vT, accT[n], 0, 0, 0);
+      }
+      for (unsigned long long mm = m; mm;) {  // G (+ t in column 9): two records per instruction
+        const int s0 = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        int s1 = -1;
+        if (mm) {
+          s1 = __builtin_ctzll(mm);
+          mm &= mm - 1;
+        }
+        const int so = (kk >> 1) ? s1 : s0;
+        float vG = 0.f;
+        if (so >= 0 && i < 10) vG = i < 9 ? lds[so * RW + 9 * (kk & 1) + i] : lds[so * RW + 24 + (kk & 1)];
+        accG[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vG, vG, accG[n], 0, 0, 0);
+      }
+    }
+    wave_fence();  // the next chunk overwrites the staging buffer
+  }
+  // per camera of the block: sum the four waves, write the segment's partial
+#pragma unroll
+  for (int c = 0; c < B; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      tile[wave][0][(lane >> 4) * 4 + r][lane & 15] = accT[c][r];
+      tile[wave][1][(lane >> 4) * 4 + r][lane & 15] = accG[c][r];
+    }
+    __syncthreads();
+    if (tid < 162) {
+      const int m = tid / 81, e = tid - 81 * m, ii = e / 9, jj = e - 9 * ii;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += tile[w][m][ii][jj];
+      part_f[(size_t(sg) * B + c) * PF3 + tid] = v;
+    }
+    if (tid >= 192 && tid < 192 + 9) {
+      const int aa = tid - 192;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += tile[w][1][aa][9];  // t = column 9 of the G tile
+      part_f[(size_t(sg) * B + c) * PF3 + 162 + aa] = v;
+    }
+  }
+}
+
+// epilogue of variant 3: the side sums come from the float partials (t: 162..170, diag2: the diagonal of G)
+__global__ __launch_bounds__(128) void k_cam_block_epilogue3(const float* __restrict__ part_f, const int* __restrict__ seg_first,
+                                                             const int* __restrict__ seg_count, float eps, float lambda,
+                                                             float* __restrict__ pose_scaling, float* __restrict__ B_mid,
+                                                             float* __restrict__ blocks, float* __restrict__ bvec, int n_cams) {
+  __shared__ float dsc[9];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int blk = c / B, cl = c - B * blk;
+  const int s0 = seg_first[blk], ns = seg_count[blk];
+  float t = 0.f, gsum = 0.f;
+  if (tid < 81)
+    for (int s = 0; s < ns; ++s) {
+      const float* pf = part_f + (size_t(s0 + s) * B + cl) * PF3;
+      t += pf[tid];
+      gsum += pf[81 + tid];
+    }
+  double bt = 0.0;
+  if (tid >= 96 && tid < 105) {
+    const int aa = tid - 96;
+    double d2 = 0.0;
+    for (int s = 0; s < ns; ++s) {
+      const float* pf = part_f + (size_t(s0 + s) * B + cl) * PF3;
+      bt += double(pf[162 + aa]);
+      d2 += double(pf[81 + 10 * aa]);
+    }
+    const float sc = 1.f / (eps + sqrtf(float(d2)));
+    pose_scaling[9 * c + aa] = sc;
+    dsc[aa] = sc;
+  }
+  __syncthreads();
+  if (tid < 81) {
+    const int ii = tid / 9, jj = tid - 9 * ii;
+    const float dd = dsc[ii] * dsc[jj];
+    const float bm = __fmul_rn(gsum, dd);
+    B_mid[81 * c + tid] = bm;
+    blocks[81 * c + tid] = __fsub_rn(bm, __fmul_rn(t, dd)) + (ii == jj ? lambda : 0.f);
+  }
+  if (tid >= 96 && tid < 105) bvec[9 * c + (tid - 96)] = float(bt * double(dsc[tid - 96]));
+}
+
 // per camera: add the partials of its block's segments in a fixed order; D, B_mid, blocks, b
 __global__ __launch_bounds__(128) void k_cam_block_epilogue(const float* __restrict__ part_f, const double* __restrict__ part_d,
                                                             const int* __restrict__ seg_first, const int* __restrict__ seg_count,
@@ -293,7 +439,9 @@ __global__ __launch_bounds__(128) void k_cam_block_epilogue(const float* __restr
 }
 
 int main() {
-  const int n_cams = 1778, K = 5, n_lms = 1000000;
+  // (CAMBLOCK_CAMS / CAMBLOCK_LMS: a small instance for the CPU execution harness of tests/hipemu)
+  const int n_cams = std::getenv("CAMBLOCK_CAMS") ? std::atoi(std::getenv("CAMBLOCK_CAMS")) : 1778, K = 5;
+  const int n_lms = std::getenv("CAMBLOCK_LMS") ? std::atoi(std::getenv("CAMBLOCK_LMS")) : 1000000;
   const int64_t n_obs = int64_t(n_lms) * K;
   std::vector<int> obs_cam(n_obs);
   std::vector<std::vector<int>> cam_list(n_cams);
@@ -335,7 +483,7 @@ int main() {
   CK(hipMalloc(&J, hJ.size() * 4)); CK(hipMalloc(&W, hW.size() * 4));
   CK(hipMemcpy(J, hJ.data(), hJ.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMalloc(&pf, size_t(n_seg) * B * PF * 4)); CK(hipMalloc(&pd, size_t(n_seg) * B * PD * 8));
+  CK(hipMalloc(&pf, size_t(n_seg) * B * PF3 * 4)); CK(hipMalloc(&pd, size_t(n_seg) * B * PD * 8));
   CK(hipMalloc(&ps, n_cams * 9 * 4)); CK(hipMalloc(&bm, n_cams * 81 * 4)); CK(hipMalloc(&bl, n_cams * 81 * 4));
   CK(hipMalloc(&bv, n_cams * 9 * 4));
   CK(hipMalloc(&dl, list.size() * 4)); CK(hipMalloc(&doff, off.size() * 8));
@@ -347,17 +495,26 @@ int main() {
   const float eps = 3.1622776601683794e-3f, lambda = 1e-4f;
   hipEvent_t e0, e1, e2;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
-  for (int variant = 1; variant <= 2; ++variant) {
+  // CAMBLOCK_SKIP=2: leave a variant out (variant 2 calls __ballot inside a divergent branch, which the CPU execution
+  // harness does not model)
+  const int skip = std::getenv("CAMBLOCK_SKIP") ? std::atoi(std::getenv("CAMBLOCK_SKIP")) : 0;
+  for (int variant = 1; variant <= 3; ++variant) {
+  if (variant == skip) continue;
   float best1 = 1e9f, best2 = 1e9f;
-  CK(hipMemset(pf, 0, size_t(n_seg) * B * PF * 4)); CK(hipMemset(pd, 0, size_t(n_seg) * B * PD * 8));
+  CK(hipMemset(pf, 0, size_t(n_seg) * B * PF3 * 4)); CK(hipMemset(pd, 0, size_t(n_seg) * B * PD * 8));
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipEventRecord(e0));
     if (variant == 1)
       hipLaunchKernelGGL(k_cam_block, dim3(8 * ((n_seg + 7) / 8)), dim3(256), 0, 0, J, W, dl, doff, pf, pd, n_seg);
-    else
+    else if (variant == 2)
       hipLaunchKernelGGL(k_cam_block2, dim3(8 * ((n_seg + 7) / 8)), dim3(256), 0, 0, J, W, dl, doff, pf, pd, n_seg);
+    else
+      hipLaunchKernelGGL(k_cam_block3, dim3(8 * ((n_seg + 7) / 8)), dim3(256), 0, 0, J, W, dl, doff, pf, n_seg);
     CK(hipEventRecord(e1));
-    hipLaunchKernelGGL(k_cam_block_epilogue, dim3(n_cams), dim3(128), 0, 0, pf, pd, dsf, dsc_, eps, lambda, ps, bm, bl, bv, n_cams);
+    if (variant == 3)
+      hipLaunchKernelGGL(k_cam_block_epilogue3, dim3(n_cams), dim3(128), 0, 0, pf, dsf, dsc_, eps, lambda, ps, bm, bl, bv, n_cams);
+    else
+      hipLaunchKernelGGL(k_cam_block_epilogue, dim3(n_cams), dim3(128), 0, 0, pf, pd, dsf, dsc_, eps, lambda, ps, bm, bl, bv, n_cams);
     CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
     float m1, m2;
     CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e1, e2));
@@ -373,7 +530,7 @@ int main() {
   CK(hipMemcpy(hps.data(), ps, hps.size() * 4, hipMemcpyDeviceToHost));
   CK(hipMemcpy(hbm.data(), bm, hbm.size() * 4, hipMemcpyDeviceToHost));
   double worst_bl = 0, worst_b = 0, worst_d = 0, worst_bm = 0;
-  for (int c : {0, 1, 7, 8, 123, 888, 1770, 1777}) {
+  for (int c : {0, 1, 7, 8, 123 % n_cams, 888 % n_cams, n_cams - 8, n_cams - 1}) {
     double G[81] = {0}, T[81] = {0}, t9[9] = {0};
     for (int o : cam_list[c]) {
       const float* jp = &hJ[size_t(o) * 18];

@@ -101,7 +101,15 @@ hipError_t hipGetDevice(int*);
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int dev);
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
-hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
+template <class T>
+hipError_t hipMalloc(T** p, size_t n) {
+  return hipMalloc(reinterpret_cast<void**>(p), n);
+}
+template <class T>
+hipError_t hipHostMalloc(T** p, size_t n, unsigned flags = 0) {
+  return hipHostMalloc(reinterpret_cast<void**>(p), n, flags);
+}
+hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
 hipError_t hipHostFree(void* p);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k, hipStream_t s);
 hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind k);
