@@ -751,6 +751,175 @@ __global__ __launch_bounds__(256) void k_cam_stage2_w8_mfma(Params<float> p, flo
   }
 }
 
+// ---------------------------------------------------------------------------
+// Camera-BLOCK form of the compact stage-2 camera pass (RBA_CAM_BLOCKS=1; written in round 2 after the GPU budget was
+// spent: correct on the CPU execution harness of tests/hipemu and in scripts/microbench/cam_block_pass.hip (variant 3)
+// against a double reference, NOT YET TIMED, therefore off by default).
+// Why: k_cam_stage2_w8_mfma gathers a 72-byte row and a 32-byte W8 record per observation out of landmark-major
+// storage; FETCH_SIZE says it moves 2.35 x the bytes it needs, and the same gather over the MERGED, address-sorted
+// observation lists of 8 consecutive cameras runs 1.8 x faster (profiles/r2b_microbench_cam_gather.txt) because the
+// records of a landmark seen by several cameras of the block arrive as one contiguous piece.
+// How: the merged list of a block is cut into one segment per camera of the block (as many workgroups as cameras);
+// a wave stages 32 records, then walks the block's cameras in a STATIC loop - the ballot of the chunk's records that
+// belong to camera n selects the records whose matrix-core instructions go into accT[n] / accG[n] (statically
+// indexed accumulators: no switch, no dynamic register indexing, 76 VGPRs). The row g of W8 rides along as a tenth
+// operand row of the G instruction, which therefore also accumulates t = sum Jp^T g (column 9 of the tile); Jp_diag2 is
+// the diagonal of G. Float accumulation throughout (the reference reduces these sums in Scalar as well); the double
+// side sums of the per-camera kernel are gone. Every segment writes partial sums per camera of its block,
+// k_cam_block_finish adds a camera's partials in a fixed order (deterministic) and writes what
+// k_cam_stage2_w8_mfma writes: [Jp_diag2, pose scaling, B_mid when GRAM], blocks, sdiag, b.
+// List entry: observation index | (camera - first camera of the block) << 28.
+// ---------------------------------------------------------------------------
+constexpr int kCbCams = 8;      // cameras per block
+constexpr int kCbPart = 171;    // floats per (segment, camera): T 81 | G 81 | t 9
+__global__ __launch_bounds__(256) void k_cam_block_accumulate(Params<float> p, const int* __restrict__ list,
+                                                              const int64_t* __restrict__ seg_off,
+                                                              float* __restrict__ part, int n_seg) {
+  constexpr int RW = 26, B = kCbCams;
+  __shared__ __attribute__((aligned(16))) float stage[4][kCamChunk * RW + 6];
+  __shared__ float tile[4][2][16][16];
+  const int sg = xcd_swizzled_camera(n_seg);  // XCD-contiguous segments
+  if (sg >= n_seg) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t t0 = seg_off[sg], t1 = seg_off[sg + 1];
+  float* lds = stage[wave];
+  f32x4 accT[B], accG[B];
+#pragma unroll
+  for (int c = 0; c < B; ++c) {
+    accT[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accG[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t base = t0 + kCamChunk * wave; base < t1; base += 4 * kCamChunk) {
+    const int cnt = int(min<int64_t>(kCamChunk, t1 - base));
+    const int e = lane < cnt ? list[base + lane] : 0;
+    const int idx = e & ((1 << 28) - 1);
+    const int myc = lane < cnt ? (e >> 28) : -1;
+#pragma unroll
+    for (int j = 0; j < (kCamChunk * 9 + 63) / 64; ++j) {
+      const int q = j * 64 + lane, r = q / 9, pc = q - 9 * r;
+      const int o = __shfl(idx, r & 31);
+      if (q < cnt * 9)
+        *reinterpret_cast<float2*>(lds + r * RW + 2 * pc) = *reinterpret_cast<const float2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
+    }
+    {
+      const int r = lane >> 1, h = lane & 1;
+      const int o = __shfl(idx, r & 31);
+      if (r < cnt) {
+        const float4 w = *reinterpret_cast<const float4*>(p.W8 + int64_t(o) * 8 + 4 * h);
+        float* d = lds + r * RW + 18 + 4 * h;
+        *reinterpret_cast<float2*>(d) = float2{w.x, w.y};
+        *reinterpret_cast<float2*>(d + 2) = float2{w.z, w.w};
+      }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int n = 0; n < B; ++n) {
+      const unsigned long long m = __ballot(myc == n);
+      for (unsigned long long mm = m; mm;) {  // T: one record per instruction (operand rows 0..2 = X = W' Jp)
+        const int s = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        const float* rec = lds + s * RW;
+        float vT = 0.f;
+        if (i < 9 && kk < 3) vT = fmaf(rec[18 + 2 * kk], rec[i], __fmul_rn(rec[19 + 2 * kk], rec[9 + i]));
+        accT[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vT, vT, accT[n], 0, 0, 0);
+      }
+      for (unsigned long long mm = m; mm;) {  // G (+ t in column 9): two records per instruction
+        const int s0 = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        int s1 = -1;
+        if (mm) {
+          s1 = __builtin_ctzll(mm);
+          mm &= mm - 1;
+        }
+        const int so = (kk >> 1) ? s1 : s0;
+        float vG = 0.f;
+        if (so >= 0 && i < 10) vG = i < 9 ? lds[so * RW + 9 * (kk & 1) + i] : lds[so * RW + 24 + (kk & 1)];
+        accG[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vG, vG, accG[n], 0, 0, 0);
+      }
+    }
+    wave_lds_fence();  // the next chunk overwrites the staging buffer
+  }
+  // per camera of the block: the four waves' sums, one partial per (segment, camera)
+#pragma unroll
+  for (int c = 0; c < B; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      tile[wave][0][(lane >> 4) * 4 + r][lane & 15] = accT[c][r];
+      tile[wave][1][(lane >> 4) * 4 + r][lane & 15] = accG[c][r];
+    }
+    __syncthreads();
+    float* out = part + (size_t(sg) * B + c) * kCbPart;
+    if (tid < 162) {
+      const int m = tid / 81, e = tid - 81 * m, ii = e / 9, jj = e - 9 * ii;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += tile[w][m][ii][jj];
+      out[tid] = v;
+    }
+    if (tid >= 192 && tid < 192 + 9) {
+      const int aa = tid - 192;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += tile[w][1][aa][9];  // t = column 9 of the G tile
+      out[162 + aa] = v;
+    }
+  }
+}
+
+// per camera: its block's segments' partials in a fixed order -> the outputs of k_cam_stage2_w8_mfma
+__global__ __launch_bounds__(128) void k_cam_block_finish(Params<float> p, const float* __restrict__ part,
+                                                          const int* __restrict__ seg_first, const int* __restrict__ seg_count,
+                                                          float lambda, int GRAM) {
+  __shared__ float dsc[9];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int blk = c / kCbCams, cl = c - kCbCams * blk;
+  const int s0 = seg_first[blk], ns = seg_count[blk];
+  float t = 0.f, gsum = 0.f;
+  if (tid < 81)
+    for (int s = 0; s < ns; ++s) {
+      const float* pf = part + (size_t(s0 + s) * kCbCams + cl) * kCbPart;
+      t += pf[tid];
+      gsum += pf[81 + tid];
+    }
+  double bt = 0.0;
+  if (tid >= 96 && tid < 105) {
+    const int aa = tid - 96;
+    double d2 = 0.0;
+    for (int s = 0; s < ns; ++s) {
+      const float* pf = part + (size_t(s0 + s) * kCbCams + cl) * kCbPart;
+      bt += double(pf[162 + aa]);
+      d2 += double(pf[81 + 10 * aa]);
+    }
+    if (GRAM) {
+      const float d2f = float(d2);
+      p.jp_diag2[9 * c + aa] = d2f;
+      const float sc = 1.f / (p.eps + sqrtf(d2f));  // k_pose_scaling
+      p.pose_scaling[9 * c + aa] = sc;
+      dsc[aa] = sc;
+    } else {
+      dsc[aa] = p.pose_scaling[9 * c + aa];
+    }
+  }
+  __syncthreads();
+  if (tid < 81) {
+    const int ii = tid / 9, jj = tid - 9 * ii;
+    const float dd = dsc[ii] * dsc[jj];
+    float bm;
+    if (GRAM) {
+      bm = __fmul_rn(gsum, dd);
+      p.B_mid[81 * c + tid] = bm;
+    } else {
+      bm = p.B_mid[81 * c + tid];
+    }
+    const float bt2 = __fsub_rn(bm, __fmul_rn(t, dd));
+    p.blocks[81 * c + tid] = (p.jacobi ? bm : bt2) + (ii == jj ? lambda : 0.f);
+    if (p.want_sdiag) p.sdiag[81 * c + tid] = bt2;
+  }
+  if (tid >= 96 && tid < 105) p.b[9 * c + (tid - 96)] = float(bt * double(dsc[tid - 96]));
+}
+
 // generic (double): records staged per workgroup, double accumulators
 template <class S>
 __global__ __launch_bounds__(256) void k_cam_stage2_w8(Params<S> p, S lambda, int GRAM) {

@@ -105,12 +105,13 @@ template <class T>
 hipError_t hipMalloc(T** p, size_t n) {
   return hipMalloc(reinterpret_cast<void**>(p), n);
 }
-template <class T>
-hipError_t hipHostMalloc(T** p, size_t n, unsigned flags = 0) {
-  return hipHostMalloc(reinterpret_cast<void**>(p), n, flags);
-}
+
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
 hipError_t hipHostFree(void* p);
+template <class T>
+hipError_t hipHostMalloc(T** p, size_t n, unsigned flags = 0) {
+  return hipHostMalloc(reinterpret_cast<void**>(p), n, flags);  // (the non-template overload, declared above)
+}
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k, hipStream_t s);
 hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind k);
 hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t s);
