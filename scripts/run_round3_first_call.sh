@@ -1,0 +1,21 @@
+#!/bin/bash
+# First GPU call of the next round (run through gpurun from the repository root, e.g.
+#   gpurun --timeout 1500 -- 'bash scripts/run_round3_first_call.sh'):
+# the GPU tests that were written in round 2 without a GPU (validated on tests/hipemu only), the two default-off
+# stage-2 candidates measured against the default, the camera-block microbenchmark, one bench line.
+set -x
+mkdir -p gpurun_out/r3
+export TMPDIR=/tmp
+python -m pytest tests -q -m gpu -x -k "reference or zz" > gpurun_out/r3/pytest_late_tests.log 2>&1
+tail -5 gpurun_out/r3/pytest_late_tests.log
+python scripts/s2_ab.py venice-1778 > gpurun_out/r3/s2_ab_venice.jsonl 2> gpurun_out/r3/s2_ab_venice.err
+cat gpurun_out/r3/s2_ab_venice.jsonl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/microbench/cam_block_pass.hip -o /tmp/cam_block_pass.bin \
+  && /tmp/cam_block_pass.bin > gpurun_out/r3/cam_block_pass.txt 2>&1
+cat gpurun_out/r3/cam_block_pass.txt
+for env in "" "RBA_CAM_BLOCKS=1" "RBA_S2_FUSED_LM=1" "RBA_CAM_BLOCKS=1 RBA_S2_FUSED_LM=1"; do
+  tag=$(echo "${env:-default}" | tr ' =' '__')
+  env $env python bench.py --steps 20 --warmup 5 --cpu-baseline-iters 0 --no-reference-semantics \
+    > gpurun_out/r3/bench_${tag}.json 2> gpurun_out/r3/bench_${tag}.log
+  python -c "import json,sys; d=json.loads(open('gpurun_out/r3/bench_${tag}.json').read().strip().splitlines()[-1]); print('${tag}', d['value'], d['roofline']['stages']['stage2'])"
+done
