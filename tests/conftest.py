@@ -25,7 +25,7 @@ def pytest_collection_modifyitems(config, items):
     # the CPU harness is for logic at test sizes: full-size workloads would take hours, the CLI binary and the
     # multi-process tests use the real library
     too_big = ("test_full_size_venice", "test_gpu_baseline_configs", "test_bal_qr_hip", "test_gpu_rccl_multi",
-               "test_gpu_sharded", "test_hip_reproduces_the_tutorial_run")
+               "test_hip_reproduces_the_tutorial_run")
     if os.environ.get("RBA_EMU_CLI") == "1":
         # the caller put a copy of the harness build named librootba_hip.so on LD_LIBRARY_PATH: the CLI binary
         # (RUNPATH $ORIGIN, searched after LD_LIBRARY_PATH) then runs on the harness too

@@ -25,6 +25,10 @@ def _worker(rank, world, port, dtype_name, env, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bench import shard_ranges, take_landmarks
     from rootba_amd import _lib as L
+    if os.environ.get("RBA_EMU") == "1":  # development runs on the CPU execution harness (tests/hipemu), as tests/conftest.py
+        sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+        import build_emu
+        L.LIB_PATH = build_emu.LIB
     from rootba_amd import problem as P
     from rootba_amd.linearizor import LinearizorHIP
     dtype = "mixed" if dtype_name == "mixed" else np.dtype(dtype_name)
