@@ -17,6 +17,8 @@ if os.environ.get("RBA_EMU") == "1":
     import build_emu  # noqa: E402
     import rootba_amd._lib as _rba_lib  # noqa: E402
     _rba_lib.LIB_PATH = build_emu.build()
+    # (the harness build of the library opens this stand-in where the product opens librccl.so.1)
+    os.environ.setdefault("HIPEMU_RCCL", os.path.join(os.path.dirname(_rba_lib.LIB_PATH), "fake_rccl", "librccl.so.1"))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -26,7 +26,7 @@ def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     deps = sources() + [os.path.join(ROOT, "include", "rootba_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
-                        os.path.join(HERE, "hipemu_runtime.cpp"), os.path.abspath(__file__)]
+                        os.path.join(HERE, "hipemu_runtime.cpp"), os.path.join(HERE, "fake_rccl.cpp"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
@@ -45,6 +45,10 @@ def build(force: bool = False) -> str:
            "-I", HERE, os.path.join(src_dir, "solver.hip"), "-x", "c++", os.path.join(HERE, "hipemu_runtime.cpp"),
            "-o", LIB, "-ldl", "-lpthread"]
     subprocess.check_call(cmd)
+    # the file-based stand-in for librccl.so.1 (multi-process runs on the harness: put its directory on LD_LIBRARY_PATH)
+    os.makedirs(os.path.join(OUT, "fake_rccl"), exist_ok=True)
+    subprocess.check_call([CXX, "-std=c++17", "-O1", "-fPIC", "-shared", os.path.join(HERE, "fake_rccl.cpp"), "-o",
+                           os.path.join(OUT, "fake_rccl", "librccl.so.1"), "-lpthread"])
     return LIB
 
 

@@ -21,6 +21,16 @@
 #include <functional>
 #include <type_traits>
 
+// ---- the library dlopens "librccl.so.1"; a process that has imported torch already holds torch's own RCCL under that
+// name, so on the harness the stand-in (fake_rccl.cpp) is opened by the path in HIPEMU_RCCL instead
+#include <dlfcn.h>
+static inline void* hipemu_dlopen(const char* name, int flags) {
+  const char* fake = std::getenv("HIPEMU_RCCL");
+  if (fake && name && std::strncmp(name, "librccl", 7) == 0) return dlopen(fake, RTLD_NOW | RTLD_LOCAL);
+  return dlopen(name, flags);
+}
+#define dlopen hipemu_dlopen
+
 // ---- qualifiers --------------------------------------------------------------------------------------------------
 #define __global__
 #define __device__
