@@ -30,3 +30,40 @@ def test_a_slice_of_the_gpu_suite_on_the_cpu_harness():
     tail = out.stdout[-1500:] + out.stderr[-500:]
     assert out.returncode == 0, tail
     assert " passed" in out.stdout and "failed" not in out.stdout, tail
+
+
+def test_bench_with_two_ranks_on_the_cpu_harness():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on the harness with the
+    file-based stand-in for librccl: the library's RCCL code path with more than one rank (rba_comm_init, the union of the
+    block structure, every all-reduce site), the collective transport decision and the JSON line. Both ranks walk the same
+    trajectory as one rank does (the per-iteration costs of the log)."""
+    import json
+    import socket
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import build_emu
+    if not os.path.exists(build_emu.CXX):
+        pytest.skip(f"{build_emu.CXX} is not available")
+    try:
+        build_emu.build()
+    except subprocess.CalledProcessError as e:
+        pytest.skip(f"the harness does not build here: {e}")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    harness = os.path.join(ROOT, "tests", "hipemu", "bench_on_harness.py")
+    common = ["--workload", "ladybug-49", "--steps", "2", "--warmup", "2", "--cpu-baseline-iters", "0",
+              "--no-reference-semantics"]
+    env = dict(os.environ, HIPEMU_THREADS="4")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), harness, "--gpus", "2", *common],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert two.returncode == 0, two.stderr[-3000:]
+    line2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and "transport=rccl, nranks=2" in line2["config"]["parallelism"]
+    assert line2["config"]["comm_per_step"]["all_reduces"] > 0
+    one = subprocess.run([sys.executable, harness, *common], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert one.returncode == 0, one.stderr[-3000:]
+    line1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line1["n_gpus"] == 1 and line1["config"]["comm_per_step"] is None
+    assert abs(line2["config"]["final_cost"] - line1["config"]["final_cost"]) <= 2e-6 * line1["config"]["final_cost"]
+    assert line2["config"]["cg_iterations_per_step"] == line1["config"]["cg_iterations_per_step"]
