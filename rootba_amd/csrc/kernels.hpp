@@ -2009,12 +2009,14 @@ __device__ __forceinline__ int hx_chunk_tile(const HxChunk& ch, int v, int n_tot
   return T;
 }
 
-template <class S>
-__global__ __launch_bounds__(1024) void k_hx_implicit_lds(Params<S> p, ImplicitTiles it,
-                                                          const HxChunk* __restrict__ chunks, int win,
-                                                          const S* __restrict__ x, S* __restrict__ y,
-                                                          const S* __restrict__ dout,
-                                                          const int* __restrict__ done_flag) {
+// NT threads per workgroup: 1024 caps a lane at 128 VGPRs - enough for float (114), 104 bytes of scratch per lane
+// for double; the 512-thread instance has 256 and spills nothing, at half the waves per CU (RBA_HX_THREADS).
+template <class S, int NT>
+__global__ __launch_bounds__(NT) void k_hx_implicit_lds(Params<S> p, ImplicitTiles it,
+                                                        const HxChunk* __restrict__ chunks, int win,
+                                                        const S* __restrict__ x, S* __restrict__ y,
+                                                        const S* __restrict__ dout,
+                                                        const int* __restrict__ done_flag) {
   // `dout` (compact stage 2: the Jacobian rows are unscaled, x arrives pre-multiplied by the pose scaling D):
   // the result is multiplied by D where it leaves the workgroup; nullptr = rows already scaled
   extern __shared__ __align__(16) unsigned char hx_lds_raw[];
@@ -2024,13 +2026,13 @@ __global__ __launch_bounds__(1024) void k_hx_implicit_lds(Params<S> p, ImplicitT
   if (threadIdx.x < sizeof(HxChunk) / sizeof(int))
     reinterpret_cast<int*>(&ch)[threadIdx.x] = reinterpret_cast<const int*>(chunks + blockIdx.x)[threadIdx.x];
   const int nwin = 9 * win;
-  for (int i = threadIdx.x; i < nwin; i += 1024) ylds[i] = 0.0;
+  for (int i = threadIdx.x; i < nwin; i += NT) ylds[i] = 0.0;
   __syncthreads();
   const int cam_lo = ch.cam_lo;
   int nV = 0;
   for (int r = 0; r < ch.n_ranges; ++r) nV += ch.tile_end[r] - ch.tile_begin[r];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr int W = 16;
+  constexpr int W = NT / 64;
   int vA = wave;
   if (vA < nV) {
     int vB = vA + W;
@@ -2075,7 +2077,7 @@ __global__ __launch_bounds__(1024) void k_hx_implicit_lds(Params<S> p, ImplicitT
   const int start = int((int64_t(blockIdx.x) * nwin) / gridDim.x);
   S* __restrict__ yw = y + 9 * cam_lo;
   const S* __restrict__ dw = dout ? dout + 9 * cam_lo : nullptr;
-  for (int i = threadIdx.x; i < nwin; i += 1024) {
+  for (int i = threadIdx.x; i < nwin; i += NT) {
     int j = i + start;
     j = j >= nwin ? j - nwin : j;
     const double v = ylds[j];

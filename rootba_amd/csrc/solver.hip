@@ -205,6 +205,7 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_Y_REPLICAS")) y_rep_ = std::max(1, std::min(64, std::atoi(ev)));
     if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
     if (const char* ev = std::getenv("RBA_HX_LDS")) hx_lds_ = std::atoi(ev);
+    if (const char* ev = std::getenv("RBA_HX_THREADS")) hx_threads_ = std::atoi(ev) == 512 ? 512 : 1024;
     compact_ = staged_;  // compact stage-2 records (W8) + unscaled Jacobian rows; RBA_S2_COMPACT=0: round-2a records
     if (const char* ev = std::getenv("RBA_S2_COMPACT")) compact_ = staged_ && std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_FUSED_GRAM")) fused_gram_ = std::atoi(ev) != 0;
@@ -1707,17 +1708,25 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_hx_implicit<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, it, xin, y,
                          dout, done_flag);
     if (use_lds) {
-      // workgroup-private window of y in LDS (double accumulators, ds_add_f64), one persistent 1024-thread
-      // workgroup per CU
+      // workgroup-private window of y in LDS (double accumulators, ds_add_f64), one persistent workgroup per CU
       const size_t ylds_bytes = size_t(9) * hx_win_ * sizeof(double);
-      if (!hx_lds_attr_set_) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_implicit_lds<S>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(kHxLdsMaxBytes)));
-        hx_lds_attr_set_ = true;
-      }
-      hipLaunchKernelGGL((rba::k_hx_implicit_lds<S>), dim3(n_hx_chunks_), dim3(1024), ylds_bytes, stream_, prm_, it,
-                         d_hx_chunks_.get(), hx_win_, xin, y, dout, done_flag);
+      if (hx_threads_ == 512)
+        launch_hx_lds<512>(it, ylds_bytes, xin, y, dout, done_flag);
+      else
+        launch_hx_lds<1024>(it, ylds_bytes, xin, y, dout, done_flag);
     }
+  }
+
+  template <int NT>
+  void launch_hx_lds(const rba::ImplicitTiles& it, size_t ylds_bytes, const S* xin, S* y, const S* dout,
+                     const int* done_flag) {
+    if (!hx_lds_attr_set_) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_implicit_lds<S, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kHxLdsMaxBytes)));
+      hx_lds_attr_set_ = true;
+    }
+    hipLaunchKernelGGL((rba::k_hx_implicit_lds<S, NT>), dim3(n_hx_chunks_), dim3(NT), ylds_bytes, stream_, prm_, it,
+                       d_hx_chunks_.get(), hx_win_, xin, y, dout, done_flag);
   }
 
   void right_multiply(const void* x, void* y) override {
@@ -2566,6 +2575,7 @@ class Solver final : public rba_solver {
   bool staged_ = false;       // stage 1 staged by parallelism (kernels_s1.hpp): implicit-Q configuration
   bool cols_pending_ = false; // linearised, column pass not yet run (it runs inside the first stage 2)
   bool bs_two_pass_ = false;  // RBA_BS_TWO_PASS=1: round-1 back-substitution kernels for every landmark
+  int hx_threads_ = 1024;     // RBA_HX_THREADS=512: 512-thread workgroups of k_hx_implicit_lds (no scratch in double)
   int hx_lds_ = 1;            // RBA_HX_LDS=0: never use the LDS-private y copy (k_hx_implicit_lds); 2: whenever y fits
                               // (default 1: when it fits and every wave gets at least four tiles)
   bool operand_prescaled_ = false;

@@ -19,3 +19,10 @@ for env in "" "RBA_CAM_BLOCKS=1" "RBA_S2_FUSED_LM=1" "RBA_CAM_BLOCKS=1 RBA_S2_FU
     > gpurun_out/r3/bench_${tag}.json 2> gpurun_out/r3/bench_${tag}.log
   python -c "import json,sys; d=json.loads(open('gpurun_out/r3/bench_${tag}.json').read().strip().splitlines()[-1]); print('${tag}', d['value'], d['roofline']['stages']['stage2'])"
 done
+# float64: the LDS-private product with 512-thread workgroups (no scratch) against the default 1024 (104 B of scratch per lane)
+for env in "" "RBA_HX_THREADS=512"; do
+  tag=f64_$(echo "${env:-default}" | tr ' =' '__')
+  env $env python bench.py --use-double --steps 10 --warmup 3 --cpu-baseline-iters 0 --no-reference-semantics \
+    > gpurun_out/r3/bench_${tag}.json 2> gpurun_out/r3/bench_${tag}.log
+  python -c "import json,sys; d=json.loads(open('gpurun_out/r3/bench_${tag}.json').read().strip().splitlines()[-1]); print('${tag}', d['value'], d['roofline'].get('achieved'))"
+done

@@ -6,6 +6,9 @@ run that includes this file says whether they are correct on the hardware; sorte
   RBA_S2_FUSED_LM=1   k_s2_w8_fused (kernels_s1.hpp): the landmark damping pass folded into the per-observation W8 pass
   RBA_CAM_BLOCKS=1    k_cam_block_accumulate / k_cam_block_finish (kernels.hpp): the stage-2 camera pass over the merged,
                       address-sorted observation lists of blocks of 8 cameras (float only)
+  RBA_HX_THREADS=512  k_hx_implicit_lds<S, 512> (kernels.hpp): the LDS-private product with 512-thread workgroups -
+                      156 VGPRs and no scratch in double (the 1024-thread instance is capped at 128 and spills 104
+                      bytes per lane), at half the waves per CU
 """
 import numpy as np
 import pytest
@@ -105,3 +108,31 @@ def test_camera_blocks_with_invalid_projections_and_odd_camera_count(small_probl
                 assert rel_err(ig, io) < 2e-3
         lg, lo = g.apply(io), o.apply(io)
         assert abs(lg - lo) / (abs(lg) + abs(lo)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("which", ["small", "mixed"])
+@pytest.mark.parametrize("env", [{"RBA_HX_LDS": "2"}, {"RBA_HX_LDS": "2", "RBA_HX_WIN": "7"}], ids=["lds-private", "lds-window"])
+def test_product_with_512_thread_workgroups(small_problem, mixed_k_problem, dtype, which, env, monkeypatch):
+    """tests/test_gpu_parity.py::test_implicit_q_product_kernels with RBA_HX_THREADS=512, then a solve."""
+    prob = {"small": small_problem, "mixed": mixed_k_problem}[which]
+    monkeypatch.setenv("RBA_HX_THREADS", "512")
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    g, o = _pair(prob, dtype, implicit_q=1)
+    assert g.linearize() == 0 and o.linearize() == 0
+    rng = np.random.default_rng(5)
+    for lam in (1e-4, 1e-6):
+        o.set_pose_damping(lam)
+        o.stage2(lam, o.pose_scaling() if lam == 1e-4 else None)
+        g.stage2(lam)
+        for _ in range(2):
+            x = rng.uniform(-1, 1, 9 * prob.n_cams).astype(dtype)
+            assert rel_err(g.right_multiply(x), o.right_multiply(x)) < TOL[dtype]
+    g2, o2 = _pair(prob, dtype, implicit_q=1)
+    assert g2.linearize() == 0 and o2.linearize() == 0
+    ig, cg = g2.solve(1e-4)
+    io, co = o2.solve(1e-4)
+    assert abs(cg.num_iterations - co.num_iterations) <= (1 if dtype == np.float32 else 0)
+    if cg.num_iterations == co.num_iterations:
+        assert rel_err(ig, io) < 10 * TOL[dtype]
