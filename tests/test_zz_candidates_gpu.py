@@ -3,6 +3,10 @@ execution harness of tests/hipemu only: they stay behind their switches until th
 These tests hold each of them to the oracle exactly like the default path (tests/test_gpu_parity.py), so the first GPU
 run that includes this file says whether they are correct on the hardware; sorted last on purpose.
 
+Not part of the acceptance suite: code that has never run on an MI355X does not belong in the run that certifies the
+default path, so the file runs only with RBA_TEST_CANDIDATES=1 (scripts/run_round3_first_call.sh sets it, each
+invocation under its own `timeout`) or on the CPU harness (RBA_EMU=1).
+
   RBA_S2_FUSED_LM=1   k_s2_w8_fused (kernels_s1.hpp): the landmark damping pass folded into the per-observation W8 pass
   RBA_CAM_BLOCKS=1    k_cam_block_accumulate / k_cam_block_finish (kernels.hpp): the stage-2 camera pass over the merged,
                       address-sorted observation lists of blocks of 8 cameras (float only)
@@ -15,7 +19,11 @@ import pytest
 
 from conftest import rel_err
 
-pytestmark = pytest.mark.gpu
+import os
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not (os.environ.get("RBA_TEST_CANDIDATES") == "1" or os.environ.get("RBA_EMU")),
+                                 reason="default-off candidates: RBA_TEST_CANDIDATES=1 runs them")]
 TOL = {np.float32: 1e-4, np.float64: 1e-10}
 
 
