@@ -57,8 +57,13 @@ def test_mixed_iteration_is_float_algebra_on_the_double_state(small_problem):
     io, co = o32.solve(1e-4)
     assert ig.dtype == np.float32 and cg.termination_type == 1
     assert abs(cg.num_iterations - co.num_iterations) <= 1
-    if cg.num_iterations == co.num_iterations:
-        assert rel_err(ig, io) < 2e-3
+    ref = io
+    if cg.num_iterations != co.num_iterations:  # the float iterate after exactly the product's count (eta = 0: no stopping test)
+        o_n = O.Oracle(prob, np.float32, _opts(O, max_cg_it=cg.num_iterations, eta=0.0))
+        assert o_n.linearize() == 0
+        ref, cn = o_n.solve(1e-4)
+        assert cn.num_iterations == cg.num_iterations
+    assert rel_err(ig, ref) < 2e-3
     c0, l0 = g.get_state()
     lg, lo = g.apply(io), o32.apply(io)
     assert abs(lg - lo) <= 1e-4 * abs(lo)
