@@ -15,6 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.environ.get("HIPEMU_BUILD_DIR", os.path.join(HERE, "_build"))  # (a second build beside a running session)
 LIB = os.path.join(OUT, "librootba_hip_emu.so")
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+# HIPEMU_SANITIZE=address: the kernels and the host side of the library under AddressSanitizer (device buffers are host
+# allocations here, so an out-of-bounds access of a kernel is reported with the kernel's source line); use a build
+# directory of its own (HIPEMU_BUILD_DIR) and run python with the runtime preloaded - see README.md
+SANITIZE = os.environ.get("HIPEMU_SANITIZE", "")
 
 
 def sources():
@@ -44,6 +48,12 @@ def build(force: bool = False) -> str:
            "-Wno-unused-value", "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-DHIPEMU=1",
            "-I", HERE, os.path.join(src_dir, "solver.hip"), "-x", "c++", os.path.join(HERE, "hipemu_runtime.cpp"),
            "-o", LIB, "-ldl", "-lpthread"]
+    if SANITIZE:
+        cmd[1:1] = [f"-fsanitize={SANITIZE}", "-fno-omit-frame-pointer", "-shared-libsan"]
+        if SANITIZE == "thread":
+            # the work-items of a workgroup are fibers on ONE OS thread: no function entry / exit events, or the
+            # sanitizer's per-thread shadow call stack would see unbalanced calls across the context switches
+            cmd[1:1] = ["-mllvm", "-tsan-instrument-func-entry-exit=0"]
     subprocess.check_call(cmd)
     # the file-based stand-in for librccl.so.1 (multi-process runs on the harness: put its directory on LD_LIBRARY_PATH)
     os.makedirs(os.path.join(OUT, "fake_rccl"), exist_ok=True)

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include <sched.h>
@@ -63,6 +64,8 @@ struct Fiber {
   Wait wait = RUN;
   Self self;
   Wave* wave = nullptr;
+  void* asan_fake = nullptr;     // AddressSanitizer builds (HIPEMU_SANITIZE=address): the fiber's fake-stack handle
+  const void* stack_lo = nullptr;
 };
 struct Block {
   std::vector<Fiber> fibers;
@@ -89,7 +92,31 @@ int first_live_lane() {
   return 0;
 }
 
-static void yield() { hipemu_switch(&g_cur->sp, g_sched_sp); }
+// AddressSanitizer has to be told about every stack switch (tests/hipemu/README.md: HIPEMU_SANITIZE=address)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN 1
+#endif
+#endif
+#ifdef HIPEMU_ASAN
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+static thread_local const void* g_sched_stack_lo = nullptr;
+static thread_local size_t g_sched_stack_size = 0;
+static thread_local void* g_sched_fake = nullptr;
+#endif
+
+static void yield() {
+#ifdef HIPEMU_ASAN
+  Fiber* f = g_cur;
+  __sanitizer_start_switch_fiber(f->wait == DONE ? nullptr : &f->asan_fake, g_sched_stack_lo, g_sched_stack_size);
+  hipemu_switch(&f->sp, g_sched_sp);
+  __sanitizer_finish_switch_fiber(f->asan_fake, &g_sched_stack_lo, &g_sched_stack_size);
+#else
+  hipemu_switch(&g_cur->sp, g_sched_sp);
+#endif
+}
 
 static void release_wave(Block& b, Wave* w) {
   for (auto& f : b.fibers)
@@ -127,6 +154,9 @@ void block_barrier() {
 
 static void trampoline() {
   Fiber* f = g_cur;
+#ifdef HIPEMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &g_sched_stack_lo, &g_sched_stack_size);
+#endif
   (*g_block->body)();
   // the work-item has returned: it leaves the wavefront and the workgroup
   Block& b = *g_block;
@@ -162,6 +192,10 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
   b.alive = int(n);
   if (!g_stacks) g_stacks = new std::vector<char>();
   if (g_stacks->size() < n * kStack) g_stacks->resize(n * kStack);
+#ifdef HIPEMU_ASAN
+  // the frames a finished fiber was abandoned in (trampoline -> yield) are still poisoned: the top of every stack
+  for (size_t t = 0; t < n; ++t) __asan_unpoison_memory_region(g_stacks->data() + (t + 1) * kStack - 8192, 8192);
+#endif
   for (size_t t = 0; t < n; ++t) {
     Fiber& f = b.fibers[t];
     f.self.tid = uint3{unsigned(t % block.x), unsigned((t / block.x) % block.y), unsigned(t / (size_t(block.x) * block.y))};
@@ -174,6 +208,7 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
     ++f.wave->alive;
     std::memset(f.wave->slots, 0, sizeof f.wave->slots);
     prepare(f, g_stacks->data() + (t + 1) * kStack);
+    f.stack_lo = g_stacks->data() + t * kStack;
   }
   g_block = &b;
   while (b.alive > 0) {
@@ -182,7 +217,13 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
       Fiber& f = b.fibers[t];
       if (f.wait != RUN) continue;
       g_cur = &f;
+#ifdef HIPEMU_ASAN
+      __sanitizer_start_switch_fiber(&g_sched_fake, f.stack_lo, kStack);
       hipemu_switch(&g_sched_sp, f.sp);
+      __sanitizer_finish_switch_fiber(g_sched_fake, nullptr, nullptr);
+#else
+      hipemu_switch(&g_sched_sp, f.sp);
+#endif
       progress = true;
     }
     if (!progress) {
@@ -326,6 +367,34 @@ hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
   *v = 4;  // "compute units": keeps the persistent kernels' grids small
   return hipSuccess;
 }
+#ifdef HIPEMU_ASAN
+// AddressSanitizer builds: no slack behind a buffer - the bytes between the requested size and the aligned size are
+// poisoned, so that an access one element past the end of a device buffer is reported
+extern "C" void __asan_poison_memory_region(void const volatile* addr, size_t size);
+static std::mutex g_alloc_mutex;
+static std::unordered_map<void*, std::pair<size_t, size_t>> g_alloc_sizes;
+hipError_t hipMalloc(void** p, size_t n) {
+  const size_t rounded = (std::max<size_t>(n, 1) + 255) / 256 * 256;
+  *p = std::aligned_alloc(256, rounded);
+  if (!*p) return hipErrorInvalidValue;
+  if (rounded > n) __asan_poison_memory_region(static_cast<char*>(*p) + n, rounded - n);
+  std::lock_guard<std::mutex> lk(g_alloc_mutex);
+  g_alloc_sizes[*p] = {n, rounded};
+  return hipSuccess;
+}
+hipError_t hipFree(void* p) {
+  if (p) {
+    std::lock_guard<std::mutex> lk(g_alloc_mutex);
+    auto it = g_alloc_sizes.find(p);
+    if (it != g_alloc_sizes.end()) {
+      hipemu::__asan_unpoison_memory_region(static_cast<char*>(p) + it->second.first, it->second.second - it->second.first);
+      g_alloc_sizes.erase(it);
+    }
+  }
+  std::free(p);
+  return hipSuccess;
+}
+#else
 hipError_t hipMalloc(void** p, size_t n) {
   *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256);
   return *p ? hipSuccess : hipErrorInvalidValue;
@@ -334,6 +403,7 @@ hipError_t hipFree(void* p) {
   std::free(p);
   return hipSuccess;
 }
+#endif
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k, hipStream_t s) {
