@@ -50,6 +50,8 @@ def build(force: bool = False) -> str:
            "-o", LIB, "-ldl", "-lpthread"]
     if SANITIZE:
         cmd[1:1] = [f"-fsanitize={SANITIZE}", "-fno-omit-frame-pointer", "-shared-libsan"]
+        if "alignment" in SANITIZE:
+            cmd[1:1] = ["-DHIPEMU_STRICT_ALIGN=1"]
         if SANITIZE == "thread":
             # the work-items of a workgroup are fibers on ONE OS thread: no function entry / exit events, or the
             # sanitizer's per-thread shadow call stack would see unbalanced calls across the context switches

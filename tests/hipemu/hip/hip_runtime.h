@@ -44,14 +44,40 @@ static inline void* hipemu_dlopen(const char* name, int flags) {
 #define __shared__ static thread_local
 
 // ---- vector types --------------------------------------------------------------------------------------------------
-struct float2 { float x, y; };
-struct float4 { float x, y, z, w; };
-struct double2 { double x, y; };
-struct double4 { double x, y, z, w; };
-struct int2 { int x, y; };
-struct int4 { int x, y, z, w; };
-struct uint2 { unsigned x, y; };
-struct uint4 { unsigned x, y, z, w; };
+// HIPEMU_STRICT_ALIGN (the UBSan build, HIPEMU_SANITIZE=alignment,bounds): the alignments HIP gives these types, so that
+// `-fsanitize=alignment` reports every vector access whose address is not a multiple of the vector size (the LDS
+// instructions for 8 / 16 bytes want that; vector accesses to global memory only need 4)
+#ifdef HIPEMU_STRICT_ALIGN
+// (user-provided copy operations: a trivial aggregate copy is emitted as a memcpy, which the sanitizer does not check;
+//  a call of a member function on a misaligned object is)
+#define HIPEMU_VEC2(NAME, T, A)                                              \
+  struct alignas(A) NAME {                                                   \
+    T x, y;                                                                  \
+    NAME() = default;                                                        \
+    NAME(T a, T b) : x(a), y(b) {}                                           \
+    NAME(const NAME& o) : x(o.x), y(o.y) {}                                  \
+    NAME& operator=(const NAME& o) { x = o.x; y = o.y; return *this; }       \
+  };
+#define HIPEMU_VEC4(NAME, T, A)                                                              \
+  struct alignas(A) NAME {                                                                   \
+    T x, y, z, w;                                                                            \
+    NAME() = default;                                                                        \
+    NAME(T a, T b, T c, T d) : x(a), y(b), z(c), w(d) {}                                     \
+    NAME(const NAME& o) : x(o.x), y(o.y), z(o.z), w(o.w) {}                                  \
+    NAME& operator=(const NAME& o) { x = o.x; y = o.y; z = o.z; w = o.w; return *this; }     \
+  };
+#else
+#define HIPEMU_VEC2(NAME, T, A) struct NAME { T x, y; };
+#define HIPEMU_VEC4(NAME, T, A) struct NAME { T x, y, z, w; };
+#endif
+HIPEMU_VEC2(float2, float, 8)
+HIPEMU_VEC4(float4, float, 16)
+HIPEMU_VEC2(double2, double, 16)
+HIPEMU_VEC4(double4, double, 32)
+HIPEMU_VEC2(int2, int, 8)
+HIPEMU_VEC4(int4, int, 16)
+HIPEMU_VEC2(uint2, unsigned, 8)
+HIPEMU_VEC4(uint4, unsigned, 16)
 struct uint3 { unsigned x, y, z; };
 struct dim3 {
   unsigned x, y, z;
