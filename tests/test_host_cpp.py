@@ -492,3 +492,31 @@ def _cereal_parse(data):
         off.append(len(cam))
     assert at == len(data)
     return P.BalProblem(cams, lms, np.array(off, dtype=np.int64), np.array(cam, dtype=np.int32), np.array(xy), "cereal")
+
+
+def test_loaders_end_cleanly_on_mutated_files(app, tmp_path):
+    """Truncations, byte flips, insertions and blown-up counts of a small valid BAL text / .cereal cache: every run ends
+    with exit code 0 (still a valid file) or 2 (rejected with a message) - never a signal, never an unbounded allocation.
+    (scripts/fuzz_loaders.py is the long form with an AddressSanitizer + UBSan build, incl. the Bundler loader.)"""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from fuzz_loaders import mutate
+    raw = P.synthetic_problem(12, 80, 300, seed=4)
+    bal = str(tmp_path / "problem-12-80-pre.txt")
+    P.write_bal(raw, bal)
+    cer = str(tmp_path / "problem-12-80-pre.cereal")
+    assert subprocess.run([app, "--input", bal, "--dry-run", "--no-normalize", "--save-output", "--output-optimized-path", cer],
+                          capture_output=True).returncode == 0
+    rng = random.Random(7)
+    codes = set()
+    for src, name in ((bal, "problem-m%d-pre.txt"), (cer, "problem-m%d-pre.cereal")):
+        data = open(src, "rb").read()
+        for i in range(40):
+            path = str(tmp_path / (name % i))
+            open(path, "wb").write(mutate(data, rng, src.endswith(".txt")))
+            out = subprocess.run([app, "--input", path, "--dry-run"], capture_output=True, text=True, timeout=60)
+            assert out.returncode in (0, 2), (path, out.returncode, out.stderr[-300:])
+            codes.add(out.returncode)
+            os.remove(path)
+    assert 2 in codes
