@@ -367,6 +367,12 @@ hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
   *v = 4;  // "compute units": keeps the persistent kernels' grids small
   return hipSuccess;
 }
+// HIPEMU_POISON=1: fresh device memory is filled with 0xff (NaN as float / double, -1 as int) instead of whatever the host
+// allocator returns (zero pages for large buffers): a kernel that consumes memory nobody wrote shows up in the results
+static bool poison_fresh_memory() {
+  static const bool on = [] { const char* e = std::getenv("HIPEMU_POISON"); return e && *e && *e != '0'; }();
+  return on;
+}
 #ifdef HIPEMU_ASAN
 // AddressSanitizer builds: no slack behind a buffer - the bytes between the requested size and the aligned size are
 // poisoned, so that an access one element past the end of a device buffer is reported
@@ -377,6 +383,7 @@ hipError_t hipMalloc(void** p, size_t n) {
   const size_t rounded = (std::max<size_t>(n, 1) + 255) / 256 * 256;
   *p = std::aligned_alloc(256, rounded);
   if (!*p) return hipErrorInvalidValue;
+  if (poison_fresh_memory()) std::memset(*p, 0xff, n);
   if (rounded > n) __asan_poison_memory_region(static_cast<char*>(*p) + n, rounded - n);
   std::lock_guard<std::mutex> lk(g_alloc_mutex);
   g_alloc_sizes[*p] = {n, rounded};
@@ -397,6 +404,7 @@ hipError_t hipFree(void* p) {
 #else
 hipError_t hipMalloc(void** p, size_t n) {
   *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+  if (*p && poison_fresh_memory()) std::memset(*p, 0xff, (n + 255) / 256 * 256 + 256);
   return *p ? hipSuccess : hipErrorInvalidValue;
 }
 hipError_t hipFree(void* p) {
