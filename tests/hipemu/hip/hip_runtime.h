@@ -93,6 +93,7 @@ typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 constexpr hipError_t hipErrorNotReady = 600;
 constexpr hipError_t hipErrorInvalidValue = 1;
+constexpr hipError_t hipErrorStreamCaptureUnsupported = 900;
 struct hipemu_stream;
 struct hipemu_event;
 struct hipemu_graph;

@@ -367,6 +367,15 @@ hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
   *v = 4;  // "compute units": keeps the persistent kernels' grids small
   return hipSuccess;
 }
+// Stream capture (the product captures with hipStreamCaptureModeThreadLocal): while THIS thread captures, the calls the real
+// runtime refuses - allocation, synchronous copies / memsets, device-wide and capturing-stream synchronisation - fail here
+// too, with a message, instead of silently working (which they would: everything is synchronous on the harness)
+static thread_local int t_captures = 0;
+static bool refused_during_capture(const char* what) {
+  if (t_captures == 0) return false;
+  std::fprintf(stderr, "hipemu: %s while this thread captures a stream (hipErrorStreamCaptureUnsupported)\n", what);
+  return true;
+}
 // HIPEMU_POISON=1: fresh device memory is filled with 0xff (NaN as float / double, -1 as int) instead of whatever the host
 // allocator returns (zero pages for large buffers): a kernel that consumes memory nobody wrote shows up in the results
 static bool poison_fresh_memory() {
@@ -380,6 +389,7 @@ extern "C" void __asan_poison_memory_region(void const volatile* addr, size_t si
 static std::mutex g_alloc_mutex;
 static std::unordered_map<void*, std::pair<size_t, size_t>> g_alloc_sizes;
 hipError_t hipMalloc(void** p, size_t n) {
+  if (refused_during_capture("hipMalloc")) return hipErrorStreamCaptureUnsupported;
   const size_t rounded = (std::max<size_t>(n, 1) + 255) / 256 * 256;
   *p = std::aligned_alloc(256, rounded);
   if (!*p) return hipErrorInvalidValue;
@@ -390,6 +400,7 @@ hipError_t hipMalloc(void** p, size_t n) {
   return hipSuccess;
 }
 hipError_t hipFree(void* p) {
+  if (refused_during_capture("hipFree")) return hipErrorStreamCaptureUnsupported;
   if (p) {
     std::lock_guard<std::mutex> lk(g_alloc_mutex);
     auto it = g_alloc_sizes.find(p);
@@ -403,11 +414,13 @@ hipError_t hipFree(void* p) {
 }
 #else
 hipError_t hipMalloc(void** p, size_t n) {
+  if (refused_during_capture("hipMalloc")) return hipErrorStreamCaptureUnsupported;
   *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256);
   if (*p && poison_fresh_memory()) std::memset(*p, 0xff, (n + 255) / 256 * 256 + 256);
   return *p ? hipSuccess : hipErrorInvalidValue;
 }
 hipError_t hipFree(void* p) {
+  if (refused_during_capture("hipFree")) return hipErrorStreamCaptureUnsupported;
   std::free(p);
   return hipSuccess;
 }
@@ -426,6 +439,7 @@ hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k,
   return hipSuccess;
 }
 hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) {
+  if (refused_during_capture("hipMemcpy")) return hipErrorStreamCaptureUnsupported;
   std::memmove(dst, src, n);
   return hipSuccess;
 }
@@ -438,6 +452,7 @@ hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t s) {
   return hipSuccess;
 }
 hipError_t hipMemset(void* dst, int v, size_t n) {
+  if (refused_during_capture("hipMemset")) return hipErrorStreamCaptureUnsupported;
   std::memset(dst, v, n);
   return hipSuccess;
 }
@@ -450,10 +465,19 @@ hipError_t hipStreamDestroy(hipStream_t s) {
   delete s;
   return hipSuccess;
 }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) {
+  if (S(s)->capturing && refused_during_capture("hipStreamSynchronize on the capturing stream")) return hipErrorStreamCaptureUnsupported;
+  return hipSuccess;
+}
+hipError_t hipStreamQuery(hipStream_t s) {
+  if (S(s)->capturing && refused_during_capture("hipStreamQuery on the capturing stream")) return hipErrorStreamCaptureUnsupported;
+  return hipSuccess;
+}
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipDeviceSynchronize() {
+  if (refused_during_capture("hipDeviceSynchronize")) return hipErrorStreamCaptureUnsupported;
+  return hipSuccess;
+}
 hipError_t hipEventCreate(hipEvent_t* e) {
   *e = new hipemu_event();
   (*e)->t = std::chrono::steady_clock::now();
@@ -479,11 +503,13 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 }
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
   S(s)->capturing = new hipemu_graph();
+  ++t_captures;
   return hipSuccess;
 }
 hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) {
   *g = S(s)->capturing;
   S(s)->capturing = nullptr;
+  if (t_captures > 0) --t_captures;
   return hipSuccess;
 }
 hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) {
