@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU call of the next round (run through gpurun from the repository root, e.g.
-#   gpurun --timeout 1500 -- 'bash scripts/run_round3_first_call.sh'):
+#   gpurun --timeout 2400 -- 'bash scripts/run_round3_first_call.sh'):
 # the GPU tests that were written in round 2 without a GPU (validated on tests/hipemu only), the two default-off
 # stage-2 candidates measured against the default, the camera-block microbenchmark, one bench line.
 set -x
