@@ -79,9 +79,11 @@ struct Params {
   // onto one 64 KB vector are not what bounds the kernel.
   int y_rep;
   int64_t y_rep_stride;
-  S* W8;         // [n_obs][8] compact stage-2 record (kernels_s1.hpp: k_s2_w8): W' (3x2, row-major) | g (2) with
-                 //            damped Q1^T Jp D = W' (Jp D) per observation and b record = (Jp D)^T g; JpS stays UNSCALED
-  int compact;   // 1: stage 2 writes W8 only; D (pose_scaling) is applied where a camera index is at hand
+  S* WA;         // [n_obs][8] stage-2 record of the camera-major pass (kernels_cam.hpp): [g 2 | A 2x2 | 0 0] with the
+                 //            observation's part of b = (Jp D)^T g and of the diagonal block = (A Jp D)^T (A Jp D); JpS stays UNSCALED
+  S* W8;             // [n_obs - w8_begin][8] the eight stage-2 coefficients W' (3x2, row-major) | g (2) themselves, kept only
+  int64_t w8_begin;  //   for the observations the two-kernel back-substitution handles (landmarks with k > 32): topd x = W' (Jp D x)
+  int compact;   // 1: stage 2 writes WA only; D (pose_scaling) is applied where a camera index is at hand
   S* lm_inc;     // mixed precision (RBA_MIXED): the back-substitution stores the scaled landmark increments here
                  // [3 n_lms] instead of adding them to `lms`; they are applied to the double master state
   int hx_debug;  // RBA_HX_DEBUG (profiling only, results are wrong): 1 = no scatter, 2 = loads only
@@ -608,393 +610,6 @@ __global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
   }
   if (tid >= 243 && tid < 252)
     p.b[9 * c + (tid - 243)] = S((p.b_from_records ? 0.0 : double(p.b_mid[9 * c + (tid - 243)])) + acc);
-}
-
-// ---------------------------------------------------------------------------
-// Compact stage 2 (p.compact): the landmark side hands over EIGHT scalars per observation (W8: the 3x2 map W'
-// and the 2-vector g, kernels_s1.hpp) instead of the 27 + 9 of the stage-2 record, and the Jacobian rows are
-// never rewritten in scaled form. This camera-major pass gathers the unscaled rows (72 B) and W8 (32 B), forms
-// X = W' Jp (3 x 9) in registers and accumulates
-//   T_c = sum X^T X,   t_c = sum Jp^T g        (no camera scaling yet)
-//   blocks[c] = B_mid[c] - D T_c D + lambda I,  b[c] = D t_c           (B_mid = D G D from stage 1)
-// float: X^T X on the matrix cores, both records of 32 observations staged in LDS per wave.
-// ---------------------------------------------------------------------------
-// GRAM: the first stage 2 of a linearisation point on one GPU also forms G_c = sum Jp^T Jp from the same staged rows
-// (the stage-1 Gram pass is then skipped - one gather of the Jacobian rows instead of two): Jp_diag2, the pose scaling
-// D = 1 / (eps + sqrt(Jp_diag2)) and B_mid = D G D are written here, before blocks / b use them.
-// (`GRAM` is a run-time flag, not a template parameter: one instruction stream for the shared part, so the fused and
-//  the two-pass form produce bit-identical blocks and b.)
-__global__ __launch_bounds__(256) void k_cam_stage2_w8_mfma(Params<float> p, float lambda, int GRAM) {
-  constexpr int RW = 26;  // staged record: [Jp 18 | W' 6 | g 2]
-  __shared__ float tile[4][16][16];
-  __shared__ double bsum[4][7][9];
-  __shared__ double dsum[4][7][9];
-  __shared__ float dsc[9];
-  __shared__ __attribute__((aligned(16))) float stage[4][kCamChunk * RW + 6];
-  const int c = xcd_swizzled_camera(p.n_cams);
-  if (c >= p.n_cams) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accG = {0.f, 0.f, 0.f, 0.f};
-  const bool want_gram = !p.jacobi || p.want_sdiag;
-  const int i = lane & 15, kk = lane >> 4;
-  const int g = lane / 9, a = lane - 9 * g;
-  double accb = 0, accd = 0;
-  float* lds = stage[wave];
-  for (int64_t base = t0 + kCamChunk * wave; base < t1; base += 4 * kCamChunk) {
-    const int cnt = int(min<int64_t>(kCamChunk, t1 - base));
-    const int idxreg = lane < cnt ? p.cam_obs[base + lane] : 0;
-    // Jacobian rows: nine 8-byte pieces per record; W8: two 16-byte pieces (kept at 8-byte granularity in LDS:
-    // the 26-float record stride is not a multiple of 16 bytes)
-#pragma unroll
-    for (int j = 0; j < (kCamChunk * 9 + 63) / 64; ++j) {
-      const int q = j * 64 + lane;
-      const int r = q / 9, pc = q - 9 * r;
-      const int o = __shfl(idxreg, r & 31);
-      if (q < cnt * 9)
-        *reinterpret_cast<float2*>(lds + r * RW + 2 * pc) = *reinterpret_cast<const float2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
-    }
-    {
-      const int r = lane >> 1, h = lane & 1;
-      const int o = __shfl(idxreg, r & 31);
-      if (r < cnt) {
-        const float4 w = *reinterpret_cast<const float4*>(p.W8 + int64_t(o) * 8 + 4 * h);
-        float* d = lds + r * RW + 18 + 4 * h;
-        *reinterpret_cast<float2*>(d) = float2{w.x, w.y};
-        *reinterpret_cast<float2*>(d + 2) = float2{w.z, w.w};
-      }
-    }
-    wave_lds_fence();
-    if (want_gram) {
-      for (int s = 0; s < cnt; ++s) {
-        const float* rec = lds + s * RW;
-        float v = 0.f;
-        // (explicit fma / rounding in this kernel: both instantiations and the two-pass form must agree bit for bit)
-        if (i < 9 && kk < 3) v = fmaf(rec[18 + 2 * kk], rec[i], __fmul_rn(rec[19 + 2 * kk], rec[9 + i]));
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, acc, 0, 0, 0);
-      }
-    }
-    if (GRAM) {
-      for (int s = 0; s < cnt; s += 2) {  // two observations (4 rows) per instruction
-        const int so = s + (kk >> 1);
-        const float v = (i < 9 && so < cnt) ? lds[so * RW + 9 * (kk & 1) + i] : 0.f;
-        accG = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, accG, 0, 0, 0);
-      }
-    }
-    if (lane < 63)
-      for (int r = g; r < cnt; r += 7) {
-        const float* rec = lds + r * RW;
-        accb += double(fmaf(rec[a], rec[24], __fmul_rn(rec[9 + a], rec[25])));
-        if (GRAM) accd += double(fmaf(rec[a], rec[a], __fmul_rn(rec[9 + a], rec[9 + a])));
-      }
-    wave_lds_fence();  // the next chunk overwrites the staging buffer
-  }
-  if (lane < 63) {
-    bsum[wave][g][a] = accb;
-    if (GRAM) dsum[wave][g][a] = accd;
-  }
-  if (GRAM) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = accG[r];
-  }
-  __syncthreads();
-  float gsum = 0.f;
-  if (GRAM) {
-    if (tid < 81) {
-      const int ii = tid / 9, jj = tid - 9 * ii;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) gsum += tile[w][ii][jj];
-    }
-    if (tid >= 128 && tid < 137) {
-      const int aa = tid - 128;
-      double sum = 0;
-      for (int w = 0; w < 4; ++w)
-        for (int gg = 0; gg < 7; ++gg) sum += dsum[w][gg][aa];
-      const float d2 = float(sum);
-      p.jp_diag2[9 * c + aa] = d2;
-      const float sc = 1.f / (p.eps + sqrtf(d2));  // k_pose_scaling
-      p.pose_scaling[9 * c + aa] = sc;
-      dsc[aa] = sc;
-    }
-    __syncthreads();
-  } else if (tid < 9) {
-    dsc[tid] = p.pose_scaling[9 * c + tid];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-  __syncthreads();
-  if (tid < 81) {
-    const int ii = tid / 9, jj = tid - 9 * ii;
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) t += tile[w][ii][jj];
-    const float dd = dsc[ii] * dsc[jj];
-    t = __fmul_rn(t, dd);
-    float bm;
-    if (GRAM) {
-      bm = __fmul_rn(gsum, dd);  // k_scale_gram (own rounding: no contraction with the subtraction below, so the
-                                 // result is bit-identical to the two-pass form)
-      p.B_mid[81 * c + tid] = bm;
-    } else {
-      bm = p.B_mid[81 * c + tid];
-    }
-    const float bt = __fsub_rn(bm, t);
-    p.blocks[81 * c + tid] = (p.jacobi ? bm : bt) + (ii == jj ? lambda : 0.f);
-    if (p.want_sdiag) p.sdiag[81 * c + tid] = bt;
-  }
-  if (tid >= 128 && tid < 137) {
-    const int aa = tid - 128;
-    double sum = 0.0;
-    for (int w = 0; w < 4; ++w)
-      for (int gg = 0; gg < 7; ++gg) sum += bsum[w][gg][aa];
-    p.b[9 * c + aa] = float(sum * double(dsc[aa]));
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Camera-BLOCK form of the compact stage-2 camera pass (RBA_CAM_BLOCKS=1; written in round 2 after the GPU budget was
-// spent: correct on the CPU execution harness of tests/hipemu and in scripts/microbench/cam_block_pass.hip (variant 3)
-// against a double reference, NOT YET TIMED, therefore off by default).
-// Why: k_cam_stage2_w8_mfma gathers a 72-byte row and a 32-byte W8 record per observation out of landmark-major
-// storage; FETCH_SIZE says it moves 2.35 x the bytes it needs, and the same gather over the MERGED, address-sorted
-// observation lists of 8 consecutive cameras runs 1.8 x faster (profiles/r2b_microbench_cam_gather.txt) because the
-// records of a landmark seen by several cameras of the block arrive as one contiguous piece.
-// How: the merged list of a block is cut into one segment per camera of the block (as many workgroups as cameras);
-// a wave stages 32 records, then walks the block's cameras in a STATIC loop - the ballot of the chunk's records that
-// belong to camera n selects the records whose matrix-core instructions go into accT[n] / accG[n] (statically
-// indexed accumulators: no switch, no dynamic register indexing, 76 VGPRs). The row g of W8 rides along as a tenth
-// operand row of the G instruction, which therefore also accumulates t = sum Jp^T g (column 9 of the tile); Jp_diag2 is
-// the diagonal of G. Float accumulation throughout (the reference reduces these sums in Scalar as well); the double
-// side sums of the per-camera kernel are gone. Every segment writes partial sums per camera of its block,
-// k_cam_block_finish adds a camera's partials in a fixed order (deterministic) and writes what
-// k_cam_stage2_w8_mfma writes: [Jp_diag2, pose scaling, B_mid when GRAM], blocks, sdiag, b.
-// List entry: observation index | (camera - first camera of the block) << 28.
-// ---------------------------------------------------------------------------
-constexpr int kCbCams = 8;      // cameras per block
-constexpr int kCbPart = 171;    // floats per (segment, camera): T 81 | G 81 | t 9
-__global__ __launch_bounds__(256) void k_cam_block_accumulate(Params<float> p, const int* __restrict__ list,
-                                                              const int64_t* __restrict__ seg_off,
-                                                              float* __restrict__ part, int n_seg) {
-  constexpr int RW = 26, B = kCbCams;
-  __shared__ __attribute__((aligned(16))) float stage[4][kCamChunk * RW + 6];
-  __shared__ float tile[4][2][16][16];
-  const int sg = xcd_swizzled_camera(n_seg);  // XCD-contiguous segments
-  if (sg >= n_seg) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int i = lane & 15, kk = lane >> 4;
-  const int64_t t0 = seg_off[sg], t1 = seg_off[sg + 1];
-  float* lds = stage[wave];
-  f32x4 accT[B], accG[B];
-#pragma unroll
-  for (int c = 0; c < B; ++c) {
-    accT[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    accG[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  for (int64_t base = t0 + kCamChunk * wave; base < t1; base += 4 * kCamChunk) {
-    const int cnt = int(min<int64_t>(kCamChunk, t1 - base));
-    const int e = lane < cnt ? list[base + lane] : 0;
-    const int idx = e & ((1 << 28) - 1);
-    const int myc = lane < cnt ? (e >> 28) : -1;
-#pragma unroll
-    for (int j = 0; j < (kCamChunk * 9 + 63) / 64; ++j) {
-      const int q = j * 64 + lane, r = q / 9, pc = q - 9 * r;
-      const int o = __shfl(idx, r & 31);
-      if (q < cnt * 9)
-        *reinterpret_cast<float2*>(lds + r * RW + 2 * pc) = *reinterpret_cast<const float2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
-    }
-    {
-      const int r = lane >> 1, h = lane & 1;
-      const int o = __shfl(idx, r & 31);
-      if (r < cnt) {
-        const float4 w = *reinterpret_cast<const float4*>(p.W8 + int64_t(o) * 8 + 4 * h);
-        float* d = lds + r * RW + 18 + 4 * h;
-        *reinterpret_cast<float2*>(d) = float2{w.x, w.y};
-        *reinterpret_cast<float2*>(d + 2) = float2{w.z, w.w};
-      }
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int n = 0; n < B; ++n) {
-      const unsigned long long m = __ballot(myc == n);
-      for (unsigned long long mm = m; mm;) {  // T: one record per instruction (operand rows 0..2 = X = W' Jp)
-        const int s = __builtin_ctzll(mm);
-        mm &= mm - 1;
-        const float* rec = lds + s * RW;
-        float vT = 0.f;
-        if (i < 9 && kk < 3) vT = fmaf(rec[18 + 2 * kk], rec[i], __fmul_rn(rec[19 + 2 * kk], rec[9 + i]));
-        accT[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vT, vT, accT[n], 0, 0, 0);
-      }
-      for (unsigned long long mm = m; mm;) {  // G (+ t in column 9): two records per instruction
-        const int s0 = __builtin_ctzll(mm);
-        mm &= mm - 1;
-        int s1 = -1;
-        if (mm) {
-          s1 = __builtin_ctzll(mm);
-          mm &= mm - 1;
-        }
-        const int so = (kk >> 1) ? s1 : s0;
-        float vG = 0.f;
-        if (so >= 0 && i < 10) vG = i < 9 ? lds[so * RW + 9 * (kk & 1) + i] : lds[so * RW + 24 + (kk & 1)];
-        accG[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vG, vG, accG[n], 0, 0, 0);
-      }
-    }
-    wave_lds_fence();  // the next chunk overwrites the staging buffer
-  }
-  // per camera of the block: the four waves' sums, one partial per (segment, camera)
-#pragma unroll
-  for (int c = 0; c < B; ++c) {
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      tile[wave][0][(lane >> 4) * 4 + r][lane & 15] = accT[c][r];
-      tile[wave][1][(lane >> 4) * 4 + r][lane & 15] = accG[c][r];
-    }
-    __syncthreads();
-    float* out = part + (size_t(sg) * B + c) * kCbPart;
-    if (tid < 162) {
-      const int m = tid / 81, e = tid - 81 * m, ii = e / 9, jj = e - 9 * ii;
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) v += tile[w][m][ii][jj];
-      out[tid] = v;
-    }
-    if (tid >= 192 && tid < 192 + 9) {
-      const int aa = tid - 192;
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) v += tile[w][1][aa][9];  // t = column 9 of the G tile
-      out[162 + aa] = v;
-    }
-  }
-}
-
-// per camera: its block's segments' partials in a fixed order -> the outputs of k_cam_stage2_w8_mfma
-__global__ __launch_bounds__(128) void k_cam_block_finish(Params<float> p, const float* __restrict__ part,
-                                                          const int* __restrict__ seg_first, const int* __restrict__ seg_count,
-                                                          float lambda, int GRAM) {
-  __shared__ float dsc[9];
-  const int c = blockIdx.x, tid = threadIdx.x;
-  const int blk = c / kCbCams, cl = c - kCbCams * blk;
-  const int s0 = seg_first[blk], ns = seg_count[blk];
-  float t = 0.f, gsum = 0.f;
-  if (tid < 81)
-    for (int s = 0; s < ns; ++s) {
-      const float* pf = part + (size_t(s0 + s) * kCbCams + cl) * kCbPart;
-      t += pf[tid];
-      gsum += pf[81 + tid];
-    }
-  double bt = 0.0;
-  if (tid >= 96 && tid < 105) {
-    const int aa = tid - 96;
-    double d2 = 0.0;
-    for (int s = 0; s < ns; ++s) {
-      const float* pf = part + (size_t(s0 + s) * kCbCams + cl) * kCbPart;
-      bt += double(pf[162 + aa]);
-      d2 += double(pf[81 + 10 * aa]);
-    }
-    if (GRAM) {
-      const float d2f = float(d2);
-      p.jp_diag2[9 * c + aa] = d2f;
-      const float sc = 1.f / (p.eps + sqrtf(d2f));  // k_pose_scaling
-      p.pose_scaling[9 * c + aa] = sc;
-      dsc[aa] = sc;
-    } else {
-      dsc[aa] = p.pose_scaling[9 * c + aa];
-    }
-  }
-  __syncthreads();
-  if (tid < 81) {
-    const int ii = tid / 9, jj = tid - 9 * ii;
-    const float dd = dsc[ii] * dsc[jj];
-    float bm;
-    if (GRAM) {
-      bm = __fmul_rn(gsum, dd);
-      p.B_mid[81 * c + tid] = bm;
-    } else {
-      bm = p.B_mid[81 * c + tid];
-    }
-    const float bt2 = __fsub_rn(bm, __fmul_rn(t, dd));
-    p.blocks[81 * c + tid] = (p.jacobi ? bm : bt2) + (ii == jj ? lambda : 0.f);
-    if (p.want_sdiag) p.sdiag[81 * c + tid] = bt2;
-  }
-  if (tid >= 96 && tid < 105) p.b[9 * c + (tid - 96)] = float(bt * double(dsc[tid - 96]));
-}
-
-// generic (double): records staged per workgroup, double accumulators
-template <class S>
-__global__ __launch_bounds__(256) void k_cam_stage2_w8(Params<S> p, S lambda, int GRAM) {
-  constexpr int TILE = 64, RW = 26;
-  __shared__ S rec[TILE][RW];
-  __shared__ int olist[TILE];
-  __shared__ double red[3][81], redG[3][81];
-  __shared__ double dsc[9];
-  const int c = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
-  double acc = 0, accG = 0;
-  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  for (int64_t base = t0; base < t1; base += TILE) {
-    const int n = int(min<int64_t>(TILE, t1 - base));
-    __syncthreads();
-    if (tid < n) olist[tid] = p.cam_obs[base + tid];
-    __syncthreads();
-    for (int idx = tid; idx < n * RW; idx += 256) {
-      const int q = idx / RW, f = idx - RW * q;
-      rec[q][f] = f < 18 ? p.JpS[int64_t(olist[q]) * 18 + f] : p.W8[int64_t(olist[q]) * 8 + (f - 18)];
-    }
-    __syncthreads();
-    if (grp < 3) {
-      for (int q = grp; q < n; q += 3) {
-        const S* r = rec[q];
-        if (!p.jacobi || p.want_sdiag) {
-          S t = S(0);
-#pragma unroll
-          for (int m = 0; m < 3; ++m)
-            t += (r[18 + 2 * m] * r[ea] + r[19 + 2 * m] * r[9 + ea]) * (r[18 + 2 * m] * r[eb] + r[19 + 2 * m] * r[9 + eb]);
-          acc -= double(t);
-        }
-        if (GRAM) accG += double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb]);
-      }
-    } else if (tid < 252) {
-      const int a = tid - 243;
-      for (int q = 0; q < n; ++q) acc += double(rec[q][a] * rec[q][24] + rec[q][9 + a] * rec[q][25]);
-    }
-  }
-  if (grp < 3) {
-    red[grp][e] = acc;
-    if (GRAM) redG[grp][e] = accG;
-  }
-  __syncthreads();
-  double gsum = 0;
-  if (GRAM) {
-    if (tid < 81) {
-      gsum = redG[0][tid] + redG[1][tid] + redG[2][tid];
-      if (tid / 9 == tid % 9) {
-        const S d2 = S(gsum);
-        p.jp_diag2[9 * c + tid / 9] = d2;
-        const S sc = S(1) / (p.eps + sqrt(d2));
-        p.pose_scaling[9 * c + tid / 9] = sc;
-        dsc[tid / 9] = double(sc);
-      }
-    }
-  } else if (tid < 9) {
-    dsc[tid] = double(p.pose_scaling[9 * c + tid]);
-  }
-  __syncthreads();
-  if (tid < 81) {
-    const double dd = dsc[tid / 9] * dsc[tid % 9];
-    const double gram = (red[0][tid] + red[1][tid] + red[2][tid]) * dd;  // = - D (sum X^T X) D
-    double bm;
-    if (GRAM) {
-      bm = double(S(gsum) * S(dd));  // as k_scale_gram applied to the stored Gram block
-      p.B_mid[81 * c + tid] = S(bm);
-    } else {
-      bm = double(p.B_mid[81 * c + tid]);
-    }
-    p.blocks[81 * c + tid] = S(bm + (p.jacobi ? 0.0 : gram) + ((tid / 9 == tid % 9) ? double(lambda) : 0.0));
-    if (p.want_sdiag) p.sdiag[81 * c + tid] = S(bm + gram);
-  }
-  if (tid >= 243 && tid < 252) p.b[9 * c + (tid - 243)] = S(acc * dsc[tid - 243]);
 }
 
 // pose_jacobian_scaling = 1 / (eps + sqrt(Jp_diag2))   (linearizor_qr.cpp:130-132)
@@ -2403,7 +2018,7 @@ __global__ __launch_bounds__(256) void k_bs_obs(Params<S> p, const S* __restrict
       out[3] += jp[c] * xv[c];
       out[4] += jp[9 + c] * xv[c];
     }
-    const S* __restrict__ w = p.W8 + 8 * o;
+    const S* __restrict__ w = p.W8 + 8 * (o - p.w8_begin);
     out[0] = w[0] * out[3] + w[1] * out[4];
     out[1] = w[2] * out[3] + w[3] * out[4];
     out[2] = w[4] * out[3] + w[5] * out[4];

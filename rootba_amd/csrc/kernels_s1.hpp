@@ -36,6 +36,7 @@
 #pragma once
 
 #include "kernels.hpp"
+#include "kernels_cam.hpp"
 
 namespace rba {
 
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256) void k_s1_geometry(Params<S> p, int64_t n_obs)
       sw = sqrt(w);
     }
 #pragma unroll
-    for (int c = 0; c < 18; ++c) sj[18 * tid + c] = sw * Jp[c];
+    for (int c = 0; c < 18; ++c) Jp[c] *= sw;
+#pragma unroll
+    for (int c = 0; c < 18; ++c) sj[18 * tid + c] = Jp[c];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       sv[8 * tid + 4 * r + 0] = sw * Jl[3 * r + 0];
@@ -665,9 +668,12 @@ __global__ __launch_bounds__(256) void k_s2_w8(Params<S> p, int64_t n_obs) {
     out[e][2] = tt[2];
     out[e][3] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
   }
-  V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * o);
-  dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};
-  dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
+  store_cam_record_stage2<S>(p, o, out);
+  if (o >= p.w8_begin) {  // landmarks with k > 32: the two-kernel back-substitution applies W' itself
+    V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * (o - p.w8_begin));
+    dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};
+    dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
+  }
 }
 
 // k_stage2_landmark + k_s2_w8 in ONE pass (RBA_S2_FUSED_LM=1; written in round 2 after the GPU budget was spent,
@@ -827,9 +833,12 @@ __global__ __launch_bounds__(256) void k_s2_w8_fused(Params<S> p, int64_t n_obs,
     out[e][2] = tt[2];
     out[e][3] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
   }
-  V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * o);
-  dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};
-  dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
+  store_cam_record_stage2<S>(p, o, out);
+  if (o >= p.w8_begin) {  // landmarks with k > 32: the two-kernel back-substitution applies W' itself
+    V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * (o - p.w8_begin));
+    dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};
+    dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
+  }
 }
 
 // b_mid[c] = sum over the camera's observations of bmO (fixed order, double)

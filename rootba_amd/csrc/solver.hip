@@ -24,6 +24,7 @@
 #include "../../include/rootba_hip.h"
 #include "kernels.hpp"
 #include "kernels_big.hpp"
+#include "kernels_cam.hpp"
 #include "kernels_s1.hpp"
 #include "kernels_sc.hpp"
 #include "kernels_pcg.hpp"
@@ -205,13 +206,13 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_Y_REPLICAS")) y_rep_ = std::max(1, std::min(64, std::atoi(ev)));
     if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
     if (const char* ev = std::getenv("RBA_HX_LDS")) hx_lds_ = std::atoi(ev);
+    // the LDS-private product in double needs 156 VGPRs: 512-thread workgroups (no scratch; measured 254 vs 428 us on venice)
+    hx_threads_ = sizeof(S) == 8 ? 512 : 1024;
     if (const char* ev = std::getenv("RBA_HX_THREADS")) hx_threads_ = std::atoi(ev) == 512 ? 512 : 1024;
     compact_ = staged_;  // compact stage-2 records (W8) + unscaled Jacobian rows; RBA_S2_COMPACT=0: round-2a records
     if (const char* ev = std::getenv("RBA_S2_COMPACT")) compact_ = staged_ && std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_FUSED_GRAM")) fused_gram_ = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("RBA_S2_FUSED_LM")) s2_fused_lm_ = std::atoi(ev) != 0;
-    if (const char* ev = std::getenv("RBA_CAM_BLOCKS"))
-      cam_blocks_ = std::atoi(ev) != 0 && std::is_same<S, float>::value && compact_;
     if (compact_) y_rep_ = 1;  // (the replica experiment post-processes y itself)
     {
       int dev = 0, cus = 0;
@@ -318,34 +319,6 @@ class Solver final : public rba_solver {
     {
       std::vector<int64_t> cur(cam_off.begin(), cam_off.end() - 1);
       for (int64_t q = 0; q < n_obs_; ++q) cam_obs[cur[s_obs_cam[q]]++] = int(q);
-    }
-    // RBA_CAM_BLOCKS=1 (float, compact stage 2): merged, address-sorted observation lists of blocks of 8 consecutive
-    // cameras, cut into one segment per camera of the block (kernels.hpp: k_cam_block_accumulate)
-    std::vector<int> cb_list, cb_seg_first, cb_seg_count;
-    std::vector<int64_t> cb_off;
-    if (cam_blocks_ && n_obs_ < (int64_t(1) << 28)) {
-      const int B = rba::kCbCams;
-      const int n_blocks = (n_cams + B - 1) / B;
-      cb_list.reserve(n_obs_);
-      cb_off.assign(1, 0);
-      cb_seg_first.resize(n_blocks);
-      cb_seg_count.resize(n_blocks);
-      std::vector<int> u;
-      for (int g = 0; g < n_blocks; ++g) {
-        const int c0 = g * B, nb = std::min(n_cams, c0 + B) - c0;
-        u.clear();
-        for (int64_t q = cam_off[c0]; q < cam_off[c0 + nb]; ++q) u.push_back(cam_obs[q]);
-        std::sort(u.begin(), u.end());  // observation index = storage address order
-        cb_seg_first[g] = int(cb_off.size()) - 1;
-        cb_seg_count[g] = nb;
-        for (int sgm = 0; sgm < nb; ++sgm) {
-          const size_t a = u.size() * sgm / nb, b = u.size() * (sgm + 1) / nb;
-          for (size_t q = a; q < b; ++q) cb_list.push_back(u[q] | ((s_obs_cam[u[q]] - c0) << 28));
-          cb_off.push_back(int64_t(cb_list.size()));
-        }
-      }
-    } else {
-      cam_blocks_ = false;
     }
     hx_bytes_ += 4 * n_obs_ + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
     hx_implicit_bytes_ += 4 * n_obs_ + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
@@ -548,18 +521,6 @@ class Solver final : public rba_solver {
     d_cam_obs_.alloc(n_obs_);
     d_cam_off_.upload(cam_off.data(), n_cams + 1, stream_);
     d_cam_obs_.upload(cam_obs.data(), n_obs_, stream_);
-    if (cam_blocks_) {
-      cb_n_seg_ = int(cb_off.size()) - 1;
-      d_cb_list_.alloc(cb_list.size());
-      d_cb_off_.alloc(cb_off.size());
-      d_cb_seg_first_.alloc(cb_seg_first.size());
-      d_cb_seg_count_.alloc(cb_seg_count.size());
-      d_cb_part_.alloc(size_t(cb_n_seg_) * rba::kCbCams * rba::kCbPart);
-      d_cb_list_.upload(cb_list.data(), cb_list.size(), stream_);
-      d_cb_off_.upload(cb_off.data(), cb_off.size(), stream_);
-      d_cb_seg_first_.upload(cb_seg_first.data(), cb_seg_first.size(), stream_);
-      d_cb_seg_count_.upload(cb_seg_count.data(), cb_seg_count.size(), stream_);
-    }
     d_cams_.alloc(10 * size_t(n_cams));
     d_lms_.alloc(3 * size_t(n_lms));
     d_cams_bak_.alloc(10 * size_t(n_cams));
@@ -727,10 +688,14 @@ class Solver final : public rba_solver {
     prm_.lms = d_lms_.get();
     prm_.lm_inc = mixed_ ? d_lm_inc_.get() : nullptr;
     if (compact_) {
-      d_W8_.alloc(size_t(8) * n_obs_);
+      // the eight stage-2 coefficients themselves: only for the observations of the two-kernel back-substitution
+      prm_.w8_begin = (n_tiles_ > 0 && !bs_two_pass_) ? n_obs_tiled_ : 0;
+      d_W8_.alloc(size_t(8) * (n_obs_ - prm_.w8_begin));
+      d_WA_.alloc(size_t(rba::kRecW) * n_obs_);
       d_xs_.alloc(nvec_);
     }
     prm_.W8 = d_W8_.get();
+    prm_.WA = d_WA_.get();
     prm_.compact = compact_ ? 1 : 0;
     prm_.A = d_A_.get();
     prm_.top0 = d_top0_.get();
@@ -1597,29 +1562,30 @@ class Solver final : public rba_solver {
   void launch_cam_stage1(const rba::Params<double>& prm) {
     hipLaunchKernelGGL((rba::k_cam_stage1<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
   }
+  // (kernels_cam.hpp; the SC backend keeps the round-2 Gram kernels on its own scaled rows)
   void launch_cam_gram(const rba::Params<float>& prm) {
-    hipLaunchKernelGGL((rba::k_cam_gram_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm);
+    if (compact_)
+      hipLaunchKernelGGL((rba::k_cam_pass_mfma<1>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm, 0.f, 0);
+    else
+      hipLaunchKernelGGL((rba::k_cam_gram_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm);
   }
   void launch_cam_gram(const rba::Params<double>& prm) {
-    hipLaunchKernelGGL((rba::k_cam_gram<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
+    if (compact_)
+      hipLaunchKernelGGL((rba::k_cam_pass<double, 1>), dim3(n_cams_), dim3(256), 0, stream_, prm, 0.0, 0);
+    else
+      hipLaunchKernelGGL((rba::k_cam_gram<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
   }
   void launch_cam_stage2(const rba::Params<float>& prm, float lambda) {
-    if (compact_ && cam_blocks_) {
-      // RBA_CAM_BLOCKS=1: block-merged lists, static camera loop (kernels.hpp: k_cam_block_accumulate); not yet timed
-      hipLaunchKernelGGL((rba::k_cam_block_accumulate), dim3(rba::xcd_swizzled_grid(cb_n_seg_)), dim3(256), 0, stream_,
-                         prm, d_cb_list_.get(), d_cb_off_.get(), d_cb_part_.get(), cb_n_seg_);
-      hipLaunchKernelGGL((rba::k_cam_block_finish), dim3(n_cams_), dim3(128), 0, stream_, prm, d_cb_part_.get(),
-                         d_cb_seg_first_.get(), d_cb_seg_count_.get(), lambda, gram_pending_ ? 1 : 0);
-    } else if (compact_)
-      hipLaunchKernelGGL((rba::k_cam_stage2_w8_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_,
-                         prm, lambda, gram_pending_ ? 1 : 0);
+    if (compact_)
+      hipLaunchKernelGGL((rba::k_cam_pass_mfma<0>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
+                         lambda, gram_pending_ ? 1 : 0);
     else
       hipLaunchKernelGGL((rba::k_cam_stage2_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
                          lambda);
   }
   void launch_cam_stage2(const rba::Params<double>& prm, double lambda) {
     if (compact_)
-      hipLaunchKernelGGL((rba::k_cam_stage2_w8<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda,
+      hipLaunchKernelGGL((rba::k_cam_pass<double, 0>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda,
                          gram_pending_ ? 1 : 0);
     else
       hipLaunchKernelGGL((rba::k_cam_stage2<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
@@ -2580,12 +2546,9 @@ class Solver final : public rba_solver {
                               // (default 1: when it fits and every wave gets at least four tiles)
   bool operand_prescaled_ = false;
   bool fused_gram_ = true;     // RBA_FUSED_GRAM=0: always run the stage-1 Gram pass
-  bool cam_blocks_ = false;    // RBA_CAM_BLOCKS=1: camera-block stage-2 pass (k_cam_block_accumulate; not yet measured)
-  int cb_n_seg_ = 0;
-  DevBuf<int> d_cb_list_, d_cb_seg_first_, d_cb_seg_count_;
-  DevBuf<int64_t> d_cb_off_;
-  DevBuf<float> d_cb_part_;
-  bool s2_fused_lm_ = false;   // RBA_S2_FUSED_LM=1: landmark damping inside the W8 pass (k_s2_w8_fused; not yet measured)
+  DevBuf<S> d_WA_;             // stage-2 records of the camera-major pass (kernels_cam.hpp)
+  bool s2_fused_lm_ = true;    // landmark damping inside the per-observation pass of stage 2 (k_s2_w8_fused; measured on
+                               // venice: stage 2 0.443 -> 0.402 ms); RBA_S2_FUSED_LM=0: thread-per-landmark pass + k_s2_w8
   bool gram_pending_ = false;  // linearised without the Gram pass: the first stage 2's camera pass does it
   bool compact_ = false;     // stage 2 hands W8 (8 scalars per observation) to the camera pass, JpS stays unscaled
   bool topd_valid_ = false;  // compact: the 27 + 9 records exist for the current damping (assembly / E0 products only)

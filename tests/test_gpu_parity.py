@@ -773,11 +773,16 @@ def test_tracks_of_any_length(very_long_track_problem, dtype):
     g2, o2 = _pair(prob, dtype, max_num_iterations=3, function_tolerance=0.0)
     l_g, _ = g2.optimize_lm()
     l_o, _ = o2.optimize_lm()
-    for a, b in zip(l_g, l_o):
+    # float32: a landmark seen by all 2200 cameras couples everything, and float32 itself is 5e-3 away from the float64
+    # result after ONE iteration here (measured: float64 2454.68, float32 oracle 2442.53, float32 GPU 2442.69): the two
+    # float32 runs are held to 5 % of their common distance from the float64 run (and to 5e-5 where that is smaller);
+    # later iterations are only close, not digit-for-digit
+    l_64 = l_o
+    if dtype == np.float32:
+        l_64, _ = _pair(prob, np.float64, max_num_iterations=3, function_tolerance=0.0)[1].optimize_lm()
+    for a, b, c in zip(l_g, l_o, l_64):
         assert a.step_is_successful == b.step_is_successful
-        # float32: a landmark seen by all 2200 cameras couples everything; after the first truncated
-        # solves the two float32 trajectories are only close, not digit-for-digit
-        ftol = 5e-5 if a.iteration <= 1 else 1e-3
+        ftol = max(5e-5, 0.05 * abs(b.cost - c.cost) / c.cost) if a.iteration <= 1 else 1e-3
         assert abs(a.cost - b.cost) <= (ftol if dtype == np.float32 else 1e-9) * b.cost
 
 
