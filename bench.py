@@ -249,10 +249,9 @@ def main():
     ap.add_argument("--preconditioner", choices=sorted(PRECOND), default="SCHUR_JACOBI",
                     help="reference default: SCHUR_JACOBI")
     ap.add_argument("--power-order", type=int, default=10)
-    ap.add_argument("--dense-blocks", action="store_true",
-                    help="matrix-free products on the dense Q2^T Jp blocks (what the reference materialises) "
-                         "instead of the default evaluation from the QR factors (implicit-Q, SURVEY.md 8f #1)")
-    ap.add_argument("--implicit-q", action="store_true", help="(default since round 1; kept for old command lines)")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="repetitions of the whole measurement (warm-up + steps, from the same initial state): `value` "
+                         "is the MEDIAN repetition (SURVEY.md 8d: median of >= 3 runs), all of them are reported")
     ap.add_argument("--solver-type", choices=["SQUARE_ROOT", "SCHUR_COMPLEMENT"], default="SQUARE_ROOT",
                     help="SCHUR_COMPLEMENT: explicit reduced camera matrix + SpMV (SURVEY.md 8f #4), 1 GPU")
     ap.add_argument("--use-double", action="store_true", help="float64 (BASELINE metric is float32)")
@@ -268,9 +267,8 @@ def main():
     GPU_DTYPE = "mixed" if args.mixed else DTYPE
     if args.mixed and args.use_double:
         raise SystemExit("--mixed and --use-double exclude each other")
-    args.implicit_q = not args.dense_blocks
     _SOLVER_KW.update(preconditioner_type=PRECOND[args.preconditioner], power_order=args.power_order)
-    _GPU_KW.update(implicit_q=int(args.implicit_q), solver_type=int(args.solver_type == "SCHUR_COMPLEMENT"))
+    _GPU_KW.update(solver_type=int(args.solver_type == "SCHUR_COMPLEMENT"))
 
     import torch
     import torch.distributed as dist
@@ -353,34 +351,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    rows, hx_time, hx_calls = [], 0.0, 0
-    lin.lm_begin()
-    for _ in range(args.warmup):
-        row, more = lin.lm_step()
-        rows.append(row)
-        if not more:
-            raise SystemExit(f"the LM loop terminated during warm-up (iteration {row.iteration}): no valid measurement")
-    lin.synchronize()
-    comm0 = lin.comm_stats()
-    barrier()
-    t_start = time.perf_counter()
-    for s_ in range(args.steps):
-        row, more = lin.lm_step()
-        rows.append(row)
-        tm = lin.timings()
-        hx_time += tm.hx_time
-        hx_calls += tm.hx_calls
-        if not more and s_ + 1 < args.steps:
-            raise SystemExit(f"the LM loop terminated after {s_ + 1} of {args.steps} timed steps (iteration "
-                             f"{row.iteration}, lambda {row.lambda_:.2e}): refusing to count no-op steps")
-    lin.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    comm1 = lin.comm_stats()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    state0 = lin.get_state()
+
+    def measure():
+        """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides."""
+        rows, hx_time, hx_calls = [], 0.0, 0
+        lin.set_state(*state0)
+        lin.lm_begin()
+        for _ in range(args.warmup):
+            row, more = lin.lm_step()
+            rows.append(row)
+            if not more:
+                raise SystemExit(f"the LM loop terminated during warm-up (iteration {row.iteration}): no valid measurement")
+        lin.synchronize()
+        comm0, pcg0 = lin.comm_stats(), lin.pcg_counters()
+        barrier()
+        t_start = time.perf_counter()
+        for s_ in range(args.steps):
+            row, more = lin.lm_step()
+            rows.append(row)
+            tm = lin.timings()
+            hx_time += tm.hx_time
+            hx_calls += tm.hx_calls
+            if not more and s_ + 1 < args.steps:
+                raise SystemExit(f"the LM loop terminated after {s_ + 1} of {args.steps} timed steps (iteration "
+                                 f"{row.iteration}, lambda {row.lambda_:.2e}): refusing to count no-op steps")
+        lin.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        comm1, pcg1 = lin.comm_stats(), lin.pcg_counters()
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return dict(elapsed=elapsed, rows=rows, hx_time=hx_time, hx_calls=hx_calls, comm0=comm0, comm1=comm1,
+                    pcg={k: pcg1[k] - pcg0[k] for k in pcg1})
+
+    reps = [measure() for _ in range(max(1, args.repeats))]
+    order = sorted(range(len(reps)), key=lambda i: reps[i]["elapsed"])
+    med = reps[order[len(order) // 2]]  # the median repetition is the one reported in detail
+    elapsed, rows, hx_time, hx_calls = med["elapsed"], med["rows"], med["hx_time"], med["hx_calls"]
+    comm0, comm1, pcg_cnt = med["comm0"], med["comm1"], med["pcg"]
     lin.close()
 
     ref_sem = None
@@ -402,8 +413,7 @@ def main():
         if os.path.exists(tpath) and world == 1 and not sc:
             try:
                 with open(tpath) as f:
-                    key = args.workload + ("/implicit_q" if args.implicit_q else "")
-                    traffic = json.load(f).get(key, {}).get("traffic_bytes_per_launch")
+                    traffic = json.load(f).get(args.workload + "/implicit_q", {}).get("traffic_bytes_per_launch")
                 traffic_source = ("profiles/hx_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                   "scripts/run_pmc_traffic.sh on this kernel and workload; not measured in this run)")
             except Exception:
@@ -424,6 +434,11 @@ def main():
         n_err = sum(2 if r.stage1_time > 0 else 1 for r in timed)
         b_iter = (bytes_model["stage1"] * n_lin + bytes_model["stage2"] * n_t + bytes_model["back_substitution"] * n_t +
                   bytes_model["compute_error"] * n_err)
+        # the PCG phase priced with what it executed (rba_get_pcg_counters): products on either operator, assemblies
+        # of the reduced matrix, the vector / preconditioner work of every iteration
+        b_pcg = (pcg_cnt["products_matrix_free"] * bytes_model["product_matrix_free"] +
+                 pcg_cnt["products_assembled"] * bytes_model["product_assembled"] +
+                 pcg_cnt["assemblies"] * bytes_model["assembly"] + pcg_cnt["iterations"] * bytes_model["pcg_vectors"])
         stages = {
             "stage1": {"bytes_per_launch": bytes_model["stage1"], "ms": 1e3 * t_s1 / max(1, n_lin),
                        "frac": frac(bytes_model["stage1"] * n_lin, t_s1)},
@@ -433,7 +448,8 @@ def main():
                                   "frac": frac(bytes_model["back_substitution"] * n_t, t_bs)},
             "compute_error": {"bytes_per_launch": bytes_model["compute_error"], "ms": 1e3 * t_err / max(1, n_err),
                               "frac": frac(bytes_model["compute_error"] * n_err, t_err)},
-            "pcg": {"ms_per_step": 1e3 * t_pcg / n_t, "cg_iterations": n_cg,
+            "pcg": {"ms_per_step": 1e3 * t_pcg / n_t, "cg_iterations": n_cg, "frac": frac(b_pcg, t_pcg),
+                    "bytes_per_step": b_pcg / n_t, "executed": pcg_cnt,
                     "bytes_per_matrix_free_product": bytes_model["product_matrix_free"],
                     "bytes_per_assembled_product": bytes_model["product_assembled"],
                     "bytes_per_assembly": bytes_model["assembly"]},
@@ -442,6 +458,10 @@ def main():
             # BASELINE.json's metric string for the headline workload; other workloads are named as what they are
             "metric": "LM iterations/sec (linearize+QR+PCG+back-sub) on BAL " + args.workload.split("+")[0],
             "value": args.steps / elapsed,
+            "value_repeats": {"what": f"{len(reps)} repetitions of warm-up + steps from the same initial state on one "
+                                      "handle; `value` is the median repetition",
+                              "values": [args.steps / r["elapsed"] for r in reps],
+                              "spread_rel": (max(r["elapsed"] for r in reps) - min(r["elapsed"] for r in reps)) / elapsed},
             "unit": "LM iterations/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -476,9 +496,7 @@ def main():
                            "81 s + 4 per block + 2 x 9 n_c s)" if sc else
                            "k_hx_implicit_lds (+ k_hx_implicit_wide for 32 < k <= 112): H*x from the QR factors, workgroup-private "
                            "double y in LDS where 9 n_c doubles fit, else k_hx_implicit; algorithmic bytes = SURVEY.md 8d "
-                           "implicit-Q formula"
-                           if args.implicit_q else
-                           "k_hx (H*x = sum_l A_l^T A_l x, all k-classes of one right_multiply)"),
+                           "implicit-Q formula"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -490,11 +508,13 @@ def main():
                 "avg_launch_ms": avg_hx * 1e3 if avg_hx else None,
                 "launches_timed": hx_calls,
                 "whole_iteration": {
-                    "what": "sum over the stage kernels (stage 1, stage 2, back-substitution, cost evaluations; "
-                            "the PCG is reported separately) of the bytes each must move in this layout / "
-                            "their summed HIP-event times / 8 TB/s",
-                    "frac": frac(b_iter, t_s1 + t_s2 + t_bs + t_err),
-                    "bytes_per_step": b_iter / n_t,
+                    "what": "EVERYTHING an LM iteration launches: stage 1, stage 2, the PCG (executed products on "
+                            "either operator, assemblies, vector work - rba_get_pcg_counters), back-substitution, "
+                            "cost evaluations: the bytes each must move in this layout (rba_get_byte_model) / their "
+                            "summed HIP-event times / 8 TB/s",
+                    "frac": frac(b_iter + b_pcg, t_s1 + t_s2 + t_bs + t_err + t_pcg),
+                    "bytes_per_step": (b_iter + b_pcg) / n_t,
+                    "frac_without_pcg": frac(b_iter, t_s1 + t_s2 + t_bs + t_err),
                 },
                 "stages": stages,
             },

@@ -26,6 +26,11 @@
  *    [lm_obs_offsets[l], lm_obs_offsets[l+1]), camera indices ascending inside a
  *    landmark (std::map order, src/rootba/bal/bal_problem.hpp:131), every
  *    landmark has >= 2 observations (landmark_block_base.ipp:70-73).
+ *  - environment: the library reads a handful of DEBUG / TEST variables once per rba_create (none is needed in
+ *    production, none changes results beyond rounding): RBA_VERBOSE, RBA_EXPLICIT_AFTER (overrides
+ *    rba_options.explicit_after), RBA_EX_PAIR_BUDGET_GB, RBA_FORCE_EXPLICIT_FALLBACK, RBA_HX_LDS, RBA_HX_WIN,
+ *    RBA_HX_TIMING_STRIDE, RBA_SORT_BY_CAMERA (rootba_amd/csrc/solver.hip: Solver::DebugEnv). The ~25 kernel-selection
+ *    switches of rounds 1-2 are gone with the kernels they selected.
  *  - camera state: 10 scalars (qx,qy,qz,qw,tx,ty,tz,f,k1,k2) = Camera::params()
  *    (bal_problem.hpp:84-95); pose/intrinsics increments: 9 per camera.
  * ==========================================================================*/
@@ -88,10 +93,10 @@ typedef struct rba_options {
   int optimized_cost;             /* 0 ERROR, 1 ERROR_VALID, 2 ERROR_VALID_AVG    */
   int staged_execution;           /* 1 (default): stage timers only. 0: the reference's unstaged sub-stage timers
                                      are measured as well (rba_get_substage_timings); same kernels either way */
-  int implicit_q;                 /* matrix-free products H*x: 1 (default) evaluated from the factors
-                                     (Jp, Householder vectors, damping rotations); the dense blocks of
-                                     landmarks with <= 112 observations are then never written.
-                                     0: stream the dense Q2^T Jp blocks the reference materialises */
+  int implicit_q;                 /* accepted, ignored (kept for ABI stability): matrix-free products H*x are always
+                                     evaluated from the factors (Jp rows, Householder vectors, damping rotations);
+                                     no dense landmark block is ever written, so there is no limit on the track
+                                     length. The dense-block configuration of rounds 1-2 (= 0) was removed in round 3 */
   int solver_type;                /* SolverOptions::SolverType: 0 SQUARE_ROOT (default, LinearizorQR),
                                      1 SCHUR_COMPLEMENT (LinearizorSC, linearizor_sc.cpp:70-211:
                                      explicit block-sparse reduced camera matrix + SpMV; preconditioners
@@ -148,9 +153,12 @@ typedef struct rba_iter_timings {
  *                                  column scaling itself is part of the QR kernels)
  *   stage1_preconditioner_time     D G D scaling of the Gram blocks (get_Jp_T_Jp_blockdiag)
  *   perform_qr_time                Jl column scaling + Householder QR kernels (scale_Jl_cols + perform_qr)
- *   landmark_damping_time          the six damping rotations per landmark (set_landmark_damping)
- *   scale_pose_jacobian_time       per-observation column pass: Jp column scaling, Q1^T Jp, rotated top
- *                                  rows, b records (scale_Jp_cols + the per-column part of the damping)
+ *   landmark_damping_time          always 0: the six damping rotations per landmark (set_landmark_damping) are
+ *                                  evaluated inside the per-observation pass of stage 2 (measured faster than a
+ *                                  pass of their own) and are timed with it
+ *   scale_pose_jacobian_time       per-observation pass of stage 2: landmark damping, Jp column scaling, the
+ *                                  observation's stage-2 record (set_landmark_damping + scale_Jp_cols + the
+ *                                  per-column part of the damping)
  *   stage2_preconditioner_and_gradient_time   camera-major pass: SCHUR_JACOBI blocks and b
  *                                  (get_Q2TJp_T_Q2TJp_blockdiag + get_Q2TJp_T_Q2Tr, one fused pass) */
 typedef struct rba_substage_timings {
@@ -285,8 +293,8 @@ int rba_synchronize(rba_handle h);
 
 int rba_get_timings(rba_handle h, rba_iter_timings* out);
 int rba_get_substage_timings(rba_handle h, rba_substage_timings* out);
-/* Profiling aid: streams the landmark-block storage once with 4-byte
- * (vec_width = 1) or 16-byte (vec_width = 4) loads and reports the bytes read —
+/* Profiling aid: streams the Jacobian-row storage (72 bytes per observation in float) once with 4-byte
+ * (vec_width = 1) or 16-byte (vec_width = 4) loads and reports the bytes read -
  * a known byte count for calibrating rocprofv3's FETCH_SIZE on gfx950. */
 int rba_debug_read_blocks(rba_handle h, int vec_width, int64_t* bytes_out);
 
@@ -308,13 +316,24 @@ typedef struct rba_byte_model {
   int64_t compute_error;       /* one cost evaluation                                        */
   int64_t stage1;              /* one linearisation: geometry, landmark QR, camera-major sums */
   int64_t stage2;              /* landmark damping + per-observation rotation + camera-major sums */
-  int64_t product_matrix_free; /* one H x from the QR factors (implicit_q) / the dense blocks */
+  int64_t product_matrix_free; /* one H x from the QR factors                                 */
   int64_t product_assembled;   /* one S x on the assembled block-CSR matrix                   */
   int64_t assembly;            /* one assembly of the reduced camera matrix                   */
   int64_t pcg_vectors;         /* vector / preconditioner work of one PCG iteration           */
   int64_t back_substitution;   /* back-substitution + landmark update                         */
 } rba_byte_model;
 int rba_get_byte_model(rba_handle h, rba_byte_model* out);
+/* What the PCG solves since rba_create actually executed (launches queued past a solve's termination are no-ops and
+ * not counted): matrix-free products, products on the assembled matrix, assemblies of that matrix, PCG iterations.
+ * With rba_byte_model this prices the PCG phase of a run (bench.py: roofline.whole_iteration). */
+typedef struct rba_pcg_counters {
+  int64_t products_matrix_free;
+  int64_t products_assembled;
+  int64_t assemblies;
+  int64_t iterations;
+  int64_t solves_repeated_matrix_free; /* solves whose assembled operator broke down (S + E lost definiteness) */
+} rba_pcg_counters;
+int rba_get_pcg_counters(rba_handle h, rba_pcg_counters* out);
 
 #ifdef __cplusplus
 }

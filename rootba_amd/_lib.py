@@ -122,13 +122,17 @@ EXPORTS = [
     "rba_right_multiply", "rba_right_multiply_explicit", "rba_apply", "rba_back_substitute", "rba_optimize_lm", "rba_lm_begin", "rba_lm_step", "rba_lm_termination", "rba_synchronize",
     "rba_get_timings", "rba_get_substage_timings", "rba_debug_read_blocks",
     "rba_get_jl_col_scale", "rba_get_pose_scaling", "rba_get_landmark_R", "rba_get_problem_stats",
-    "rba_get_byte_model",
+    "rba_get_byte_model", "rba_get_pcg_counters",
 ]
 
 
 class RbaByteModel(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("compute_error", "stage1", "stage2", "product_matrix_free",
                                          "product_assembled", "assembly", "pcg_vectors", "back_substitution")]
+
+class RbaPcgCounters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("products_matrix_free", "products_assembled", "assemblies", "iterations",
+                                         "solves_repeated_matrix_free")]
 
 _lib = None
 

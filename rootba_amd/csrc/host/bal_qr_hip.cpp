@@ -37,7 +37,6 @@ void usage() {
       "  --eta <e> --max-linear-solver-iterations <n> --function-tolerance <t>\n"
       "  --jacobi-scaling-epsilon <e> --log-path <ba_log.json> --device <n>\n"
       "  --solver-type SQUARE_ROOT|SCHUR_COMPLEMENT   (default SQUARE_ROOT)\n"
-      "  --dense-blocks                         matrix-free products on the dense Q2^T Jp blocks (default: from the QR factors)\n"
       "  --save-log-flags <JSON,UBJSON>         (default JSON; UBJSON writes <log>.ubjson next to it)\n"
       "  --input-type <AUTO|ROOTBA|BAL|BUNDLER> AUTO: '*.cereal' = rootba problem cache, '*bundle*' = Bundler, else BAL text\n"
       "  --[no-]save-output, --output-optimized-path <p>   write the optimised problem as a .cereal cache (default optimized.cereal)\n"
@@ -273,7 +272,6 @@ int main(int argc, char** argv) {
     else if (a == "--self-test-parser") return self_test_parser(std::stol(val()));
     else if (a == "--self-test-log") return self_test_log(val());
     else if (a == "--implicit-q") so.implicit_q = true;
-    else if (a == "--dense-blocks") so.implicit_q = false;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 1; }
   }
   if (dump_options) {

@@ -65,7 +65,7 @@ struct SolverOptions {
   int power_order = 10;
   double initial_vee = 2.0;
   double vee_factor = 2.0;
-  bool implicit_q = true;   // not in the reference: matrix-free products from the QR factors (false: dense blocks)
+  bool implicit_q = true;   // not in the reference; accepted, ignored: products are always evaluated from the QR factors
   int explicit_after = -1;  // not in the reference: rba_options.explicit_after (-1 = measured break-even)
   bool use_projection_validity_check() const { return optimized_cost != OptimizedCost::ERROR; }
 

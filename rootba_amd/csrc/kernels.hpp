@@ -1,25 +1,15 @@
 // kernels.hpp — hand-written HIP kernels (gfx950) of the square-root BA solver.
 //
-// Two generations live here:
-//  * the default configuration (implicit_q = 1, "staged"): work runs at the parallelism it has - thread per
-//    observation (kernels_s1.hpp), lane per block row on WAVE TILES (a landmark = an aligned group of 4..64 lanes,
-//    k_hx_implicit*, k_bs_tile, k_s1_qr_tile), workgroup per camera for the camera-indexed sums
-//    (k_cam_gram_mfma, k_cam_stage2_w8_mfma). Products scatter into workgroup-private double copies of y in LDS
-//    (k_hx_implicit_lds). No dense landmark block exists.
-//  * the dense-block configuration (implicit_q = 0, round 1): ONE WAVEFRONT PER LANDMARK, lanes run along the 9k pose
-//    columns of the landmark's block. A chunk is 7 whole cameras = 63 columns (lane 63 idles), so a camera's 9
-//    columns never straddle chunks: column j = 63*chunk + lane, camera slot i = 7*chunk + lane/9, component lane%9;
-//    CH chunks per lane are chosen per k-class (k <= 7*CH). Rows are streamed. Cross-lane sums (one per block row)
-//    use the DPP network (k_linearize_qr*, k_hx, k_hx_small, k_stage2_cols, k_cam_stage1/2).
-//    Device layout per landmark s (k observations, sorted order):
-//      A     [2k x 9k] row-major, dense: rows 0..2k-4 = Q2^T Jp (scaled), rows
-//            2k-3..2k-1 = the three landmark-damping rows      -> operand of H*x
-//      top0  [k][3][9] Q1^T Jp (undamped), observation-major; topd: with damping
-//      qtr   [2k]      Q^T r (first 3 = Q1^T r);   R0 / Rd [6] upper 3x3 of R
-//    i.e. the reference's (2k+3) x (9k+pad+4) LandmarkBlock storage
-//    (landmark_block_dynamic.hpp:49-69) split into its streamed and its small parts.
-// Landmarks are sorted by track-length class at setup (and by first camera inside a class in the default
-// configuration), so a launch covers one contiguous class. See DESIGN.md for bytes per kernel.
+// Work runs at the parallelism it has: thread per observation (kernels_s1.hpp), lane per block row
+// on WAVE TILES (a landmark = an aligned group of 4..64 lanes: k_hx_implicit*, k_bs_tile, k_s1_qr_tile), workgroup
+// per camera for the camera-indexed sums (kernels_cam.hpp), workgroup per landmark for tracks longer than 112
+// (kernels_big.hpp). Products scatter into workgroup-private double copies of y in LDS (k_hx_implicit_lds).
+// No dense landmark block exists: the reference's (2k+3) x (9k+pad+4) LandmarkBlock storage
+// (landmark_block_dynamic.hpp:49-69) is replaced by per-row records (Jacobian rows, Householder vectors) and
+// per-landmark scalars; the dense-block kernel generation of rounds 1-2 (one wavefront per landmark along the 9k
+// columns) was removed in round 3.
+// Landmarks are sorted by track-length class and by first camera inside a class at setup, so a launch covers one
+// contiguous class. See DESIGN.md for bytes per kernel.
 #pragma once
 
 #include <type_traits>
@@ -39,7 +29,6 @@ struct Params {
   // topology (sorted landmark order)
   const int* __restrict__ lm_k;         // [n_lms]
   const int64_t* __restrict__ lm_obs;   // [n_lms+1] first observation
-  const int64_t* __restrict__ lm_blk;   // [n_lms+1] offset of A block (scalars)
   const int* __restrict__ obs_cam;      // [n_obs]
   const int* __restrict__ obs_lm;       // [n_obs] sorted landmark index
   const S* __restrict__ obs_xy;         // [2 n_obs]
@@ -48,63 +37,50 @@ struct Params {
   // state
   S* cams;  // [10 n_cams]
   S* lms;   // [3 n_lms]
-  // landmark blocks
-  S* A;
-  S* top0;      // [n_obs][3][9] Q1^T Jp, undamped (observation-major)
-  S* topd;      // [n_obs][kTd]  rows 0..26: Q1^T Jp with landmark damping ([3][9]); 27..35: the observation's
-                //               part of b (staged path: Q2 rows + damping rows; round-1 path: damping rows only)
-  S* JpS;       // [n_obs][2][9] weighted, column-scaled pose Jacobian
-  S* bmO;       // [n_obs][9]    per-observation part of b from the Q2 rows
-  // implicit-Q operator (k_hx_implicit): the factors instead of the product
+  // per-observation / per-row records (landmark-major)
+  S* JpS;       // [n_obs][2][9] weighted pose Jacobian rows, UNSCALED: the Jacobi column scaling D (pose_scaling) is
+                //               applied where a camera index is at hand (operand and result of H x, increment of the
+                //               back-substitution, epilogue of the camera-major pass)
   S* Vh;        // [2 n_obs][4]  per block row: Householder vectors v0, v1, v2 and (Q^T r)[row]
-  S* tauH;      // [3 n_lms]     their tau
-  S* Zd;        // [9 n_lms]     3x3 map of the top rows through damp / drop-Q1 / undamp
+  S* JlS;       // [n_obs][2][3] sqrt(w) Jl D_l before the QR (back-substitution)
+  S* rS;        // [n_obs][2]    sqrt(w) r
+  S* WA;        // [n_obs][8]    stage-2 record of the camera-major pass (kernels_cam.hpp): [g 2 | A 2x2 | 0 0] with the
+                //               observation's part of b = (Jp D)^T g and of the diagonal block = (A Jp D)^T (A Jp D)
+  S* W8;             // [n_obs - w8_begin][8] the eight stage-2 coefficients W' (3x2, row-major) | g (2) themselves, kept
+  int64_t w8_begin;  //   only for the observations of the two-kernel back-substitution (k > 32): topd x = W' (Jp D x)
+  S* topd;      // [n_obs][kTd]  damped Q1^T Jp D ([3][9]) | the observation's part of b: materialised ON DEMAND from
+                //               JpS and the factors (k_s12_cols) for the assembly of the reduced matrix and E0 products
+  S* bsO;       // [n_obs][5]    back-substitution scratch (k > 32): topd x (3), Jp x (2)
+  // per-landmark records
+  S* tauH;      // [3 n_lms]     reflector tau
   S* LQ;        // [n_lms][12]   tau[3], reflector cross products g10 g20 g21, d[3] (kernels_s1.hpp)
+  S* R0;        // [6 n_lms]     upper 3x3 of R, undamped
+  S* jl_scale;  // [3 n_lms]     Jl_col_scale
+  S* givens;    // [n_lms][16]   the 6 damping rotations of stage 2: c[6], s[6], damping-row residual[3], pad
+  S* Rd;        // [6 n_lms]     damped R
+  S* q1trd;     // [3 n_lms]     damped Q1^T r
+  S* damp_r;    // [3 n_lms]
+  S* Zd;        // [9 n_lms]     3x3 map of the top rows through damp / drop-Q1 / undamp (implicit-Q operator)
   // wave tiles for k <= 32 (one lane per block row, landmark = aligned group of P2 lanes, see
   // k_hx_implicit / k_s1_qr_tile): static maps lane -> camera / block row, -1 = padding
   const int* __restrict__ CT;        // [tiles][64] camera of the row's observation
   const int* __restrict__ RT;        // [tiles][64] global block row 2 o + r
-  int implicit;                      // products from the factors: the dense blocks of k <= 112 are not written
-  S* JlS;       // [n_obs][2][3]  sqrt(w) Jl D_l before the QR (back-substitution)
-  S* rS;        // [n_obs][2]     sqrt(w) r
-  S* bsO;       // [n_obs][5]     back-substitution scratch: topd x (3), Jp x (2)
-  S* givens;    // [n_lms][16]    the 6 damping rotations of stage 2: c[6], s[6], damping-row residual[3], pad
-  int b_from_records;  // b = sum_obs (b record) (staged path, kernels_s1.hpp) instead of b_mid + sum_obs (b record)
-  S* sdiag;            // [81 n_cams] JACOBI / power-series with the assembled matrix: B_mid - sum topd^T topd, i.e.
-                       // the diagonal blocks of the reduced matrix (the preconditioner blocks are B_mid + lambda I there)
-  int want_sdiag;
-  // Optional privatised scatter targets: the camera-indexed scatter-adds of the products go to one of
-  // `y_rep` replicas of the 9 n_c vector (chosen by workgroup), summed afterwards. An experiment switch
-  // (RBA_Y_REPLICAS): on venice 4 / 16 / 64 replicas move H*x by < 2 %, i.e. the 7.5 M atomic requests
-  // onto one 64 KB vector are not what bounds the kernel.
-  int y_rep;
-  int64_t y_rep_stride;
-  S* WA;         // [n_obs][8] stage-2 record of the camera-major pass (kernels_cam.hpp): [g 2 | A 2x2 | 0 0] with the
-                 //            observation's part of b = (Jp D)^T g and of the diagonal block = (A Jp D)^T (A Jp D); JpS stays UNSCALED
-  S* W8;             // [n_obs - w8_begin][8] the eight stage-2 coefficients W' (3x2, row-major) | g (2) themselves, kept only
-  int64_t w8_begin;  //   for the observations the two-kernel back-substitution handles (landmarks with k > 32): topd x = W' (Jp D x)
-  int compact;   // 1: stage 2 writes WA only; D (pose_scaling) is applied where a camera index is at hand
   S* lm_inc;     // mixed precision (RBA_MIXED): the back-substitution stores the scaled landmark increments here
                  // [3 n_lms] instead of adding them to `lms`; they are applied to the double master state
-  int hx_debug;  // RBA_HX_DEBUG (profiling only, results are wrong): 1 = no scatter, 2 = loads only
-  S* R0;        // [6 n_lms]
-  S* Rd;        // [6 n_lms]
-  S* q1trd;     // [3 n_lms]
-  S* damp_r;    // [3 n_lms]
-  S* jl_scale;  // [3 n_lms]
   // camera-sized vectors
   S* jp_diag2;      // [9 n_cams]
   S* pose_scaling;  // [9 n_cams]
-  S* b_mid;         // [9 n_cams]
-  S* B_mid;         // [81 n_cams]
+  S* B_mid;         // [81 n_cams] D G D (JACOBI blocks without the damping)
   S* b;             // [9 n_cams]
   S* blocks;        // [81 n_cams]
+  S* sdiag;         // [81 n_cams] JACOBI / power-series with the assembled matrix: the diagonal blocks of the reduced
+  int want_sdiag;   //             matrix (the preconditioner blocks are B_mid + lambda I there)
   int* fail_flag;   // numerical failure
   double* lm_ldiff;  // [n_lms] per-landmark model cost change
   // options
   int robust_norm;
   int valid_only;
-  int jacobi;  // preconditioner_type == JACOBI
+  int jacobi;  // preconditioner_type == JACOBI / POWER_SCHUR_COMPLEMENT: blocks = Hpp + lambda I
   S huber;
   S eps;  // jacobi scaling epsilon
 };
@@ -121,21 +97,6 @@ __device__ __forceinline__ void apply_landmark_increment(const Params<S>& p, int
     else
       p.lms[3 * s + j] += d;
   }
-}
-
-template <class S>
-__device__ __forceinline__ S* scatter_replica(const Params<S>& p, S* y) {
-  return p.y_rep > 1 ? y + int64_t(blockIdx.x % unsigned(p.y_rep)) * p.y_rep_stride : y;
-}
-
-// y[i] += sum over the replicas
-template <class S>
-__global__ void k_sum_replicas(S* __restrict__ y, const S* __restrict__ rep, int n_rep, int64_t stride, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  S acc = S(0);
-  for (int r = 0; r < n_rep; ++r) acc += rep[r * stride + i];
-  y[i] += acc;
 }
 
 // ===========================================================================
@@ -221,122 +182,9 @@ __device__ __forceinline__ double block_sum_256(double v, double* sm4) {
   return sm4[0] + sm4[1] + sm4[2] + sm4[3];
 }
 
-// Stage 1, pass A: squared column norms of the weighted pose Jacobian
-// (add_Jp_diag2, landmark_block_base.ipp:493-518) and the non-finite check of
-// linearize_landmark (ipp:123-146).
-template <class S>
-__global__ __launch_bounds__(256) void k_cam_jp_diag2(Params<S> p) {
-  __shared__ double sm4[4];
-  const int c = blockIdx.x;
-  S cam[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) cam[i] = p.cams[10 * c + i];
-  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  bool fin = true;
-  for (int64_t t = p.cam_obs_off[c] + threadIdx.x; t < p.cam_obs_off[c + 1]; t += 256) {
-    const int o = p.cam_obs[t];
-    const int l = p.obs_lm[o];
-    S res[2], Jp[18], Jl[6];
-    const bool valid = linearize_obs<S>(cam, p.lms[3 * l], p.lms[3 * l + 1], p.lms[3 * l + 2],
-                                        p.obs_xy[2 * o], p.obs_xy[2 * o + 1], res, Jp, Jl);
-    if (p.valid_only && !valid) continue;
-    fin = fin && is_finite(res[0]) && is_finite(res[1]);
-#pragma unroll
-    for (int i = 0; i < 18; ++i) fin = fin && is_finite(Jp[i]);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) fin = fin && is_finite(Jl[i]);
-    S err, w;
-    error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
-#pragma unroll
-    for (int a = 0; a < 9; ++a) acc[a] += double(w * (Jp[a] * Jp[a] + Jp[9 + a] * Jp[9 + a]));
-  }
-  if (!fin) atomicOr(p.fail_flag, 1);
-#pragma unroll
-  for (int a = 0; a < 9; ++a) {
-    const double t = block_sum_256(acc[a], sm4);
-    if (threadIdx.x == 0) p.jp_diag2[9 * c + a] = S(t);
-  }
-}
-
-// Stage 1, camera-major part: damping-independent terms of the preconditioner
-// and of the gradient,
-//   B_mid[c] = sum_obs JpS^T JpS    (H_pp diagonal block; JACOBI: add_Jp_T_Jp_blockdiag
-//              ipp:554-569. SCHUR_JACOBI subtracts the Gram matrix of the damped top rows in
-//              stage 2: add_Q2TJp_T_Q2TJp_blockdiag ipp:520-552 through orthogonality)
-//   b_mid[c] = sum_obs bmO                           (add_Q2TJp_T_Q2Tr ipp:443-466)
-// Threads 0..242: 3 observation groups x 81 block entries; 243..251: b.
-// ---------------------------------------------------------------------------
-// The 9x9 tile contractions sum_obs X_o^T X_o (X_o = the 2 Jacobian rows, the 3
-// top rows or the 3 damping rows of one observation, 9 wide) run on the matrix
-// cores: v_mfma_f32_16x16x4_f32 takes 4 rows of X per instruction; both operands
-// are the SAME register because lane l holds A[i=l&15][k=l>>4] = X[k][i] and
-// B[k=l>>4][j=l&15] = X[k][j]. Exact f32 (an fmaf chain), no LDS staging of the
-// records, the accumulator tile D[(l>>4)*4+reg][l&15] is summed over the four
-// waves of the workgroup at the end. double uses the VALU path below.
-// ---------------------------------------------------------------------------
+// f32 accumulator tile of v_mfma_f32_16x16x4_f32: lane l holds D[(l >> 4) * 4 + r][l & 15], r = 0..3
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// acc += sum over this wave's share of the observation list [t0, t1) of 4-row
-// tiles. The wave takes 64-observation chunks (wave w: chunks w, w+4, ...), loads
-// the chunk's indices with ONE coalesced load, broadcasts them with v_readlane and
-// keeps 8 record loads in flight ahead of the MFMAs.
-template <int ROWS_PER_OBS>
-__device__ __forceinline__ f32x4 mfma_xtx(const float* __restrict__ rec, int rec_stride,
-                                          const int* __restrict__ cam_obs, int64_t t0, int64_t t1,
-                                          int wave, int lane, f32x4 acc) {
-  const int i = lane & 15, kk = lane >> 4;
-  constexpr int OPI = ROWS_PER_OBS == 2 ? 2 : 1;  // observations per instruction
-  constexpr int U = 8;
-  for (int64_t base = t0 + 64 * wave; base < t1; base += 256) {
-    const int cnt = int(min<int64_t>(64, t1 - base));
-    const int idxreg = lane < cnt ? cam_obs[base + lane] : 0;
-    for (int s0 = 0; s0 < cnt; s0 += U * OPI) {
-      float v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int s = s0 + u * OPI;
-        float val = 0.f;
-        if (ROWS_PER_OBS == 2) {
-          const int oa = __builtin_amdgcn_readlane(idxreg, s & 63);
-          const int ob = __builtin_amdgcn_readlane(idxreg, (s + 1) & 63);
-          const int so = s + (kk >> 1);
-          const int o = (kk >> 1) ? ob : oa;
-          if (i < 9 && so < cnt) val = rec[int64_t(o) * rec_stride + 9 * (kk & 1) + i];
-        } else {
-          const int o = __builtin_amdgcn_readlane(idxreg, s & 63);
-          if (i < 9 && kk < 3 && s < cnt) val = rec[int64_t(o) * rec_stride + 9 * kk + i];
-        }
-        v[u] = val;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u], v[u], acc, 0, 0, 0);
-    }
-  }
-  return acc;
-}
-
-// sum over the camera's observations of a 9-vector per observation (double
-// accumulators, fixed order): thread = (group g of 28, component a); 4 loads in flight
-template <class F>
-__device__ __forceinline__ double cam_sum9(const int* __restrict__ cam_obs, int64_t t0, int64_t t1,
-                                           int g, F&& term) {
-  double acc = 0;
-  int64_t t = t0 + g;
-  for (; t + 3 * 28 < t1; t += 4 * 28) {
-    const int o0 = cam_obs[t], o1 = cam_obs[t + 28], o2 = cam_obs[t + 56], o3 = cam_obs[t + 84];
-    const float v0 = term(o0), v1 = term(o1), v2 = term(o2), v3 = term(o3);
-    acc += (double(v0) + double(v1)) + (double(v2) + double(v3));
-  }
-  for (; t < t1; t += 28) acc += double(term(cam_obs[t]));
-  return acc;
-}
-
-// LDS-staged variant: the wave fetches WHOLE records of 32 observations with 8- / 16-byte pieces
-// (nine pieces per record, every lane busy: 5 gather instructions per 32 observations instead of 16-32
-// four-byte ones with 36 of 64 lanes active), then feeds the matrix cores out of LDS. `side(r, rec)` is
-// called per lane group for VALU side sums over the same staged records (no second gather).
-//   W = 18, ROWS = 2: [Jp row 0 | Jp row 1]          (8-byte pieces)
-//   W = 36, ROWS = 3: [top row 0 | 1 | 2 | b record]  (16-byte pieces)
 // Camera-major workgroups are launched as 8 * ceil(n_cams / 8) blocks and mapped so that one XCD
 // (block b runs on XCD b % 8, each with its own L2) walks a CONTIGUOUS range of cameras: the records
 // of a landmark sit next to each other in HBM and belong to cameras that are close in index, so the
@@ -349,980 +197,12 @@ __device__ __forceinline__ int xcd_swizzled_camera(int n_cams) {
 inline int xcd_swizzled_grid(int n_cams) { return 8 * ((n_cams + 7) / 8); }
 
 constexpr int kCamChunk = 32;
-template <int W, int ROWS, bool PREFETCH, class F>
-__device__ __forceinline__ f32x4 mfma_xtx_staged(const float* __restrict__ rec, const int* __restrict__ cam_obs,
-                                                 int64_t t0, int64_t t1, int wave, int lane, f32x4 acc, float* lds,
-                                                 bool use_mfma, F&& side) {
-  constexpr int PS = W == 18 ? 2 : 4;  // floats per piece
-  constexpr int NP = W / PS;           // 9 pieces per record
-  constexpr int NJ = (kCamChunk * NP + 63) / 64;
-  static_assert(NP == 9, "nine pieces per record");
-  using PV = typename std::conditional<PS == 2, float2, float4>::type;
-  const int i = lane & 15, kk = lane >> 4;
-  // PREFETCH: the records of chunk c + 1 are in flight (in registers) while chunk c is multiplied out of
-  // LDS. Used for the 72-byte Gram records (158 -> 139 us on venice); with the 16-byte pieces of the
-  // 144-byte stage-2 records the compiler moves the register array to scratch (324 -> 513 us), so that
-  // pass loads straight into LDS.
-  PV regs[NJ];
-  auto issue = [&](int64_t base, int cnt) {
-    const int idxreg = lane < cnt ? cam_obs[base + lane] : 0;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int q = j * 64 + lane;
-      const int r = q / NP, pc = q - NP * r;
-      const int o = __shfl(idxreg, r & 31);
-      if (q < cnt * NP) regs[j] = *reinterpret_cast<const PV*>(rec + int64_t(o) * W + PS * pc);
-    }
-  };
-  int64_t base = t0 + kCamChunk * wave;
-  int cnt = base < t1 ? int(min<int64_t>(kCamChunk, t1 - base)) : 0;
-  if (PREFETCH && cnt > 0) issue(base, cnt);
-  while (cnt > 0) {
-    if (PREFETCH) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int q = j * 64 + lane;
-        const int r = q / NP, pc = q - NP * r;
-        if (q < cnt * NP) *reinterpret_cast<PV*>(lds + r * W + PS * pc) = regs[j];
-      }
-    } else {
-      // straight global -> LDS (a register array here ends up in scratch for the 16-byte pieces)
-      const int idxreg = lane < cnt ? cam_obs[base + lane] : 0;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int q = j * 64 + lane;
-        const int r = q / NP, pc = q - NP * r;
-        const int o = __shfl(idxreg, r & 31);
-        if (q < cnt * NP)
-          *reinterpret_cast<PV*>(lds + r * W + PS * pc) = *reinterpret_cast<const PV*>(rec + int64_t(o) * W + PS * pc);
-      }
-    }
-    wave_lds_fence();
-    const int cur = cnt;
-    base += 4 * kCamChunk;
-    cnt = base < t1 ? int(min<int64_t>(kCamChunk, t1 - base)) : 0;
-    if (PREFETCH && cnt > 0) issue(base, cnt);
-    if (use_mfma) {
-      if (ROWS == 2) {
-        for (int s = 0; s < cur; s += 2) {
-          const int so = s + (kk >> 1);
-          const float v = (i < 9 && so < cur) ? lds[so * W + 9 * (kk & 1) + i] : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, acc, 0, 0, 0);
-        }
-      } else {
-        for (int s = 0; s < cur; ++s) {
-          const float v = (i < 9 && kk < 3) ? lds[s * W + 9 * kk + i] : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, acc, 0, 0, 0);
-        }
-      }
-    }
-    side(cur, lds);
-    wave_lds_fence();  // the next chunk overwrites the staging buffer
-  }
-  return acc;
-}
-
-// float: matrix-core version
-__global__ __launch_bounds__(256) void k_cam_stage1_mfma(Params<float> p) {
-  __shared__ float tile[4][16][16];
-  __shared__ double bsum[28][9];
-  const int c = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  f32x4 accJ = {0.f, 0.f, 0.f, 0.f};
-  accJ = mfma_xtx<2>(p.JpS, 18, p.cam_obs, t0, t1, wave, lane, accJ);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = accJ[r];
-  // b_mid: 28 groups x 9 components on the VALU, double
-  if (tid < 252) {
-    const int g = tid / 9, a = tid - 9 * g;
-    bsum[g][a] = cam_sum9(p.cam_obs, t0, t1, g, [&](int o) { return p.bmO[int64_t(o) * 9 + a]; });
-  }
-  __syncthreads();
-  if (tid < 81) {
-    const int i = tid / 9, j = tid - 9 * i;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) v += tile[w][i][j];
-    p.B_mid[81 * c + tid] = v;
-  }
-  if (tid >= 128 && tid < 137) {
-    const int a = tid - 128;
-    double acc = 0;
-    for (int g = 0; g < 28; ++g) acc += bsum[g][a];
-    p.b_mid[9 * c + a] = float(acc);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_cam_stage2_mfma(Params<float> p, float lambda) {
-  __shared__ float tile[4][16][16];
-  __shared__ double bsum[4][7][9];
-  __shared__ __attribute__((aligned(16))) float stage[4][kCamChunk * kTd];
-  const int c = xcd_swizzled_camera(p.n_cams);
-  if (c >= p.n_cams) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const bool damped = lambda != 0.f;
-  const bool want_b = p.b_from_records || damped;
-  // b: lane (g, a) of 7 groups x 9 components sums the b records of observations g, g+7, ... (double)
-  const int g = lane / 9, a = lane - 9 * g;
-  double accb = 0;
-  acc = mfma_xtx_staged<kTd, 3, false>(p.topd, p.cam_obs, t0, t1, wave, lane, acc, stage[wave], !p.jacobi || p.want_sdiag,
-                                [&](int cnt, const float* rec) {
-                                  if (want_b && lane < 63)
-                                    for (int r = g; r < cnt; r += 7) accb += double(rec[r * kTd + 27 + a]);
-                                });
-#pragma unroll
-  for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-  if (lane < 63) bsum[wave][g][a] = accb;
-  __syncthreads();
-  if (tid < 81) {
-    const int i = tid / 9, j = tid - 9 * i;
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) t += tile[w][i][j];
-    const float bm = p.B_mid[81 * c + tid];
-    p.blocks[81 * c + tid] = (p.jacobi ? bm : bm - t) + (i == j ? lambda : 0.f);
-    if (p.want_sdiag) p.sdiag[81 * c + tid] = bm - t;
-  }
-  if (tid >= 128 && tid < 137) {
-    const int aa = tid - 128;
-    double sum = p.b_from_records ? 0.0 : double(p.b_mid[9 * c + aa]);
-    for (int w = 0; w < 4; ++w)
-      for (int gg = 0; gg < 7; ++gg) sum += bsum[w][gg][aa];
-    p.b[9 * c + aa] = float(sum);
-  }
-}
-
-template <class S>
-__global__ __launch_bounds__(256) void k_cam_stage1(Params<S> p) {
-  constexpr int TILE = 64, W = 27, NLD = (TILE * W + 255) / 256;
-  __shared__ S rec[TILE][W];  // [JpS 18 | bmO 9]
-  __shared__ int olist[TILE];
-  __shared__ double red[3][81];
-  const int c = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
-  double acc = 0;
-  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  for (int64_t base = t0; base < t1; base += TILE) {
-    const int n = int(min<int64_t>(TILE, t1 - base));
-    __syncthreads();
-    if (tid < n) olist[tid] = p.cam_obs[base + tid];
-    __syncthreads();
-    // all record loads of the tile are issued before the first LDS store
-    S v[NLD];
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int idx = u * 256 + tid;
-      v[u] = S(0);
-      if (idx < n * W) {
-        const int q = idx / W, f = idx - W * q;
-        const int64_t o = olist[q];
-        v[u] = f < 18 ? p.JpS[o * 18 + f] : p.bmO[o * 9 + (f - 18)];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int idx = u * 256 + tid;
-      if (idx < n * W) rec[idx / W][idx % W] = v[u];
-    }
-    __syncthreads();
-    if (grp < 3) {
-      for (int q = grp; q < n; q += 3) {
-        const S* r = rec[q];
-        acc += double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb]);
-      }
-    } else if (tid < 252) {
-      const int a = tid - 243;
-      for (int q = 0; q < n; ++q) acc += double(rec[q][18 + a]);
-    }
-  }
-  if (grp < 3) red[grp][e] = acc;
-  __syncthreads();
-  if (tid < 81) p.B_mid[81 * c + tid] = S(red[0][tid] + red[1][tid] + red[2][tid]);
-  if (tid >= 243 && tid < 252) p.b_mid[9 * c + (tid - 243)] = S(acc);
-}
-
-// Stage 2, camera-major part:
-//   blocks[c] = B_mid[c] - sum_obs topd^T topd + lambda I      (B_mid = sum_obs Jp^T Jp)
-//   b[c]      = b_mid[c] + sum_obs bdO        (bdO = damping rows^T damping-row residual)
-// With Q orthogonal for the damped system, sum over the kept rows of A^T A equals
-// Jp^T Jp minus the Gram matrix of the (damped) top rows.
-// (last three rows of add_Q2TJp_T_Q2TJp_blockdiag / add_Q2TJp_T_Q2Tr; pose
-//  damping on the preconditioner: linearization_qr.hpp:796-802, JACOBI:
-//  linearizor_qr.cpp:227-232)
-template <class S>
-__global__ __launch_bounds__(256) void k_cam_stage2(Params<S> p, S lambda) {
-  constexpr int TILE = 64, W = 36, NLD = (TILE * W + 255) / 256;
-  __shared__ S rec[TILE][W];  // [topd 27 | bdO 9]
-  __shared__ int olist[TILE];
-  __shared__ double red[3][81];
-  const int c = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
-  double acc = 0;
-  {
-    const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-    for (int64_t base = t0; base < t1; base += TILE) {
-      const int n = int(min<int64_t>(TILE, t1 - base));
-      __syncthreads();
-      if (tid < n) olist[tid] = p.cam_obs[base + tid];
-      __syncthreads();
-      S v[NLD];
-#pragma unroll
-      for (int u = 0; u < NLD; ++u) {
-        const int idx = u * 256 + tid;
-        v[u] = S(0);
-        if (idx < n * W) {
-          const int q = idx / W, f = idx - W * q;
-          v[u] = p.topd[int64_t(olist[q]) * kTd + f];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < NLD; ++u) {
-        const int idx = u * 256 + tid;
-        if (idx < n * W) rec[idx / W][idx % W] = v[u];
-      }
-      __syncthreads();
-      if (grp < 3) {
-        if (!p.jacobi || p.want_sdiag) {
-          for (int q = grp; q < n; q += 3) {
-            const S* r = rec[q];
-            acc -= double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb] + r[18 + ea] * r[18 + eb]);
-          }
-        }
-      } else if (tid < 252) {
-        const int a = tid - 243;
-        if (lambda != S(0) || p.b_from_records)
-          for (int q = 0; q < n; ++q) acc += double(rec[q][27 + a]);
-      }
-    }
-  }
-  if (grp < 3) red[grp][e] = acc;
-  __syncthreads();
-  if (tid < 81) {
-    const double gram = red[0][tid] + red[1][tid] + red[2][tid];  // = - sum topd^T topd
-    p.blocks[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + (p.jacobi ? 0.0 : gram) +
-                               ((tid / 9 == tid % 9) ? double(lambda) : 0.0));
-    if (p.want_sdiag) p.sdiag[81 * c + tid] = S(double(p.B_mid[81 * c + tid]) + gram);
-  }
-  if (tid >= 243 && tid < 252)
-    p.b[9 * c + (tid - 243)] = S((p.b_from_records ? 0.0 : double(p.b_mid[9 * c + (tid - 243)])) + acc);
-}
 
 // pose_jacobian_scaling = 1 / (eps + sqrt(Jp_diag2))   (linearizor_qr.cpp:130-132)
 template <class S>
 __global__ void k_pose_scaling(const S* __restrict__ d2, S* __restrict__ sc, S eps, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) sc[i] = S(1) / (eps + sqrt(d2[i]));
-}
-
-// ===========================================================================
-// Stage 1, pass B: linearise + scale + Householder-marginalise one landmark per
-// wavefront, write the block, and accumulate the damping-independent parts of
-// the RCS gradient and of the block-diagonal preconditioner.
-//   (linearize_landmark ipp:88-147, scale_Jl_cols ipp:571-587,
-//    perform_qr_householder ipp:717-743, scale_Jp_cols ipp:589-614,
-//    mid-row parts of add_Q2TJp_T_Q2Tr ipp:443-466 and
-//    add_Q2TJp_T_Q2TJp_blockdiag ipp:520-552 / add_Jp_T_Jp_blockdiag ipp:554-569)
-// The three reflectors are applied in compact form: column j of Jp has only two
-// non-zero rows, so v_m^T Jp[:,j] costs 2 FMAs and the rank-3 update is 3 FMAs
-// per element; Q depends on Jl only, so the Jp column scaling commutes with it
-// and is folded in here (pass A made the scale available).
-// LDS per wave: JpL[k][18], V[2k][4] (v0,v1,v2,Q^T r).
-// ===========================================================================
-template <int CH>
-struct ClassCfg {
-  static constexpr int KMAX = 7 * CH;
-  static constexpr int RCH = (2 * KMAX + 63) / 64;
-  static constexpr int WAVE_LDS = 18 * KMAX + 8 * KMAX;  // scalars
-};
-
-template <class S, int CH>
-__global__ __launch_bounds__(256) void k_linearize_qr(Params<S> p, int lm_begin, int lm_end) {
-  using Cfg = ClassCfg<CH>;
-  constexpr int RCH = Cfg::RCH;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s = lm_begin + blockIdx.x * 4 + wave;
-  if (s >= lm_end) return;  // whole wave exits; no block-level barriers below
-  S* JpL = reinterpret_cast<S*>(smem_raw) + size_t(wave) * Cfg::WAVE_LDS;
-  S* V = JpL + 18 * Cfg::KMAX;   // [2k][4]
-
-  const int k = p.lm_k[s];
-  const int64_t o0 = p.lm_obs[s];
-  const int nrows = 2 * k, ncols = 9 * k;
-  const S pwx = p.lms[3 * s], pwy = p.lms[3 * s + 1], pwz = p.lms[3 * s + 2];
-
-  // ---- geometry: one lane per observation --------------------------------
-  for (int i = lane; i < k; i += 64) {
-    const int64_t o = o0 + i;
-    const int cam = p.obs_cam[o];
-    S res[2], Jp[18], Jl[6];
-    const bool valid = linearize_obs<S>(p.cams + 10 * cam, pwx, pwy, pwz, p.obs_xy[2 * o],
-                                        p.obs_xy[2 * o + 1], res, Jp, Jl);
-    S sw = S(0);
-    if (!p.valid_only || valid) {
-      S err, w;
-      error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
-      sw = sqrt(w);
-    }
-#pragma unroll
-    for (int c = 0; c < 18; ++c) JpL[18 * i + c] = sw * Jp[c];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      V[4 * (2 * i + r) + 0] = sw * Jl[3 * r + 0];
-      V[4 * (2 * i + r) + 1] = sw * Jl[3 * r + 1];
-      V[4 * (2 * i + r) + 2] = sw * Jl[3 * r + 2];
-      V[4 * (2 * i + r) + 3] = sw * res[r];
-    }
-  }
-  wave_lds_fence();
-
-  // ---- row lanes: Jl (2k x 3) and residual --------------------------------
-  S jl[RCH][3], rs[RCH];
-  bool rvalid[RCH];
-#pragma unroll
-  for (int rc = 0; rc < RCH; ++rc) {
-    const int r = rc * 64 + lane;
-    rvalid[rc] = r < nrows;
-    jl[rc][0] = rvalid[rc] ? V[4 * r + 0] : S(0);
-    jl[rc][1] = rvalid[rc] ? V[4 * r + 1] : S(0);
-    jl[rc][2] = rvalid[rc] ? V[4 * r + 2] : S(0);
-    rs[rc] = rvalid[rc] ? V[4 * r + 3] : S(0);
-  }
-  wave_lds_fence();
-
-  // Jl column scaling (scale_Jl_cols)
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    S ss = S(0);
-#pragma unroll
-    for (int rc = 0; rc < RCH; ++rc) ss += jl[rc][c] * jl[rc][c];
-    ss = wave_sum(ss);
-    const S sc = S(1) / (p.eps + sqrt(ss));
-#pragma unroll
-    for (int rc = 0; rc < RCH; ++rc) jl[rc][c] *= sc;
-    if (lane == 0) p.jl_scale[3 * s + c] = sc;
-  }
-  // raw (weighted, column-scaled) Jl rows and residual for the back-substitution's l_diff
-#pragma unroll
-  for (int rc = 0; rc < RCH; ++rc) {
-    const int r = rc * 64 + lane;
-    if (rvalid[rc]) {
-      S* dst = p.JlS + 3 * (2 * o0 + r);
-      dst[0] = jl[rc][0];
-      dst[1] = jl[rc][1];
-      dst[2] = jl[rc][2];
-      p.rS[2 * o0 + r] = rs[rc];
-    }
-  }
-
-  // Householder QR of Jl; reflectors v_m kept in registers and in LDS
-  S vm[3][RCH];
-  S tau[3];
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    const S c0 = read_lane(jl[0][m], m);
-    S tail = S(0);
-#pragma unroll
-    for (int rc = 0; rc < RCH; ++rc) {
-      const int r = rc * 64 + lane;
-      tail += (r > m && rvalid[rc]) ? jl[rc][m] * jl[rc][m] : S(0);
-    }
-    tail = wave_sum(tail);
-    S beta, inv;
-    if (tail <= Eps<S>::tiny) {
-      tau[m] = S(0);
-      beta = c0;
-      inv = S(0);
-    } else {
-      beta = sqrt(c0 * c0 + tail);
-      if (c0 >= S(0)) beta = -beta;
-      inv = S(1) / (c0 - beta);
-      tau[m] = (beta - c0) / beta;
-    }
-#pragma unroll
-    for (int rc = 0; rc < RCH; ++rc) {
-      const int r = rc * 64 + lane;
-      vm[m][rc] = (r == m) ? S(1) : ((r > m && rvalid[rc]) ? jl[rc][m] * inv : S(0));
-    }
-    // apply to the remaining Jl columns and to the residual
-#pragma unroll
-    for (int c2 = m + 1; c2 < 3; ++c2) {
-      S d = S(0);
-#pragma unroll
-      for (int rc = 0; rc < RCH; ++rc) d += vm[m][rc] * jl[rc][c2];
-      d = tau[m] * wave_sum(d);
-#pragma unroll
-      for (int rc = 0; rc < RCH; ++rc) jl[rc][c2] -= d * vm[m][rc];
-    }
-    {
-      S d = S(0);
-#pragma unroll
-      for (int rc = 0; rc < RCH; ++rc) d += vm[m][rc] * rs[rc];
-      d = tau[m] * wave_sum(d);
-#pragma unroll
-      for (int rc = 0; rc < RCH; ++rc) rs[rc] -= d * vm[m][rc];
-    }
-#pragma unroll
-    for (int rc = 0; rc < RCH; ++rc) {
-      const int r = rc * 64 + lane;
-      if (r == m) jl[rc][m] = beta;
-      if (r > m) jl[rc][m] = S(0);
-    }
-  }
-  // cross products of the reflectors (compact application)
-  S g10 = S(0), g20 = S(0), g21 = S(0);
-#pragma unroll
-  for (int rc = 0; rc < RCH; ++rc) {
-    g10 += vm[1][rc] * vm[0][rc];
-    g20 += vm[2][rc] * vm[0][rc];
-    g21 += vm[2][rc] * vm[1][rc];
-  }
-  g10 = wave_sum(g10);
-  g20 = wave_sum(g20);
-  g21 = wave_sum(g21);
-
-  // R (upper 3x3), Q^T r -> global; reflectors + Q^T r -> LDS
-  {
-    const S r00 = read_lane(jl[0][0], 0), r01 = read_lane(jl[0][1], 0),
-            r02 = read_lane(jl[0][2], 0), r11 = read_lane(jl[0][1], 1),
-            r12 = read_lane(jl[0][2], 1), r22 = read_lane(jl[0][2], 2);
-    if (lane == 0) {
-      S* R = p.R0 + 6 * s;
-      R[0] = r00;
-      R[1] = r01;
-      R[2] = r02;
-      R[3] = r11;
-      R[4] = r12;
-      R[5] = r22;
-    }
-  }
-#pragma unroll
-  for (int rc = 0; rc < RCH; ++rc) {
-    const int r = rc * 64 + lane;
-    if (rvalid[rc]) {
-      V[4 * r + 0] = vm[0][rc];
-      V[4 * r + 1] = vm[1][rc];
-      V[4 * r + 2] = vm[2][rc];
-      V[4 * r + 3] = rs[rc];
-      S* vh = p.Vh + 4 * (2 * o0 + r);
-      vh[0] = vm[0][rc];
-      vh[1] = vm[1][rc];
-      vh[2] = vm[2][rc];
-      vh[3] = rs[rc];
-    }
-  }
-  if (lane == 0) {
-    p.tauH[3 * s + 0] = tau[0];
-    p.tauH[3 * s + 1] = tau[1];
-    p.tauH[3 * s + 2] = tau[2];
-  }
-  wave_lds_fence();
-
-  // ---- column lanes: apply Q^T to the scaled Jp, stream the block out ------
-  S* Ablk = p.A + p.lm_blk[s];
-  S* T0 = p.top0 + 27 * o0;
-  const int lane9 = lane / 9, comp = lane - 9 * lane9;
-#pragma unroll 1
-  for (int ch = 0; ch < CH; ++ch) {
-    const int islot = 7 * ch + lane9;
-    const bool act = lane < 63 && islot < k;
-    const int i = act ? islot : 0;
-    const int j = 9 * i + comp;
-    const int cam = act ? p.obs_cam[o0 + i] : 0;
-    S m0 = S(0), m1 = S(0);
-    if (act) {
-      const S d = p.pose_scaling[9 * cam + comp];
-      m0 = JpL[18 * i + comp] * d;
-      m1 = JpL[18 * i + 9 + comp] * d;
-    }
-    const S va0 = V[4 * (2 * i) + 0], va1 = V[4 * (2 * i) + 1], va2 = V[4 * (2 * i) + 2];
-    const S vb0 = V[4 * (2 * i + 1) + 0], vb1 = V[4 * (2 * i + 1) + 1],
-            vb2 = V[4 * (2 * i + 1) + 2];
-    const S c0 = tau[0] * (va0 * m0 + vb0 * m1);
-    const S c1 = tau[1] * (va1 * m0 + vb1 * m1 - c0 * g10);
-    const S c2 = tau[2] * (va2 * m0 + vb2 * m1 - c0 * g20 - c1 * g21);
-    S bm = S(0);
-    for (int r = 0; r < nrows; ++r) {
-      const S w0 = V[4 * r + 0], w1 = V[4 * r + 1], w2 = V[4 * r + 2], cr = V[4 * r + 3];
-      S val = -(c0 * w0 + c1 * w1 + c2 * w2);
-      if (r == 2 * i) val += m0;
-      if (r == 2 * i + 1) val += m1;
-      if (r < 3) {
-        if (act) T0[27 * i + 9 * r + comp] = val;  // [i][r][comp]
-      } else {
-        if (act && !p.implicit) Ablk[size_t(r - 3) * ncols + j] = val;
-        bm += val * cr;
-      }
-    }
-    if (act) {
-      // landmark-damping rows start out as zeros (the implicit-Q operator never reads the
-      // dense block of a k <= 112 landmark: it is not written then)
-      if (!p.implicit) {
-        Ablk[size_t(nrows - 3) * ncols + j] = S(0);
-        Ablk[size_t(nrows - 2) * ncols + j] = S(0);
-        Ablk[size_t(nrows - 1) * ncols + j] = S(0);
-      }
-      p.JpS[(o0 + i) * 18 + comp] = m0;
-      p.JpS[(o0 + i) * 18 + 9 + comp] = m1;
-      p.bmO[(o0 + i) * 9 + comp] = bm;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// The same for small landmarks: k <= 7 (2k <= 14 rows): FOUR landmarks per wavefront in the
-// geometry and Householder phases, one per 16-lane DPP row, so that the reductions are
-// row-local (4 DPP steps); k <= 14: TWO landmarks, 32 lanes each (one more step); and the ~800 instructions of those phases are
-// shared by four landmarks; the column phase then runs once per landmark as above.
-// (One wavefront per 2-3 observation landmark executes at 5-20 % lane utilisation.)
-// ---------------------------------------------------------------------------
-// sum over an aligned group of SEG lanes (16: one DPP row; 32: two rows)
-template <class S, int SEG>
-__device__ __forceinline__ S seg_row_sum(S v) {
-  v = row_sum(v);
-  if (SEG == 32) v += __shfl_xor(v, 16);
-  return v;
-}
-
-template <class S, int CH>
-__global__ __launch_bounds__(256) void k_linearize_qr_packed(Params<S> p, int lm_begin, int lm_end) {
-  static_assert(CH == 1 || CH == 2, "k <= 7: four landmarks per wavefront, k <= 14: two");
-  using Cfg = ClassCfg<CH>;
-  constexpr int SEG = 16 * CH, P = 64 / SEG;  // lanes per landmark, landmarks per wavefront
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int g = lane / SEG, sl = lane & (SEG - 1), row_base = lane & ~(SEG - 1);
-  const int s_first = lm_begin + (blockIdx.x * 4 + wave) * P;
-  if (s_first >= lm_end) return;  // whole wave exits; no block-level barriers below
-  const int s = s_first + g;
-  const bool lm_ok = s < lm_end;
-  S* JpL = reinterpret_cast<S*>(smem_raw) + size_t(wave * P + g) * Cfg::WAVE_LDS;
-  S* V = JpL + 18 * Cfg::KMAX;  // [2k][4]
-
-  const int k = lm_ok ? p.lm_k[s] : 0;
-  const int64_t o0 = lm_ok ? p.lm_obs[s] : 0;
-  const int nrows = 2 * k;
-
-  // ---- geometry: lane sl of the row = observation sl ----------------------------
-  if (sl < k) {
-    const S pwx = p.lms[3 * s], pwy = p.lms[3 * s + 1], pwz = p.lms[3 * s + 2];
-    const int i = sl;
-    const int64_t o = o0 + i;
-    const int cam = p.obs_cam[o];
-    S res[2], Jp[18], Jl[6];
-    const bool valid = linearize_obs<S>(p.cams + 10 * cam, pwx, pwy, pwz, p.obs_xy[2 * o],
-                                        p.obs_xy[2 * o + 1], res, Jp, Jl);
-    S sw = S(0);
-    if (!p.valid_only || valid) {
-      S err, w;
-      error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
-      sw = sqrt(w);
-    }
-#pragma unroll
-    for (int c = 0; c < 18; ++c) JpL[18 * i + c] = sw * Jp[c];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      V[4 * (2 * i + r) + 0] = sw * Jl[3 * r + 0];
-      V[4 * (2 * i + r) + 1] = sw * Jl[3 * r + 1];
-      V[4 * (2 * i + r) + 2] = sw * Jl[3 * r + 2];
-      V[4 * (2 * i + r) + 3] = sw * res[r];
-    }
-  }
-  wave_lds_fence();
-
-  // ---- row lanes: lane sl of the row = block row sl ------------------------------
-  const bool rvalid = sl < nrows;
-  const int r = sl;
-  S jl[3], rs;
-  jl[0] = rvalid ? V[4 * r + 0] : S(0);
-  jl[1] = rvalid ? V[4 * r + 1] : S(0);
-  jl[2] = rvalid ? V[4 * r + 2] : S(0);
-  rs = rvalid ? V[4 * r + 3] : S(0);
-  wave_lds_fence();
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const S ss = seg_row_sum<S, SEG>(jl[c] * jl[c]);
-    const S sc = S(1) / (p.eps + sqrt(ss));
-    jl[c] *= sc;
-    if (sl == 0 && lm_ok) p.jl_scale[3 * s + c] = sc;
-  }
-  if (rvalid) {
-    S* dst = p.JlS + 3 * (2 * o0 + r);
-    dst[0] = jl[0];
-    dst[1] = jl[1];
-    dst[2] = jl[2];
-    p.rS[2 * o0 + r] = rs;
-  }
-  S vm[3], tau[3];
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    const S c0 = __shfl(jl[m], row_base + m);
-    const S tail = seg_row_sum<S, SEG>((r > m && rvalid) ? jl[m] * jl[m] : S(0));
-    S beta, inv;
-    if (tail <= Eps<S>::tiny) {
-      tau[m] = S(0);
-      beta = c0;
-      inv = S(0);
-    } else {
-      beta = sqrt(c0 * c0 + tail);
-      if (c0 >= S(0)) beta = -beta;
-      inv = S(1) / (c0 - beta);
-      tau[m] = (beta - c0) / beta;
-    }
-    vm[m] = (r == m) ? S(1) : ((r > m && rvalid) ? jl[m] * inv : S(0));
-#pragma unroll
-    for (int c2 = m + 1; c2 < 3; ++c2) {
-      const S d = tau[m] * seg_row_sum<S, SEG>(vm[m] * jl[c2]);
-      jl[c2] -= d * vm[m];
-    }
-    {
-      const S d = tau[m] * seg_row_sum<S, SEG>(vm[m] * rs);
-      rs -= d * vm[m];
-    }
-    if (r == m) jl[m] = beta;
-    if (r > m) jl[m] = S(0);
-  }
-  const S g10 = seg_row_sum<S, SEG>(vm[1] * vm[0]), g20 = seg_row_sum<S, SEG>(vm[2] * vm[0]), g21 = seg_row_sum<S, SEG>(vm[2] * vm[1]);
-  {
-    const S r00 = __shfl(jl[0], row_base), r01 = __shfl(jl[1], row_base), r02 = __shfl(jl[2], row_base),
-            r11 = __shfl(jl[1], row_base + 1), r12 = __shfl(jl[2], row_base + 1),
-            r22 = __shfl(jl[2], row_base + 2);
-    if (sl == 0 && lm_ok) {
-      S* R = p.R0 + 6 * s;
-      R[0] = r00;
-      R[1] = r01;
-      R[2] = r02;
-      R[3] = r11;
-      R[4] = r12;
-      R[5] = r22;
-      p.tauH[3 * s + 0] = tau[0];
-      p.tauH[3 * s + 1] = tau[1];
-      p.tauH[3 * s + 2] = tau[2];
-    }
-  }
-  if (rvalid) {
-    V[4 * r + 0] = vm[0];
-    V[4 * r + 1] = vm[1];
-    V[4 * r + 2] = vm[2];
-    V[4 * r + 3] = rs;
-    S* vh = p.Vh + 4 * (2 * o0 + r);
-    vh[0] = vm[0];
-    vh[1] = vm[1];
-    vh[2] = vm[2];
-    vh[3] = rs;
-  }
-  wave_lds_fence();
-
-  // ---- column lanes, one landmark of the wave after the other ---------------------
-  const int lane9 = lane / 9, comp = lane - 9 * lane9;
-#pragma unroll
-  for (int gg = 0; gg < P; ++gg) {
-    const int s2 = s_first + gg;
-    if (s2 >= lm_end) break;  // wave-uniform
-    const int k2 = p.lm_k[s2];
-    const int64_t o2 = p.lm_obs[s2];
-    const int nrows2 = 2 * k2, ncols2 = 9 * k2;
-    const S t0 = read_lane(tau[0], SEG * gg), t1 = read_lane(tau[1], SEG * gg), t2 = read_lane(tau[2], SEG * gg);
-    const S h10 = read_lane(g10, SEG * gg), h20 = read_lane(g20, SEG * gg), h21 = read_lane(g21, SEG * gg);
-    const S* JpL2 = reinterpret_cast<S*>(smem_raw) + size_t(wave * P + gg) * Cfg::WAVE_LDS;
-    const S* V2 = JpL2 + 18 * Cfg::KMAX;
-    S* Ablk = p.A + p.lm_blk[s2];
-    S* T0 = p.top0 + 27 * o2;
-#pragma unroll 1
-    for (int ch = 0; ch < CH; ++ch) {
-    const int islot = 7 * ch + lane9;
-    const bool act = lane < 63 && islot < k2;
-    const int i = act ? islot : 0;
-    const int j = 9 * i + comp;
-    const int cam = act ? p.obs_cam[o2 + i] : 0;
-    S m0 = S(0), m1 = S(0);
-    if (act) {
-      const S d = p.pose_scaling[9 * cam + comp];
-      m0 = JpL2[18 * i + comp] * d;
-      m1 = JpL2[18 * i + 9 + comp] * d;
-    }
-    const S va0 = V2[4 * (2 * i) + 0], va1 = V2[4 * (2 * i) + 1], va2 = V2[4 * (2 * i) + 2];
-    const S vb0 = V2[4 * (2 * i + 1) + 0], vb1 = V2[4 * (2 * i + 1) + 1], vb2 = V2[4 * (2 * i + 1) + 2];
-    const S c0 = t0 * (va0 * m0 + vb0 * m1);
-    const S c1 = t1 * (va1 * m0 + vb1 * m1 - c0 * h10);
-    const S c2 = t2 * (va2 * m0 + vb2 * m1 - c0 * h20 - c1 * h21);
-    S bm = S(0);
-    for (int rr = 0; rr < nrows2; ++rr) {
-      const S w0 = V2[4 * rr + 0], w1 = V2[4 * rr + 1], w2 = V2[4 * rr + 2], cr = V2[4 * rr + 3];
-      S val = -(c0 * w0 + c1 * w1 + c2 * w2);
-      if (rr == 2 * i) val += m0;
-      if (rr == 2 * i + 1) val += m1;
-      if (rr < 3) {
-        if (act) T0[27 * i + 9 * rr + comp] = val;  // [i][r][comp]
-      } else {
-        if (act && !p.implicit) Ablk[size_t(rr - 3) * ncols2 + j] = val;
-        bm += val * cr;
-      }
-    }
-    if (act) {
-      if (!p.implicit) {  // landmark-damping rows start out as zeros
-        Ablk[size_t(nrows2 - 3) * ncols2 + j] = S(0);
-        Ablk[size_t(nrows2 - 2) * ncols2 + j] = S(0);
-        Ablk[size_t(nrows2 - 1) * ncols2 + j] = S(0);
-      }
-      p.JpS[(o2 + i) * 18 + comp] = m0;
-      p.JpS[(o2 + i) * 18 + 9 + comp] = m1;
-      p.bmO[(o2 + i) * 9 + comp] = bm;
-    }
-    }  // ch
-  }
-}
-
-// ===========================================================================
-// Stage 2: landmark damping by 6 Givens rotations against the stored undamped
-// top rows (set_landmark_damping, ipp:149-210). Because the linearisation is
-// kept undamped (top0, R0, Q1^T r), changing lambda needs no "undo" pass; the
-// rotations only touch the three top rows and the three extra rows, which is
-// exactly what gets recomputed here.
-// (get_Q2TJp_T_Q2Tr / get_Q2TJp_T_Q2TJp_blockdiag: see k_cam_stage2.)
-// Two fully occupied passes instead of one wavefront per landmark (which runs at 30 %
-// lane utilisation for the 2-3 observation landmarks that dominate BAL problems):
-//   k_stage2_landmark  one thread per landmark: the 6 rotations from R0, damped R / Q1^T r,
-//                      damping-row residual, Z for the implicit-Q operator
-//   k_stage2_cols      one thread per (observation, pose component): rotates the stored top0
-//                      column into topd, the three damping rows of the dense block and their part of b
-// ===========================================================================
-template <class S>
-__global__ __launch_bounds__(256) void k_stage2_landmark(Params<S> p, S lambda) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= p.n_lms) return;
-  const int64_t o0 = p.lm_obs[s];
-  // [R | q] rows 0..2 and the damping rows [sqrt(lambda) I | 0]
-  S T[3][4], D[3][4];
-  {
-    const S* R = p.R0 + 6 * s;
-    T[0][0] = R[0];
-    T[0][1] = R[1];
-    T[0][2] = R[2];
-    T[1][0] = S(0);
-    T[1][1] = R[3];
-    T[1][2] = R[4];
-    T[2][0] = S(0);
-    T[2][1] = S(0);
-    T[2][2] = R[5];
-    T[0][3] = p.Vh[4 * (2 * o0 + 0) + 3];  // Q1^T r = first three entries of Q^T r
-    T[1][3] = p.Vh[4 * (2 * o0 + 1) + 3];
-    T[2][3] = p.Vh[4 * (2 * o0 + 2) + 3];
-  }
-  const S sl = sqrt(lambda);
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) D[a][b] = (a == b) ? sl : S(0);
-  S gc[6], gs[6];
-  {
-    int idx = 0;
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-#pragma unroll
-      for (int m = 0; m <= n; ++m) {
-        S c = S(1), sn = S(0);
-        if (lambda != S(0)) make_givens<S>(T[n][n], D[n - m][n], c, sn);
-        gc[idx] = c;
-        gs[idx] = sn;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const S x = D[n - m][b], y = T[n][b];
-          D[n - m][b] = c * x + sn * y;
-          T[n][b] = -sn * x + c * y;
-        }
-        ++idx;
-      }
-    }
-  }
-  {
-    // one 64-byte record per landmark for the column pass: c[6], s[6], damping-row residual[3]
-    S* grec = p.givens + 16 * size_t(s);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      grec[i] = gc[i];
-      grec[6 + i] = gs[i];
-    }
-    grec[12] = D[0][3];
-    grec[13] = D[1][3];
-    grec[14] = D[2][3];
-    grec[15] = S(0);
-  }
-  S* R = p.Rd + 6 * s;
-  R[0] = T[0][0];
-  R[1] = T[0][1];
-  R[2] = T[0][2];
-  R[3] = T[1][1];
-  R[4] = T[1][2];
-  R[5] = T[2][2];
-  p.q1trd[3 * s + 0] = T[0][3];
-  p.q1trd[3 * s + 1] = T[1][3];
-  p.q1trd[3 * s + 2] = T[2][3];
-  p.damp_r[3 * s + 0] = D[0][3];
-  p.damp_r[3 * s + 1] = D[1][3];
-  p.damp_r[3 * s + 2] = D[2][3];
-  if (!p.implicit) return;
-  // Z: what "apply the 6 damping rotations, drop the three Q1 rows, rotate back"
-  // does to the top three entries of a vector (the three extra rows start at 0
-  // and are discarded afterwards). Used by the implicit-Q operator.
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    S u[3] = {S(0), S(0), S(0)}, e[3] = {S(0), S(0), S(0)};
-    u[j] = S(1);
-    int idx = 0;
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-#pragma unroll
-      for (int m = 0; m <= n; ++m) {
-        const S x = e[n - m], y = u[n];
-        e[n - m] = gc[idx] * x + gs[idx] * y;
-        u[n] = -gs[idx] * x + gc[idx] * y;
-        ++idx;
-      }
-    }
-    u[0] = u[1] = u[2] = S(0);
-#pragma unroll
-    for (int n = 2; n >= 0; --n) {
-#pragma unroll
-      for (int m = n; m >= 0; --m) {
-        --idx;
-        const S x = e[n - m], y = u[n];
-        e[n - m] = gc[idx] * x - gs[idx] * y;
-        u[n] = gs[idx] * x + gc[idx] * y;
-      }
-    }
-    p.Zd[9 * s + 0 + j] = u[0];
-    p.Zd[9 * s + 3 + j] = u[1];
-    p.Zd[9 * s + 6 + j] = u[2];
-  }
-}
-
-template <class S>
-__global__ __launch_bounds__(256) void k_stage2_cols(Params<S> p, int64_t o_begin, int64_t n_obs) {
-  const int64_t t = 9 * o_begin + int64_t(blockIdx.x) * 256 + threadIdx.x;
-  if (t >= 9 * n_obs) return;
-  const int64_t o = t / 9;
-  const int comp = int(t - 9 * o);
-  const int s = p.obs_lm[o];
-  // the landmark's record as four 16-byte loads (the pass is bound by the number of vector
-  // memory instructions, not by bytes)
-  S g[16];
-  {
-    using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
-    const V4* __restrict__ src = reinterpret_cast<const V4*>(p.givens + 16 * size_t(s));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const V4 v = src[q];
-      g[4 * q] = v.x;
-      g[4 * q + 1] = v.y;
-      g[4 * q + 2] = v.z;
-      g[4 * q + 3] = v.w;
-    }
-  }
-  const S* __restrict__ T0 = p.top0 + 27 * o;
-  S tt[3] = {T0[comp], T0[9 + comp], T0[18 + comp]}, d[3] = {S(0), S(0), S(0)};
-  {
-    int idx = 0;
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-#pragma unroll
-      for (int m = 0; m <= n; ++m) {
-        const S c = g[idx], sn = g[6 + idx];
-        const S x = d[n - m], y = tt[n];
-        d[n - m] = c * x + sn * y;
-        tt[n] = -sn * x + c * y;
-        ++idx;
-      }
-    }
-  }
-  S* Td = p.topd + kTd * o;
-  Td[comp] = tt[0];
-  Td[9 + comp] = tt[1];
-  Td[18 + comp] = tt[2];
-  // the damping rows' part of b (add_Q2TJp_T_Q2Tr on rows 2k-3..2k-1), summed camera-major later
-  const S bd = d[0] * g[12] + d[1] * g[13] + d[2] * g[14];
-  Td[27 + comp] = p.b_from_records ? p.bmO[9 * o + comp] + bd : bd;
-  const int k = p.lm_k[s];
-  if (p.implicit && k <= 112) return;  // dense block unused (only the k > 112 kernels read it)
-  const int nrows = 2 * k, ncols = 9 * k;
-  S* Ablk = p.A + p.lm_blk[s];
-  const int j = 9 * int(o - p.lm_obs[s]) + comp;
-  Ablk[size_t(nrows - 3) * ncols + j] = d[0];
-  Ablk[size_t(nrows - 2) * ncols + j] = d[1];
-  Ablk[size_t(nrows - 1) * ncols + j] = d[2];
-}
-
-// ===========================================================================
-// H*x = sum_l A_l^T (A_l x_l)  — the dominant kernel
-// (add_Q2TJp_T_Q2TJp_mult_x ipp:400-441 via get_Q2TJp_T_Q2TJp_mult_x_v3,
-//  linearization_qr.hpp:406-429). A is read exactly once: a row lives in
-// registers between the dot product (DPP reduction) and the rank-1 update.
-// ===========================================================================
-template <class S, int CH, int U>
-__global__ __launch_bounds__(256) void k_hx(Params<S> p, int lm_begin, int lm_end,
-                                            const S* __restrict__ x, S* __restrict__ y,
-                                            const int* __restrict__ done_flag) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s = lm_begin + blockIdx.x * 4 + wave;
-  if (s >= lm_end) return;
-  if (done_flag && *done_flag) return;  // PCG already terminated (host polls lazily)
-  y = scatter_replica(p, y);
-  const int k = p.lm_k[s];
-  const int64_t o0 = p.lm_obs[s];
-  const int nrows = 2 * k, ncols = 9 * k;
-  const S* __restrict__ Ablk = p.A + p.lm_blk[s];
-
-  S xr[CH], yr[CH];
-  int yidx[CH];
-  bool act[CH];
-  const int lane9 = lane / 9, comp = lane - 9 * lane9;
-#pragma unroll
-  for (int ch = 0; ch < CH; ++ch) {
-    const int islot = 7 * ch + lane9;
-    act[ch] = lane < 63 && islot < k;
-    const int cam = act[ch] ? p.obs_cam[o0 + islot] : 0;
-    yidx[ch] = 9 * cam + comp;
-    xr[ch] = act[ch] ? x[yidx[ch]] : S(0);
-    yr[ch] = S(0);
-  }
-  int r = 0;
-  for (; r + U <= nrows; r += U) {
-    S a[U][CH];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int ch = 0; ch < CH; ++ch)
-        a[u][ch] = act[ch] ? Ablk[size_t(r + u) * ncols + ch * 63 + lane] : S(0);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      S d = S(0);
-#pragma unroll
-      for (int ch = 0; ch < CH; ++ch) d += a[u][ch] * xr[ch];
-      const S t = wave_sum(d);
-#pragma unroll
-      for (int ch = 0; ch < CH; ++ch) yr[ch] += a[u][ch] * t;
-    }
-  }
-  for (; r < nrows; ++r) {
-    S a[CH];
-    S d = S(0);
-#pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {
-      a[ch] = act[ch] ? Ablk[size_t(r) * ncols + ch * 63 + lane] : S(0);
-      d += a[ch] * xr[ch];
-    }
-    const S t = wave_sum(d);
-#pragma unroll
-    for (int ch = 0; ch < CH; ++ch) yr[ch] += a[ch] * t;
-  }
-#pragma unroll
-  for (int ch = 0; ch < CH; ++ch)
-    if (act[ch]) atomic_add(y + yidx[ch], yr[ch]);
 }
 
 // ===========================================================================
@@ -1454,7 +334,6 @@ __global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, ImplicitTiles 
   // the PCG "done" flag is fetched alongside the data and only gates the scatter, so
   // it does not add a memory round trip in front of the loads
   const int done = done_flag ? *done_flag : 0;
-  y = scatter_replica(p, y);
   S* yb = ybuf[wave];
   int* cb = cbuf[wave];
   if (T >= it.tile_begin[4])
@@ -1543,18 +422,11 @@ __device__ __forceinline__ void hx_tile_load(const Params<S>& p, const ImplicitT
 // (row 2i takes components 0,2,4,6,8, row 2i+1 takes 1,3,5,7).
 // ---------------------------------------------------------------------------
 template <class S, int P2>
-__device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int cam, int lane, double* ylds, int dbg,
+__device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int cam, int lane, double* ylds,
                                                     int cam_lo, int win, S* __restrict__ y,
                                                     const S* __restrict__ dout) {
   const int r = lane & (P2 - 1);
   const bool act = cam >= 0;
-  if (dbg == 2) {
-    S acc = d.v0 + d.v1 + d.v2 + d.t0 + d.t1 + d.t2 + d.z0 + d.z1 + d.z2;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) acc += d.jp[c] + d.xc[c];
-    if (acc == S(1.2345e30)) ylds[0] = double(acc);
-    return;
-  }
   S u = S(0);
 #pragma unroll
   for (int c = 0; c < 9; ++c) u += d.jp[c] * d.xc[c];
@@ -1589,7 +461,7 @@ __device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int 
       const S so = vo + dpp_mov0<0xb1>(vo);
       mine = par ? so : se;
     }
-    if (act && (q < 4 || par == 0) && (dbg == 0 || mine == S(1.2345e30))) {
+    if (act && (q < 4 || par == 0)) {
       if (inside)
         lds_atomic_add(yc + 2 * q, double(mine));
       else
@@ -1658,11 +530,11 @@ __global__ __launch_bounds__(NT) void k_hx_implicit_lds(Params<S> p, ImplicitTil
     hx_tile_load(p, it, TA, camA, rowA, lane, x, dA);
     auto compute = [&](int T, const HxTileData<S>& d, int cam) {
       switch (hx_tile_class(it, T)) {
-        case 0: hx_tile_compute_lds<S, 4>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y, dout); break;
-        case 1: hx_tile_compute_lds<S, 8>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y, dout); break;
-        case 2: hx_tile_compute_lds<S, 16>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y, dout); break;
-        case 3: hx_tile_compute_lds<S, 32>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y, dout); break;
-        default: hx_tile_compute_lds<S, 64>(d, cam, lane, ylds, p.hx_debug, cam_lo, win, y, dout); break;
+        case 0: hx_tile_compute_lds<S, 4>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
+        case 1: hx_tile_compute_lds<S, 8>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
+        case 2: hx_tile_compute_lds<S, 16>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
+        case 3: hx_tile_compute_lds<S, 32>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
+        default: hx_tile_compute_lds<S, 64>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
       }
     };
     for (;;) {
@@ -1713,7 +585,6 @@ __global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_be
   const int s = lm_begin + blockIdx.x * 4 + wave;
   if (s >= lm_end) return;
   if (done_flag && *done_flag) return;
-  y = scatter_replica(p, y);
   const int k = p.lm_k[s];
   const int64_t o0 = p.lm_obs[s];
   S jp[RCH][9], u[RCH], v[3][RCH];
@@ -1794,156 +665,6 @@ __global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_be
 }
 
 // ===========================================================================
-// H*x for SMALL landmarks (k <= 7): LDS-staged batches.
-// One wavefront per 0.3-3.5 KB landmark is latency bound (profiles/README.md),
-// so a workgroup takes G consecutive landmarks of the SAME k — their blocks are
-// contiguous in HBM because landmarks are sorted by k — copies the whole
-// G x (2k x 9k) region into LDS with 16-byte coalesced loads, then
-//   phase 1: thread (g, row i):  t[g][i] = A_g[i,:] . x_g      (9k LDS reads)
-//   phase 2: thread (g, col j):  y[g][j] = A_g[:,j] . t[g][:]  (2k LDS reads)
-// and scatter-adds y (9 consecutive threads <-> 9 consecutive floats).
-// A is read from HBM exactly once; no cross-lane reductions at all.
-// ===========================================================================
-struct SmallBatch {
-  int s0;       // first (sorted) landmark of the super-batch
-  int G;        // landmarks per LDS batch, G * 2k <= 256
-  int K;        // observations per landmark (2..7)
-  int count;    // landmarks in the super-batch (processed G at a time)
-  int64_t blk;  // = lm_blk[s0]: offset of the first block in A
-  int64_t obs;  // = lm_obs[s0]: first observation
-};
-
-// One workgroup walks a super-batch G landmarks at a time. The global loads of
-// batch b+1 (A through registers, camera indices, x) are in flight while batch b
-// is being reduced out of LDS, so the workgroup keeps ~16 KB outstanding all the
-// time instead of only during its prologue.
-template <class S, int K>
-__device__ __forceinline__ void hx_small_body(const Params<S>& p, const SmallBatch d,
-                                              const S* __restrict__ x, S* __restrict__ y,
-                                              char* smem) {
-  constexpr int NC = 9 * K, NR = 2 * K, BLK = (NR * NC + 3) / 4 * 4;
-  constexpr int NLD = 4;  // host caps a batch at NLD x 256 x 16 B of A
-  constexpr int NG = 5;   // G * NC <= 64 * 18 = 1152 < NG * 256
-  const int tid = threadIdx.x;
-  const int G = d.G;
-  S* Al = reinterpret_cast<S*>(smem);
-  S* xs = Al + G * BLK;
-  S* ts = xs + G * NC;
-  int* yidx = reinterpret_cast<int*>(ts + 256);
-  const int nb = (d.count + G - 1) / G;
-
-  uint4 buf[NLD];
-  int idx[NG];
-  S xv[NG];
-
-  auto issue_idx_and_A = [&](int b) {
-    const int gb = min(G, d.count - b * G);
-    const int64_t o0 = d.obs + int64_t(b) * G * K;
-#pragma unroll
-    for (int u = 0; u < NG; ++u) {
-      const int e = u * 256 + tid;
-      idx[u] = 0;
-      if (e < gb * NC) {
-        const int g = e / NC, j = e - NC * g;
-        const int i = j / 9;
-        idx[u] = p.obs_cam[o0 + g * K + i];
-      }
-    }
-    const uint4* src = reinterpret_cast<const uint4*>(p.A + d.blk + int64_t(b) * G * BLK);
-    const int n16 = gb * BLK * int(sizeof(S)) / 16;
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int q = u * 256 + tid;
-      buf[u] = (q < n16) ? src[q] : uint4{0, 0, 0, 0};
-    }
-  };
-  auto issue_x = [&](int b) {
-    const int gb = min(G, d.count - b * G);
-#pragma unroll
-    for (int u = 0; u < NG; ++u) {
-      const int e = u * 256 + tid;
-      const int j = e % NC;
-      idx[u] = 9 * idx[u] + (j % 9);
-      xv[u] = (e < gb * NC) ? x[idx[u]] : S(0);
-    }
-  };
-  auto store_lds = [&](int b) {
-    const int gb = min(G, d.count - b * G);
-    uint4* dst = reinterpret_cast<uint4*>(Al);
-    const int n16 = gb * BLK * int(sizeof(S)) / 16;
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int q = u * 256 + tid;
-      if (q < n16) dst[q] = buf[u];
-    }
-#pragma unroll
-    for (int u = 0; u < NG; ++u) {
-      const int e = u * 256 + tid;
-      if (e < gb * NC) {
-        yidx[e] = idx[u];
-        xs[e] = xv[u];
-      }
-    }
-  };
-
-  issue_idx_and_A(0);
-  issue_x(0);
-  for (int b = 0; b < nb; ++b) {
-    const int gb = min(G, d.count - b * G);
-    store_lds(b);
-    __syncthreads();
-    const bool more = b + 1 < nb;
-    if (more) issue_idx_and_A(b + 1);  // stays in flight during the two phases below
-    // rows: t = A x  (column order rotated per thread when 9k is even so that
-    // the 9k-strided rows do not collide on LDS banks)
-    if (tid < gb * NR) {
-      const int g = tid / NR, i = tid - NR * g;
-      const S* row = Al + g * BLK + i * NC;
-      const S* xr = xs + g * NC;
-      int c = (K % 2 == 0) ? tid % NC : 0;
-      S acc = S(0);
-#pragma unroll 9
-      for (int jj = 0; jj < NC; ++jj) {
-        acc += row[c] * xr[c];
-        c = (c + 1 == NC) ? 0 : c + 1;
-      }
-      ts[tid] = acc;
-    }
-    __syncthreads();
-    if (more) issue_x(b + 1);  // camera indices have arrived; A may still be in flight
-    // columns: y = A^T t, scatter
-    for (int e = tid; e < gb * NC; e += 256) {
-      const int g = e / NC, j = e - NC * g;
-      const S* col = Al + g * BLK + j;
-      const S* tv = ts + g * NR;
-      S acc = S(0);
-#pragma unroll
-      for (int i = 0; i < NR; ++i) acc += col[i * NC] * tv[i];
-      atomic_add(y + yidx[e], acc);
-    }
-    __syncthreads();
-  }
-}
-
-template <class S>
-__global__ __launch_bounds__(256) void k_hx_small(Params<S> p, const SmallBatch* __restrict__ batches,
-                                                  const S* __restrict__ x, S* __restrict__ y,
-                                                  const int* __restrict__ done_flag) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (done_flag && *done_flag) return;  // PCG already terminated (host polls lazily)
-  y = scatter_replica(p, y);
-  const SmallBatch d = batches[blockIdx.x];
-  switch (d.K) {
-    case 2: hx_small_body<S, 2>(p, d, x, y, smem_raw); break;
-    case 3: hx_small_body<S, 3>(p, d, x, y, smem_raw); break;
-    case 4: hx_small_body<S, 4>(p, d, x, y, smem_raw); break;
-    case 5: hx_small_body<S, 5>(p, d, x, y, smem_raw); break;
-    case 6: hx_small_body<S, 6>(p, d, x, y, smem_raw); break;
-    default: hx_small_body<S, 7>(p, d, x, y, smem_raw); break;
-  }
-}
-
-// ===========================================================================
 // E0 * v = sum_l (Q1^T Jp)_l^T (Q1^T Jp)_l v_l  with the DAMPED top rows, i.e.
 // Jp^T Jl (Jl^T Jl + lambda I)^-1 Jl^T Jp v of the power-series (PoBA)
 // preconditioner (right_mul_e0, src/rootba/cg/preconditioner.hpp:223-245) —
@@ -1959,7 +680,6 @@ __global__ __launch_bounds__(256) void k_e0(Params<S> p, int lm_begin, int lm_en
   const int s = lm_begin + blockIdx.x * 4 + wave;
   if (s >= lm_end) return;
   if (done_flag && *done_flag) return;
-  y = scatter_replica(p, y);
   const int k = p.lm_k[s];
   const int64_t o0 = p.lm_obs[s];
   const S* __restrict__ Td = p.topd + kTd * o0;
@@ -2011,28 +731,16 @@ __global__ __launch_bounds__(256) void k_bs_obs(Params<S> p, const S* __restrict
 #pragma unroll
   for (int c = 0; c < 9; ++c) xv[c] = xc[c];
   S out[5] = {S(0), S(0), S(0), S(0), S(0)};
-  if (p.compact) {
-    // x arrives pre-multiplied by the pose scaling; topd x = W' (Jp D x)
+  // x arrives pre-multiplied by the pose scaling; topd x = W' (Jp D x)
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      out[3] += jp[c] * xv[c];
-      out[4] += jp[9 + c] * xv[c];
-    }
-    const S* __restrict__ w = p.W8 + 8 * (o - p.w8_begin);
-    out[0] = w[0] * out[3] + w[1] * out[4];
-    out[1] = w[2] * out[3] + w[3] * out[4];
-    out[2] = w[4] * out[3] + w[5] * out[4];
-  } else {
-    const S* __restrict__ td = p.topd + kTd * o;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      out[0] += td[c] * xv[c];
-      out[1] += td[9 + c] * xv[c];
-      out[2] += td[18 + c] * xv[c];
-      out[3] += jp[c] * xv[c];
-      out[4] += jp[9 + c] * xv[c];
-    }
+  for (int c = 0; c < 9; ++c) {
+    out[3] += jp[c] * xv[c];
+    out[4] += jp[9 + c] * xv[c];
   }
+  const S* __restrict__ w = p.W8 + 8 * (o - p.w8_begin);
+  out[0] = w[0] * out[3] + w[1] * out[4];
+  out[1] = w[2] * out[3] + w[3] * out[4];
+  out[2] = w[4] * out[3] + w[5] * out[4];
 #pragma unroll
   for (int m = 0; m < 5; ++m) p.bsO[5 * o + m] = out[m];
 }

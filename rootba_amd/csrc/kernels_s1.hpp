@@ -1,38 +1,33 @@
-// kernels_s1.hpp — stage 1 (linearise + marginalise, LinearizationQR::get_stage1,
-// src/rootba/qr/linearization_qr.hpp:634-712) staged BY PARALLELISM for the implicit-Q
-// configuration (the dense 2k x 9k block of a landmark is never materialised there).
+// kernels_s1.hpp — the landmark side of stage 1 (linearise + marginalise, LinearizationQR::get_stage1,
+// src/rootba/qr/linearization_qr.hpp:634-712) and of stage 2 (get_stage2, :716-815), staged BY PARALLELISM.
+// The dense 2k x 9k block of a landmark is never materialised.
 //
 // Round 1 ran geometry, Householder QR and the column pass inside ONE wavefront-per-landmark(s)
-// kernel: 86 % VALU-busy (profiles/r2_pmc_stage1.csv) at 5-40 % lane utilisation, 1.5 ms on
-// venice-1778 — geometry with one lane per observation of a 2-7 observation landmark, a column
-// pass that walks all 2k rows per column. Here every pass runs at the parallelism its work has:
+// kernel: 86 % VALU-busy (profiles/r2_pmc_stage1_round1_kernels.csv) at 5-40 % lane utilisation, 1.5 ms on
+// venice-1778. Here every pass runs at the parallelism its work has:
 //
 //   k_s1_geometry   one THREAD per observation: projection, analytic Jacobians, Huber weight
 //                   (linearize_landmark, landmark_block_base.ipp:88-147). Writes the weighted pose
-//                   Jacobian rows (JpS, still unscaled) and the rows [sqrt(w) Jl | sqrt(w) r] (Vh),
+//                   Jacobian rows (JpS, unscaled) and the rows [sqrt(w) Jl | sqrt(w) r] (Vh),
 //                   transposed through LDS so that both stores are contiguous 16-byte streams.
-//   k_cam_gram      one WORKGROUP per camera (camera-major, fixed order): G_c = sum_obs Jp^T Jp.
-//                   Its diagonal is Jp_diag2 (add_Jp_diag2, ipp:493-518; double accumulation), and
-//                   D_c G_c D_c is the JACOBI block / the minuend of the SCHUR_JACOBI block
-//                   (add_Jp_T_Jp_blockdiag, ipp:554-569): one gather pass over the records instead of a
-//                   second geometry evaluation per observation plus a separate Gram pass.
+//   (camera-major Gram pass: kernels_cam.hpp)
 //   k_s1_qr_tile    one LANE per block row, a landmark = an aligned group of 4..64 lanes (the wave
 //                   tiles of the implicit-Q operator): Jl column scaling (scale_Jl_cols, ipp:571-587),
 //                   Householder QR of the 2k x 3 Jl (perform_qr_householder, ipp:717-743), Q^T r, and the
 //                   per-landmark scalars of the compact reflector application. Only the 4 columns
 //                   [Jl | r] are transformed here - Q depends on Jl alone.
-//   k_s12_cols      one THREAD per observation, run inside the first stage 2 of the linearisation point
-//                   (fused with the landmark-damping rotation of the top rows): column scaling
-//                   (scale_Jp_cols, ipp:589-614, commutes with Q^T), the three top rows Q1^T Jp and the
-//                   Q2 part of b in CLOSED FORM: with Q^T Jp[:, j] = Jp[:, j] - sum_m c_m v_m (three reflectors,
-//                   c_m from two FMAs each because column j has two non-zero rows),
+//   k_s2_obs        stage 2, one THREAD per observation: the six damping rotations of its landmark
+//                   (set_landmark_damping, ipp:165-210) and the observation's stage-2 record WA.
+//   k_s12_cols      one THREAD per observation, ON DEMAND (assembly of the reduced matrix, matrix-free E0
+//                   products): column scaling (scale_Jp_cols, ipp:589-614, commutes with Q^T), the three damped
+//                   top rows Q1^T Jp and the Q2 part of b in CLOSED FORM: with
+//                   Q^T Jp[:, j] = Jp[:, j] - sum_m c_m v_m (three reflectors, c_m from two FMAs each because
+//                   column j has two non-zero rows),
 //                     b_j = sum_{r >= 3} (Q^T Jp)[r, j] (Q^T r)[r]
 //                         = m0 q[2i] + m1 q[2i+1] (rows >= 3 only) - sum_m c_m d_m,   d_m = sum_{r>=3} v_m[r] q[r]
-//                   — the same products as the row-by-row sum, associated per reflector, O(1) per
+//                   - the same products as the row-by-row sum, associated per reflector, O(1) per
 //                   column instead of O(2k).
-//                   The camera-major sum of the b records happens in stage 2's camera pass.
-// Landmarks with more than 112 observations keep the workgroup-per-landmark kernel (kernels_big.hpp),
-// the dense-block configuration (implicit_q = 0) the round-1 kernels (kernels.hpp).
+// Landmarks with more than 112 observations keep a workgroup-per-landmark QR (kernels_big.hpp).
 #pragma once
 
 #include "kernels.hpp"
@@ -96,125 +91,6 @@ __global__ __launch_bounds__(256) void k_s1_geometry(Params<S> p, int64_t n_obs)
     S* dst = p.Vh + 8 * o_base;
     const int nvec = 8 * n_here / N;
     for (int i = tid; i < nvec; i += 256) reinterpret_cast<V*>(dst)[i] = reinterpret_cast<const V*>(sv)[i];
-  }
-}
-
-// ---------------------------------------------------------------------------
-// camera-major Gram pass on the UNSCALED records
-// ---------------------------------------------------------------------------
-// Jp_diag2 in double, fixed order: thread = (group of 28, component)
-template <class S>
-__device__ __forceinline__ void cam_diag2(const Params<S>& p, int c, int64_t t0, int64_t t1, double (*bsum)[9]) {
-  const int tid = threadIdx.x;
-  if (tid < 252) {
-    const int g = tid / 9, a = tid - 9 * g;
-    double acc = 0;
-    int64_t t = t0 + g;
-    for (; t + 3 * 28 < t1; t += 4 * 28) {
-      const int o0 = p.cam_obs[t], o1 = p.cam_obs[t + 28], o2 = p.cam_obs[t + 56], o3 = p.cam_obs[t + 84];
-      const S a0 = p.JpS[int64_t(o0) * 18 + a], b0 = p.JpS[int64_t(o0) * 18 + 9 + a];
-      const S a1 = p.JpS[int64_t(o1) * 18 + a], b1 = p.JpS[int64_t(o1) * 18 + 9 + a];
-      const S a2 = p.JpS[int64_t(o2) * 18 + a], b2 = p.JpS[int64_t(o2) * 18 + 9 + a];
-      const S a3 = p.JpS[int64_t(o3) * 18 + a], b3 = p.JpS[int64_t(o3) * 18 + 9 + a];
-      acc += (double(a0 * a0 + b0 * b0) + double(a1 * a1 + b1 * b1)) +
-             (double(a2 * a2 + b2 * b2) + double(a3 * a3 + b3 * b3));
-    }
-    for (; t < t1; t += 28) {
-      const int o = p.cam_obs[t];
-      const S a0 = p.JpS[int64_t(o) * 18 + a], b0 = p.JpS[int64_t(o) * 18 + 9 + a];
-      acc += double(a0 * a0 + b0 * b0);
-    }
-    bsum[g][a] = acc;
-  }
-}
-
-// float: Gram tile on the matrix cores (exact f32 fmaf chains) from LDS-staged whole records
-// (mfma_xtx_staged); Jp_diag2 from the same staged records, double accumulation, fixed order
-__global__ __launch_bounds__(256) void k_cam_gram_mfma(Params<float> p) {
-  __shared__ float tile[4][16][16];
-  __shared__ double dsum[4][7][9];
-  __shared__ __attribute__((aligned(16))) float stage[4][kCamChunk * 18];
-  const int c = xcd_swizzled_camera(p.n_cams);
-  if (c >= p.n_cams) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int g = lane / 9, a = lane - 9 * g;
-  double accd = 0;
-  acc = mfma_xtx_staged<18, 2, true>(p.JpS, p.cam_obs, t0, t1, wave, lane, acc, stage[wave], true,
-                               [&](int cnt, const float* rec) {
-                                 if (lane < 63)
-                                   for (int r = g; r < cnt; r += 7) {
-                                     const float x0 = rec[r * 18 + a], x1 = rec[r * 18 + 9 + a];
-                                     accd += double(fmaf(x0, x0, __fmul_rn(x1, x1)));  // as in k_cam_stage2_w8_mfma<true>
-                                   }
-                               });
-#pragma unroll
-  for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-  if (lane < 63) dsum[wave][g][a] = accd;
-  __syncthreads();
-  if (tid < 81) {
-    const int i = tid / 9, j = tid - 9 * i;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) v += tile[w][i][j];
-    p.B_mid[81 * c + tid] = v;
-  }
-  if (tid >= 128 && tid < 137) {
-    const int aa = tid - 128;
-    double sum = 0;
-    for (int w = 0; w < 4; ++w)
-      for (int gg = 0; gg < 7; ++gg) sum += dsum[w][gg][aa];
-    p.jp_diag2[9 * c + aa] = float(sum);
-  }
-}
-
-// generic (double): LDS-staged records, double accumulators
-template <class S>
-__global__ __launch_bounds__(256) void k_cam_gram(Params<S> p) {
-  constexpr int TILE = 64, W = 18, NLD = (TILE * W + 255) / 256;
-  __shared__ S rec[TILE][W];
-  __shared__ int olist[TILE];
-  __shared__ double red[3][81];
-  const int c = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
-  double acc = 0;
-  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  for (int64_t base = t0; base < t1; base += TILE) {
-    const int n = int(min<int64_t>(TILE, t1 - base));
-    __syncthreads();
-    if (tid < n) olist[tid] = p.cam_obs[base + tid];
-    __syncthreads();
-    S v[NLD];
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int idx = u * 256 + tid;
-      v[u] = S(0);
-      if (idx < n * W) {
-        const int q = idx / W, f = idx - W * q;
-        v[u] = p.JpS[int64_t(olist[q]) * 18 + f];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int idx = u * 256 + tid;
-      if (idx < n * W) rec[idx / W][idx % W] = v[u];
-    }
-    __syncthreads();
-    if (grp < 3) {
-      for (int q = grp; q < n; q += 3) {
-        const S* r = rec[q];
-        acc += double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb]);
-      }
-    }
-  }
-  if (grp < 3) red[grp][e] = acc;
-  __syncthreads();
-  if (tid < 81) {
-    const double v = red[0][tid] + red[1][tid] + red[2][tid];
-    p.B_mid[81 * c + tid] = S(v);
-    if (tid / 9 == tid % 9) p.jp_diag2[9 * c + tid / 9] = S(v);
   }
 }
 
@@ -476,22 +352,17 @@ __global__ __launch_bounds__(256) void k_s1_qr_wide(Params<S> p, int lm_begin, i
 }
 
 // ---------------------------------------------------------------------------
-// pass C + stage 2 columns, fused: one thread per observation (nine columns in registers).
-// The column pass needs the pose scaling, the first stage 2 after a linearisation needs the column
-// pass's top rows and the damping: like the reference, which scales the block lazily inside the
-// first stage 2 (linearizor_qr.cpp:189-191), the column pass runs THERE and rotates its three top
-// rows straight into the damped ones (set_landmark_damping, ipp:165-210, six Givens rotations per
-// landmark from k_stage2_landmark) - the undamped top rows are never stored. A later stage 2 of the
-// same linearisation point (rejected step, new lambda) re-runs the pass on the already scaled rows.
-// Outputs per observation: the stage-2 record [damped Q1^T Jp 3x9 | Q2 + damping rows' part of b 9] (kTd
-// scalars) and JpS [2][9] (scaled rows, first pass only). The workgroup's 128 observations are consecutive, so
-// the records are staged in LDS and move as contiguous 16-byte streams.
+// The 27 + 9 stage-2 record [damped Q1^T Jp D 3x9 | Q2 + damping rows' part of b 9] (kTd scalars) of every
+// observation for the CURRENT damping, from the unscaled rows and the factors: one thread per observation (nine
+// columns in registers); the three top rows are rotated straight into the damped ones by the landmark's six
+// Givens rotations (k_s2_obs). Only the assembly of the reduced matrix and matrix-free E0 products read these
+// records (Solver::ensure_topd). The workgroup's 128 observations are consecutive, so the records are staged in
+// LDS and move as contiguous 16-byte streams.
 // ---------------------------------------------------------------------------
 constexpr int kS1ColsThreads = 128;
 
 template <class S>
-__global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_t n_obs, int scaled_input,
-                                                             int write_jps) {
+__global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_t n_obs) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
   using V = typename std::conditional<sizeof(S) == 4, float4, double2>::type;
   constexpr int N = 16 / int(sizeof(S)), NT = kS1ColsThreads;
@@ -517,7 +388,7 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
   const V4 va = vh[2 * oc], vb = vh[2 * oc + 1];
   S dsc[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) dsc[c] = scaled_input ? S(1) : p.pose_scaling[9 * cam + c];
+  for (int c = 0; c < 9; ++c) dsc[c] = p.pose_scaling[9 * cam + c];
   const int64_t o0 = p.lm_obs[s];
   const V4* __restrict__ lq = reinterpret_cast<const V4*>(p.LQ + 12 * size_t(s));
   const V4 q0 = lq[0], q1 = lq[1], q2 = lq[2];
@@ -577,8 +448,6 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
       sT[kTd * tid + c] = tt[0];
       sT[kTd * tid + 9 + c] = tt[1];
       sT[kTd * tid + 18 + c] = tt[2];
-      sJ[18 * tid + c] = m0;
-      sJ[18 * tid + 9 + c] = m1;
       // Q2 rows' part of b (add_Q2TJp_T_Q2Tr) + the damping rows' part
       sT[kTd * tid + 27 + c] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
     }
@@ -591,101 +460,23 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
   };
   // (16-byte alignment of the destinations: o_base is a multiple of 128)
   copy_out(p.topd + kTd * o_base, sT, kTd * n_here);
-  // (compact stage 2, p.compact: this kernel only materialises the 27 + 9 record for the assembly of the reduced
-  //  matrix / the matrix-free E0 products, from the UNSCALED rows, which stay as they are: write_jps = 0)
-  if (!scaled_input && write_jps) copy_out(p.JpS + 18 * o_base, sJ, 18 * n_here);
 }
 
 // ---------------------------------------------------------------------------
-// Compact stage 2, landmark side (p.compact): everything the fused pass above computes per observation is LINEAR
-// in the two scaled Jacobian entries (m0, m1) of a column:
+// Stage 2, landmark side, one thread per observation. Everything stage 2 needs per observation is LINEAR in the two
+// scaled Jacobian entries (m0, m1) of a column:
 //   damped top rows    tt[n] = W'[n][0] m0 + W'[n][1] m1          (n = 0..2)
 //   b record           bm    = g[0] m0 + g[1] m1
-// so the eight coefficients are all that has to leave the landmark side: W8 = [W' row-major | g], obtained by
-// running the same closed form on the unit inputs (1, 0) and (0, 1) instead of on nine columns. The Jacobian rows
-// are neither read nor rewritten here: 32 bytes written per observation instead of 216.
+// so eight coefficients (W' 3x2, g) - obtained by running the closed form of k_s12_cols on the unit inputs (1, 0) and
+// (0, 1) - are all that leaves the landmark side; the camera-major pass gets them as the record WA (g and a factor
+// of I - W'^T W', kernels_cam.hpp). Every work-item evaluates the six damping rotations of ITS landmark from R0,
+// Q1^T r and lambda (set_landmark_damping, ipp:165-210; about 250 flops against the ~100 bytes the pass moves per
+// observation - measured faster than a separate thread-per-landmark pass + a 64-byte record load, venice stage 2
+// 0.443 -> 0.402 ms); the work-item of a landmark's FIRST observation also writes the landmark's records (givens,
+// damped R, Q1^T r, damping-row residual, Z).
 // ---------------------------------------------------------------------------
 template <class S>
-__global__ __launch_bounds__(256) void k_s2_w8(Params<S> p, int64_t n_obs) {
-  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
-  const int64_t o = blockIdx.x * int64_t(256) + threadIdx.x;
-  if (o >= n_obs) return;
-  const int s = p.obs_lm[o];
-  const V4* __restrict__ vh = reinterpret_cast<const V4*>(p.Vh);
-  const V4 va = vh[2 * o], vb = vh[2 * o + 1];
-  const int64_t o0 = p.lm_obs[s];
-  const V4* __restrict__ lq = reinterpret_cast<const V4*>(p.LQ + 12 * size_t(s));
-  const V4 q0 = lq[0], q1 = lq[1], q2 = lq[2];
-  const V4 w0 = vh[2 * o0], w1 = vh[2 * o0 + 1], w2 = vh[2 * o0 + 2];
-  S g[16];  // the landmark's damping record: c[6], s[6], damping-row residual[3]
-  {
-    const V4* __restrict__ src = reinterpret_cast<const V4*>(p.givens + 16 * size_t(s));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const V4 v = src[q];
-      g[4 * q] = v.x;
-      g[4 * q + 1] = v.y;
-      g[4 * q + 2] = v.z;
-      g[4 * q + 3] = v.w;
-    }
-  }
-  const int i = int(o - o0);
-  const S tau0 = q0.x, tau1 = q0.y, tau2 = q0.z, g10 = q0.w, g20 = q1.x, g21 = q1.y, d0 = q1.z, d1 = q1.w, d2 = q2.x;
-  S out[2][4];  // [input][tt0 tt1 tt2 bm]
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const S m0 = e == 0 ? S(1) : S(0), m1 = e == 0 ? S(0) : S(1);
-    const S c0 = tau0 * (va.x * m0 + vb.x * m1);
-    const S c1 = tau1 * (va.y * m0 + vb.y * m1 - c0 * g10);
-    const S c2 = tau2 * (va.z * m0 + vb.z * m1 - c0 * g20 - c1 * g21);
-    S tt[3] = {-(c0 * w0.x + c1 * w0.y + c2 * w0.z), -(c0 * w1.x + c1 * w1.y + c2 * w1.z),
-               -(c0 * w2.x + c1 * w2.y + c2 * w2.z)};
-    S bm = -(c0 * d0 + c1 * d1 + c2 * d2);
-    if (i == 0) {
-      tt[0] += m0;
-      tt[1] += m1;
-    } else if (i == 1) {
-      tt[2] += m0;
-      bm += m1 * vb.w;
-    } else {
-      bm += m0 * va.w + m1 * vb.w;
-    }
-    S d[3] = {S(0), S(0), S(0)};
-    int idx = 0;
-#pragma unroll
-    for (int n = 0; n < 3; ++n) {
-#pragma unroll
-      for (int m = 0; m <= n; ++m) {
-        const S cc = g[idx], sn = g[6 + idx];
-        const S x = d[n - m], y = tt[n];
-        d[n - m] = cc * x + sn * y;
-        tt[n] = -sn * x + cc * y;
-        ++idx;
-      }
-    }
-    out[e][0] = tt[0];
-    out[e][1] = tt[1];
-    out[e][2] = tt[2];
-    out[e][3] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
-  }
-  store_cam_record_stage2<S>(p, o, out);
-  if (o >= p.w8_begin) {  // landmarks with k > 32: the two-kernel back-substitution applies W' itself
-    V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * (o - p.w8_begin));
-    dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};
-    dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
-  }
-}
-
-// k_stage2_landmark + k_s2_w8 in ONE pass (RBA_S2_FUSED_LM=1; written in round 2 after the GPU budget was spent,
-// validated on the CPU execution harness of tests/hipemu only, therefore off by default until it has been measured):
-// every observation's work-item evaluates the six damping rotations of ITS landmark from R0, Q1^T r and lambda
-// (the arithmetic of k_stage2_landmark, kernels.hpp, statement for statement - about 250 flops against the ~100
-// bytes the pass moves per observation) instead of loading the 64-byte `givens` record that a separate
-// thread-per-landmark pass wrote; the work-item of a landmark's FIRST observation also writes the landmark's
-// records (givens, damped R, Q1^T r, damping-row residual, Z). One launch and one pass over the per-landmark
-// data less per stage 2.
-template <class S>
-__global__ __launch_bounds__(256) void k_s2_w8_fused(Params<S> p, int64_t n_obs, S lambda) {
+__global__ __launch_bounds__(256) void k_s2_obs(Params<S> p, int64_t n_obs, S lambda) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
   const int64_t o = blockIdx.x * int64_t(256) + threadIdx.x;
   if (o >= n_obs) return;
@@ -697,7 +488,7 @@ __global__ __launch_bounds__(256) void k_s2_w8_fused(Params<S> p, int64_t n_obs,
   const V4 q0 = lq[0], q1 = lq[1], q2 = lq[2];
   const V4 w0 = vh[2 * o0], w1 = vh[2 * o0 + 1], w2 = vh[2 * o0 + 2];
   const int i = int(o - o0);
-  // ---- the landmark's damping (k_stage2_landmark) -----------------------------------------------------------
+  // ---- the landmark's damping -----------------------------------------------------------
   S T[3][4], D[3][4];
   {
     const S* R = p.R0 + 6 * size_t(s);
@@ -719,7 +510,7 @@ __global__ __launch_bounds__(256) void k_s2_w8_fused(Params<S> p, int64_t n_obs,
   for (int a = 0; a < 3; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) D[a][b] = (a == b) ? sl : S(0);
-  S g[16];  // c[6], s[6], damping-row residual[3], 0: the record k_s2_w8 loads
+  S g[16];  // c[6], s[6], damping-row residual[3], 0
   {
     int idx = 0;
 #pragma unroll
@@ -761,7 +552,7 @@ __global__ __launch_bounds__(256) void k_s2_w8_fused(Params<S> p, int64_t n_obs,
     p.damp_r[3 * size_t(s) + 0] = D[0][3];
     p.damp_r[3 * size_t(s) + 1] = D[1][3];
     p.damp_r[3 * size_t(s) + 2] = D[2][3];
-    if (p.implicit) {
+    {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         S u[3] = {S(0), S(0), S(0)}, e[3] = {S(0), S(0), S(0)};
@@ -794,7 +585,7 @@ __global__ __launch_bounds__(256) void k_s2_w8_fused(Params<S> p, int64_t n_obs,
       }
     }
   }
-  // ---- the observation's eight coefficients (k_s2_w8) -------------------------------------------------------
+  // ---- the observation's eight coefficients -------------------------------------------------------
   const S tau0 = q0.x, tau1 = q0.y, tau2 = q0.z, g10 = q0.w, g20 = q1.x, g21 = q1.y, d0 = q1.z, d1 = q1.w, d2 = q2.x;
   S out[2][4];  // [input][tt0 tt1 tt2 bm]
 #pragma unroll
@@ -838,33 +629,6 @@ __global__ __launch_bounds__(256) void k_s2_w8_fused(Params<S> p, int64_t n_obs,
     V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * (o - p.w8_begin));
     dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};
     dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
-  }
-}
-
-// b_mid[c] = sum over the camera's observations of bmO (fixed order, double)
-template <class S>
-__global__ __launch_bounds__(256) void k_cam_bmid(Params<S> p) {
-  __shared__ double bsum[28][9];
-  const int c = blockIdx.x, tid = threadIdx.x;
-  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  if (tid < 252) {
-    const int g = tid / 9, a = tid - 9 * g;
-    double acc = 0;
-    int64_t t = t0 + g;
-    for (; t + 3 * 28 < t1; t += 4 * 28) {
-      const int o0 = p.cam_obs[t], o1 = p.cam_obs[t + 28], o2 = p.cam_obs[t + 56], o3 = p.cam_obs[t + 84];
-      const S v0 = p.bmO[int64_t(o0) * 9 + a], v1 = p.bmO[int64_t(o1) * 9 + a], v2 = p.bmO[int64_t(o2) * 9 + a],
-              v3 = p.bmO[int64_t(o3) * 9 + a];
-      acc += (double(v0) + double(v1)) + (double(v2) + double(v3));
-    }
-    for (; t < t1; t += 28) acc += double(p.bmO[int64_t(p.cam_obs[t]) * 9 + a]);
-    bsum[g][a] = acc;
-  }
-  __syncthreads();
-  if (tid < 9) {
-    double s = 0;
-    for (int g = 0; g < 28; ++g) s += bsum[g][tid];
-    p.b_mid[9 * c + tid] = S(s);
   }
 }
 

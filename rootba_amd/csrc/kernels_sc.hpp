@@ -71,6 +71,43 @@ struct ScParams {
   S huber, eps;
 };
 
+// SC backend, stage 1, pass A (camera-major, geometry re-evaluated per observation): squared column norms of the weighted pose Jacobian
+// (add_Jp_diag2, landmark_block_base.ipp:493-518) and the non-finite check of
+// linearize_landmark (ipp:123-146).
+template <class S>
+__global__ __launch_bounds__(256) void k_sc_jp_diag2(Params<S> p) {
+  __shared__ double sm4[4];
+  const int c = blockIdx.x;
+  S cam[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) cam[i] = p.cams[10 * c + i];
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool fin = true;
+  for (int64_t t = p.cam_obs_off[c] + threadIdx.x; t < p.cam_obs_off[c + 1]; t += 256) {
+    const int o = p.cam_obs[t];
+    const int l = p.obs_lm[o];
+    S res[2], Jp[18], Jl[6];
+    const bool valid = linearize_obs<S>(cam, p.lms[3 * l], p.lms[3 * l + 1], p.lms[3 * l + 2],
+                                        p.obs_xy[2 * o], p.obs_xy[2 * o + 1], res, Jp, Jl);
+    if (p.valid_only && !valid) continue;
+    fin = fin && is_finite(res[0]) && is_finite(res[1]);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) fin = fin && is_finite(Jp[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fin = fin && is_finite(Jl[i]);
+    S err, w;
+    error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
+#pragma unroll
+    for (int a = 0; a < 9; ++a) acc[a] += double(w * (Jp[a] * Jp[a] + Jp[9 + a] * Jp[9 + a]));
+  }
+  if (!fin) atomicOr(p.fail_flag, 1);
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+    const double t = block_sum_256(acc[a], sm4);
+    if (threadIdx.x == 0) p.jp_diag2[9 * c + a] = S(t);
+  }
+}
+
 // ---- linearize ----------------------------------------------------------------
 // linearize_landmark + scale_Jp_cols (sc/landmark_block.hpp:127-176, 200-213), one
 // thread per observation

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -153,6 +154,7 @@ struct rba_solver {
   virtual void get_landmark_R(int damped, void* R6, void* q3) = 0;
   virtual void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) = 0;
   virtual void get_byte_model(rba_byte_model* out) = 0;
+  virtual void get_pcg_counters(rba_pcg_counters* out) = 0;
 };
 
 namespace {
@@ -192,28 +194,10 @@ class Solver final : public rba_solver {
     const int n_cams = n_cams_, n_lms = n_lms_;
     HIP_CHECK(hipSetDevice(device_));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     n_obs_ = lm_off[n_lms];
     nvec_ = 9 * n_cams_;
-    if (const char* ev = std::getenv("RBA_S1_FUSED")) s1_fused_ = std::atoi(ev) != 0;
     sc_ = opt_.solver_type == 1;
-    staged_ = !sc_ && opt_.implicit_q && !s1_fused_;  // kernels_s1.hpp: no dense blocks at all
-    if (const char* ev = std::getenv("RBA_HX_SINGLE_STREAM")) hx_single_stream_ = std::atoi(ev) != 0;
-    if (const char* ev = std::getenv("RBA_QR_UNPACKED")) qr_unpacked_ = std::atoi(ev) != 0;
-    if (const char* ev = std::getenv("RBA_BS_TWO_PASS")) bs_two_pass_ = std::atoi(ev) != 0;
-    if (const char* ev = std::getenv("RBA_Y_REPLICAS")) y_rep_ = std::max(1, std::min(64, std::atoi(ev)));
-    if (const char* ev = std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = std::max(0, std::atoi(ev));
-    if (const char* ev = std::getenv("RBA_HX_LDS")) hx_lds_ = std::atoi(ev);
-    // the LDS-private product in double needs 156 VGPRs: 512-thread workgroups (no scratch; measured 254 vs 428 us on venice)
-    hx_threads_ = sizeof(S) == 8 ? 512 : 1024;
-    if (const char* ev = std::getenv("RBA_HX_THREADS")) hx_threads_ = std::atoi(ev) == 512 ? 512 : 1024;
-    compact_ = staged_;  // compact stage-2 records (W8) + unscaled Jacobian rows; RBA_S2_COMPACT=0: round-2a records
-    if (const char* ev = std::getenv("RBA_S2_COMPACT")) compact_ = staged_ && std::atoi(ev) != 0;
-    if (const char* ev = std::getenv("RBA_FUSED_GRAM")) fused_gram_ = std::atoi(ev) != 0;
-    if (const char* ev = std::getenv("RBA_S2_FUSED_LM")) s2_fused_lm_ = std::atoi(ev) != 0;
-    if (compact_) y_rep_ = 1;  // (the replica experiment post-processes y itself)
+    read_debug_env();
     {
       int dev = 0, cus = 0;
       HIP_CHECK(hipGetDevice(&dev));
@@ -231,7 +215,7 @@ class Solver final : public rba_solver {
     // the same cameras cost nothing, the camera windows of large problems need this locality, and the
     // camera-major gathers get slightly faster (venice: stage 1 440 -> 410 us). RBA_SORT_BY_CAMERA=0 keeps the
     // input order inside a track length.
-    int sort_by_camera = opt_.implicit_q ? 1 : 0;
+    int sort_by_camera = 1;
     if (sort_by_camera) {
       // More cameras than an LDS window holds: the sort only pays if tracks are local in camera index. Without
       // that locality (e.g. an unordered photo collection) the windows would miss, the products would fall back to
@@ -247,9 +231,9 @@ class Solver final : public rba_solver {
         if (double(local_rows) < 0.9 * double(rows)) sort_by_camera = 0;
       }
     }
-    if (const char* ev = std::getenv("RBA_SORT_BY_CAMERA")) sort_by_camera = std::atoi(ev);
+    if (env_.sort_by_camera >= 0) sort_by_camera = env_.sort_by_camera;
     // track-length classes: the common refinement of the wave-tile classes (k <= 2, 4, 8, 16, 32, 64, 112) and
-    // of the dense-block classes (k <= 7, 14, 28, 56, 112): every class range the kernels use stays contiguous
+    // of the chunk classes of the matrix-free E0 products (k <= 7, 14, 28, 56, 112): every class range stays contiguous
     auto k_class = [](int64_t k) {
       static const int bounds[] = {2, 4, 7, 8, 14, 16, 28, 32, 56, 64, 112};
       int c = 0;
@@ -269,11 +253,11 @@ class Solver final : public rba_solver {
       std::stable_sort(perm_.begin(), perm_.end(), [&](int a, int b) { return key[a] < key[b]; });
     }
     std::vector<int> lm_k(n_lms);
-    std::vector<int64_t> lm_obs(n_lms + 1), lm_blk(n_lms + 1);
+    std::vector<int64_t> lm_obs(n_lms + 1);
     std::vector<int> s_obs_cam(n_obs_), s_obs_lm(n_obs_);
     std::vector<S> s_obs_xy(2 * size_t(n_obs_));
     std::vector<double> s_obs_xy64(mixed_ ? 2 * size_t(n_obs_) : 0);
-    int64_t o = 0, blk = 0;
+    int64_t o = 0;
     int kmax = 0;
     hx_bytes_ = 0;
     hx_flops_ = 0;
@@ -283,7 +267,6 @@ class Solver final : public rba_solver {
       const int k = int(lm_off[l + 1] - lm_off[l]);
       lm_k[s] = k;
       lm_obs[s] = o;
-      lm_blk[s] = blk;
       kmax = std::max(kmax, k);
       for (int i = 0; i < k; ++i) {
         const int64_t src = lm_off[l] + i;
@@ -297,8 +280,6 @@ class Solver final : public rba_solver {
         }
         ++o;
       }
-      const int64_t elems = int64_t(2 * k) * (9 * k);
-      blk += (elems + 3) / 4 * 4;
       // algorithmic counts in the reference's padded layout
       const int64_t pad = (4 - (9 * k) % 4) % 4;
       hx_bytes_ += int64_t(sizeof(S)) * 2 * k * (9 * k + pad);
@@ -308,8 +289,6 @@ class Solver final : public rba_solver {
       hx_implicit_bytes_ += int64_t(sizeof(S)) * (2 * k * 12 + 3 * (2 * k + 3) + 12);
     }
     lm_obs[n_lms] = o;
-    lm_blk[n_lms] = blk;
-    storage_dense_bytes_ = int64_t(sizeof(S)) * blk;
     // CSC index camera -> observations (sorted-observation numbering), used by
     // the camera-major reductions
     std::vector<int64_t> cam_off(n_cams + 1, 0);
@@ -322,10 +301,6 @@ class Solver final : public rba_solver {
     }
     hx_bytes_ += 4 * n_obs_ + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
     hx_implicit_bytes_ += 4 * n_obs_ + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
-    if (kmax > rba::kBigMaxK && !staged_)  // (the implicit-Q configuration has no limit)
-      throw HipError{"landmark with " + std::to_string(kmax) + " observations: more than " +
-                         std::to_string(rba::kBigMaxK) + " is not supported",
-                     RBA_ERR_UNSUPPORTED};
     // class ranges (k <= 7*CH)
     int begin = 0;
     for (int c = 0; c < kNumClasses; ++c) {
@@ -364,13 +339,12 @@ class Solver final : public rba_solver {
         }
         tiles += imp_tiles_[c];
       }
-      n_tiles_ = opt_.implicit_q ? tiles : 0;
+      n_tiles_ = tiles;
       tile_cam.assign(size_t(n_tiles_) * 64, -1);
       tile_row.assign(size_t(n_tiles_) * 64, -1);
       if (2 * n_obs_ > int64_t(std::numeric_limits<int>::max()))
         throw HipError{"more than 2^30 observations: block-row indices exceed 32 bits", RBA_ERR_UNSUPPORTED};
-      if (opt_.implicit_q)
-        for (int s2 = 0; s2 < n_lms; ++s2)
+      for (int s2 = 0; s2 < n_lms; ++s2)
           if (lm_tile[s2] >= 0)
             for (int rr = 0; rr < 2 * lm_k[s2]; ++rr) {
               tile_cam[size_t(lm_tile[s2]) * 64 + lm_lane0[s2] + rr] = s_obs_cam[lm_obs[s2] + rr / 2];
@@ -381,7 +355,7 @@ class Solver final : public rba_solver {
     if (n_tiles_ > 0) {
       const int G = std::max(1, std::min(n_cus_, (n_tiles_ + 15) / 16));
       hx_win_ = std::min(n_cams, int(kHxLdsMaxBytes / (9 * sizeof(double))));
-      if (const char* ev = std::getenv("RBA_HX_WIN")) hx_win_ = std::max(1, std::min(hx_win_, std::atoi(ev)));  // tests
+      if (env_.hx_win > 0) hx_win_ = std::max(1, std::min(hx_win_, env_.hx_win));  // tests
       auto first_cam = [&](int T) { return tile_cam[size_t(T) * 64]; };
       // runs of ascending first camera
       std::vector<int> run_begin{0};
@@ -450,7 +424,7 @@ class Solver final : public rba_solver {
       d_hx_chunks_.upload(chunks.data(), chunks.size(), stream_);
       HIP_CHECK(hipStreamSynchronize(stream_));  // `chunks` is a local
       n_hx_chunks_ = G;
-      if (std::getenv("RBA_VERBOSE"))
+      if (env_.verbose)
         std::fprintf(stderr, "[rootba_hip] H*x: %d persistent workgroups, %d tile runs, window %d of %d cameras, %.2f %% of "
                      "the block rows inside their window\n", G, n_runs, hx_win_, n_cams, 100.0 * hx_coverage_);
     }
@@ -458,62 +432,14 @@ class Solver final : public rba_solver {
     big_begin_ = begin;
     n_big_ = n_lms - begin;
     big_kmax_ = n_big_ > 0 ? kmax : 0;
-    if (n_big_ > 0 && !staged_) {
-      const size_t lds = size_t(18) * big_kmax_ * sizeof(S);  // largest request of the dense big kernels
-      if (lds > 160 * 1024)
-        throw HipError{"landmark with " + std::to_string(kmax) + " observations does not fit the 160 KB LDS",
-                       RBA_ERR_UNSUPPORTED};
-      if (lds > 64 * 1024) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_linearize_qr_big<S>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_big<S>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-      }
-    }
-
-    // batches of same-k small landmarks for the LDS-staged H*x (k <= 7)
-    std::vector<rba::SmallBatch> batches;
-    small_lds_bytes_ = 0;
-    {
-      int s = cls_begin_[0];
-      while (s < cls_end_[0]) {
-        const int k = lm_k[s];
-        int e = s;
-        while (e < cls_end_[0] && lm_k[e] == k) ++e;
-        const int blk_elems = (2 * k * 9 * k + 3) / 4 * 4;
-        const int g_rows = 256 / (2 * k);
-        size_t budget = kSmallLdsBudget;
-        if (const char* ev = std::getenv("RBA_SMALL_LDS_KB")) budget = std::min<size_t>(kSmallLdsBudget, size_t(std::atoi(ev)) * 1024);
-        const int g_lds = int(budget / (size_t(blk_elems) * sizeof(S)));
-        const int gmax = std::max(1, std::min(g_rows, g_lds));
-        int nbatch = kSmallBatchesPerBlock;
-        if (const char* ev = std::getenv("RBA_SMALL_NB")) nbatch = std::max(1, std::atoi(ev));
-        const int span = gmax * nbatch;
-        for (int b0 = s; b0 < e; b0 += span) {
-          const int count = std::min(span, e - b0);
-          const int G = std::min(gmax, count);
-          batches.push_back(rba::SmallBatch{b0, G, k, count, lm_blk[b0], lm_obs[b0]});
-          const size_t lds = size_t(G) * blk_elems * sizeof(S) + size_t(G) * 9 * k * sizeof(S) +
-                             256 * sizeof(S) + size_t(G) * 9 * k * sizeof(int);
-          small_lds_bytes_ = std::max(small_lds_bytes_, lds);
-        }
-        s = e;
-      }
-    }
-    n_small_batches_ = int(batches.size());
-    d_batches_.alloc(batches.size());
-    if (!batches.empty()) d_batches_.upload(batches.data(), batches.size(), stream_);
-
     // ---- device memory ------------------------------------------------------
     d_lm_k_.alloc(n_lms);
     d_lm_obs_.alloc(n_lms + 1);
-    d_lm_blk_.alloc(n_lms + 1);
     d_obs_cam_.alloc(n_obs_);
     d_obs_lm_.alloc(n_obs_);
     d_obs_xy_.alloc(2 * size_t(n_obs_));
     d_lm_k_.upload(lm_k.data(), n_lms, stream_);
     d_lm_obs_.upload(lm_obs.data(), n_lms + 1, stream_);
-    d_lm_blk_.upload(lm_blk.data(), n_lms + 1, stream_);
     d_obs_cam_.upload(s_obs_cam.data(), n_obs_, stream_);
     d_obs_lm_.upload(s_obs_lm.data(), n_obs_, stream_);
     d_obs_xy_.upload(s_obs_xy.data(), 2 * size_t(n_obs_), stream_);
@@ -543,10 +469,7 @@ class Solver final : public rba_solver {
                      "implemented (the reference's LinearizorSC has no JACOBI either)", RBA_ERR_UNSUPPORTED};
     // the dense landmark blocks and the QR by-products exist only for the square-root solver
     const size_t qr_obs = sc_ ? 0 : size_t(n_obs_);
-    d_A_.alloc((sc_ || staged_) ? 0 : size_t(blk));
-    // staged path: no dense blocks, no undamped top rows, no separate b parts
-    const size_t legacy_obs = staged_ ? 0 : qr_obs;
-    if (staged_ && n_big_ > 0) {
+    if (!sc_ && n_big_ > 0) {
       // global scratch of the long-track kernels: 8 scalars per block row (kernels_big.hpp)
       std::vector<int64_t> off(size_t(n_big_) + 1, 0);
       for (int q = 0; q < n_big_; ++q) off[q + 1] = off[q] + 2 * int64_t(lm_k[big_begin_ + q]);
@@ -555,19 +478,17 @@ class Solver final : public rba_solver {
       d_big_scratch_.alloc(size_t(8) * off[n_big_]);
       HIP_CHECK(hipStreamSynchronize(stream_));
     }
-    d_top0_.alloc(27 * legacy_obs);
     d_topd_.alloc(rba::kTd * qr_obs);
     d_JpS_.alloc(18 * size_t(n_obs_));
     d_JlS_.alloc(6 * qr_obs);
     d_rS_.alloc(2 * qr_obs);
     d_bsO_.alloc(5 * qr_obs);
     d_givens_.alloc(sc_ ? 0 : 16 * size_t(n_lms));
-    d_bmO_.alloc(9 * legacy_obs);
     d_Vh_.alloc(8 * qr_obs);
     if (sc_) build_sc_structure(lm_k, lm_obs, s_obs_cam);
     // square-root solver: explicit reduced matrix for long PCG solves (see pcg())
     explicit_after_ = opt_.explicit_after;
-    if (const char* ev = std::getenv("RBA_EXPLICIT_AFTER")) explicit_after_ = std::atoi(ev);
+    if (env_.explicit_after != INT_MIN) explicit_after_ = env_.explicit_after;
     if (explicit_after_ < 0) {  // auto: start with 6, then the measured break-even (see solve())
       explicit_auto_ = true;
       explicit_after_ = 6;
@@ -581,10 +502,9 @@ class Solver final : public rba_solver {
     int64_t n_pairs_total = 0;
     for (int l = 0; l < n_lms; ++l) n_pairs_total += int64_t(lm_k[l]) * (lm_k[l] - 1) / 2;
     ex_pair_bytes_ = 8 * n_pairs_total;
-    double pair_budget_gb = 24.0;
-    if (const char* ev = std::getenv("RBA_EX_PAIR_BUDGET_GB")) pair_budget_gb = std::atof(ev);
+    const double pair_budget_gb = env_.pair_budget_gb;
     const bool pairs_fit = double(ex_pair_bytes_) <= pair_budget_gb * 1e9;
-    if (!pairs_fit && std::getenv("RBA_VERBOSE"))
+    if (!pairs_fit && env_.verbose)
       std::fprintf(stderr, "[rootba_hip] pair lists of the reduced matrix would take %.1f GB (> %.1f GB): "
                            "products stay matrix-free\n", ex_pair_bytes_ * 1e-9, pair_budget_gb);
     if (!sc_ && explicit_after_ > 0 && n_cams_ <= 20000 && pairs_fit) {
@@ -600,7 +520,7 @@ class Solver final : public rba_solver {
       }
       build_explicit_structure();
       // only the first explicit_after products of a solve are matrix-free: sample them densely
-      if (!std::getenv("RBA_HX_TIMING_STRIDE")) hx_timing_stride_ = 2;
+      if (env_.hx_timing_stride < 0) hx_timing_stride_ = 2;
     }
     d_tauH_.alloc(3 * size_t(n_lms));
     d_Zd_.alloc(9 * size_t(n_lms));
@@ -621,7 +541,7 @@ class Solver final : public rba_solver {
     d_jl_scale_.alloc(3 * size_t(n_lms));
     d_jp_diag2_.alloc(nvec_);
     d_pose_scaling_.alloc(nvec_);
-    d_mid_.alloc(size_t(90) * n_cams);  // [b_mid | B_mid]
+    d_mid_.alloc(size_t(81) * n_cams);  // B_mid
     d_bb_.alloc(size_t(171) * n_cams);  // [b | blocks | diagonal blocks of the reduced matrix (JACOBI / series)]
     d_inv_.alloc(size_t(81) * n_cams);
     d_fail_.alloc(1);
@@ -631,25 +551,14 @@ class Solver final : public rba_solver {
     d_pcg_partials_.alloc(3 * rba::kPcgBlocks);
     for (auto* v : {&d_x_, &d_r_, &d_p_, &d_z_, &d_q_, &d_tmp_, &d_inc_, &d_vin_, &d_pw_t_, &d_pw_e_})
       v->alloc(nvec_);
-    d_A_.zero(stream_);
-    d_top0_.zero(stream_);
     d_topd_.zero(stream_);
     d_pose_scaling_.zero(stream_);
     d_fail_.zero(stream_);
     d_partials_.zero(stream_);
     d_p2_.alloc(nvec_);
-    if (y_rep_ > 1 && !sc_) d_yrep_.alloc(size_t(y_rep_) * nvec_);
-    prm_.y_rep = (y_rep_ > 1 && !sc_) ? y_rep_ : 1;
-    prm_.y_rep_stride = nvec_;
-    prm_.hx_debug = 0;
-    if (const char* ev = std::getenv("RBA_HX_DEBUG")) prm_.hx_debug = std::atoi(ev);
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 4096));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_progress_), 64));
     h_progress_[0] = h_progress_[1] = 0;
-    if (const char* ev = std::getenv("RBA_FUSED_PCG")) fused_pcg_ = std::atoi(ev) != 0;
-    if (const char* ev = std::getenv("RBA_PCG_RUN_AHEAD")) pcg_run_ahead_ = std::max(1, std::atoi(ev));
-    if (const char* ev = std::getenv("RBA_PCG_GRAPHS")) use_pcg_graphs_ = std::atoi(ev) != 0;
-    if (const char* ev = std::getenv("RBA_SWITCH_REFRESH")) switch_refresh_ = std::atoi(ev) != 0;
     HIP_CHECK(hipEventCreate(&ev_a_));
     HIP_CHECK(hipEventCreate(&ev_asm0_));
     HIP_CHECK(hipEventCreate(&ev_asm1_));
@@ -664,7 +573,6 @@ class Solver final : public rba_solver {
     prm_.n_lms = n_lms;
     prm_.lm_k = d_lm_k_.get();
     prm_.lm_obs = d_lm_obs_.get();
-    prm_.lm_blk = d_lm_blk_.get();
     prm_.obs_cam = d_obs_cam_.get();
     prm_.obs_lm = d_obs_lm_.get();
     prm_.obs_xy = d_obs_xy_.get();
@@ -675,30 +583,24 @@ class Solver final : public rba_solver {
     prm_.rS = d_rS_.get();
     prm_.bsO = d_bsO_.get();
     prm_.givens = d_givens_.get();
-    prm_.b_from_records = staged_ ? 1 : 0;
-    prm_.bmO = d_bmO_.get();
     prm_.Vh = d_Vh_.get();
     prm_.tauH = d_tauH_.get();
     prm_.Zd = d_Zd_.get();
     prm_.LQ = d_LQ_.get();
     prm_.CT = d_CT_.get();
     prm_.RT = d_RT_.get();
-    prm_.implicit = opt_.implicit_q ? 1 : 0;
     prm_.cams = d_cams_.get();
     prm_.lms = d_lms_.get();
     prm_.lm_inc = mixed_ ? d_lm_inc_.get() : nullptr;
-    if (compact_) {
+    if (!sc_) {
       // the eight stage-2 coefficients themselves: only for the observations of the two-kernel back-substitution
-      prm_.w8_begin = (n_tiles_ > 0 && !bs_two_pass_) ? n_obs_tiled_ : 0;
+      prm_.w8_begin = n_tiles_ > 0 ? n_obs_tiled_ : 0;
       d_W8_.alloc(size_t(8) * (n_obs_ - prm_.w8_begin));
       d_WA_.alloc(size_t(rba::kRecW) * n_obs_);
       d_xs_.alloc(nvec_);
     }
     prm_.W8 = d_W8_.get();
     prm_.WA = d_WA_.get();
-    prm_.compact = compact_ ? 1 : 0;
-    prm_.A = d_A_.get();
-    prm_.top0 = d_top0_.get();
     prm_.topd = d_topd_.get();
     prm_.R0 = d_R0_.get();
     prm_.Rd = d_Rd_.get();
@@ -707,8 +609,7 @@ class Solver final : public rba_solver {
     prm_.jl_scale = d_jl_scale_.get();
     prm_.jp_diag2 = d_jp_diag2_.get();
     prm_.pose_scaling = d_pose_scaling_.get();
-    prm_.b_mid = d_mid_.get();
-    prm_.B_mid = d_mid_.get() + nvec_;
+    prm_.B_mid = d_mid_.get();
     prm_.b = d_bb_.get();
     prm_.blocks = d_bb_.get() + nvec_;
     prm_.fail_flag = d_fail_.get();
@@ -774,7 +675,7 @@ class Solver final : public rba_solver {
       scp_.eps = prm_.eps;
     }
     // capture the launch graphs of the fused PCG now (one-off cost, not part of an LM iteration)
-    if (fused_pcg_ && use_pcg_graphs_ && n_items_ > 0 && opt_.preconditioner_type != 2 && (sc_ || ex_ready_))
+    if (n_items_ > 0 && opt_.preconditioner_type != 2 && (sc_ || ex_ready_))
       build_pcg_graphs(sc_ ? scp_ : exp_);
   }
 
@@ -901,7 +802,8 @@ class Solver final : public rba_solver {
     const bool measure = explicit_auto_ && !asm_measured_ && !asm_pending_;
     if (measure) HIP_CHECK(hipEventRecord(ev_asm0_, stream_));
     if (comm_ || cb_fn_) d_ex_vals_.zero(stream_);  // sharded: blocks without local pairs must be 0
-    ensure_topd();  // compact stage 2: the off-diagonal blocks are built from the 27-scalar rows
+    ensure_topd();  // the off-diagonal blocks are built from the 27-scalar rows
+    ++pcg_counters_.assemblies;
     if (ex_n_upper_ > 0) launch_offdiag(prm_.topd, d_ex_vals_.get());
     all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
     // (the diagonal blocks were all-reduced by stage 2 already)
@@ -1028,7 +930,6 @@ class Solver final : public rba_solver {
     (void)hipSetDevice(device_);
     destroy_pcg_graphs();
     if (stream_) (void)hipStreamSynchronize(stream_);
-    if (stream2_) (void)hipStreamSynchronize(stream2_);
     if (comm_ && g_rccl.CommDestroy) g_rccl.CommDestroy(comm_);
     comm_ = nullptr;
     for (auto& e : hx_events_)
@@ -1040,7 +941,7 @@ class Solver final : public rba_solver {
     for (auto& e : comm_events_)
       if (e) (void)hipEventDestroy(e);
     comm_events_.clear();
-    for (hipEvent_t* e : {&ev_a_, &ev_b_, &ev_asm0_, &ev_asm1_, &ev_fork_, &ev_join_}) {
+    for (hipEvent_t* e : {&ev_a_, &ev_b_, &ev_asm0_, &ev_asm1_}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
     }
@@ -1048,9 +949,8 @@ class Solver final : public rba_solver {
     h_pinned_ = nullptr;
     if (h_progress_) (void)hipHostFree(h_progress_);
     h_progress_ = nullptr;
-    if (stream2_) (void)hipStreamDestroy(stream2_);
     if (stream_) (void)hipStreamDestroy(stream_);
-    stream_ = stream2_ = nullptr;
+    stream_ = nullptr;
   }
 
   // ---- multi-GPU ------------------------------------------------------------
@@ -1278,77 +1178,49 @@ class Solver final : public rba_solver {
     time_begin();
     sub_begin();
     d_fail_.zero(stream_);
-    const bool staged = staged_;  // kernels_s1.hpp
-    if (staged) {
+    if (!sc_) {
       // geometry once per observation; Jp_diag2 falls out of the camera-major Gram pass
       hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256),
                          256 * 26 * sizeof(S), stream_, prm_, int64_t(n_obs_));
       sub_mark(&sub_.jacobian_evaluation_time);  // linearize_problem()
-      // One GPU, compact stage 2: the Gram pass (Jp_diag2, pose scaling, B_mid) is folded into the camera-major
-      // pass of the first stage 2, which gathers the same Jacobian rows anyway (k_cam_stage2_w8*<GRAM>). Not when
-      // the caller wants Jp_diag2 now, with more than one rank (Jp_diag2 is all-reduced before it is used) or
-      // with the unstaged sub-stage timers.
-      gram_pending_ = fused_gram_ && compact_ && !comm_ && !cb_fn_ && !jp_diag2_out && !sub_timing();
+      // One GPU: the Gram pass (Jp_diag2, pose scaling, B_mid) is folded into the camera-major pass of the first
+      // stage 2, which gathers the same Jacobian rows anyway (k_cam_pass*<0>, GRAM). Not when the caller wants
+      // Jp_diag2 now, with more than one rank (Jp_diag2 is all-reduced before it is used) or with the unstaged
+      // sub-stage timers.
+      gram_pending_ = !comm_ && !cb_fn_ && !jp_diag2_out && !sub_timing();
       if (!gram_pending_) launch_cam_gram(prm_);
     } else {
-      hipLaunchKernelGGL((rba::k_cam_jp_diag2<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
+      hipLaunchKernelGGL((rba::k_sc_jp_diag2<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
     }
     if (!gram_pending_) all_reduce(d_jp_diag2_.get(), nvec_);
     all_reduce(d_fail_.get(), 1, kNcclMax);
     if (!gram_pending_)
       hipLaunchKernelGGL((rba::k_pose_scaling<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                          d_jp_diag2_.get(), d_pose_scaling_.get(), prm_.eps, nvec_);
-    if (staged) {
+    if (!sc_) {
       sub_mark(&sub_.scale_landmark_jacobian_time);  // get_Jp_diag2() (+ scale_Jl_cols, done inside the QR kernels)
       if (!gram_pending_)
         hipLaunchKernelGGL((rba::k_scale_gram<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_, prm_);
-      sub_mark(&sub_.stage1_preconditioner_time);  // get_Jp_T_Jp_blockdiag() (JACOBI; minuend of SCHUR_JACOBI)
-      if (n_tiles_ > 0) {
-        rba::ImplicitTiles it;
-        for (int c = 0; c < 5; ++c) {
-          it.tile_begin[c] = imp_tile_begin_[c];
-          it.lm_begin[c] = imp_begin_[c];
-          it.lm_end[c] = imp_end_[c];
-        }
-        it.tile_begin[5] = n_tiles_;
-        hipLaunchKernelGGL((rba::k_s1_qr_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, it);
-      }
+      sub_mark(&sub_.stage1_preconditioner_time);  // get_Jp_T_Jp_blockdiag() (JACOBI blocks)
+      if (n_tiles_ > 0)
+        hipLaunchKernelGGL((rba::k_s1_qr_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_,
+                           implicit_tiles());
       if (imp_end_[5] > imp_begin_[5])
         hipLaunchKernelGGL((rba::k_s1_qr_wide<S, 2>), dim3((imp_end_[5] - imp_begin_[5] + 3) / 4), dim3(256), 0,
                            stream_, prm_, imp_begin_[5], imp_end_[5]);
       if (imp_end_[6] > imp_begin_[6])
         hipLaunchKernelGGL((rba::k_s1_qr_wide<S, 4>), dim3((imp_end_[6] - imp_begin_[6] + 3) / 4), dim3(256), 0,
                            stream_, prm_, imp_begin_[6], imp_end_[6]);
-      // the column pass (scaled rows, top rows, b records) runs inside the first stage 2 (k_s12_cols)
-      cols_pending_ = true;
       if (n_big_ > 0)
         hipLaunchKernelGGL((rba::k_s1_qr_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
                            d_big_scratch_.get(), d_big_off_.get());
       sub_mark(&sub_.perform_qr_time);  // perform_qr()
-    } else if (sc_) {
+    } else {
       // LinearizorSC::linearize (linearizor_sc.cpp:70-99)
       hipLaunchKernelGGL((rba::k_sc_linearize_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0,
                          stream_, scp_);
       hipLaunchKernelGGL((rba::k_sc_landmark_moments<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_,
                          scp_);
-    } else {
-      for_each_class([&](auto ch_tag, int begin, int end) {
-        constexpr int CH = decltype(ch_tag)::value;
-        const size_t lds = 4 * size_t(rba::ClassCfg<CH>::WAVE_LDS) * sizeof(S);
-        if (CH <= 2 && !qr_unpacked_) {
-          // k <= 7 / k <= 14: four / two landmarks per wavefront in the QR phases
-          constexpr int PCH = CH <= 2 ? CH : 1, P = 4 / PCH;
-          hipLaunchKernelGGL((rba::k_linearize_qr_packed<S, PCH>), dim3((end - begin + 4 * P - 1) / (4 * P)),
-                             dim3(256), P * lds, stream_, prm_, begin, end);
-        }
-        else
-          hipLaunchKernelGGL((rba::k_linearize_qr<S, CH>), dim3((end - begin + 3) / 4), dim3(256),
-                             lds, stream_, prm_, begin, end);
-      });
-      if (n_big_ > 0)
-        hipLaunchKernelGGL((rba::k_linearize_qr_big<S>), dim3(n_big_), dim3(256),
-                           size_t(16) * big_kmax_ * sizeof(S), stream_, prm_, big_begin_);
-      launch_cam_stage1(prm_);
     }
     HIP_CHECK(hipGetLastError());
     int fail = 0;
@@ -1390,37 +1262,12 @@ class Solver final : public rba_solver {
       return;
     }
     sub_begin();
-    const bool fused_lm = compact_ && s2_fused_lm_;  // RBA_S2_FUSED_LM=1 (kernels_s1.hpp: k_s2_w8_fused)
-    if (!fused_lm)
-      hipLaunchKernelGGL((rba::k_stage2_landmark<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_, prm_,
-                         lambda);
-    sub_mark(&sub_.landmark_damping_time);  // set_landmark_damping(): the six rotations per landmark
-    if (fused_lm) {
-      hipLaunchKernelGGL((rba::k_s2_w8_fused<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0, stream_, prm_,
-                         int64_t(n_obs_), lambda);
-      cols_pending_ = false;
-      topd_valid_ = false;
-      sub_mark(&sub_.scale_pose_jacobian_time);
-    } else if (compact_) {
-      // eight coefficients per observation; the Jacobian rows are neither read nor rewritten (kernels_s1.hpp)
-      hipLaunchKernelGGL((rba::k_s2_w8<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0, stream_, prm_,
-                         int64_t(n_obs_));
-      cols_pending_ = false;
-      topd_valid_ = false;
-      sub_mark(&sub_.scale_pose_jacobian_time);
-    } else if (staged_) {
-      // column pass + rotation of the top rows, fused (kernels_s1.hpp), every observation
-      hipLaunchKernelGGL((rba::k_s12_cols<S>),
-                         dim3(unsigned((n_obs_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
-                         dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTd) * sizeof(S), stream_,
-                         prm_, int64_t(n_obs_), cols_pending_ ? 0 : 1, 1);
-      cols_pending_ = false;
-      // scale_Jp_cols() + the column part of the damping (top rows of Q^T Jp rotated, b records)
-      sub_mark(&sub_.scale_pose_jacobian_time);
-    } else {
-      hipLaunchKernelGGL((rba::k_stage2_cols<S>), dim3(unsigned((9 * int64_t(n_obs_) + 255) / 256)), dim3(256), 0,
-                         stream_, prm_, int64_t(0), int64_t(n_obs_));
-    }
+    // landmark side: the six damping rotations per landmark and the stage-2 record of every observation
+    // (set_landmark_damping + scale_Jp_cols + the per-column part of the damping, kernels_s1.hpp)
+    hipLaunchKernelGGL((rba::k_s2_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0, stream_, prm_,
+                       int64_t(n_obs_), lambda);
+    topd_valid_ = false;
+    sub_mark(&sub_.scale_pose_jacobian_time);
     launch_cam_stage2(prm_, lambda);
     gram_pending_ = false;
     sub_mark(&sub_.stage2_preconditioner_and_gradient_time);  // get_Q2TJp_T_Q2TJp_blockdiag() + get_Q2TJp_T_Q2Tr()
@@ -1477,53 +1324,7 @@ class Solver final : public rba_solver {
       ++hx_calls_;
       return;
     }
-    // matrix-free products scatter-add into privatised replicas of y, summed at the end
-    S* const y_out = y;
-    if (prm_.y_rep > 1) {
-      d_yrep_.zero(stream_);
-      y = d_yrep_.get();
-    }
-    auto finish_replicas = [&]() {
-      if (prm_.y_rep > 1)
-        hipLaunchKernelGGL((rba::k_sum_replicas<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y_out,
-                           d_yrep_.get(), prm_.y_rep, int64_t(nvec_), nvec_);
-    };
-    if (opt_.implicit_q) {
-      launch_hx_implicit(x, y, done_flag);
-      finish_replicas();
-      if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
-      ++hx_calls_;
-      return;
-    }
-    // The LDS-staged small-landmark kernel (latency bound) and the register-streaming
-    // kernels of the larger classes run concurrently on two streams; both scatter-add
-    // into y with atomics, so there is no ordering between them.
-    // (RBA_HX_SINGLE_STREAM=1 serialises them, for per-kernel profiles that add up)
-    const bool two_streams = n_small_batches_ > 0 && !hx_single_stream_;
-    if (two_streams) {
-      HIP_CHECK(hipEventRecord(ev_fork_, stream_));
-      HIP_CHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
-      hipLaunchKernelGGL((rba::k_hx_small<S>), dim3(n_small_batches_), dim3(256), small_lds_bytes_,
-                         stream2_, prm_, d_batches_.get(), x, y, done_flag);
-      HIP_CHECK(hipEventRecord(ev_join_, stream2_));
-    } else if (n_small_batches_ > 0) {
-      hipLaunchKernelGGL((rba::k_hx_small<S>), dim3(n_small_batches_), dim3(256), small_lds_bytes_,
-                         stream_, prm_, d_batches_.get(), x, y, done_flag);
-    }
-    if (n_big_ > 0)
-      hipLaunchKernelGGL((rba::k_hx_big<S>), dim3(n_big_), dim3(256), size_t(18) * big_kmax_ * sizeof(S),
-                         stream_, prm_, big_begin_, x, y, done_flag);
-    // largest landmarks first: the low-parallelism tail classes then overlap with
-    // the bulk instead of running alone at the end
-    for_each_class_reverse([&](auto ch_tag, int begin, int end) {
-      constexpr int CH = decltype(ch_tag)::value;
-      constexpr int U = CH <= 2 ? 4 : 2;
-      if (CH == 1) return;  // k <= 7 is handled by the LDS-staged kernel
-      hipLaunchKernelGGL((rba::k_hx<S, CH, U>), dim3((end - begin + 3) / 4), dim3(256), 0,
-                         stream_, prm_, begin, end, x, y, done_flag);
-    });
-    if (two_streams) HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
-    finish_replicas();
+    launch_hx_implicit(x, y, done_flag);
     if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
     ++hx_calls_;
   }
@@ -1555,49 +1356,31 @@ class Solver final : public rba_solver {
                        d_ex_pair_oj_.get());
   }
 
-  // camera-major 9x9 contractions: matrix cores for float, VALU (double accumulators) for double
-  void launch_cam_stage1(const rba::Params<float>& prm) {
-    hipLaunchKernelGGL((rba::k_cam_stage1_mfma), dim3(n_cams_), dim3(256), 0, stream_, prm);
-  }
-  void launch_cam_stage1(const rba::Params<double>& prm) {
-    hipLaunchKernelGGL((rba::k_cam_stage1<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
-  }
-  // (kernels_cam.hpp; the SC backend keeps the round-2 Gram kernels on its own scaled rows)
+  // camera-major passes (kernels_cam.hpp): matrix cores for float, VALU (double accumulators) for double.
+  // launch_cam_gram: Jp_diag2 + the unscaled Gram blocks on their own (sharded runs, Jp_diag2 requested at once, the SC
+  // backend's power-series blocks); launch_cam_stage2: blocks, b (and on one GPU the Gram part of the first stage 2)
   void launch_cam_gram(const rba::Params<float>& prm) {
-    if (compact_)
-      hipLaunchKernelGGL((rba::k_cam_pass_mfma<1>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm, 0.f, 0);
-    else
-      hipLaunchKernelGGL((rba::k_cam_gram_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm);
+    hipLaunchKernelGGL((rba::k_cam_pass_mfma<1>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm, 0.f, 0);
   }
   void launch_cam_gram(const rba::Params<double>& prm) {
-    if (compact_)
-      hipLaunchKernelGGL((rba::k_cam_pass<double, 1>), dim3(n_cams_), dim3(256), 0, stream_, prm, 0.0, 0);
-    else
-      hipLaunchKernelGGL((rba::k_cam_gram<double>), dim3(n_cams_), dim3(256), 0, stream_, prm);
+    hipLaunchKernelGGL((rba::k_cam_pass<double, 1>), dim3(n_cams_), dim3(256), 0, stream_, prm, 0.0, 0);
   }
   void launch_cam_stage2(const rba::Params<float>& prm, float lambda) {
-    if (compact_)
-      hipLaunchKernelGGL((rba::k_cam_pass_mfma<0>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
-                         lambda, gram_pending_ ? 1 : 0);
-    else
-      hipLaunchKernelGGL((rba::k_cam_stage2_mfma), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
-                         lambda);
+    hipLaunchKernelGGL((rba::k_cam_pass_mfma<0>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
+                       lambda, gram_pending_ ? 1 : 0);
   }
   void launch_cam_stage2(const rba::Params<double>& prm, double lambda) {
-    if (compact_)
-      hipLaunchKernelGGL((rba::k_cam_pass<double, 0>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda,
-                         gram_pending_ ? 1 : 0);
-    else
-      hipLaunchKernelGGL((rba::k_cam_stage2<double>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda);
+    hipLaunchKernelGGL((rba::k_cam_pass<double, 0>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda,
+                       gram_pending_ ? 1 : 0);
   }
-  // compact stage 2: the 27 + 9 records of the current damping, for the consumers that still read them (assembly of
-  // the reduced matrix, matrix-free E0 products): the round-2a column pass on the unscaled rows, nothing rewritten
+  // the 27 + 9 records of the current damping, for the consumers that read them (assembly of the reduced matrix,
+  // matrix-free E0 products): the closed-form column pass on the unscaled rows (kernels_s1.hpp)
   void ensure_topd() {
-    if (!compact_ || topd_valid_) return;
+    if (topd_valid_) return;
     hipLaunchKernelGGL((rba::k_s12_cols<S>),
                        dim3(unsigned((n_obs_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
                        dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTd) * sizeof(S), stream_,
-                       prm_, int64_t(n_obs_), 0, 0);
+                       prm_, int64_t(n_obs_));
     topd_valid_ = true;
   }
   // the stage-1 Gram pass on its own, for callers that read the pose scaling / Jp_diag2 before any stage 2
@@ -1609,9 +1392,8 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_scale_gram<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_, prm_);
     gram_pending_ = false;
   }
-  // x -> D x for the kernels that read the unscaled Jacobian rows (compact stage 2)
+  // x -> D x for the kernels that read the unscaled Jacobian rows
   const S* scaled_operand(const S* x) {
-    if (!compact_) return x;
     if (operand_prescaled_) return d_xs_.get();  // the producer of x wrote D x already (k_pcg_a2)
     hipLaunchKernelGGL((rba::k_scale_vec<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, x, prm_.pose_scaling,
                        d_xs_.get(), nvec_);
@@ -1621,11 +1403,6 @@ class Solver final : public rba_solver {
   // y += E0 v over the local landmarks (power-series preconditioner)
   void launch_e0(const S* v, S* y, const int* done_flag) {
     ensure_topd();
-    S* const y_out = y;
-    if (prm_.y_rep > 1) {
-      d_yrep_.zero(stream_);
-      y = d_yrep_.get();
-    }
     for_each_class([&](auto ch_tag, int begin, int end) {
       constexpr int CH = decltype(ch_tag)::value;
       hipLaunchKernelGGL((rba::k_e0<S, CH>), dim3((end - begin + 3) / 4), dim3(256), 0, stream_,
@@ -1634,9 +1411,6 @@ class Solver final : public rba_solver {
     if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_e0_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_, v, y,
                          done_flag);
-    if (prm_.y_rep > 1)
-      hipLaunchKernelGGL((rba::k_sum_replicas<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y_out,
-                         d_yrep_.get(), prm_.y_rep, int64_t(nvec_), nvec_);
   }
 
   rba::ImplicitTiles implicit_tiles() const {
@@ -1650,25 +1424,22 @@ class Solver final : public rba_solver {
     return it;
   }
 
-  // same operator from the factors; long tracks use the workgroup-per-landmark kernels.
-  // Compact stage 2: the Jacobian rows are unscaled, so the kernels get D x and multiply what they add to y by D
+  // H x from the factors; long tracks use the workgroup-per-landmark kernel.
+  // The Jacobian rows are unscaled, so the kernels get D x and multiply what they add to y by D
   // (the LDS kernel where its sums leave the workgroup, the others per scatter-add).
   void launch_hx_implicit(const S* x, S* y, const int* done_flag) {
     const S* xin = scaled_operand(x);
-    const S* dout = compact_ ? prm_.pose_scaling : nullptr;
-    if (n_big_ > 0 && staged_)
+    const S* dout = prm_.pose_scaling;
+    if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_hx_implicit_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
                          d_big_scratch_.get(), d_big_off_.get(), xin, y, dout, done_flag);
-    else if (n_big_ > 0)
-      hipLaunchKernelGGL((rba::k_hx_big<S>), dim3(n_big_), dim3(256), size_t(18) * big_kmax_ * sizeof(S),
-                         stream_, prm_, big_begin_, x, y, done_flag);
     if (imp_end_[6] > imp_begin_[6])
       hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 4>), dim3((imp_end_[6] - imp_begin_[6] + 3) / 4),
                          dim3(256), 0, stream_, prm_, imp_begin_[6], imp_end_[6], xin, y, dout, done_flag);
     if (imp_end_[5] > imp_begin_[5])
       hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 2>), dim3((imp_end_[5] - imp_begin_[5] + 3) / 4),
                          dim3(256), 0, stream_, prm_, imp_begin_[5], imp_end_[5], xin, y, dout, done_flag);
-    const bool use_lds = n_tiles_ > 0 && hx_lds_ && (hx_lds_ == 2 || (n_tiles_ >= 16 * n_cus_ && hx_coverage_ >= 0.9));
+    const bool use_lds = n_tiles_ > 0 && env_.hx_lds && (env_.hx_lds == 2 || (n_tiles_ >= 16 * n_cus_ && hx_coverage_ >= 0.9));
     rba::ImplicitTiles it = implicit_tiles();
     if (n_tiles_ > 0 && !use_lds)
       hipLaunchKernelGGL((rba::k_hx_implicit<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, it, xin, y,
@@ -1676,10 +1447,9 @@ class Solver final : public rba_solver {
     if (use_lds) {
       // workgroup-private window of y in LDS (double accumulators, ds_add_f64), one persistent workgroup per CU
       const size_t ylds_bytes = size_t(9) * hx_win_ * sizeof(double);
-      if (hx_threads_ == 512)
-        launch_hx_lds<512>(it, ylds_bytes, xin, y, dout, done_flag);
-      else
-        launch_hx_lds<1024>(it, ylds_bytes, xin, y, dout, done_flag);
+      // double needs 156 VGPRs: 512-thread workgroups (no scratch; venice: 254 us against 428 with 1024 threads capped
+      // at 128 VGPRs); float runs 1024 threads at 114 VGPRs
+      launch_hx_lds<(sizeof(S) == 8 ? 512 : 1024)>(it, ylds_bytes, xin, y, dout, done_flag);
     }
   }
 
@@ -1697,7 +1467,7 @@ class Solver final : public rba_solver {
 
   void right_multiply(const void* x, void* y) override {
     use_device();
-    if (cols_pending_) run_stage2(S(0));  // the operator needs the scaled rows of the column pass
+    if (!landmark_damping_valid_) run_stage2(S(0));  // the operator needs the damping records (lambda = 0)
     d_vin_.upload(static_cast<const S*>(x), nvec_, stream_);
     d_tmp_.zero(stream_);
     launch_hx(d_vin_.get(), d_tmp_.get());
@@ -1715,19 +1485,12 @@ class Solver final : public rba_solver {
     if (!landmark_damping_valid_) throw HipError{"right_multiply_explicit needs a stage 2 first", RBA_ERR_INVALID_ARGUMENT};
     if (!ex_valid_) assemble_explicit();
     d_vin_.upload(static_cast<const S*>(x), nvec_, stream_);
-    if (fused_pcg_) {
-      // the SpMV of the fused PCG (kernels_pcg.hpp), refresh-product mode, on a cleared state
-      HIP_CHECK(hipMemsetAsync(d_cg_.get(), 0, sizeof(rba::CgState), stream_));
-      hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, d_cg_.get(), double(pose_damping_), 0);
-      launch_pcgs_product(exp_, d_vin_.get(), /*period=*/1);
-      hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, d_tmp_.get(),
-                         d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), nvec_);
-    } else {
-      hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, exp_, d_vin_.get(),
-                         d_tmp_.get(), static_cast<const int*>(nullptr));
-      hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
-                         d_vin_.get(), d_tmp_.get(), pose_damping_, nvec_);
-    }
+    // the SpMV of the fused PCG (kernels_pcg.hpp), refresh-product mode, on a cleared state
+    HIP_CHECK(hipMemsetAsync(d_cg_.get(), 0, sizeof(rba::CgState), stream_));
+    hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, d_cg_.get(), double(pose_damping_), 0);
+    launch_pcgs_product(exp_, d_vin_.get(), /*period=*/1);
+    hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, d_tmp_.get(),
+                       d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), nvec_);
     d_tmp_.download(static_cast<S*>(y), nvec_, stream_);
     sync();
   }
@@ -1743,6 +1506,7 @@ class Solver final : public rba_solver {
 
   static constexpr int kPcgPeriod = 10;  // residual_reset_period (conjugate_gradient.hpp:86-88)
   static constexpr int kPcgBlock = 5;    // iterations per captured launch graph
+  static constexpr int kPcgRunAhead = 6; // single iterations the host may queue ahead of the device
 
   // one PCG iteration of the fused path: product + update (+ the residual refresh)
   void enqueue_pcgs_iteration(const rba::ScParams<S>& M, bool with_refresh) {
@@ -1810,7 +1574,7 @@ class Solver final : public rba_solver {
     double* part_rho = d_pcg_partials_.get();
     // the device reads the direction of `it` completed iterations from P[(it + pswap) & 1]; it is in d_p_ now
     hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, st, double(lambda), (it_start - 1) & 1);
-    if (it_start > 1 && switch_refresh_) {
+    if (it_start > 1) {
       // operator switch inside a running solve: the residual is recomputed with the operator used
       // from here on, r = b - (S + lambda I) x, exactly like the periodic refresh
       launch_pcgs_product(M, d_x_.get(), 1);
@@ -1819,7 +1583,7 @@ class Solver final : public rba_solver {
     }
     hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(), d_z_.get(),
                        n, st, part_rho);
-    if (use_pcg_graphs_ && !pcg_graph_exec_[0]) build_pcg_graphs(M);
+    if (!pcg_graph_exec_[0]) build_pcg_graphs(M);
     volatile int* hp = h_progress_;
     hp[0] = it_start - 1;
     hp[1] = 0;
@@ -1835,18 +1599,18 @@ class Solver final : public rba_solver {
     bool running = true;
     while (running && it <= max_it) {
       const bool aligned = (it - 1) % kPcgBlock == 0;
-      if (use_pcg_graphs_ && aligned && it + kPcgBlock - 1 <= max_it) {
+      if (aligned && it + kPcgBlock - 1 <= max_it) {
         if (!(running = wait_for(it, kPcgBlock))) break;  // at most one block queued behind the running one
         const bool refresh = (it + kPcgBlock - 1) % kPcgPeriod == 0;
         HIP_CHECK(hipGraphLaunch(pcg_graph_exec_[refresh ? 1 : 0], stream_));
         it += kPcgBlock;
       } else {
-        if (!(running = wait_for(it, pcg_run_ahead_))) break;
+        if (!(running = wait_for(it, kPcgRunAhead))) break;
         enqueue_pcgs_iteration(M, it % kPcgPeriod == 0);
         ++it;
       }
     }
-    if (running && wait_for(it, pcg_run_ahead_)) enqueue_pcgs_final_test(M);
+    if (running && wait_for(it, kPcgRunAhead)) enqueue_pcgs_final_test(M);
     HIP_CHECK(hipGetLastError());
   }
 
@@ -1868,13 +1632,12 @@ class Solver final : public rba_solver {
     hx_event_count_ = 0;
     hx_calls_ = 0;
     rba_cg_summary cg = pcg(sc_ ? S(0) : lambda);  // SC: the damping is inside the matrix
-    static const bool force_fallback = std::getenv("RBA_FORCE_EXPLICIT_FALLBACK") != nullptr;  // tests
-    if (pcg_used_explicit_ && !sc_ && (cg.termination_type == 2 || pcg_indefinite_ || force_fallback)) {
+    if (pcg_used_explicit_ && !sc_ && (cg.termination_type == 2 || pcg_indefinite_ || env_.force_explicit_fallback)) {
       // The assembled operator is S + E with |E| ~ eps |S|: unlike the square-root product
       // (p.q = |A p|^2 + lambda |p|^2 >= 0 by construction) it can lose definiteness when
       // lambda < eps |S|. The reference's operator cannot - repeat this solve matrix-free.
       explicit_off_for_solve_ = true;
-      ++explicit_fallbacks_;
+      ++pcg_counters_.solves_repeated_matrix_free;
       cg = pcg(lambda);
       explicit_off_for_solve_ = false;
     }
@@ -1910,7 +1673,7 @@ class Solver final : public rba_solver {
         d_scratch_int_.download(&t, 1, stream_);
         sync();
       }
-      if (std::getenv("RBA_VERBOSE"))
+      if (env_.verbose)
         std::fprintf(stderr, "[rootba_hip] assembly %.3f ms, matrix-free product %.3f ms -> explicit_after = %d\n",
                      double(asm_ms), hx_ms / timed, t);
       explicit_after_ = t;
@@ -1941,9 +1704,9 @@ class Solver final : public rba_solver {
     // are no-ops (`done`).
     ex_active_ = false;
     pcg_used_explicit_ = false;
-    const bool fused = fused_pcg_ && n_items_ > 0 && opt_.preconditioner_type != 2;  // block-diagonal preconditioners
+    const bool fused = n_items_ > 0 && opt_.preconditioner_type != 2;  // block-diagonal preconditioners
     bool go_fused = sc_ && fused;  // explicit Schur-complement backend: the matrix exists from the start
-    int it = 1;
+    int it = 1, it_first_assembled = 1;
     for (; it <= max_it && !go_fused; ++it) {
       // Long solve: from here on the product is an SpMV with the explicitly assembled
       // S = sum_l A_l^T A_l (one assembly ~ 16 matrix-free products on venice; S is all-reduced
@@ -1954,6 +1717,7 @@ class Solver final : public rba_solver {
         if (!ex_valid_) assemble_explicit();
         ex_active_ = true;
         pcg_used_explicit_ = true;
+        it_first_assembled = it;
         if (fused) {
           go_fused = true;
           break;
@@ -1977,20 +1741,14 @@ class Solver final : public rba_solver {
         for (int i = 1; i <= opt_.power_order; ++i) {
           if (series_on_matrix) {
             // through the assembled matrix: (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t), no collective
-            if (n_items_ > 0) {
-              // the row-staged SpMV of the fused PCG (kernels_pcg.hpp, plain-product mode) + its collect
-              hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
-                                 SM.cols, SM.vals, d_items_.get(), static_cast<const S*>(nullptr),
-                                 static_cast<S*>(nullptr), static_cast<S*>(nullptr), t, d_qmain_.get(), d_qpart_.get(),
-                                 st, static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
-                                 static_cast<double*>(nullptr), double(lambda), 0, 0, 1, static_cast<int*>(nullptr));
-              hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, e,
-                                 d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), n);
-            } else {
-              hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, SM, t, e, done);
-              hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, t, e,
-                                 lambda, n);
-            }
+            // the row-staged SpMV of the fused PCG (kernels_pcg.hpp, plain-product mode) + its collect
+            hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
+                               SM.cols, SM.vals, d_items_.get(), static_cast<const S*>(nullptr),
+                               static_cast<S*>(nullptr), static_cast<S*>(nullptr), t, d_qmain_.get(), d_qpart_.get(),
+                               st, static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
+                               static_cast<double*>(nullptr), double(lambda), 0, 0, 1, static_cast<int*>(nullptr));
+            hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, e,
+                               d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), n);
             hipLaunchKernelGGL((rba::k_series_step<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), e, t,
                                d_z_.get(), n, st);
             continue;
@@ -2008,8 +1766,8 @@ class Solver final : public rba_solver {
         hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(),
                            d_r_.get(), d_z_.get(), n, st, part_rho);
       }
-      // (compact stage 2 and a matrix-free product next: the direction update also writes D p for it)
-      const bool pre = compact_ && !ex_active_;
+      // (a matrix-free product next: the direction update also writes D p for it)
+      const bool pre = !sc_ && !ex_active_;
       hipLaunchKernelGGL((rba::k_pcg_a2<S>), dim3(NB), dim3(T), 0, stream_, d_z_.get(), d_p_.get(),
                          d_q_.get(), n, st, part_rho, static_cast<const S*>(pre ? prm_.pose_scaling : nullptr),
                          pre ? d_xs_.get() : static_cast<S*>(nullptr));
@@ -2048,6 +1806,18 @@ class Solver final : public rba_solver {
     summary.termination_type = hst->termination;
     summary.num_iterations = hst->result_iter;
     pcg_indefinite_ = hst->indefinite != 0;
+    {
+      // products that did real work: one per iteration + one per residual refresh (every 10th), split at the
+      // iteration `it_switch` from which the assembled matrix was used (+ the refresh product of the switch)
+      const int n_it = summary.num_iterations;
+      const int it_switch = pcg_used_explicit_ && !sc_ ? std::min(it_first_assembled, n_it + 1) : (sc_ ? 1 : n_it + 1);
+      const int64_t mf_it = it_switch - 1, as_it = n_it - mf_it;
+      const int64_t series = opt_.preconditioner_type == 2 ? opt_.power_order : 0;  // products of the preconditioner
+      pcg_counters_.iterations += n_it;
+      pcg_counters_.products_matrix_free += mf_it + mf_it / 10 + (pcg_used_explicit_ || sc_ ? 0 : series * mf_it);
+      pcg_counters_.products_assembled += as_it > 0 ? as_it + (n_it / 10 - mf_it / 10) + (it_switch > 1 ? 1 : 0) + series * as_it
+                                                    : 0;
+    }
     return summary;
   }
 
@@ -2065,8 +1835,8 @@ class Solver final : public rba_solver {
       // tiled landmarks (k <= 32, implicit-Q configuration): one lane-per-row pass; the rest: two passes
       int lm0 = 0;
       int64_t o0 = 0;
-      const S* xin = scaled_operand(d_inc_.get());  // compact stage 2: D inc for the unscaled Jacobian rows
-      if (staged_ && n_tiles_ > 0 && !bs_two_pass_) {
+      const S* xin = scaled_operand(d_inc_.get());  // D inc for the unscaled Jacobian rows
+      if (n_tiles_ > 0) {
         hipLaunchKernelGGL((rba::k_bs_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, implicit_tiles(),
                            xin);
         lm0 = imp_end_[4];
@@ -2313,10 +2083,9 @@ class Solver final : public rba_solver {
   // ---- misc -----------------------------------------------------------------------------
   // PMC calibration helper: stream the block storage once; returns bytes read
   int64_t debug_read_A(int vec) override {
-    if (sc_) throw HipError{"the SCHUR_COMPLEMENT solver has no dense landmark blocks", RBA_ERR_UNSUPPORTED};
     use_device();
-    const size_t n = d_A_.size() * sizeof(S) / sizeof(float);
-    const float* src = reinterpret_cast<const float*>(d_A_.get());
+    const size_t n = d_JpS_.size() * sizeof(S) / sizeof(float);
+    const float* src = reinterpret_cast<const float*>(d_JpS_.get());
     float* sink = reinterpret_cast<float*>(d_tmp_.get());
     if (vec == 4)
       hipLaunchKernelGGL((rba::k_calib_read<4>), dim3(8192), dim3(256), 0, stream_, src, n, sink);
@@ -2371,10 +2140,14 @@ class Solver final : public rba_solver {
       for (int c = 0; c < 3; ++c) qo[3 * size_t(perm_[s]) + c] = q[3 * size_t(s) + c];
     }
   }
-  // compulsory HBM bytes per launch group in this layout (include/rootba_hip.h: rba_byte_model)
+  // compulsory HBM bytes per launch group in this layout (include/rootba_hip.h: rba_byte_model): every record read
+  // or written once by the kernel group that needs it, per-landmark and camera-sized data once per kernel. The
+  // measured traffic (rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/) can only be larger: gathers fetch whole cache
+  // lines, per-landmark records are re-read by the work-items of a landmark. tests/test_byte_model.py holds the
+  // model to that bound on the committed counter tables.
   void get_byte_model(rba_byte_model* m) override {
     const int64_t s = sizeof(S), no = n_obs_, nl = n_lms_, nc = n_cams_;
-    const int64_t geometry_in = no * (2 * s + 8) + nl * (3 * s + 12) + nc * 10 * s;  // obs, indices, points, cameras
+    const int64_t geometry_in = no * (2 * s + 8) + nl * 3 * s + nc * 10 * s;  // observations, their two indices, points, cameras
     m->compute_error = geometry_in;
     if (sc_) {
       m->stage1 = 2 * geometry_in + no * (26 * s) + nl * 12 * s + nc * 9 * s;
@@ -2382,41 +2155,38 @@ class Solver final : public rba_solver {
       m->back_substitution = no * (26 * s + 4) + nl * 18 * s;
       m->product_matrix_free = 0;
     } else {
-      if (opt_.implicit_q) {
-        // kernels_s1.hpp: geometry writes JpS 18 + Vh 8; Gram pass reads JpS 18 (+ CSC index); QR pass reads
-        // Vh 8, writes Vh 8 + JlS 6 + rS 2 (the column pass belongs to stage 2 here)
-        m->stage1 = geometry_in + no * ((18 + 8) + 18 + (8 + 8 + 6 + 2)) * s + no * (4 + 8) + nl * (12 + 12) * s +
-                    nc * (9 + 81 + 81 + 9) * s;
-        // one GPU, compact stage 2: the Gram pass (JpS 18 + CSC index) is folded into the stage-2 camera pass, which
-        // reads those rows anyway (already counted there)
-        if (compact_ && fused_gram_ && !comm_ && !cb_fn_ && opt_.staged_execution) m->stage1 -= no * (18 * s + 4);
-      } else {
-        // round-1 kernels: top0 27, JpS 18, bmO 9, JlS 6, rS 2, Vh 8 and the dense blocks
-        m->stage1 = 2 * geometry_in + no * 4 /* CSC */ + no * (27 + 18 + 9 + 6 + 2 + 8) * s + nl * 12 * s +
-                    storage_dense_bytes_ + no * (27 * s + 4) /* camera-major read of JpS, bmO */ + nc * (9 + 90) * s;
-      }
-      if (compact_)  // landmark records; W8 pass: Vh 8 in, W8 8 out; camera pass: JpS 18 + W8 8 (+ CSC index) in
-        m->stage2 = nl * (6 + 3 + 16 + 6 + 3 + 3 + 9 + 12) * s + no * (8 + 8) * s + no * 8 + no * ((18 + 8) * s + 4) +
-                    nc * 180 * s;
-      else if (opt_.implicit_q)  // landmark records; fused column pass: JpS 18 + Vh 8 in, topd 27 + JpS 18 + bO 9 out; camera pass
-        m->stage2 = nl * (6 + 3 + 16 + 6 + 3 + 3 + 9 + 12) * s + no * ((18 + 8) + (27 + 18 + 9)) * s + no * 8 +
-                    no * ((27 + 9) * s + 4) + nc * 180 * s;
-      else
-        m->stage2 = nl * (6 + 3 + 16 + 6 + 3 + 3 + 9) * s + no * (27 + 27 + 9) * s + no * ((27 + 9) * s + 4) + nc * 180 * s;
-      m->back_substitution = no * (18 + 27 + 5 + 4) * s + no * (5 + 6 + 2 + 2) * s + nl * (6 + 3 + 3 + 3 + 3 + 8) * s;
+      const int64_t no_untiled = no - (n_tiles_ > 0 ? n_obs_tiled_ : 0);
+      // stage 1: geometry writes JpS 18 + Vh 8; the QR pass reads Vh 8 (+ the row map, 4 B per block row) and writes
+      // Vh 8 + JlS 6 + rS 2 per observation, R0 6 + tau 3 + LQ 12 + Jl_col_scale 3 per landmark
+      m->stage1 = geometry_in + no * ((18 + 8) + (8 + 8 + 6 + 2)) * s + no * 8 + nl * 24 * s;
+      // the Gram pass on its own (JpS 18 + CSC index in, G 81 + Jp_diag2 9 out): not on one GPU, where it rides on the
+      // camera pass of the first stage 2, which reads those rows anyway (already counted there)
+      if (comm_ || cb_fn_ || !opt_.staged_execution) m->stage1 += no * (18 * s + 4) + nc * 90 * s;
+      // stage 2, landmark side (k_s2_obs): Vh 8 + landmark index in, WA 8 out per observation (+ the eight coefficients
+      // of the untiled ones); R0 6 + LQ 12 + the first three reflector rows 12 in, givens 16 + Rd 6 + Q1^T r 3 +
+      // damping residual 3 + Z 9 out per landmark. Camera pass: JpS 18 + WA 8 + CSC index in; blocks 81, b 9,
+      // Jp_diag2 9, scaling 9 out
+      m->stage2 = no * (8 * s + 4) + no * 8 * s + no_untiled * 8 * s + nl * (30 + 37) * s + no * (26 * s + 4) +
+                  nc * 108 * s;
+      // back-substitution, one pass on the wave tiles (k_bs_tile): JpS 18 + Vh 8 + JlS 6 + rS 2 and the two lane
+      // maps (4 B each per block row) per observation = 152 B in float; tau 3 + givens 16 + Rd 6 + Q1^T r 3 +
+      // Jl_col_scale 3 in, the point in and out (6) and l_diff (8 B) out per landmark. The two-kernel form of the
+      // untiled landmarks adds the eight coefficients and its 5-scalar scratch (write + read) per observation.
+      m->back_substitution = no * (34 * s + 16) + no_untiled * (8 + 10) * s + nl * (37 * s + 8) + nc * 9 * s;
       // implicit-Q product: JpS row 9 + Vh row 4 per block row, camera / row maps, tau + Z per landmark
-      m->product_matrix_free = opt_.implicit_q ? no * (26 * s + 16) + nl * 12 * s + nc * 18 * s : hx_bytes_;
+      m->product_matrix_free = no * (26 * s + 16) + nl * 12 * s + nc * 18 * s;
     }
     const int64_t nnz = sc_ ? sc_nnz_ : ex_nnz_;
     m->product_assembled = nnz * (81 * s + 4) + nc * 18 * s;
     m->assembly = sc_ ? sc_assemble_bytes_ : ex_pairs_ * (8 + 54 * s) + nnz * 81 * s;
-    if (compact_ && !sc_)  // + the column pass that materialises the 27 + 9 records: JpS 18 + Vh 8 in, 36 out
+    if (!sc_)  // + the column pass that materialises the 27 + 9 records: JpS 18 + Vh 8 in, 36 out
       m->assembly += int64_t(n_obs_) * (18 + 8 + 36) * s;
     m->pcg_vectors = nc * (81 + 10 * 9) * s;
   }
+  void get_pcg_counters(rba_pcg_counters* out) override { *out = pcg_counters_; }
   void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) override {
     *storage = storage_bytes_;
-    *hx_bytes = (opt_.implicit_q && !sc_) ? hx_implicit_bytes_ : hx_bytes_;
+    *hx_bytes = sc_ ? hx_bytes_ : hx_implicit_bytes_;
     *hx_flops = hx_flops_;
   }
 
@@ -2479,13 +2249,33 @@ class Solver final : public rba_solver {
     if (cls_end_[4] > cls_begin_[4]) f(std::integral_constant<int, 16>{}, cls_begin_[4], cls_end_[4]);
   }
 
-  template <class F>
-  void for_each_class_reverse(F&& f) {
-    if (cls_end_[4] > cls_begin_[4]) f(std::integral_constant<int, 16>{}, cls_begin_[4], cls_end_[4]);
-    if (cls_end_[3] > cls_begin_[3]) f(std::integral_constant<int, 8>{}, cls_begin_[3], cls_end_[3]);
-    if (cls_end_[2] > cls_begin_[2]) f(std::integral_constant<int, 4>{}, cls_begin_[2], cls_end_[2]);
-    if (cls_end_[1] > cls_begin_[1]) f(std::integral_constant<int, 2>{}, cls_begin_[1], cls_end_[1]);
-    if (cls_end_[0] > cls_begin_[0]) f(std::integral_constant<int, 1>{}, cls_begin_[0], cls_end_[0]);
+  // Debug / test environment, read ONCE per handle in construct() (none is needed in production; include/rootba_hip.h
+  // lists them). Everything that selects between kernels of equal results is a test hook here, not API.
+  struct DebugEnv {
+    int verbose = 0;                   // RBA_VERBOSE=1: break-even / budget messages on stderr
+    int explicit_after = INT_MIN;      // RBA_EXPLICIT_AFTER=n: overrides rba_options.explicit_after
+    double pair_budget_gb = 24.0;      // RBA_EX_PAIR_BUDGET_GB=x: budget of the pair lists of the assembled matrix
+    int force_explicit_fallback = 0;   // RBA_FORCE_EXPLICIT_FALLBACK=1: treat every solve on the assembled matrix as broken down
+    int hx_lds = 1;                    // RBA_HX_LDS=0 never / 1 automatic / 2 whenever possible: LDS-private products
+    int hx_win = 0;                    // RBA_HX_WIN=n: cap of the camera window of the LDS-private products
+    int hx_timing_stride = -1;         // RBA_HX_TIMING_STRIDE=n: HIP events around every n-th matrix-free product
+    int sort_by_camera = -1;           // RBA_SORT_BY_CAMERA=0/1: override the automatic choice
+  };
+  DebugEnv env_;
+  void read_debug_env() {
+    auto geti = [](const char* name, int dflt) {
+      const char* ev = std::getenv(name);
+      return ev ? std::atoi(ev) : dflt;
+    };
+    env_.verbose = geti("RBA_VERBOSE", 0);
+    env_.explicit_after = geti("RBA_EXPLICIT_AFTER", INT_MIN);
+    if (const char* ev = std::getenv("RBA_EX_PAIR_BUDGET_GB")) env_.pair_budget_gb = std::atof(ev);
+    env_.force_explicit_fallback = geti("RBA_FORCE_EXPLICIT_FALLBACK", 0);
+    env_.hx_lds = geti("RBA_HX_LDS", 1);
+    env_.hx_win = geti("RBA_HX_WIN", 0);
+    env_.hx_timing_stride = geti("RBA_HX_TIMING_STRIDE", -1);
+    env_.sort_by_camera = geti("RBA_SORT_BY_CAMERA", -1);
+    if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }
 
   int device_;
@@ -2493,24 +2283,23 @@ class Solver final : public rba_solver {
   int64_t n_obs_ = 0;
   int nvec_ = 0;
   rba_options opt_;
-  hipStream_t stream_ = nullptr, stream2_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  hipStream_t stream_ = nullptr;
   std::vector<int> perm_;
   int cls_begin_[kNumClasses], cls_end_[kNumClasses];
   int big_begin_ = 0, n_big_ = 0, big_kmax_ = 0;
   static constexpr int kNumImplicit = 7;
   int imp_begin_[kNumImplicit], imp_end_[kNumImplicit];
   int64_t hx_bytes_ = 0, hx_flops_ = 0, storage_bytes_ = 0, hx_implicit_bytes_ = 0;
-  int64_t storage_dense_bytes_ = 0, ex_pairs_ = 0, ex_pair_bytes_ = 0;
+  int64_t ex_pairs_ = 0, ex_pair_bytes_ = 0;
   rba::Params<S> prm_{};
   S pose_damping_ = S(0);
   bool landmark_damping_valid_ = false;
   rba_iter_timings timings_{};
   // device buffers
   DevBuf<int> d_lm_k_, d_obs_cam_, d_obs_lm_, d_fail_;
-  DevBuf<int64_t> d_lm_obs_, d_lm_blk_, d_cam_off_;
+  DevBuf<int64_t> d_lm_obs_, d_cam_off_;
   DevBuf<int> d_cam_obs_;
-  DevBuf<S> d_JpS_, d_bmO_, d_Vh_, d_tauH_, d_Zd_, d_LQ_, d_JlS_, d_rS_, d_bsO_, d_givens_;
+  DevBuf<S> d_JpS_, d_Vh_, d_tauH_, d_Zd_, d_LQ_, d_JlS_, d_rS_, d_bsO_, d_givens_;
   DevBuf<int> d_CT_, d_RT_;
   int64_t n_obs_small_ = 0, n_obs_tiled_ = 0;
   DevBuf<S> d_big_scratch_;
@@ -2522,36 +2311,20 @@ class Solver final : public rba_solver {
   DevBuf<double> d_obs_xy64_, d_cams64_, d_lms64_, d_cams64_bak_, d_lms64_bak_;
   DevBuf<S> d_lm_inc_;
   rba::Params<double> prm64_{};
-  DevBuf<S> d_A_, d_top0_, d_topd_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;
+  DevBuf<S> d_topd_, d_R0_, d_Rd_, d_q1trd_, d_damp_r_, d_jl_scale_;
   DevBuf<S> d_jp_diag2_, d_pose_scaling_, d_mid_, d_bb_, d_inv_;
   DevBuf<S> d_x_, d_r_, d_p_, d_z_, d_q_, d_tmp_, d_inc_, d_vin_, d_pw_t_, d_pw_e_;
   DevBuf<double> d_lm_ldiff_, d_partials_, d_pcg_partials_;
   DevBuf<rba::CgState> d_cg_;
-  DevBuf<rba::SmallBatch> d_batches_;
-  int n_small_batches_ = 0;
-  size_t small_lds_bytes_ = 0;
   char* h_pinned_ = nullptr;
   hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
   std::vector<hipEvent_t> hx_events_;
   std::vector<int> hx_event_call_;  // which H*x call of the solve each event pair brackets
   int hx_event_count_ = 0, hx_calls_ = 0;
-  bool hx_single_stream_ = false;
-  bool qr_unpacked_ = false;  // RBA_QR_UNPACKED=1: one wavefront per landmark also for k <= 7
-  bool s1_fused_ = false;     // RBA_S1_FUSED=1: round-1 stage 1 (geometry + QR + columns in one kernel)
-  bool staged_ = false;       // stage 1 staged by parallelism (kernels_s1.hpp): implicit-Q configuration
-  bool cols_pending_ = false; // linearised, column pass not yet run (it runs inside the first stage 2)
-  bool bs_two_pass_ = false;  // RBA_BS_TWO_PASS=1: round-1 back-substitution kernels for every landmark
-  int hx_threads_ = 1024;     // RBA_HX_THREADS=512: 512-thread workgroups of k_hx_implicit_lds (no scratch in double)
-  int hx_lds_ = 1;            // RBA_HX_LDS=0: never use the LDS-private y copy (k_hx_implicit_lds); 2: whenever y fits
-                              // (default 1: when it fits and every wave gets at least four tiles)
   bool operand_prescaled_ = false;
-  bool fused_gram_ = true;     // RBA_FUSED_GRAM=0: always run the stage-1 Gram pass
   DevBuf<S> d_WA_;             // stage-2 records of the camera-major pass (kernels_cam.hpp)
-  bool s2_fused_lm_ = true;    // landmark damping inside the per-observation pass of stage 2 (k_s2_w8_fused; measured on
-                               // venice: stage 2 0.443 -> 0.402 ms); RBA_S2_FUSED_LM=0: thread-per-landmark pass + k_s2_w8
   bool gram_pending_ = false;  // linearised without the Gram pass: the first stage 2's camera pass does it
-  bool compact_ = false;     // stage 2 hands W8 (8 scalars per observation) to the camera pass, JpS stays unscaled
-  bool topd_valid_ = false;  // compact: the 27 + 9 records exist for the current damping (assembly / E0 products only)
+  bool topd_valid_ = false;    // the 27 + 9 records exist for the current damping (assembly / E0 products only)
   DevBuf<S> d_W8_, d_xs_;
   rba_substage_timings sub_{};
   std::vector<hipEvent_t> sub_events_;
@@ -2563,10 +2336,6 @@ class Solver final : public rba_solver {
   double hx_coverage_ = 1.0;  // share of the tiled block rows whose camera lies inside its workgroup's LDS window
   static constexpr size_t kHxLdsMaxBytes = 152 * 1024;  // of the CU's 160 KB
   int n_cus_ = 256;
-  int y_rep_ = 1;             // RBA_Y_REPLICAS=n: privatised scatter targets of the matrix-free products
-                              // (measured on venice: 4 / 16 / 64 replicas change H*x by < 2 % - the kernel is bound
-                              //  by its 0.96 GB of HBM traffic, not by atomic serialisation; off by default)
-  DevBuf<S> d_yrep_;
   // explicit reduced matrix of the square-root solver (adaptive, see pcg())
   int explicit_after_ = 0;  // matrix-free products before a solve switches to S x; 0 = never
   bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;
@@ -2589,12 +2358,8 @@ class Solver final : public rba_solver {
   int n_items_ = 0;
   int* h_progress_ = nullptr;  // pinned: [0] iteration started on the device, [1] done
   bool pcg_used_explicit_ = false, pcg_indefinite_ = false, explicit_off_for_solve_ = false;
-  int explicit_fallbacks_ = 0;  // solves repeated matrix-free after the assembled operator broke down
+  rba_pcg_counters pcg_counters_{};
   hipGraphExec_t pcg_graph_exec_[2] = {nullptr, nullptr};
-  bool use_pcg_graphs_ = true;  // RBA_PCG_GRAPHS=0: eager launches
-  bool switch_refresh_ = true;  // RBA_SWITCH_REFRESH=0: keep the recursive residual across the operator switch
-  bool fused_pcg_ = true;      // RBA_FUSED_PCG=0: the seven-launch iteration of round 1
-  int pcg_run_ahead_ = 6;      // iterations the host may queue ahead of the device
   // explicit Schur-complement backend (solver_type = 1)
   bool sc_ = false;
   int sc_nnz_ = 0;
@@ -2939,6 +2704,13 @@ int rba_get_landmark_R(rba_handle h, int damped, void* R6, void* q3) {
 int rba_get_byte_model(rba_handle h, rba_byte_model* out) {
   return guarded([&]() -> int {
     h->get_byte_model(out);
+    return RBA_OK;
+  });
+}
+int rba_get_pcg_counters(rba_handle h, rba_pcg_counters* out) {
+  return guarded([&]() -> int {
+    if (!out) return RBA_ERR_INVALID_ARGUMENT;
+    h->get_pcg_counters(out);
     return RBA_OK;
   });
 }

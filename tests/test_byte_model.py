@@ -1,0 +1,50 @@
+"""The library's byte model (rba_get_byte_model: compulsory HBM bytes per launch group, the numerator of the per-stage
+rooflines bench.py prints) against the traffic MEASURED with rocprofv3 PMC counters on an MI355X
+(profiles/r3_pmc_stage_traffic.json, made by scripts/run_pmc_stage_traffic.sh from the same run that recorded the
+model). A compulsory-bytes model can never exceed what the hardware moved; round 2's back-substitution model did
+ and nothing checked it."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "profiles", "r3_pmc_stage_traffic.json")
+
+
+@pytest.fixture(scope="module")
+def table():
+    with open(PATH) as f:
+        return json.load(f)
+
+
+def test_model_never_exceeds_measured_traffic(table):
+    for name, g in table["groups"].items():
+        assert g["launches"] > 0, name
+        # 3 %: FETCH_SIZE is calibrated on a streaming read, per-kernel access patterns deviate slightly
+        assert g["model_bytes_per_launch"] <= 1.03 * g["measured_bytes_per_launch"], (name, g)
+
+
+def test_measured_traffic_is_close_to_the_model_where_the_kernels_stream(table):
+    """Streams (cost evaluation, stage 1, the products, the back-substitution) move within 15 % of the model; the
+    camera-major gather of stage 2 and the pair gather of the assembly fetch whole cache lines for 72- / 108-byte
+    records and stay below 2 x (DESIGN.md 4 discusses both)."""
+    g = table["groups"]
+    for name in ("compute_error", "stage1", "product_matrix_free", "product_assembled", "back_substitution"):
+        assert g[name]["measured_over_model"] < 1.15, (name, g[name])
+    for name in ("stage2", "assembly"):
+        assert g[name]["measured_over_model"] < 2.0, (name, g[name])
+
+
+def test_fetch_size_calibration_matches_the_guide(table):
+    """gfx950: FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section)."""
+    c = table["fetch_correction"]
+    assert 1.9 < c["measured_16B_loads"] < 2.1 and 1.9 < c["measured_4B_loads"] < 2.1
+    assert c["used"] == c["measured_16B_loads"]
+
+
+def test_bench_traffic_file_comes_from_the_same_pass(table):
+    with open(os.path.join(ROOT, "profiles", "hx_traffic.json")) as f:
+        hx = json.load(f)["venice-1778/implicit_q"]
+    assert hx["traffic_bytes_per_launch"] == table["groups"]["product_matrix_free"]["measured_bytes_per_launch"]
+    assert hx["model_bytes_per_launch"] == table["groups"]["product_matrix_free"]["model_bytes_per_launch"]

@@ -121,11 +121,10 @@ def test_compute_error(small_problem, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("which", ["small", "mixed"])
-@pytest.mark.parametrize("implicit_q", [1, 0])  # products from the QR factors (default) / dense blocks
-def test_linearization_stage2_operator_backsub(small_problem, mixed_k_problem, dtype, which, implicit_q):
+def test_linearization_stage2_operator_backsub(small_problem, mixed_k_problem, dtype, which):
     prob = small_problem if which == "small" else mixed_k_problem
     tol = TOL[dtype]
-    g, o = _pair(prob, dtype, implicit_q=implicit_q)
+    g, o = _pair(prob, dtype)
     st, d2 = g.linearize(want_jp_diag2=True)
     assert st == 0 and o.linearize() == 0
     assert rel_err(g.pose_scaling(), o.pose_scaling()) < tol
@@ -159,10 +158,9 @@ def test_linearization_stage2_operator_backsub(small_problem, mixed_k_problem, d
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("precond", [0, 1])
-@pytest.mark.parametrize("implicit_q", [1, 0])
-def test_solve_and_apply(small_problem, dtype, precond, implicit_q):
+def test_solve_and_apply(small_problem, dtype, precond):
     tol = TOL[dtype]
-    g, o = _pair(small_problem, dtype, preconditioner_type=precond, implicit_q=implicit_q)
+    g, o = _pair(small_problem, dtype, preconditioner_type=precond)
     assert g.linearize() == 0 and o.linearize() == 0
     ig, cg = g.solve(1e-4)
     io, co = o.solve(1e-4)
@@ -214,7 +212,7 @@ def test_implicit_q_operator(small_problem, mixed_k_problem, long_track_problem,
     is the same operator as the dense Q2^T Jp product (and as the oracle's)."""
     prob = {"small": small_problem, "mixed": mixed_k_problem, "long": long_track_problem}[which]
     tol = TOL[dtype]
-    gi, o = _pair(prob, dtype, implicit_q=1)
+    gi, o = _pair(prob, dtype)
     gd, _ = _pair(prob, dtype)
     assert gi.linearize() == 0 and gd.linearize() == 0 and o.linearize() == 0
     rng = np.random.default_rng(0)
@@ -227,7 +225,7 @@ def test_implicit_q_operator(small_problem, mixed_k_problem, long_track_problem,
         h_o, h_i, h_d = o.right_multiply(x), gi.right_multiply(x), gd.right_multiply(x)
         assert rel_err(h_i, h_o) < tol and rel_err(h_i, h_d) < tol
     # full solve on a fresh pair (the oracle scales Jp inside its first stage 2)
-    gi2, o2 = _pair(prob, dtype, implicit_q=1)
+    gi2, o2 = _pair(prob, dtype)
     assert gi2.linearize() == 0 and o2.linearize() == 0
     ii, ci = gi2.solve(1e-4)
     io, co = o2.solve(1e-4)
@@ -248,7 +246,7 @@ def test_implicit_q_product_kernels(small_problem, mixed_k_problem, dtype, which
     prob = {"small": small_problem, "mixed": mixed_k_problem}[which]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    g, o = _pair(prob, dtype, implicit_q=1)
+    g, o = _pair(prob, dtype)
     assert g.linearize() == 0 and o.linearize() == 0
     rng = np.random.default_rng(5)
     for lam in (LAMBDA, 1e-6):
@@ -261,7 +259,7 @@ def test_implicit_q_product_kernels(small_problem, mixed_k_problem, dtype, which
 
 
 def test_implicit_q_lm_run(ladybug_far):
-    gi, o = _pair(ladybug_far, np.float64, implicit_q=1, max_num_iterations=8)
+    gi, o = _pair(ladybug_far, np.float64, max_num_iterations=8)
     li, _ = gi.optimize_lm()
     lo, _ = o.optimize_lm()
     assert len(li) == len(lo)
@@ -290,8 +288,7 @@ def ladybug_far():
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("implicit_q", [1, 0])
-def test_lm_trajectory_matches_oracle(ladybug_far, dtype, implicit_q):
+def test_lm_trajectory_matches_oracle(ladybug_far, dtype):
     """Whole LM runs: same accept/reject decisions, CG iteration counts and costs
     while the steps are large, and the SAME FINAL COST within 1e-6 relative
     (north_star). Both sides run a fixed 12 iterations (function_tolerance = 0):
@@ -300,7 +297,7 @@ def test_lm_trajectory_matches_oracle(ladybug_far, dtype, implicit_q):
     different summation orders drift apart at the 1e-3 level in the late, tiny
     increments (truncated CG, eta = 0.1); increments are therefore compared in
     lock-step in the next test."""
-    g, o = _pair(ladybug_far, dtype, max_num_iterations=12, function_tolerance=0.0, implicit_q=implicit_q)
+    g, o = _pair(ladybug_far, dtype, max_num_iterations=12, function_tolerance=0.0)
     lg, tg = g.optimize_lm()
     lo, to = o.optimize_lm()
     for a, b in zip(lg[:5], lo[:5]):
@@ -494,19 +491,18 @@ def test_numerical_failure_is_reported_not_fatal(small_problem):
 # ---------------------------------------------------------------------------
 # BASELINE.json's full size: size-independent properties on venice-1778
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("implicit_q", [1, 0])
-def test_full_size_venice_properties(implicit_q):
+def test_full_size_venice_properties():
     import torch  # noqa: F401
     from rootba_amd import _lib as L
     from rootba_amd import problem as P
     from rootba_amd.linearizor import LinearizorHIP
     prob = P.preprocess(P.named_synthetic("venice-1778"), translation_sigma=0.5, point_sigma=0.5)
-    g = LinearizorHIP(prob, np.float32, _opts(L, max_num_iterations=3, implicit_q=implicit_q))
+    g = LinearizorHIP(prob, np.float32, _opts(L, max_num_iterations=3))
     stats = g.problem_stats()
     want = {k: prob.block_stats()[k] for k in stats}
-    if implicit_q:  # s * sum_l (2k (9 + 3) + 3 (2k + 3) + 12) + camera indices + x and y
-        k = prob.obs_per_lm().astype(np.int64)
-        want["hx_bytes"] = int(4 * (2 * k * 12 + 3 * (2 * k + 3) + 12).sum() + 4 * prob.n_obs + 4 * 18 * prob.n_cams)
+    # SURVEY.md 8d, implicit-Q product: s * sum_l (2k (9 + 3) + 3 (2k + 3) + 12) + camera indices + x and y
+    k = prob.obs_per_lm().astype(np.int64)
+    want["hx_bytes"] = int(4 * (2 * k * 12 + 3 * (2 * k + 3) + 12).sum() + 4 * prob.n_obs + 4 * 18 * prob.n_cams)
     assert stats == want
     e0 = g.compute_error()
     assert e0.all_num_obs == prob.n_obs and e0.is_numerically_valid
@@ -652,14 +648,12 @@ def test_schur_complement_unsupported_combinations(small_problem):
 # ---- explicit reduced matrix of the square-root solver (rba_options.explicit_after) -------------
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("which", ["small", "mixed", "long"])
-@pytest.mark.parametrize("implicit_q", [1, 0])
-def test_explicit_reduced_matrix_is_the_same_operator(small_problem, mixed_k_problem, long_track_problem, dtype, which,
-                                                      implicit_q):
+def test_explicit_reduced_matrix_is_the_same_operator(small_problem, mixed_k_problem, long_track_problem, dtype, which):
     """S = sum_l A_l^T A_l assembled block-wise (off-diagonal blocks from the damped top rows,
     diagonal blocks from stage 2) applies like the matrix-free product and like the oracle."""
     prob = {"small": small_problem, "mixed": mixed_k_problem, "long": long_track_problem}[which]
     tol = TOL[dtype]
-    g, o = _pair(prob, dtype, implicit_q=implicit_q)
+    g, o = _pair(prob, dtype)
     assert g.linearize() == 0 and o.linearize() == 0
     rng = np.random.default_rng(3)
     for lam in (LAMBDA, 1e-6):
@@ -786,16 +780,6 @@ def test_tracks_of_any_length(very_long_track_problem, dtype):
         assert abs(a.cost - b.cost) <= (ftol if dtype == np.float32 else 1e-9) * b.cost
 
 
-def test_dense_block_configuration_still_limits_track_length(very_long_track_problem):
-    """implicit_q = 0 materialises the 2k x 9k blocks and keeps landmark-sized vectors in LDS: it
-    refuses what it cannot hold instead of failing later."""
-    import torch  # noqa: F401
-    from rootba_amd import _lib as L
-    from rootba_amd.linearizor import LinearizorHIP
-    with pytest.raises(RuntimeError, match="not supported|does not fit"):
-        LinearizorHIP(very_long_track_problem, np.float32, _opts(L, implicit_q=0))
-
-
 def test_unstaged_substage_timers(small_problem):
     """staged_execution = 0: the reference's unstaged timers (linearizor_qr.cpp:94-112, 166-187) are measured
     between the kernel groups of the two stages and add up to (at most) the stage times; staged execution
@@ -816,6 +800,9 @@ def test_unstaged_substage_timers(small_problem):
         if staged:
             assert all(v == 0.0 for v in vals.values()), vals
         else:
+            # (the landmark damping is evaluated inside the per-observation pass of stage 2 and timed with it:
+            #  include/rootba_hip.h, rba_substage_timings)
+            assert vals.pop("landmark_damping_time") == 0.0
             assert all(v > 0.0 for v in vals.values()), vals
             st1 = s1.jacobian_evaluation_time + s1.scale_landmark_jacobian_time + s1.stage1_preconditioner_time + \
                 s1.perform_qr_time

@@ -91,7 +91,7 @@ def test_compute_error(R, small_problem, dtype):
 
 
 VARIANTS = [("sqrt-schur_jacobi", dict()), ("sqrt-jacobi", dict(preconditioner_type=0)),
-            ("sqrt-dense-blocks", dict(implicit_q=0)), ("sqrt-squared-norm", dict(robust_norm=0)),
+            ("sqrt-squared-norm", dict(robust_norm=0)),
             ("sc-schur_jacobi", dict(solver_type=1)), ("sc-power", dict(solver_type=1, preconditioner_type=2, power_order=5))]
 
 
