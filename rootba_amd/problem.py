@@ -165,11 +165,17 @@ def so3_log(R: np.ndarray) -> np.ndarray:
     return v * scale[..., None]
 
 
-def project(cams: np.ndarray, p_w: np.ndarray):
+def project(cams: np.ndarray, p_w: np.ndarray, cam_idx=None):
     """Snavely projection without the minus sign (reference
-    src/rootba/bal/snavely_projection.hpp:182-190). cams [n,10], p_w [n,3].
+    src/rootba/bal/snavely_projection.hpp:182-190). cams [n,10], p_w [n,3] - or, with `cam_idx` [n], the camera
+    TABLE [n_cams,10] (the rotation matrices are then formed once per camera and gathered: the same values bit for
+    bit, 30 M quaternion conversions less at final-13682 size).
     Returns (proj [n,2], z [n])."""
-    R = quat_to_rot(cams[:, :4])
+    if cam_idx is not None:
+        R = quat_to_rot(cams[:, :4])[cam_idx]
+        cams = cams[cam_idx]
+    else:
+        R = quat_to_rot(cams[:, :4])
     p_c = np.einsum("nij,nj->ni", R, p_w) + cams[:, 4:7]
     m = p_c[:, :2] / p_c[:, 2:3]
     r2 = (m * m).sum(1)
@@ -239,7 +245,7 @@ def synthetic_problem(n_cams: int, n_lms: int, n_obs_target: int, seed: int = RA
         lms[todo] = np.einsum("nij,nj->ni", R_w_c[base[todo]], p_c) + centers[base[todo]]
         sel = np.isin(lm_of_obs, todo) if todo.size < n_lms else slice(None)
         lm_sel = lm_of_obs[sel]
-        _, z = project(cams[cam_idx[sel]], lms[lm_sel])
+        _, z = project(cams, lms[lm_sel], cam_idx[sel])
         bad = np.unique(lm_sel[z < 0.1])
         if bad.size == 0:
             break
@@ -247,7 +253,7 @@ def synthetic_problem(n_cams: int, n_lms: int, n_obs_target: int, seed: int = RA
     else:
         raise RuntimeError("could not place all landmarks in front of their cameras")
 
-    proj, _ = project(cams[cam_idx], lms[lm_of_obs])
+    proj, _ = project(cams, lms[lm_of_obs], cam_idx)
     obs_xy = proj + rng.normal(0, obs_noise, proj.shape)
     return BalProblem(cams, lms, off, cam_idx, obs_xy, name)
 
@@ -328,7 +334,7 @@ def filter_obs(prob: BalProblem, threshold: float) -> BalProblem:
         return prob
     k = prob.obs_per_lm()
     lm_of_obs = np.repeat(np.arange(prob.n_lms, dtype=np.int64), k)
-    _, z = project(prob.cams[prob.obs_cam_idx], prob.lms[lm_of_obs])
+    _, z = project(prob.cams, prob.lms[lm_of_obs], prob.obs_cam_idx)
     keep = z >= threshold
     k_new = np.bincount(lm_of_obs[keep], minlength=prob.n_lms)
     lm_keep = k_new >= 2

@@ -1,0 +1,107 @@
+"""BASELINE.json config 5's problem size on one GPU: final-13682 (13 682 cameras, 4.46 M landmarks, 29.0 M
+observations; synthetic stand-in), float32 and the mixed f32/f64 mode, against the float32 CPU oracle
+(27.5 GB of dense landmark blocks on the host): every vector of one LM iteration - cost, Jl / Jp scalings, b, the
+SCHUR_JACOBI block diagonal, one H x from the factors and one through the assembled matrix, the back-substitution -
+and a two-iteration LM lock-step from identical states with the increment VECTORS compared (VERDICT round 2,
+"next round" 1a; reference test: src/rootba/qr/linearization_qr.test.cpp:125-211).
+
+What float32 resolves at this size is measured, not assumed: a FLOAT64 run of the HIP library from the same state
+(with the float Jacobian-scaling epsilon; the float64 path is held to the float64 oracle at 1e-10 by
+tests/test_gpu_parity.py - the float64 oracle itself would need 55 GB here) is the referee, and every float32 vector
+must be as close to it as the float32 oracle's: `|gpu32 - f64| <= 1.5 |oracle32 - f64| + floor`. Measured on an
+MI355X (round 3): b 5.8e-5 / 8.7e-4 (oracle 5.9e-5 / 8.8e-4 - the gradient cancels near the optimum), blocks 7e-7,
+H x 9e-7, increments 1.5e-4 / 8.3e-4 (oracle 1.6e-4 / 8.4e-4), PCG iterations 2 / 5 in all three.
+Costs ~1 minute on the GPU box (problem 11 s, oracle 3 s, two oracle iterations of 4-5 s per precision).
+Skipped on hosts with less than 48 GB of free memory."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+LAMBDAS = (1e-4, 1e-4 / 3)  # the first two damping values of the LM loop while every step is accepted
+
+
+@pytest.fixture(scope="module")
+def final_problem():
+    import psutil
+    if psutil.virtual_memory().available < 48e9:
+        pytest.skip("the float32 oracle needs 27.5 GB of host memory for final-13682's dense landmark blocks")
+    import types
+
+    import bench
+    args = types.SimpleNamespace(translation_sigma=0.01, point_sigma=0.01, rotation_sigma=0.0)
+    return bench.make_problem("final-13682", args)[0]
+
+
+@pytest.fixture(scope="module")
+def oracle32(final_problem):
+    from oracle import oracle as O
+    return O.Oracle(final_problem, np.float32, O.default_options(robust_norm=1, huber_parameter=1.0))
+
+
+@pytest.fixture(scope="module")
+def referee64(final_problem):
+    import torch  # noqa: F401
+    from lockstep import EPS_SQRT_FLOAT
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    return LinearizorHIP(final_problem, np.float64, L.default_options(robust_norm=1, huber_parameter=1.0,
+                                                                      jacobi_scaling_eps=EPS_SQRT_FLOAT))
+
+
+def _as_accurate(x_gpu, x_oracle, x_ref, floor):
+    """the float32 GPU result is as close to the float64 referee as the float32 oracle's, and the two float32 results are
+    no further apart than two results of that accuracy can be"""
+    eg, eo = rel_err(x_gpu, x_ref), rel_err(x_oracle, x_ref)
+    assert eg <= 1.5 * eo + floor, (eg, eo)
+    assert rel_err(x_gpu, x_oracle) <= 2 * eo + 2 * floor, (rel_err(x_gpu, x_oracle), eo)
+
+
+@pytest.mark.parametrize("dts", ["float32", "mixed"])
+def test_final13682_one_iteration_vectors_and_two_step_lockstep(final_problem, oracle32, referee64, dts):
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    prob, o, g64 = final_problem, oracle32, referee64
+    mixed = dts == "mixed"
+    g = LinearizorHIP(prob, "mixed" if mixed else np.float32, L.default_options(robust_norm=1, huber_parameter=1.0))
+    c0 = np.asarray(prob.cams, np.float32)
+    l0 = np.asarray(prob.lms, np.float32)
+    o.set_state(c0, l0)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, 9 * prob.n_cams).astype(np.float32)
+    for it, lam in enumerate(LAMBDAS, 1):
+        c_, l_ = o.get_state()
+        g64.set_state(c_.astype(np.float64), l_.astype(np.float64))
+        g.set_state(c_.astype(np.float64), l_.astype(np.float64)) if mixed else g.set_state(c_, l_)
+        eg, eo, e64 = g.compute_error(), o.compute_error(), g64.compute_error()
+        assert eg.all_num_obs == eo.all_num_obs == e64.all_num_obs == prob.n_obs
+        # 29 M float32 residuals resolve the cost to ~3e-7 (measured, both); the mixed mode sums double residuals
+        assert abs(eg.all_error - e64.all_error) <= (1e-12 if mixed else 2e-6) * e64.all_error
+        assert abs(eo.all_error - e64.all_error) <= 2e-6 * e64.all_error
+        assert g.linearize() == 0 and o.linearize() == 0 and g64.linearize() == 0
+        b_g, bl_g = g.stage2(lam)
+        b_64, bl_64 = g64.stage2(lam)
+        ig, cg = g.solve(lam)
+        io, co = o.solve(lam)
+        i64, c64 = g64.solve(lam)
+        _as_accurate(g.pose_scaling(), o.pose_scaling(), g64.pose_scaling(), 1e-6)
+        _as_accurate(g.jl_col_scale(), o.jl_col_scale(), g64.jl_col_scale(), 5e-6)
+        _as_accurate(b_g, o.last_b(), b_64, 1e-5)
+        _as_accurate(bl_g, o.precond_blocks(), bl_64, 2e-6)
+        assert cg.termination_type == 1 and cg.num_iterations == co.num_iterations == c64.num_iterations
+        _as_accurate(ig, io, i64, 5e-5)
+        if it == 1:
+            h_64 = g64.right_multiply(x.astype(np.float64))
+            h_o = o.right_multiply(x)
+            _as_accurate(g.right_multiply(x), h_o, h_64, 2e-6)
+            _as_accurate(g.right_multiply_explicit(x), h_o, h_64, 5e-6)
+        ldg, ldo, ld64 = g.apply(io), o.apply(io), g64.apply(io.astype(np.float64))
+        assert abs(ldg - ld64) <= 1e-5 * abs(ld64) and abs(ldo - ld64) <= 1e-5 * abs(ld64)
+        (cg_, lg_), (co_, lo_), (c6, l6) = g.get_state(), o.get_state(), g64.get_state()
+        # float32 landmark update: one rounding of ~100-unit coordinates (measured 2.5e-6 ... 8.4e-6, both); the mixed
+        # mode applies the float increment to the double state
+        assert rel_err(cg_, c6) < 1e-6 and rel_err(co_, c6) < 1e-6
+        assert rel_err(lg_, l6) < 2e-5 and rel_err(lo_, l6) < 2e-5
+    g.close()
