@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_a2(const S* __restrict__ z,
   const double rho_prev = st->rho_hist[(iter + 1) & 1];  // written one iteration ago
   int stop = 0;
   double beta = 0.0;
-  if (rho == 0.0 || isinf(rho)) {
+  if (rho == 0.0 || isinf(rho) || rho != rho) {
     stop = 1;
   } else if (iter > 0) {
     beta = rho / rho_prev;
@@ -1321,7 +1321,10 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_b2(const S* __restrict__ bv
   const double pq = pcg_sum_partials(partial_pq);
   int stop = 0, term = 0;
   double alpha = 0;
-  if (pq <= 0.0 || isinf(pq)) {
+  if (pq != pq) {
+    stop = 1;  // NaN: the reference would iterate on NaNs up to max_iterations and the LM loop reject the non-finite
+    term = 2;  // increment; ended here as a numerical failure at once (same decision, no wasted iterations)
+  } else if (pq <= 0.0 || isinf(pq)) {
     stop = 1;  // "Matrix is indefinite, no more progress can be made." -> NO_CONVERGENCE
   } else {
     alpha = st->rho_hist[iter & 1] / pq;

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
         }
       }
       if (!own_stop) {
-        if (rho == 0.0 || isinf(rho)) {
+        if (rho == 0.0 || isinf(rho) || rho != rho) {
           own_stop = 1;
           term = 2;  // "Numerical failure. rho / beta"
           res_it = it + 1;
@@ -370,7 +370,10 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
     __syncthreads();
     int own_stop = 0, term = 0;
     double alpha = 0;
-    if (pq <= 0.0 || isinf(pq)) {
+    if (pq != pq) {
+      own_stop = 1;  // NaN: numerical failure at once (the reference would iterate on NaNs up to max_iterations and the
+      term = 2;      // LM loop reject the non-finite increment all the same)
+    } else if (pq <= 0.0 || isinf(pq)) {
       own_stop = 1;  // "Matrix is indefinite, no more progress can be made." -> NO_CONVERGENCE
     } else {
       alpha = ((cur + 1) & 1 ? rho1 : rho0) / pq;

@@ -559,11 +559,9 @@ class Solver final : public rba_solver {
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 4096));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_progress_), 64));
     h_progress_[0] = h_progress_[1] = 0;
-    HIP_CHECK(hipEventCreate(&ev_a_));
     HIP_CHECK(hipEventCreate(&ev_asm0_));
     HIP_CHECK(hipEventCreate(&ev_asm1_));
     d_scratch_int_.alloc(1);
-    HIP_CHECK(hipEventCreate(&ev_b_));
     hx_events_.assign(2 * kMaxHxEvents, nullptr);
     hx_event_call_.resize(kMaxHxEvents);
     for (auto& e : hx_events_) HIP_CHECK(hipEventCreate(&e));
@@ -941,7 +939,10 @@ class Solver final : public rba_solver {
     for (auto& e : comm_events_)
       if (e) (void)hipEventDestroy(e);
     comm_events_.clear();
-    for (hipEvent_t* e : {&ev_a_, &ev_b_, &ev_asm0_, &ev_asm1_}) {
+    for (auto& e : timer_pool_)
+      if (e) (void)hipEventDestroy(e);
+    timer_pool_.clear();
+    for (hipEvent_t* e : {&ev_asm0_, &ev_asm1_}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
     }
@@ -1148,6 +1149,13 @@ class Solver final : public rba_solver {
   // ---- compute_error ----------------------------------------------------------
   void compute_error(rba_residual_info* out) override {
     use_device();
+    double* h = pinned_doubles(kPinCe0);
+    compute_error_enqueue(h);
+    if (lm_async_) sync();  // (a direct call from inside the LM loop: not used by lm_step itself)
+    compute_error_parse(h, out);
+  }
+  // kernels + the copy of the eight sums into pinned host memory `h`; valid after the next synchronisation
+  void compute_error_enqueue(double* h) {
     time_begin();
     const int blocks = int(std::min<int64_t>(kReduceBlocks, (n_obs_ + 255) / 256));
     if (mixed_)
@@ -1160,9 +1168,10 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, stream_,
                        d_partials_.get(), int64_t(blocks), red);
     all_reduce(red, 8);
-    double h[8];
-    HIP_CHECK(hipMemcpyAsync(h, red, sizeof(h), hipMemcpyDeviceToHost, stream_));
-    timings_.residual_evaluation_time += time_end();
+    HIP_CHECK(hipMemcpyAsync(h, red, 8 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    time_end(&timings_.residual_evaluation_time, true);
+  }
+  static void compute_error_parse(const double* h, rba_residual_info* out) {
     out->all_num_obs = int(std::llround(h[0]));
     out->all_error = h[1];
     out->all_residual_sum = h[2];
@@ -1223,15 +1232,16 @@ class Solver final : public rba_solver {
                          scp_);
     }
     HIP_CHECK(hipGetLastError());
-    int fail = 0;
-    HIP_CHECK(hipMemcpyAsync(&fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
+    int* fail = pinned_int(kPinFailLin);
+    HIP_CHECK(hipMemcpyAsync(fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
     if (jp_diag2_out) d_jp_diag2_.download(static_cast<S*>(jp_diag2_out), nvec_, stream_);
-    timings_.stage1_time = time_end();
+    time_end(&timings_.stage1_time);
     sub_collect();
     pose_damping_ = S(0);
     landmark_damping_valid_ = false;
     ex_valid_ = false;
-    return (fail & 1) ? RBA_NUMERICAL_FAILURE : RBA_OK;
+    if (lm_async_) return RBA_OK;  // lm_step reads the flag at its next synchronisation point (linearize_failed)
+    return (*fail & 1) ? RBA_NUMERICAL_FAILURE : RBA_OK;
   }
 
   // ---- stage 2 ------------------------------------------------------------------
@@ -1291,7 +1301,7 @@ class Solver final : public rba_solver {
     if (blocks_out)
       HIP_CHECK(hipMemcpyAsync(blocks_out, prm_.blocks, size_t(81) * n_cams_ * sizeof(S),
                                hipMemcpyDeviceToHost, stream_));
-    timings_.stage2_time = time_end();
+    time_end(&timings_.stage2_time);
     sub_collect();
     return RBA_OK;
   }
@@ -1620,13 +1630,13 @@ class Solver final : public rba_solver {
     const S lambda = S(lambda_d);
     time_begin();
     run_stage2(lambda);
-    timings_.stage2_time = time_end();
+    time_end(&timings_.stage2_time);
     sub_collect();
 
     time_begin();
     hipLaunchKernelGGL((rba::k_invert_blocks<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_,
                        prm_.blocks, d_inv_.get(), n_cams_, d_fail_.get());
-    timings_.compute_preconditioner_time = time_end();
+    time_end(&timings_.compute_preconditioner_time);
 
     time_begin();
     hx_event_count_ = 0;
@@ -1644,7 +1654,11 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_negate<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                        d_x_.get(), nvec_);
     d_x_.download(static_cast<S*>(inc_out), nvec_, stream_);
-    timings_.solve_reduced_system_time = time_end();
+    time_end(&timings_.solve_reduced_system_time);
+    if (lm_async_) {  // the caller reads the increment, and the product timers below need their events completed
+      sync();
+      flush_timers();
+    }
     // H*x launches that did real work: one per PCG iteration plus the residual
     // refreshes; launches queued after termination are no-ops and are excluded
     const int real_hx = cg.num_iterations + cg.num_iterations / 10;
@@ -1863,18 +1877,16 @@ class Solver final : public rba_solver {
                        d_partials_.get(), int64_t(blocks), red);
     all_reduce(red, 1);
     all_reduce(d_fail_.get(), 1, kNcclMax);
-    double l_diff = 0;
-    int fail = 0;
-    HIP_CHECK(hipMemcpyAsync(&l_diff, red, sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipMemcpyAsync(&fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
-    timings_.back_substitution_time = time_end();
+    double* l_diff = pinned_doubles(kPinLdiff);
+    int* fail = pinned_int(kPinFailApply);
+    HIP_CHECK(hipMemcpyAsync(l_diff, red, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
+    time_end(&timings_.back_substitution_time);
     // the back-substitution leaves the blocks undamped in the reference
     // (ipp:247-248); here damped rows are rebuilt by the next stage 2 anyway
-    if (!std::isfinite(l_diff) || (fail & 2)) {
-      *l_diff_out = std::numeric_limits<double>::quiet_NaN();
-      return RBA_NUMERICAL_FAILURE;
-    }
-    *l_diff_out = double(S(l_diff));
+    // (inside rba_lm_step the outcome is read at the iteration's last synchronisation, apply_outcome(): the camera
+    //  update below is enqueued regardless - a failed step is restored from the backup by the LM loop)
+    if (!lm_async_ && apply_outcome(l_diff_out) != RBA_OK) return RBA_NUMERICAL_FAILURE;
     if (mixed_) {
       // the float landmark increments go to the double masters; the float state is re-rounded from them
       const int64_t nl = 3 * int64_t(n_lms_);
@@ -1892,8 +1904,19 @@ class Solver final : public rba_solver {
       else
         hipLaunchKernelGGL((rba::k_update_cameras<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0,
                            stream_, prm_, d_inc_.get());
-      timings_.update_cameras_time = time_end();
+      time_end(&timings_.update_cameras_time);
     }
+    return RBA_OK;
+  }
+
+  // l_diff / failure flag of the last back-substitution (pinned slots; valid after a synchronisation)
+  int apply_outcome(double* l_diff_out) {
+    const double l_diff = *pinned_doubles(kPinLdiff);
+    if (!std::isfinite(l_diff) || (*pinned_int(kPinFailApply) & 2)) {
+      *l_diff_out = std::numeric_limits<double>::quiet_NaN();
+      return RBA_NUMERICAL_FAILURE;
+    }
+    *l_diff_out = double(S(l_diff));
     return RBA_OK;
   }
 
@@ -1924,7 +1947,19 @@ class Solver final : public rba_solver {
     }
     reset_timings();
     const double t_it = wall_seconds();
+    // Inside this function stage results and timers are collected at the iteration's own synchronisation points (the
+    // PCG's polls, the increment after the solve, the end) instead of after every stage; the unstaged sub-stage timers
+    // keep the per-stage synchronisation they are read at.
+    struct AsyncScope {
+      bool& flag;
+      AsyncScope(bool& f, bool on) : flag(f) { flag = on; }
+      ~AsyncScope() { flag = false; }
+    } async_scope(lm_async_, !sub_timing());
     auto finish = [&](bool keep_going) {
+      if (lm_async_) {
+        sync();
+        flush_timers();
+      }
       row.iteration_time = wall_seconds() - t_it;
       row.stage1_time = timings_.stage1_time;
       row.stage2_time = timings_.stage2_time;
@@ -1938,15 +1973,19 @@ class Solver final : public rba_solver {
     };
     // the reference re-evaluates the error at every outer iteration (bal_bundle_adjustment.cpp:297-301,
     // with a TODO to avoid it); so does this loop - the metric of SURVEY.md 8d includes both evaluations
-    if (lm_.it == 0 || lm_.need_linearize) {
-      compute_error(&lm_.ri);
-      if (!lm_.ri.is_numerically_valid) {
+    const bool fresh_cost = lm_.it == 0 || lm_.need_linearize;
+    if (fresh_cost) compute_error_enqueue(pinned_doubles(kPinCe0));
+    auto cost_is_valid = [&]() {  // (after a synchronisation)
+      if (fresh_cost) compute_error_parse(pinned_doubles(kPinCe0), &lm_.ri);
+      return lm_.ri.is_numerically_valid != 0;
+    };
+    if (lm_.it == 0) {
+      sync();
+      if (!cost_is_valid()) {
         lm_.terminated = true;
         lm_.termination = -1;
         return finish(false);
       }
-    }
-    if (lm_.it == 0) {
       // iteration 0 is evaluation only (bal_bundle_adjustment.cpp:311-322)
       row.cost = lm_.ri.all_error;
       row.cost_valid = lm_.ri.valid_error;
@@ -1963,8 +2002,9 @@ class Solver final : public rba_solver {
       lm_.ri_is_current = true;
       return finish(true);
     }
-    if (lm_.need_linearize) {
-      if (linearize(nullptr) != RBA_OK) {
+    const bool linearized = lm_.need_linearize;
+    if (linearized) {
+      if (linearize(nullptr) != RBA_OK) {  // (asynchronous: the failure flag is read after the solve below)
         lm_.terminated = true;
         lm_.termination = -1;
         return finish(false);
@@ -1975,7 +2015,15 @@ class Solver final : public rba_solver {
     row.lambda = lm_.lambda;
     rba_cg_summary cg{};
     lm_inc_.resize(nvec_);
-    solve(lm_.lambda, lm_inc_.data(), &cg);
+    solve(lm_.lambda, lm_inc_.data(), &cg);  // (ends with a synchronisation: the increment is on the host)
+    if (!cost_is_valid() || (linearized && (*pinned_int(kPinFailLin) & 1))) {
+      // non-finite residuals / Jacobians at this state (detected by the cost evaluation or the linearisation that
+      // were queued ahead of the solve): numerical failure, as where the reference returns an empty vector
+      lm_.terminated = true;
+      lm_.termination = -1;
+      lm_.need_linearize = true;
+      return finish(false);
+    }
     row.cg_iterations = cg.num_iterations;
     row.cg_termination = cg.termination_type;
     double nrm = 0;
@@ -1997,9 +2045,13 @@ class Solver final : public rba_solver {
     backup();
     double l_diff_d = 0;
     apply(lm_inc_.data(), &l_diff_d, true);
-    S l_diff = S(l_diff_d);
     rba_residual_info ri2{};
-    compute_error(&ri2);
+    compute_error_enqueue(pinned_doubles(kPinCe1));
+    sync();
+    flush_timers();
+    if (lm_async_) apply_outcome(&l_diff_d);
+    compute_error_parse(pinned_doubles(kPinCe1), &ri2);
+    S l_diff = S(l_diff_d);
     row.cost = ri2.all_error;
     row.cost_valid = ri2.valid_error;
     row.num_obs = int(ri2.all_num_obs);
@@ -2197,14 +2249,50 @@ class Solver final : public rba_solver {
   static constexpr int kMaxHxEvents = 1024;
 
   void use_device() { HIP_CHECK(hipSetDevice(device_)); }
+  // result slots in the pinned page h_pinned_ (the PCG state copy lives at offset 0)
+  static constexpr size_t kPinCe0 = 1024, kPinCe1 = 1024 + 64, kPinLdiff = 1024 + 128, kPinFailLin = 1024 + 136,
+                          kPinFailApply = 1024 + 140;
+  double* pinned_doubles(size_t off) { return reinterpret_cast<double*>(h_pinned_ + off); }
+  int* pinned_int(size_t off) { return reinterpret_cast<int*>(h_pinned_ + off); }
   void sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
-  void time_begin() { HIP_CHECK(hipEventRecord(ev_a_, stream_)); }
-  double time_end() {
-    HIP_CHECK(hipEventRecord(ev_b_, stream_));
-    HIP_CHECK(hipEventSynchronize(ev_b_));
-    float ms = 0;
-    HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
-    return double(ms) * 1e-3;
+  // Stage timers: HIP-event pairs on the solver stream. A single C-ABI call waits for its own pair; inside
+  // rba_lm_step (lm_async_) the pairs are only RECORDED and read after the iteration's last synchronisation, so the
+  // host never stalls the queue just to read a clock (round 2: ~10 synchronisations per LM iteration, 0.14 ms of gaps).
+  struct PendingTimer {
+    hipEvent_t e0, e1;
+    double* field;
+    bool accumulate;
+  };
+  hipEvent_t timer_event() {
+    if (timer_pool_used_ == timer_pool_.size()) {
+      hipEvent_t e = nullptr;
+      HIP_CHECK(hipEventCreate(&e));
+      timer_pool_.push_back(e);
+    }
+    return timer_pool_[timer_pool_used_++];
+  }
+  void time_begin() {
+    timer_t0_ = timer_event();
+    HIP_CHECK(hipEventRecord(timer_t0_, stream_));
+  }
+  void time_end(double* field, bool accumulate = false) {
+    hipEvent_t e1 = timer_event();
+    HIP_CHECK(hipEventRecord(e1, stream_));
+    pending_timers_.push_back(PendingTimer{timer_t0_, e1, field, accumulate});
+    if (!lm_async_) {
+      HIP_CHECK(hipEventSynchronize(e1));
+      flush_timers();
+    }
+  }
+  // (all recorded pairs have completed: the caller synchronised the stream or the last pair's end event)
+  void flush_timers() {
+    for (const PendingTimer& t : pending_timers_) {
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, t.e0, t.e1));
+      *t.field = (t.accumulate ? *t.field : 0.0) + double(ms) * 1e-3;
+    }
+    pending_timers_.clear();
+    timer_pool_used_ = 0;
   }
   void reset_timings() {
     timings_ = rba_iter_timings{};
@@ -2317,7 +2405,11 @@ class Solver final : public rba_solver {
   DevBuf<double> d_lm_ldiff_, d_partials_, d_pcg_partials_;
   DevBuf<rba::CgState> d_cg_;
   char* h_pinned_ = nullptr;
-  hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
+  hipEvent_t timer_t0_ = nullptr;
+  std::vector<hipEvent_t> timer_pool_;
+  size_t timer_pool_used_ = 0;
+  std::vector<PendingTimer> pending_timers_;
+  bool lm_async_ = false;  // inside rba_lm_step: results and timers are collected at the iteration's own sync points
   std::vector<hipEvent_t> hx_events_;
   std::vector<int> hx_event_call_;  // which H*x call of the solve each event pair brackets
   int hx_event_count_ = 0, hx_calls_ = 0;

@@ -125,8 +125,13 @@ def test_config3_trafalgar257_f32_full_lm_run(monkeypatch):
         ev.set_state(*lin.get_state())
         return ev.compute_error().all_error
     fg, fo = cost64(g), cost64(o)
-    assert abs(fg - f64) / f64 < 1e-6 and abs(fo - f64) / f64 < 1e-6, (fg, fo, f64)
-    assert abs(fg - fo) / fo < 1.5e-6
+    # Measured (round 3, three GPU runs each; the float atomics of the matrix-free product make runs differ): after 12
+    # iterations the float32 GPU run ends 5.3e-7 / 1.0e-6 / 1.3e-6 above the float64 optimum, the float32 oracle 6.2e-7;
+    # after 16 iterations 1.7e-7 ... 8.2e-7 against 8.3e-7, after 20 2.9e-7 ... 8.5e-7 against 6.5e-7: a float32 STATE
+    # resolves the optimum to ~1e-6, for either implementation, so the bar here is 2e-6 and "not worse than the float32
+    # oracle by more than 1e-6"; the mixed mode (double state, tests/test_gpu_mixed.py) meets 2e-7.
+    assert abs(fg - f64) / f64 < 2e-6 and abs(fo - f64) / f64 < 2e-6, (fg, fo, f64)
+    assert (fg - fo) / fo < 1.5e-6
     # and the float32 costs the runs report are those costs up to that evaluation noise
     assert abs(min(r.cost for r in lg if r.step_is_successful) - fg) / fg < 2e-6
 
