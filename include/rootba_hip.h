@@ -236,6 +236,8 @@ int rba_get_comm_stats(rba_handle h, int64_t* calls_out, int64_t* bytes_out, dou
 /* BalProblem state upload/download (Camera::params()/from_params(),
  * bal_problem.hpp:84-95; copy_to/from_camera_state, bal_problem.cpp:570-588). */
 int rba_set_state(rba_handle h, const void* cams10, const void* lms3);
+/* (rba_get_state: either output may be NULL - the reference-side binding fetches the cameras after every apply and
+ * the landmarks only when BalProblem is read, integration/rootba/solver/linearizor_hip.hpp) */
 int rba_get_state(rba_handle h, void* cams10, void* lms3);
 /* BalProblem::backup / restore (bal_problem.cpp:590-608), device-side copies. */
 int rba_backup(rba_handle h);

@@ -18,6 +18,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "rootba/solver/host_state_sync.hpp"
 #include "rootba/solver/linearizor_base.hpp"
 #include "rootba/util/time_utils.hpp"
 #include "rootba_hip.h"
@@ -25,7 +26,7 @@
 namespace rootba {
 
 template <class Scalar_>
-class LinearizorHIP : public LinearizorBase<Scalar_> {
+class LinearizorHIP : public LinearizorBase<Scalar_>, public HostStateSync {
  public:
   using Scalar = Scalar_;
   using Base = LinearizorBase<Scalar>;
@@ -77,13 +78,43 @@ class LinearizorHIP : public LinearizorBase<Scalar_> {
     upload();
   }
   ~LinearizorHIP() override {
-    if (h_) rba_destroy(h_);
+    if (h_) {
+      // optimize_lm_ours destroys its linearizor before it returns: BalProblem receives the final state here
+      ensure_device_state();
+      sync_host();
+      rba_destroy(h_);
+    }
+  }
+
+  // ---- state protocol ---------------------------------------------------------------------------------------
+  // Round 2 treated BalProblem as the source of truth at every call: three host loops over all landmarks plus the
+  // PCIe copies per LM iteration (at venice size an order of magnitude more than the GPU work). Now the DEVICE holds
+  // the state between calls:
+  //  * cameras (n_c x 10 scalars) go back to BalProblem after every apply(), landmarks only on demand (sync_host():
+  //    the destructor, i.e. the end of optimize_lm_ours, or an explicit call);
+  //  * the reference's LM loop brackets a step with bal_problem.backup() ... bal_problem.restore()
+  //    (bal_bundle_adjustment.cpp:401, 509): apply() takes the matching device-side backup (rba_backup), and a
+  //    restore() is RECOGNISED at the next call by the cameras of BalProblem being those of the backup again, upon
+  //    which the device restores too (rba_restore) - no upload;
+  //  * any other change of the cameras (the caller edited the problem) falls back to a full upload, after the
+  //    pending landmark download so that BalProblem really is complete; callers that edit LANDMARKS announce it with
+  //    host_state_changed().
+  void sync_host() override {
+    if (!host_lms_stale_) return;
+    CHECK(rba_get_state(h_, cams_.data(), lms_.data()) == RBA_OK) << rba_last_error();
+    for (int l = 0; l < bal_problem_.num_landmarks(); ++l)
+      for (int k = 0; k < 3; ++k) bal_problem_.landmarks()[l].p_w(k) = lms_[size_t(3) * l + k];
+    host_lms_stale_ = false;
+  }
+  void host_state_changed() override {
+    host_lms_stale_ = false;
+    upload();
   }
 
   // LinearizorBase::compute_error (linearizor_base.cpp:60-68)
   void compute_error(ResidualInfo& ri) override {
     Timer<> timer;
-    upload();  // BalProblem is the source of truth (the driver may have called restore())
+    ensure_device_state();  // (the driver may have called bal_problem.restore())
     rba_residual_info r;
     CHECK(rba_compute_error(h_, &r) == RBA_OK) << rba_last_error();
     ri.all.num_obs = r.all_num_obs;
@@ -129,13 +160,23 @@ class LinearizorHIP : public LinearizorBase<Scalar_> {
   // state goes up before the update and comes back after it.
   Scalar apply(VecX&& inc) override {
     Timer<> timer;
-    upload();
+    ensure_device_state();
+    // the device-side twin of the bal_problem.backup() the driver has just made
+    CHECK(rba_backup(h_) == RBA_OK) << rba_last_error();
+    host_cams_backup_ = host_cams_;
+    stale_at_backup_ = host_lms_stale_;
+    have_backup_ = true;
     double l_diff = 0;
     const int st = rba_apply(h_, inc.data(), &l_diff);
     CHECK(st >= 0) << rba_last_error();
     if (it_summary_) it_summary_->back_substitution_time_in_seconds = timer.elapsed();
-    if (st != RBA_OK) return std::numeric_limits<Scalar>::quiet_NaN();
-    download();
+    if (st != RBA_OK) {
+      // numerical failure: the library left cameras untouched and may have moved landmarks; back to the backup
+      CHECK(rba_restore(h_) == RBA_OK) << rba_last_error();
+      return std::numeric_limits<Scalar>::quiet_NaN();
+    }
+    download_cameras();
+    host_lms_stale_ = true;
     return Scalar(l_diff);
   }
 
@@ -144,30 +185,55 @@ class LinearizorHIP : public LinearizorBase<Scalar_> {
   using Base::it_summary_;
   using Base::summary_;
 
-  // Camera::params() (bal_problem.hpp:84-89): qx qy qz qw tx ty tz f k1 k2
-  void upload() {
+  // what BalProblem's cameras say right now (Camera::params(), bal_problem.hpp:84-89: qx qy qz qw tx ty tz f k1 k2)
+  void read_host_cameras(std::vector<Scalar>& out) const {
+    out.resize(size_t(10) * bal_problem_.num_cameras());
     for (int c = 0; c < bal_problem_.num_cameras(); ++c) {
       const VecX p = bal_problem_.cameras()[c].params();
-      for (int k = 0; k < 10; ++k) cams_[size_t(10) * c + k] = p(k);
+      for (int k = 0; k < 10; ++k) out[size_t(10) * c + k] = p(k);
     }
+  }
+  // BalProblem -> device, everything
+  void upload() {
+    read_host_cameras(host_cams_);
+    cams_ = host_cams_;
     for (int l = 0; l < bal_problem_.num_landmarks(); ++l)
       for (int k = 0; k < 3; ++k) lms_[size_t(3) * l + k] = bal_problem_.landmarks()[l].p_w(k);
     CHECK(rba_set_state(h_, cams_.data(), lms_.data()) == RBA_OK) << rba_last_error();
+    have_backup_ = false;
   }
-  // Camera::from_params (bal_problem.hpp:91-95)
-  void download() {
-    CHECK(rba_get_state(h_, cams_.data(), lms_.data()) == RBA_OK) << rba_last_error();
+  // device cameras -> BalProblem (Camera::from_params, bal_problem.hpp:91-95); `host_cams_` then records what
+  // BalProblem REPORTS (from_params normalises the quaternion), the reference value of the change detection
+  void download_cameras() {
+    CHECK(rba_get_state(h_, cams_.data(), nullptr) == RBA_OK) << rba_last_error();
     VecX p(10);
     for (int c = 0; c < bal_problem_.num_cameras(); ++c) {
       for (int k = 0; k < 10; ++k) p(k) = cams_[size_t(10) * c + k];
       bal_problem_.cameras()[c].from_params(p);
     }
-    for (int l = 0; l < bal_problem_.num_landmarks(); ++l)
-      for (int k = 0; k < 3; ++k) bal_problem_.landmarks()[l].p_w(k) = lms_[size_t(3) * l + k];
+    read_host_cameras(host_cams_);
+  }
+  // make the device hold the state BalProblem describes (see "state protocol" above)
+  void ensure_device_state() {
+    read_host_cameras(probe_);
+    if (probe_ == host_cams_) return;  // nothing happened on the host side (the common case)
+    if (have_backup_ && probe_ == host_cams_backup_) {
+      // bal_problem.restore() after a rejected step: the device restores its twin of that backup
+      CHECK(rba_restore(h_) == RBA_OK) << rba_last_error();
+      host_cams_ = host_cams_backup_;
+      host_lms_stale_ = stale_at_backup_;
+      return;
+    }
+    // the caller changed the cameras: complete BalProblem first (landmarks it has not seen yet), then upload
+    sync_host();
+    upload();
   }
 
   rba_handle h_ = nullptr;
-  std::vector<Scalar> cams_, lms_;
+  std::vector<Scalar> cams_, lms_;              // transfer buffers
+  std::vector<Scalar> host_cams_, host_cams_backup_, probe_;  // BalProblem's cameras as last seen / at the backup
+  bool host_lms_stale_ = false;  // the device holds newer landmarks than BalProblem
+  bool stale_at_backup_ = false, have_backup_ = false;
 };
 
 }  // namespace rootba

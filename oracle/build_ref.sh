@@ -33,7 +33,7 @@ for s in $SRCS; do
   fi
 done
 for p in $pids; do wait "$p"; done
-$CXX $FLAGS -c "$HERE/ref_driver.cpp" -o "$OUT/obj/ref_driver.o"
+$CXX $FLAGS -I"$HERE/../integration" -c "$HERE/ref_driver.cpp" -o "$OUT/obj/ref_driver.o"
 $CXX -shared -o "$OUT/librootba_ref.so" $OBJS "$OUT/obj/ref_driver.o"
 echo "built $OUT/librootba_ref.so"
 

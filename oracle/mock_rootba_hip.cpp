@@ -137,14 +137,22 @@ int rba_set_state(rba_handle h, const void* cams, const void* lms) {
                 }))
   return RBA_OK;
 }
+int rba_backup(rba_handle h) {
+  MOCK_DISPATCH(o->backup(), o->backup())
+  return RBA_OK;
+}
+int rba_restore(rba_handle h) {
+  MOCK_DISPATCH(o->restore(), o->restore())
+  return RBA_OK;
+}
 int rba_get_state(rba_handle h, void* cams, void* lms) {
   MOCK_DISPATCH(({
-                  std::copy(o->cams().begin(), o->cams().end(), static_cast<S*>(cams));
-                  std::copy(o->lms().begin(), o->lms().end(), static_cast<S*>(lms));
+                  if (cams) std::copy(o->cams().begin(), o->cams().end(), static_cast<S*>(cams));
+                  if (lms) std::copy(o->lms().begin(), o->lms().end(), static_cast<S*>(lms));
                 }),
                 ({
-                  std::copy(o->cams().begin(), o->cams().end(), static_cast<S*>(cams));
-                  std::copy(o->lms().begin(), o->lms().end(), static_cast<S*>(lms));
+                  if (cams) std::copy(o->cams().begin(), o->cams().end(), static_cast<S*>(cams));
+                  if (lms) std::copy(o->lms().begin(), o->lms().end(), static_cast<S*>(lms));
                 }))
   return RBA_OK;
 }

@@ -36,6 +36,7 @@
 #include "rootba/qr/landmark_block_dynamic.hpp"
 #include "rootba/qr/linearization_qr.hpp"
 #include "rootba/solver/bal_bundle_adjustment.hpp"
+#include "rootba/solver/host_state_sync.hpp"  // (integration/: the binding's host <-> device state protocol)
 #include "rootba/solver/linearizor.hpp"
 #include "rootba/solver/solver_summary.hpp"
 #include "rootba/util/system_utils.hpp"
@@ -274,6 +275,12 @@ Handle<S>* h_create(int n_cams, int n_lms, const int64_t* off, const int32_t* ca
 template <class S>
 void h_set_state(Handle<S>* h, const S* cams, const S* lms) {
   using VecX = typename Handle<S>::VecX;
+  struct Announce {  // (a LinearizorHIP keeps the state on the device: tell it that BalProblem is authoritative again)
+    Handle<S>* h;
+    ~Announce() {
+      if (auto* s = dynamic_cast<rootba::HostStateSync*>(h->lin.get())) s->host_state_changed();
+    }
+  } announce{h};
   for (size_t c = 0; c < h->problem.cameras().size(); ++c) {
     VecX p(10);
     for (int k = 0; k < 10; ++k) p(k) = cams[10 * c + k];
@@ -284,6 +291,7 @@ void h_set_state(Handle<S>* h, const S* cams, const S* lms) {
 }
 template <class S>
 void h_get_state(Handle<S>* h, S* cams, S* lms) {
+  if (auto* s = dynamic_cast<rootba::HostStateSync*>(h->lin.get())) s->sync_host();  // (landmarks come back on demand)
   for (size_t c = 0; c < h->problem.cameras().size(); ++c) {
     const auto p = h->problem.cameras()[c].params();
     for (int k = 0; k < 10; ++k) cams[10 * c + k] = p(k);

@@ -18,9 +18,11 @@
 
 namespace rba {
 
-// Per-observation record of stage 2: [damped Q1^T Jp 3x9 | b record 9] = 36 scalars (144 B in float:
-// nine 16-byte pieces, so camera-major passes fetch whole records with wide loads).
-constexpr int kTd = 36;
+// Per-observation record of damped top rows [damped Q1^T Jp D 3x9 | 5 unused] = 32 scalars: one 128-byte cache line
+// per record in float, so the pair gather of the reduced-matrix assembly fetches exactly the lines it needs (round
+// 2: 36 scalars incl. a b part nobody reads any more - 144-byte records straddled lines, 6.8 GB fetched per
+// venice assembly for 3.7 GB of rows).
+constexpr int kTd = 32;
 
 template <class S>
 struct Params {
@@ -48,7 +50,7 @@ struct Params {
                 //               observation's part of b = (Jp D)^T g and of the diagonal block = (A Jp D)^T (A Jp D)
   S* W8;             // [n_obs - w8_begin][8] the eight stage-2 coefficients W' (3x2, row-major) | g (2) themselves, kept
   int64_t w8_begin;  //   only for the observations of the two-kernel back-substitution (k > 32): topd x = W' (Jp D x)
-  S* topd;      // [n_obs][kTd]  damped Q1^T Jp D ([3][9]) | the observation's part of b: materialised ON DEMAND from
+  S* topd;      // [n_obs][kTd]  damped Q1^T Jp D ([3][9], padded to 32): materialised ON DEMAND from
                 //               JpS and the factors (k_s12_cols) for the assembly of the reduced matrix and E0 products
   S* bsO;       // [n_obs][5]    back-substitution scratch (k > 32): topd x (3), Jp x (2)
   // per-landmark records
@@ -824,8 +826,11 @@ __global__ __launch_bounds__(256) void k_bs_landmark_wave(Params<S> p, int lm_be
 // (the wave tiles of k_hx_implicit): u = Jp x per row; Q^T u by the three reflectors (segmented
 // reductions); its three top entries rotated by the landmark's damping rotations are exactly
 // topd x, so the stored damped top rows are not read at all; delta from the damped triangle; the
-// model-cost term from the undamped rows v = u + Jl delta. Reads 152 bytes per observation
-// (Jacobian rows, reflectors, Jl rows, residual) instead of 268 in the two-kernel form.
+// model-cost term sum v (v / 2 + r) of the undamped rows v = u + Jl delta is evaluated in the ROTATED frame - Q is
+// orthogonal, Q^T v = Q^T u + [R0 delta; 0] and Q^T r are at hand (the reflected u and the fourth entry of the
+// reflector record) - so neither the pre-QR Jl rows nor the residuals are read (round 2 read them: 152 bytes per
+// observation; now 120: Jacobian rows, reflector records, the two lane maps), and the QR pass of the wave tiles no
+// longer writes them.
 template <class S, int P2>
 __device__ __forceinline__ void bs_tile(const Params<S>& p, size_t T, int t_in_class, int lm_begin, int lm_end,
                                         const S* __restrict__ x, int lane) {
@@ -837,7 +842,7 @@ __device__ __forceinline__ void bs_tile(const Params<S>& p, size_t T, int t_in_c
   const int cam = p.CT[T * 64 + lane];
   const int row = p.RT[T * 64 + lane];
   const bool act = cam >= 0;
-  S u = S(0), v0 = S(0), v1 = S(0), v2 = S(0), jl0 = S(0), jl1 = S(0), jl2 = S(0), rs = S(0);
+  S u = S(0), v0 = S(0), v1 = S(0), v2 = S(0), qr = S(0);
   if (act) {
     const S* __restrict__ jrow = p.JpS + 9 * int64_t(row);
     const S* __restrict__ xc = x + 9 * cam;
@@ -847,14 +852,15 @@ __device__ __forceinline__ void bs_tile(const Params<S>& p, size_t T, int t_in_c
     v0 = vv.x;
     v1 = vv.y;
     v2 = vv.z;
-    const S* __restrict__ jl = p.JlS + 3 * int64_t(row);
-    jl0 = jl[0];
-    jl1 = jl[1];
-    jl2 = jl[2];
-    rs = p.rS[row];
+    qr = vv.w;  // (Q^T r)[row]
   }
   const int sl = lm_ok ? s : 0;
   const S t0 = p.tauH[3 * sl + 0], t1 = p.tauH[3 * sl + 1], t2 = p.tauH[3 * sl + 2];
+  // row r < 3 of the undamped triangle (for the model cost below): requested up front with the other landmark
+  // records, unconditionally (clamped), so that no load sits behind the dependent chain of reductions
+  const int rr = min(r, 2), ri = rr == 0 ? 0 : (rr == 1 ? 3 : 5);
+  const S* __restrict__ R0 = p.R0 + 6 * size_t(sl);
+  const S ra = R0[ri], rb = R0[min(ri + 1, 5)], rc = R0[min(ri + 2, 5)];
   S t = u;
   t -= t0 * seg_sum<S, P2>(v0 * t) * v0;
   t -= t1 * seg_sum<S, P2>(v1 * t) * v1;
@@ -886,8 +892,12 @@ __device__ __forceinline__ void bs_tile(const Params<S>& p, size_t T, int t_in_c
   inc[0] = -inc[0];
   inc[1] = -inc[1];
   inc[2] = -inc[2];
-  const S v = u + jl0 * inc[0] + jl1 * inc[1] + jl2 * inc[2];
-  const S acc = seg_sum<S, P2>(act ? v * (S(0.5) * v + rs) : S(0));
+  // w = Q^T (u + Jl delta) = t + [R0 delta; 0] (undamped triangle), model cost = sum w (w / 2 + Q^T r)
+  S w = t;
+  if (r == 0) w += ra * inc[0] + rb * inc[1] + rc * inc[2];
+  if (r == 1) w += ra * inc[1] + rb * inc[2];
+  if (r == 2) w += ra * inc[2];
+  const S acc = seg_sum<S, P2>(act ? w * (S(0.5) * w + qr) : S(0));
   if (r == 0 && lm_ok) {
     p.lm_ldiff[s] = -double(acc);
     const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) && is_finite(acc) &&

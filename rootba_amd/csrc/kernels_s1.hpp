@@ -133,13 +133,8 @@ __device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_i
     jl[c] *= sc;
     if (r == 0 && lm_ok) p.jl_scale[3 * s + c] = sc;
   }
-  if (rvalid) {
-    S* dst = p.JlS + 3 * row;
-    dst[0] = jl[0];
-    dst[1] = jl[1];
-    dst[2] = jl[2];
-    p.rS[row] = rs;
-  }
+  // (the pre-QR rows are not kept for the wave tiles: their back-substitution evaluates the model cost in the
+  //  rotated frame, k_bs_tile; the wide / big kernels below keep JlS / rS for the two-kernel back-substitution)
   S vm[3], tau[3];
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
@@ -352,7 +347,7 @@ __global__ __launch_bounds__(256) void k_s1_qr_wide(Params<S> p, int lm_begin, i
 }
 
 // ---------------------------------------------------------------------------
-// The 27 + 9 stage-2 record [damped Q1^T Jp D 3x9 | Q2 + damping rows' part of b 9] (kTd scalars) of every
+// The record of damped top rows [damped Q1^T Jp D 3x9 | padding] (kTd = 32 scalars, one cache line in float) of every
 // observation for the CURRENT damping, from the unscaled rows and the factors: one thread per observation (nine
 // columns in registers); the three top rows are rotated straight into the damped ones by the landmark's six
 // Givens rotations (k_s2_obs). Only the assembly of the reduced matrix and matrix-free E0 products read these
@@ -360,6 +355,7 @@ __global__ __launch_bounds__(256) void k_s1_qr_wide(Params<S> p, int lm_begin, i
 // LDS and move as contiguous 16-byte streams.
 // ---------------------------------------------------------------------------
 constexpr int kS1ColsThreads = 128;
+constexpr int kTdLds = 36;  // LDS stride of a staged record (32 would put every work-item's column on two banks)
 
 template <class S>
 __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_t n_obs) {
@@ -368,7 +364,7 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
   constexpr int N = 16 / int(sizeof(S)), NT = kS1ColsThreads;
   extern __shared__ __attribute__((aligned(16))) char smem_s1c[];
   S* sJ = reinterpret_cast<S*>(smem_s1c);  // [NT][18]  in: Jacobian rows, out: scaled rows
-  S* sT = sJ + NT * 18;                    // [NT][kTd] damped Q1^T Jp (27) | b record (9)
+  S* sT = sJ + NT * 18;                    // [NT][kTdLds] damped Q1^T Jp (27), padded
   const int tid = threadIdx.x;
   const int64_t o_base = int64_t(blockIdx.x) * NT;
   const int n_here = int(min<int64_t>(NT, n_obs - o_base));
@@ -419,15 +415,11 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
       // rows 0..2 of Q^T Jp (column j): Q1^T Jp
       S tt[3] = {-(c0 * w0.x + c1 * w0.y + c2 * w0.z), -(c0 * w1.x + c1 * w1.y + c2 * w1.z),
                  -(c0 * w2.x + c1 * w2.y + c2 * w2.z)};
-      S bm = -(c0 * d0 + c1 * d1 + c2 * d2);
       if (i == 0) {
         tt[0] += m0;
         tt[1] += m1;
       } else if (i == 1) {
         tt[2] += m0;
-        bm += m1 * vb.w;
-      } else {
-        bm += m0 * va.w + m1 * vb.w;
       }
       // landmark damping: rotate the top rows against the three damping rows (start at zero)
       S d[3] = {S(0), S(0), S(0)};
@@ -445,21 +437,22 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
           }
         }
       }
-      sT[kTd * tid + c] = tt[0];
-      sT[kTd * tid + 9 + c] = tt[1];
-      sT[kTd * tid + 18 + c] = tt[2];
-      // Q2 rows' part of b (add_Q2TJp_T_Q2Tr) + the damping rows' part
-      sT[kTd * tid + 27 + c] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
+      sT[kTdLds * tid + c] = tt[0];
+      sT[kTdLds * tid + 9 + c] = tt[1];
+      sT[kTdLds * tid + 18 + c] = tt[2];
     }
   }
   __syncthreads();
-  auto copy_out = [&](S* dst, const S* src, int total) {
-    const int nvec = total / N;
-    for (int q = tid; q < nvec; q += NT) reinterpret_cast<V*>(dst)[q] = reinterpret_cast<const V*>(src)[q];
-    for (int q = nvec * N + tid; q < total; q += NT) dst[q] = src[q];
-  };
-  // (16-byte alignment of the destinations: o_base is a multiple of 128)
-  copy_out(p.topd + kTd * o_base, sT, kTd * n_here);
+  // records of kTd = 32 scalars (one cache line in float) out of the 36-scalar LDS rows, as 16-byte pieces
+  // (o_base is a multiple of 128: the destination is aligned; entries 27..31 are padding nobody reads)
+  {
+    constexpr int VPR = kTd / N;  // vectors per record
+    V* dst = reinterpret_cast<V*>(p.topd + kTd * o_base);
+    for (int q = tid; q < n_here * VPR; q += NT) {
+      const int rec = q / VPR, v = q - VPR * rec;
+      dst[q] = *reinterpret_cast<const V*>(sT + kTdLds * rec + N * v);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------

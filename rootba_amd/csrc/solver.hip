@@ -970,12 +970,39 @@ class Solver final : public rba_solver {
     if (rc != 0) throw HipError{"ncclCommInitRank failed: " + std::to_string(rc), RBA_ERR_COMM};
     rank_ = rank;
     nranks_ = nranks;
+    comm_events_.assign(2 * kCommEvents, nullptr);  // (not lazily inside a timed stage)
+    for (auto& e : comm_events_) HIP_CHECK(hipEventCreate(&e));
     union_structure_over_ranks();
+  }
+
+  // Whether the reduced matrix is assembled at all is decided per rank from ITS shard (pair-list budget): ranks that
+  // disagreed would enter different collectives (171 vs 90 n_c in stage 2, the matrix itself, the structure union)
+  // and deadlock. The decision is made collective here: if any rank cannot hold its pair lists, every rank drops the
+  // assembled operator and stays matrix-free.
+  void agree_on_explicit_matrix() {
+    if (nranks_ <= 1) return;
+    int veto = ex_ready_ ? 0 : 1;
+    d_scratch_int_.upload(&veto, 1, stream_);
+    all_reduce(d_scratch_int_.get(), 1, kNcclMax);
+    d_scratch_int_.download(&veto, 1, stream_);
+    sync();
+    if (veto && ex_ready_) {
+      if (env_.verbose)
+        std::fprintf(stderr, "[rootba_hip] rank %d: another rank's pair lists exceed the budget: all ranks stay matrix-free\n",
+                     rank_);
+      destroy_pcg_graphs();
+      ex_ready_ = false;
+      ex_valid_ = false;
+      prm_.want_sdiag = 0;
+      pair_mark_.clear();
+      pair_mark_.shrink_to_fit();
+    }
   }
 
   // every rank must hold the SAME block structure for the explicit reduced matrix: union of
   // the co-observation marks of all landmark shards
   void union_structure_over_ranks() {
+    agree_on_explicit_matrix();
     if (!ex_ready_ || nranks_ <= 1) return;
     std::vector<int> marks(pair_mark_.begin(), pair_mark_.end());
     DevBuf<int> d;
@@ -1010,21 +1037,28 @@ class Solver final : public rba_solver {
   }
   void comm_stats(int64_t* calls, int64_t* bytes, double* seconds) override {
     use_device();
-    flush_comm_events(true);
+    if (comm_ev_tail_ != comm_ev_head_) sync();
+    drain_comm_events();
     *calls = comm_calls_;
     *bytes = comm_bytes_;
     *seconds = comm_seconds_;
+    if (comm_untimed_ > 0 && comm_timed_ > 0)  // collectives that found the ring full: priced at the timed ones' mean
+      *seconds += comm_seconds_ / double(comm_timed_) * double(comm_untimed_);
   }
-  // elapsed time of the recorded collectives (event pairs are recycled)
-  void flush_comm_events(bool wait) {
-    if (comm_ev_used_ == 0) return;
-    if (wait) sync();
-    for (int i = 0; i < comm_ev_used_; ++i) {
+  // Elapsed time of the collectives: a RING of event pairs on the solver stream. Completed pairs are drained with
+  // hipEventQuery - never a blocking wait inside a solve (round 2 synchronised the stream every 64 collectives, in the
+  // middle of the matrix-free PCG it was measuring); a collective that finds the ring full goes untimed.
+  void drain_comm_events() {
+    while (comm_ev_tail_ != comm_ev_head_) {
+      const int i = comm_ev_tail_ % kCommEvents;
+      if (hipEventQuery(comm_events_[2 * i + 1]) != hipSuccess) break;
       float ms = 0;
-      if (hipEventElapsedTime(&ms, comm_events_[2 * i], comm_events_[2 * i + 1]) == hipSuccess)
+      if (hipEventElapsedTime(&ms, comm_events_[2 * i], comm_events_[2 * i + 1]) == hipSuccess) {
         comm_seconds_ += double(ms) * 1e-3;
+        ++comm_timed_;
+      }
+      ++comm_ev_tail_;
     }
-    comm_ev_used_ = 0;
   }
 
   template <class T>
@@ -1038,19 +1072,21 @@ class Solver final : public rba_solver {
       comm_seconds_ += wall_seconds() - t0;
       return;
     }
-    if (comm_ev_used_ == kCommEvents) flush_comm_events(true);
-    if (comm_events_.empty()) {
-      comm_events_.assign(2 * kCommEvents, nullptr);
-      for (auto& e : comm_events_) HIP_CHECK(hipEventCreate(&e));
-    }
-    HIP_CHECK(hipEventRecord(comm_events_[2 * comm_ev_used_], stream_));
+    drain_comm_events();
+    const bool timed = comm_ev_head_ - comm_ev_tail_ < kCommEvents;
+    const int slot = comm_ev_head_ % kCommEvents;
+    if (timed) HIP_CHECK(hipEventRecord(comm_events_[2 * slot], stream_));
     const int dt = std::is_same<T, float>::value    ? kNcclFloat32
                    : std::is_same<T, double>::value ? kNcclFloat64
                                                     : kNcclInt32;
     const int rc = g_rccl.AllReduce(buf, buf, count, dt, op, comm_, stream_);
     if (rc != 0) throw HipError{"ncclAllReduce failed: " + std::to_string(rc), RBA_ERR_COMM};
-    HIP_CHECK(hipEventRecord(comm_events_[2 * comm_ev_used_ + 1], stream_));
-    ++comm_ev_used_;
+    if (timed) {
+      HIP_CHECK(hipEventRecord(comm_events_[2 * slot + 1], stream_));
+      ++comm_ev_head_;
+    } else {
+      ++comm_untimed_;
+    }
   }
 
   template <class T>
@@ -1091,25 +1127,28 @@ class Solver final : public rba_solver {
     d_lms_.upload(sorted.data(), sorted.size(), stream_);
     sync();
   }
+  // (either pointer may be null: cameras only / landmarks only)
   void get_state(void* cams, void* lms) override {
     use_device();
     if (mixed_) {
-      std::vector<double> sorted(3 * size_t(n_lms_));
-      d_cams64_.download(static_cast<double*>(cams), 10 * size_t(n_cams_), stream_);
-      d_lms64_.download(sorted.data(), sorted.size(), stream_);
+      std::vector<double> sorted(lms ? 3 * size_t(n_lms_) : 0);
+      if (cams) d_cams64_.download(static_cast<double*>(cams), 10 * size_t(n_cams_), stream_);
+      if (lms) d_lms64_.download(sorted.data(), sorted.size(), stream_);
       sync();
       double* l = static_cast<double*>(lms);
-      for (int s = 0; s < n_lms_; ++s)
-        for (int c = 0; c < 3; ++c) l[3 * size_t(perm_[s]) + c] = sorted[3 * size_t(s) + c];
+      if (lms)
+        for (int s = 0; s < n_lms_; ++s)
+          for (int c = 0; c < 3; ++c) l[3 * size_t(perm_[s]) + c] = sorted[3 * size_t(s) + c];
       return;
     }
-    std::vector<S> sorted(3 * size_t(n_lms_));
-    d_cams_.download(static_cast<S*>(cams), 10 * size_t(n_cams_), stream_);
-    d_lms_.download(sorted.data(), sorted.size(), stream_);
+    std::vector<S> sorted(lms ? 3 * size_t(n_lms_) : 0);
+    if (cams) d_cams_.download(static_cast<S*>(cams), 10 * size_t(n_cams_), stream_);
+    if (lms) d_lms_.download(sorted.data(), sorted.size(), stream_);
     sync();
     S* l = static_cast<S*>(lms);
-    for (int s = 0; s < n_lms_; ++s)
-      for (int c = 0; c < 3; ++c) l[3 * size_t(perm_[s]) + c] = sorted[3 * size_t(s) + c];
+    if (lms)
+      for (int s = 0; s < n_lms_; ++s)
+        for (int c = 0; c < 3; ++c) l[3 * size_t(perm_[s]) + c] = sorted[3 * size_t(s) + c];
   }
   void backup() override {
     use_device();
@@ -1389,7 +1428,7 @@ class Solver final : public rba_solver {
     if (topd_valid_) return;
     hipLaunchKernelGGL((rba::k_s12_cols<S>),
                        dim3(unsigned((n_obs_ + rba::kS1ColsThreads - 1) / rba::kS1ColsThreads)),
-                       dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTd) * sizeof(S), stream_,
+                       dim3(rba::kS1ColsThreads), size_t(rba::kS1ColsThreads) * (18 + rba::kTdLds) * sizeof(S), stream_,
                        prm_, int64_t(n_obs_));
     topd_valid_ = true;
   }
@@ -2209,8 +2248,8 @@ class Solver final : public rba_solver {
     } else {
       const int64_t no_untiled = no - (n_tiles_ > 0 ? n_obs_tiled_ : 0);
       // stage 1: geometry writes JpS 18 + Vh 8; the QR pass reads Vh 8 (+ the row map, 4 B per block row) and writes
-      // Vh 8 + JlS 6 + rS 2 per observation, R0 6 + tau 3 + LQ 12 + Jl_col_scale 3 per landmark
-      m->stage1 = geometry_in + no * ((18 + 8) + (8 + 8 + 6 + 2)) * s + no * 8 + nl * 24 * s;
+      // Vh 8 (+ JlS 6 + rS 2 for the untiled landmarks) per observation, R0 6 + tau 3 + LQ 12 + Jl_col_scale 3 per landmark
+      m->stage1 = geometry_in + no * ((18 + 8) + (8 + 8)) * s + no_untiled * 8 * s + no * 8 + nl * 24 * s;
       // the Gram pass on its own (JpS 18 + CSC index in, G 81 + Jp_diag2 9 out): not on one GPU, where it rides on the
       // camera pass of the first stage 2, which reads those rows anyway (already counted there)
       if (comm_ || cb_fn_ || !opt_.staged_execution) m->stage1 += no * (18 * s + 4) + nc * 90 * s;
@@ -2220,19 +2259,19 @@ class Solver final : public rba_solver {
       // Jp_diag2 9, scaling 9 out
       m->stage2 = no * (8 * s + 4) + no * 8 * s + no_untiled * 8 * s + nl * (30 + 37) * s + no * (26 * s + 4) +
                   nc * 108 * s;
-      // back-substitution, one pass on the wave tiles (k_bs_tile): JpS 18 + Vh 8 + JlS 6 + rS 2 and the two lane
-      // maps (4 B each per block row) per observation = 152 B in float; tau 3 + givens 16 + Rd 6 + Q1^T r 3 +
-      // Jl_col_scale 3 in, the point in and out (6) and l_diff (8 B) out per landmark. The two-kernel form of the
-      // untiled landmarks adds the eight coefficients and its 5-scalar scratch (write + read) per observation.
-      m->back_substitution = no * (34 * s + 16) + no_untiled * (8 + 10) * s + nl * (37 * s + 8) + nc * 9 * s;
+      // back-substitution, one pass on the wave tiles (k_bs_tile): JpS 18 + Vh 8 and the two lane maps (4 B each per
+      // block row) per observation = 120 B in float; tau 3 + givens 16 + R0 6 + Rd 6 + Q1^T r 3 + Jl_col_scale 3 in,
+      // the point in and out (6) and l_diff (8 B) out per landmark. The two-kernel form of the untiled landmarks adds
+      // JlS 6 + rS 2, the eight coefficients and its 5-scalar scratch (write + read) per observation.
+      m->back_substitution = no * (26 * s + 16) + no_untiled * (8 + 8 + 10) * s + nl * (43 * s + 8) + nc * 9 * s;
       // implicit-Q product: JpS row 9 + Vh row 4 per block row, camera / row maps, tau + Z per landmark
       m->product_matrix_free = no * (26 * s + 16) + nl * 12 * s + nc * 18 * s;
     }
     const int64_t nnz = sc_ ? sc_nnz_ : ex_nnz_;
     m->product_assembled = nnz * (81 * s + 4) + nc * 18 * s;
     m->assembly = sc_ ? sc_assemble_bytes_ : ex_pairs_ * (8 + 54 * s) + nnz * 81 * s;
-    if (!sc_)  // + the column pass that materialises the 27 + 9 records: JpS 18 + Vh 8 in, 36 out
-      m->assembly += int64_t(n_obs_) * (18 + 8 + 36) * s;
+    if (!sc_)  // + the column pass that materialises the records of damped top rows: JpS 18 + Vh 8 in, 32 out
+      m->assembly += int64_t(n_obs_) * (18 + 8 + 32) * s;
     m->pcg_vectors = nc * (81 + 10 * 9) * s;
   }
   void get_pcg_counters(rba_pcg_counters* out) override { *out = pcg_counters_; }
@@ -2481,7 +2520,7 @@ class Solver final : public rba_solver {
   std::vector<char> cb_stage_;
   static constexpr int kCommEvents = 64;
   std::vector<hipEvent_t> comm_events_;
-  int comm_ev_used_ = 0;
+  int64_t comm_ev_head_ = 0, comm_ev_tail_ = 0, comm_timed_ = 0, comm_untimed_ = 0;
   int64_t comm_calls_ = 0, comm_bytes_ = 0;
   double comm_seconds_ = 0;
 };
