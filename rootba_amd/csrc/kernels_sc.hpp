@@ -610,36 +610,54 @@ __global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const float* __restrict
                                                          const int* __restrict__ mirror_slot,
                                                          const int64_t* __restrict__ pair_ptr,
                                                          const int* __restrict__ pair_oi,
-                                                         const int* __restrict__ pair_oj) {
+                                                         const int* __restrict__ pair_oj, int n_upper) {
   __shared__ float tile[4][16][16];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int u = blockIdx.x;
+  // XCD-contiguous block order (workgroup b runs on XCD b % 8): consecutive upper blocks share their row camera, so
+  // the records an XCD gathers are re-used out of its own L2 instead of being fetched once per XCD
+  const int u = xcd_swizzled_camera(n_upper);
+  if (u >= n_upper) return;
   const int i = lane & 15, kk = lane >> 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
   const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
-  for (int64_t q = q0 + wave * 4; q < q1; q += 16) {
-    int oi[4], oj[4];
+  // 16 pairs per wave and step. A record (one observation's damped top rows) is ONE 128-byte cache line: the eight
+  // records of a quad of pairs are fetched with one 16-byte load per lane (lane = record x piece), staged in LDS and
+  // read back in the operand layout of the matrix-core instruction. (Round 2 gathered 4 bytes per lane straight into
+  // the operand registers: six 36-of-64-lane gather instructions per quad kept the kernel on the texture-address
+  // path - 0.95 ms on venice whatever the record size or the block order.)
+  constexpr int U = 4;
+  __shared__ __attribute__((aligned(16))) float stage[4][U][8][kTd];
+  const int rec = lane >> 3, vec = lane & 7;
+  const int* __restrict__ pair_side = rec < 4 ? pair_oi : pair_oj;
+  for (int64_t q = q0 + wave * (4 * U); q < q1; q += 16 * U) {
+    float4 v[U];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = q + r < q1;
-      oi[r] = ok ? pair_oi[q + r] : -1;
-      oj[r] = ok ? pair_oj[q + r] : -1;
-    }
-    float av[3], bv[3];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int g = 4 * m + kk;          // inner index 0..11 = (pair, factor column)
-      const int pp = g / 3, c = g - 3 * pp;
-      const int o_i = pp == 0 ? oi[0] : pp == 1 ? oi[1] : pp == 2 ? oi[2] : oi[3];
-      const int o_j = pp == 0 ? oj[0] : pp == 1 ? oj[1] : pp == 2 ? oj[2] : oj[3];
-      const bool ok = i < 9 && o_i >= 0;
-      av[m] = ok ? topd[kTd * int64_t(o_i) + 9 * c + i] : 0.f;
-      bv[m] = ok ? topd[kTd * int64_t(o_j) + 9 * c + i] : 0.f;
+    for (int uq = 0; uq < U; ++uq) {
+      const int64_t qq = q + 4 * uq + (rec & 3);
+      const int o = qq < q1 ? pair_side[qq] : -1;
+      v[uq] = o >= 0 ? reinterpret_cast<const float4*>(topd + kTd * int64_t(o))[vec] : float4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int m = 0; m < 3; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[m], acc, 0, 0, 0);
+    for (int uq = 0; uq < U; ++uq) *reinterpret_cast<float4*>(&stage[wave][uq][rec][4 * vec]) = v[uq];
+    wave_lds_fence();
+#pragma unroll
+    for (int uq = 0; uq < U; ++uq)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int g = 4 * m + kk;  // inner index 0..11 = (pair of the quad, factor row)
+        const int pp = g / 3, c = g - 3 * pp;
+        const float av = i < 9 ? stage[wave][uq][pp][9 * c + i] : 0.f;
+        const float bv = i < 9 ? stage[wave][uq][4 + pp][9 * c + i] : 0.f;
+        if (uq & 1)
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc2, 0, 0, 0);
+        else
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      }
+    wave_lds_fence();  // the next step overwrites the staging buffer
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][kk * 4 + r][i] = acc[r];
   __syncthreads();

@@ -1391,9 +1391,9 @@ class Solver final : public rba_solver {
 
   // off-diagonal blocks of the explicit reduced matrix: matrix cores for float, VALU for double
   void launch_offdiag(const float* topd, float* vals) {
-    hipLaunchKernelGGL((rba::k_ex_offdiag_mfma), dim3(ex_n_upper_), dim3(256), 0, stream_, topd, vals,
-                       d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(), d_ex_pair_oi_.get(),
-                       d_ex_pair_oj_.get());
+    hipLaunchKernelGGL((rba::k_ex_offdiag_mfma), dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_, topd,
+                       vals, d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(), d_ex_pair_oi_.get(),
+                       d_ex_pair_oj_.get(), ex_n_upper_);
   }
   void launch_offdiag(const double* topd, double* vals) {
     // the VALU version takes its factors as 12-byte loads from a [obs][9][3] copy
