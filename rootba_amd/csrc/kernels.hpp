@@ -1146,6 +1146,37 @@ __device__ __forceinline__ double pcg_sum_partials(const double* __restrict__ pa
   return r;
 }
 
+// Verification of a solve that ran on the ASSEMBLED float32 matrix (Solver::solve): with hx = (sum_l A_l^T A_l) x from
+// the matrix-free operator, the Q model -x.(b + r) / 2 is evaluated once with the recursion's residual r and once with
+// the true one b - (hx + lambda x). out = { x.(b + r_rec), x.(b + r_true), |r_true|^2, |r_rec|^2 }   (single workgroup)
+template <class S>
+__global__ __launch_bounds__(1024) void k_solve_check(const S* __restrict__ x, const S* __restrict__ bvec,
+                                                     const S* __restrict__ r, const S* __restrict__ hx, S lambda, int n,
+                                                     double* __restrict__ out) {
+  __shared__ double sm[16][4];
+  double acc[4] = {0, 0, 0, 0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double xi = double(x[i]), bi = double(bvec[i]), ri = double(r[i]);
+    const double rt = bi - (double(hx[i]) + double(lambda) * xi);
+    acc[0] += xi * (bi + ri);
+    acc[1] += xi * (bi + rt);
+    acc[2] += rt * rt;
+    acc[3] += ri * ri;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double t = wave_sum(acc[k]);
+    if (lane == 0) sm[wave][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double v = 0;
+    for (int w = 0; w < int(blockDim.x >> 6); ++w) v += sm[w][threadIdx.x];
+    out[threadIdx.x] = v;
+  }
+}
+
 // x = 0, r = b, state reset, |b|^2   (single workgroup)
 template <class S>
 __global__ __launch_bounds__(1024) void k_pcg_init(const S* __restrict__ bvec, S* __restrict__ x,

@@ -1681,7 +1681,34 @@ class Solver final : public rba_solver {
     hx_event_count_ = 0;
     hx_calls_ = 0;
     rba_cg_summary cg = pcg(sc_ ? S(0) : lambda);  // SC: the damping is inside the matrix
-    if (pcg_used_explicit_ && !sc_ && (cg.termination_type == 2 || pcg_indefinite_ || env_.force_explicit_fallback)) {
+    bool redo = pcg_used_explicit_ && !sc_ && (cg.termination_type == 2 || pcg_indefinite_ || env_.force_explicit_fallback);
+    if (pcg_used_explicit_ && !sc_ && !redo && env_.verify_assembled) {
+      // Trust, but verify: a solve that ran on the assembled float32 matrix S + E (|E| ~ eps |S|: step lengths along
+      // near-null directions are off) is checked with ONE product of the reference's operator: the
+      // Q model -x.(b + r)/2 that the stopping rule watched against its true value. Measured (venice / trafalgar /
+      // final-13682): 1e-5 ... 1e-3 relative for solves of up to ~150 iterations, 1.5e-2 at 350, ~1e-1 for the
+      // noise-limited solves that run into max_iterations (which do so matrix-free as well, and in the reference). The
+      // check is a SAFETY NET against an operator that misjudged the system altogether (a step that would raise the
+      // cost many-fold): beyond `verify_tolerance` the solve is repeated with the reference's operator.
+      d_tmp_.zero(stream_);
+      launch_hx_implicit(d_x_.get(), d_tmp_.get(), nullptr);
+      all_reduce(d_tmp_.get(), nvec_);
+      double* chk = d_partials_.get() + size_t(kReduceBlocks) * 8 + 8;
+      hipLaunchKernelGGL((rba::k_solve_check<S>), dim3(1), dim3(1024), 0, stream_, d_x_.get(), prm_.b, d_r_.get(),
+                         d_tmp_.get(), lambda, nvec_, chk);
+      double* h = pinned_doubles(kPinCheck);
+      HIP_CHECK(hipMemcpyAsync(h, chk, 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      sync();
+      ++pcg_counters_.products_matrix_free;
+      const double q_rec = h[0], q_true = h[1];
+      const bool ok = std::isfinite(q_true) && std::abs(q_true - q_rec) <= env_.verify_tolerance * std::abs(q_true);
+      if (env_.verbose)
+        std::fprintf(stderr, "[rootba_hip] assembled solve (%d iterations, lambda %.2e): Q model %.6e, true %.6e, |r| %.3e "
+                     "true %.3e -> %s\n", cg.num_iterations, double(lambda), -0.5 * q_rec, -0.5 * q_true, std::sqrt(h[3]),
+                     std::sqrt(h[2]), ok ? "kept" : "repeated matrix-free");
+      redo = !ok;
+    }
+    if (redo) {
       // The assembled operator is S + E with |E| ~ eps |S|: unlike the square-root product
       // (p.q = |A p|^2 + lambda |p|^2 >= 0 by construction) it can lose definiteness when
       // lambda < eps |S|. The reference's operator cannot - repeat this solve matrix-free.
@@ -2290,7 +2317,7 @@ class Solver final : public rba_solver {
   void use_device() { HIP_CHECK(hipSetDevice(device_)); }
   // result slots in the pinned page h_pinned_ (the PCG state copy lives at offset 0)
   static constexpr size_t kPinCe0 = 1024, kPinCe1 = 1024 + 64, kPinLdiff = 1024 + 128, kPinFailLin = 1024 + 136,
-                          kPinFailApply = 1024 + 140;
+                          kPinFailApply = 1024 + 140, kPinCheck = 1024 + 192;
   double* pinned_doubles(size_t off) { return reinterpret_cast<double*>(h_pinned_ + off); }
   int* pinned_int(size_t off) { return reinterpret_cast<int*>(h_pinned_ + off); }
   void sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
@@ -2387,6 +2414,8 @@ class Solver final : public rba_solver {
     int hx_win = 0;                    // RBA_HX_WIN=n: cap of the camera window of the LDS-private products
     int hx_timing_stride = -1;         // RBA_HX_TIMING_STRIDE=n: HIP events around every n-th matrix-free product
     int sort_by_camera = -1;           // RBA_SORT_BY_CAMERA=0/1: override the automatic choice
+    int verify_assembled = 1;          // RBA_VERIFY_ASSEMBLED=0: skip the one-product check of assembled-operator solves
+    double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
   };
   DebugEnv env_;
   void read_debug_env() {
@@ -2402,6 +2431,8 @@ class Solver final : public rba_solver {
     env_.hx_win = geti("RBA_HX_WIN", 0);
     env_.hx_timing_stride = geti("RBA_HX_TIMING_STRIDE", -1);
     env_.sort_by_camera = geti("RBA_SORT_BY_CAMERA", -1);
+    env_.verify_assembled = geti("RBA_VERIFY_ASSEMBLED", 1);
+    if (const char* ev = std::getenv("RBA_VERIFY_TOLERANCE")) env_.verify_tolerance = std::atof(ev);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }
 
