@@ -29,7 +29,8 @@
  *  - environment: the library reads a handful of DEBUG / TEST variables once per rba_create (none is needed in
  *    production, none changes results beyond rounding): RBA_VERBOSE, RBA_EXPLICIT_AFTER (overrides
  *    rba_options.explicit_after), RBA_EX_PAIR_BUDGET_GB, RBA_FORCE_EXPLICIT_FALLBACK, RBA_HX_LDS, RBA_HX_WIN,
- *    RBA_HX_TIMING_STRIDE, RBA_SORT_BY_CAMERA (rootba_amd/csrc/solver.hip: Solver::DebugEnv). The ~25 kernel-selection
+ *    RBA_HX_TIMING_STRIDE, RBA_SORT_BY_CAMERA, RBA_VERIFY_ASSEMBLED, RBA_VERIFY_TOLERANCE (rootba_amd/csrc/solver.hip:
+ *    Solver::DebugEnv). The ~25 kernel-selection
  *    switches of rounds 1-2 are gone with the kernels they selected.
  *  - camera state: 10 scalars (qx,qy,qz,qw,tx,ty,tz,f,k1,k2) = Camera::params()
  *    (bal_problem.hpp:84-95); pose/intrinsics increments: 9 per camera.
