@@ -146,9 +146,21 @@ __global__ __launch_bounds__(256) void k_compute_error(Params<S> p, int64_t n_ob
 }
 
 // Sum rows of a [n][W] double array into out[W] (single block, deterministic).
+// Results that the host reads at its next synchronisation point are written straight into the pinned host page
+// (`out_host`, `flag_host`: mapped, fine-grained) by the kernel that produces them - a device-to-host copy of a few
+// bytes is a blit kernel of its own (4.8 us each on the profile, eight to ten per LM iteration). `flag`: the numerical
+// failure word of the phase that ends here is published and its bits `flag_clear` are reset for the next phase.
+// Null host pointers (more than one rank: the values are all-reduced on the device first) leave that to the caller.
 template <int W>
 __global__ __launch_bounds__(256) void k_reduce_rows(const double* __restrict__ in, int64_t n,
-                                                     double* __restrict__ out) {
+                                                     double* __restrict__ out, double* __restrict__ out_host,
+                                                     int* __restrict__ flag, int* __restrict__ flag_host,
+                                                     int flag_clear) {
+  if (flag_host && threadIdx.x == 255) {
+    const int f = *flag;
+    *flag_host = f;
+    if (f & flag_clear) *flag = f & ~flag_clear;
+  }
   double acc[W];
 #pragma unroll
   for (int i = 0; i < W; ++i) acc[i] = 0;
@@ -164,8 +176,18 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const double* __restrict__ 
     if (lane == 0) sm[wave][i] = t;
   }
   __syncthreads();
-  if (threadIdx.x < W)
-    out[threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+  if (threadIdx.x < W) {
+    const double t = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    out[threadIdx.x] = t;
+    if (out_host) out_host[threadIdx.x] = t;
+  }
+}
+
+// the failure word of a phase that ends without a reduction of its own (stage 1)
+__global__ void k_publish_flag(int* __restrict__ flag, int* __restrict__ flag_host, int flag_clear) {
+  const int f = *flag;
+  *flag_host = f;
+  if (f & flag_clear) *flag = f & ~flag_clear;
 }
 
 // ===========================================================================
@@ -1426,8 +1448,8 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_c1(const S* __restrict__ bv
 
 // Q-model termination (conjugate_gradient.hpp:239-276) and bookkeeping; one thread.
 // `phase` 0: after k_pcg_b2 (skipped on refresh iterations), 1: after k_pcg_c1.
-__global__ void k_pcg_fin(CgState* st, const double* __restrict__ partial_q1, int phase,
-                          double q_tolerance, int min_it, int max_it) {
+__device__ __forceinline__ void pcg_fin(CgState* st, const double* __restrict__ partial_q1, int phase,
+                                        double q_tolerance, int min_it, int max_it) {
   if (st->done) return;
   if (phase == 0 && st->refresh) return;
   if (phase == 1 && !st->refresh) return;
@@ -1447,6 +1469,21 @@ __global__ void k_pcg_fin(CgState* st, const double* __restrict__ partial_q1, in
   if (it >= max_it) {
     st->termination = 0;
     st->done = 1;
+  }
+}
+
+// `host_copy`: the state the host polls goes straight to its pinned page (see k_reduce_rows); one work-item, which
+// reads back its own stores
+__global__ void k_pcg_fin(CgState* st, const double* __restrict__ partial_q1, int phase, double q_tolerance,
+                          int min_it, int max_it, CgState* host_copy) {
+  pcg_fin(st, partial_q1, phase, q_tolerance, min_it, max_it);
+  if (host_copy) {
+    __threadfence();
+    constexpr int kWords = int(sizeof(CgState) / sizeof(int));
+    static_assert(sizeof(CgState) % sizeof(int) == 0, "copied as words");
+#pragma unroll
+    for (int i = 0; i < kWords; ++i)
+      reinterpret_cast<int*>(host_copy)[i] = reinterpret_cast<const volatile int*>(st)[i];
   }
 }
 

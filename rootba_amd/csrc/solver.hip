@@ -1204,10 +1204,14 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, stream_, prm_,
                          n_obs_, d_partials_.get());
     double* red = d_partials_.get() + size_t(kReduceBlocks) * 8;
-    hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, stream_,
-                       d_partials_.get(), int64_t(blocks), red);
-    all_reduce(red, 8);
-    HIP_CHECK(hipMemcpyAsync(h, red, 8 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    const bool direct = results_go_direct();
+    hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, stream_, d_partials_.get(), int64_t(blocks), red,
+                       direct ? h : static_cast<double*>(nullptr), static_cast<int*>(nullptr),
+                       static_cast<int*>(nullptr), 0);
+    if (!direct) {
+      all_reduce(red, 8);
+      HIP_CHECK(hipMemcpyAsync(h, red, 8 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    }
     time_end(&timings_.residual_evaluation_time, true);
   }
   static void compute_error_parse(const double* h, rba_residual_info* out) {
@@ -1225,7 +1229,7 @@ class Solver final : public rba_solver {
     use_device();
     time_begin();
     sub_begin();
-    d_fail_.zero(stream_);
+    // (the failure word is clean here: whoever publishes it to the host resets the bits of its phase)
     if (!sc_) {
       // geometry once per observation; Jp_diag2 falls out of the camera-major Gram pass
       hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256),
@@ -1272,7 +1276,12 @@ class Solver final : public rba_solver {
     }
     HIP_CHECK(hipGetLastError());
     int* fail = pinned_int(kPinFailLin);
-    HIP_CHECK(hipMemcpyAsync(fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (results_go_direct()) {
+      hipLaunchKernelGGL(rba::k_publish_flag, dim3(1), dim3(1), 0, stream_, d_fail_.get(), fail, 1);
+    } else {
+      HIP_CHECK(hipMemcpyAsync(fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
+      hipLaunchKernelGGL(rba::k_publish_flag, dim3(1), dim3(1), 0, stream_, d_fail_.get(), d_scratch_int_.get(), 1);
+    }
     if (jp_diag2_out) d_jp_diag2_.download(static_cast<S*>(jp_diag2_out), nvec_, stream_);
     time_end(&timings_.stage1_time);
     sub_collect();
@@ -1859,6 +1868,9 @@ class Solver final : public rba_solver {
                          lambda, n, st, part_pq);
       hipLaunchKernelGGL((rba::k_pcg_b2<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
                          d_r_.get(), d_p_.get(), d_q_.get(), d_tmp_.get(), n, st, 10, part_pq, part_q1);
+      // (the iterations the host polls at: the closing kernel leaves a copy of the state in the pinned page)
+      const bool poll = it <= 8 || it % 4 == 0 || it == max_it;
+      rba::CgState* pub = poll ? hst : static_cast<rba::CgState*>(nullptr);
       if (it % 10 == 0) {
         // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
         launch_hx(d_x_.get(), d_tmp_.get(), done);
@@ -1866,13 +1878,12 @@ class Solver final : public rba_solver {
         hipLaunchKernelGGL((rba::k_pcg_c1<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
                            d_r_.get(), d_tmp_.get(), lambda, n, st, part_q1);
         hipLaunchKernelGGL((rba::k_pcg_fin), dim3(1), dim3(1), 0, stream_, st, part_q1, 1, eta, min_it,
-                           max_it);
+                           max_it, pub);
       } else {
         hipLaunchKernelGGL((rba::k_pcg_fin), dim3(1), dim3(1), 0, stream_, st, part_q1, 0, eta, min_it,
-                           max_it);
+                           max_it, pub);
       }
-      if (it <= 8 || it % 4 == 0 || it == max_it) {
-        HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
+      if (poll) {
         sync();
         if (hst->done) break;
       }
@@ -1907,7 +1918,6 @@ class Solver final : public rba_solver {
     if (!landmark_damping_valid_) run_stage2(S(0));
     time_begin();
     d_inc_.upload(static_cast<const S*>(inc), nvec_, stream_);
-    HIP_CHECK(hipMemsetAsync(d_fail_.get(), 0, sizeof(int), stream_));
     if (sc_) {
       hipLaunchKernelGGL((rba::k_sc_back_substitute<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_,
                          scp_, d_inc_.get());
@@ -1939,14 +1949,21 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_sum_ldiff), dim3(blocks), dim3(256), 0, stream_,
                        d_lm_ldiff_.get(), n_lms_, d_partials_.get());
     double* red = d_partials_.get() + size_t(kReduceBlocks) * 8;
-    hipLaunchKernelGGL((rba::k_reduce_rows<1>), dim3(1), dim3(256), 0, stream_,
-                       d_partials_.get(), int64_t(blocks), red);
-    all_reduce(red, 1);
-    all_reduce(d_fail_.get(), 1, kNcclMax);
     double* l_diff = pinned_doubles(kPinLdiff);
     int* fail = pinned_int(kPinFailApply);
-    HIP_CHECK(hipMemcpyAsync(l_diff, red, sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipMemcpyAsync(fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (results_go_direct()) {
+      // l_diff and the failure word (bits 2: back-substitution, 4: block inversion of the solve) land in the pinned page
+      hipLaunchKernelGGL((rba::k_reduce_rows<1>), dim3(1), dim3(256), 0, stream_, d_partials_.get(), int64_t(blocks),
+                         red, l_diff, d_fail_.get(), fail, 2 | 4);
+    } else {
+      hipLaunchKernelGGL((rba::k_reduce_rows<1>), dim3(1), dim3(256), 0, stream_, d_partials_.get(), int64_t(blocks),
+                         red, static_cast<double*>(nullptr), static_cast<int*>(nullptr), static_cast<int*>(nullptr), 0);
+      all_reduce(red, 1);
+      all_reduce(d_fail_.get(), 1, kNcclMax);
+      HIP_CHECK(hipMemcpyAsync(l_diff, red, sizeof(double), hipMemcpyDeviceToHost, stream_));
+      HIP_CHECK(hipMemcpyAsync(fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
+      hipLaunchKernelGGL(rba::k_publish_flag, dim3(1), dim3(1), 0, stream_, d_fail_.get(), d_scratch_int_.get(), 2 | 4);
+    }
     time_end(&timings_.back_substitution_time);
     // the back-substitution leaves the blocks undamped in the reference
     // (ipp:247-248); here damped rows are rebuilt by the next stage 2 anyway
@@ -2296,7 +2313,10 @@ class Solver final : public rba_solver {
     }
     const int64_t nnz = sc_ ? sc_nnz_ : ex_nnz_;
     m->product_assembled = nnz * (81 * s + 4) + nc * 18 * s;
-    m->assembly = sc_ ? sc_assemble_bytes_ : ex_pairs_ * (8 + 54 * s) + nnz * 81 * s;
+    // assembly, COMPULSORY bytes: the pair list (8 B per pair), every 32-scalar record once, the blocks out. The
+    // gather itself requests two records per pair (256 B in float); what L2 does not keep of that is re-read traffic
+    // and shows up as measured / model > 1 (profiles/r3_pmc_stage_traffic.csv), not as algorithmic bytes.
+    m->assembly = sc_ ? sc_assemble_bytes_ : ex_pairs_ * 8 + int64_t(n_obs_) * 32 * s + nnz * 81 * s;
     if (!sc_)  // + the column pass that materialises the records of damped top rows: JpS 18 + Vh 8 in, 32 out
       m->assembly += int64_t(n_obs_) * (18 + 8 + 32) * s;
     m->pcg_vectors = nc * (81 + 10 * 9) * s;
@@ -2368,6 +2388,8 @@ class Solver final : public rba_solver {
   // staged_execution = 0 the kernel groups of a stage are separated by HIP events (a marker packet each) and the
   // elapsed times are filed under the reference's IterationSummary fields; the kernels are the same either way.
   bool sub_timing() const { return !opt_.staged_execution; }
+  // one rank: sums and failure words need no all-reduce, the kernels that produce them write the pinned host page
+  bool results_go_direct() const { return !comm_ && !cb_fn_; }
   void sub_begin() {
     sub_n_ = 0;
     if (sub_timing()) sub_mark(nullptr);

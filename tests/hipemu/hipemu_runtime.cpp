@@ -497,6 +497,7 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
   return hipSuccess;
 }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }  // streams execute at enqueue: a recorded event has completed
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
   return hipSuccess;

@@ -27,13 +27,14 @@ def test_model_never_exceeds_measured_traffic(table):
 
 def test_measured_traffic_is_close_to_the_model_where_the_kernels_stream(table):
     """Streams (cost evaluation, stage 1, the products, the back-substitution) move within 15 % of the model; the
-    camera-major gather of stage 2 and the pair gather of the assembly fetch whole cache lines for 72- / 108-byte
-    records and stay below 2 x (DESIGN.md 4 discusses both)."""
+    camera-major gather of stage 2 fetches whole cache lines for 72-byte rows and stays below 2 x; the pair gather of
+    the assembly re-reads a record once per pair it takes part in, of which L2 absorbs about half: below 2.5 x of the
+    compulsory bytes (DESIGN.md 4 discusses both)."""
     g = table["groups"]
     for name in ("compute_error", "stage1", "product_matrix_free", "product_assembled", "back_substitution"):
         assert g[name]["measured_over_model"] < 1.15, (name, g[name])
-    for name in ("stage2", "assembly"):
-        assert g[name]["measured_over_model"] < 2.0, (name, g[name])
+    assert g["stage2"]["measured_over_model"] < 2.0, g["stage2"]
+    assert g["assembly"]["measured_over_model"] < 2.5, g["assembly"]
 
 
 def test_fetch_size_calibration_matches_the_guide(table):
