@@ -87,17 +87,31 @@ struct Params {
   S eps;  // jacobi scaling epsilon
 };
 
-// landmark update of the back-substitution (ipp:279-283): lms += Jl_col_scale * inc, or - mixed precision - the
-// scaled increment is handed to the double master state (k_mixed_update_landmarks)
+// End of a landmark's back-substitution: model-cost term, non-finite check, and the update (ipp:279-283): lms +=
+// Jl_col_scale * inc, or - mixed precision - the scaled increment is handed to the double master state
+// (k_mixed_update_landmarks). All loads are issued before the
+// first store and none sits behind a short-circuit: through pointers that may alias, a load behind a store is issued in
+// order after it, and load - store pairs (or loads guarded by the result of earlier ones) in a row are as many memory
+// round trips at the tail of every wave.
 template <class S>
-__device__ __forceinline__ void apply_landmark_increment(const Params<S>& p, int s, const S inc[3]) {
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const S d = inc[j] * p.jl_scale[3 * s + j];
-    if (p.lm_inc)
-      p.lm_inc[3 * s + j] = d;
-    else
-      p.lms[3 * s + j] += d;
+__device__ __forceinline__ void finish_landmark(const Params<S>& p, int s, const S inc[3], S acc) {
+  const S* __restrict__ sc = p.jl_scale + 3 * size_t(s);
+  const S* __restrict__ lm = p.lms + 3 * size_t(s);
+  const S s0 = sc[0], s1 = sc[1], s2 = sc[2];
+  const S l0 = lm[0], l1 = lm[1], l2 = lm[2];
+  const bool fin = is_finite(inc[0]) & is_finite(inc[1]) & is_finite(inc[2]) & is_finite(acc) & is_finite(l0) &
+                   is_finite(l1) & is_finite(l2);
+  p.lm_ldiff[s] = -double(acc);
+  if (!fin) atomicOr(p.fail_flag, 2);
+  const S d0 = inc[0] * s0, d1 = inc[1] * s1, d2 = inc[2] * s2;
+  if (p.lm_inc) {
+    p.lm_inc[3 * size_t(s) + 0] = d0;
+    p.lm_inc[3 * size_t(s) + 1] = d1;
+    p.lm_inc[3 * size_t(s) + 2] = d2;
+  } else {
+    p.lms[3 * size_t(s) + 0] = l0 + d0;
+    p.lms[3 * size_t(s) + 1] = l1 + d1;
+    p.lms[3 * size_t(s) + 2] = l2 + d2;
   }
 }
 
@@ -796,11 +810,7 @@ __global__ __launch_bounds__(256) void k_bs_landmark(Params<S> p, int lm_begin, 
       acc += v * (S(0.5) * v + p.rS[2 * o + r]);
     }
   }
-  p.lm_ldiff[s] = -double(acc);
-  const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) && is_finite(acc) &&
-                   is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) && is_finite(p.lms[3 * s + 2]);
-  if (!fin) atomicOr(p.fail_flag, 2);
-  apply_landmark_increment(p, s, inc);
+  finish_landmark(p, s, inc, acc);
 }
 
 // the same, one WAVEFRONT per landmark (lanes run over the observations): for the few landmarks with 32 < k <= 112
@@ -836,11 +846,7 @@ __global__ __launch_bounds__(256) void k_bs_landmark_wave(Params<S> p, int lm_be
   }
   acc = wave_sum(acc);
   if (lane == 0) {
-    p.lm_ldiff[s] = -double(acc);
-    const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) && is_finite(acc) &&
-                     is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) && is_finite(p.lms[3 * s + 2]);
-    if (!fin) atomicOr(p.fail_flag, 2);
-    apply_landmark_increment(p, s, inc);
+    finish_landmark(p, s, inc, acc);
   }
 }
 
@@ -853,36 +859,88 @@ __global__ __launch_bounds__(256) void k_bs_landmark_wave(Params<S> p, int lm_be
 // reflector record) - so neither the pre-QR Jl rows nor the residuals are read (round 2 read them: 152 bytes per
 // observation; now 120: Jacobian rows, reflector records, the two lane maps), and the QR pass of the wave tiles no
 // longer writes them.
-template <class S, int P2>
-__device__ __forceinline__ void bs_tile(const Params<S>& p, size_t T, int t_in_class, int lm_begin, int lm_end,
-                                        const S* __restrict__ x, int lane) {
+//
+// One tile per wave (the persistent, software-pipelined form of the product - k_hx_implicit_lds - was measured here too:
+// 239 us against 219 on venice-1778; without atomics in the way the hardware's eight waves per SIMD hide the latency
+// better than four waves with a prefetched tile), every load unconditional (clamped indices, zeros selected afterwards).
+// The landmark's 30 scalars (rotations, damped triangle, damped Q1^T r, tau, undamped triangle) are fetched
+// CO-OPERATIVELY: lane q of a quad loads piece q of the rotation record and element q (and 4 + q) of the short arrays,
+// and quad-broadcast DPP moves hand them round - every quad of the landmark's lane group ends up with everything -
+// instead of 27 loads of one scalar per lane that all lanes of the group repeat (measured on venice-1778 with those
+// loads stubbed out: 34 us of the pass's 258). (One 128-byte record per landmark written by stage 2 was measured as
+// well: the back-substitution gained the same, k_s2_obs lost 45 us on the eight sparse 16-byte stores per landmark.)
+template <class S>
+struct BsTileData {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  S jp[9], xc[9];
+  V4 vv;  // v0 v1 v2 (Q^T r)[row]
+  V4 g;   // piece (lane & 3) of the landmark's rotation record [c 6 | s 6 | ...]
+  S rd0, rd1, q1, tau, r00, r01;  // elements q / 4 + q (clamped) of Rd, q of Q1^T r and tau, q / 4 + q of R0
+};
+
+template <class S>
+__device__ __forceinline__ void bs_tile_load(const Params<S>& p, const ImplicitTiles& it, int T, int cam, int row,
+                                             int lane, const S* __restrict__ x, BsTileData<S>& d) {
+  using V4 = typename BsTileData<S>::V4;
+  const int cls = hx_tile_class(it, T);  // wave-uniform
+  const int sh = 2 + cls;                // P2 = 1 << sh lanes per landmark
+  const int seg = lane >> sh;
+  const int lb = cls == 0 ? it.lm_begin[0] : cls == 1 ? it.lm_begin[1] : cls == 2 ? it.lm_begin[2]
+               : cls == 3 ? it.lm_begin[3] : it.lm_begin[4];
+  const int le = cls == 0 ? it.lm_end[0] : cls == 1 ? it.lm_end[1] : cls == 2 ? it.lm_end[2]
+               : cls == 3 ? it.lm_end[3] : it.lm_end[4];
+  const int tb = cls == 0 ? it.tile_begin[0] : cls == 1 ? it.tile_begin[1] : cls == 2 ? it.tile_begin[2]
+               : cls == 3 ? it.tile_begin[3] : it.tile_begin[4];
+  const size_t s = size_t(min(lb + ((T - tb) << (6 - sh)) + seg, le - 1));  // clamped: padding segments read a valid landmark
+  const int64_t rw = cam >= 0 ? row : 0;
+  const int cc = cam >= 0 ? cam : 0;
+  const S* __restrict__ jrow = p.JpS + 9 * rw;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) d.jp[c] = jrow[c];
+  d.vv = reinterpret_cast<const V4*>(p.Vh)[rw];
+  const S* __restrict__ xc = x + 9 * cc;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) d.xc[c] = xc[c];
+  const int q = lane & 3;
+  d.g = reinterpret_cast<const V4*>(p.givens + 16 * s)[q];
+  d.rd0 = p.Rd[6 * s + q];
+  d.rd1 = p.Rd[6 * s + min(4 + q, 5)];
+  d.q1 = p.q1trd[3 * s + min(q, 2)];
+  d.tau = p.tauH[3 * s + min(q, 2)];
+  d.r00 = p.R0[6 * s + q];
+  d.r01 = p.R0[6 * s + min(4 + q, 5)];
+}
+
+// quad-broadcast of lane Q's value (quad_perm:[Q,Q,Q,Q])
+template <int Q, class S>
+__device__ __forceinline__ S quad_bcast(S v) {
+  return dpp_mov0<Q | (Q << 2) | (Q << 4) | (Q << 6)>(v);
+}
+
+template <class S, int P2>
+__device__ __forceinline__ void bs_tile_compute(const Params<S>& p, const BsTileData<S>& d, int t_in_class,
+                                                int lm_begin, int lm_end, int cam, int lane) {
   constexpr int LPW = 64 / P2;
   const int seg = lane / P2, r = lane - P2 * seg, base = lane - r;
   const int s = lm_begin + t_in_class * LPW + seg;
   const bool lm_ok = s < lm_end;
-  const int cam = p.CT[T * 64 + lane];
-  const int row = p.RT[T * 64 + lane];
   const bool act = cam >= 0;
-  S u = S(0), v0 = S(0), v1 = S(0), v2 = S(0), qr = S(0);
-  if (act) {
-    const S* __restrict__ jrow = p.JpS + 9 * int64_t(row);
-    const S* __restrict__ xc = x + 9 * cam;
+  // the landmark's scalars, whole, in every lane
+  const S gc[6] = {quad_bcast<0>(d.g.x), quad_bcast<0>(d.g.y), quad_bcast<0>(d.g.z), quad_bcast<0>(d.g.w),
+                   quad_bcast<1>(d.g.x), quad_bcast<1>(d.g.y)};
+  const S gs[6] = {quad_bcast<1>(d.g.z), quad_bcast<1>(d.g.w), quad_bcast<2>(d.g.x), quad_bcast<2>(d.g.y),
+                   quad_bcast<2>(d.g.z), quad_bcast<2>(d.g.w)};
+  const S Rd[6] = {quad_bcast<0>(d.rd0), quad_bcast<1>(d.rd0), quad_bcast<2>(d.rd0), quad_bcast<3>(d.rd0),
+                   quad_bcast<0>(d.rd1), quad_bcast<1>(d.rd1)};
+  const S R0[6] = {quad_bcast<0>(d.r00), quad_bcast<1>(d.r00), quad_bcast<2>(d.r00), quad_bcast<3>(d.r00),
+                   quad_bcast<0>(d.r01), quad_bcast<1>(d.r01)};
+  const S q1[3] = {quad_bcast<0>(d.q1), quad_bcast<1>(d.q1), quad_bcast<2>(d.q1)};
+  const S t0 = quad_bcast<0>(d.tau), t1 = quad_bcast<1>(d.tau), t2 = quad_bcast<2>(d.tau);
+  S u = S(0);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) u += jrow[c] * xc[c];
-    const V4 vv = reinterpret_cast<const V4*>(p.Vh)[row];
-    v0 = vv.x;
-    v1 = vv.y;
-    v2 = vv.z;
-    qr = vv.w;  // (Q^T r)[row]
-  }
-  const int sl = lm_ok ? s : 0;
-  const S t0 = p.tauH[3 * sl + 0], t1 = p.tauH[3 * sl + 1], t2 = p.tauH[3 * sl + 2];
-  // row r < 3 of the undamped triangle (for the model cost below): requested up front with the other landmark
-  // records, unconditionally (clamped), so that no load sits behind the dependent chain of reductions
-  const int rr = min(r, 2), ri = rr == 0 ? 0 : (rr == 1 ? 3 : 5);
-  const S* __restrict__ R0 = p.R0 + 6 * size_t(sl);
-  const S ra = R0[ri], rb = R0[min(ri + 1, 5)], rc = R0[min(ri + 2, 5)];
+  for (int c = 0; c < 9; ++c) u += d.jp[c] * d.xc[c];
+  u = act ? u : S(0);
+  const S v0 = act ? d.vv.x : S(0), v1 = act ? d.vv.y : S(0), v2 = act ? d.vv.z : S(0), qr = act ? d.vv.w : S(0);
   S t = u;
   t -= t0 * seg_sum<S, P2>(v0 * t) * v0;
   t -= t1 * seg_sum<S, P2>(v1 * t) * v1;
@@ -890,23 +948,21 @@ __device__ __forceinline__ void bs_tile(const Params<S>& p, size_t T, int t_in_c
   S tt[3] = {__shfl(t, base), __shfl(t, base + 1), __shfl(t, base + 2)};
   // landmark damping: the six rotations of stage 2 on (top rows, zero damping rows)
   {
-    const S* __restrict__ g = p.givens + 16 * size_t(sl);
-    S d[3] = {S(0), S(0), S(0)};
+    S dd[3] = {S(0), S(0), S(0)};
     int idx = 0;
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
 #pragma unroll
       for (int m = 0; m <= n; ++m) {
-        const S cc = g[idx], sn = g[6 + idx];
-        const S xx = d[n - m], yy = tt[n];
-        d[n - m] = cc * xx + sn * yy;
+        const S cc = gc[idx], sn = gs[idx];
+        const S xx = dd[n - m], yy = tt[n];
+        dd[n - m] = cc * xx + sn * yy;
         tt[n] = -sn * xx + cc * yy;
         ++idx;
       }
     }
   }
-  const S* __restrict__ Rd = p.Rd + 6 * size_t(sl);
-  const S rhs0 = p.q1trd[3 * sl] + tt[0], rhs1 = p.q1trd[3 * sl + 1] + tt[1], rhs2 = p.q1trd[3 * sl + 2] + tt[2];
+  const S rhs0 = q1[0] + tt[0], rhs1 = q1[1] + tt[1], rhs2 = q1[2] + tt[2];
   S inc[3];
   inc[2] = rhs2 / Rd[5];
   inc[1] = (rhs1 - Rd[4] * inc[2]) / Rd[3];
@@ -916,17 +972,11 @@ __device__ __forceinline__ void bs_tile(const Params<S>& p, size_t T, int t_in_c
   inc[2] = -inc[2];
   // w = Q^T (u + Jl delta) = t + [R0 delta; 0] (undamped triangle), model cost = sum w (w / 2 + Q^T r)
   S w = t;
-  if (r == 0) w += ra * inc[0] + rb * inc[1] + rc * inc[2];
-  if (r == 1) w += ra * inc[1] + rb * inc[2];
-  if (r == 2) w += ra * inc[2];
+  if (r == 0) w += R0[0] * inc[0] + R0[1] * inc[1] + R0[2] * inc[2];
+  if (r == 1) w += R0[3] * inc[1] + R0[4] * inc[2];
+  if (r == 2) w += R0[5] * inc[2];
   const S acc = seg_sum<S, P2>(act ? w * (S(0.5) * w + qr) : S(0));
-  if (r == 0 && lm_ok) {
-    p.lm_ldiff[s] = -double(acc);
-    const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) && is_finite(acc) &&
-                     is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) && is_finite(p.lms[3 * s + 2]);
-    if (!fin) atomicOr(p.fail_flag, 2);
-    apply_landmark_increment(p, s, inc);
-  }
+  if (r == 0 && lm_ok) finish_landmark(p, s, inc, acc);
 }
 
 template <class S>
@@ -934,16 +984,16 @@ __global__ __launch_bounds__(256) void k_bs_tile(Params<S> p, ImplicitTiles it, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int T = blockIdx.x * 4 + wave;
   if (T >= it.tile_begin[5]) return;
-  if (T >= it.tile_begin[4])
-    bs_tile<S, 64>(p, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], x, lane);
-  else if (T >= it.tile_begin[3])
-    bs_tile<S, 32>(p, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], x, lane);
-  else if (T >= it.tile_begin[2])
-    bs_tile<S, 16>(p, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], x, lane);
-  else if (T >= it.tile_begin[1])
-    bs_tile<S, 8>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], x, lane);
-  else
-    bs_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], x, lane);
+  const int cam = p.CT[size_t(T) * 64 + lane], row = p.RT[size_t(T) * 64 + lane];
+  BsTileData<S> d;
+  bs_tile_load(p, it, T, cam, row, lane, x, d);
+  switch (hx_tile_class(it, T)) {
+    case 0: bs_tile_compute<S, 4>(p, d, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], cam, lane); break;
+    case 1: bs_tile_compute<S, 8>(p, d, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], cam, lane); break;
+    case 2: bs_tile_compute<S, 16>(p, d, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], cam, lane); break;
+    case 3: bs_tile_compute<S, 32>(p, d, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], cam, lane); break;
+    default: bs_tile_compute<S, 64>(p, d, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], cam, lane); break;
+  }
 }
 
 // deterministic sum of the per-landmark model cost changes

@@ -237,13 +237,7 @@ __global__ __launch_bounds__(256) void k_bs_landmark_big(Params<S> p, int lm_beg
     }
   }
   big_block_sum3(acc, z1, z2, sm);
-  if (tid == 0) {
-    p.lm_ldiff[s] = -double(acc);
-    const bool fin = is_finite(inc[0]) && is_finite(inc[1]) && is_finite(inc[2]) && is_finite(acc) &&
-                     is_finite(p.lms[3 * s]) && is_finite(p.lms[3 * s + 1]) && is_finite(p.lms[3 * s + 2]);
-    if (!fin) atomicOr(p.fail_flag, 2);
-    apply_landmark_increment(p, s, inc);
-  }
+  if (tid == 0) finish_landmark(p, s, inc, acc);
 }
 
 // H*x from the factors for one long track (same operator as hx_implicit_tile): u = Jp x per row in the

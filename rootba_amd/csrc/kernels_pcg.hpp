@@ -314,7 +314,11 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
                                                      const int* __restrict__ extra_ptr, int n_items, int n_cams,
                                                      CgState* st, const double* __restrict__ part_pq,
                                                      double* __restrict__ part_rho, double* __restrict__ part_q,
-                                                     int phase, int period, int* host_progress) {
+                                                     int phase, int period, int* host_progress, int mf, S lambda_mf,
+                                                     S* __restrict__ zero_me) {
+  // `mf`: the product came from the matrix-free operator (k_hx_implicit*: `qmain` = sum_l A_l^T A_l v without the pose
+  // damping, no item partials): p.q is summed here, by every workgroup alike, over the whole vectors, and lambda_mf v is
+  // added where the product is used. `zero_me`: the accumulator of the refresh product, cleared on refresh iterations.
   __shared__ double sm[4][2];
   __shared__ S rl[252];
   const int tid = threadIdx.x;
@@ -322,7 +326,20 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
   const int n_tiles = (n_cams + 27) / 28;
   // ---- loads first --------------------------------------------------------------------------
   double accp = 0;
-  if (phase == 0) {
+  if (phase == 0 && mf) {
+    const int n = 9 * n_cams;
+    const S* __restrict__ pv = ((st->cur + st->pswap) & 1) ? pbuf1 : pbuf0;
+    for (int base = 0; base < n; base += 2048) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid, ic = min(idx, n - 1);
+        const S pi = pv[ic], qi = qmain[ic] + lambda_mf * pi;
+        v[u] = idx < n ? double(pi) * double(qi) : 0.0;
+      }
+      accp += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+  } else if (phase == 0) {
     // eight independent loads per thread and batch (a serial strided loop would be eight memory
     // round trips); fixed summation order
     for (int base = 0; base < n_items; base += 2048) {
@@ -353,8 +370,10 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
     po0 = pbuf0[i];
     po1 = pbuf1[i];
     qm = qmain[i];
-    e0 = extra_ptr[c];
-    e1 = extra_ptr[c + 1];
+    if (!mf) {
+      e0 = extra_ptr[c];
+      e1 = extra_ptr[c + 1];
+    }
 #pragma unroll
     for (int j = 0; j < 9; ++j) Mrow[j] = inv[81 * c + 9 * row + j];
   }
@@ -413,21 +432,26 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
         po0 = p[i];
         po1 = po0;
         qm = qmain[i];
-        e0 = extra_ptr[c];
-        e1 = extra_ptr[c + 1];
+        if (!mf) {
+          e0 = extra_ptr[c];
+          e1 = extra_ptr[c + 1];
+        }
 #pragma unroll
         for (int j = 0; j < 9; ++j) Mrow[j] = inv[81 * c + 9 * row + j];
       }
     }
     S xn = S(0), rn = S(0);
     if (act) {
-      const S qv = pcgs_gather_q(qm, qextra, e0, e1, row);
+      const S pi = odd ? po1 : po0;
+      const S qv = mf ? qm + lambda_mf * (phase == 0 ? pi : xo) : pcgs_gather_q(qm, qextra, e0, e1, row);
       if (phase == 0) {
-        xn = xo + a * (odd ? po1 : po0);
+        xn = xo + a * pi;
         x[i] = xn;
         if (!refresh) {
           rn = ro - a * qv;
           r[i] = rn;
+        } else if (zero_me) {
+          zero_me[i] = S(0);
         }
       } else {
         xn = xo;
@@ -463,6 +487,79 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
       st->iter = cur;
       st->need_test = 1;
     }
+  }
+}
+
+// The matrix-free iterations of a solve (before the assembled matrix pays off, or all of them) in the same protocol:
+// this kernel is the prologue of k_pcgs_spmv<0> on its own - Q-model test of the previous iteration, rho, beta, state
+// hand-over, host progress - followed by the direction update p = z + beta p (in place), the pre-scaled operand D p of
+// the product and the cleared accumulator; then k_hx_implicit*, then k_pcgs_update with `mf`. Two vector kernels per
+// iteration instead of the five of round 1 (k_pcg_a1 a2 b1 b2 fin, still used by the power-series preconditioner).
+template <class S>
+__global__ __launch_bounds__(256) void k_pcgs_direction(const S* __restrict__ z, S* __restrict__ pvec, S* __restrict__ q,
+                                                        int n, CgState* st, const double* __restrict__ part_rho,
+                                                        const double* __restrict__ part_q, const S* __restrict__ dscale,
+                                                        S* __restrict__ pscaled, double q_tolerance, int min_it,
+                                                        int max_it, int* host_progress) {
+  const int lane = threadIdx.x & 63;
+  const double prho = part_rho[lane], pq1 = part_q[lane];
+  const int done = st->done, it = st->iter, need_test = st->need_test;
+  const double q_prev = st->q_hist[(it + 1) & 1], rho_prev = st->rho_hist[(it + 1) & 1];
+  const double rho = wave_sum(prho), q1 = wave_sum(pq1);
+  int term = 0, res_it = it, own_stop = 0;
+  double beta = 0.0;
+  if (!done) {
+    if (need_test) {
+      // Q-model test (conjugate_gradient.hpp:239-276); residual-based test is off (r_tolerance = -1)
+      const double zeta = it * (q1 - q_prev) / q1;
+      if (zeta < q_tolerance && it >= min_it) {
+        own_stop = 1;
+        term = 1;
+      } else if (it >= max_it) {
+        own_stop = 1;
+        term = 0;
+      }
+    }
+    if (!own_stop) {
+      if (rho == 0.0 || isinf(rho) || rho != rho) {
+        own_stop = 1;
+        term = 2;  // "Numerical failure. rho / beta"
+        res_it = it + 1;
+      } else if (it > 0) {
+        beta = rho / rho_prev;
+        if (beta == 0.0 || isinf(beta)) {
+          own_stop = 1;
+          term = 2;
+          res_it = it + 1;
+        }
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (done) {
+      if (host_progress) __hip_atomic_store(host_progress + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      if (need_test) st->q_hist[it & 1] = q1;
+      if (own_stop) {
+        st->termination = term;
+        st->result_iter = res_it;
+        st->done = 1;
+        if (host_progress) __hip_atomic_store(host_progress + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        st->rho_hist[it & 1] = rho;
+        st->beta = beta;
+        st->cur = it + 1;
+        if (host_progress) __hip_atomic_store(host_progress, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+  if (done | own_stop) return;
+  const S bs = S(beta);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const S pn = it == 0 ? z[i] : z[i] + bs * pvec[i];
+    pvec[i] = pn;
+    if (pscaled) pscaled[i] = dscale[i] * pn;  // compact stage 2: the operand of the matrix-free product is D p
+    q[i] = S(0);
   }
 }
 

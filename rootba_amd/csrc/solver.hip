@@ -1579,14 +1579,14 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), prm_.b,
                        d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), d_qmain_.get(),
                        d_qpart_.get(), d_item_ptr_.get(), n_items_, n_cams_, st, d_pcgs_pq_.get(), part_rho,
-                       part_q, 0, kPcgPeriod, h_progress_);
+                       part_q, 0, kPcgPeriod, h_progress_, 0, S(0), static_cast<S*>(nullptr));
     if (with_refresh) {
       // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
       launch_pcgs_product(M, d_x_.get(), kPcgPeriod);
       hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), prm_.b,
                          d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), d_qmain_.get(),
                          d_qpart_.get(), d_item_ptr_.get(), n_items_, n_cams_, st, d_pcgs_pq_.get(), part_rho,
-                         part_q, 1, kPcgPeriod, h_progress_);
+                         part_q, 1, kPcgPeriod, h_progress_, 0, S(0), static_cast<S*>(nullptr));
     }
   }
 
@@ -1796,7 +1796,76 @@ class Solver final : public rba_solver {
     const bool fused = n_items_ > 0 && opt_.preconditioner_type != 2;  // block-diagonal preconditioners
     bool go_fused = sc_ && fused;  // explicit Schur-complement backend: the matrix exists from the start
     int it = 1, it_first_assembled = 1;
-    for (; it <= max_it && !go_fused; ++it) {
+    // Block-diagonal preconditioners: the matrix-free iterations run in the protocol of the fused PCG (kernels_pcg.hpp) -
+    // direction kernel (test of the previous iteration, rho, beta, p, D p), product, update kernel (p.q, alpha, x, r,
+    // z = M^-1 r, partials) - and the host follows through the pinned progress words instead of copies of the state.
+    const bool mf_protocol = !sc_ && opt_.preconditioner_type != 2;
+    bool mf_open = false;  // iterations were enqueued whose closing test still lives in the next prologue
+    if (mf_protocol) {
+      volatile int* hp = h_progress_;
+      hp[0] = 0;
+      hp[1] = 0;
+      hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, st, double(lambda), 0);
+      hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(), d_z_.get(), n,
+                         st, part_rho);
+      auto direction = [&]() {
+        const bool pre = !ex_active_;
+        hipLaunchKernelGGL((rba::k_pcgs_direction<S>), dim3(NB), dim3(256), 0, stream_, d_z_.get(), d_p_.get(),
+                           d_q_.get(), n, st, part_rho, part_q1, static_cast<const S*>(pre ? prm_.pose_scaling : nullptr),
+                           pre ? d_xs_.get() : static_cast<S*>(nullptr), eta, min_it, max_it, h_progress_);
+        return pre;
+      };
+      auto update = [&](int phase, const S* product) {
+        hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), b, d_x_.get(),
+                           d_r_.get(), d_z_.get(), d_p_.get(), d_p_.get(), product, static_cast<const S*>(nullptr),
+                           static_cast<const int*>(nullptr), 0, n_cams_, st, static_cast<const double*>(nullptr),
+                           part_rho, part_q1, phase, kPcgPeriod, h_progress_, 1, lambda, d_tmp_.get());
+      };
+      // the device publishes the iteration it has started (hp[0]) or the end of the solve (hp[1])
+      auto started = [&](int k) {
+        long spins = 0;
+        while (!hp[1] && hp[0] < k)
+          if ((++spins & 0x3fff) == 0 && hipStreamQuery(stream_) == hipSuccess) break;
+        return hp[1] == 0;
+      };
+      bool running = true;
+      for (; it <= max_it; ++it) {
+        if (ex_ready_ && !explicit_off_for_solve_ && it > explicit_after_) {
+          if (!ex_valid_) assemble_explicit();
+          ex_active_ = true;
+          pcg_used_explicit_ = true;
+          it_first_assembled = it;
+          if (fused) {
+            go_fused = true;
+            break;
+          }
+        }
+        operand_prescaled_ = direction();
+        // many solves need two or three iterations: the first eight products wait for the verdict of the test that
+        // precedes them, later ones are queued ahead (launches behind the end of the solve are no-ops)
+        if ((it <= 8 || it % 4 == 0) && !(running = started(it))) {
+          operand_prescaled_ = false;
+          break;
+        }
+        launch_hx(d_p_.get(), d_q_.get(), done);
+        operand_prescaled_ = false;
+        if (!ex_active_) all_reduce(d_q_.get(), n);
+        update(0, d_q_.get());
+        if (it % kPcgPeriod == 0) {
+          // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
+          launch_hx(d_x_.get(), d_tmp_.get(), done);
+          if (!ex_active_) all_reduce(d_tmp_.get(), n);
+          update(1, d_tmp_.get());
+        }
+        mf_open = true;
+      }
+      if (!go_fused) {
+        if (running && mf_open) direction();  // the test of the last iteration
+        HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
+        sync();
+      }
+    }
+    for (; !mf_protocol && it <= max_it && !go_fused; ++it) {
       // Long solve: from here on the product is an SpMV with the explicitly assembled
       // S = sum_l A_l^T A_l (one assembly ~ 16 matrix-free products on venice; S is all-reduced
       // once, after which the iterations need no collective at all)
@@ -2329,7 +2398,7 @@ class Solver final : public rba_solver {
   }
 
  private:
-  static constexpr int kReduceBlocks = 1024;
+  static constexpr int kReduceBlocks = 2048;  // = the wave slots of the chip at 256 threads x 8 waves per SIMD
   static constexpr size_t kSmallLdsBudget = 16 * 1024;
   static constexpr int kSmallBatchesPerBlock = 8;  // LDS batches walked by one workgroup  // bytes of A per small-landmark batch
   static constexpr int kMaxHxEvents = 1024;

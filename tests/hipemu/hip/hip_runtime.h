@@ -166,6 +166,7 @@ hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventQuery(hipEvent_t e);
+hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void* f, int block, size_t lds);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
 hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);
