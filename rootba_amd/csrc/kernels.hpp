@@ -125,9 +125,13 @@ template <class S>
 __global__ __launch_bounds__(256) void k_compute_error(Params<S> p, int64_t n_obs,
                                                        double* __restrict__ partials) {
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int64_t o = blockIdx.x * 256ll + threadIdx.x; o < n_obs; o += gridDim.x * 256ll) {
-    const int cam = p.obs_cam[o];
-    const int l = p.obs_lm[o];
+  // (the two indices of the work-item's NEXT observation are requested before the current one is gathered: one memory
+  //  round trip per observation instead of two dependent ones)
+  const int64_t stride = gridDim.x * 256ll, o0 = blockIdx.x * 256ll + threadIdx.x;
+  int cam = p.obs_cam[min(o0, n_obs - 1)], l = p.obs_lm[min(o0, n_obs - 1)];
+  for (int64_t o = o0; o < n_obs; o += stride) {
+    const int64_t on = min(o + stride, n_obs - 1);
+    const int cam_next = p.obs_cam[on], l_next = p.obs_lm[on];
     S rx, ry;
     const bool valid = project_residual<S>(p.cams + 10 * cam, p.lms[3 * l], p.lms[3 * l + 1],
                                            p.lms[3 * l + 2], p.obs_xy[2 * o], p.obs_xy[2 * o + 1],
@@ -145,6 +149,8 @@ __global__ __launch_bounds__(256) void k_compute_error(Params<S> p, int64_t n_ob
       acc[5] += rn;
     }
     if (!(is_finite(rx) && is_finite(ry))) acc[6] += 1.0;
+    cam = cam_next;
+    l = l_next;
   }
   __shared__ double sm[4][7];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

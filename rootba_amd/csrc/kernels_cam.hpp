@@ -62,24 +62,40 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<float> p, float la
   const int g = lane / 9, a = lane - 9 * g;
   double accb = 0, accd = 0;
   float* lds = stage[wave];
+  // (the observation indices of the wave's next chunk are requested before the current one is processed; clamped, not
+  //  predicated: every lane holds a valid observation of this camera)
+  int idxreg = t1 > t0 ? p.cam_obs[min<int64_t>(t0 + CH * wave + lane, t1 - 1)] : 0;
   for (int64_t base = t0 + CH * wave; base < t1; base += 4 * CH) {
     const int cnt = int(min<int64_t>(CH, t1 - base));
-    const int idxreg = lane < cnt ? p.cam_obs[base + lane] : 0;
+    const int idxnext = p.cam_obs[min<int64_t>(base + 4 * CH + lane, t1 - 1)];
     // Jacobian rows: nine 8-byte pieces per record; WA: two 16-byte pieces (kept at 8-byte granularity in LDS:
-    // the 26-float record stride is not a multiple of 16 bytes)
+    // the 26-float record stride is not a multiple of 16 bytes). Every load of the chunk is issued before the first
+    // LDS store and none is conditional (lanes past the chunk re-read one of its first records: `idxreg` is a valid
+    // observation in every lane) - a load inside `if (q < ...)` is a basic block of its own that waits for its data
+    // before the next one is issued: seven memory round trips per chunk instead of two.
+    constexpr int NJ = (CH * 9 + 63) / 64;
+    float2 jv[NJ];
 #pragma unroll
-    for (int j = 0; j < (CH * 9 + 63) / 64; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int q = j * 64 + lane;
       const int r = q / 9, pc = q - 9 * r;
       const int o = __shfl(idxreg, r & 31);
-      if (q < cnt * 9)
-        *reinterpret_cast<float2*>(lds + r * RW + 2 * pc) = *reinterpret_cast<const float2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
+      jv[j] = *reinterpret_cast<const float2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
+    }
+    float4 w = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0) {
+      const int o = __shfl(idxreg, (lane >> 1) & 31);
+      w = *reinterpret_cast<const float4*>(p.WA + int64_t(o) * kRecW + 4 * (lane & 1));
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int q = j * 64 + lane;
+      const int r = q / 9, pc = q - 9 * r;
+      if (q < cnt * 9) *reinterpret_cast<float2*>(lds + r * RW + 2 * pc) = jv[j];
     }
     if (MODE == 0) {
       const int r = lane >> 1, h = lane & 1;
-      const int o = __shfl(idxreg, r & 31);
       if (r < cnt) {
-        const float4 w = *reinterpret_cast<const float4*>(p.WA + int64_t(o) * kRecW + 4 * h);
         float* d = lds + r * RW + 18 + 4 * h;
         *reinterpret_cast<float2*>(d) = float2{w.x, w.y};
         *reinterpret_cast<float2*>(d + 2) = float2{w.z, w.w};
@@ -119,6 +135,7 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<float> p, float la
         if (want_d) accd += double(fmaf(rec[a], rec[a], __fmul_rn(rec[9 + a], rec[9 + a])));
       }
     wave_lds_fence();  // the next chunk overwrites the staging buffer
+    idxreg = idxnext;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) accK[r] += accK2[r];

@@ -333,9 +333,11 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
       double v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
+        // (clamped and masked, not selected: a value that is only used under `idx < n` gets its load sunk into a
+        //  conditional block, and the sixteen loads of a batch become sixteen waits)
         const int idx = base + u * 256 + tid, ic = min(idx, n - 1);
         const S pi = pv[ic], qi = qmain[ic] + lambda_mf * pi;
-        v[u] = idx < n ? double(pi) * double(qi) : 0.0;
+        v[u] = double(pi) * double(qi) * (idx < n ? 1.0 : 0.0);
       }
       accp += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }

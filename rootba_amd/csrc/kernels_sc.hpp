@@ -631,15 +631,19 @@ __global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const float* __restrict
   const int rec = lane >> 3, vec = lane & 7;
   const int* __restrict__ pair_side = rec < 4 ? pair_oi : pair_oj;
   for (int64_t q = q0 + wave * (4 * U); q < q1; q += 16 * U) {
+    // (clamped, not predicated: the U index loads go out together, then the U record loads - a load inside a
+    //  conditional is a basic block of its own that waits for its operand and for everything issued before it)
     float4 v[U];
+    int o[U];
+#pragma unroll
+    for (int uq = 0; uq < U; ++uq) o[uq] = pair_side[min(q + 4 * uq + (rec & 3), q1 - 1)];
+#pragma unroll
+    for (int uq = 0; uq < U; ++uq) v[uq] = reinterpret_cast<const float4*>(topd + kTd * int64_t(o[uq]))[vec];
 #pragma unroll
     for (int uq = 0; uq < U; ++uq) {
-      const int64_t qq = q + 4 * uq + (rec & 3);
-      const int o = qq < q1 ? pair_side[qq] : -1;
-      v[uq] = o >= 0 ? reinterpret_cast<const float4*>(topd + kTd * int64_t(o))[vec] : float4{0.f, 0.f, 0.f, 0.f};
+      const bool ok = q + 4 * uq + (rec & 3) < q1;
+      *reinterpret_cast<float4*>(&stage[wave][uq][rec][4 * vec]) = ok ? v[uq] : float4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int uq = 0; uq < U; ++uq) *reinterpret_cast<float4*>(&stage[wave][uq][rec][4 * vec]) = v[uq];
     wave_lds_fence();
 #pragma unroll
     for (int uq = 0; uq < U; ++uq)
