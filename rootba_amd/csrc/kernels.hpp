@@ -1582,6 +1582,35 @@ __global__ void k_negate(S* __restrict__ v, int n) {
   if (i < n) v[i] = -v[i];
 }
 
+// End of a solve inside the LM loop (rba_lm_step): x = -x stays on the device - a copy goes to the buffer the
+// back-substitution reads - and the host gets what it needs to judge the step, |x|^2 and the number of non-finite
+// entries, in its pinned page instead of the vector itself (single workgroup).
+template <class S>
+__global__ __launch_bounds__(1024) void k_finish_increment(S* __restrict__ x, S* __restrict__ inc, int n,
+                                                          double* __restrict__ out_host) {
+  __shared__ double sm[16][2];
+  double acc = 0, bad = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const S v = -x[i];
+    x[i] = v;
+    inc[i] = v;
+    acc += double(v) * double(v);
+    bad += is_finite(v) ? 0.0 : 1.0;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double t0 = wave_sum(acc), t1 = wave_sum(bad);
+  if (lane == 0) {
+    sm[wave][0] = t0;
+    sm[wave][1] = t1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double v = 0;
+    for (int w = 0; w < 16; ++w) v += sm[w][threadIdx.x];
+    out_host[threadIdx.x] = v;
+  }
+}
+
 template <class S>
 __global__ void k_axpy_lambda(const S* __restrict__ x, S* __restrict__ y, S lambda, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

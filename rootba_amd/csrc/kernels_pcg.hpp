@@ -565,6 +565,87 @@ __global__ __launch_bounds__(256) void k_pcgs_direction(const S* __restrict__ z,
   }
 }
 
+// Start of a solve in one kernel (round 1: k_pcg_init, k_pcgs_begin, k_pcg_a1): x = 0, r = b, z = M^-1 b with the
+// partials of rho = r.z (28 cameras per 252-thread tile, as in k_pcgs_update), and the reset state - |b|^2 is summed by
+// every workgroup alike, workgroup 0 writes the state.
+template <class S>
+__global__ __launch_bounds__(256) void k_pcgs_start(const S* __restrict__ inv, const S* __restrict__ bvec,
+                                                    S* __restrict__ x, S* __restrict__ r, S* __restrict__ z, int n_cams,
+                                                    CgState* st, double* __restrict__ part_rho, double lambda,
+                                                    int pswap) {
+  __shared__ double sm[4];
+  __shared__ S rl[252];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = 9 * n_cams, n_tiles = (n_cams + 27) / 28;
+  double accb = 0;
+  if (blockIdx.x == 0) {
+    for (int base = 0; base < n; base += 2048) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        const S bi = bvec[min(idx, n - 1)];
+        v[u] = double(bi) * double(bi) * (idx < n ? 1.0 : 0.0);
+      }
+      accb += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+  }
+  double acc_rho = 0;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int i = 252 * tile + tid;
+    const bool act = tid < 252 && i < n;
+    const int c = act ? i / 9 : 0, row = act ? i - 9 * c : 0;
+    S bi = S(0), Mrow[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) Mrow[j] = S(0);
+    if (act) {
+      bi = bvec[i];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) Mrow[j] = inv[81 * c + 9 * row + j];
+      x[i] = S(0);
+      r[i] = bi;
+    }
+    __syncthreads();
+    if (tid < 252) rl[tid] = bi;
+    __syncthreads();
+    if (act) {
+      const S* rc = rl + 9 * (tid / 9);
+      S zc = S(0);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) zc += Mrow[j] * rc[j];
+      z[i] = zc;
+      acc_rho += double(bi) * double(zc);
+    }
+  }
+  const double t0 = wave_sum(acc_rho), t1 = wave_sum(accb);
+  __syncthreads();
+  if (lane == 0) sm[wave] = t0;
+  __syncthreads();
+  if (tid == 0) part_rho[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  if (blockIdx.x != 0) return;
+  __syncthreads();
+  if (lane == 0) sm[wave] = t1;
+  __syncthreads();
+  if (tid == 0) {
+    const double nb2 = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    st->rho_hist[0] = st->rho_hist[1] = 1.0;
+    st->pq = 0;
+    st->q_hist[0] = st->q_hist[1] = 0;  // -x.(b + r) with x = 0
+    st->norm_b2 = nb2;
+    st->alpha = st->beta = 0;
+    st->iter = 0;
+    st->cur = 0;
+    st->need_test = 0;
+    st->result_iter = 0;
+    st->indefinite = 0;
+    st->refresh = 0;
+    st->termination = nb2 == 0.0 ? 1 : 0;  // "Convergence. |b| = 0."
+    st->done = nb2 == 0.0 ? 1 : 0;
+    st->lambda = lambda;
+    st->pswap = pswap;
+  }
+}
+
 // per-solve parameters (see CgState)
 __global__ void k_pcgs_begin(CgState* st, double lambda, int pswap) {
   st->lambda = lambda;

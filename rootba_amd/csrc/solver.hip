@@ -1726,9 +1726,15 @@ class Solver final : public rba_solver {
       cg = pcg(lambda);
       explicit_off_for_solve_ = false;
     }
-    hipLaunchKernelGGL((rba::k_negate<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
-                       d_x_.get(), nvec_);
-    d_x_.download(static_cast<S*>(inc_out), nvec_, stream_);
+    if (inc_out) {
+      hipLaunchKernelGGL((rba::k_negate<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
+                         d_x_.get(), nvec_);
+      d_x_.download(static_cast<S*>(inc_out), nvec_, stream_);
+    } else {
+      // rba_lm_step: the increment stays on the device (apply(nullptr) reads d_inc_), the host gets its norm
+      hipLaunchKernelGGL((rba::k_finish_increment<S>), dim3(1), dim3(1024), 0, stream_, d_x_.get(), d_inc_.get(),
+                         nvec_, pinned_doubles(kPinInc));
+    }
     time_end(&timings_.solve_reduced_system_time);
     if (lm_async_) {  // the caller reads the increment, and the product timers below need their events completed
       sync();
@@ -1786,8 +1792,12 @@ class Solver final : public rba_solver {
     const int max_it = opt_.max_cg_it, min_it = opt_.min_cg_it;
     const double eta = opt_.eta;
     rba::CgState* hst = reinterpret_cast<rba::CgState*>(h_pinned_);
-    hipLaunchKernelGGL((rba::k_pcg_init<S>), dim3(1), dim3(1024), 0, stream_, b, d_x_.get(),
-                       d_r_.get(), n, st);
+    const bool mf_protocol = !sc_ && opt_.preconditioner_type != 2;
+    if (mf_protocol)
+      hipLaunchKernelGGL((rba::k_pcgs_start<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), b, d_x_.get(),
+                         d_r_.get(), d_z_.get(), n_cams_, st, part_rho, double(lambda), 0);
+    else
+      hipLaunchKernelGGL((rba::k_pcg_init<S>), dim3(1), dim3(1024), 0, stream_, b, d_x_.get(), d_r_.get(), n, st);
     // The host polls the device state lazily: every iteration at first (many
     // solves need 2-3 iterations), every 4th later; kernels queued past the end
     // are no-ops (`done`).
@@ -1799,15 +1809,11 @@ class Solver final : public rba_solver {
     // Block-diagonal preconditioners: the matrix-free iterations run in the protocol of the fused PCG (kernels_pcg.hpp) -
     // direction kernel (test of the previous iteration, rho, beta, p, D p), product, update kernel (p.q, alpha, x, r,
     // z = M^-1 r, partials) - and the host follows through the pinned progress words instead of copies of the state.
-    const bool mf_protocol = !sc_ && opt_.preconditioner_type != 2;
     bool mf_open = false;  // iterations were enqueued whose closing test still lives in the next prologue
     if (mf_protocol) {
       volatile int* hp = h_progress_;
       hp[0] = 0;
       hp[1] = 0;
-      hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, st, double(lambda), 0);
-      hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(), d_z_.get(), n,
-                         st, part_rho);
       auto direction = [&]() {
         const bool pre = !ex_active_;
         hipLaunchKernelGGL((rba::k_pcgs_direction<S>), dim3(NB), dim3(256), 0, stream_, d_z_.get(), d_p_.get(),
@@ -1841,9 +1847,10 @@ class Solver final : public rba_solver {
           }
         }
         operand_prescaled_ = direction();
-        // many solves need two or three iterations: the first eight products wait for the verdict of the test that
-        // precedes them, later ones are queued ahead (launches behind the end of the solve are no-ops)
-        if ((it <= 8 || it % 4 == 0) && !(running = started(it))) {
+        // many solves need two or three iterations: products 3 to 8 wait for the verdict of the test that precedes
+        // them, later ones are queued ahead (launches behind the end of the solve are no-ops). The first two never
+        // wait: the Q-model test cannot end a solve after one iteration (zeta = 1 * (Q_1 - 0) / Q_1 = 1 > eta).
+        if (it >= 3 && (it <= 8 || it % 4 == 0) && !(running = started(it))) {
           operand_prescaled_ = false;
           break;
         }
@@ -1986,7 +1993,7 @@ class Solver final : public rba_solver {
     use_device();
     if (!landmark_damping_valid_) run_stage2(S(0));
     time_begin();
-    d_inc_.upload(static_cast<const S*>(inc), nvec_, stream_);
+    if (inc) d_inc_.upload(static_cast<const S*>(inc), nvec_, stream_);  // (nullptr: left there by the solve of rba_lm_step)
     if (sc_) {
       hipLaunchKernelGGL((rba::k_sc_back_substitute<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_,
                          scp_, d_inc_.get());
@@ -2166,8 +2173,9 @@ class Solver final : public rba_solver {
     const rba_residual_info& ri = lm_.ri;
     row.lambda = lm_.lambda;
     rba_cg_summary cg{};
-    lm_inc_.resize(nvec_);
-    solve(lm_.lambda, lm_inc_.data(), &cg);  // (ends with a synchronisation: the increment is on the host)
+    // (the increment itself stays on the device; the solve ends with a synchronisation, after which its squared norm
+    //  and the number of non-finite entries are in the pinned page)
+    solve(lm_.lambda, nullptr, &cg);
     if (!cost_is_valid() || (linearized && (*pinned_int(kPinFailLin) & 1))) {
       // non-finite residuals / Jacobians at this state (detected by the cost evaluation or the linearisation that
       // were queued ahead of the solve): numerical failure, as where the reference returns an empty vector
@@ -2178,12 +2186,8 @@ class Solver final : public rba_solver {
     }
     row.cg_iterations = cg.num_iterations;
     row.cg_termination = cg.termination_type;
-    double nrm = 0;
-    bool finite = true;
-    for (S v : lm_inc_) {
-      nrm += double(v) * double(v);
-      finite = finite && std::isfinite(v);
-    }
+    const double nrm = pinned_doubles(kPinInc)[0];
+    const bool finite = pinned_doubles(kPinInc)[1] == 0.0;
     row.inc_norm = std::sqrt(nrm);
     if (!finite) {
       // non-finite increment: reject, increase damping (:360-399)
@@ -2196,7 +2200,7 @@ class Solver final : public rba_solver {
     }
     backup();
     double l_diff_d = 0;
-    apply(lm_inc_.data(), &l_diff_d, true);
+    apply(nullptr, &l_diff_d, true);
     rba_residual_info ri2{};
     compute_error_enqueue(pinned_doubles(kPinCe1));
     sync();
@@ -2406,7 +2410,7 @@ class Solver final : public rba_solver {
   void use_device() { HIP_CHECK(hipSetDevice(device_)); }
   // result slots in the pinned page h_pinned_ (the PCG state copy lives at offset 0)
   static constexpr size_t kPinCe0 = 1024, kPinCe1 = 1024 + 64, kPinLdiff = 1024 + 128, kPinFailLin = 1024 + 136,
-                          kPinFailApply = 1024 + 140, kPinCheck = 1024 + 192;
+                          kPinFailApply = 1024 + 140, kPinCheck = 1024 + 192, kPinInc = 1024 + 256;
   double* pinned_doubles(size_t off) { return reinterpret_cast<double*>(h_pinned_ + off); }
   int* pinned_int(size_t off) { return reinterpret_cast<int*>(h_pinned_ + off); }
   void sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
@@ -2633,7 +2637,6 @@ class Solver final : public rba_solver {
     rba_residual_info ri{};
   };
   LmState lm_;
-  std::vector<S> lm_inc_;
   // multi-GPU
   void* comm_ = nullptr;
   int rank_ = 0, nranks_ = 1;
@@ -2864,7 +2867,10 @@ int rba_linearize(rba_handle h, void* jp_diag2_out) {
   return guarded([&]() -> int { return h->linearize(jp_diag2_out); });
 }
 int rba_solve(rba_handle h, double lambda, void* inc_out, rba_cg_summary* cg) {
-  return guarded([&]() -> int { return h->solve(lambda, inc_out, cg); });
+  return guarded([&]() -> int {
+    if (!inc_out) throw HipError{"rba_solve: inc_out is NULL", RBA_ERR_INVALID_ARGUMENT};
+    return h->solve(lambda, inc_out, cg);
+  });
 }
 int rba_stage2(rba_handle h, double lambda, void* b_out, void* blocks_out) {
   return guarded([&]() -> int { return h->stage2(lambda, b_out, blocks_out); });
@@ -2883,10 +2889,16 @@ int rba_right_multiply_explicit(rba_handle h, const void* x, void* y) {
   });
 }
 int rba_apply(rba_handle h, const void* inc, double* l_diff_out) {
-  return guarded([&]() -> int { return h->apply(inc, l_diff_out, true); });
+  return guarded([&]() -> int {
+    if (!inc) throw HipError{"rba_apply: inc is NULL", RBA_ERR_INVALID_ARGUMENT};
+    return h->apply(inc, l_diff_out, true);
+  });
 }
 int rba_back_substitute(rba_handle h, const void* inc, double* l_diff_out) {
-  return guarded([&]() -> int { return h->apply(inc, l_diff_out, false); });
+  return guarded([&]() -> int {
+    if (!inc) throw HipError{"rba_back_substitute: inc is NULL", RBA_ERR_INVALID_ARGUMENT};
+    return h->apply(inc, l_diff_out, false);
+  });
 }
 int rba_optimize_lm(rba_handle h, rba_lm_iteration* log, int max_rows, int* n_rows_out,
                     int* termination_out) {
