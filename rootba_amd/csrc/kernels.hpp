@@ -1587,8 +1587,14 @@ __global__ void k_negate(S* __restrict__ v, int n) {
 // entries, in its pinned page instead of the vector itself (single workgroup).
 template <class S>
 __global__ __launch_bounds__(1024) void k_finish_increment(S* __restrict__ x, S* __restrict__ inc, int n,
-                                                          double* __restrict__ out_host) {
+                                                          double* __restrict__ out_host, const CgState* st,
+                                                          CgState* st_host) {
   __shared__ double sm[16][2];
+  if (st_host) {  // the final PCG state, if the host has not read it yet
+    constexpr int kWords = int(sizeof(CgState) / sizeof(int));
+    static_assert(kWords <= 64 && sizeof(CgState) % sizeof(int) == 0, "copied as words by one wave");
+    if (threadIdx.x < kWords) reinterpret_cast<int*>(st_host)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
+  }
   double acc = 0, bad = 0;
   for (int i = threadIdx.x; i < n; i += 1024) {
     const S v = -x[i];

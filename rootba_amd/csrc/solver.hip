@@ -1731,14 +1731,31 @@ class Solver final : public rba_solver {
                          d_x_.get(), nvec_);
       d_x_.download(static_cast<S*>(inc_out), nvec_, stream_);
     } else {
-      // rba_lm_step: the increment stays on the device (apply(nullptr) reads d_inc_), the host gets its norm
+      // rba_lm_step: the increment stays on the device (apply(nullptr) reads d_inc_), the host gets its norm - and,
+      // when nobody has read it yet, the final PCG state
       hipLaunchKernelGGL((rba::k_finish_increment<S>), dim3(1), dim3(1024), 0, stream_, d_x_.get(), d_inc_.get(),
-                         nvec_, pinned_doubles(kPinInc));
+                         nvec_, pinned_doubles(kPinInc), static_cast<const rba::CgState*>(d_cg_.get()),
+                         pcg_state_pending_ ? reinterpret_cast<rba::CgState*>(h_pinned_)
+                                            : static_cast<rba::CgState*>(nullptr));
     }
     time_end(&timings_.solve_reduced_system_time);
+    solve_cg_ = cg;
+    if (solve_defer_) return RBA_OK;  // rba_lm_step calls solve_collect() after its synchronisation
     if (lm_async_) {  // the caller reads the increment, and the product timers below need their events completed
       sync();
       flush_timers();
+    }
+    solve_collect(cg_out);
+    return RBA_OK;
+  }
+
+  // What a solve leaves for the host once its kernels have completed: the PCG summary (if the state was not read
+  // inside), the product timers and, once, the break-even of the operator switch.
+  void solve_collect(rba_cg_summary* cg_out) {
+    rba_cg_summary cg = solve_cg_;
+    if (pcg_state_pending_) {
+      pcg_collect(&cg, pcg_it_first_assembled_);
+      pcg_state_pending_ = false;
     }
     // H*x launches that did real work: one per PCG iteration plus the residual
     // refreshes; launches queued after termination are no-ops and are excluded
@@ -1776,7 +1793,6 @@ class Solver final : public rba_solver {
       asm_measured_ = true;
     }
     if (cg_out) *cg_out = cg;
-    return RBA_OK;
   }
 
   rba_cg_summary pcg(S lambda) {
@@ -1868,6 +1884,13 @@ class Solver final : public rba_solver {
       }
       if (!go_fused) {
         if (running && mf_open) direction();  // the test of the last iteration
+        if (solve_defer_) {
+          // rba_lm_step: the state travels with the end of the solve (k_finish_increment) and is read at the
+          // iteration's one synchronisation (solve_collect)
+          pcg_state_pending_ = true;
+          pcg_it_first_assembled_ = it_first_assembled;
+          return summary;
+        }
         HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
         sync();
       }
@@ -1970,6 +1993,14 @@ class Solver final : public rba_solver {
       sync();
     }
     ex_active_ = false;
+    pcg_collect(&summary, it_first_assembled);
+    return summary;
+  }
+
+  // summary and counters of a finished PCG from the copy of its state in the pinned page
+  void pcg_collect(rba_cg_summary* out, int it_first_assembled) {
+    const rba::CgState* hst = reinterpret_cast<const rba::CgState*>(h_pinned_);
+    rba_cg_summary summary{0, 0};
     summary.termination_type = hst->termination;
     summary.num_iterations = hst->result_iter;
     pcg_indefinite_ = hst->indefinite != 0;
@@ -1985,7 +2016,7 @@ class Solver final : public rba_solver {
       pcg_counters_.products_assembled += as_it > 0 ? as_it + (n_it / 10 - mf_it / 10) + (it_switch > 1 ? 1 : 0) + series * as_it
                                                     : 0;
     }
-    return summary;
+    *out = summary;
   }
 
   // ---- apply ------------------------------------------------------------------------
@@ -2173,12 +2204,30 @@ class Solver final : public rba_solver {
     const rba_residual_info& ri = lm_.ri;
     row.lambda = lm_.lambda;
     rba_cg_summary cg{};
-    // (the increment itself stays on the device; the solve ends with a synchronisation, after which its squared norm
-    //  and the number of non-finite entries are in the pinned page)
+    // The increment stays on the device, and inside this loop nothing about the solve is needed on the host before the
+    // trial point has been evaluated: the back-substitution and the cost evaluation are queued right behind the solve
+    // and ONE synchronisation delivers the PCG summary, the increment's norm and non-finite count, l_diff and the
+    // costs. The two outcomes that used to stop short of the back-substitution - a non-finite state / Jacobian, a
+    // non-finite increment - undo it from the backup instead.
+    const bool one_sync = lm_async_;
+    solve_defer_ = one_sync;
     solve(lm_.lambda, nullptr, &cg);
+    solve_defer_ = false;
+    double l_diff_d = 0;
+    bool applied = false;
+    if (one_sync) {
+      backup();
+      apply(nullptr, &l_diff_d, true);
+      compute_error_enqueue(pinned_doubles(kPinCe1));
+      sync();
+      flush_timers();
+      solve_collect(&cg);
+      applied = true;
+    }
     if (!cost_is_valid() || (linearized && (*pinned_int(kPinFailLin) & 1))) {
       // non-finite residuals / Jacobians at this state (detected by the cost evaluation or the linearisation that
       // were queued ahead of the solve): numerical failure, as where the reference returns an empty vector
+      if (applied) restore();
       lm_.terminated = true;
       lm_.termination = -1;
       lm_.need_linearize = true;
@@ -2191,6 +2240,7 @@ class Solver final : public rba_solver {
     row.inc_norm = std::sqrt(nrm);
     if (!finite) {
       // non-finite increment: reject, increase damping (:360-399)
+      if (applied) restore();
       lm_.lambda = lm_.lambda_vee * lm_.lambda;
       lm_.lambda_vee *= S(opt_.vee_factor);
       lm_.prev_all = lm_.prev_valid = 0;  // the reference leaves it_summary.cost zeroed here
@@ -2198,13 +2248,14 @@ class Solver final : public rba_solver {
       if (lm_.lambda > max_lambda) lm_.terminated = true;
       return finish(true);
     }
-    backup();
-    double l_diff_d = 0;
-    apply(nullptr, &l_diff_d, true);
     rba_residual_info ri2{};
-    compute_error_enqueue(pinned_doubles(kPinCe1));
-    sync();
-    flush_timers();
+    if (!applied) {
+      backup();
+      apply(nullptr, &l_diff_d, true);
+      compute_error_enqueue(pinned_doubles(kPinCe1));
+      sync();
+      flush_timers();
+    }
     if (lm_async_) apply_outcome(&l_diff_d);
     compute_error_parse(pinned_doubles(kPinCe1), &ri2);
     S l_diff = S(l_diff_d);
@@ -2593,6 +2644,10 @@ class Solver final : public rba_solver {
   double hx_coverage_ = 1.0;  // share of the tiled block rows whose camera lies inside its workgroup's LDS window
   static constexpr size_t kHxLdsMaxBytes = 152 * 1024;  // of the CU's 160 KB
   int n_cus_ = 256;
+  bool solve_defer_ = false;         // rba_lm_step: solve() leaves its host-side collection to solve_collect()
+  bool pcg_state_pending_ = false;   // the PCG ended without a host copy of its state (k_finish_increment carries it)
+  int pcg_it_first_assembled_ = 1;
+  rba_cg_summary solve_cg_{0, 0};
   // explicit reduced matrix of the square-root solver (adaptive, see pcg())
   int explicit_after_ = 0;  // matrix-free products before a solve switches to S x; 0 = never
   bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;
