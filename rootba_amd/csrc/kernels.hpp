@@ -228,6 +228,36 @@ __device__ __forceinline__ double block_sum_256(double v, double* sm4) {
 
 // f32 accumulator tile of v_mfma_f32_16x16x4_f32: lane l holds D[(l >> 4) * 4 + r][l & 15], r = 0..3
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// The 16x16x4 matrix-core instruction of either precision (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64): lane l
+// supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; the four accumulator registers of a lane hold column l & 15 of the
+// rows row(l, r) - (l >> 4) * 4 + r in float, (l >> 4) + 4 r in double (scripts/microbench/mfma_f64_layout.hip, run on
+// gfx950).
+template <class S>
+struct Mfma;
+template <>
+struct Mfma<float> {
+  using acc = f32x4;
+  using V2 = float2;
+  using V4 = float4;
+  static __device__ __forceinline__ acc mma(float a, float b, acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+  static __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+};
+template <>
+struct Mfma<double> {
+  using acc = f64x4;
+  using V2 = double2;
+  using V4 = double4;
+  static __device__ __forceinline__ acc mma(double a, double b, acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+  static __device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+};
 
 // Camera-major workgroups are launched as 8 * ceil(n_cams / 8) blocks and mapped so that one XCD
 // (block b runs on XCD b % 8, each with its own L2) walks a CONTIGUOUS range of cameras: the records

@@ -42,14 +42,18 @@ constexpr int kRecA = 2;     // offset of A
 //         here too (and B_mid = D G D when the preconditioner needs it), from the same staged records.
 // MODE 1: stage-1 Gram pass on its own (sharded runs: Jp_diag2 is all-reduced before D exists; callers that read
 //         Jp_diag2 right after rba_linearize): Jp_diag2 and the UNSCALED G into B_mid (k_scale_gram scales it).
-template <int MODE>
-__global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<float> p, float lambda, int GRAM) {
+template <class S, int MODE>
+__global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<S> p, S lambda, int GRAM) {
+  using M = Mfma<S>;
+  using V2 = typename M::V2;
+  using V4 = typename M::V4;
+  using Acc = typename M::acc;
   constexpr int CH = kCamChunk, RW = 26;  // staged record: [Jp 18 | g 2 | A 4 | (2 unused)]
-  __shared__ __attribute__((aligned(16))) float stage[4][CH * RW + 6];
-  __shared__ float tile[4][16][16];
+  __shared__ __attribute__((aligned(16))) S stage[4][CH * RW + 6];
+  __shared__ S tile[4][16][16];
   __shared__ double bsum[4][7][9];
   __shared__ double dsum[4][7][9];
-  __shared__ float dsc[9];
+  __shared__ S dsc[9];
   const int c = xcd_swizzled_camera(p.n_cams);
   if (c >= p.n_cams) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -57,48 +61,48 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<float> p, float la
   const bool want_K = MODE == 0 && (!p.jacobi || p.want_sdiag);
   const bool want_G = MODE == 1 || (GRAM && p.jacobi);
   const bool want_d = MODE == 1 || GRAM;
-  f32x4 accK = {0.f, 0.f, 0.f, 0.f}, accK2 = {0.f, 0.f, 0.f, 0.f}, accG = {0.f, 0.f, 0.f, 0.f};
+  Acc accK = {0, 0, 0, 0}, accK2 = {0, 0, 0, 0}, accG = {0, 0, 0, 0};
   const int i = lane & 15, kk = lane >> 4;
   const int g = lane / 9, a = lane - 9 * g;
   double accb = 0, accd = 0;
-  float* lds = stage[wave];
+  S* lds = stage[wave];
   // (the observation indices of the wave's next chunk are requested before the current one is processed; clamped, not
   //  predicated: every lane holds a valid observation of this camera)
   int idxreg = t1 > t0 ? p.cam_obs[min<int64_t>(t0 + CH * wave + lane, t1 - 1)] : 0;
   for (int64_t base = t0 + CH * wave; base < t1; base += 4 * CH) {
     const int cnt = int(min<int64_t>(CH, t1 - base));
     const int idxnext = p.cam_obs[min<int64_t>(base + 4 * CH + lane, t1 - 1)];
-    // Jacobian rows: nine 8-byte pieces per record; WA: two 16-byte pieces (kept at 8-byte granularity in LDS:
-    // the 26-float record stride is not a multiple of 16 bytes). Every load of the chunk is issued before the first
+    // Jacobian rows: nine two-scalar pieces per record; WA: two four-scalar pieces (kept at two-scalar granularity
+    // in LDS: the 26-scalar record stride is not a multiple of four). Every load of the chunk is issued before the first
     // LDS store and none is conditional (lanes past the chunk re-read one of its first records: `idxreg` is a valid
     // observation in every lane) - a load inside `if (q < ...)` is a basic block of its own that waits for its data
     // before the next one is issued: seven memory round trips per chunk instead of two.
     constexpr int NJ = (CH * 9 + 63) / 64;
-    float2 jv[NJ];
+    V2 jv[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int q = j * 64 + lane;
       const int r = q / 9, pc = q - 9 * r;
       const int o = __shfl(idxreg, r & 31);
-      jv[j] = *reinterpret_cast<const float2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
+      jv[j] = *reinterpret_cast<const V2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
     }
-    float4 w = {0.f, 0.f, 0.f, 0.f};
+    V4 w = {0, 0, 0, 0};
     if (MODE == 0) {
       const int o = __shfl(idxreg, (lane >> 1) & 31);
-      w = *reinterpret_cast<const float4*>(p.WA + int64_t(o) * kRecW + 4 * (lane & 1));
+      w = *reinterpret_cast<const V4*>(p.WA + int64_t(o) * kRecW + 4 * (lane & 1));
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int q = j * 64 + lane;
       const int r = q / 9, pc = q - 9 * r;
-      if (q < cnt * 9) *reinterpret_cast<float2*>(lds + r * RW + 2 * pc) = jv[j];
+      if (q < cnt * 9) *reinterpret_cast<V2*>(lds + r * RW + 2 * pc) = jv[j];
     }
     if (MODE == 0) {
       const int r = lane >> 1, h = lane & 1;
       if (r < cnt) {
-        float* d = lds + r * RW + 18 + 4 * h;
-        *reinterpret_cast<float2*>(d) = float2{w.x, w.y};
-        *reinterpret_cast<float2*>(d + 2) = float2{w.z, w.w};
+        S* d = lds + r * RW + 18 + 4 * h;
+        *reinterpret_cast<V2*>(d) = V2{w.x, w.y};
+        *reinterpret_cast<V2*>(d + 2) = V2{w.z, w.w};
       }
     }
     wave_lds_fence();
@@ -108,31 +112,31 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<float> p, float la
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int so = s + 2 * h + (kk >> 1);
-          float v = 0.f;
+          S v = S(0);
           if (i < 9 && so < cnt) {
-            const float* rec = lds + so * RW;
-            const float* arow = rec + 18 + kRecA + 2 * (kk & 1);
-            v = fmaf(arow[0], rec[i], __fmul_rn(arow[1], rec[9 + i]));
+            const S* rec = lds + so * RW;
+            const S* arow = rec + 18 + kRecA + 2 * (kk & 1);
+            v = fma(arow[0], rec[i], M::mul_rn(arow[1], rec[9 + i]));
           }
           if (h == 0)
-            accK = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, accK, 0, 0, 0);
+            accK = M::mma(v, v, accK);
           else
-            accK2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, accK2, 0, 0, 0);
+            accK2 = M::mma(v, v, accK2);
         }
       }
     }
     if (want_G) {
       for (int s = 0; s < cnt; s += 2) {
         const int so = s + (kk >> 1);
-        const float v = (i < 9 && so < cnt) ? lds[so * RW + 9 * (kk & 1) + i] : 0.f;
-        accG = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, accG, 0, 0, 0);
+        const S v = (i < 9 && so < cnt) ? lds[so * RW + 9 * (kk & 1) + i] : S(0);
+        accG = M::mma(v, v, accG);
       }
     }
     if (lane < 63)
       for (int r = g; r < cnt; r += 7) {
-        const float* rec = lds + r * RW;
-        if (MODE == 0) accb += double(fmaf(rec[a], rec[18 + kRecG], __fmul_rn(rec[9 + a], rec[18 + kRecG + 1])));
-        if (want_d) accd += double(fmaf(rec[a], rec[a], __fmul_rn(rec[9 + a], rec[9 + a])));
+        const S* rec = lds + r * RW;
+        if (MODE == 0) accb += double(fma(rec[a], rec[18 + kRecG], M::mul_rn(rec[9 + a], rec[18 + kRecG + 1])));
+        if (want_d) accd += double(fma(rec[a], rec[a], M::mul_rn(rec[9 + a], rec[9 + a])));
       }
     wave_lds_fence();  // the next chunk overwrites the staging buffer
     idxreg = idxnext;
@@ -144,9 +148,9 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<float> p, float la
     dsum[wave][g][a] = accd;
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = accG[r];
+  for (int r = 0; r < 4; ++r) tile[wave][M::row(lane, r)][lane & 15] = accG[r];
   __syncthreads();
-  float gsum = 0.f;
+  S gsum = S(0);
   if (want_G && tid < 81) {
     const int ii = tid / 9, jj = tid - 9 * ii;
 #pragma unroll
@@ -157,10 +161,10 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<float> p, float la
     double sum = 0;
     for (int w = 0; w < 4; ++w)
       for (int gg = 0; gg < 7; ++gg) sum += dsum[w][gg][aa];
-    const float d2 = float(sum);
+    const S d2 = S(sum);
     p.jp_diag2[9 * c + aa] = d2;
     if (MODE == 0) {
-      const float sc = 1.f / (p.eps + sqrtf(d2));  // k_pose_scaling
+      const S sc = S(1) / (p.eps + sqrt(d2));  // k_pose_scaling
       p.pose_scaling[9 * c + aa] = sc;
       dsc[aa] = sc;
     }
@@ -172,27 +176,27 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<float> p, float la
   if (!want_d && tid < 9) dsc[tid] = p.pose_scaling[9 * c + tid];
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 4; ++r) tile[wave][(lane >> 4) * 4 + r][lane & 15] = accK[r];
+  for (int r = 0; r < 4; ++r) tile[wave][M::row(lane, r)][lane & 15] = accK[r];
   __syncthreads();
   if (tid < 81) {
     const int ii = tid / 9, jj = tid - 9 * ii;
-    float t = 0.f;
+    S t = S(0);
 #pragma unroll
     for (int w = 0; w < 4; ++w) t += tile[w][ii][jj];
-    const float dd = dsc[ii] * dsc[jj];
-    const float kd = __fmul_rn(t, dd);  // D K D: the camera's diagonal block of the reduced matrix (lambda = 0)
+    const S dd = dsc[ii] * dsc[jj];
+    const S kd = M::mul_rn(t, dd);  // D K D: the camera's diagonal block of the reduced matrix (lambda = 0)
     if (p.jacobi) {
-      float bm;
+      S bm;
       if (GRAM) {
-        bm = __fmul_rn(gsum, dd);
+        bm = M::mul_rn(gsum, dd);
         p.B_mid[81 * c + tid] = bm;
       } else {
         bm = p.B_mid[81 * c + tid];
       }
-      p.blocks[81 * c + tid] = bm + (ii == jj ? lambda : 0.f);
+      p.blocks[81 * c + tid] = bm + (ii == jj ? lambda : S(0));
       if (p.want_sdiag) p.sdiag[81 * c + tid] = kd;
     } else {
-      p.blocks[81 * c + tid] = kd + (ii == jj ? lambda : 0.f);
+      p.blocks[81 * c + tid] = kd + (ii == jj ? lambda : S(0));
     }
   }
   if (tid >= 128 && tid < 137) {
@@ -200,96 +204,8 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<float> p, float la
     double sum = 0.0;
     for (int w = 0; w < 4; ++w)
       for (int gg = 0; gg < 7; ++gg) sum += bsum[w][gg][aa];
-    p.b[9 * c + aa] = float(sum * double(dsc[aa]));
+    p.b[9 * c + aa] = S(sum * double(dsc[aa]));
   }
-}
-
-// generic (double): the same pass on the vector ALU with double accumulators, 64 records staged per workgroup
-template <class S, int MODE>
-__global__ __launch_bounds__(256) void k_cam_pass(Params<S> p, S lambda, int GRAM) {
-  constexpr int TILE = 64, RW = 18 + kRecW;
-  __shared__ S rec[TILE][RW];  // [Jp 18 | g 2 | A 4 | 0 0]
-  __shared__ int olist[TILE];
-  __shared__ double red[3][81], redG[3][81];
-  __shared__ double dsc[9];
-  const int c = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int grp = tid / 81, e = tid - 81 * grp, ea = e / 9, eb = e - 9 * ea;
-  const bool want_K = MODE == 0 && (!p.jacobi || p.want_sdiag);
-  const bool want_G = MODE == 1 || GRAM;  // (its diagonal is Jp_diag2)
-  double acc = 0, accG = 0;
-  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  for (int64_t base = t0; base < t1; base += TILE) {
-    const int n = int(min<int64_t>(TILE, t1 - base));
-    __syncthreads();
-    if (tid < n) olist[tid] = p.cam_obs[base + tid];
-    __syncthreads();
-    for (int idx = tid; idx < n * RW; idx += 256) {
-      const int q = idx / RW, f = idx - RW * q;
-      if (f < 18)
-        rec[q][f] = p.JpS[int64_t(olist[q]) * 18 + f];
-      else if (MODE == 0)
-        rec[q][f] = p.WA[int64_t(olist[q]) * kRecW + (f - 18)];
-    }
-    __syncthreads();
-    if (grp < 3) {
-      for (int q = grp; q < n; q += 3) {
-        const S* r = rec[q];
-        if (want_K) {
-          const S a00 = r[18 + kRecA], a01 = r[18 + kRecA + 1], a10 = r[18 + kRecA + 2], a11 = r[18 + kRecA + 3];
-          const S ya = a00 * r[ea] + a01 * r[9 + ea], yb = a00 * r[eb] + a01 * r[9 + eb];
-          const S za = a10 * r[ea] + a11 * r[9 + ea], zb = a10 * r[eb] + a11 * r[9 + eb];
-          acc += double(ya * yb + za * zb);
-        }
-        if (want_G) accG += double(r[ea] * r[eb] + r[9 + ea] * r[9 + eb]);
-      }
-    } else if (MODE == 0 && tid < 252) {
-      const int a = tid - 243;
-      for (int q = 0; q < n; ++q) acc += double(rec[q][a] * rec[q][18 + kRecG] + rec[q][9 + a] * rec[q][18 + kRecG + 1]);
-    }
-  }
-  if (grp < 3) {
-    red[grp][e] = acc;
-    redG[grp][e] = accG;
-  }
-  __syncthreads();
-  double gsum = 0;
-  if (want_G && tid < 81) {
-    gsum = redG[0][tid] + redG[1][tid] + redG[2][tid];
-    if (ea == eb) {
-      const S d2 = S(gsum);
-      p.jp_diag2[9 * c + ea] = d2;
-      if (MODE == 0) {
-        const S sc = S(1) / (p.eps + sqrt(d2));
-        p.pose_scaling[9 * c + ea] = sc;
-        dsc[ea] = double(sc);
-      }
-    }
-  }
-  if (MODE == 1) {
-    if (tid < 81) p.B_mid[81 * c + tid] = S(gsum);
-    return;
-  }
-  if (!want_G && tid < 9) dsc[tid] = double(p.pose_scaling[9 * c + tid]);
-  __syncthreads();
-  if (tid < 81) {
-    const double dd = dsc[ea] * dsc[eb];
-    const double kd = (red[0][tid] + red[1][tid] + red[2][tid]) * dd;  // D K D
-    if (p.jacobi) {
-      double bm;
-      if (GRAM) {
-        bm = double(S(gsum) * S(dd));  // as k_scale_gram applied to the stored Gram block
-        p.B_mid[81 * c + tid] = S(bm);
-      } else {
-        bm = double(p.B_mid[81 * c + tid]);
-      }
-      p.blocks[81 * c + tid] = S(bm + (ea == eb ? double(lambda) : 0.0));
-      if (p.want_sdiag) p.sdiag[81 * c + tid] = S(kd);
-    } else {
-      p.blocks[81 * c + tid] = S(kd + (ea == eb ? double(lambda) : 0.0));
-    }
-  }
-  if (tid >= 243 && tid < 252) p.b[9 * c + (tid - 243)] = S(acc * dsc[tid - 243]);
 }
 
 // an observation's stage-2 record WA from its eight stage-2 coefficients

@@ -526,92 +526,19 @@ __global__ __launch_bounds__(256) void k_sc_back_substitute(ScParams<S> p, const
 // both sums have thousands of terms, the rounding error of the difference is of the
 // same order, eps sqrt(n), as that of accumulating Gram blocks).
 // ===========================================================================
-// topd [obs][3][9] -> [obs][9][3] so that a lane's three factors are one 12-byte load
+// Strictly upper blocks on the matrix cores (v_mfma_*_16x16x4 of either precision, Mfma<S>): the block is the GEMM
+//  - [T_1 T_2 ...] [W_1 W_2 ...]^T   (9 x 3P)(3P x 9) over the P pairs of its list, fixed order, mirrored write.
 template <class S>
-__global__ __launch_bounds__(256) void k_topd_transpose(const S* __restrict__ topd, S* __restrict__ topdT,
-                                                        int64_t n) {
-  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  if (t >= n) return;
-  const int64_t o = t / 27;
-  const int e = int(t - 27 * o), m = e / 9, c = e - 9 * m;
-  topdT[27 * o + 3 * c + m] = topd[kTd * o + e];
-}
-
-// strictly upper blocks: one workgroup per block, fixed order, mirrored write
-template <class S>
-__global__ __launch_bounds__(256) void k_ex_offdiag(const S* __restrict__ topdT, S* __restrict__ vals,
-                                                    const int* __restrict__ upper_slot,
-                                                    const int* __restrict__ mirror_slot,
-                                                    const int64_t* __restrict__ pair_ptr,
-                                                    const int* __restrict__ pair_oi,
-                                                    const int* __restrict__ pair_oj) {
-  __shared__ S part[3][81];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int u = blockIdx.x;
-  const int a0 = lane / 9, b0 = lane - 9 * a0;
-  const int e1 = 64 + lane;
-  const bool has1 = e1 < 81;
-  const int a1 = has1 ? e1 / 9 : 0, b1 = has1 ? e1 - 9 * a1 : 0;
-  S acc0 = S(0), acc1 = S(0);
-  const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
-  for (int64_t q = q0 + wave * kScUnroll; q < q1; q += 4 * kScUnroll) {
-    int oi[kScUnroll], oj[kScUnroll];
-    S t0[kScUnroll][3], w0[kScUnroll][3], t1[kScUnroll][3], w1[kScUnroll][3];
-#pragma unroll
-    for (int r = 0; r < kScUnroll; ++r) {
-      const bool ok = q + r < q1;
-      oi[r] = ok ? pair_oi[q + r] : -1;
-      oj[r] = ok ? pair_oj[q + r] : -1;
-    }
-#pragma unroll
-    for (int r = 0; r < kScUnroll; ++r) {
-      const bool ok = oi[r] >= 0;
-      const S* __restrict__ T = topdT + 27 * int64_t(ok ? oi[r] : 0);
-      const S* __restrict__ W = topdT + 27 * int64_t(ok ? oj[r] : 0);
-      load3(T + 3 * a0, t0[r]);
-      load3(W + 3 * b0, w0[r]);
-      load3(T + 3 * a1, t1[r]);
-      load3(W + 3 * b1, w1[r]);
-      if (!ok) t0[r][0] = t0[r][1] = t0[r][2] = S(0);
-      if (!ok || !has1) t1[r][0] = t1[r][1] = t1[r][2] = S(0);
-    }
-#pragma unroll
-    for (int r = 0; r < kScUnroll; ++r) {
-      acc0 -= t0[r][0] * w0[r][0] + t0[r][1] * w0[r][1] + t0[r][2] * w0[r][2];
-      acc1 -= t1[r][0] * w1[r][0] + t1[r][1] * w1[r][1] + t1[r][2] * w1[r][2];
-    }
-  }
-  if (wave > 0) {
-    part[wave - 1][lane] = acc0;
-    if (has1) part[wave - 1][e1] = acc1;
-  }
-  __syncthreads();
-  if (wave > 0) return;
-  acc0 = ((acc0 + part[0][lane]) + part[1][lane]) + part[2][lane];
-  if (has1) acc1 = ((acc1 + part[0][e1]) + part[1][e1]) + part[2][e1];
-  S* out = vals + size_t(81) * upper_slot[u];
-  out[lane] = acc0;
-  if (has1) out[e1] = acc1;
-  S* outT = vals + size_t(81) * mirror_slot[u];
-  outT[9 * b0 + a0] = acc0;
-  if (has1) outT[9 * b1 + a1] = acc1;
-}
-
-// float version on the matrix cores: the block is the GEMM  - [T_1 T_2 ...] [W_1 W_2 ...]^T
-// (9 x 3P)(3P x 9) over the P pairs of its list. v_mfma_f32_16x16x4_f32 consumes 4 of the 3P
-// inner indices per instruction with ONE 4-byte gather per lane and operand, i.e. 6 vector
-// memory instructions per 4 pairs instead of 16 — the kernel is bound by the number of
-// memory instructions (address processing of 64-lane gathers), not by bytes or flops.
-// Reads the damped top rows in their native [obs][3][9] layout (single-float gathers, the nine
-// components of a factor column are contiguous).
-__global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const float* __restrict__ topd, float* __restrict__ vals,
+__global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const S* __restrict__ topd, S* __restrict__ vals,
                                                          const int* __restrict__ upper_slot,
                                                          const int* __restrict__ mirror_slot,
                                                          const int64_t* __restrict__ pair_ptr,
                                                          const int* __restrict__ pair_oi,
                                                          const int* __restrict__ pair_oj, int n_upper) {
-  __shared__ float tile[4][16][16];
+  using M = Mfma<S>;
+  using V4 = typename M::V4;
+  using Acc = typename M::acc;
+  __shared__ S tile[4][16][16];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-contiguous block order (workgroup b runs on XCD b % 8): consecutive upper blocks share their row camera, so
@@ -619,30 +546,30 @@ __global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const float* __restrict
   const int u = xcd_swizzled_camera(n_upper);
   if (u >= n_upper) return;
   const int i = lane & 15, kk = lane >> 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  Acc acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
   const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
-  // 16 pairs per wave and step. A record (one observation's damped top rows) is ONE 128-byte cache line: the eight
-  // records of a quad of pairs are fetched with one 16-byte load per lane (lane = record x piece), staged in LDS and
+  // 16 pairs per wave and step. A record (one observation's damped top rows) is ONE 128-byte cache line in float: the
+  // eight records of a quad of pairs are fetched with one four-scalar load per lane (lane = record x piece), staged in LDS and
   // read back in the operand layout of the matrix-core instruction. (Round 2 gathered 4 bytes per lane straight into
   // the operand registers: six 36-of-64-lane gather instructions per quad kept the kernel on the texture-address
   // path - 0.95 ms on venice whatever the record size or the block order.)
   constexpr int U = 4;
-  __shared__ __attribute__((aligned(16))) float stage[4][U][8][kTd];
+  __shared__ __attribute__((aligned(16))) S stage[4][U][8][kTd];
   const int rec = lane >> 3, vec = lane & 7;
   const int* __restrict__ pair_side = rec < 4 ? pair_oi : pair_oj;
   for (int64_t q = q0 + wave * (4 * U); q < q1; q += 16 * U) {
     // (clamped, not predicated: the U index loads go out together, then the U record loads - a load inside a
     //  conditional is a basic block of its own that waits for its operand and for everything issued before it)
-    float4 v[U];
+    V4 v[U];
     int o[U];
 #pragma unroll
     for (int uq = 0; uq < U; ++uq) o[uq] = pair_side[min(q + 4 * uq + (rec & 3), q1 - 1)];
 #pragma unroll
-    for (int uq = 0; uq < U; ++uq) v[uq] = reinterpret_cast<const float4*>(topd + kTd * int64_t(o[uq]))[vec];
+    for (int uq = 0; uq < U; ++uq) v[uq] = reinterpret_cast<const V4*>(topd + kTd * int64_t(o[uq]))[vec];
 #pragma unroll
     for (int uq = 0; uq < U; ++uq) {
       const bool ok = q + 4 * uq + (rec & 3) < q1;
-      *reinterpret_cast<float4*>(&stage[wave][uq][rec][4 * vec]) = ok ? v[uq] : float4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<V4*>(&stage[wave][uq][rec][4 * vec]) = ok ? v[uq] : V4{0, 0, 0, 0};
     }
     wave_lds_fence();
 #pragma unroll
@@ -651,23 +578,23 @@ __global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const float* __restrict
       for (int m = 0; m < 3; ++m) {
         const int g = 4 * m + kk;  // inner index 0..11 = (pair of the quad, factor row)
         const int pp = g / 3, c = g - 3 * pp;
-        const float av = i < 9 ? stage[wave][uq][pp][9 * c + i] : 0.f;
-        const float bv = i < 9 ? stage[wave][uq][4 + pp][9 * c + i] : 0.f;
+        const S av = i < 9 ? stage[wave][uq][pp][9 * c + i] : S(0);
+        const S bv = i < 9 ? stage[wave][uq][4 + pp][9 * c + i] : S(0);
         if (uq & 1)
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc2, 0, 0, 0);
+          acc2 = M::mma(av, bv, acc2);
         else
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+          acc = M::mma(av, bv, acc);
       }
     wave_lds_fence();  // the next step overwrites the staging buffer
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) tile[wave][kk * 4 + r][i] = acc[r];
+  for (int r = 0; r < 4; ++r) tile[wave][M::row(lane, r)][i] = acc[r];
   __syncthreads();
   if (threadIdx.x < 81) {
     const int a = threadIdx.x / 9, b = threadIdx.x - 9 * a;
-    const float v = -(((tile[0][a][b] + tile[1][a][b]) + tile[2][a][b]) + tile[3][a][b]);
+    const S v = -(((tile[0][a][b] + tile[1][a][b]) + tile[2][a][b]) + tile[3][a][b]);
     vals[size_t(81) * upper_slot[u] + threadIdx.x] = v;
     vals[size_t(81) * mirror_slot[u] + 9 * b + a] = v;
   }

@@ -743,7 +743,6 @@ class Solver final : public rba_solver {
     d_ex_pair_oi_.alloc(n_pairs);
     d_ex_pair_oj_.alloc(n_pairs);
     d_ex_vals_.alloc(size_t(81) * nnz + 4);  // + 4: the SpMV's last 16-byte load may run past the end
-    d_ex_topdT_.alloc(sizeof(S) == 8 ? 27 * size_t(n_obs_) : 0);
     d_ex_rowptr_.upload(row_ptr.data(), row_ptr.size(), stream_);
     d_ex_cols_.upload(cols.data(), cols.size(), stream_);
     d_ex_diag_.upload(diag.data(), diag.size(), stream_);
@@ -1399,37 +1398,22 @@ class Solver final : public rba_solver {
   }
 
   // off-diagonal blocks of the explicit reduced matrix: matrix cores for float, VALU for double
-  void launch_offdiag(const float* topd, float* vals) {
-    hipLaunchKernelGGL((rba::k_ex_offdiag_mfma), dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_, topd,
-                       vals, d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(), d_ex_pair_oi_.get(),
+  void launch_offdiag(const S* topd, S* vals) {
+    hipLaunchKernelGGL((rba::k_ex_offdiag_mfma<S>), dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_,
+                       topd, vals, d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(), d_ex_pair_oi_.get(),
                        d_ex_pair_oj_.get(), ex_n_upper_);
   }
-  void launch_offdiag(const double* topd, double* vals) {
-    // the VALU version takes its factors as 12-byte loads from a [obs][9][3] copy
-    const int64_t n27 = 27 * int64_t(n_obs_);
-    hipLaunchKernelGGL((rba::k_topd_transpose<double>), dim3(unsigned((n27 + 255) / 256)), dim3(256), 0, stream_,
-                       topd, d_ex_topdT_.get(), n27);
-    hipLaunchKernelGGL((rba::k_ex_offdiag<double>), dim3(ex_n_upper_), dim3(256), 0, stream_, d_ex_topdT_.get(), vals,
-                       d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(), d_ex_pair_oi_.get(),
-                       d_ex_pair_oj_.get());
-  }
 
-  // camera-major passes (kernels_cam.hpp): matrix cores for float, VALU (double accumulators) for double.
+  // camera-major passes (kernels_cam.hpp) on the matrix cores of either precision.
   // launch_cam_gram: Jp_diag2 + the unscaled Gram blocks on their own (sharded runs, Jp_diag2 requested at once, the SC
   // backend's power-series blocks); launch_cam_stage2: blocks, b (and on one GPU the Gram part of the first stage 2)
-  void launch_cam_gram(const rba::Params<float>& prm) {
-    hipLaunchKernelGGL((rba::k_cam_pass_mfma<1>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm, 0.f, 0);
+  void launch_cam_gram(const rba::Params<S>& prm) {
+    hipLaunchKernelGGL((rba::k_cam_pass_mfma<S, 1>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
+                       S(0), 0);
   }
-  void launch_cam_gram(const rba::Params<double>& prm) {
-    hipLaunchKernelGGL((rba::k_cam_pass<double, 1>), dim3(n_cams_), dim3(256), 0, stream_, prm, 0.0, 0);
-  }
-  void launch_cam_stage2(const rba::Params<float>& prm, float lambda) {
-    hipLaunchKernelGGL((rba::k_cam_pass_mfma<0>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
+  void launch_cam_stage2(const rba::Params<S>& prm, S lambda) {
+    hipLaunchKernelGGL((rba::k_cam_pass_mfma<S, 0>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm,
                        lambda, gram_pending_ ? 1 : 0);
-  }
-  void launch_cam_stage2(const rba::Params<double>& prm, double lambda) {
-    hipLaunchKernelGGL((rba::k_cam_pass<double, 0>), dim3(n_cams_), dim3(256), 0, stream_, prm, lambda,
-                       gram_pending_ ? 1 : 0);
   }
   // the 27 + 9 records of the current damping, for the consumers that read them (assembly of the reduced matrix,
   // matrix-free E0 products): the closed-form column pass on the unscaled rows (kernels_s1.hpp)
@@ -2661,7 +2645,7 @@ class Solver final : public rba_solver {
   std::vector<int> h_obs_cam_;
   DevBuf<int> d_ex_rowptr_, d_ex_cols_, d_ex_diag_, d_ex_upper_, d_ex_mirror_, d_ex_pair_oi_, d_ex_pair_oj_;
   DevBuf<int64_t> d_ex_pair_ptr_;
-  DevBuf<S> d_ex_vals_, d_ex_topdT_;
+  DevBuf<S> d_ex_vals_;
   // fused PCG on the assembled matrix (kernels_pcg.hpp)
   DevBuf<rba::SpmvItem> d_items_;
   DevBuf<int> d_item_ptr_;

@@ -378,3 +378,24 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_f32_16x16x4f32(a, b, c)
+// v_mfma_f64_16x16x4_f64: same operand layout; C/D[(l >> 4) + 4 r][l & 15], r = 0..3 (measured on gfx950:
+// scripts/microbench/mfma_f64_layout.hip)
+typedef double hipemu_f64x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f64x4 hipemu_mfma_f64_16x16x4f64(double a, double b, hipemu_f64x4 c) {
+  uint64_t* s = hipemu::wave_slots();
+  const int lane = hipemu::self()->lane;
+  s[lane] = hipemu::bits(a);
+  s[64 + lane] = hipemu::bits(b);
+  hipemu::wave_barrier();
+  const int col = lane & 15, r0 = lane >> 4;
+  hipemu_f64x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    double t = c[r];
+    for (int k = 0; k < 4; ++k)
+      t = std::fma(hipemu::from_bits<double>(s[k * 16 + r0 + 4 * r]), hipemu::from_bits<double>(s[64 + k * 16 + col]), t);
+    d[r] = t;
+  }
+  hipemu::wave_barrier();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) hipemu_mfma_f64_16x16x4f64(a, b, c)
