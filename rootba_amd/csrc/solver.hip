@@ -1367,16 +1367,22 @@ class Solver final : public rba_solver {
       ++hx_event_count_;
       HIP_CHECK(hipEventRecord(e0, stream_));
     }
-    if (ex_active_) {
-      // y = (sum_l A_l^T A_l) x from the assembled matrix; overwrites y (y was zero)
-      hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, exp_, x, y, done_flag);
-      if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
-      ++hx_calls_;
-      return;
-    }
-    if (sc_) {
-      // y = S x (pose damping is part of S); overwrites y
-      hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_, x, y, done_flag);
+    if (ex_active_ || sc_) {
+      // y = (sum_l A_l^T A_l) x from the assembled matrix (SC backend: y = S x, the pose damping is part of S);
+      // overwrites y. Through the row-staged SpMV of the fused PCG in its plain-product mode (+ the collect of long
+      // rows' partial sums) where its work items exist: 75 us against 183 for k_sc_spmv on final-13682.
+      const rba::ScParams<S>& M = sc_ ? scp_ : exp_;
+      if (n_items_ > 0 && done_flag == &d_cg_.get()->done) {
+        hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_, M.cols,
+                           M.vals, d_items_.get(), static_cast<const S*>(nullptr), static_cast<S*>(nullptr),
+                           static_cast<S*>(nullptr), x, d_qmain_.get(), d_qpart_.get(), d_cg_.get(),
+                           static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
+                           static_cast<double*>(nullptr), 0.0, 0, 0, 1, static_cast<int*>(nullptr));
+        hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y, d_qmain_.get(),
+                           d_qpart_.get(), d_item_ptr_.get(), nvec_);
+      } else {
+        hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, M, x, y, done_flag);
+      }
       if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
       ++hx_calls_;
       return;
@@ -1919,10 +1925,8 @@ class Solver final : public rba_solver {
                                static_cast<S*>(nullptr), static_cast<S*>(nullptr), t, d_qmain_.get(), d_qpart_.get(),
                                st, static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
                                static_cast<double*>(nullptr), double(lambda), 0, 0, 1, static_cast<int*>(nullptr));
-            hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, e,
-                               d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), n);
-            hipLaunchKernelGGL((rba::k_series_step<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), e, t,
-                               d_z_.get(), n, st);
+            hipLaunchKernelGGL((rba::k_series_step<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_qmain_.get(),
+                               d_qpart_.get(), d_item_ptr_.get(), t, d_z_.get(), n, st);
             continue;
           }
           launch_e0(t, e, done);
