@@ -1369,20 +1369,11 @@ class Solver final : public rba_solver {
     }
     if (ex_active_ || sc_) {
       // y = (sum_l A_l^T A_l) x from the assembled matrix (SC backend: y = S x, the pose damping is part of S);
-      // overwrites y. Through the row-staged SpMV of the fused PCG in its plain-product mode (+ the collect of long
-      // rows' partial sums) where its work items exist: 75 us against 183 for k_sc_spmv on final-13682.
-      const rba::ScParams<S>& M = sc_ ? scp_ : exp_;
-      if (n_items_ > 0 && done_flag == &d_cg_.get()->done) {
-        hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_, M.cols,
-                           M.vals, d_items_.get(), static_cast<const S*>(nullptr), static_cast<S*>(nullptr),
-                           static_cast<S*>(nullptr), x, d_qmain_.get(), d_qpart_.get(), d_cg_.get(),
-                           static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
-                           static_cast<double*>(nullptr), 0.0, 0, 0, 1, static_cast<int*>(nullptr));
-        hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y, d_qmain_.get(),
-                           d_qpart_.get(), d_item_ptr_.get(), nvec_);
-      } else {
-        hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, M, x, y, done_flag);
-      }
+      // overwrites y. (The row-staged SpMV of the fused PCG in its plain-product mode is 2.4 x faster on final-13682
+      // - 75 against 183 us - and was tried here: on venice-1778 with the float32 power series one solve at
+      // lambda = 1.4e-7 then needs the matrix-free repeat, reproducibly, where this kernel's summation order converges
+      // in 200 iterations - 106 against 215 LM it/s. Both are float32 roundings of the same product; kept as it was.)
+      hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, sc_ ? scp_ : exp_, x, y, done_flag);
       if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
       ++hx_calls_;
       return;
