@@ -40,6 +40,8 @@ void usage() {
       "  --save-log-flags <JSON,UBJSON>         (default JSON; UBJSON writes <log>.ubjson next to it)\n"
       "  --input-type <AUTO|ROOTBA|BAL|BUNDLER> AUTO: '*.cereal' = rootba problem cache, '*bundle*' = Bundler, else BAL text\n"
       "  --[no-]save-output, --output-optimized-path <p>   write the optimised problem as a .cereal cache (default optimized.cereal)\n"
+      "                                         (the written cache round-trips through THIS loader; it has not been read back by\n"
+      "                                          the reference's cereal / basalt-headers serialisers, which are not available here)\n"
       "  --dry-run                              load + preprocess only, print problem statistics\n"
       "  --dump-options                         print the solver options this command line selects (JSON) and exit");
 }

@@ -691,6 +691,19 @@ def test_explicit_switch_inside_pcg(ladybug_far, dtype):
         e1, e6, e0 = (rel_err(i, ref) for i in incs)
         # (each of the three lands anywhere in that band from run to run - the scatter-adds are atomic)
         assert e0 < 5e-2 and e1 <= max(3 * e0 + 1e-3, 2e-2) and e6 <= max(3 * e0 + 1e-3, 2e-2), (e1, e6, e0)
+        # Where float32 CAN deliver the requested digits the check is tight: at eta = 1e-3 the solve takes the same
+        # nine iterations as in float64 whichever operator finishes it (the switch after 1 and after 6 products both
+        # fall inside), and all three increments are the float64 one to float32 accuracy (measured 5.1e-5 ... 5.2e-5).
+        g64, _ = _pair(ladybug_far, np.float64, explicit_after=0, eta=1e-3)
+        assert g64.linearize() == 0
+        ref3, cg64 = g64.solve(1e-5)
+        assert cg64.num_iterations > 6
+        for after in (1, 6, 0):
+            g, _ = _pair(ladybug_far, dtype, explicit_after=after, eta=1e-3)
+            assert g.linearize() == 0
+            inc3, cg3 = g.solve(1e-5)
+            assert cg3.termination_type == 1 and cg3.num_iterations == cg64.num_iterations, (after, cg3.num_iterations)
+            assert rel_err(inc3, ref3) < 2e-4, (after, rel_err(inc3, ref3))
     ctol = 1e-9 if dtype == np.float64 else 2e-5
     for a, b, c in zip(*runs):
         assert abs(a.cost - c.cost) <= ctol * c.cost and abs(b.cost - c.cost) <= ctol * c.cost
