@@ -1134,6 +1134,14 @@ __global__ void k_mixed_round(const double* __restrict__ src, float* __restrict_
 // Block-diagonal preconditioner (BlockDiagonalPreconditioner,
 // src/rootba/cg/preconditioner.hpp:79-136): one thread per camera inverts its
 // SPD 9x9 block by Cholesky (upper triangle is the definition, App. A.5).
+// A block with a pivot that is not positive - a float32 block whose smallest eigenvalue sits below its rounding error,
+// met on final-13682 at lambda ~ 1e-6 - is replaced by its DIAGONAL (a point-Jacobi preconditioner for that camera):
+// Eigen's LLT stops at such a pivot and leaves a meaningless but finite factor (the reference then preconditions that
+// camera with garbage), while the square root of a negative pivot would put NaNs into every PCG vector and end the
+// solve at its first iteration with a zero camera increment (observed: seven LM iterations in a row moved landmarks
+// only). Any SPD matrix is a valid preconditioner; blocks that factor are untouched; bit 4 of the failure word records
+// that it happened. (Raising the pivot to the rounding level of its diagonal entry instead was tried: the huge inverse
+// entries along the near-null direction produce wild steps.)
 // ===========================================================================
 template <class S>
 __global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ inv, int n_cams,
@@ -1160,8 +1168,18 @@ __global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ in
       L[i * (i + 1) / 2 + j] = v * ij;
     }
   }
-  if (!ok) atomicOr(fail_flag, 4);
   S* out = inv + 81 * c;
+  if (!ok) {
+    atomicOr(fail_flag, 4);
+    bool diag_ok = true;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) diag_ok = diag_ok && (a[9 * j + j] > S(0)) && is_finite(a[9 * j + j]);
+    if (diag_ok) {  // (else: NaN / non-positive diagonal - a numerical failure upstream, left to propagate)
+#pragma unroll
+      for (int e = 0; e < 81; ++e) out[e] = (e % 10 == 0) ? S(1) / a[e] : S(0);
+      return;
+    }
+  }
 #pragma unroll
   for (int col = 0; col < 9; ++col) {
     S yv[9], xv[9];
