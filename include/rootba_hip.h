@@ -257,7 +257,9 @@ int rba_linearize(rba_handle h, void* jp_diag2_out);
 /* LinearizorQR::solve (linearizor_qr.cpp:141-265): set_pose_damping,
  * get_stage2 (linearization_qr.hpp:716-815), BlockDiagonalPreconditioner
  * (preconditioner.hpp:79-120), PCG (conjugate_gradient.hpp:113-298). inc_out
- * (9*n_cams) is already negated (linearizor_base.cpp:100). */
+ * (9*n_cams, not NULL: RBA_ERR_INVALID_ARGUMENT) is already negated
+ * (linearizor_base.cpp:100). (rba_lm_step keeps the increment on the device
+ * between its solve and its back-substitution; this entry always returns it.) */
 int rba_solve(rba_handle h, double lambda, void* inc_out, rba_cg_summary* cg);
 
 /* Pieces of rba_solve, exposed because the reference's tests call them
@@ -271,7 +273,8 @@ int rba_right_multiply_explicit(rba_handle h, const void* x, void* y);
 
 /* LinearizorQR::apply (linearizor_qr.cpp:268-291): back_substitute
  * (linearization_qr.hpp:165-179, landmark_block_base.ipp:212-284), un-scale,
- * camera retraction. l_diff_out is NaN (status 1) on a non-finite update. */
+ * camera retraction. l_diff_out is NaN (status 1) on a non-finite update.
+ * inc (9*n_cams) must not be NULL. */
 int rba_apply(rba_handle h, const void* inc, double* l_diff_out);
 /* LinearizationQR::back_substitute alone (landmarks only; reference tests call
  * it with a random increment, linearization_qr.test.cpp:194-200). */

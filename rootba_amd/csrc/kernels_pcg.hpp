@@ -502,7 +502,10 @@ __global__ __launch_bounds__(256) void k_pcgs_direction(const S* __restrict__ z,
                                                         int n, CgState* st, const double* __restrict__ part_rho,
                                                         const double* __restrict__ part_q, const S* __restrict__ dscale,
                                                         S* __restrict__ pscaled, double q_tolerance, int min_it,
-                                                        int max_it, int* host_progress) {
+                                                        int max_it, int* host_progress, int test_only) {
+  // `test_only`: the decisions alone - the host asks whether the solve goes on before it pays for the assembly of the
+  // reduced matrix at the operator switch; nothing of the iteration that follows is started (the prologue that starts
+  // it evaluates the same sums again and comes to the same verdict).
   const int lane = threadIdx.x & 63;
   const double prho = part_rho[lane], pq1 = part_q[lane];
   const int done = st->done, it = st->iter, need_test = st->need_test;
@@ -548,14 +551,16 @@ __global__ __launch_bounds__(256) void k_pcgs_direction(const S* __restrict__ z,
         st->done = 1;
         if (host_progress) __hip_atomic_store(host_progress + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       } else {
-        st->rho_hist[it & 1] = rho;
-        st->beta = beta;
-        st->cur = it + 1;
+        if (!test_only) {
+          st->rho_hist[it & 1] = rho;
+          st->beta = beta;
+          st->cur = it + 1;
+        }
         if (host_progress) __hip_atomic_store(host_progress, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
-  if (done | own_stop) return;
+  if (done | own_stop | test_only) return;
   const S bs = S(beta);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const S pn = it == 0 ? z[i] : z[i] + bs * pvec[i];

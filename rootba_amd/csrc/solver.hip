@@ -1811,11 +1811,12 @@ class Solver final : public rba_solver {
       volatile int* hp = h_progress_;
       hp[0] = 0;
       hp[1] = 0;
-      auto direction = [&]() {
+      auto direction = [&](bool test_only = false) {
         const bool pre = !ex_active_;
         hipLaunchKernelGGL((rba::k_pcgs_direction<S>), dim3(NB), dim3(256), 0, stream_, d_z_.get(), d_p_.get(),
                            d_q_.get(), n, st, part_rho, part_q1, static_cast<const S*>(pre ? prm_.pose_scaling : nullptr),
-                           pre ? d_xs_.get() : static_cast<S*>(nullptr), eta, min_it, max_it, h_progress_);
+                           pre ? d_xs_.get() : static_cast<S*>(nullptr), eta, min_it, max_it, h_progress_,
+                           test_only ? 1 : 0);
         return pre;
       };
       auto update = [&](int phase, const S* product) {
@@ -1834,6 +1835,11 @@ class Solver final : public rba_solver {
       bool running = true;
       for (; it <= max_it; ++it) {
         if (ex_ready_ && !explicit_off_for_solve_ && it > explicit_after_) {
+          // (the verdict on the iterations so far first: a solve that ends exactly here must not pay for an assembly)
+          if (it >= 3 && !ex_valid_) {
+            direction(true);
+            if (!(running = started(it))) break;
+          }
           if (!ex_valid_) assemble_explicit();
           ex_active_ = true;
           pcg_used_explicit_ = true;
