@@ -1,4 +1,5 @@
-// kernels_cam.hpp — camera-major passes over the CAMERA-MAJOR record copy (round 3).
+// kernels_cam.hpp — camera-major passes: the records of a camera's observations are GATHERED from landmark-major
+// storage (a camera-major copy was measured and dropped, see below), float and double on the matrix cores.
 //
 // Rows G, M of SURVEY.md 8a: Jp_diag2 / JACOBI blocks (add_Jp_diag2, add_Jp_T_Jp_blockdiag,
 // src/rootba/qr/impl/landmark_block_base.ipp:493-518, 554-569) and the SCHUR_JACOBI blocks + gradient of stage 2

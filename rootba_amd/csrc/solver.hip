@@ -1394,7 +1394,7 @@ class Solver final : public rba_solver {
                        d_sc_pair_oj_.get(), sc_n_upper_);
   }
 
-  // off-diagonal blocks of the explicit reduced matrix: matrix cores for float, VALU for double
+  // off-diagonal blocks of the explicit reduced matrix on the matrix cores of either precision (kernels_sc.hpp)
   void launch_offdiag(const S* topd, S* vals) {
     hipLaunchKernelGGL((rba::k_ex_offdiag_mfma<S>), dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_,
                        topd, vals, d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(), d_ex_pair_oi_.get(),
