@@ -89,6 +89,6 @@ if __name__ == "__main__":
         if not any(w == short or (w.endswith("*") and short.startswith(w[:-1])) for w in want):
             continue
         i = text.index("\n" + name + ":")
-        j = text.index("s_endpgm", i)
+        j = text.index(".Lfunc_end", i)  # (a kernel may hold several s_endpgm: early exits)
         print("==", short)
         print(trace(text[i:j]))
