@@ -476,6 +476,16 @@ def test_invalid_inputs_are_rejected(small_problem):
         LinearizorHIP(one, np.float32)
     with pytest.raises(RuntimeError, match="preconditioner_type"):  # linearizor_qr.cpp:208-240
         LinearizorHIP(small_problem, np.float32, L.default_options(preconditioner_type=3))
+    # NULL increments at the C ABI: an error code and a message, not a crash (inside rba_lm_step the increment stays on
+    # the device and the internal calls pass none - the public entries always exchange it)
+    import ctypes as C
+    g = LinearizorHIP(small_problem, np.float32)
+    assert g.linearize() == 0
+    cg = L.RbaCgSummary()
+    assert g.lib.rba_solve(g.h, C.c_double(1e-4), None, C.byref(cg)) == -1 and "inc_out" in L.last_error()
+    ld = C.c_double(0)
+    assert g.lib.rba_apply(g.h, None, C.byref(ld)) == -1 and "inc is NULL" in L.last_error()
+    assert g.lib.rba_back_substitute(g.h, None, C.byref(ld)) == -1
 
 
 def test_numerical_failure_is_reported_not_fatal(small_problem):
