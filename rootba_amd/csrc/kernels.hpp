@@ -99,8 +99,9 @@ __device__ __forceinline__ void finish_landmark(const Params<S>& p, int s, const
   const S* __restrict__ lm = p.lms + 3 * size_t(s);
   const S s0 = sc[0], s1 = sc[1], s2 = sc[2];
   const S l0 = lm[0], l1 = lm[1], l2 = lm[2];
-  const bool fin = is_finite(inc[0]) & is_finite(inc[1]) & is_finite(inc[2]) & is_finite(acc) & is_finite(l0) &
-                   is_finite(l1) & is_finite(l2);
+  // (bit-wise on purpose: `&&` would put the later operands - and their loads - behind branches)
+  const bool fin = (int(is_finite(inc[0])) & int(is_finite(inc[1])) & int(is_finite(inc[2])) & int(is_finite(acc)) &
+                    int(is_finite(l0)) & int(is_finite(l1)) & int(is_finite(l2))) != 0;
   p.lm_ldiff[s] = -double(acc);
   if (!fin) atomicOr(p.fail_flag, 2);
   const S d0 = inc[0] * s0, d1 = inc[1] * s1, d2 = inc[2] * s2;
