@@ -214,27 +214,29 @@ __device__ __forceinline__ bool linearize_obs(const S* __restrict__ cam, S pwx, 
   return pz >= Eps<S>::eps_sqrt;
 }
 
-// Eigen-style Givens coefficients: G^T [p; q] = [r; 0]
+// Eigen-style Givens coefficients: G^T [p; q] = [r; 0] (Eigen's makeGivens: the larger of |p|, |q|
+// is the divisor). Branch-free: the two general cases differ only in which operand is the divisor and where the
+// results go, so ONE division, one square root and one reciprocal serve both (as four-way branches the lanes of a wave
+// - neighbouring landmarks - diverge and every wave pays for both cases: 25 of the 70 division / square-root
+// instructions per rotation; k_s2_obs evaluates six rotations per work-item). Every lane performs exactly the
+// operations of its own case in the same order: the results are those of the branches bit for bit (up to the sign of a
+// zero); q == 0 (which includes p == q == 0, where the general formula would divide zero by zero) is selected last.
 template <class S>
 __device__ __forceinline__ void make_givens(S p, S q, S& c, S& s) {
+  const bool p_is_divisor = fabs(p) > fabs(q);
+  const S den = p_is_divisor ? p : q, num = p_is_divisor ? q : p;
+  const S t = num / den;
+  S u = sqrt(S(1) + t * t);
+  if (den < S(0)) u = -u;
+  const S inv = S(1) / u;
+  // |p| > |q|: c = 1 / u, s = -t c.        else: s = -1 / u, c = -t s.
+  const S first = p_is_divisor ? inv : -inv;
+  const S second = -t * first;
+  c = p_is_divisor ? first : second;
+  s = p_is_divisor ? second : first;
   if (q == S(0)) {
     c = p < S(0) ? S(-1) : S(1);
     s = S(0);
-  } else if (p == S(0)) {
-    c = S(0);
-    s = q < S(0) ? S(1) : S(-1);
-  } else if (fabs(p) > fabs(q)) {
-    const S t = q / p;
-    S u = sqrt(S(1) + t * t);
-    if (p < S(0)) u = -u;
-    c = S(1) / u;
-    s = -t * c;
-  } else {
-    const S t = p / q;
-    S u = sqrt(S(1) + t * t);
-    if (q < S(0)) u = -u;
-    s = -S(1) / u;
-    c = -t * s;
   }
 }
 

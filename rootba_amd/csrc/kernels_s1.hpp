@@ -467,6 +467,12 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
 // observation - measured faster than a separate thread-per-landmark pass + a 64-byte record load, venice stage 2
 // 0.443 -> 0.402 ms); the work-item of a landmark's FIRST observation also writes the landmark's records (givens,
 // damped R, Q1^T r, damping-row residual, Z).
+// What bounds the pass (127-133 us on venice for 0.58 GB): neither its arithmetic - the branch-free make_givens took
+// 26 % of its instructions out, 1318 -> 969, without moving the time - nor the chain of dependent loads - with the
+// observation's position in its landmark stored per observation the chain is two round trips instead of three: 129 ->
+// 128 us, not kept - which leaves the ~40 sparse stores of the landmark records from one lane in five (measured
+// elsewhere this round: scattered partial-line writes are what the memory system likes least). Staging them through LDS
+// into contiguous stores is the open item.
 // ---------------------------------------------------------------------------
 template <class S>
 __global__ __launch_bounds__(256) void k_s2_obs(Params<S> p, int64_t n_obs, S lambda) {
