@@ -470,16 +470,30 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
 // What bounds the pass (127-133 us on venice for 0.58 GB): neither its arithmetic - the branch-free make_givens took
 // 26 % of its instructions out, 1318 -> 969, without moving the time - nor the chain of dependent loads - with the
 // observation's position in its landmark stored per observation the chain is two round trips instead of three: 129 ->
-// 128 us, not kept - which leaves the ~40 sparse stores of the landmark records from one lane in five (measured
-// elsewhere this round: scattered partial-line writes are what the memory system likes least). Staging them through LDS
-// into contiguous stores is the open item.
+// 128 us, not kept - which left the ~40 sparse stores of the landmark records from one lane in five (measured
+// elsewhere this round: scattered partial-line writes are what the memory system likes least): they are staged in LDS
+// and leave as contiguous stores of the workgroup.
 // ---------------------------------------------------------------------------
 template <class S>
 __global__ __launch_bounds__(256) void k_s2_obs(Params<S> p, int64_t n_obs, S lambda) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
-  const int64_t o = blockIdx.x * int64_t(256) + threadIdx.x;
-  if (o >= n_obs) return;
+  // The landmark records (rotations 16, damped triangle 6, damped Q1^T r 3, damping-row residual 3, Z 9) of the
+  // landmarks whose FIRST observation lies in this workgroup - consecutive landmarks sA .. sA + nH - 1, at most 128
+  // (k >= 2) - are staged here and leave as contiguous stores of the whole workgroup: written straight from the
+  // first-observation work-items they were ~40 sparse stores from one lane in five, which is what bounded the pass.
+  constexpr int kHeadsMax = 128, kLmRec = 37, kOffRd = 16, kOffQ = 22, kOffDr = 25, kOffZ = 28;
+  __shared__ S lmrec[kHeadsMax * kLmRec];
+  const int tid = threadIdx.x;
+  const int64_t o_base = blockIdx.x * int64_t(256);
+  const bool valid = o_base + tid < n_obs;
+  const int64_t o = valid ? o_base + tid : n_obs - 1;  // (clamped: the spare lanes of the last workgroup store nothing)
   const int s = p.obs_lm[o];
+  int sA, nH;
+  {
+    const int s_first = p.obs_lm[o_base], s_last = p.obs_lm[min(o_base + 255, n_obs - 1)];  // (workgroup-uniform)
+    sA = p.lm_obs[s_first] == o_base ? s_first : s_first + 1;
+    nH = s_last - sA + 1;
+  }
   const V4* __restrict__ vh = reinterpret_cast<const V4*>(p.Vh);
   const V4 va = vh[2 * o], vb = vh[2 * o + 1];
   const int64_t o0 = p.lm_obs[s];
@@ -534,23 +548,22 @@ __global__ __launch_bounds__(256) void k_s2_obs(Params<S> p, int64_t n_obs, S la
   g[13] = D[1][3];
   g[14] = D[2][3];
   g[15] = S(0);
-  if (i == 0) {
-    S* grec = p.givens + 16 * size_t(s);
+  if (valid && i == 0) {
+    S* rec = lmrec + kLmRec * (s - sA);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) grec[q] = g[q];
-    S* R = p.Rd + 6 * size_t(s);
-    R[0] = T[0][0];
-    R[1] = T[0][1];
-    R[2] = T[0][2];
-    R[3] = T[1][1];
-    R[4] = T[1][2];
-    R[5] = T[2][2];
-    p.q1trd[3 * size_t(s) + 0] = T[0][3];
-    p.q1trd[3 * size_t(s) + 1] = T[1][3];
-    p.q1trd[3 * size_t(s) + 2] = T[2][3];
-    p.damp_r[3 * size_t(s) + 0] = D[0][3];
-    p.damp_r[3 * size_t(s) + 1] = D[1][3];
-    p.damp_r[3 * size_t(s) + 2] = D[2][3];
+    for (int q = 0; q < 16; ++q) rec[q] = g[q];
+    rec[kOffRd + 0] = T[0][0];
+    rec[kOffRd + 1] = T[0][1];
+    rec[kOffRd + 2] = T[0][2];
+    rec[kOffRd + 3] = T[1][1];
+    rec[kOffRd + 4] = T[1][2];
+    rec[kOffRd + 5] = T[2][2];
+    rec[kOffQ + 0] = T[0][3];
+    rec[kOffQ + 1] = T[1][3];
+    rec[kOffQ + 2] = T[2][3];
+    rec[kOffDr + 0] = D[0][3];
+    rec[kOffDr + 1] = D[1][3];
+    rec[kOffDr + 2] = D[2][3];
     {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -578,9 +591,9 @@ __global__ __launch_bounds__(256) void k_s2_obs(Params<S> p, int64_t n_obs, S la
             u[n] = g[6 + idx] * x + g[idx] * y;
           }
         }
-        p.Zd[9 * size_t(s) + 0 + j] = u[0];
-        p.Zd[9 * size_t(s) + 3 + j] = u[1];
-        p.Zd[9 * size_t(s) + 6 + j] = u[2];
+        rec[kOffZ + 0 + j] = u[0];
+        rec[kOffZ + 3 + j] = u[1];
+        rec[kOffZ + 6 + j] = u[2];
       }
     }
   }
@@ -623,11 +636,28 @@ __global__ __launch_bounds__(256) void k_s2_obs(Params<S> p, int64_t n_obs, S la
     out[e][2] = tt[2];
     out[e][3] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
   }
-  store_cam_record_stage2<S>(p, o, out);
-  if (o >= p.w8_begin) {  // landmarks with k > 32: the two-kernel back-substitution applies W' itself
-    V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * (o - p.w8_begin));
-    dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};
-    dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
+  if (valid) {
+    store_cam_record_stage2<S>(p, o, out);
+    if (o >= p.w8_begin) {  // landmarks with k > 32: the two-kernel back-substitution applies W' itself
+      V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * (o - p.w8_begin));
+      dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};
+      dst[1] = V4{out[0][2], out[1][2], out[0][3], out[1][3]};
+    }
+  }
+  // ---- the staged landmark records (last: nothing of the per-observation part is live across the barrier) ----
+  __syncthreads();
+  {
+    // contiguous copy-out: element t of an array's part belongs to record t / width, entry t % width
+    for (int t = tid; t < 4 * nH; t += 256) {
+      const S* r = lmrec + kLmRec * (t >> 2) + 4 * (t & 3);
+      reinterpret_cast<V4*>(p.givens + 16 * size_t(sA))[t] = V4{r[0], r[1], r[2], r[3]};
+    }
+    for (int t = tid; t < 6 * nH; t += 256) p.Rd[6 * size_t(sA) + t] = lmrec[kLmRec * (t / 6) + kOffRd + t % 6];
+    for (int t = tid; t < 3 * nH; t += 256) {
+      p.q1trd[3 * size_t(sA) + t] = lmrec[kLmRec * (t / 3) + kOffQ + t % 3];
+      p.damp_r[3 * size_t(sA) + t] = lmrec[kLmRec * (t / 3) + kOffDr + t % 3];
+    }
+    for (int t = tid; t < 9 * nH; t += 256) p.Zd[9 * size_t(sA) + t] = lmrec[kLmRec * (t / 9) + kOffZ + t % 9];
   }
 }
 
