@@ -1631,7 +1631,8 @@ class Solver final : public rba_solver {
     auto wait_for = [&](int it, int ahead) {
       long spins = 0;
       while (!hp[1] && it - hp[0] > ahead)
-        if ((++spins & 0x3fff) == 0 && hipStreamQuery(stream_) == hipSuccess) break;  // nothing left in flight
+        // (nothing left in flight - or the stream has failed: the next synchronisation reports it)
+        if ((++spins & 0x3fff) == 0 && hipStreamQuery(stream_) != hipErrorNotReady) break;
       return hp[1] == 0;
     };
     int it = it_start;
@@ -1829,7 +1830,7 @@ class Solver final : public rba_solver {
       auto started = [&](int k) {
         long spins = 0;
         while (!hp[1] && hp[0] < k)
-          if ((++spins & 0x3fff) == 0 && hipStreamQuery(stream_) == hipSuccess) break;
+          if ((++spins & 0x3fff) == 0 && hipStreamQuery(stream_) != hipErrorNotReady) break;  // idle or failed
         return hp[1] == 0;
       };
       bool running = true;
