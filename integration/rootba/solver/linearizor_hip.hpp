@@ -96,6 +96,15 @@ class LinearizorHIP : public LinearizorBase<Scalar_>, public HostStateSync {
   //    (bal_bundle_adjustment.cpp:401, 509): apply() takes the matching device-side backup (rba_backup), and a
   //    restore() is RECOGNISED at the next call by the cameras of BalProblem being those of the backup again, upon
   //    which the device restores too (rba_restore) - no upload;
+  //  * that recognition needs the step to have CHANGED the cameras. A step that leaves every camera parameter
+  //    bit-identical (a zero camera increment: the PCG ended with x = 0 - |b| = 0 or a numerical failure at its first
+  //    iteration - and only landmarks moved) makes "restored" and "not restored" look alike from here: BalProblem's
+  //    cameras equal the backup either way and its landmarks are stale either way. apply() then does not try to infer
+  //    anything: it brings the moved landmarks to BalProblem at once, and until the next step every call compares
+  //    BalProblem's LANDMARKS with that copy as well: if they differ the driver has restored (whatever its backup held
+  //    - landmarks that were stale already when it was taken, possibly - differs from the moved ones), and the device
+  //    restores its own twin of the backup. BalProblem's restored landmarks are never uploaded: they are only as
+  //    complete as they were when the driver backed them up;
   //  * any other change of the cameras (the caller edited the problem) falls back to a full upload, after the
   //    pending landmark download so that BalProblem really is complete; callers that edit LANDMARKS announce it with
   //    host_state_changed().
@@ -131,6 +140,7 @@ class LinearizorHIP : public LinearizorBase<Scalar_>, public HostStateSync {
   // LinearizorQR::linearize (linearizor_qr.cpp:78-138)
   void linearize() override {
     Timer<> timer;
+    ensure_device_state();
     const int st = rba_linearize(h_, nullptr);
     CHECK(st == RBA_OK) << "did not expect numerical failure during linearization (" << rba_last_error() << ")";
     if (it_summary_) it_summary_->stage1_time_in_seconds = timer.elapsed();
@@ -177,6 +187,14 @@ class LinearizorHIP : public LinearizorBase<Scalar_>, public HostStateSync {
     }
     download_cameras();
     host_lms_stale_ = true;
+    if (host_cams_ == host_cams_backup_) {
+      // the step moved no camera: a bal_problem.restore() would be invisible in BalProblem's cameras (see "state
+      // protocol"). BalProblem gets the moved landmarks now; ensure_device_state() compares them from here on.
+      sync_host();
+      lms_tracked_ = true;
+    } else {
+      lms_tracked_ = false;
+    }
     return Scalar(l_diff);
   }
 
@@ -201,6 +219,7 @@ class LinearizorHIP : public LinearizorBase<Scalar_>, public HostStateSync {
       for (int k = 0; k < 3; ++k) lms_[size_t(3) * l + k] = bal_problem_.landmarks()[l].p_w(k);
     CHECK(rba_set_state(h_, cams_.data(), lms_.data()) == RBA_OK) << rba_last_error();
     have_backup_ = false;
+    lms_tracked_ = false;
   }
   // device cameras -> BalProblem (Camera::from_params, bal_problem.hpp:91-95); `host_cams_` then records what
   // BalProblem REPORTS (from_params normalises the quaternion), the reference value of the change detection
@@ -216,17 +235,27 @@ class LinearizorHIP : public LinearizorBase<Scalar_>, public HostStateSync {
   // make the device hold the state BalProblem describes (see "state protocol" above)
   void ensure_device_state() {
     read_host_cameras(probe_);
-    if (probe_ == host_cams_) return;  // nothing happened on the host side (the common case)
+    const bool cams_same = probe_ == host_cams_;
+    if (cams_same && !lms_tracked_) return;               // nothing happened on the host side (the common case)
+    if (cams_same && host_landmarks_are(lms_)) return;    // ... after a step that moved no camera the landmarks decide
     if (have_backup_ && probe_ == host_cams_backup_) {
-      // bal_problem.restore() after a rejected step: the device restores its twin of that backup
+      // bal_problem.restore() after a rejected step (cameras back at the backup; after a landmark-only step: cameras
+      // unchanged, landmarks no longer the moved ones): the device restores its twin of that backup
       CHECK(rba_restore(h_) == RBA_OK) << rba_last_error();
       host_cams_ = host_cams_backup_;
       host_lms_stale_ = stale_at_backup_;
+      lms_tracked_ = false;
       return;
     }
     // the caller changed the cameras: complete BalProblem first (landmarks it has not seen yet), then upload
     sync_host();
     upload();
+  }
+  bool host_landmarks_are(const std::vector<Scalar>& v) const {
+    for (int l = 0; l < bal_problem_.num_landmarks(); ++l)
+      for (int k = 0; k < 3; ++k)
+        if (!(bal_problem_.landmarks()[l].p_w(k) == v[size_t(3) * l + k])) return false;
+    return true;
   }
 
   rba_handle h_ = nullptr;
@@ -234,6 +263,9 @@ class LinearizorHIP : public LinearizorBase<Scalar_>, public HostStateSync {
   std::vector<Scalar> host_cams_, host_cams_backup_, probe_;  // BalProblem's cameras as last seen / at the backup
   bool host_lms_stale_ = false;  // the device holds newer landmarks than BalProblem
   bool stale_at_backup_ = false, have_backup_ = false;
+  // the last step moved no camera: BalProblem's landmarks were completed and `lms_` is the copy of what the device
+  // holds - compared at every call until a step moves a camera again
+  bool lms_tracked_ = false;
 };
 
 }  // namespace rootba

@@ -6,6 +6,8 @@
 // the product: nothing in rootba_amd/ or include/ knows about it, it is built into oracle/_ref/ only, and the real
 // library keeps failing loudly when there is no GPU (tests/test_cabi_cpu.py). Only the entry points the binding calls
 // are defined.
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -27,6 +29,12 @@ struct Mock {
   int dtype;
   orc::Oracle<float>* f = nullptr;
   orc::Oracle<double>* d = nullptr;
+  // Test hook (tests/test_reference_loop_on_hip.py): RBA_MOCK_ZERO_INC_SOLVE=n makes the n-th rba_solve of a handle
+  // return a ZERO camera increment - what the real library returns when its PCG ends with x = 0 (|b| = 0, numerical
+  // failure at the first iteration) - and the rba_apply that follows report a negative model cost change, so that the
+  // reference's LM loop rejects the landmark-only step and calls bal_problem.restore() behind the binding's back.
+  int zero_inc_solve = 0, solves = 0;
+  bool negate_next_l_diff = false;
 };
 orc::Options to_orc(const rba_options& o) {
   orc::Options d;
@@ -93,6 +101,7 @@ int rba_create(int dtype, int /*device*/, int32_t n_cams, int32_t n_lms, const i
                const void* xy, const rba_options* options, rba_handle* out) {
   return guarded([&] {
     auto* m = new Mock{dtype};
+    if (const char* ev = std::getenv("RBA_MOCK_ZERO_INC_SOLVE")) m->zero_inc_solve = std::atoi(ev);
     if (dtype == RBA_F32)
       m->f = new orc::Oracle<float>(n_cams, n_lms, off, cam, static_cast<const float*>(xy), to_orc(*options));
     else if (dtype == RBA_F64)
@@ -187,18 +196,38 @@ int rba_solve(rba_handle h, double lambda, void* inc_out, rba_cg_summary* cg) {
     cg->termination_type = s.termination_type;
     cg->num_iterations = s.num_iterations;
   }
+  {
+    auto* mk = reinterpret_cast<Mock*>(h);
+    if (++mk->solves == mk->zero_inc_solve) {
+      const size_t n = size_t(9) * (mk->f ? mk->f->n_cams() : mk->d->n_cams());
+      std::memset(inc_out, 0, n * (mk->f ? sizeof(float) : sizeof(double)));
+      mk->negate_next_l_diff = true;
+    }
+  }
   return RBA_OK;
 }
 int rba_apply(rba_handle h, const void* inc, double* l_diff_out) {
   double l = 0;
+  // (hooked step: the cameras stay BIT-identical - a retraction by zero may re-normalise the quaternion's last bit, and
+  //  the case under test is the one where it does not)
+  const bool keep_cams = reinterpret_cast<Mock*>(h)->negate_next_l_diff;
   MOCK_DISPATCH(({
                   std::vector<S> v(static_cast<const S*>(inc), static_cast<const S*>(inc) + size_t(9) * o->n_cams());
+                  const auto cams = o->cams();
                   l = double(o->apply(std::move(v)));
+                  if (keep_cams) std::copy(cams.begin(), cams.end(), o->cams().begin());
                 }),
                 ({
                   std::vector<S> v(static_cast<const S*>(inc), static_cast<const S*>(inc) + size_t(9) * o->n_cams());
+                  const auto cams = o->cams();
                   l = double(o->apply(std::move(v)));
+                  if (keep_cams) std::copy(cams.begin(), cams.end(), o->cams().begin());
                 }))
+  {
+    auto* mk = reinterpret_cast<Mock*>(h);
+    if (mk->negate_next_l_diff) l = -std::abs(l) - 1e-30;
+    mk->negate_next_l_diff = false;
+  }
   *l_diff_out = l;
   return std::isfinite(l) ? RBA_OK : RBA_NUMERICAL_FAILURE;
 }

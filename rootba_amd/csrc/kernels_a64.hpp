@@ -1,0 +1,330 @@
+// kernels_a64.hpp — the ASSEMBLED reduced camera matrix of a FLOAT solver, evaluated in DOUBLE from the float factors.
+//
+// Why. Long PCG solves run on the assembled matrix S = sum_l A_l^T A_l instead of the matrix-free product
+// (solver.hip: pcg()). Rounds 2-3 assembled and stored S in float: S~ = S + E with |E| ~ eps |S|, and
+// the curvature p^T S~ p of a near-null direction then carries a relative error eps * kappa(S) where the square-root
+// product |A p|^2 (orthogonal transformations applied to J p, the reason the reference's solver exists,
+// src/rootba/qr/linearization_qr.hpp:406-429) carries eps * sqrt(kappa): increments of 150-500-iteration solves were
+// 3-10 x further from the float64 iterate than the float32 reference's. ANY float storage of
+// S has that error, however the entries are computed. So the matrix is DOUBLE - and it is computed in double from
+// the float factors in a way that keeps it the exact (to 1e-16) reduced camera matrix of a nearby (eps_float
+// backward error in J, the class of the matrix-free float product) problem:
+//
+//   * reflectors: the float vectors v_m are kept, tau_m is RE-DERIVED as 2 / (v_m^T v_m) in double, which makes every
+//     H_m = I - tau_m v_m v_m^T orthogonal to double precision (the float tau makes it orthogonal to 6e-8 only);
+//     the products v_a^T v_b of the compact application are re-summed in double as well (k_a64_landmark);
+//   * landmark damping: the six rotations are re-evaluated in double from the float triangle R0 and lambda
+//     (c^2 + s^2 = 1 to 1e-16), so the 3 x 2 coefficient block W' of an observation (its rows of the damped Q1) is a
+//     piece of an orthogonal matrix to double precision;
+//   * with that, the identities the float assembly relied on hold to 1e-16 instead of 6e-8:
+//        diagonal block      sum_o (A_o Jp_o D)^T (A_o Jp_o D),   A_o^T A_o = I - W'_o^T W'_o      (k_a64_diag)
+//        off-diagonal block  - sum_l (W'_i Jp_i D)^T (W'_j Jp_j D)                                  (k_ex_offdiag_mfma<double>)
+//     The Jacobian rows Jp (float, exact inputs) and the Jacobi scaling D (float) enter as they are.
+// The PCG vectors stay float, as in the float reference; k_pcgs_spmv multiplies double blocks with float operands
+// in double (kernels_pcg.hpp). Cost on venice-1778: see DESIGN.md 3c.
+#pragma once
+
+#include "kernels_cam.hpp"
+#include "kernels_sc.hpp"
+
+namespace rba {
+
+struct A64Params {
+  int n_cams, n_lms;
+  const int* __restrict__ lm_k;
+  const int64_t* __restrict__ lm_obs;
+  const int* __restrict__ obs_cam;
+  const int* __restrict__ obs_lm;
+  const int64_t* __restrict__ cam_obs_off;
+  const int* __restrict__ cam_obs;
+  const float* __restrict__ JpS;           // [n_obs][18]
+  const float* __restrict__ Vh;            // [2 n_obs][4]
+  const float* __restrict__ tauH;          // [3 n_lms] (only its zeros are used: a skipped reflector stays skipped)
+  const float* __restrict__ R0;            // [6 n_lms]
+  const float* __restrict__ pose_scaling;  // [9 n_cams]
+  double* LQ;    // [n_lms][8]  tau0 tau1 tau2 g10 g20 g21 - -   (double re-derivation of Params::LQ)
+  double* A;     // [n_obs][4]  2x2 factor A, A^T A = I - W'^T W'
+  double* topd;  // [n_obs][kTd] damped Q1^T Jp D (3 x 9, padded)
+};
+
+constexpr int kA64Lq = 8;
+
+// the six sums of one landmark's reflector rows -> tau (double), cross products
+__device__ __forceinline__ void a64_store_lq(const A64Params& p, int s, const double n[3], double g10, double g20,
+                                             double g21) {
+  double* lq = p.LQ + size_t(kA64Lq) * s;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) lq[m] = p.tauH[3 * s + m] == 0.0f ? 0.0 : 2.0 / n[m];
+  lq[3] = g10;
+  lq[4] = g20;
+  lq[5] = g21;
+  lq[6] = lq[7] = 0.0;
+}
+
+// short tracks: one work-item per landmark walks its 2k rows (16 bytes each, consecutive)
+__global__ __launch_bounds__(256) void k_a64_landmark(A64Params p, int lm_begin, int lm_end) {
+  const int s = lm_begin + blockIdx.x * 256 + threadIdx.x;
+  if (s >= lm_end) return;
+  const int nrows = 2 * p.lm_k[s];
+  const float4* __restrict__ vh = reinterpret_cast<const float4*>(p.Vh) + 2 * p.lm_obs[s];
+  double n[3] = {0, 0, 0}, g10 = 0, g20 = 0, g21 = 0;
+  for (int r = 0; r < nrows; ++r) {
+    const float4 v = vh[r];
+    const double v0 = v.x, v1 = v.y, v2 = v.z;
+    n[0] += v0 * v0;
+    n[1] += v1 * v1;
+    n[2] += v2 * v2;
+    g10 += v1 * v0;
+    g20 += v2 * v0;
+    g21 += v2 * v1;
+  }
+  a64_store_lq(p, s, n, g10, g20, g21);
+}
+
+// long tracks: one wavefront per landmark
+__global__ __launch_bounds__(256) void k_a64_landmark_wave(A64Params p, int lm_begin, int lm_end) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;
+  const int nrows = 2 * p.lm_k[s];
+  const float4* __restrict__ vh = reinterpret_cast<const float4*>(p.Vh) + 2 * p.lm_obs[s];
+  double n[3] = {0, 0, 0}, g10 = 0, g20 = 0, g21 = 0;
+  for (int r = lane; r < nrows; r += 64) {
+    const float4 v = vh[r];
+    const double v0 = v.x, v1 = v.y, v2 = v.z;
+    n[0] += v0 * v0;
+    n[1] += v1 * v1;
+    n[2] += v2 * v2;
+    g10 += v1 * v0;
+    g20 += v2 * v0;
+    g21 += v2 * v1;
+  }
+#pragma unroll
+  for (int m = 0; m < 3; ++m) n[m] = wave_sum(n[m]);
+  g10 = wave_sum(g10);
+  g20 = wave_sum(g20);
+  g21 = wave_sum(g21);
+  if (lane == 0) a64_store_lq(p, s, n, g10, g20, g21);
+}
+
+// One work-item per observation (the double twin of k_s2_obs + k_s12_cols, without the b part): the landmark's six
+// damping rotations, the observation's coefficient block W' (3 x 2), the factor A of I - W'^T W', and the record
+// W' (Jp D) of damped top rows. The workgroup's observations are consecutive: Jacobian rows in and records out move
+// as contiguous 16-byte streams through LDS.
+constexpr int kA64Threads = 128;
+constexpr int kA64TdLds = 33;  // LDS stride (doubles) of a staged record: odd, conflict-free column writes
+
+__global__ __launch_bounds__(kA64Threads) void k_a64_obs(A64Params p, int64_t n_obs, double lambda) {
+  constexpr int NT = kA64Threads;
+  extern __shared__ __attribute__((aligned(16))) char smem_a64[];
+  double* sT = reinterpret_cast<double*>(smem_a64);        // [NT][kA64TdLds]
+  float* sJ = reinterpret_cast<float*>(sT + NT * kA64TdLds);  // [NT][18]
+  const int tid = threadIdx.x;
+  const int64_t o_base = int64_t(blockIdx.x) * NT;
+  const int n_here = int(min<int64_t>(NT, n_obs - o_base));
+  const bool act = tid < n_here;
+  const int64_t o = act ? o_base + tid : o_base;
+  {
+    const float* src = p.JpS + 18 * o_base;
+    const int total = 18 * n_here, nvec = total / 4;
+    for (int i = tid; i < nvec; i += NT) reinterpret_cast<float4*>(sJ)[i] = reinterpret_cast<const float4*>(src)[i];
+    for (int i = nvec * 4 + tid; i < total; i += NT) sJ[i] = src[i];
+  }
+  const int s = p.obs_lm[o];
+  const int cam = p.obs_cam[o];
+  const float4* __restrict__ vh = reinterpret_cast<const float4*>(p.Vh);
+  const float4 va = vh[2 * o], vb = vh[2 * o + 1];
+  const int64_t o0 = p.lm_obs[s];
+  const float4 w0 = vh[2 * o0], w1 = vh[2 * o0 + 1], w2 = vh[2 * o0 + 2];
+  const double* __restrict__ lq = p.LQ + size_t(kA64Lq) * s;
+  const double tau0 = lq[0], tau1 = lq[1], tau2 = lq[2], g10 = lq[3], g20 = lq[4], g21 = lq[5];
+  float dscf[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) dscf[c] = p.pose_scaling[9 * cam + c];
+  const float* __restrict__ R = p.R0 + 6 * size_t(s);
+  const float r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4], r5 = R[5];
+  const int i = int(o - o0);
+  // ---- the landmark's damping rotations (set_landmark_damping, landmark_block_base.ipp:165-210) in double ----
+  double T[3][3] = {{double(r0), double(r1), double(r2)}, {0.0, double(r3), double(r4)}, {0.0, 0.0, double(r5)}};
+  double D[3][3];
+  const double sl = sqrt(lambda);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) D[a][b] = (a == b) ? sl : 0.0;
+  double gc[6], gs[6];
+  {
+    int idx = 0;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+#pragma unroll
+      for (int m = 0; m <= n; ++m) {
+        double c = 1.0, sn = 0.0;
+        if (lambda != 0.0) make_givens<double>(T[n][n], D[n - m][n], c, sn);
+        gc[idx] = c;
+        gs[idx] = sn;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const double x = D[n - m][b], y = T[n][b];
+          D[n - m][b] = c * x + sn * y;
+          T[n][b] = -sn * x + c * y;
+        }
+        ++idx;
+      }
+    }
+  }
+  // ---- W' (3 x 2): the damped top rows of Q^T applied to the unit entries of the observation's two rows ----
+  double W[3][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const double m0 = e == 0 ? 1.0 : 0.0, m1 = e == 0 ? 0.0 : 1.0;
+    const double c0 = tau0 * (double(va.x) * m0 + double(vb.x) * m1);
+    const double c1 = tau1 * (double(va.y) * m0 + double(vb.y) * m1 - c0 * g10);
+    const double c2 = tau2 * (double(va.z) * m0 + double(vb.z) * m1 - c0 * g20 - c1 * g21);
+    double tt[3] = {-(c0 * double(w0.x) + c1 * double(w0.y) + c2 * double(w0.z)),
+                    -(c0 * double(w1.x) + c1 * double(w1.y) + c2 * double(w1.z)),
+                    -(c0 * double(w2.x) + c1 * double(w2.y) + c2 * double(w2.z))};
+    if (i == 0) {
+      tt[0] += m0;
+      tt[1] += m1;
+    } else if (i == 1) {
+      tt[2] += m0;
+    }
+    double d[3] = {0.0, 0.0, 0.0};
+    int idx = 0;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+#pragma unroll
+      for (int m = 0; m <= n; ++m) {
+        const double x = d[n - m], y = tt[n];
+        d[n - m] = gc[idx] * x + gs[idx] * y;
+        tt[n] = -gs[idx] * x + gc[idx] * y;
+        ++idx;
+      }
+    }
+    W[0][e] = tt[0];
+    W[1][e] = tt[1];
+    W[2][e] = tt[2];
+  }
+  // ---- A: Cholesky of M = I - W'^T W' with the larger diagonal entry as pivot (kernels_cam.hpp) ----
+  {
+    const double m00 = 1.0 - (W[0][0] * W[0][0] + W[1][0] * W[1][0] + W[2][0] * W[2][0]);
+    const double m01 = -(W[0][0] * W[0][1] + W[1][0] * W[1][1] + W[2][0] * W[2][1]);
+    const double m11 = 1.0 - (W[0][1] * W[0][1] + W[1][1] * W[1][1] + W[2][1] * W[2][1]);
+    double a00, a01, a10, a11;
+    if (m00 >= m11) {
+      a00 = sqrt(fmax(m00, 0.0));
+      a01 = a00 > 0.0 ? m01 / a00 : 0.0;
+      a10 = 0.0;
+      a11 = sqrt(fmax(m11 - a01 * a01, 0.0));
+    } else {
+      a11 = sqrt(fmax(m11, 0.0));
+      a10 = a11 > 0.0 ? m01 / a11 : 0.0;
+      a01 = 0.0;
+      a00 = sqrt(fmax(m00 - a10 * a10, 0.0));
+    }
+    if (act) {
+      double2* dst = reinterpret_cast<double2*>(p.A + 4 * o);
+      dst[0] = double2{a00, a01};
+      dst[1] = double2{a10, a11};
+    }
+  }
+  __syncthreads();  // sJ complete
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const double dc = double(dscf[c]);
+      const double m0 = double(sJ[18 * tid + c]) * dc, m1 = double(sJ[18 * tid + 9 + c]) * dc;
+      sT[kA64TdLds * tid + c] = W[0][0] * m0 + W[0][1] * m1;
+      sT[kA64TdLds * tid + 9 + c] = W[1][0] * m0 + W[1][1] * m1;
+      sT[kA64TdLds * tid + 18 + c] = W[2][0] * m0 + W[2][1] * m1;
+    }
+#pragma unroll
+    for (int c = 27; c < kTd; ++c) sT[kA64TdLds * tid + c] = 0.0;
+  }
+  __syncthreads();
+  {
+    double* dst = p.topd + size_t(kTd) * o_base;
+    for (int q = tid; q < n_here * kTd; q += NT) dst[q] = sT[kA64TdLds * (q / kTd) + (q % kTd)];
+  }
+}
+
+// Diagonal blocks, one workgroup per camera (the double twin of k_cam_pass_mfma<S, 0>'s K part): gathers the float
+// Jacobian rows (72 B) and the double factor A (32 B) of the camera's observations, Y = A Jp in double, K = sum Y^T Y
+// on v_mfma_f64_16x16x4_f64 (two observations per instruction), vals[diag] = D K D (no pose damping: the product adds
+// lambda x).
+__global__ __launch_bounds__(256) void k_a64_diag(A64Params p, const int* __restrict__ diag_slot,
+                                                  double* __restrict__ vals) {
+  using M = Mfma<double>;
+  using Acc = typename M::acc;
+  constexpr int CH = kCamChunk, RW = 22;  // staged record: [Jp 18 | A 4]
+  __shared__ __attribute__((aligned(16))) double stage[4][CH * RW];
+  __shared__ double tile[4][16][16];
+  const int c = xcd_swizzled_camera(p.n_cams);
+  if (c >= p.n_cams) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  Acc accK = {0, 0, 0, 0}, accK2 = {0, 0, 0, 0};
+  const int i = lane & 15, kk = lane >> 4;
+  double* lds = stage[wave];
+  int idxreg = t1 > t0 ? p.cam_obs[min<int64_t>(t0 + CH * wave + lane, t1 - 1)] : 0;
+  for (int64_t base = t0 + CH * wave; base < t1; base += 4 * CH) {
+    const int cnt = int(min<int64_t>(CH, t1 - base));
+    const int idxnext = p.cam_obs[min<int64_t>(base + 4 * CH + lane, t1 - 1)];
+    constexpr int NJ = (CH * 9 + 63) / 64;
+    float2 jv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int q = j * 64 + lane;
+      const int r = q / 9, pc = q - 9 * r;
+      const int o = __shfl(idxreg, r & 31);
+      jv[j] = *reinterpret_cast<const float2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
+    }
+    double2 w;
+    {
+      const int o = __shfl(idxreg, (lane >> 1) & 31);
+      w = *reinterpret_cast<const double2*>(p.A + int64_t(o) * 4 + 2 * (lane & 1));
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int q = j * 64 + lane;
+      const int r = q / 9, pc = q - 9 * r;
+      if (q < cnt * 9) *reinterpret_cast<double2*>(lds + r * RW + 2 * pc) = double2{double(jv[j].x), double(jv[j].y)};
+    }
+    {
+      const int r = lane >> 1, h = lane & 1;
+      if (r < cnt) *reinterpret_cast<double2*>(lds + r * RW + 18 + 2 * h) = w;
+    }
+    wave_lds_fence();
+    for (int s = 0; s < cnt; s += 4) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int so = s + 2 * h + (kk >> 1);
+        double v = 0.0;
+        if (i < 9 && so < cnt) {
+          const double* rec = lds + so * RW;
+          const double* arow = rec + 18 + 2 * (kk & 1);
+          v = fma(arow[0], rec[i], arow[1] * rec[9 + i]);
+        }
+        if (h == 0)
+          accK = M::mma(v, v, accK);
+        else
+          accK2 = M::mma(v, v, accK2);
+      }
+    }
+    wave_lds_fence();  // the next chunk overwrites the staging buffer
+    idxreg = idxnext;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) accK[r] += accK2[r];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[wave][M::row(lane, r)][lane & 15] = accK[r];
+  __syncthreads();
+  if (tid < 81) {
+    const int ii = tid / 9, jj = tid - 9 * ii;
+    const double t = (tile[0][ii][jj] + tile[1][ii][jj]) + (tile[2][ii][jj] + tile[3][ii][jj]);
+    vals[size_t(81) * diag_slot[c] + tid] = t * double(p.pose_scaling[9 * c + ii]) * double(p.pose_scaling[9 * c + jj]);
+  }
+}
+
+}  // namespace rba

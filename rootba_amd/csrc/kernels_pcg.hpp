@@ -101,17 +101,18 @@ struct ChunkStage {
   }
 };
 
-// lane j multiplies ITS block out of LDS (lane stride 81 words: conflict-free)
-template <class S>
-__device__ __forceinline__ void spmv_block_times(const S* lds, int off, int lane, bool act, const S xv[9],
+// lane j multiplies ITS block out of LDS (lane stride 81 words: conflict-free). MT = matrix scalar: a double matrix
+// with float vectors (the assembled matrix of a float solver, kernels_a64.hpp) is multiplied in double.
+template <class S, class MT>
+__device__ __forceinline__ void spmv_block_times(const MT* lds, int off, int lane, bool act, const S xv[9],
                                                  double acc[9]) {
   if (act) {
-    const S* blk = lds + off + 81 * lane;
+    const MT* blk = lds + off + 81 * lane;
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
-      S t = S(0);
+      MT t = MT(0);
 #pragma unroll
-      for (int b = 0; b < 9; ++b) t += blk[9 * a + b] * xv[b];
+      for (int b = 0; b < 9; ++b) t += blk[9 * a + b] * MT(xv[b]);
       acc[a] += double(t);
     }
   }
@@ -126,23 +127,23 @@ __device__ __forceinline__ void spmv_block_times(const S* lds, int off, int lane
 //            the PCG state - all independent, all issued before anything is waited for
 //   round 3  the gathers of z / p (need the column indices)
 // The termination decision is evaluated while rounds 2/3 are in flight.
-template <class S, int MODE>
-__global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, const S* __restrict__ vals,
+template <class S, int MODE, class MT = S>
+__global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, const MT* __restrict__ vals,
                                                   const SpmvItem* __restrict__ items, const S* __restrict__ z,
                                                   S* pbuf0, S* pbuf1, const S* __restrict__ xvec,
                                                   S* __restrict__ qmain, S* __restrict__ qextra, CgState* st, const double* __restrict__ part_rho,
                                                   const double* __restrict__ part_q,
                                                   double* __restrict__ part_pq, double q_tolerance, int min_it,
                                                   int max_it, int period, int* host_progress) {
-  using V = typename Vec16<S>::type;
+  using V = typename Vec16<MT>::type;
   extern __shared__ __attribute__((aligned(16))) char smem_pcgs[];
-  S* lds = reinterpret_cast<S*>(smem_pcgs);
+  MT* lds = reinterpret_cast<MT*>(smem_pcgs);
   const int lane = threadIdx.x;
   const SpmvItem item = items[blockIdx.x];
   const int c = item.row;
   // ---- round 2: everything that depends on the item only. vmcnt retires in order: what the
   //      next round needs (column indices, partials) is requested BEFORE the 21 matrix vectors
-  ChunkStage<S> cs;
+  ChunkStage<MT> cs;
   const int nb0 = min(64, item.slot1 - item.slot0);
   const bool act0 = lane < nb0;
   const int col0 = cols[item.slot0 + min(lane, nb0 - 1)];
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
     cs.store(v0, lane, tmp, lds);
   }
   __syncthreads();
-  spmv_block_times<S>(lds, cs.off, lane, act0, xv, acc);
+  spmv_block_times<S, MT>(lds, cs.off, lane, act0, xv, acc);
   for (int chunk = item.slot0 + 64; chunk < item.slot1; chunk += 64) {  // long rows only
     __syncthreads();  // the staging buffer is overwritten
     const int nb = min(64, item.slot1 - chunk);
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
       }
     }
     __syncthreads();
-    spmv_block_times<S>(lds, cs.off, lane, act, xv, acc);
+    spmv_block_times<S, MT>(lds, cs.off, lane, act, xv, acc);
   }
   S mine = S(0);
 #pragma unroll

@@ -29,6 +29,7 @@
 #include "kernels_s1.hpp"
 #include "kernels_sc.hpp"
 #include "kernels_pcg.hpp"
+#include "kernels_a64.hpp"
 
 namespace {
 
@@ -674,7 +675,7 @@ class Solver final : public rba_solver {
     }
     // capture the launch graphs of the fused PCG now (one-off cost, not part of an LM iteration)
     if (n_items_ > 0 && opt_.preconditioner_type != 2 && (sc_ || ex_ready_))
-      build_pcg_graphs(sc_ ? scp_ : exp_);
+      build_pcg_graphs();
   }
 
   // Block-CSR structure for the explicit reduced matrix of the square-root solver, from the
@@ -743,6 +744,12 @@ class Solver final : public rba_solver {
     d_ex_pair_oi_.alloc(n_pairs);
     d_ex_pair_oj_.alloc(n_pairs);
     d_ex_vals_.alloc(size_t(81) * nnz + 4);  // + 4: the SpMV's last 16-byte load may run past the end
+    if (kA64) {
+      // float solver: the matrix is assembled in double from the float factors (kernels_a64.hpp)
+      d_a64_lq_.alloc(size_t(rba::kA64Lq) * n_lms_);
+      d_a64_A_.alloc(size_t(4) * n_obs_);
+      d_a64_topd_.alloc(size_t(rba::kTd) * n_obs_);
+    }
     d_ex_rowptr_.upload(row_ptr.data(), row_ptr.size(), stream_);
     d_ex_cols_.upload(cols.data(), cols.size(), stream_);
     d_ex_diag_.upload(diag.data(), diag.size(), stream_);
@@ -756,7 +763,7 @@ class Solver final : public rba_solver {
     exp_.n_cams = n_cams_;
     exp_.row_ptr = d_ex_rowptr_.get();
     exp_.cols = d_ex_cols_.get();
-    exp_.vals = d_ex_vals_.get();
+    exp_.vals = nullptr;  // the values are double for either solver scalar: with_matrix()
     ex_ready_ = true;
   }
 
@@ -784,14 +791,7 @@ class Solver final : public rba_solver {
     d_qmain_.alloc(nvec_);
     d_pcgs_pq_.alloc(n_items_);
     HIP_CHECK(hipStreamSynchronize(stream_));
-    if (rba::spmv_lds_bytes<S>() > 48 * 1024) {
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_pcgs_spmv<S, 0>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(rba::spmv_lds_bytes<S>())));
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_pcgs_spmv<S, 1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(rba::spmv_lds_bytes<S>())));
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_pcgs_spmv<S, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(rba::spmv_lds_bytes<S>())));
-    }
+    static_assert(rba::spmv_lds_bytes<double>() <= 48 * 1024, "the SpMV staging buffer needs the large-LDS attribute");
   }
 
   // S = sum_l A_l^T A_l of the CURRENT damped blocks (valid until the next stage 2)
@@ -799,22 +799,76 @@ class Solver final : public rba_solver {
     const bool measure = explicit_auto_ && !asm_measured_ && !asm_pending_;
     if (measure) HIP_CHECK(hipEventRecord(ev_asm0_, stream_));
     if (comm_ || cb_fn_) d_ex_vals_.zero(stream_);  // sharded: blocks without local pairs must be 0
-    ensure_topd();  // the off-diagonal blocks are built from the 27-scalar rows
     ++pcg_counters_.assemblies;
-    if (ex_n_upper_ > 0) launch_offdiag(prm_.topd, d_ex_vals_.get());
-    all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
-    // (the diagonal blocks were all-reduced by stage 2 already)
-    if (prm_.want_sdiag)
-      hipLaunchKernelGGL((rba::k_ex_copy_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
-                         prm_.sdiag, d_ex_diag_.get(), d_ex_vals_.get(), n_cams_);
-    else
-      hipLaunchKernelGGL((rba::k_ex_set_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
-                         prm_.blocks, d_ex_diag_.get(), d_ex_vals_.get(), pose_damping_, n_cams_);
+    assemble_values();
     if (measure) {
       HIP_CHECK(hipEventRecord(ev_asm1_, stream_));
       asm_pending_ = true;
     }
     ex_valid_ = true;
+  }
+
+  // The values of the assembled matrix, always DOUBLE. Double solver: off-diagonal blocks from the records of damped
+  // top rows, diagonal blocks = the SCHUR_JACOBI blocks of stage 2 (all-reduced there already). Float solver: every
+  // block is re-derived in double from the float factors (kernels_a64.hpp) - a float matrix S + E, |E| ~ eps |S|,
+  // costs the PCG its accuracy along near-null directions (eps kappa instead of the eps sqrt(kappa) of the square-root
+  // product) however its entries are computed.
+  void assemble_values() {
+    if constexpr (kA64) {
+      a64_.n_cams = n_cams_;
+      a64_.n_lms = n_lms_;
+      a64_.lm_k = prm_.lm_k;
+      a64_.lm_obs = prm_.lm_obs;
+      a64_.obs_cam = prm_.obs_cam;
+      a64_.obs_lm = prm_.obs_lm;
+      a64_.cam_obs_off = prm_.cam_obs_off;
+      a64_.cam_obs = prm_.cam_obs;
+      a64_.JpS = prm_.JpS;
+      a64_.Vh = prm_.Vh;
+      a64_.tauH = prm_.tauH;
+      a64_.R0 = prm_.R0;
+      a64_.pose_scaling = prm_.pose_scaling;
+      a64_.LQ = d_a64_lq_.get();
+      a64_.A = d_a64_A_.get();
+      a64_.topd = d_a64_topd_.get();
+      if (!a64_lm_valid_) {  // per linearisation point: tau and the reflector cross products in double
+        const int short_end = imp_end_[4];  // k <= 32: a work-item per landmark; longer tracks: a wavefront each
+        if (short_end > 0)
+          hipLaunchKernelGGL(rba::k_a64_landmark, dim3((short_end + 255) / 256), dim3(256), 0, stream_, a64_, 0, short_end);
+        if (n_lms_ > short_end)
+          hipLaunchKernelGGL(rba::k_a64_landmark_wave, dim3((n_lms_ - short_end + 3) / 4), dim3(256), 0, stream_, a64_,
+                             short_end, n_lms_);
+        a64_lm_valid_ = true;
+      }
+      const size_t lds = size_t(rba::kA64Threads) * (rba::kA64TdLds * sizeof(double) + 18 * sizeof(float));
+      hipLaunchKernelGGL(rba::k_a64_obs, dim3(unsigned((n_obs_ + rba::kA64Threads - 1) / rba::kA64Threads)),
+                         dim3(rba::kA64Threads), lds, stream_, a64_, int64_t(n_obs_), double(pose_damping_));
+      hipLaunchKernelGGL(rba::k_a64_diag, dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, a64_,
+                         d_ex_diag_.get(), d_ex_vals_.get());
+      if (ex_n_upper_ > 0) launch_offdiag(d_a64_topd_.get(), d_ex_vals_.get());
+      all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);  // (diagonal blocks included: local sums so far)
+    } else {
+      ensure_topd();  // the off-diagonal blocks are built from the 27-scalar rows
+      if (ex_n_upper_ > 0) launch_offdiag(prm_.topd, d_ex_vals_.get());
+      all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
+      // (the diagonal blocks were all-reduced by stage 2 already)
+      if (prm_.want_sdiag)
+        hipLaunchKernelGGL((rba::k_ex_copy_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
+                           prm_.sdiag, d_ex_diag_.get(), d_ex_vals_.get(), n_cams_);
+      else
+        hipLaunchKernelGGL((rba::k_ex_set_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
+                           prm_.blocks, d_ex_diag_.get(), d_ex_vals_.get(), pose_damping_, n_cams_);
+    }
+  }
+
+  // the block-CSR matrix the PCG runs on: the explicit Schur complement of the SC backend (solver scalar) or the
+  // assembled reduced matrix of the square-root solver (double)
+  template <class F>
+  void with_matrix(F&& f) {
+    if (sc_)
+      f(static_cast<const int*>(scp_.cols), static_cast<const S*>(scp_.vals));
+    else
+      f(static_cast<const int*>(d_ex_cols_.get()), static_cast<const double*>(d_ex_vals_.get()));
   }
 
   // Block structure of the reduced camera matrix: every ordered pair of cameras that
@@ -1287,6 +1341,7 @@ class Solver final : public rba_solver {
     pose_damping_ = S(0);
     landmark_damping_valid_ = false;
     ex_valid_ = false;
+    a64_lm_valid_ = false;
     if (lm_async_) return RBA_OK;  // lm_step reads the flag at its next synchronisation point (linearize_failed)
     return (*fail & 1) ? RBA_NUMERICAL_FAILURE : RBA_OK;
   }
@@ -1373,7 +1428,18 @@ class Solver final : public rba_solver {
       // - 75 against 183 us - and was tried here: on venice-1778 with the float32 power series one solve at
       // lambda = 1.4e-7 then needs the matrix-free repeat, reproducibly, where this kernel's summation order converges
       // in 200 iterations - 106 against 215 LM it/s. Both are float32 roundings of the same product; kept as it was.)
-      hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, sc_ ? scp_ : exp_, x, y, done_flag);
+      if (sc_) {
+        hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_, x, y, done_flag);
+      } else {
+        // the row-staged SpMV of the fused PCG in its plain-product mode (double blocks, kernels_pcg.hpp) + its collect
+        hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2, double>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<double>(),
+                           stream_, d_ex_cols_.get(), d_ex_vals_.get(), d_items_.get(), static_cast<const S*>(nullptr),
+                           static_cast<S*>(nullptr), static_cast<S*>(nullptr), x, d_qmain_.get(), d_qpart_.get(),
+                           d_cg_.get(), static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
+                           static_cast<double*>(nullptr), 0.0, 0, 0, 1, static_cast<int*>(nullptr));
+        hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y, d_qmain_.get(),
+                           d_qpart_.get(), d_item_ptr_.get(), nvec_);
+      }
       if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
       ++hx_calls_;
       return;
@@ -1395,8 +1461,8 @@ class Solver final : public rba_solver {
   }
 
   // off-diagonal blocks of the explicit reduced matrix on the matrix cores of either precision (kernels_sc.hpp)
-  void launch_offdiag(const S* topd, S* vals) {
-    hipLaunchKernelGGL((rba::k_ex_offdiag_mfma<S>), dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_,
+  void launch_offdiag(const double* topd, double* vals) {
+    hipLaunchKernelGGL((rba::k_ex_offdiag_mfma<double>), dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_,
                        topd, vals, d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(), d_ex_pair_oi_.get(),
                        d_ex_pair_oj_.get(), ex_n_upper_);
   }
@@ -1527,7 +1593,7 @@ class Solver final : public rba_solver {
     // the SpMV of the fused PCG (kernels_pcg.hpp), refresh-product mode, on a cleared state
     HIP_CHECK(hipMemsetAsync(d_cg_.get(), 0, sizeof(rba::CgState), stream_));
     hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, d_cg_.get(), double(pose_damping_), 0);
-    launch_pcgs_product(exp_, d_vin_.get(), /*period=*/1);
+    launch_pcgs_product(d_vin_.get(), /*period=*/1);
     hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, d_tmp_.get(),
                        d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), nvec_);
     d_tmp_.download(static_cast<S*>(y), nvec_, stream_);
@@ -1535,12 +1601,28 @@ class Solver final : public rba_solver {
   }
 
   // q = M x + lambda x   (k_pcgs_spmv, refresh-product mode; lambda from the device state)
-  void launch_pcgs_product(const rba::ScParams<S>& M, const S* x, int period) {
-    hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 1>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
-                       M.cols, M.vals, d_items_.get(), static_cast<const S*>(nullptr), static_cast<S*>(nullptr),
-                       static_cast<S*>(nullptr), x, d_qmain_.get(), d_qpart_.get(), d_cg_.get(),
-                       static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
-                       static_cast<double*>(nullptr), 0.0, 0, 0, period, static_cast<int*>(nullptr));
+  void launch_pcgs_product(const S* x, int period) {
+    with_matrix([&](const int* cols, auto* vals) {
+      using MT = std::remove_cv_t<std::remove_pointer_t<decltype(vals)>>;
+      hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 1, MT>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<MT>(), stream_,
+                         cols, vals, d_items_.get(), static_cast<const S*>(nullptr), static_cast<S*>(nullptr),
+                         static_cast<S*>(nullptr), x, d_qmain_.get(), d_qpart_.get(), d_cg_.get(),
+                         static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
+                         static_cast<double*>(nullptr), 0.0, 0, 0, period, static_cast<int*>(nullptr));
+    });
+  }
+  // k_pcgs_spmv<0>: direction update + product + p.q partials (also the termination test of the previous iteration)
+  void launch_pcgs_direction_product() {
+    constexpr int NB = rba::kPcgBlocks;
+    double* part_rho = d_pcg_partials_.get();
+    with_matrix([&](const int* cols, auto* vals) {
+      using MT = std::remove_cv_t<std::remove_pointer_t<decltype(vals)>>;
+      hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 0, MT>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<MT>(), stream_,
+                         cols, vals, d_items_.get(), d_z_.get(), d_p_.get(), d_p2_.get(),
+                         static_cast<const S*>(nullptr), d_qmain_.get(), d_qpart_.get(), d_cg_.get(), part_rho,
+                         part_rho + 2 * NB, d_pcgs_pq_.get(), opt_.eta, opt_.min_cg_it, opt_.max_cg_it, kPcgPeriod,
+                         h_progress_);
+    });
   }
 
   static constexpr int kPcgPeriod = 10;  // residual_reset_period (conjugate_gradient.hpp:86-88)
@@ -1548,22 +1630,19 @@ class Solver final : public rba_solver {
   static constexpr int kPcgRunAhead = 6; // single iterations the host may queue ahead of the device
 
   // one PCG iteration of the fused path: product + update (+ the residual refresh)
-  void enqueue_pcgs_iteration(const rba::ScParams<S>& M, bool with_refresh) {
+  void enqueue_pcgs_iteration(bool with_refresh) {
     constexpr int NB = rba::kPcgBlocks;
     rba::CgState* st = d_cg_.get();
     double* part_rho = d_pcg_partials_.get();
     double* part_q = part_rho + 2 * NB;
-    hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 0>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
-                       M.cols, M.vals, d_items_.get(), d_z_.get(), d_p_.get(), d_p2_.get(),
-                       static_cast<const S*>(nullptr), d_qmain_.get(), d_qpart_.get(), st, part_rho, part_q,
-                       d_pcgs_pq_.get(), opt_.eta, opt_.min_cg_it, opt_.max_cg_it, kPcgPeriod, h_progress_);
+    launch_pcgs_direction_product();
     hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), prm_.b,
                        d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), d_qmain_.get(),
                        d_qpart_.get(), d_item_ptr_.get(), n_items_, n_cams_, st, d_pcgs_pq_.get(), part_rho,
                        part_q, 0, kPcgPeriod, h_progress_, 0, S(0), static_cast<S*>(nullptr));
     if (with_refresh) {
       // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
-      launch_pcgs_product(M, d_x_.get(), kPcgPeriod);
+      launch_pcgs_product(d_x_.get(), kPcgPeriod);
       hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), prm_.b,
                          d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), d_qmain_.get(),
                          d_qpart_.get(), d_item_ptr_.get(), n_items_, n_cams_, st, d_pcgs_pq_.get(), part_rho,
@@ -1572,15 +1651,7 @@ class Solver final : public rba_solver {
   }
 
   // the termination test of the last iteration lives in the next product's prologue
-  void enqueue_pcgs_final_test(const rba::ScParams<S>& M) {
-    constexpr int NB = rba::kPcgBlocks;
-    double* part_rho = d_pcg_partials_.get();
-    hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 0>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
-                       M.cols, M.vals, d_items_.get(), d_z_.get(), d_p_.get(), d_p2_.get(),
-                       static_cast<const S*>(nullptr), d_qmain_.get(), d_qpart_.get(), d_cg_.get(), part_rho,
-                       part_rho + 2 * NB, d_pcgs_pq_.get(), opt_.eta, opt_.min_cg_it, opt_.max_cg_it, kPcgPeriod,
-                       h_progress_);
-  }
+  void enqueue_pcgs_final_test() { launch_pcgs_direction_product(); }
 
   // Launch graphs of kPcgBlock iterations (the host cannot issue two launches per 13 us iteration
   // eagerly): [0] plain, [1] with the residual refresh after the block's last iteration. All
@@ -1591,11 +1662,11 @@ class Solver final : public rba_solver {
       g = nullptr;
     }
   }
-  void build_pcg_graphs(const rba::ScParams<S>& M) {
+  void build_pcg_graphs() {
     for (int v = 0; v < 2; ++v) {
       hipGraph_t graph = nullptr;
       HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-      for (int i = 0; i < kPcgBlock; ++i) enqueue_pcgs_iteration(M, v == 1 && i == kPcgBlock - 1);
+      for (int i = 0; i < kPcgBlock; ++i) enqueue_pcgs_iteration(v == 1 && i == kPcgBlock - 1);
       HIP_CHECK(hipStreamEndCapture(stream_, &graph));
       HIP_CHECK(hipGraphInstantiate(&pcg_graph_exec_[v], graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
@@ -1605,7 +1676,7 @@ class Solver final : public rba_solver {
   // The PCG from iteration `it_start` on, on the assembled matrix M, two launches per iteration
   // (kernels_pcg.hpp). State (x, r, p, rho/Q history, iteration counter) is taken over from the
   // round-1 kernels when a solve switches operators mid-way.
-  void pcg_fused(const rba::ScParams<S>& M, S lambda, int it_start) {
+  void pcg_fused(S lambda, int it_start) {
     const int n = nvec_, max_it = opt_.max_cg_it;
     constexpr int NB = rba::kPcgBlocks, T = rba::kPcgThreads;
     static_assert(kPcgPeriod % kPcgBlock == 0, "graph blocks must tile the refresh period");
@@ -1616,13 +1687,13 @@ class Solver final : public rba_solver {
     if (it_start > 1) {
       // operator switch inside a running solve: the residual is recomputed with the operator used
       // from here on, r = b - (S + lambda I) x, exactly like the periodic refresh
-      launch_pcgs_product(M, d_x_.get(), 1);
+      launch_pcgs_product(d_x_.get(), 1);
       hipLaunchKernelGGL((rba::k_pcgs_residual<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, prm_.b,
                          d_r_.get(), d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), n, st);
     }
     hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(), d_z_.get(),
                        n, st, part_rho);
-    if (!pcg_graph_exec_[0]) build_pcg_graphs(M);
+    if (!pcg_graph_exec_[0]) build_pcg_graphs();
     volatile int* hp = h_progress_;
     hp[0] = it_start - 1;
     hp[1] = 0;
@@ -1646,11 +1717,11 @@ class Solver final : public rba_solver {
         it += kPcgBlock;
       } else {
         if (!(running = wait_for(it, kPcgRunAhead))) break;
-        enqueue_pcgs_iteration(M, it % kPcgPeriod == 0);
+        enqueue_pcgs_iteration(it % kPcgPeriod == 0);
         ++it;
       }
     }
-    if (running && wait_for(it, kPcgRunAhead)) enqueue_pcgs_final_test(M);
+    if (running && wait_for(it, kPcgRunAhead)) enqueue_pcgs_final_test();
     HIP_CHECK(hipGetLastError());
   }
 
@@ -1913,16 +1984,19 @@ class Solver final : public rba_solver {
         // inverse tolerates its eps |S| error, and order m costs m SpMVs instead of m matrix-free E0 products
         // (final-13682, order 10: 2 ms instead of 25 ms per PCG iteration).
         const bool series_on_matrix = sc_ || ex_active_ || (explicit_off_for_solve_ && ex_ready_ && ex_valid_);
-        const rba::ScParams<S>& SM = sc_ ? scp_ : exp_;  // (SC backend: the damping is inside the matrix, lambda = 0)
+        // (SC backend: the damping is inside the matrix, lambda = 0)
         for (int i = 1; i <= opt_.power_order; ++i) {
           if (series_on_matrix) {
             // through the assembled matrix: (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t), no collective
             // the row-staged SpMV of the fused PCG (kernels_pcg.hpp, plain-product mode) + its collect
-            hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<S>(), stream_,
-                               SM.cols, SM.vals, d_items_.get(), static_cast<const S*>(nullptr),
-                               static_cast<S*>(nullptr), static_cast<S*>(nullptr), t, d_qmain_.get(), d_qpart_.get(),
-                               st, static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
-                               static_cast<double*>(nullptr), double(lambda), 0, 0, 1, static_cast<int*>(nullptr));
+            with_matrix([&](const int* cols, auto* vals) {
+              using MT = std::remove_cv_t<std::remove_pointer_t<decltype(vals)>>;
+              hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2, MT>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<MT>(),
+                                 stream_, cols, vals, d_items_.get(), static_cast<const S*>(nullptr),
+                                 static_cast<S*>(nullptr), static_cast<S*>(nullptr), t, d_qmain_.get(), d_qpart_.get(),
+                                 st, static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
+                                 static_cast<double*>(nullptr), double(lambda), 0, 0, 1, static_cast<int*>(nullptr));
+            });
             hipLaunchKernelGGL((rba::k_series_step<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_qmain_.get(),
                                d_qpart_.get(), d_item_ptr_.get(), t, d_z_.get(), n, st);
             continue;
@@ -1974,7 +2048,7 @@ class Solver final : public rba_solver {
       }
     }
     if (go_fused) {
-      pcg_fused(sc_ ? scp_ : exp_, lambda, it);
+      pcg_fused(lambda, it);
       HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
       sync();
     }
@@ -2422,13 +2496,17 @@ class Solver final : public rba_solver {
       m->product_matrix_free = no * (26 * s + 16) + nl * 12 * s + nc * 18 * s;
     }
     const int64_t nnz = sc_ ? sc_nnz_ : ex_nnz_;
-    m->product_assembled = nnz * (81 * s + 4) + nc * 18 * s;
+    const int64_t ms = sc_ ? s : int64_t(sizeof(double));  // the assembled matrix of the square-root solver is double
+    m->product_assembled = nnz * (81 * ms + 4) + nc * 18 * s;
     // assembly, COMPULSORY bytes: the pair list (8 B per pair), every 32-scalar record once, the blocks out. The
     // gather itself requests two records per pair (256 B in float); what L2 does not keep of that is re-read traffic
     // and shows up as measured / model > 1 (profiles/r3_pmc_stage_traffic.csv), not as algorithmic bytes.
-    m->assembly = sc_ ? sc_assemble_bytes_ : ex_pairs_ * 8 + int64_t(n_obs_) * 32 * s + nnz * 81 * s;
+    m->assembly = sc_ ? sc_assemble_bytes_ : ex_pairs_ * 8 + int64_t(n_obs_) * 32 * ms + nnz * 81 * ms;
     if (!sc_)  // + the column pass that materialises the records of damped top rows: JpS 18 + Vh 8 in, 32 out
-      m->assembly += int64_t(n_obs_) * (18 + 8 + 32) * s;
+      m->assembly += int64_t(n_obs_) * ((18 + 8) * s + 32 * ms);
+    if (!sc_ && kA64)  // float solver (kernels_a64.hpp): + the landmark pass (Vh 8 in), the factor A (4 doubles) out and
+      m->assembly += int64_t(n_obs_) * (8 * s + 4 * ms + 18 * s + 4 * ms + 4);  // back in with JpS 18 + the CSC index
+
     m->pcg_vectors = nc * (81 + 10 * 9) * s;
   }
   void get_pcg_counters(rba_pcg_counters* out) override { *out = pcg_counters_; }
@@ -2647,7 +2725,12 @@ class Solver final : public rba_solver {
   std::vector<int> h_obs_cam_;
   DevBuf<int> d_ex_rowptr_, d_ex_cols_, d_ex_diag_, d_ex_upper_, d_ex_mirror_, d_ex_pair_oi_, d_ex_pair_oj_;
   DevBuf<int64_t> d_ex_pair_ptr_;
-  DevBuf<S> d_ex_vals_;
+  DevBuf<double> d_ex_vals_;  // always double (assemble_values)
+  // float solver: double re-derivation of the factors for the assembled matrix (kernels_a64.hpp)
+  static constexpr bool kA64 = std::is_same<S, float>::value;
+  DevBuf<double> d_a64_lq_, d_a64_A_, d_a64_topd_;
+  rba::A64Params a64_{};
+  bool a64_lm_valid_ = false;  // per linearisation point
   // fused PCG on the assembled matrix (kernels_pcg.hpp)
   DevBuf<rba::SpmvItem> d_items_;
   DevBuf<int> d_item_ptr_;

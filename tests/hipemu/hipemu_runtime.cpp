@@ -548,4 +548,5 @@ alignas(16) thread_local unsigned char hx_lds_raw[160 * 1024];
 alignas(16) thread_local char smem_pcgs[160 * 1024];
 alignas(16) thread_local char smem_s1[160 * 1024];
 alignas(16) thread_local char smem_s1c[160 * 1024];
+alignas(16) thread_local char smem_a64[160 * 1024];
 }  // namespace rba
