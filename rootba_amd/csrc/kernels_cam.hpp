@@ -226,9 +226,10 @@ __device__ __forceinline__ void store_cam_record_stage2(const Params<S>& p, int6
     a01 = a00 > S(0) ? m01 / a00 : S(0);
     a10 = S(0);
     a11 = sqrt(max(m11 - a01 * a01, S(0)));
-  } else {  // M = U U^T, A = U^T
-    a11 = sqrt(m11);
-    a10 = m01 / a11;
+  } else {  // M = U U^T, A = U^T   (same guards: at lambda = 0 both diagonal entries of a landmark seen twice can
+            //                      round to <= 0; max() also maps a NaN m11 to 0)
+    a11 = sqrt(max(m11, S(0)));
+    a10 = a11 > S(0) ? m01 / a11 : S(0);
     a01 = S(0);
     a00 = sqrt(max(m00 - a10 * a10, S(0)));
   }

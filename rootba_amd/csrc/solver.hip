@@ -20,6 +20,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rootba_hip.h"
@@ -49,6 +50,24 @@ struct HipError {
                      RBA_ERR_HIP};                                                   \
     }                                                                                \
   } while (0)
+
+// sets a flag for a scope (cleared on every exit path, exceptions included)
+struct FlagScope {
+  bool& flag;
+  FlagScope(bool& f, bool on) : flag(f) { flag = on; }
+  ~FlagScope() { flag = false; }
+  FlagScope(const FlagScope&) = delete;
+  FlagScope& operator=(const FlagScope&) = delete;
+};
+
+// one step of a host spin loop on a pinned word: lets the sibling hardware thread run
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
 
 template <class T>
 class DevBuf {
@@ -1700,10 +1719,7 @@ class Solver final : public rba_solver {
     // run-ahead throttle: the device publishes the iteration it has started; launches queued
     // after the termination are no-ops
     auto wait_for = [&](int it, int ahead) {
-      long spins = 0;
-      while (!hp[1] && it - hp[0] > ahead)
-        // (nothing left in flight - or the stream has failed: the next synchronisation reports it)
-        if ((++spins & 0x3fff) == 0 && hipStreamQuery(stream_) != hipErrorNotReady) break;
+      spin_while([&] { return !hp[1] && it - hp[0] > ahead; });
       return hp[1] == 0;
     };
     int it = it_start;
@@ -1729,6 +1745,7 @@ class Solver final : public rba_solver {
   int solve(double lambda_d, void* inc_out, rba_cg_summary* cg_out) override {
     use_device();
     const S lambda = S(lambda_d);
+    pcg_state_pending_ = false;  // (a solve that threw may have left it set)
     time_begin();
     run_stage2(lambda);
     time_end(&timings_.stage2_time);
@@ -1774,10 +1791,9 @@ class Solver final : public rba_solver {
       // The assembled operator is S + E with |E| ~ eps |S|: unlike the square-root product
       // (p.q = |A p|^2 + lambda |p|^2 >= 0 by construction) it can lose definiteness when
       // lambda < eps |S|. The reference's operator cannot - repeat this solve matrix-free.
-      explicit_off_for_solve_ = true;
       ++pcg_counters_.solves_repeated_matrix_free;
+      FlagScope off(explicit_off_for_solve_, true);
       cg = pcg(lambda);
-      explicit_off_for_solve_ = false;
     }
     if (inc_out) {
       hipLaunchKernelGGL((rba::k_negate<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
@@ -1899,9 +1915,7 @@ class Solver final : public rba_solver {
       };
       // the device publishes the iteration it has started (hp[0]) or the end of the solve (hp[1])
       auto started = [&](int k) {
-        long spins = 0;
-        while (!hp[1] && hp[0] < k)
-          if ((++spins & 0x3fff) == 0 && hipStreamQuery(stream_) != hipErrorNotReady) break;  // idle or failed
+        spin_while([&] { return !hp[1] && hp[0] < k; });
         return hp[1] == 0;
       };
       bool running = true;
@@ -2200,11 +2214,7 @@ class Solver final : public rba_solver {
     // Inside this function stage results and timers are collected at the iteration's own synchronisation points (the
     // PCG's polls, the increment after the solve, the end) instead of after every stage; the unstaged sub-stage timers
     // keep the per-stage synchronisation they are read at.
-    struct AsyncScope {
-      bool& flag;
-      AsyncScope(bool& f, bool on) : flag(f) { flag = on; }
-      ~AsyncScope() { flag = false; }
-    } async_scope(lm_async_, !sub_timing());
+    FlagScope async_scope(lm_async_, !sub_timing());
     auto finish = [&](bool keep_going) {
       if (lm_async_) {
         sync();
@@ -2270,9 +2280,10 @@ class Solver final : public rba_solver {
     // costs. The two outcomes that used to stop short of the back-substitution - a non-finite state / Jacobian, a
     // non-finite increment - undo it from the backup instead.
     const bool one_sync = lm_async_;
-    solve_defer_ = one_sync;
-    solve(lm_.lambda, nullptr, &cg);
-    solve_defer_ = false;
+    {
+      FlagScope defer(solve_defer_, one_sync);
+      solve(lm_.lambda, nullptr, &cg);
+    }
     double l_diff_d = 0;
     bool applied = false;
     if (one_sync) {
@@ -2529,6 +2540,22 @@ class Solver final : public rba_solver {
   double* pinned_doubles(size_t off) { return reinterpret_cast<double*>(h_pinned_ + off); }
   int* pinned_int(size_t off) { return reinterpret_cast<int*>(h_pinned_ + off); }
   void sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+  // Host side of the run-ahead throttles: spin on pinned words the device publishes its progress to, with a pause per
+  // turn (the sibling hardware thread - possibly the one that feeds another rank's stream - gets the core). Every
+  // 16384 turns the stream is queried: an idle stream ends the wait (everything queued has run: the caller queues
+  // more), an error is reported at once instead of at the next synchronisation.
+  template <class Pred>
+  void spin_while(Pred&& pred) {
+    long spins = 0;
+    while (pred()) {
+      cpu_relax();
+      if ((++spins & 0x3fff) == 0) {
+        const hipError_t e = hipStreamQuery(stream_);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) HIP_CHECK(e);
+      }
+    }
+  }
   // Stage timers: HIP-event pairs on the solver stream. A single C-ABI call waits for its own pair; inside
   // rba_lm_step (lm_async_) the pairs are only RECORDED and read after the iteration's last synchronisation, so the
   // host never stalls the queue just to read a clock (round 2: ~10 synchronisations per LM iteration, 0.14 ms of gaps).

@@ -216,21 +216,20 @@ def test_config3_trafalgar257_f32_increment_vectors_reference_algorithm(monkeypa
 
 
 def test_config3_trafalgar257_f32_increment_vectors_default_configuration():
-    """The default configuration switches long solves to the assembled float32 reduced matrix. Solves that
-    stay matrix-free (iterations 1, 2: 3 and 11 PCG iterations) agree as above; for the others the assembled operator
-    S + E, |E| ~ eps |S|, costs accuracy along near-null directions - STATED tolerance: increment within 2.5e-2 of the
-    oracle's iterate of the same index (measured 2.9e-4 at 57, 3.0e-3 at 186, 6.4e-3 at ~200, 1.7e-2 at ~220 PCG
-    iterations; the float32 oracle itself is 0.9e-3 ... 1.5e-3 from float64 there), final costs unaffected
-    (test_config3_trafalgar257_f32_full_lm_run: 1e-6)."""
+    """The default configuration switches long solves to the ASSEMBLED reduced matrix. Rounds 2-3 held
+    that matrix in float32 and accepted 2.5e-2 on the increments of such solves (S + E, |E| ~ eps |S|: 3-10 x further
+    from float64 than the float32 reference, different PCG counts - VERDICT round 3, weak 1). Since round 4 the matrix
+    is DOUBLE, derived from the float factors with reflectors and rotations that are orthogonal to double precision
+    (kernels_a64.hpp): the default configuration is held to the SAME assertions as the all-matrix-free run above -
+    PCG counts of the float32 oracle (3 / 11 / 57 / 186 / 279 / 276), increments as close to the float64 iterate as the
+    float32 oracle's."""
     rows = _lockstep("trafalgar-257", "float32", 6)
+    assert len(rows) == 6
     for r in rows:
-        assert r["termination"] == 1 and r["cost_rel"] < 2e-6 and r["hx_rel"] < 1e-5, r
-        if r["cg_oracle"] <= 60:
-            assert r["cg_gpu"] == r["cg_oracle"], r
-            assert r["inc_rel"] <= 2 * r["oracle32_vs_f64"] + 2e-4 and r["gpu_vs_f64"] <= 1.5 * r["oracle32_vs_f64"] + 1e-4, r
-        else:
-            assert 0.5 * r["cg_oracle"] <= r["cg_gpu"] <= 2 * r["cg_oracle"], r
-            assert r["inc_rel"] < 2.5e-2 and r["gpu_vs_f64"] < 2.5e-2, r
+        assert r["termination"] == 1 and abs(r["cg_gpu"] - r["cg_oracle"]) <= 1, r
+        assert r["cost_rel"] < 2e-6 and r["hx_rel"] < 1e-5 and r["l_diff_rel"] < 2e-3, r
+        assert r["inc_rel"] <= 2 * r["oracle32_vs_f64"] + 2e-4, r
+        assert r["gpu_vs_f64"] <= 1.5 * r["oracle32_vs_f64"] + 1e-4, r
         assert r["cams_rel"] < 1e-6 and r["lms_rel"] < 1e-5, r
 
 
@@ -247,16 +246,84 @@ def test_config4_venice1778_f32_increment_vectors():
         assert r["cams_rel"] < 1e-6 and r["lms_rel"] < 1e-5, r
 
 
+def _fixture(name):
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "_big", f"lockstep_{name}_f32.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} is absent (scripts/make_lockstep_fixture.py {name} <iterations> writes it: oracle solves "
+                    "of ~20 CPU-minutes that the GPU box's rationed minutes are not spent on)")
+    return np.load(path)
+
+
+def _fixture_rows(name, dts="float32", **extra):
+    """tests/lockstep.py with the oracle side read from the fixture: per stored iteration the GPU is set to the oracle's
+    state, linearised, and solves with the oracle run's lambda; compared with the float32 oracle's increment and the
+    float64 oracle's iterate of the same index (a second handle with max_cg_it = the oracle's count, eta = 0 supplies
+    the GPU's iterate of that index when the counts differ)."""
+    import torch  # noqa: F401
+    from lockstep import rel
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    fx = _fixture(name)
+    prob = _bench_problem(name)
+    kw = dict(robust_norm=1, huber_parameter=1.0, function_tolerance=0.0)
+    kw.update(extra)
+    gdt = "mixed" if dts == "mixed" else np.float32
+    g = LinearizorHIP(prob, gdt, L.default_options(**kw))
+    rows = []
+    for it in fx["iterations"]:
+        c_, l_ = fx[f"cams_{it}"], fx[f"lms_{it}"]
+        up = (lambda a: a.astype(np.float64)) if gdt == "mixed" else (lambda a: a)
+        g.set_state(up(c_), up(l_))
+        eg = g.compute_error()
+        assert g.linearize() == 0
+        lam, n32 = float(fx[f"lambda_{it}"]), int(fx[f"cg32_{it}"])
+        ig, cg = g.solve(lam)
+        row = {"it": int(it), "lambda": lam, "cost_rel": float(abs(eg.all_error - fx[f"cost_{it}"]) / fx[f"cost_{it}"]),
+               "cg_gpu": cg.num_iterations, "cg_oracle": n32, "termination": cg.termination_type}
+        same = ig
+        if cg.num_iterations != n32:
+            gn = LinearizorHIP(prob, gdt, L.default_options(**dict(kw, max_cg_it=n32, eta=0.0)))
+            gn.set_state(up(c_), up(l_))
+            assert gn.linearize() == 0
+            same, cn = gn.solve(lam)
+            assert cn.num_iterations == n32
+            del gn
+        row["inc_rel"] = rel(same, fx[f"inc32_{it}"])
+        row["gpu_vs_f64"] = rel(same, fx[f"inc64_{it}"])
+        row["oracle32_vs_f64"] = rel(fx[f"inc32_{it}"], fx[f"inc64_{it}"])
+        row["own_vs_f64"] = rel(ig, fx[f"inc64_{it}"])  # the increment the solve returned (its own stopping index)
+        l_diff = g.apply(fx[f"inc32_{it}"])
+        row["l_diff_rel"] = float(abs(l_diff - fx[f"l_diff_{it}"]) / abs(fx[f"l_diff_{it}"]))
+        rows.append(row)
+    return rows
+
+
+def test_config4_venice1778_f32_increment_vectors_long_solves():
+    """The solves that dominate the timed region of the headline bench: venice-1778
+    iterations 3..8 of the float32 oracle's run (28 / 124 / 330 / 480 / ... PCG iterations), default configuration
+    (assembled double matrix after the measured break-even), from the oracle's states (fixture, see _fixture_rows).
+    Same assertions as the short solves: the oracle's PCG count within 2 %, the iterate of the oracle's index as close
+    to float64 as the float32 oracle's."""
+    rows = _fixture_rows("venice-1778")
+    assert len(rows) >= 5
+    for r in rows:
+        assert r["termination"] == 1 and abs(r["cg_gpu"] - r["cg_oracle"]) <= max(1, r["cg_oracle"] // 50), r
+        assert r["cost_rel"] < 2e-6 and r["l_diff_rel"] < 2e-3, r
+        assert r["inc_rel"] <= 2 * r["oracle32_vs_f64"] + 2e-4, r
+        assert r["gpu_vs_f64"] <= 1.5 * r["oracle32_vs_f64"] + 1e-4, r
+
+
 def test_config5_mixed_precision_with_power_series_at_trafalgar_size():
     """BASELINE config 5's actual combination - mixed f32/f64 state + PoBA power-series preconditioner - at trafalgar-257
-    size against the float32 oracle from identical (float-representable) states: identical PCG counts (2 / 6 / 29 / 92 /
-    97); the series and, from the second product on, the operator run through the assembled float32 matrix, so the
-    increment tolerance is the stated one of the default configuration (measured 1.5e-4 / 3.2e-4 / 5.2e-4 / 3.9e-3 /
-    6.1e-3)."""
+    size against the float32 oracle from identical (float-representable) states: PCG counts within 5 % (2 / 6 / 29 / 92 /
+    97); the series and, from the second product on, the operator run through the assembled DOUBLE matrix
+    (kernels_a64.hpp), so the increments are held to the accuracy parity of the matrix-free runs (round 3, float32
+    matrix: 2.5e-2 stated, 3.9e-3 / 6.1e-3 measured on the long solves)."""
     rows = _lockstep("trafalgar-257", "mixed", 5, precond=2)
     assert len(rows) == 5
     for r in rows:
         assert r["termination"] == 1 and abs(r["cg_gpu"] - r["cg_oracle"]) <= max(1, r["cg_oracle"] // 20), r
         assert r["cost_rel"] < 5e-6 and r["hx_rel"] < 1e-5, r
-        assert r["inc_rel"] < (1e-3 if r["cg_oracle"] <= 30 else 2.5e-2), r
+        assert r["inc_rel"] <= 2 * r["oracle32_vs_f64"] + 2e-4 and r["gpu_vs_f64"] <= 1.5 * r["oracle32_vs_f64"] + 1e-4, r
         assert r["cams_rel"] < 1e-6 and r["lms_rel"] < 1e-5, r
