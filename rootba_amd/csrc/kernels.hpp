@@ -1388,26 +1388,18 @@ __global__ __launch_bounds__(kPcgThreads) void k_block_apply(const S* __restrict
 }
 
 // one term of the power series through the assembled matrix: with E0 = Hpp_damped - (S + lambda I),
-//   (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t);   w = (S + lambda I) t comes from the SpMV
-// (`w` is taken as the row-staged SpMV leaves it: the first item's sums in `qmain` plus, for the rare rows of more than
-//  64 * kSpmvChunksPerItem blocks, the partial sums of their further items - no separate collect launch per term)
+//   (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t);   w = (S + lambda I) t comes from the SpMV + its collect
 template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_series_step(const S* __restrict__ inv, const S* __restrict__ qmain,
-                                                            const S* __restrict__ qextra,
-                                                            const int* __restrict__ extra_ptr, S* __restrict__ t,
-                                                            S* __restrict__ z, int n, const CgState* st) {
+__global__ __launch_bounds__(kPcgThreads) void k_series_step(const S* __restrict__ inv, const S* __restrict__ w,
+                                                            S* __restrict__ t, S* __restrict__ z, int n,
+                                                            const CgState* st) {
   if (st->done) return;
   for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
     const int c = i / 9, row = i - 9 * c;
     const S* M = inv + 81 * c + 9 * row;
-    const int e0 = extra_ptr[c], e1 = extra_ptr[c + 1];
     S v = S(0);
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      S wj = qmain[9 * c + j];
-      for (int q = e0; q < e1; ++q) wj += qextra[9 * q + j];
-      v += M[j] * wj;
-    }
+    for (int j = 0; j < 9; ++j) v += M[j] * w[9 * c + j];
     const S tn = t[i] - v;
     t[i] = tn;
     z[i] += tn;

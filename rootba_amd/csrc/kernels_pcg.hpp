@@ -41,6 +41,30 @@ namespace rba {
 
 constexpr int kSpmvChunksPerItem = 4;  // 64-block chunks walked by one wavefront
 
+// HALF STORAGE (the assembled reduced matrix of the square-root solver; round 4). The matrix is symmetric and its
+// values are double (kernels_a64.hpp), so the SpMV is a stream of 8-byte scalars: a row holds its diagonal block and
+// its blocks RIGHT of the diagonal only; the wavefront of row c multiplies block (c, j) twice out of the same LDS copy -
+// S_cj v_j into its own row sums and the transposed S_cj^T v_c into a 9-double slot of `tpart` that belongs to the
+// block - and whoever consumes q_j adds the slots of the blocks (c, j), c < j, in a FIXED order (QPieces / pcgs_gather_q:
+// bitwise reproducible, identical on all ranks of a sharded run - an atomic scatter would not be). p.q needs no
+// complete q: it is sum over stored blocks of w p_c^T S_cj p_j with w = 2 right of the diagonal. Half the bytes per
+// product (venice-1778: 35 instead of 70 MB), half the all-reduce of a sharded assembly.
+// A camera that co-observes with very many EARLIER cameras would gather very many slots in one work-item: above
+// kHalfLowerMax such blocks are stored in BOTH rows instead (flag bit 31 of the column index: no slot, weight 1).
+constexpr int kHalfLowerMax = 192;
+constexpr int kColDup = int(0x80000000u);
+
+// where the pieces of a product q = M v lie
+template <class S>
+struct QPieces {
+  const S* __restrict__ qmain;         // [9 n_c] sums of a row's first item
+  const S* __restrict__ qextra;        // [9 n_extra] sums of the further items of long rows ...
+  const int* __restrict__ extra_ptr;   // [n_c + 1]    ... of row c: extra_ptr[c] .. extra_ptr[c + 1]
+  const double* __restrict__ tpart;    // [9 nnz] half storage: transposed contribution of block `slot` (nullptr: full storage)
+  const int* __restrict__ low_ptr;     // [n_c + 1]
+  const int* __restrict__ low_slot;    // slots of the blocks (c', c), c' < c, stored in earlier rows, ascending c'
+};
+
 struct SpmvItem {
   int row;    // camera (block row)
   int slot0;  // first block slot of the item
@@ -103,17 +127,34 @@ struct ChunkStage {
 
 // lane j multiplies ITS block out of LDS (lane stride 81 words: conflict-free). MT = matrix scalar: a double matrix
 // with float vectors (the assembled matrix of a float solver, kernels_a64.hpp) is multiplied in double.
-template <class S, class MT>
+// HALF (see the top of the file): the same pass over the block also forms the transposed product S_cj^T v_c (stored to
+// the block's slot `tdst` unless the block is the diagonal one or is stored in both rows) and the lane's share
+// w v_c^T S_cj v_j of p.q.
+template <class S, class MT, bool HALF>
 __device__ __forceinline__ void spmv_block_times(const MT* lds, int off, int lane, bool act, const S xv[9],
-                                                 double acc[9]) {
+                                                 double acc[9], const S vc[9], bool single, double* tdst,
+                                                 double& pq) {
   if (act) {
     const MT* blk = lds + off + 81 * lane;
+    MT tt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dot = MT(0);
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
       MT t = MT(0);
 #pragma unroll
-      for (int b = 0; b < 9; ++b) t += blk[9 * a + b] * MT(xv[b]);
+      for (int b = 0; b < 9; ++b) {
+        const MT v = blk[9 * a + b];
+        t += v * MT(xv[b]);
+        if (HALF) tt[b] += v * MT(vc[a]);
+      }
       acc[a] += double(t);
+      if (HALF) dot += MT(vc[a]) * t;
+    }
+    if (HALF) {
+      pq += double(dot) * (single ? 2.0 : 1.0);
+      if (single) {
+#pragma unroll
+        for (int b = 0; b < 9; ++b) tdst[b] = double(tt[b]);
+      }
     }
   }
 }
@@ -127,11 +168,12 @@ __device__ __forceinline__ void spmv_block_times(const MT* lds, int off, int lan
 //            the PCG state - all independent, all issued before anything is waited for
 //   round 3  the gathers of z / p (need the column indices)
 // The termination decision is evaluated while rounds 2/3 are in flight.
-template <class S, int MODE, class MT = S>
+template <class S, int MODE, class MT = S, bool HALF = false>
 __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, const MT* __restrict__ vals,
                                                   const SpmvItem* __restrict__ items, const S* __restrict__ z,
                                                   S* pbuf0, S* pbuf1, const S* __restrict__ xvec,
-                                                  S* __restrict__ qmain, S* __restrict__ qextra, CgState* st, const double* __restrict__ part_rho,
+                                                  S* __restrict__ qmain, S* __restrict__ qextra,
+                                                  double* __restrict__ tpart, CgState* st, const double* __restrict__ part_rho,
                                                   const double* __restrict__ part_q,
                                                   double* __restrict__ part_pq, double q_tolerance, int min_it,
                                                   int max_it, int period, int* host_progress) {
@@ -146,7 +188,8 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
   ChunkStage<MT> cs;
   const int nb0 = min(64, item.slot1 - item.slot0);
   const bool act0 = lane < nb0;
-  const int col0 = cols[item.slot0 + min(lane, nb0 - 1)];
+  const int colraw0 = cols[item.slot0 + min(lane, nb0 - 1)];
+  const int col0 = HALF ? (colraw0 & ~kColDup) : colraw0;
   double prho = 0, pq1 = 0;
   if (MODE == 0) {
     prho = part_rho[lane];
@@ -244,18 +287,25 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
 #pragma unroll
   for (int t = 0; t < 9; ++t) xv[t] = (MODE == 0 && !first_it) ? za[t] + bs * pa[t] : za[t];
   (void)pa;
+  const S pc = (MODE == 0 && !first_it) ? zc + bs * pcold : zc;  // lane t < 9: entry t of p_c (MODE 0) / x_c
+  S vc[9];  // half storage: v_c in every lane
+#pragma unroll
+  for (int t = 0; t < 9; ++t) vc[t] = HALF ? read_lane(pc, t) : S(0);
+  double pq = 0.0;
   cs.store(0, lane, tmp, lds);
   for (int v0 = 64 * kSpmvPass; v0 < cs.nvec; v0 += 64 * kSpmvPass) {  // double: second half of the chunk
     cs.issue(v0, lane, tmp);
     cs.store(v0, lane, tmp, lds);
   }
   __syncthreads();
-  spmv_block_times<S, MT>(lds, cs.off, lane, act0, xv, acc);
+  spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act0, xv, acc, vc, HALF && col0 != c && colraw0 >= 0,
+                                HALF ? tpart + size_t(9) * (item.slot0 + lane) : nullptr, pq);
   for (int chunk = item.slot0 + 64; chunk < item.slot1; chunk += 64) {  // long rows only
     __syncthreads();  // the staging buffer is overwritten
     const int nb = min(64, item.slot1 - chunk);
     const bool act = lane < nb;
-    const int col = act ? cols[chunk + lane] : 0;
+    const int colraw = act ? cols[chunk + lane] : 0;
+    const int col = HALF ? (colraw & ~kColDup) : colraw;
     cs.setup(vals, chunk, nb);
     for (int v0 = 0; v0 < cs.nvec; v0 += 64 * kSpmvPass) {
       cs.issue(v0, lane, tmp);
@@ -272,7 +322,8 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
       }
     }
     __syncthreads();
-    spmv_block_times<S, MT>(lds, cs.off, lane, act, xv, acc);
+    spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act, xv, acc, vc, HALF && col != c && colraw >= 0,
+                                  HALF ? tpart + size_t(9) * (chunk + lane) : nullptr, pq);
   }
   S mine = S(0);
 #pragma unroll
@@ -280,17 +331,16 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
     const double tot = wave_sum(acc[a]);
     if (lane == a) mine = S(tot);
   }
-  double pq = 0.0;
   if (lane < 9) {
-    const S pc = (MODE == 0 && !first_it) ? zc + bs * pcold : zc;  // p_c (MODE 0) / x_c (MODE 1)
     if (item.extra < 0) {
       mine += lambda * pc;  // pose damping term of right_multiply
       if (MODE == 0) p_new[9 * c + lane] = pc;
       qmain[9 * c + lane] = mine;
+      if (HALF) pq += double(lambda) * double(pc) * double(pc);
     } else {
       qextra[9 * item.extra + lane] = mine;
     }
-    pq = double(pc) * double(mine);
+    if (!HALF) pq = double(pc) * double(mine);
   }
   if (MODE == 0) {
     pq = wave_sum(pq);
@@ -298,11 +348,31 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
   }
 }
 
-// q_i = first item's sum + the extra items of a long row (fixed order)
+// q_i = first item's sum + the extra items of a long row + (half storage) the transposed contributions of the blocks
+// of earlier rows, each in a fixed order. The slot indices of a batch are requested together, then the values: two
+// memory round trips per batch of eight, not sixteen.
 template <class S>
-__device__ __forceinline__ S pcgs_gather_q(S qm, const S* __restrict__ qextra, int e0, int e1, int row) {
-  for (int q = e0; q < e1; ++q) qm += qextra[9 * q + row];
-  return qm;
+__device__ __forceinline__ S pcgs_gather_q(const QPieces<S>& qp, S qm, int e0, int e1, int l0, int l1, int row) {
+  for (int q = e0; q < e1; ++q) qm += qp.qextra[9 * q + row];
+  if (qp.tpart == nullptr || l1 <= l0) return qm;
+  double acc = double(qm);
+  for (int base = l0; base < l1; base += 8) {
+    int sl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sl[u] = qp.low_slot[min(base + u, l1 - 1)];
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = qp.tpart[size_t(9) * sl[u] + row] * (base + u < l1 ? 1.0 : 0.0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  return S(acc);
+}
+template <class S>
+__device__ __forceinline__ S pcgs_gather_q(const QPieces<S>& qp, int c, int row) {
+  const bool half = qp.tpart != nullptr;
+  return pcgs_gather_q(qp, qp.qmain[9 * c + row], qp.extra_ptr[c], qp.extra_ptr[c + 1], half ? qp.low_ptr[c] : 0,
+                       half ? qp.low_ptr[c + 1] : 0, row);
 }
 
 // phase 0: after the direction product; phase 1: after the refresh product.
@@ -310,9 +380,8 @@ __device__ __forceinline__ S pcgs_gather_q(S qm, const S* __restrict__ qextra, i
 template <class S>
 __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, const S* __restrict__ bvec,
                                                      S* __restrict__ x, S* __restrict__ r, S* __restrict__ z,
-                                                     const S* pbuf0, const S* pbuf1, const S* __restrict__ qmain,
-                                                     const S* __restrict__ qextra,
-                                                     const int* __restrict__ extra_ptr, int n_items, int n_cams,
+                                                     const S* pbuf0, const S* pbuf1, QPieces<S> qp, int n_items,
+                                                     int n_cams,
                                                      CgState* st, const double* __restrict__ part_pq,
                                                      double* __restrict__ part_rho, double* __restrict__ part_q,
                                                      int phase, int period, int* host_progress, int mf, S lambda_mf,
@@ -337,7 +406,7 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
         // (clamped and masked, not selected: a value that is only used under `idx < n` gets its load sunk into a
         //  conditional block, and the sixteen loads of a batch become sixteen waits)
         const int idx = base + u * 256 + tid, ic = min(idx, n - 1);
-        const S pi = pv[ic], qi = qmain[ic] + lambda_mf * pi;
+        const S pi = pv[ic], qi = qp.qmain[ic] + lambda_mf * pi;
         v[u] = double(pi) * double(qi) * (idx < n ? 1.0 : 0.0);
       }
       accp += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
@@ -363,7 +432,8 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
   bool act = tile < n_tiles && tid < 252 && i < 9 * n_cams;
   int c = act ? i / 9 : 0, row = act ? i - 9 * c : 0;
   S xo = S(0), ro = S(0), bo = S(0), po0 = S(0), po1 = S(0), qm = S(0), Mrow[9];
-  int e0 = 0, e1 = 0;
+  int e0 = 0, e1 = 0, l0 = 0, l1 = 0;
+  const bool half = qp.tpart != nullptr;
 #pragma unroll
   for (int j = 0; j < 9; ++j) Mrow[j] = S(0);
   if (act) {
@@ -372,10 +442,14 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
     bo = bvec[i];
     po0 = pbuf0[i];
     po1 = pbuf1[i];
-    qm = qmain[i];
+    qm = qp.qmain[i];
     if (!mf) {
-      e0 = extra_ptr[c];
-      e1 = extra_ptr[c + 1];
+      e0 = qp.extra_ptr[c];
+      e1 = qp.extra_ptr[c + 1];
+      if (half) {
+        l0 = qp.low_ptr[c];
+        l1 = qp.low_ptr[c + 1];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 9; ++j) Mrow[j] = inv[81 * c + 9 * row + j];
@@ -434,10 +508,14 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
         bo = bvec[i];
         po0 = p[i];
         po1 = po0;
-        qm = qmain[i];
+        qm = qp.qmain[i];
         if (!mf) {
-          e0 = extra_ptr[c];
-          e1 = extra_ptr[c + 1];
+          e0 = qp.extra_ptr[c];
+          e1 = qp.extra_ptr[c + 1];
+          if (half) {
+            l0 = qp.low_ptr[c];
+            l1 = qp.low_ptr[c + 1];
+          }
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) Mrow[j] = inv[81 * c + 9 * row + j];
@@ -446,7 +524,7 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
     S xn = S(0), rn = S(0);
     if (act) {
       const S pi = odd ? po1 : po0;
-      const S qv = mf ? qm + lambda_mf * (phase == 0 ? pi : xo) : pcgs_gather_q(qm, qextra, e0, e1, row);
+      const S qv = mf ? qm + lambda_mf * (phase == 0 ? pi : xo) : pcgs_gather_q(qp, qm, e0, e1, l0, l1, row);
       if (phase == 0) {
         xn = xo + a * pi;
         x[i] = xn;
@@ -660,26 +738,22 @@ __global__ void k_pcgs_begin(CgState* st, double lambda, int pswap) {
 
 // y = q (+ the extra items of long rows)   (tests: rba_right_multiply_explicit)
 template <class S>
-__global__ __launch_bounds__(256) void k_pcgs_collect(S* __restrict__ y, const S* __restrict__ qmain,
-                                                      const S* __restrict__ qextra,
-                                                      const int* __restrict__ extra_ptr, int n) {
+__global__ __launch_bounds__(256) void k_pcgs_collect(S* __restrict__ y, QPieces<S> qp, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int c = i / 9, row = i - 9 * c;
-  y[i] = pcgs_gather_q(qmain[i], qextra, extra_ptr[c], extra_ptr[c + 1], row);
+  y[i] = pcgs_gather_q(qp, c, row);
 }
 
 // r = b - (S x + lambda x) from a refresh product (operator switch inside a solve)
 template <class S>
-__global__ __launch_bounds__(256) void k_pcgs_residual(const S* __restrict__ bvec, S* __restrict__ r,
-                                                       const S* __restrict__ qmain, const S* __restrict__ qextra,
-                                                       const int* __restrict__ extra_ptr, int n,
-                                                       const CgState* st) {
+__global__ __launch_bounds__(256) void k_pcgs_residual(const S* __restrict__ bvec, S* __restrict__ r, QPieces<S> qp,
+                                                       int n, const CgState* st) {
   if (st->done) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int c = i / 9, row = i - 9 * c;
-  r[i] = bvec[i] - pcgs_gather_q(qmain[i], qextra, extra_ptr[c], extra_ptr[c + 1], row);
+  r[i] = bvec[i] - pcgs_gather_q(qp, c, row);
 }
 
 }  // namespace rba

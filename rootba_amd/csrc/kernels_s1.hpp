@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
   for (int c = 0; c < 9; ++c) dsc[c] = p.pose_scaling[9 * cam + c];
   const int64_t o0 = p.lm_obs[s];
   const V4* __restrict__ lq = reinterpret_cast<const V4*>(p.LQ + 12 * size_t(s));
-  const V4 q0 = lq[0], q1 = lq[1], q2 = lq[2];
+  const V4 q0 = lq[0], q1 = lq[1];
   const V4 w0 = vh[2 * o0], w1 = vh[2 * o0 + 1], w2 = vh[2 * o0 + 2];
   S g[16];  // the landmark's damping record: c[6], s[6], damping-row residual[3]
   {
@@ -404,8 +404,7 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
   const int i = int(oc - o0);
   __syncthreads();
   if (act) {
-    const S tau0 = q0.x, tau1 = q0.y, tau2 = q0.z, g10 = q0.w, g20 = q1.x, g21 = q1.y, d0 = q1.z, d1 = q1.w,
-            d2 = q2.x;
+    const S tau0 = q0.x, tau1 = q0.y, tau2 = q0.z, g10 = q0.w, g20 = q1.x, g21 = q1.y;
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
       const S m0 = sJ[18 * tid + c] * dsc[c], m1 = sJ[18 * tid + 9 + c] * dsc[c];

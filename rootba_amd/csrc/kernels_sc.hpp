@@ -596,7 +596,8 @@ __global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const S* __restrict__ t
     const int a = threadIdx.x / 9, b = threadIdx.x - 9 * a;
     const S v = -(((tile[0][a][b] + tile[1][a][b]) + tile[2][a][b]) + tile[3][a][b]);
     vals[size_t(81) * upper_slot[u] + threadIdx.x] = v;
-    vals[size_t(81) * mirror_slot[u] + 9 * b + a] = v;
+    const int m = mirror_slot[u];  // (-1: half storage, the block lives in its upper row only)
+    if (m >= 0) vals[size_t(81) * m + 9 * b + a] = v;
   }
 }
 

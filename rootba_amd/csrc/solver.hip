@@ -701,33 +701,62 @@ class Solver final : public rba_solver {
   // co-observation marks (the union over ranks when landmarks are sharded), and the per-block
   // lists of the LOCAL observation pairs (i < j) that contribute to each strictly upper block
   void build_explicit_structure() {
+    // HALF storage (kernels_pcg.hpp): row c holds its diagonal block and the blocks (c, d), d > c; the product's
+    // contribution of such a block to row d travels through a 9-double slot that row d's consumers gather. A camera
+    // with more than kHalfLowerMax earlier neighbours keeps its blocks left of the diagonal too (both copies flagged
+    // in their column index: no slot, weight 1 in p.q), so that no work-item gathers an unbounded list.
     const size_t nc = size_t(n_cams_);
     std::vector<int> slot(nc * nc, -1), row_ptr(nc + 1, 0), cols, diag(nc), upper_slot, mirror_slot;
+    std::vector<uint8_t> heavy(nc, 0);
+    for (size_t c = 0; c < nc; ++c) {
+      int lower = 0;
+      for (size_t d = 0; d < c; ++d) lower += pair_mark_[c * nc + d] ? 1 : 0;
+      heavy[c] = lower > env_.half_lower_max ? 1 : 0;
+    }
     int nnz = 0;
     for (size_t c = 0; c < nc; ++c) {
       row_ptr[c] = nnz;
-      for (size_t d = 0; d < nc; ++d)
-        if (pair_mark_[c * nc + d] || c == d) {
-          if (c == d) diag[c] = nnz;
-          slot[c * nc + d] = nnz++;
-          cols.push_back(int(d));
-        }
+      for (size_t d = 0; d < nc; ++d) {
+        const bool present = d == c || (pair_mark_[c * nc + d] && (d > c || heavy[c]));
+        if (!present) continue;
+        if (c == d) diag[c] = nnz;
+        slot[c * nc + d] = nnz++;
+        // both copies of a duplicated block carry the flag: (c, d) with d < c exists only for a heavy c; (c, d) with
+        // d > c is duplicated when d is heavy
+        const bool dup = d != c && (d < c || heavy[d]);
+        cols.push_back(int(d) | (dup ? rba::kColDup : 0));
+      }
     }
     row_ptr[nc] = nnz;
     std::vector<int> upper_of(size_t(nnz), -1);
+    std::vector<int> low_ptr(nc + 1, 0), low_slot;
     for (size_t c = 0; c < nc; ++c)
       for (size_t d = c + 1; d < nc; ++d)
         if (slot[c * nc + d] >= 0) {
           upper_of[slot[c * nc + d]] = int(upper_slot.size());
           upper_slot.push_back(slot[c * nc + d]);
-          mirror_slot.push_back(slot[d * nc + c]);
+          mirror_slot.push_back(slot[d * nc + c]);  // -1 unless d is heavy
         }
+    for (size_t d = 0; d < nc; ++d) {
+      low_ptr[d] = int(low_slot.size());
+      if (!heavy[d])
+        for (size_t c = 0; c < d; ++c)
+          if (slot[c * nc + d] >= 0) low_slot.push_back(slot[c * nc + d]);
+    }
+    low_ptr[nc] = int(low_slot.size());
+    if (low_slot.empty()) low_slot.push_back(0);
+    d_low_ptr_.alloc(low_ptr.size());
+    d_low_slot_.alloc(low_slot.size());
+    d_low_ptr_.upload(low_ptr.data(), low_ptr.size(), stream_);
+    d_low_slot_.upload(low_slot.data(), low_slot.size(), stream_);
+    d_tpart_.alloc(size_t(9) * nnz);
+    d_tpart_.zero(stream_);
     const int n_upper = int(upper_slot.size());
     std::vector<int64_t> pair_ptr(size_t(n_upper) + 1, 0);
     for (int l = 0; l < n_lms_; ++l) {
       const int64_t o0 = h_lm_obs_[l];
       const int k = int(h_lm_obs_[l + 1] - o0);
-      for (int i = 0; i < k; ++i) {
+      for (int i = 0; i < k; ++i) {  // (cameras ascend inside a landmark: (i, j > i) is a block right of the diagonal)
         const int* row = slot.data() + size_t(h_obs_cam_[o0 + i]) * nc;
         for (int j = i + 1; j < k; ++j) ++pair_ptr[size_t(upper_of[row[h_obs_cam_[o0 + j]]]) + 1];
       }
@@ -885,9 +914,35 @@ class Solver final : public rba_solver {
   template <class F>
   void with_matrix(F&& f) {
     if (sc_)
-      f(static_cast<const int*>(scp_.cols), static_cast<const S*>(scp_.vals));
-    else
-      f(static_cast<const int*>(d_ex_cols_.get()), static_cast<const double*>(d_ex_vals_.get()));
+      f(static_cast<const int*>(scp_.cols), static_cast<const S*>(scp_.vals), std::false_type{});
+    else  // (half storage: kernels_pcg.hpp)
+      f(static_cast<const int*>(d_ex_cols_.get()), static_cast<const double*>(d_ex_vals_.get()), std::true_type{});
+  }
+  // where the pieces of the last product lie (first items, further items of long rows, half storage: transposed parts)
+  rba::QPieces<S> q_pieces() const {
+    rba::QPieces<S> qp{};
+    qp.qmain = d_qmain_.get();
+    qp.qextra = d_qpart_.get();
+    qp.extra_ptr = d_item_ptr_.get();
+    if (!sc_) {
+      qp.tpart = d_tpart_.get();
+      qp.low_ptr = d_low_ptr_.get();
+      qp.low_slot = d_low_slot_.get();
+    }
+    return qp;
+  }
+  // the row-staged SpMV of kernels_pcg.hpp on the PCG's matrix, MODE 0 / 1 / 2
+  template <int MODE>
+  void launch_spmv(const S* z, S* p0, S* p1, const S* xvec, const double* part_rho, const double* part_q,
+                   double* part_pq, double q_tol, int min_it, int max_it, int period, int* progress) {
+    with_matrix([&](const int* cols, auto* vals, auto half) {
+      using MT = std::remove_cv_t<std::remove_pointer_t<decltype(vals)>>;
+      constexpr bool H = decltype(half)::value;
+      hipLaunchKernelGGL((rba::k_pcgs_spmv<S, MODE, MT, H>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<MT>(), stream_,
+                         cols, vals, d_items_.get(), z, p0, p1, xvec, d_qmain_.get(), d_qpart_.get(),
+                         H ? d_tpart_.get() : static_cast<double*>(nullptr), d_cg_.get(), part_rho, part_q, part_pq, q_tol,
+                         min_it, max_it, period, progress);
+    });
   }
 
   // Block structure of the reduced camera matrix: every ordered pair of cameras that
@@ -1451,13 +1506,9 @@ class Solver final : public rba_solver {
         hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_, x, y, done_flag);
       } else {
         // the row-staged SpMV of the fused PCG in its plain-product mode (double blocks, kernels_pcg.hpp) + its collect
-        hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2, double>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<double>(),
-                           stream_, d_ex_cols_.get(), d_ex_vals_.get(), d_items_.get(), static_cast<const S*>(nullptr),
-                           static_cast<S*>(nullptr), static_cast<S*>(nullptr), x, d_qmain_.get(), d_qpart_.get(),
-                           d_cg_.get(), static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
-                           static_cast<double*>(nullptr), 0.0, 0, 0, 1, static_cast<int*>(nullptr));
-        hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y, d_qmain_.get(),
-                           d_qpart_.get(), d_item_ptr_.get(), nvec_);
+        launch_spmv<2>(nullptr, nullptr, nullptr, x, nullptr, nullptr, nullptr, 0.0, 0, 0, 1, nullptr);
+        hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y, q_pieces(),
+                           nvec_);
       }
       if (e1) HIP_CHECK(hipEventRecord(e1, stream_));
       ++hx_calls_;
@@ -1614,34 +1665,21 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, d_cg_.get(), double(pose_damping_), 0);
     launch_pcgs_product(d_vin_.get(), /*period=*/1);
     hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, d_tmp_.get(),
-                       d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), nvec_);
+                       q_pieces(), nvec_);
     d_tmp_.download(static_cast<S*>(y), nvec_, stream_);
     sync();
   }
 
   // q = M x + lambda x   (k_pcgs_spmv, refresh-product mode; lambda from the device state)
   void launch_pcgs_product(const S* x, int period) {
-    with_matrix([&](const int* cols, auto* vals) {
-      using MT = std::remove_cv_t<std::remove_pointer_t<decltype(vals)>>;
-      hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 1, MT>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<MT>(), stream_,
-                         cols, vals, d_items_.get(), static_cast<const S*>(nullptr), static_cast<S*>(nullptr),
-                         static_cast<S*>(nullptr), x, d_qmain_.get(), d_qpart_.get(), d_cg_.get(),
-                         static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
-                         static_cast<double*>(nullptr), 0.0, 0, 0, period, static_cast<int*>(nullptr));
-    });
+    launch_spmv<1>(nullptr, nullptr, nullptr, x, nullptr, nullptr, nullptr, 0.0, 0, 0, period, nullptr);
   }
   // k_pcgs_spmv<0>: direction update + product + p.q partials (also the termination test of the previous iteration)
   void launch_pcgs_direction_product() {
     constexpr int NB = rba::kPcgBlocks;
     double* part_rho = d_pcg_partials_.get();
-    with_matrix([&](const int* cols, auto* vals) {
-      using MT = std::remove_cv_t<std::remove_pointer_t<decltype(vals)>>;
-      hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 0, MT>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<MT>(), stream_,
-                         cols, vals, d_items_.get(), d_z_.get(), d_p_.get(), d_p2_.get(),
-                         static_cast<const S*>(nullptr), d_qmain_.get(), d_qpart_.get(), d_cg_.get(), part_rho,
-                         part_rho + 2 * NB, d_pcgs_pq_.get(), opt_.eta, opt_.min_cg_it, opt_.max_cg_it, kPcgPeriod,
-                         h_progress_);
-    });
+    launch_spmv<0>(d_z_.get(), d_p_.get(), d_p2_.get(), nullptr, part_rho, part_rho + 2 * NB, d_pcgs_pq_.get(), opt_.eta,
+                   opt_.min_cg_it, opt_.max_cg_it, kPcgPeriod, h_progress_);
   }
 
   static constexpr int kPcgPeriod = 10;  // residual_reset_period (conjugate_gradient.hpp:86-88)
@@ -1656,16 +1694,16 @@ class Solver final : public rba_solver {
     double* part_q = part_rho + 2 * NB;
     launch_pcgs_direction_product();
     hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), prm_.b,
-                       d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), d_qmain_.get(),
-                       d_qpart_.get(), d_item_ptr_.get(), n_items_, n_cams_, st, d_pcgs_pq_.get(), part_rho,
-                       part_q, 0, kPcgPeriod, h_progress_, 0, S(0), static_cast<S*>(nullptr));
+                       d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), q_pieces(), n_items_, n_cams_, st,
+                       d_pcgs_pq_.get(), part_rho, part_q, 0, kPcgPeriod, h_progress_, 0, S(0),
+                       static_cast<S*>(nullptr));
     if (with_refresh) {
       // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
       launch_pcgs_product(d_x_.get(), kPcgPeriod);
       hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), prm_.b,
-                         d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), d_qmain_.get(),
-                         d_qpart_.get(), d_item_ptr_.get(), n_items_, n_cams_, st, d_pcgs_pq_.get(), part_rho,
-                         part_q, 1, kPcgPeriod, h_progress_, 0, S(0), static_cast<S*>(nullptr));
+                         d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), q_pieces(), n_items_, n_cams_,
+                         st, d_pcgs_pq_.get(), part_rho, part_q, 1, kPcgPeriod, h_progress_, 0, S(0),
+                         static_cast<S*>(nullptr));
     }
   }
 
@@ -1708,7 +1746,7 @@ class Solver final : public rba_solver {
       // from here on, r = b - (S + lambda I) x, exactly like the periodic refresh
       launch_pcgs_product(d_x_.get(), 1);
       hipLaunchKernelGGL((rba::k_pcgs_residual<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, prm_.b,
-                         d_r_.get(), d_qmain_.get(), d_qpart_.get(), d_item_ptr_.get(), n, st);
+                         d_r_.get(), q_pieces(), n, st);
     }
     hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(), d_z_.get(),
                        n, st, part_rho);
@@ -1908,10 +1946,12 @@ class Solver final : public rba_solver {
         return pre;
       };
       auto update = [&](int phase, const S* product) {
+        rba::QPieces<S> qp{};  // (matrix-free product: one complete vector)
+        qp.qmain = product;
         hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), b, d_x_.get(),
-                           d_r_.get(), d_z_.get(), d_p_.get(), d_p_.get(), product, static_cast<const S*>(nullptr),
-                           static_cast<const int*>(nullptr), 0, n_cams_, st, static_cast<const double*>(nullptr),
-                           part_rho, part_q1, phase, kPcgPeriod, h_progress_, 1, lambda, d_tmp_.get());
+                           d_r_.get(), d_z_.get(), d_p_.get(), d_p_.get(), qp, 0, n_cams_, st,
+                           static_cast<const double*>(nullptr), part_rho, part_q1, phase, kPcgPeriod, h_progress_, 1,
+                           lambda, d_tmp_.get());
       };
       // the device publishes the iteration it has started (hp[0]) or the end of the solve (hp[1])
       auto started = [&](int k) {
@@ -2003,16 +2043,10 @@ class Solver final : public rba_solver {
           if (series_on_matrix) {
             // through the assembled matrix: (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t), no collective
             // the row-staged SpMV of the fused PCG (kernels_pcg.hpp, plain-product mode) + its collect
-            with_matrix([&](const int* cols, auto* vals) {
-              using MT = std::remove_cv_t<std::remove_pointer_t<decltype(vals)>>;
-              hipLaunchKernelGGL((rba::k_pcgs_spmv<S, 2, MT>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<MT>(),
-                                 stream_, cols, vals, d_items_.get(), static_cast<const S*>(nullptr),
-                                 static_cast<S*>(nullptr), static_cast<S*>(nullptr), t, d_qmain_.get(), d_qpart_.get(),
-                                 st, static_cast<const double*>(nullptr), static_cast<const double*>(nullptr),
-                                 static_cast<double*>(nullptr), double(lambda), 0, 0, 1, static_cast<int*>(nullptr));
-            });
-            hipLaunchKernelGGL((rba::k_series_step<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_qmain_.get(),
-                               d_qpart_.get(), d_item_ptr_.get(), t, d_z_.get(), n, st);
+            launch_spmv<2>(nullptr, nullptr, nullptr, t, nullptr, nullptr, nullptr, double(lambda), 0, 0, 1, nullptr);
+            hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, e, q_pieces(), n);
+            hipLaunchKernelGGL((rba::k_series_step<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), e, t, d_z_.get(), n,
+                               st);
             continue;
           }
           launch_e0(t, e, done);
@@ -2509,6 +2543,7 @@ class Solver final : public rba_solver {
     const int64_t nnz = sc_ ? sc_nnz_ : ex_nnz_;
     const int64_t ms = sc_ ? s : int64_t(sizeof(double));  // the assembled matrix of the square-root solver is double
     m->product_assembled = nnz * (81 * ms + 4) + nc * 18 * s;
+    if (!sc_) m->product_assembled += int64_t(nnz) * (2 * 9 * 8 + 4);  // half storage: the transposed parts out and back in
     // assembly, COMPULSORY bytes: the pair list (8 B per pair), every 32-scalar record once, the blocks out. The
     // gather itself requests two records per pair (256 B in float); what L2 does not keep of that is re-read traffic
     // and shows up as measured / model > 1 (profiles/r3_pmc_stage_traffic.csv), not as algorithmic bytes.
@@ -2653,6 +2688,8 @@ class Solver final : public rba_solver {
     int sort_by_camera = -1;           // RBA_SORT_BY_CAMERA=0/1: override the automatic choice
     int verify_assembled = 1;          // RBA_VERIFY_ASSEMBLED=0: skip the one-product check of assembled-operator solves
     double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
+    int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: earlier neighbours above which a camera's row of
+                                              // the assembled matrix is stored in full (tests of that path)
   };
   DebugEnv env_;
   void read_debug_env() {
@@ -2670,6 +2707,7 @@ class Solver final : public rba_solver {
     env_.sort_by_camera = geti("RBA_SORT_BY_CAMERA", -1);
     env_.verify_assembled = geti("RBA_VERIFY_ASSEMBLED", 1);
     if (const char* ev = std::getenv("RBA_VERIFY_TOLERANCE")) env_.verify_tolerance = std::atof(ev);
+    env_.half_lower_max = geti("RBA_HALF_LOWER_MAX", rba::kHalfLowerMax);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }
 
@@ -2752,7 +2790,9 @@ class Solver final : public rba_solver {
   std::vector<int> h_obs_cam_;
   DevBuf<int> d_ex_rowptr_, d_ex_cols_, d_ex_diag_, d_ex_upper_, d_ex_mirror_, d_ex_pair_oi_, d_ex_pair_oj_;
   DevBuf<int64_t> d_ex_pair_ptr_;
-  DevBuf<double> d_ex_vals_;  // always double (assemble_values)
+  DevBuf<double> d_ex_vals_;  // always double (assemble_values), half storage (kernels_pcg.hpp)
+  DevBuf<double> d_tpart_;    // [9 nnz] transposed contributions of the blocks right of the diagonal, per product
+  DevBuf<int> d_low_ptr_, d_low_slot_;
   // float solver: double re-derivation of the factors for the assembled matrix (kernels_a64.hpp)
   static constexpr bool kA64 = std::is_same<S, float>::value;
   DevBuf<double> d_a64_lq_, d_a64_A_, d_a64_topd_;
@@ -2900,6 +2940,13 @@ int rba_create(int dtype, int device, int32_t n_cams, int32_t n_lms,
         g_last_error = std::string("rba_create: ") + bad;
         return RBA_ERR_INVALID_ARGUMENT;
       }
+    }
+    if (options->implicit_q == 0) {
+      static bool warned = false;
+      if (!warned)
+        std::fprintf(stderr, "[rootba_hip] rba_options.implicit_q = 0 is ignored: the dense-block products were removed in "
+                             "round 3, H*x is always evaluated from the factors\n");
+      warned = true;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
