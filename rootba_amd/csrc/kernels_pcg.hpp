@@ -42,14 +42,17 @@ namespace rba {
 constexpr int kSpmvChunksPerItem = 4;  // 64-block chunks walked by one wavefront
 
 // HALF STORAGE (the assembled reduced matrix of the square-root solver; round 4). The matrix is symmetric and its
-// values are double (kernels_a64.hpp), so the SpMV is a stream of 8-byte scalars: a row holds its diagonal block and
-// its blocks RIGHT of the diagonal only; the wavefront of row c multiplies block (c, j) twice out of the same LDS copy -
-// S_cj v_j into its own row sums and the transposed S_cj^T v_c into a 9-double slot of `tpart` that belongs to the
-// block - and whoever consumes q_j adds the slots of the blocks (c, j), c < j, in a FIXED order (QPieces / pcgs_gather_q:
-// bitwise reproducible, identical on all ranks of a sharded run - an atomic scatter would not be). p.q needs no
-// complete q: it is sum over stored blocks of w p_c^T S_cj p_j with w = 2 right of the diagonal. Half the bytes per
-// product (venice-1778: 35 instead of 70 MB), half the all-reduce of a sharded assembly.
-// A camera that co-observes with very many EARLIER cameras would gather very many slots in one work-item: above
+// values are double (kernels_a64.hpp), so the SpMV is a stream of 8-byte scalars. Every off-diagonal block {c, d} is
+// stored ONCE, in the row of its OWNER - c or d, alternating with the parity of c + d, so that every row owns about
+// half of its blocks (an upper-triangular assignment would give the first rows all of theirs and the last rows none:
+// the longest wavefront decides the kernel time) - as the owner sees it (S_cd in row c, S_dc = S_cd^T in row d).
+// The wavefront of row c multiplies its block (c, j) twice out of the same LDS copy - S_cj v_j into its own row sums
+// and the transposed S_cj^T v_c into a 9-double slot of `tpart` - and the slots of the blocks row j does NOT own are
+// laid out row by row, so whoever consumes q_j adds a CONTIGUOUS run of slots in a fixed order (QPieces /
+// pcgs_gather_q: bitwise reproducible, identical on all ranks of a sharded run - an atomic scatter would not be).
+// p.q needs no complete q: it is the sum over stored blocks of w p_c^T S_cj p_j with w = 2 off the diagonal.
+// Half the bytes per product (venice-1778: 35 instead of 70 MB), half the all-reduce of a sharded assembly.
+// A camera with very many neighbours it does not own would gather very many slots in one work-item: above
 // kHalfLowerMax such blocks are stored in BOTH rows instead (flag bit 31 of the column index: no slot, weight 1).
 constexpr int kHalfLowerMax = 192;
 constexpr int kColDup = int(0x80000000u);
@@ -60,9 +63,8 @@ struct QPieces {
   const S* __restrict__ qmain;         // [9 n_c] sums of a row's first item
   const S* __restrict__ qextra;        // [9 n_extra] sums of the further items of long rows ...
   const int* __restrict__ extra_ptr;   // [n_c + 1]    ... of row c: extra_ptr[c] .. extra_ptr[c + 1]
-  const double* __restrict__ tpart;    // [9 nnz] half storage: transposed contribution of block `slot` (nullptr: full storage)
-  const int* __restrict__ low_ptr;     // [n_c + 1]
-  const int* __restrict__ low_slot;    // slots of the blocks (c', c), c' < c, stored in earlier rows, ascending c'
+  const double* __restrict__ tpart;    // [9 n_slots] half storage: transposed contributions, grouped by RECEIVING row
+  const int* __restrict__ low_ptr;     // [n_c + 1]   (nullptr tpart: full storage) ... row c: low_ptr[c] .. low_ptr[c + 1]
 };
 
 struct SpmvItem {
@@ -87,12 +89,17 @@ struct Vec16<double> {
   static constexpr int N = 2;
 };
 
+constexpr int kSpmvPass = 21;  // 16-byte loads in flight per lane: 21.5 KB per wavefront, ONE chunk of either scalar
+// blocks per chunk = what one pass of kSpmvPass loads per lane covers: 64 float blocks, 32 double blocks (a second
+// pass would be a second, dependent memory round trip of the wavefront)
+template <class S>
+constexpr int spmv_chunk_blocks() {
+  return 64 * 4 / int(sizeof(S));
+}
 template <class S>
 constexpr size_t spmv_lds_bytes() {
-  return (size_t(64) * 81 + Vec16<S>::N) * sizeof(S);
+  return (size_t(spmv_chunk_blocks<S>()) * 81 + Vec16<S>::N) * sizeof(S);
 }
-
-constexpr int kSpmvPass = 21;  // 16-byte loads in flight per lane (float: a whole 64-block chunk)
 
 // One 64-block chunk of a row strip: the chunk's scalars [81 chunk, 81 (chunk + nb)) are copied to
 // LDS at the same 16-byte phase with fully coalesced 16-byte loads (kSpmvPass per lane in flight).
@@ -173,7 +180,8 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
                                                   const SpmvItem* __restrict__ items, const S* __restrict__ z,
                                                   S* pbuf0, S* pbuf1, const S* __restrict__ xvec,
                                                   S* __restrict__ qmain, S* __restrict__ qextra,
-                                                  double* __restrict__ tpart, CgState* st, const double* __restrict__ part_rho,
+                                                  double* __restrict__ tpart, const int* __restrict__ tdst,
+                                                  CgState* st, const double* __restrict__ part_rho,
                                                   const double* __restrict__ part_q,
                                                   double* __restrict__ part_pq, double q_tolerance, int min_it,
                                                   int max_it, int period, int* host_progress) {
@@ -186,10 +194,13 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
   // ---- round 2: everything that depends on the item only. vmcnt retires in order: what the
   //      next round needs (column indices, partials) is requested BEFORE the 21 matrix vectors
   ChunkStage<MT> cs;
-  const int nb0 = min(64, item.slot1 - item.slot0);
+  constexpr int CB = spmv_chunk_blocks<MT>();
+  static_assert((81 * CB + 2 * (Vec16<MT>::N - 1)) / Vec16<MT>::N <= 64 * kSpmvPass, "a chunk is one pass of loads");
+  const int nb0 = min(CB, item.slot1 - item.slot0);
   const bool act0 = lane < nb0;
   const int colraw0 = cols[item.slot0 + min(lane, nb0 - 1)];
   const int col0 = HALF ? (colraw0 & ~kColDup) : colraw0;
+  const int td0 = HALF ? tdst[item.slot0 + min(lane, nb0 - 1)] : -1;  // slot of the transposed product (-1: none)
   double prho = 0, pq1 = 0;
   if (MODE == 0) {
     prho = part_rho[lane];
@@ -293,24 +304,19 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
   for (int t = 0; t < 9; ++t) vc[t] = HALF ? read_lane(pc, t) : S(0);
   double pq = 0.0;
   cs.store(0, lane, tmp, lds);
-  for (int v0 = 64 * kSpmvPass; v0 < cs.nvec; v0 += 64 * kSpmvPass) {  // double: second half of the chunk
-    cs.issue(v0, lane, tmp);
-    cs.store(v0, lane, tmp, lds);
-  }
   __syncthreads();
-  spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act0, xv, acc, vc, HALF && col0 != c && colraw0 >= 0,
-                                HALF ? tpart + size_t(9) * (item.slot0 + lane) : nullptr, pq);
-  for (int chunk = item.slot0 + 64; chunk < item.slot1; chunk += 64) {  // long rows only
+  spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act0, xv, acc, vc, HALF && td0 >= 0,
+                                HALF ? tpart + size_t(9) * max(td0, 0) : nullptr, pq);
+  for (int chunk = item.slot0 + CB; chunk < item.slot1; chunk += CB) {  // long rows only
     __syncthreads();  // the staging buffer is overwritten
-    const int nb = min(64, item.slot1 - chunk);
+    const int nb = min(CB, item.slot1 - chunk);
     const bool act = lane < nb;
     const int colraw = act ? cols[chunk + lane] : 0;
     const int col = HALF ? (colraw & ~kColDup) : colraw;
+    const int td = (HALF && act) ? tdst[chunk + lane] : -1;
     cs.setup(vals, chunk, nb);
-    for (int v0 = 0; v0 < cs.nvec; v0 += 64 * kSpmvPass) {
-      cs.issue(v0, lane, tmp);
-      cs.store(v0, lane, tmp, lds);
-    }
+    cs.issue(0, lane, tmp);
+    cs.store(0, lane, tmp, lds);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       if (MODE == 0) {
@@ -322,8 +328,8 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
       }
     }
     __syncthreads();
-    spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act, xv, acc, vc, HALF && col != c && colraw >= 0,
-                                  HALF ? tpart + size_t(9) * (chunk + lane) : nullptr, pq);
+    spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act, xv, acc, vc, HALF && td >= 0,
+                                  HALF ? tpart + size_t(9) * max(td, 0) : nullptr, pq);
   }
   S mine = S(0);
 #pragma unroll
@@ -349,22 +355,19 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
 }
 
 // q_i = first item's sum + the extra items of a long row + (half storage) the transposed contributions of the blocks
-// of earlier rows, each in a fixed order. The slot indices of a batch are requested together, then the values: two
-// memory round trips per batch of eight, not sixteen.
+// other rows own, each in a fixed order. The slots of a row are contiguous: all loads of a batch of sixteen are
+// requested together (one memory round trip per batch).
 template <class S>
 __device__ __forceinline__ S pcgs_gather_q(const QPieces<S>& qp, S qm, int e0, int e1, int l0, int l1, int row) {
   for (int q = e0; q < e1; ++q) qm += qp.qextra[9 * q + row];
   if (qp.tpart == nullptr || l1 <= l0) return qm;
   double acc = double(qm);
-  for (int base = l0; base < l1; base += 8) {
-    int sl[8];
+  for (int base = l0; base < l1; base += 16) {
+    double v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) sl[u] = qp.low_slot[min(base + u, l1 - 1)];
-    double v[8];
+    for (int u = 0; u < 16; ++u) v[u] = qp.tpart[size_t(9) * min(base + u, l1 - 1) + row] * (base + u < l1 ? 1.0 : 0.0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = qp.tpart[size_t(9) * sl[u] + row] * (base + u < l1 ? 1.0 : 0.0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
+    for (int u = 0; u < 16; ++u) acc += v[u];
   }
   return S(acc);
 }

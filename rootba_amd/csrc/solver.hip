@@ -701,64 +701,73 @@ class Solver final : public rba_solver {
   // co-observation marks (the union over ranks when landmarks are sharded), and the per-block
   // lists of the LOCAL observation pairs (i < j) that contribute to each strictly upper block
   void build_explicit_structure() {
-    // HALF storage (kernels_pcg.hpp): row c holds its diagonal block and the blocks (c, d), d > c; the product's
-    // contribution of such a block to row d travels through a 9-double slot that row d's consumers gather. A camera
-    // with more than kHalfLowerMax earlier neighbours keeps its blocks left of the diagonal too (both copies flagged
-    // in their column index: no slot, weight 1 in p.q), so that no work-item gathers an unbounded list.
+    // HALF storage (kernels_pcg.hpp): every off-diagonal block {c, d} lives in the row of its owner - the smaller
+    // index when c + d is even, the larger when it is odd: every row owns about half of its blocks -, as the owner
+    // sees it; the product's contribution to the OTHER row travels through a 9-double slot, and the slots a row
+    // receives are contiguous (low_ptr). A camera that would receive more than kHalfLowerMax slots stores those
+    // blocks too (both copies flagged in their column index: no slot, weight 1 in p.q), so that no work-item gathers
+    // an unbounded run.
     const size_t nc = size_t(n_cams_);
+    auto owner_is_first = [](size_t c, size_t d) { return ((c + d) & 1) == 0 ? c < d : c > d; };  // does c own {c, d}?
     std::vector<int> slot(nc * nc, -1), row_ptr(nc + 1, 0), cols, diag(nc), upper_slot, mirror_slot;
     std::vector<uint8_t> heavy(nc, 0);
     for (size_t c = 0; c < nc; ++c) {
-      int lower = 0;
-      for (size_t d = 0; d < c; ++d) lower += pair_mark_[c * nc + d] ? 1 : 0;
-      heavy[c] = lower > env_.half_lower_max ? 1 : 0;
+      int received = 0;
+      for (size_t d = 0; d < nc; ++d) received += (d != c && pair_mark_[c * nc + d] && !owner_is_first(c, d)) ? 1 : 0;
+      heavy[c] = received > env_.half_lower_max ? 1 : 0;
     }
     int nnz = 0;
     for (size_t c = 0; c < nc; ++c) {
       row_ptr[c] = nnz;
       for (size_t d = 0; d < nc; ++d) {
-        const bool present = d == c || (pair_mark_[c * nc + d] && (d > c || heavy[c]));
+        const bool present = d == c || (pair_mark_[c * nc + d] && (owner_is_first(c, d) || heavy[c]));
         if (!present) continue;
         if (c == d) diag[c] = nnz;
         slot[c * nc + d] = nnz++;
-        // both copies of a duplicated block carry the flag: (c, d) with d < c exists only for a heavy c; (c, d) with
-        // d > c is duplicated when d is heavy
-        const bool dup = d != c && (d < c || heavy[d]);
+        // both copies of a duplicated block carry the flag: (c, d) that c does not own exists only for a heavy c; one
+        // that c owns is duplicated when d is heavy
+        const bool dup = d != c && (!owner_is_first(c, d) || heavy[d]);
         cols.push_back(int(d) | (dup ? rba::kColDup : 0));
       }
     }
     row_ptr[nc] = nnz;
-    std::vector<int> upper_of(size_t(nnz), -1);
-    std::vector<int> low_ptr(nc + 1, 0), low_slot;
+    // slots of the transposed products, grouped by receiving row (ascending sender): tdst[slot of (c, d)] = position in
+    // row d's run, for the blocks stored once
+    std::vector<int> low_ptr(nc + 1, 0), tdst(size_t(nnz), -1);
+    {
+      int n_slots = 0;
+      for (size_t d = 0; d < nc; ++d) {
+        low_ptr[d] = n_slots;
+        if (!heavy[d])
+          for (size_t c = 0; c < nc; ++c)
+            if (c != d && slot[c * nc + d] >= 0 && slot[d * nc + c] < 0) tdst[slot[c * nc + d]] = n_slots++;
+      }
+      low_ptr[nc] = n_slots;
+      d_low_ptr_.alloc(low_ptr.size());
+      d_low_ptr_.upload(low_ptr.data(), low_ptr.size(), stream_);
+      d_tdst_.alloc(tdst.size());
+      d_tdst_.upload(tdst.data(), tdst.size(), stream_);
+      d_tpart_.alloc(size_t(9) * std::max(1, n_slots));
+      d_tpart_.zero(stream_);
+    }
+    // the blocks as the assembly produces them: (c, d) with c < d from the observation pairs (i, j > i) of a landmark;
+    // written straight into row c and / or transposed into row d, wherever it is stored
+    std::vector<int> upper_index(nc * nc, -1);
     for (size_t c = 0; c < nc; ++c)
       for (size_t d = c + 1; d < nc; ++d)
-        if (slot[c * nc + d] >= 0) {
-          upper_of[slot[c * nc + d]] = int(upper_slot.size());
-          upper_slot.push_back(slot[c * nc + d]);
-          mirror_slot.push_back(slot[d * nc + c]);  // -1 unless d is heavy
+        if (pair_mark_[c * nc + d]) {
+          upper_index[c * nc + d] = int(upper_slot.size());
+          upper_slot.push_back(slot[c * nc + d]);   // -1: stored in row d only
+          mirror_slot.push_back(slot[d * nc + c]);  // -1: stored in row c only
         }
-    for (size_t d = 0; d < nc; ++d) {
-      low_ptr[d] = int(low_slot.size());
-      if (!heavy[d])
-        for (size_t c = 0; c < d; ++c)
-          if (slot[c * nc + d] >= 0) low_slot.push_back(slot[c * nc + d]);
-    }
-    low_ptr[nc] = int(low_slot.size());
-    if (low_slot.empty()) low_slot.push_back(0);
-    d_low_ptr_.alloc(low_ptr.size());
-    d_low_slot_.alloc(low_slot.size());
-    d_low_ptr_.upload(low_ptr.data(), low_ptr.size(), stream_);
-    d_low_slot_.upload(low_slot.data(), low_slot.size(), stream_);
-    d_tpart_.alloc(size_t(9) * nnz);
-    d_tpart_.zero(stream_);
     const int n_upper = int(upper_slot.size());
     std::vector<int64_t> pair_ptr(size_t(n_upper) + 1, 0);
     for (int l = 0; l < n_lms_; ++l) {
       const int64_t o0 = h_lm_obs_[l];
       const int k = int(h_lm_obs_[l + 1] - o0);
       for (int i = 0; i < k; ++i) {  // (cameras ascend inside a landmark: (i, j > i) is a block right of the diagonal)
-        const int* row = slot.data() + size_t(h_obs_cam_[o0 + i]) * nc;
-        for (int j = i + 1; j < k; ++j) ++pair_ptr[size_t(upper_of[row[h_obs_cam_[o0 + j]]]) + 1];
+        const int* row = upper_index.data() + size_t(h_obs_cam_[o0 + i]) * nc;
+        for (int j = i + 1; j < k; ++j) ++pair_ptr[size_t(row[h_obs_cam_[o0 + j]]) + 1];
       }
     }
     for (int t = 0; t < n_upper; ++t) pair_ptr[t + 1] += pair_ptr[t];
@@ -771,9 +780,9 @@ class Solver final : public rba_solver {
         const int64_t o0 = h_lm_obs_[l];
         const int k = int(h_lm_obs_[l + 1] - o0);
         for (int i = 0; i < k; ++i) {
-          const int* row = slot.data() + size_t(h_obs_cam_[o0 + i]) * nc;
+          const int* row = upper_index.data() + size_t(h_obs_cam_[o0 + i]) * nc;
           for (int j = i + 1; j < k; ++j) {
-            const int64_t d = fill[upper_of[row[h_obs_cam_[o0 + j]]]]++;
+            const int64_t d = fill[row[h_obs_cam_[o0 + j]]]++;
             pair_oi[d] = int(o0 + i);
             pair_oj[d] = int(o0 + j);
           }
@@ -782,7 +791,8 @@ class Solver final : public rba_solver {
     }
     ex_nnz_ = nnz;
     ex_n_upper_ = n_upper;
-    build_spmv_items(row_ptr);
+    // one chunk of 32 double blocks per item: every wavefront is one pass of loads (kernels_pcg.hpp)
+    build_spmv_items(row_ptr, rba::spmv_chunk_blocks<double>());
     d_ex_rowptr_.alloc(row_ptr.size());
     d_ex_cols_.alloc(cols.size());
     d_ex_diag_.alloc(diag.size());
@@ -817,11 +827,10 @@ class Solver final : public rba_solver {
 
   // work items of the fused PCG's SpMV (kernels_pcg.hpp): one wavefront per block row, rows with
   // more than 64 * kSpmvChunksPerItem blocks are split (their partial sums are added in item order)
-  void build_spmv_items(const std::vector<int>& row_ptr) {
+  void build_spmv_items(const std::vector<int>& row_ptr, int span) {
     destroy_pcg_graphs();  // they hold the addresses of the buffers (re)allocated here
     std::vector<rba::SpmvItem> items;
     std::vector<int> extra_ptr(size_t(n_cams_) + 1, 0);
-    const int span = 64 * rba::kSpmvChunksPerItem;
     int n_extra = 0;
     for (int c = 0; c < n_cams_; ++c) {
       extra_ptr[c] = n_extra;
@@ -927,7 +936,6 @@ class Solver final : public rba_solver {
     if (!sc_) {
       qp.tpart = d_tpart_.get();
       qp.low_ptr = d_low_ptr_.get();
-      qp.low_slot = d_low_slot_.get();
     }
     return qp;
   }
@@ -940,7 +948,8 @@ class Solver final : public rba_solver {
       constexpr bool H = decltype(half)::value;
       hipLaunchKernelGGL((rba::k_pcgs_spmv<S, MODE, MT, H>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<MT>(), stream_,
                          cols, vals, d_items_.get(), z, p0, p1, xvec, d_qmain_.get(), d_qpart_.get(),
-                         H ? d_tpart_.get() : static_cast<double*>(nullptr), d_cg_.get(), part_rho, part_q, part_pq, q_tol,
+                         H ? d_tpart_.get() : static_cast<double*>(nullptr),
+                         H ? d_tdst_.get() : static_cast<const int*>(nullptr), d_cg_.get(), part_rho, part_q, part_pq, q_tol,
                          min_it, max_it, period, progress);
     });
   }
@@ -976,7 +985,7 @@ class Solver final : public rba_solver {
     }
     row_ptr[nc] = nnz;
     sc_nnz_ = nnz;
-    build_spmv_items(row_ptr);
+    build_spmv_items(row_ptr, rba::spmv_chunk_blocks<S>() * rba::kSpmvChunksPerItem);
     // upper blocks (ci <= cj; cameras ascend inside a landmark, so i <= j) and, per upper
     // block, the list of contributing observation pairs (counting sort, landmark order)
     std::vector<int> upper_of(size_t(nnz), -1), upper_slot, mirror_slot;
@@ -2792,7 +2801,7 @@ class Solver final : public rba_solver {
   DevBuf<int64_t> d_ex_pair_ptr_;
   DevBuf<double> d_ex_vals_;  // always double (assemble_values), half storage (kernels_pcg.hpp)
   DevBuf<double> d_tpart_;    // [9 nnz] transposed contributions of the blocks right of the diagonal, per product
-  DevBuf<int> d_low_ptr_, d_low_slot_;
+  DevBuf<int> d_low_ptr_, d_tdst_;
   // float solver: double re-derivation of the factors for the assembled matrix (kernels_a64.hpp)
   static constexpr bool kA64 = std::is_same<S, float>::value;
   DevBuf<double> d_a64_lq_, d_a64_A_, d_a64_topd_;

@@ -280,7 +280,8 @@ def _fixture_rows(name, dts="float32", **extra):
         lam, n32 = float(fx[f"lambda_{it}"]), int(fx[f"cg32_{it}"])
         ig, cg = g.solve(lam)
         row = {"it": int(it), "lambda": lam, "cost_rel": float(abs(eg.all_error - fx[f"cost_{it}"]) / fx[f"cost_{it}"]),
-               "cg_gpu": cg.num_iterations, "cg_oracle": n32, "termination": cg.termination_type}
+               "cg_gpu": cg.num_iterations, "cg_oracle": n32, "termination": cg.termination_type,
+               "termination_oracle": int(fx[f"term32_{it}"])}
         same = ig
         if cg.num_iterations != n32:
             gn = LinearizorHIP(prob, gdt, L.default_options(**dict(kw, max_cg_it=n32, eta=0.0)))
@@ -296,6 +297,12 @@ def _fixture_rows(name, dts="float32", **extra):
         l_diff = g.apply(fx[f"inc32_{it}"])
         row["l_diff_rel"] = float(abs(l_diff - fx[f"l_diff_{it}"]) / abs(fx[f"l_diff_{it}"]))
         rows.append(row)
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):  # (the numbers DESIGN.md quotes)
+        with open(os.path.join(out, f"fixture_lockstep_{name}_{dts}.jsonl"), "w") as f:
+            f.writelines(json.dumps(r) + "\n" for r in rows)
     return rows
 
 
@@ -308,7 +315,9 @@ def test_config4_venice1778_f32_increment_vectors_long_solves():
     rows = _fixture_rows("venice-1778")
     assert len(rows) >= 5
     for r in rows:
-        assert r["termination"] == 1 and abs(r["cg_gpu"] - r["cg_oracle"]) <= max(1, r["cg_oracle"] // 50), r
+        # (iteration 8 runs into max_linear_solver_iterations = 500 in the oracle too: NO_CONVERGENCE for both)
+        assert r["termination"] == r["termination_oracle"], r
+        assert abs(r["cg_gpu"] - r["cg_oracle"]) <= max(1, r["cg_oracle"] // 50), r
         assert r["cost_rel"] < 2e-6 and r["l_diff_rel"] < 2e-3, r
         assert r["inc_rel"] <= 2 * r["oracle32_vs_f64"] + 2e-4, r
         assert r["gpu_vs_f64"] <= 1.5 * r["oracle32_vs_f64"] + 1e-4, r
