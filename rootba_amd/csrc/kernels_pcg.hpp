@@ -43,9 +43,10 @@ constexpr int kSpmvChunksPerItem = 4;  // 64-block chunks walked by one wavefron
 
 // HALF STORAGE (the assembled reduced matrix of the square-root solver; round 4). The matrix is symmetric and its
 // values are double (kernels_a64.hpp), so the SpMV is a stream of 8-byte scalars. Every off-diagonal block {c, d} is
-// stored ONCE, in the row of its OWNER - c or d, alternating with the parity of c + d, so that every row owns about
-// half of its blocks (an upper-triangular assignment would give the first rows all of theirs and the last rows none:
-// the longest wavefront decides the kernel time) - as the owner sees it (S_cd in row c, S_dc = S_cd^T in row d).
+// stored ONCE, in the row of its OWNER - c or d, chosen on the host so that every row owns about half of its blocks
+// and as few rows as possible more than one wavefront's worth (Solver::build_explicit_structure; an upper-triangular
+// assignment would give the first rows all of theirs and the last rows none: the longest wavefront decides the kernel
+// time) - as the owner sees it (S_cd in row c, S_dc = S_cd^T in row d).
 // The wavefront of row c multiplies its block (c, j) twice out of the same LDS copy - S_cj v_j into its own row sums
 // and the transposed S_cj^T v_c into a 9-double slot of `tpart` - and the slots of the blocks row j does NOT own are
 // laid out row by row, so whoever consumes q_j adds a CONTIGUOUS run of slots in a fixed order (QPieces /
@@ -94,7 +95,7 @@ constexpr int kSpmvPass = 21;  // 16-byte loads in flight per lane: 21.5 KB per 
 // pass would be a second, dependent memory round trip of the wavefront)
 template <class S>
 constexpr int spmv_chunk_blocks() {
-  return 64 * 4 / int(sizeof(S));
+  return sizeof(S) == 8 ? 33 : 64;  // (81 CB scalars + alignment slack <= 64 kSpmvPass 16-byte vectors)
 }
 template <class S>
 constexpr size_t spmv_lds_bytes() {
@@ -146,6 +147,9 @@ __device__ __forceinline__ void spmv_block_times(const MT* lds, int off, int lan
     MT tt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dot = MT(0);
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
+      // (three block rows at a time: left alone the scheduler hoists all 81 LDS reads of a double block - 162
+      //  registers - above the arithmetic, and the kernel needs more than 256 registers: one wavefront per SIMD)
+      if (sizeof(MT) == 8 && a % 3 == 0 && a > 0) __builtin_amdgcn_sched_barrier(0);
       MT t = MT(0);
 #pragma unroll
       for (int b = 0; b < 9; ++b) {
@@ -176,7 +180,7 @@ __device__ __forceinline__ void spmv_block_times(const MT* lds, int off, int lan
 //   round 3  the gathers of z / p (need the column indices)
 // The termination decision is evaluated while rounds 2/3 are in flight.
 template <class S, int MODE, class MT = S, bool HALF = false>
-__global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, const MT* __restrict__ vals,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_pcgs_spmv(const int* __restrict__ cols, const MT* __restrict__ vals,
                                                   const SpmvItem* __restrict__ items, const S* __restrict__ z,
                                                   S* pbuf0, S* pbuf1, const S* __restrict__ xvec,
                                                   S* __restrict__ qmain, S* __restrict__ qextra,
@@ -307,7 +311,8 @@ __global__ __launch_bounds__(64) void k_pcgs_spmv(const int* __restrict__ cols, 
   __syncthreads();
   spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act0, xv, acc, vc, HALF && td0 >= 0,
                                 HALF ? tpart + size_t(9) * max(td0, 0) : nullptr, pq);
-  for (int chunk = item.slot0 + CB; chunk < item.slot1; chunk += CB) {  // long rows only
+  // (half storage: an item is ONE chunk - Solver::build_explicit_structure splits rows at spmv_chunk_blocks<double>())
+  for (int chunk = item.slot0 + CB; !HALF && chunk < item.slot1; chunk += CB) {  // long rows only
     __syncthreads();  // the staging buffer is overwritten
     const int nb = min(CB, item.slot1 - chunk);
     const bool act = lane < nb;

@@ -708,7 +708,61 @@ class Solver final : public rba_solver {
     // blocks too (both copies flagged in their column index: no slot, weight 1 in p.q), so that no work-item gathers
     // an unbounded run.
     const size_t nc = size_t(n_cams_);
-    auto owner_is_first = [](size_t c, size_t d) { return ((c + d) & 1) == 0 ? c < d : c > d; };  // does c own {c, d}?
+    // Ownership. Start: parity of c + d (every row owns about half of its blocks). Then blocks are handed over from
+    // rows that own more than one wavefront's worth (CB blocks incl. the diagonal one: such a row needs a second
+    // work item) to neighbours with room, directly or through a full neighbour (chains of two) - venice-1778: 2308
+    // -> ~1890 work items for 55 K blocks, against 1792 wavefronts the chip holds at once. Deterministic: every rank
+    // of a sharded run derives the same table from the same (united) structure.
+    std::vector<uint8_t> own(nc * nc, 0);  // own[c * nc + d] = 1: row c owns {c, d}
+    {
+      constexpr int CB = rba::spmv_chunk_blocks<double>();
+      std::vector<int> cnt(nc, 1);
+      std::vector<std::vector<int>> nb(nc);  // neighbours
+      for (size_t c = 0; c < nc; ++c)
+        for (size_t d = 0; d < nc; ++d)
+          if (d != c && pair_mark_[c * nc + d]) {
+            nb[c].push_back(int(d));
+            if (((c + d) & 1) == 0 ? c < d : c > d) {
+              own[c * nc + d] = 1;
+              ++cnt[c];
+            }
+          }
+      auto hand_over = [&](int from, int to) {
+        own[size_t(from) * nc + to] = 0;
+        own[size_t(to) * nc + from] = 1;
+        --cnt[from];
+        ++cnt[to];
+      };
+      for (int sweep = 0; sweep < 8; ++sweep) {
+        int moved = 0;
+        for (size_t o = 0; o < nc; ++o) {
+          while (cnt[o] > CB) {
+            bool done = false;
+            for (int t : nb[o])
+              if (own[o * nc + t] && cnt[t] < CB) {
+                hand_over(int(o), t);
+                done = true;
+                break;
+              }
+            for (size_t q = 0; !done && q < nb[o].size(); ++q) {
+              const int t = nb[o][q];
+              if (!own[o * nc + t] || cnt[t] != CB) continue;
+              for (int u : nb[t])
+                if (u != int(o) && own[size_t(t) * nc + u] && cnt[u] < CB) {
+                  hand_over(t, u);
+                  hand_over(int(o), t);
+                  done = true;
+                  break;
+                }
+            }
+            if (!done) break;
+            ++moved;
+          }
+        }
+        if (!moved) break;
+      }
+    }
+    auto owner_is_first = [&](size_t c, size_t d) { return own[c * nc + d] != 0; };  // does c own {c, d}?
     std::vector<int> slot(nc * nc, -1), row_ptr(nc + 1, 0), cols, diag(nc), upper_slot, mirror_slot;
     std::vector<uint8_t> heavy(nc, 0);
     for (size_t c = 0; c < nc; ++c) {
