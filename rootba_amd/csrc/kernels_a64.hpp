@@ -17,9 +17,15 @@
 //     (c^2 + s^2 = 1 to 1e-16), so the 3 x 2 coefficient block W' of an observation (its rows of the damped Q1) is a
 //     piece of an orthogonal matrix to double precision;
 //   * with that, the identities the float assembly relied on hold to 1e-16 instead of 6e-8:
-//        diagonal block      sum_o (A_o Jp_o D)^T (A_o Jp_o D),   A_o^T A_o = I - W'_o^T W'_o      (k_a64_diag)
-//        off-diagonal block  - sum_l (W'_i Jp_i D)^T (W'_j Jp_j D)                                  (k_ex_offdiag_mfma<double>)
-//     The Jacobian rows Jp (float, exact inputs) and the Jacobi scaling D (float) enter as they are.
+//        diagonal block      D [sum_o (A_o Jp_o)^T (A_o Jp_o)] D,   A_o^T A_o = I - W'_o^T W'_o      (k_a64_diag)
+//        off-diagonal block  - D_c [sum_l (W'_i Jp_i)^T (W'_j Jp_j)] D_d                               (k_a64_offdiag)
+//     The Jacobian rows Jp (float, exact inputs) enter as they are and the Jacobi scaling D (float) multiplies the
+//     finished blocks, in double: diagonal and off-diagonal blocks are sums over the SAME rows (a record of rows
+//     scaled and rounded to float would be a different Jacobian in the off-diagonal blocks than on the diagonal - an
+//     eps_float inconsistency of the matrix, the error class this file exists to avoid).
+//   * the per-observation record of the assembly is ONE 128-byte cache line: [Jp 18 float | W' 6 double | pad]; the
+//     pair gather of the off-diagonal blocks forms the three damped top rows W' Jp on the fly (two FMAs per operand
+//     of the matrix-core instruction) instead of fetching a 256-byte record of them.
 // The PCG vectors stay float, as in the float reference; k_pcgs_spmv multiplies double blocks with float operands
 // in double (kernels_pcg.hpp). Cost on venice-1778: see DESIGN.md 3c.
 #pragma once
@@ -44,10 +50,12 @@ struct A64Params {
   const float* __restrict__ pose_scaling;  // [9 n_cams]
   double* LQ;    // [n_lms][8]  tau0 tau1 tau2 g10 g20 g21 - -   (double re-derivation of Params::LQ)
   double* A;     // [n_obs][4]  2x2 factor A, A^T A = I - W'^T W'
-  double* topd;  // [n_obs][kTd] damped Q1^T Jp D (3 x 9, padded)
+  double* rec;   // [n_obs][16] one cache line per observation: Jp (18 float = 9 double slots) | W' (3x2 double, row-major) | pad
 };
 
 constexpr int kA64Lq = 8;
+constexpr int kA64Rec = 16;   // doubles per record
+constexpr int kA64RecW = 9;   // offset of W' (doubles)
 
 // the six sums of one landmark's reflector rows -> tau (double), cross products
 __device__ __forceinline__ void a64_store_lq(const A64Params& p, int s, const double n[3], double g10, double g20,
@@ -107,40 +115,46 @@ __global__ __launch_bounds__(256) void k_a64_landmark_wave(A64Params p, int lm_b
   if (lane == 0) a64_store_lq(p, s, n, g10, g20, g21);
 }
 
-// One work-item per observation (the double twin of k_s2_obs + k_s12_cols, without the b part): the landmark's six
-// damping rotations, the observation's coefficient block W' (3 x 2), the factor A of I - W'^T W', and the record
-// W' (Jp D) of damped top rows. The workgroup's observations are consecutive: Jacobian rows in and records out move
-// as contiguous 16-byte streams through LDS.
+// One work-item per observation (the double twin of k_s2_obs, without the b part): the landmark's six damping
+// rotations, the observation's coefficient block W' (3 x 2), the factor A of I - W'^T W', and the observation's record
+// [Jp | W']. The workgroup's observations are consecutive: Jacobian rows in and records out move as contiguous 16-byte
+// streams through LDS.
 constexpr int kA64Threads = 128;
-constexpr int kA64TdLds = 33;  // LDS stride (doubles) of a staged record: odd, conflict-free column writes
 
 __global__ __launch_bounds__(kA64Threads) void k_a64_obs(A64Params p, int64_t n_obs, double lambda) {
   constexpr int NT = kA64Threads;
-  extern __shared__ __attribute__((aligned(16))) char smem_a64[];
-  double* sT = reinterpret_cast<double*>(smem_a64);        // [NT][kA64TdLds]
-  float* sJ = reinterpret_cast<float*>(sT + NT * kA64TdLds);  // [NT][18]
+  __shared__ __attribute__((aligned(16))) double sRec[NT * kA64Rec];
+  float* sRecF = reinterpret_cast<float*>(sRec);
   const int tid = threadIdx.x;
   const int64_t o_base = int64_t(blockIdx.x) * NT;
   const int n_here = int(min<int64_t>(NT, n_obs - o_base));
   const bool act = tid < n_here;
   const int64_t o = act ? o_base + tid : o_base;
   {
+    // the workgroup's Jacobian rows: a contiguous stream of 18 n_here floats, scattered into the records
     const float* src = p.JpS + 18 * o_base;
     const int total = 18 * n_here, nvec = total / 4;
-    for (int i = tid; i < nvec; i += NT) reinterpret_cast<float4*>(sJ)[i] = reinterpret_cast<const float4*>(src)[i];
-    for (int i = nvec * 4 + tid; i < total; i += NT) sJ[i] = src[i];
+    for (int i = tid; i < nvec; i += NT) {
+      const float4 v = reinterpret_cast<const float4*>(src)[i];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = 4 * i + u, r = q / 18;
+        sRecF[2 * kA64Rec * r + (q - 18 * r)] = e[u];
+      }
+    }
+    for (int q = nvec * 4 + tid; q < total; q += NT) {
+      const int r = q / 18;
+      sRecF[2 * kA64Rec * r + (q - 18 * r)] = src[q];
+    }
   }
   const int s = p.obs_lm[o];
-  const int cam = p.obs_cam[o];
   const float4* __restrict__ vh = reinterpret_cast<const float4*>(p.Vh);
   const float4 va = vh[2 * o], vb = vh[2 * o + 1];
   const int64_t o0 = p.lm_obs[s];
   const float4 w0 = vh[2 * o0], w1 = vh[2 * o0 + 1], w2 = vh[2 * o0 + 2];
   const double* __restrict__ lq = p.LQ + size_t(kA64Lq) * s;
   const double tau0 = lq[0], tau1 = lq[1], tau2 = lq[2], g10 = lq[3], g20 = lq[4], g21 = lq[5];
-  float dscf[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) dscf[c] = p.pose_scaling[9 * cam + c];
   const float* __restrict__ R = p.R0 + 6 * size_t(s);
   const float r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4], r5 = R[5];
   const int i = int(o - o0);
@@ -229,23 +243,98 @@ __global__ __launch_bounds__(kA64Threads) void k_a64_obs(A64Params p, int64_t n_
       dst[1] = double2{a10, a11};
     }
   }
-  __syncthreads();  // sJ complete
-  if (act) {
+  {
+    double* r = sRec + kA64Rec * tid + kA64RecW;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      const double dc = double(dscf[c]);
-      const double m0 = double(sJ[18 * tid + c]) * dc, m1 = double(sJ[18 * tid + 9 + c]) * dc;
-      sT[kA64TdLds * tid + c] = W[0][0] * m0 + W[0][1] * m1;
-      sT[kA64TdLds * tid + 9 + c] = W[1][0] * m0 + W[1][1] * m1;
-      sT[kA64TdLds * tid + 18 + c] = W[2][0] * m0 + W[2][1] * m1;
+    for (int n = 0; n < 3; ++n) {
+      r[2 * n] = W[n][0];
+      r[2 * n + 1] = W[n][1];
     }
-#pragma unroll
-    for (int c = 27; c < kTd; ++c) sT[kA64TdLds * tid + c] = 0.0;
+    r[6] = 0.0;
   }
   __syncthreads();
   {
-    double* dst = p.topd + size_t(kTd) * o_base;
-    for (int q = tid; q < n_here * kTd; q += NT) dst[q] = sT[kA64TdLds * (q / kTd) + (q % kTd)];
+    double2* dst = reinterpret_cast<double2*>(p.rec + size_t(kA64Rec) * o_base);
+    const double2* src = reinterpret_cast<const double2*>(sRec);
+    for (int q = tid; q < n_here * (kA64Rec / 2); q += NT) dst[q] = src[q];
+  }
+}
+
+// Off-diagonal blocks, one workgroup per block {c, d}, c < d, over its list of observation pairs (the double twin of
+// k_ex_offdiag_mfma for the records of this file): - D_c [sum_pairs (W'_i Jp_i)^T (W'_j Jp_j)] D_d on
+// v_mfma_f64_16x16x4_f64, four pairs per three instructions. The eight records of a quad of pairs are eight cache
+// lines, fetched with one 16-byte load per lane (lane = record x piece) and staged in LDS; an operand of the
+// instruction is two FMAs on two doubles (W') and two floats (Jp) of a staged record. The block is written where it
+// is stored: as S_cd in row c and / or transposed in row d (half storage, kernels_pcg.hpp).
+__global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __restrict__ vals,
+                                                     const int* __restrict__ upper_slot,
+                                                     const int* __restrict__ mirror_slot,
+                                                     const int64_t* __restrict__ pair_ptr,
+                                                     const int* __restrict__ pair_oi, const int* __restrict__ pair_oj,
+                                                     int n_upper) {
+  using M = Mfma<double>;
+  using Acc = typename M::acc;
+  constexpr int U = 4;
+  __shared__ double tile[4][16][16];
+  __shared__ __attribute__((aligned(16))) double stage[4][U][8][kA64Rec];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = xcd_swizzled_camera(n_upper);
+  if (u >= n_upper) return;
+  const int i = lane & 15, kk = lane >> 4;
+  Acc acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+  const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
+  const int rec = lane >> 3, vec = lane & 7;
+  const int* __restrict__ pair_side = rec < 4 ? pair_oi : pair_oj;
+  for (int64_t q = q0 + wave * (4 * U); q < q1; q += 16 * U) {
+    // (clamped, not predicated: the U index loads go out together, then the U record loads)
+    double2 v[U];
+    int o[U];
+#pragma unroll
+    for (int uq = 0; uq < U; ++uq) o[uq] = pair_side[min(q + 4 * uq + (rec & 3), q1 - 1)];
+#pragma unroll
+    for (int uq = 0; uq < U; ++uq) v[uq] = reinterpret_cast<const double2*>(p.rec + size_t(kA64Rec) * o[uq])[vec];
+#pragma unroll
+    for (int uq = 0; uq < U; ++uq) {
+      const bool ok = q + 4 * uq + (rec & 3) < q1;
+      *reinterpret_cast<double2*>(&stage[wave][uq][rec][2 * vec]) = ok ? v[uq] : double2{0.0, 0.0};
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int uq = 0; uq < U; ++uq)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int g = 4 * m + kk;  // inner index 0..11 = (pair of the quad, top row)
+        const int pp = g / 3, c = g - 3 * pp;
+        double av = 0.0, bv = 0.0;
+        if (i < 9) {
+          const double* ri = stage[wave][uq][pp];
+          const double* rj = stage[wave][uq][4 + pp];
+          const float* fi = reinterpret_cast<const float*>(ri);
+          const float* fj = reinterpret_cast<const float*>(rj);
+          av = fma(ri[kA64RecW + 2 * c], double(fi[i]), ri[kA64RecW + 2 * c + 1] * double(fi[9 + i]));
+          bv = fma(rj[kA64RecW + 2 * c], double(fj[i]), rj[kA64RecW + 2 * c + 1] * double(fj[9 + i]));
+        }
+        if (uq & 1)
+          acc2 = M::mma(av, bv, acc2);
+        else
+          acc = M::mma(av, bv, acc);
+      }
+    wave_lds_fence();  // the next step overwrites the staging buffer
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[wave][M::row(lane, r)][i] = acc[r];
+  __syncthreads();
+  if (threadIdx.x < 81 && q1 > q0) {
+    const int a = threadIdx.x / 9, b = threadIdx.x - 9 * a;
+    const int ci = p.obs_cam[pair_oi[q0]], cj = p.obs_cam[pair_oj[q0]];
+    const double t = ((tile[0][a][b] + tile[1][a][b]) + tile[2][a][b]) + tile[3][a][b];
+    const double v = -t * double(p.pose_scaling[9 * ci + a]) * double(p.pose_scaling[9 * cj + b]);
+    const int us = upper_slot[u], m = mirror_slot[u];
+    if (us >= 0) vals[size_t(81) * us + threadIdx.x] = v;
+    if (m >= 0) vals[size_t(81) * m + 9 * b + a] = v;
   }
 }
 

@@ -860,7 +860,7 @@ class Solver final : public rba_solver {
       // float solver: the matrix is assembled in double from the float factors (kernels_a64.hpp)
       d_a64_lq_.alloc(size_t(rba::kA64Lq) * n_lms_);
       d_a64_A_.alloc(size_t(4) * n_obs_);
-      d_a64_topd_.alloc(size_t(rba::kTd) * n_obs_);
+      d_a64_rec_.alloc(size_t(rba::kA64Rec) * n_obs_);
     }
     d_ex_rowptr_.upload(row_ptr.data(), row_ptr.size(), stream_);
     d_ex_cols_.upload(cols.data(), cols.size(), stream_);
@@ -941,7 +941,7 @@ class Solver final : public rba_solver {
       a64_.pose_scaling = prm_.pose_scaling;
       a64_.LQ = d_a64_lq_.get();
       a64_.A = d_a64_A_.get();
-      a64_.topd = d_a64_topd_.get();
+      a64_.rec = d_a64_rec_.get();
       if (!a64_lm_valid_) {  // per linearisation point: tau and the reflector cross products in double
         const int short_end = imp_end_[4];  // k <= 32: a work-item per landmark; longer tracks: a wavefront each
         if (short_end > 0)
@@ -951,12 +951,14 @@ class Solver final : public rba_solver {
                              short_end, n_lms_);
         a64_lm_valid_ = true;
       }
-      const size_t lds = size_t(rba::kA64Threads) * (rba::kA64TdLds * sizeof(double) + 18 * sizeof(float));
       hipLaunchKernelGGL(rba::k_a64_obs, dim3(unsigned((n_obs_ + rba::kA64Threads - 1) / rba::kA64Threads)),
-                         dim3(rba::kA64Threads), lds, stream_, a64_, int64_t(n_obs_), double(pose_damping_));
+                         dim3(rba::kA64Threads), 0, stream_, a64_, int64_t(n_obs_), double(pose_damping_));
       hipLaunchKernelGGL(rba::k_a64_diag, dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, a64_,
                          d_ex_diag_.get(), d_ex_vals_.get());
-      if (ex_n_upper_ > 0) launch_offdiag(d_a64_topd_.get(), d_ex_vals_.get());
+      if (ex_n_upper_ > 0)
+        hipLaunchKernelGGL(rba::k_a64_offdiag, dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_, a64_,
+                           d_ex_vals_.get(), d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(),
+                           d_ex_pair_oi_.get(), d_ex_pair_oj_.get(), ex_n_upper_);
       all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);  // (diagonal blocks included: local sums so far)
     } else {
       ensure_topd();  // the off-diagonal blocks are built from the 27-scalar rows
@@ -2858,7 +2860,7 @@ class Solver final : public rba_solver {
   DevBuf<int> d_low_ptr_, d_tdst_;
   // float solver: double re-derivation of the factors for the assembled matrix (kernels_a64.hpp)
   static constexpr bool kA64 = std::is_same<S, float>::value;
-  DevBuf<double> d_a64_lq_, d_a64_A_, d_a64_topd_;
+  DevBuf<double> d_a64_lq_, d_a64_A_, d_a64_rec_;
   rba::A64Params a64_{};
   bool a64_lm_valid_ = false;  // per linearisation point
   // fused PCG on the assembled matrix (kernels_pcg.hpp)
