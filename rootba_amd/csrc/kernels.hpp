@@ -1144,26 +1144,30 @@ __global__ void k_mixed_round(const double* __restrict__ src, float* __restrict_
 // that it happened. (Raising the pivot to the rounding level of its diagonal entry instead was tried: the huge inverse
 // entries along the near-null direction produce wild steps.)
 // ===========================================================================
-template <class S>
-__global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ inv, int n_cams,
-                                int* fail_flag) {
+// SB = scalar of the blocks and of the factorisation (double blocks of a float solver: kernels_a64.hpp, k_a64_diag<true>),
+// `damp` is added to their diagonal; the inverse is stored in the solver scalar.
+template <class S, class SB = S>
+__global__ void k_invert_blocks(const SB* __restrict__ blocks, S* __restrict__ inv, int n_cams,
+                                int* fail_flag, SB damp = SB(0)) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cams) return;
-  S L[45];  // lower triangle, row-major packed: L(i,j) at i(i+1)/2 + j
-  const S* a = blocks + 81 * c;
+  using T = SB;
+  T L[45];  // lower triangle, row-major packed: L(i,j) at i(i+1)/2 + j
+  const SB* __restrict__ src = blocks + 81 * c;
+  auto a = [&](int e) { return T(src[e]) + (e % 10 == 0 ? damp : T(0)); };
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
-    S d = a[9 * j + j];
+    T d = a(9 * j + j);
 #pragma unroll
     for (int q = 0; q < j; ++q) d -= L[j * (j + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
-    ok = ok && (d > S(0));
-    const S ljj = sqrt(d);
+    ok = ok && (d > T(0));
+    const T ljj = sqrt(d);
     L[j * (j + 1) / 2 + j] = ljj;
-    const S ij = S(1) / ljj;
+    const T ij = T(1) / ljj;
 #pragma unroll
     for (int i = j + 1; i < 9; ++i) {
-      S v = a[9 * j + i];  // upper triangle entry (j,i)
+      T v = a(9 * j + i);  // upper triangle entry (j,i)
 #pragma unroll
       for (int q = 0; q < j; ++q) v -= L[i * (i + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
       L[i * (i + 1) / 2 + j] = v * ij;
@@ -1174,32 +1178,32 @@ __global__ void k_invert_blocks(const S* __restrict__ blocks, S* __restrict__ in
     atomicOr(fail_flag, 4);
     bool diag_ok = true;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) diag_ok = diag_ok && (a[9 * j + j] > S(0)) && is_finite(a[9 * j + j]);
+    for (int j = 0; j < 9; ++j) diag_ok = diag_ok && (a(9 * j + j) > T(0)) && is_finite(a(9 * j + j));
     if (diag_ok) {  // (else: NaN / non-positive diagonal - a numerical failure upstream, left to propagate)
 #pragma unroll
-      for (int e = 0; e < 81; ++e) out[e] = (e % 10 == 0) ? S(1) / a[e] : S(0);
+      for (int e = 0; e < 81; ++e) out[e] = (e % 10 == 0) ? S(T(1) / a(e)) : S(0);
       return;
     }
   }
 #pragma unroll
   for (int col = 0; col < 9; ++col) {
-    S yv[9], xv[9];
+    T yv[9], xv[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      S v = (i == col) ? S(1) : S(0);
+      T v = (i == col) ? T(1) : T(0);
 #pragma unroll
       for (int q = 0; q < i; ++q) v -= L[i * (i + 1) / 2 + q] * yv[q];
       yv[i] = v / L[i * (i + 1) / 2 + i];
     }
 #pragma unroll
     for (int i = 8; i >= 0; --i) {
-      S v = yv[i];
+      T v = yv[i];
 #pragma unroll
       for (int q = i + 1; q < 9; ++q) v -= L[q * (q + 1) / 2 + i] * xv[q];
       xv[i] = v / L[i * (i + 1) / 2 + i];
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) out[9 * i + col] = xv[i];
+    for (int i = 0; i < 9; ++i) out[9 * i + col] = S(xv[i]);
   }
 }
 

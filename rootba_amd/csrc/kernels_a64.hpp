@@ -342,6 +342,11 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
 // Jacobian rows (72 B) and the double factor A (32 B) of the camera's observations, Y = A Jp in double, K = sum Y^T Y
 // on v_mfma_f64_16x16x4_f64 (two observations per instruction), vals[diag] = D K D (no pose damping: the product adds
 // lambda x).
+// GRAM = true: A = I, i.e. the blocks D (sum Jp^T Jp) D = D Hpp D of the JACOBI and power-series preconditioners, in
+// double, into a dense [n_c][81] array (diag_slot == nullptr): a float Cholesky of the float-accumulated Hpp + lambda I
+// met non-positive pivots on final-13682; sums and factorisation in double do not
+// (k_invert_blocks<S, double>).
+template <bool GRAM>
 __global__ __launch_bounds__(256) void k_a64_diag(A64Params p, const int* __restrict__ diag_slot,
                                                   double* __restrict__ vals) {
   using M = Mfma<double>;
@@ -369,8 +374,8 @@ __global__ __launch_bounds__(256) void k_a64_diag(A64Params p, const int* __rest
       const int o = __shfl(idxreg, r & 31);
       jv[j] = *reinterpret_cast<const float2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
     }
-    double2 w;
-    {
+    double2 w = {0.0, 0.0};
+    if (!GRAM) {
       const int o = __shfl(idxreg, (lane >> 1) & 31);
       w = *reinterpret_cast<const double2*>(p.A + int64_t(o) * 4 + 2 * (lane & 1));
     }
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256) void k_a64_diag(A64Params p, const int* __rest
       const int r = q / 9, pc = q - 9 * r;
       if (q < cnt * 9) *reinterpret_cast<double2*>(lds + r * RW + 2 * pc) = double2{double(jv[j].x), double(jv[j].y)};
     }
-    {
+    if (!GRAM) {
       const int r = lane >> 1, h = lane & 1;
       if (r < cnt) *reinterpret_cast<double2*>(lds + r * RW + 18 + 2 * h) = w;
     }
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) void k_a64_diag(A64Params p, const int* __rest
         if (i < 9 && so < cnt) {
           const double* rec = lds + so * RW;
           const double* arow = rec + 18 + 2 * (kk & 1);
-          v = fma(arow[0], rec[i], arow[1] * rec[9 + i]);
+          v = GRAM ? rec[9 * (kk & 1) + i] : fma(arow[0], rec[i], arow[1] * rec[9 + i]);
         }
         if (h == 0)
           accK = M::mma(v, v, accK);
@@ -412,7 +417,8 @@ __global__ __launch_bounds__(256) void k_a64_diag(A64Params p, const int* __rest
   if (tid < 81) {
     const int ii = tid / 9, jj = tid - 9 * ii;
     const double t = (tile[0][ii][jj] + tile[1][ii][jj]) + (tile[2][ii][jj] + tile[3][ii][jj]);
-    vals[size_t(81) * diag_slot[c] + tid] = t * double(p.pose_scaling[9 * c + ii]) * double(p.pose_scaling[9 * c + jj]);
+    vals[size_t(81) * (diag_slot ? diag_slot[c] : c) + tid] =
+        t * double(p.pose_scaling[9 * c + ii]) * double(p.pose_scaling[9 * c + jj]);
   }
 }
 

@@ -212,7 +212,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
   }
   const int done = st->done, it = st->iter, cur_st = st->cur, need_test = st->need_test, pswap = st->pswap;
   const double q_prev = st->q_hist[(it + 1) & 1], rho_prev = st->rho_hist[(it + 1) & 1];
-  const S lambda = MODE == 2 ? S(q_tolerance) : S(st->lambda);
+  // (MODE 2: lambda in `q_tolerance`; negative = take it from the device state like the other modes - inside the
+  //  captured launch graphs of the PCG, whose arguments are fixed)
+  const S lambda = (MODE == 2 && q_tolerance >= 0.0) ? S(q_tolerance) : S(st->lambda);
   cs.setup(vals, item.slot0, nb0);
   V tmp[kSpmvPass];
   cs.issue(0, lane, tmp);
@@ -393,7 +395,9 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
                                                      CgState* st, const double* __restrict__ part_pq,
                                                      double* __restrict__ part_rho, double* __restrict__ part_q,
                                                      int phase, int period, int* host_progress, int mf, S lambda_mf,
-                                                     S* __restrict__ zero_me) {
+                                                     S* __restrict__ zero_me, S* __restrict__ tser) {
+  // `tser`: power-series preconditioner - z = Hpp^-1 r is only the first term: it is also the first `t` of the series
+  // (k_pcgs_series_step adds the others and then replaces the partials of rho this kernel leaves).
   // `mf`: the product came from the matrix-free operator (k_hx_implicit*: `qmain` = sum_l A_l^T A_l v without the pose
   // damping, no item partials): p.q is summed here, by every workgroup alike, over the whole vectors, and lambda_mf v is
   // added where the product is used. `zero_me`: the accumulator of the refresh product, cleared on refresh iterations.
@@ -462,6 +466,10 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
 #pragma unroll
     for (int j = 0; j < 9; ++j) Mrow[j] = inv[81 * c + 9 * row + j];
   }
+  // the product's pieces of the first tile are gathered NOW: the loads (a second round trip behind the pointers above)
+  // are in flight while p.q is reduced, instead of a third round trip behind alpha
+  S qg = qm;
+  if (act && !mf) qg = pcgs_gather_q(qp, qm, e0, e1, l0, l1, row);
   // ---- p.q, alpha ---------------------------------------------------------------------------
   const bool refresh = (cur % period) == 0;
   int stop = done | ((phase == 1 && !refresh) ? 1 : 0);
@@ -527,12 +535,13 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) Mrow[j] = inv[81 * c + 9 * row + j];
+        qg = mf ? qm : pcgs_gather_q(qp, qm, e0, e1, l0, l1, row);
       }
     }
     S xn = S(0), rn = S(0);
     if (act) {
       const S pi = odd ? po1 : po0;
-      const S qv = mf ? qm + lambda_mf * (phase == 0 ? pi : xo) : pcgs_gather_q(qp, qm, e0, e1, l0, l1, row);
+      const S qv = mf ? qm + lambda_mf * (phase == 0 ? pi : xo) : qg;
       if (phase == 0) {
         xn = xo + a * pi;
         x[i] = xn;
@@ -558,6 +567,7 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
 #pragma unroll
       for (int j = 0; j < 9; ++j) zc += Mrow[j] * rc[j];
       z[i] = zc;
+      if (tser) tser[i] = zc;
       acc_rho += double(rn) * double(zc);
       acc_q -= double(xn) * double(bo + rn);
     }
@@ -762,6 +772,58 @@ __global__ __launch_bounds__(256) void k_pcgs_residual(const S* __restrict__ bve
   if (i >= n) return;
   const int c = i / 9, row = i - 9 * c;
   r[i] = bvec[i] - pcgs_gather_q(qp, c, row);
+}
+
+// One term of the power-series preconditioner z = sum_{i=0..m} (Hpp^-1 E0)^i Hpp^-1 r (PowerSCPreconditioner::solve_assign,
+// src/rootba/cg/preconditioner.hpp:180-192) through the assembled matrix: with E0 = Hpp + lambda I - (S + lambda I),
+//   t <- (Hpp^-1 E0) t = t - Hpp^-1 w,  w = (S + lambda I) t  (the plain product k_pcgs_spmv<2>, pieces gathered here);  z += t.
+// Tiles of 28 cameras like k_pcgs_update (the 9 entries of a camera's w are exchanged through LDS). The LAST term also
+// leaves the partials of rho = r.z for the next direction update.
+template <class S>
+__global__ __launch_bounds__(256) void k_pcgs_series_step(const S* __restrict__ inv, QPieces<S> qp, S* __restrict__ t,
+                                                          S* __restrict__ z, const S* __restrict__ r, int n_cams,
+                                                          const CgState* st, int last, double* __restrict__ part_rho) {
+  __shared__ double sm[4];
+  __shared__ S wl[252];
+  if (st->done) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = 9 * n_cams, n_tiles = (n_cams + 27) / 28;
+  double acc_rho = 0;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int i = 252 * tile + tid;
+    const bool act = tid < 252 && i < n;
+    const int c = act ? i / 9 : 0, row = act ? i - 9 * c : 0;
+    S Mrow[9], ti = S(0), zi = S(0), ri = S(0), wi = S(0);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) Mrow[j] = S(0);
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) Mrow[j] = inv[81 * c + 9 * row + j];
+      ti = t[i];
+      zi = z[i];
+      if (last) ri = r[i];
+      wi = pcgs_gather_q(qp, c, row);
+    }
+    __syncthreads();
+    if (tid < 252) wl[tid] = wi;
+    __syncthreads();
+    if (act) {
+      const S* wc = wl + 9 * (tid / 9);
+      S v = S(0);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) v += Mrow[j] * wc[j];
+      const S tn = ti - v, zn = zi + tn;
+      t[i] = tn;
+      z[i] = zn;
+      acc_rho += double(ri) * double(zn);
+    }
+  }
+  if (!last) return;
+  const double t0 = wave_sum(acc_rho);
+  __syncthreads();
+  if (lane == 0) sm[wave] = t0;
+  __syncthreads();
+  if (tid == 0) part_rho[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
 }  // namespace rba

@@ -693,8 +693,7 @@ class Solver final : public rba_solver {
       scp_.eps = prm_.eps;
     }
     // capture the launch graphs of the fused PCG now (one-off cost, not part of an LM iteration)
-    if (n_items_ > 0 && opt_.preconditioner_type != 2 && (sc_ || ex_ready_))
-      build_pcg_graphs();
+    if (n_items_ > 0 && (sc_ || ex_ready_)) build_pcg_graphs();
   }
 
   // Block-CSR structure for the explicit reduced matrix of the square-root solver, from the
@@ -924,7 +923,7 @@ class Solver final : public rba_solver {
   // block is re-derived in double from the float factors (kernels_a64.hpp) - a float matrix S + E, |E| ~ eps |S|,
   // costs the PCG its accuracy along near-null directions (eps kappa instead of the eps sqrt(kappa) of the square-root
   // product) however its entries are computed.
-  void assemble_values() {
+  void init_a64() {
     if constexpr (kA64) {
       a64_.n_cams = n_cams_;
       a64_.n_lms = n_lms_;
@@ -942,6 +941,33 @@ class Solver final : public rba_solver {
       a64_.LQ = d_a64_lq_.get();
       a64_.A = d_a64_A_.get();
       a64_.rec = d_a64_rec_.get();
+    }
+  }
+  // JACOBI / power-series preconditioners of a float solver: Hpp^-1 from blocks summed AND factored in double
+  // (k_a64_diag<true>, k_invert_blocks<float, double>; a float Cholesky of the float-accumulated Hpp + lambda I met
+  // non-positive pivots on final-13682). The scaled Gram blocks D Hpp D belong to the linearisation point.
+  void invert_preconditioner_blocks(S lambda) {
+    if constexpr (kA64) {
+      if (prm_.jacobi && !sc_) {
+        if (!gram64_valid_) {
+          init_a64();
+          if (d_gram64_.size() == 0) d_gram64_.alloc(size_t(81) * n_cams_);
+          hipLaunchKernelGGL(rba::k_a64_diag<true>, dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, a64_,
+                             static_cast<const int*>(nullptr), d_gram64_.get());
+          all_reduce(d_gram64_.get(), size_t(81) * n_cams_);
+          gram64_valid_ = true;
+        }
+        hipLaunchKernelGGL((rba::k_invert_blocks<S, double>), dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_,
+                           d_gram64_.get(), d_inv_.get(), n_cams_, d_fail_.get(), double(lambda));
+        return;
+      }
+    }
+    hipLaunchKernelGGL((rba::k_invert_blocks<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_, prm_.blocks,
+                       d_inv_.get(), n_cams_, d_fail_.get(), S(0));
+  }
+  void assemble_values() {
+    if constexpr (kA64) {
+      init_a64();
       if (!a64_lm_valid_) {  // per linearisation point: tau and the reflector cross products in double
         const int short_end = imp_end_[4];  // k <= 32: a work-item per landmark; longer tracks: a wavefront each
         if (short_end > 0)
@@ -953,7 +979,7 @@ class Solver final : public rba_solver {
       }
       hipLaunchKernelGGL(rba::k_a64_obs, dim3(unsigned((n_obs_ + rba::kA64Threads - 1) / rba::kA64Threads)),
                          dim3(rba::kA64Threads), 0, stream_, a64_, int64_t(n_obs_), double(pose_damping_));
-      hipLaunchKernelGGL(rba::k_a64_diag, dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, a64_,
+      hipLaunchKernelGGL(rba::k_a64_diag<false>, dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, a64_,
                          d_ex_diag_.get(), d_ex_vals_.get());
       if (ex_n_upper_ > 0)
         hipLaunchKernelGGL(rba::k_a64_offdiag, dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_, a64_,
@@ -1481,6 +1507,7 @@ class Solver final : public rba_solver {
     landmark_damping_valid_ = false;
     ex_valid_ = false;
     a64_lm_valid_ = false;
+    gram64_valid_ = false;
     if (lm_async_) return RBA_OK;  // lm_step reads the flag at its next synchronisation point (linearize_failed)
     return (*fail & 1) ? RBA_NUMERICAL_FAILURE : RBA_OK;
   }
@@ -1761,14 +1788,30 @@ class Solver final : public rba_solver {
     hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), prm_.b,
                        d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), q_pieces(), n_items_, n_cams_, st,
                        d_pcgs_pq_.get(), part_rho, part_q, 0, kPcgPeriod, h_progress_, 0, S(0),
-                       static_cast<S*>(nullptr));
+                       static_cast<S*>(nullptr), series_t());
+    if (!with_refresh) enqueue_series();
     if (with_refresh) {
       // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
       launch_pcgs_product(d_x_.get(), kPcgPeriod);
       hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), prm_.b,
                          d_x_.get(), d_r_.get(), d_z_.get(), d_p_.get(), d_p2_.get(), q_pieces(), n_items_, n_cams_,
                          st, d_pcgs_pq_.get(), part_rho, part_q, 1, kPcgPeriod, h_progress_, 0, S(0),
-                         static_cast<S*>(nullptr));
+                         static_cast<S*>(nullptr), series_t());
+      enqueue_series();
+    }
+  }
+  // Power-series preconditioner on the fused path: the terms 1..m of the series behind the kernel that formed
+  // z = t = Hpp^-1 r (k_pcgs_update / k_pcg_a1), two launches per term; the last one leaves the partials of rho.
+  bool series_fused() const { return opt_.preconditioner_type == 2; }
+  S* series_t() { return series_fused() ? d_pw_t_.get() : static_cast<S*>(nullptr); }
+  void enqueue_series() {
+    if (!series_fused()) return;
+    constexpr int NB = rba::kPcgBlocks;
+    for (int i = 1; i <= opt_.power_order; ++i) {
+      launch_spmv<2>(nullptr, nullptr, nullptr, d_pw_t_.get(), nullptr, nullptr, nullptr, -1.0, 0, 0, 1, nullptr);
+      hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), q_pieces(),
+                         d_pw_t_.get(), d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(), i == opt_.power_order ? 1 : 0,
+                         d_pcg_partials_.get());
     }
   }
 
@@ -1815,6 +1858,10 @@ class Solver final : public rba_solver {
     }
     hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), d_r_.get(), d_z_.get(),
                        n, st, part_rho);
+    if (series_fused()) {
+      HIP_CHECK(hipMemcpyAsync(d_pw_t_.get(), d_z_.get(), n * sizeof(S), hipMemcpyDeviceToDevice, stream_));
+      enqueue_series();
+    }
     if (!pcg_graph_exec_[0]) build_pcg_graphs();
     volatile int* hp = h_progress_;
     hp[0] = it_start - 1;
@@ -1855,8 +1902,7 @@ class Solver final : public rba_solver {
     sub_collect();
 
     time_begin();
-    hipLaunchKernelGGL((rba::k_invert_blocks<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_,
-                       prm_.blocks, d_inv_.get(), n_cams_, d_fail_.get());
+    invert_preconditioner_blocks(lambda);
     time_end(&timings_.compute_preconditioner_time);
 
     time_begin();
@@ -1991,7 +2037,9 @@ class Solver final : public rba_solver {
     // are no-ops (`done`).
     ex_active_ = false;
     pcg_used_explicit_ = false;
-    const bool fused = n_items_ > 0 && opt_.preconditioner_type != 2;  // block-diagonal preconditioners
+    // (the power series runs on the fused path too, through the assembled matrix - not in the repeat of a solve whose
+    //  products went back to matrix-free)
+    const bool fused = n_items_ > 0 && (opt_.preconditioner_type != 2 || !explicit_off_for_solve_);
     bool go_fused = sc_ && fused;  // explicit Schur-complement backend: the matrix exists from the start
     int it = 1, it_first_assembled = 1;
     // Block-diagonal preconditioners: the matrix-free iterations run in the protocol of the fused PCG (kernels_pcg.hpp) -
@@ -2016,7 +2064,7 @@ class Solver final : public rba_solver {
         hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), b, d_x_.get(),
                            d_r_.get(), d_z_.get(), d_p_.get(), d_p_.get(), qp, 0, n_cams_, st,
                            static_cast<const double*>(nullptr), part_rho, part_q1, phase, kPcgPeriod, h_progress_, 1,
-                           lambda, d_tmp_.get());
+                           lambda, d_tmp_.get(), static_cast<S*>(nullptr));
       };
       // the device publishes the iteration it has started (hp[0]) or the end of the solve (hp[1])
       auto started = [&](int k) {
@@ -2863,6 +2911,8 @@ class Solver final : public rba_solver {
   DevBuf<double> d_a64_lq_, d_a64_A_, d_a64_rec_;
   rba::A64Params a64_{};
   bool a64_lm_valid_ = false;  // per linearisation point
+  DevBuf<double> d_gram64_;    // [81 n_c] D Hpp D in double (JACOBI / power-series preconditioners)
+  bool gram64_valid_ = false;  // per linearisation point
   // fused PCG on the assembled matrix (kernels_pcg.hpp)
   DevBuf<rba::SpmvItem> d_items_;
   DevBuf<int> d_item_ptr_;

@@ -6,7 +6,9 @@
          mfma_flops = SQ_INSTS_VALU_MFMA_MOPS_<F32|F64> * 512 (the definition of rocprofv3's MfmaFlops*),
          TFLOP/s = mfma_flops / kernel duration (from the kernel trace of the same pass),
          frac_of_peak against the dense matrix peak of the dtype (MI355X_MICROARCH.md: 157.3 TF f32, 78.6 TF f64),
-         mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES of the same dispatch) where both were collected.
+         mfma_busy = rocprofv3's MfmaUtil: SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's 1024 SIMDs) / (GRBM_GUI_ACTIVE
+         per XCD * 1024); the dispatch rows of GRBM_GUI_ACTIVE are sums over the 8 XCDs (checked against the kernel
+         duration: 18.9 M cycles for a 1062 us kernel = 8 x 2.23 GHz x 1062 us).
 Driven by scripts/run_pmc_mfma.sh; the summary is committed under profiles/."""
 import csv
 import glob
@@ -54,7 +56,7 @@ def parse(dirs, out_csv):
     with open(out_csv, "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "dispatches", "mean_duration_us(under counter collection)"] + [n + "(mean per dispatch)" for n in names] +
-                   ["mfma_TFLOPs", "frac_of_dense_matrix_peak", "mfma_busy_cycles/busy_cycles"])
+                   ["mfma_TFLOPs", "frac_of_dense_matrix_peak", "mfma_busy(SQ_VALU_MFMA_BUSY_CYCLES/(GRBM_GUI_ACTIVE/8*1024))"])
         for k in sorted(cnt):
             mean = {n: (cnt[k][n][0] / cnt[k][n][1]) if n in cnt[k] else None for n in names}
             if not any((mean.get(n) or 0) > 0 for n in names if "MFMA" in n):
@@ -67,8 +69,8 @@ def parse(dirs, out_csv):
                     tf = mops * 512 / (d_ns * 1e-9) * 1e-12
                     frac = tf * 1e12 / PEAK[ty]
             busy = None
-            if mean.get("SQ_VALU_MFMA_BUSY_CYCLES") and mean.get("SQ_BUSY_CYCLES"):
-                busy = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / mean["SQ_BUSY_CYCLES"]
+            if mean.get("SQ_VALU_MFMA_BUSY_CYCLES") and mean.get("GRBM_GUI_ACTIVE"):
+                busy = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (mean["GRBM_GUI_ACTIVE"] / 8 * 1024)
             n_disp = max(v[1] for v in cnt[k].values())
             w.writerow([k, n_disp, f"{d_ns * 1e-3:.1f}" if d_ns else ""] +
                        [f"{mean[n]:.0f}" if mean[n] is not None else "" for n in names] +

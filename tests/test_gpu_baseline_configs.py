@@ -255,7 +255,7 @@ def _fixture(name):
     return np.load(path)
 
 
-def _fixture_rows(name, dts="float32", **extra):
+def _fixture_rows(name, dts="float32", tag="", **extra):
     """tests/lockstep.py with the oracle side read from the fixture: per stored iteration the GPU is set to the oracle's
     state, linearised, and solves with the oracle run's lambda; compared with the float32 oracle's increment and the
     float64 oracle's iterate of the same index (a second handle with max_cg_it = the oracle's count, eta = 0 supplies
@@ -291,9 +291,10 @@ def _fixture_rows(name, dts="float32", **extra):
             assert cn.num_iterations == n32
             del gn
         row["inc_rel"] = rel(same, fx[f"inc32_{it}"])
-        row["gpu_vs_f64"] = rel(same, fx[f"inc64_{it}"])
-        row["oracle32_vs_f64"] = rel(fx[f"inc32_{it}"], fx[f"inc64_{it}"])
-        row["own_vs_f64"] = rel(ig, fx[f"inc64_{it}"])  # the increment the solve returned (its own stopping index)
+        if f"inc64_{it}" in fx:  # (final-13682: the float64 oracle does not fit the host)
+            row["gpu_vs_f64"] = rel(same, fx[f"inc64_{it}"])
+            row["oracle32_vs_f64"] = rel(fx[f"inc32_{it}"], fx[f"inc64_{it}"])
+            row["own_vs_f64"] = rel(ig, fx[f"inc64_{it}"])  # the increment the solve returned (its own stopping index)
         l_diff = g.apply(fx[f"inc32_{it}"])
         row["l_diff_rel"] = float(abs(l_diff - fx[f"l_diff_{it}"]) / abs(fx[f"l_diff_{it}"]))
         rows.append(row)
@@ -301,7 +302,7 @@ def _fixture_rows(name, dts="float32", **extra):
     import os
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):  # (the numbers DESIGN.md quotes)
-        with open(os.path.join(out, f"fixture_lockstep_{name}_{dts}.jsonl"), "w") as f:
+        with open(os.path.join(out, f"fixture_lockstep_{name}_{dts}{'_' + tag if tag else ''}.jsonl"), "w") as f:
             f.writelines(json.dumps(r) + "\n" for r in rows)
     return rows
 
@@ -321,6 +322,32 @@ def test_config4_venice1778_f32_increment_vectors_long_solves():
         assert r["cost_rel"] < 2e-6 and r["l_diff_rel"] < 2e-3, r
         assert r["inc_rel"] <= 2 * r["oracle32_vs_f64"] + 2e-4, r
         assert r["gpu_vs_f64"] <= 1.5 * r["oracle32_vs_f64"] + 1e-4, r
+
+
+def test_config5_final13682_f32_lockstep_iterations_3_to_7(monkeypatch):
+    """final-13682 (BASELINE config 5's size) in lock-step with the float32 oracle over LM
+    iterations 3..7 - the range where the round-3 GPU run left the oracle's trajectory (13 instead of 49 PCG iterations at
+    iteration 4, then a rejected step with cost 3.6e14) - from the oracle's states (fixture; the float64 oracle does not
+    fit the host: increments are compared with the float32 oracle's iterate of the same index only).
+
+    What the fixture itself shows (profiles/r4_final13682_oracle_f32_lm_and_replay.log): the float32 oracle's PCG counts
+    at this size are NOT reproducible between two runs of the oracle - its LM run takes 22 / 49 / 5 / 3 / 2 iterations
+    where its replay from the same states (same code, another OpenMP summation order) takes 23 / 36 / 5 / 3 / 137: the
+    Q-model stopping test (eta = 0.1) is decided by float32 rounding there. So the counts are held to the factor two
+    the oracle differs from itself by, the increment of the ORACLE'S index to float32 accuracy - with every product
+    matrix-free (the reference algorithm) and in the default configuration (assembled double matrix)."""
+    for env in ("0", None):
+        if env is None:
+            monkeypatch.delenv("RBA_EXPLICIT_AFTER", raising=False)
+        else:
+            monkeypatch.setenv("RBA_EXPLICIT_AFTER", env)
+        rows = _fixture_rows("final-13682", tag="matrix_free" if env else "default")
+        assert len(rows) == 5
+        for r in rows:
+            assert r["termination"] == 1 and r["cost_rel"] < 3e-6, r
+            assert 0.5 * r["cg_oracle"] - 1 <= r["cg_gpu"] <= 2 * r["cg_oracle"] + 1, r
+            # (measured: see profiles/r4_fixture_lockstep_final-13682_*.jsonl)
+            assert r["inc_rel"] < 5e-3 and r["l_diff_rel"] < 5e-3, r
 
 
 def test_config5_mixed_precision_with_power_series_at_trafalgar_size():
