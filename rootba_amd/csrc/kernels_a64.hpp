@@ -286,18 +286,36 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
   const int rec = lane >> 3, vec = lane & 7;
   const int* __restrict__ pair_side = rec < 4 ? pair_oi : pair_oj;
-  for (int64_t q = q0 + wave * (4 * U); q < q1; q += 16 * U) {
-    // (clamped, not predicated: the U index loads go out together, then the U record loads)
-    double2 v[U];
-    int o[U];
+  // Software pipeline (a wavefront's step is two DEPENDENT gathers - pair indices, then records that mostly miss L2 -
+  // in front of 12 matrix-core instructions; without it the kernel ran at a third of the matrix rate with the matrix
+  // pipe idle two thirds of the time, profiles/r4_pmc_mfma_float32.csv): the records of step s + 1 and the indices of
+  // step s + 2 are in flight while step s is staged and multiplied. Clamped, not predicated: every load is issued.
+  const int64_t qw = q0 + wave * (4 * U);
+  auto load_idx = [&](int64_t q, int o[U]) {
 #pragma unroll
-    for (int uq = 0; uq < U; ++uq) o[uq] = pair_side[min(q + 4 * uq + (rec & 3), q1 - 1)];
+    for (int uq = 0; uq < U; ++uq) o[uq] = pair_side[max(q0, min(q + 4 * uq + (rec & 3), q1 - 1))];
+  };
+  auto load_rec = [&](const int o[U], double2 v[U]) {
 #pragma unroll
     for (int uq = 0; uq < U; ++uq) v[uq] = reinterpret_cast<const double2*>(p.rec + size_t(kA64Rec) * o[uq])[vec];
+  };
+  int o_next[U];
+  double2 v_cur[U] = {};
+  if (q1 > q0) {
+    int o_cur[U];
+    load_idx(qw, o_cur);
+    load_idx(qw + 16 * U, o_next);
+    load_rec(o_cur, v_cur);
+  }
+  for (int64_t q = qw; q < q1; q += 16 * U) {
+    double2 v_next[U];
+    int o_next2[U];
+    load_rec(o_next, v_next);
+    load_idx(q + 32 * U, o_next2);
 #pragma unroll
     for (int uq = 0; uq < U; ++uq) {
       const bool ok = q + 4 * uq + (rec & 3) < q1;
-      *reinterpret_cast<double2*>(&stage[wave][uq][rec][2 * vec]) = ok ? v[uq] : double2{0.0, 0.0};
+      *reinterpret_cast<double2*>(&stage[wave][uq][rec][2 * vec]) = ok ? v_cur[uq] : double2{0.0, 0.0};
     }
     wave_lds_fence();
 #pragma unroll
@@ -321,6 +339,11 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
           acc = M::mma(av, bv, acc);
       }
     wave_lds_fence();  // the next step overwrites the staging buffer
+#pragma unroll
+    for (int uq = 0; uq < U; ++uq) {
+      v_cur[uq] = v_next[uq];
+      o_next[uq] = o_next2[uq];
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
