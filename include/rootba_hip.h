@@ -338,6 +338,7 @@ typedef struct rba_pcg_counters {
   int64_t assemblies;
   int64_t iterations;
   int64_t solves_repeated_matrix_free; /* solves whose assembled operator broke down (S + E lost definiteness) */
+  int64_t early_switches;              /* solves switched to the assembled matrix at iteration 5 (rising zeta) */
 } rba_pcg_counters;
 int rba_get_pcg_counters(rba_handle h, rba_pcg_counters* out);
 

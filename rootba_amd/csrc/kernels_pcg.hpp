@@ -614,6 +614,9 @@ __global__ __launch_bounds__(256) void k_pcgs_direction(const S* __restrict__ z,
     if (need_test) {
       // Q-model test (conjugate_gradient.hpp:239-276); residual-based test is off (r_tolerance = -1)
       const double zeta = it * (q1 - q_prev) / q1;
+      // (the host's early operator switch looks at the trend of zeta over iterations 3 and 4, Solver::pcg)
+      if (host_progress && (it == 3 || it == 4) && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(host_progress + it - 1, __float_as_int(float(zeta)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (zeta < q_tolerance && it >= min_it) {
         own_stop = 1;
         term = 1;

@@ -2050,6 +2050,7 @@ class Solver final : public rba_solver {
       volatile int* hp = h_progress_;
       hp[0] = 0;
       hp[1] = 0;
+      hp[2] = hp[3] = 0x7fc00000;  // zeta of iterations 3, 4 (float bits): NaN until the device publishes them
       auto direction = [&](bool test_only = false) {
         const bool pre = !ex_active_;
         hipLaunchKernelGGL((rba::k_pcgs_direction<S>), dim3(NB), dim3(256), 0, stream_, d_z_.get(), d_p_.get(),
@@ -2073,9 +2074,28 @@ class Solver final : public rba_solver {
       };
       bool running = true;
       for (; it <= max_it; ++it) {
-        if (ex_ready_ && !explicit_off_for_solve_ && it > explicit_after_) {
+        // Early switch (measured break-even only): solves are bimodal - they end after two or three iterations or run
+        // for tens to hundreds - and the long ones show it early: the stopping quantity zeta_i = i (Q_i - Q_i-1) / Q_i
+        // (conjugate_gradient.hpp:263-276) RISES from iteration 3 to 4 where it falls steadily in the solves that end
+        // within a dozen iterations (ladybug / trafalgar / venice: every solve of 40+ iterations rises, those of 6 - 24
+        // fall). A solve that rises is switched to the assembled matrix at iteration 5 instead of after
+        // `explicit_after_` (~12) products: eight products of 0.14 ms saved per long solve on venice. All ranks of a
+        // sharded run see the same zeta (identical scalars by construction) and decide alike.
+        bool tested = false, switch_now = false;
+        if (it == 5 && explicit_auto_ && ex_ready_ && !explicit_off_for_solve_ && !ex_valid_ && explicit_after_ >= it) {
+          direction(true);
+          if (!(running = started(it))) break;
+          tested = true;
+          float z3, z4;
+          const int b3 = hp[2], b4 = hp[3];
+          std::memcpy(&z3, &b3, sizeof z3);
+          std::memcpy(&z4, &b4, sizeof z4);
+          switch_now = std::isfinite(z3) && std::isfinite(z4) && z4 >= z3;
+          if (switch_now) ++pcg_counters_.early_switches;
+        }
+        if (ex_ready_ && !explicit_off_for_solve_ && (it > explicit_after_ || switch_now)) {
           // (the verdict on the iterations so far first: a solve that ends exactly here must not pay for an assembly)
-          if (it >= 3 && !ex_valid_) {
+          if (it >= 3 && !ex_valid_ && !tested) {
             direction(true);
             if (!(running = started(it))) break;
           }
