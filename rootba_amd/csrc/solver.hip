@@ -1028,8 +1028,12 @@ class Solver final : public rba_solver {
     with_matrix([&](const int* cols, auto* vals, auto half) {
       using MT = std::remove_cv_t<std::remove_pointer_t<decltype(vals)>>;
       constexpr bool H = decltype(half)::value;
-      hipLaunchKernelGGL((rba::k_pcgs_spmv<S, MODE, MT, H>), dim3(n_items_), dim3(64), rba::spmv_lds_bytes<MT>(), stream_,
-                         cols, vals, d_items_.get(), z, p0, p1, xvec, d_qmain_.get(), d_qpart_.get(),
+      // (MODE 2 with the products split over the ranks: this rank's range of work items)
+      const bool part = MODE == 2 && split_ && split_partial_;
+      const int i0 = part ? split_item0_ : 0, ni = part ? split_item1_ - split_item0_ : n_items_;
+      if (ni <= 0) return;
+      hipLaunchKernelGGL((rba::k_pcgs_spmv<S, MODE, MT, H>), dim3(ni), dim3(64), rba::spmv_lds_bytes<MT>(), stream_,
+                         cols, vals, d_items_.get() + i0, z, p0, p1, xvec, d_qmain_.get(), d_qpart_.get(),
                          H ? d_tpart_.get() : static_cast<double*>(nullptr),
                          H ? d_tdst_.get() : static_cast<const int*>(nullptr), d_cg_.get(), part_rho, part_q, part_pq, q_tol,
                          min_it, max_it, period, progress);
@@ -1191,6 +1195,7 @@ class Solver final : public rba_solver {
     comm_events_.assign(2 * kCommEvents, nullptr);  // (not lazily inside a timed stage)
     for (auto& e : comm_events_) HIP_CHECK(hipEventCreate(&e));
     union_structure_over_ranks();
+    decide_product_split();
   }
 
   // Whether the reduced matrix is assembled at all is decided per rank from ITS shard (pair-list budget): ranks that
@@ -1233,6 +1238,38 @@ class Solver final : public rba_solver {
     build_explicit_structure();
   }
 
+  // Products on the assembled matrix SPLIT over the ranks (more than one rank, large matrices). Replicated, every rank
+  // streams the whole matrix per PCG iteration and needs no collective (venice-1778: 35 MB, ~10 us - an all-reduce of
+  // the 64 KB product vector over xGMI would cost more than it saves); at final-13682 size the matrix is ~1 GB, a product
+  // a quarter of a millisecond, and N ranks that each multiply 1/N of the block work items and all-reduce the 0.5 MB
+  // vector of partial products are faster. The iteration then runs in the protocol of the matrix-free products
+  // (direction kernel, product, all-reduce, update kernel: one collective per iteration, like them); everything but
+  // the product stays replicated and bit-identical on all ranks. The decision is a function of the (united) structure
+  // and the rank count only - identical on every rank.
+  void decide_product_split() {
+    split_ = false;
+    if (nranks_ <= 1 || !ex_ready_ || sc_) return;
+    const double t_product = double(ex_nnz_) * 81 * sizeof(double) / 3.5e12;           // replicated, ~3.5 TB/s measured
+    const double t_collective = 30e-6 + double(nvec_) * sizeof(S) * 2 / 50e9;           // latency + ring volume
+    split_ = env_.pcg_split >= 0 ? env_.pcg_split != 0 : t_product * (1.0 - 1.0 / nranks_) > t_collective + 10e-6;
+    if (!split_) return;
+    // contiguous ranges of work items with equal block counts
+    std::vector<rba::SpmvItem> items{size_t(n_items_)};
+    d_items_.download(items.data(), items.size(), stream_);
+    sync();
+    std::vector<int64_t> before(size_t(n_items_) + 1, 0);  // blocks in the work items [0, i)
+    for (int i = 0; i < n_items_; ++i) before[i + 1] = before[i] + (items[i].slot1 - items[i].slot0);
+    auto boundary = [&](int r) {  // first work item of rank r
+      const int64_t target = before[n_items_] * r / nranks_;
+      return int(std::lower_bound(before.begin(), before.end(), target) - before.begin());
+    };
+    split_item0_ = rank_ == 0 ? 0 : boundary(rank_);
+    split_item1_ = rank_ == nranks_ - 1 ? n_items_ : boundary(rank_ + 1);
+    if (env_.verbose)
+      std::fprintf(stderr, "[rootba_hip] rank %d: products on the assembled matrix split over %d ranks: work items %d..%d of %d\n",
+                   rank_, nranks_, split_item0_, split_item1_, n_items_);
+  }
+
   void comm_init_callback(int rank, int nranks, rba_allreduce_fn fn, void* ctx) override {
     if (sc_ && nranks > 1)
       throw HipError{"SCHUR_COMPLEMENT solver: landmark sharding is not implemented (single GPU only)",
@@ -1242,6 +1279,7 @@ class Solver final : public rba_solver {
     cb_fn_ = fn;
     cb_ctx_ = ctx;
     union_structure_over_ranks();
+    decide_product_split();
   }
 
   void comm_info(int* rank, int* nranks, int* transport) override {
@@ -1597,8 +1635,17 @@ class Solver final : public rba_solver {
       if (sc_) {
         hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_, x, y, done_flag);
       } else {
-        // the row-staged SpMV of the fused PCG in its plain-product mode (double blocks, kernels_pcg.hpp) + its collect
+        // the row-staged SpMV of the fused PCG in its plain-product mode (double blocks, kernels_pcg.hpp) + its collect.
+        // Split over the ranks (decide_product_split): this rank's work items only, into cleared pieces - the caller
+        // all-reduces y
+        if (split_) {
+          d_qmain_.zero(stream_);
+          d_qpart_.zero(stream_);
+          d_tpart_.zero(stream_);
+          split_partial_ = true;
+        }
         launch_spmv<2>(nullptr, nullptr, nullptr, x, nullptr, nullptr, nullptr, 0.0, 0, 0, 1, nullptr);
+        split_partial_ = false;
         hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, y, q_pieces(),
                            nvec_);
       }
@@ -2039,7 +2086,7 @@ class Solver final : public rba_solver {
     pcg_used_explicit_ = false;
     // (the power series runs on the fused path too, through the assembled matrix - not in the repeat of a solve whose
     //  products went back to matrix-free)
-    const bool fused = n_items_ > 0 && (opt_.preconditioner_type != 2 || !explicit_off_for_solve_);
+    const bool fused = n_items_ > 0 && (opt_.preconditioner_type != 2 || !explicit_off_for_solve_) && !split_;
     bool go_fused = sc_ && fused;  // explicit Schur-complement backend: the matrix exists from the start
     int it = 1, it_first_assembled = 1;
     // Block-diagonal preconditioners: the matrix-free iterations run in the protocol of the fused PCG (kernels_pcg.hpp) -
@@ -2093,7 +2140,7 @@ class Solver final : public rba_solver {
           switch_now = std::isfinite(z3) && std::isfinite(z4) && z4 >= z3;
           if (switch_now) ++pcg_counters_.early_switches;
         }
-        if (ex_ready_ && !explicit_off_for_solve_ && (it > explicit_after_ || switch_now)) {
+        if (ex_ready_ && !ex_active_ && !explicit_off_for_solve_ && (it > explicit_after_ || switch_now)) {
           // (the verdict on the iterations so far first: a solve that ends exactly here must not pay for an assembly)
           if (it >= 3 && !ex_valid_ && !tested) {
             direction(true);
@@ -2118,12 +2165,12 @@ class Solver final : public rba_solver {
         }
         launch_hx(d_p_.get(), d_q_.get(), done);
         operand_prescaled_ = false;
-        if (!ex_active_) all_reduce(d_q_.get(), n);
+        if (!ex_active_ || split_) all_reduce(d_q_.get(), n);
         update(0, d_q_.get());
         if (it % kPcgPeriod == 0) {
           // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
           launch_hx(d_x_.get(), d_tmp_.get(), done);
-          if (!ex_active_) all_reduce(d_tmp_.get(), n);
+          if (!ex_active_ || split_) all_reduce(d_tmp_.get(), n);
           update(1, d_tmp_.get());
         }
         mf_open = true;
@@ -2203,7 +2250,7 @@ class Solver final : public rba_solver {
       operand_prescaled_ = pre;
       launch_hx(d_p_.get(), d_q_.get(), done);
       operand_prescaled_ = false;
-      if (!ex_active_) all_reduce(d_q_.get(), n);
+      if (!ex_active_ || split_) all_reduce(d_q_.get(), n);
       hipLaunchKernelGGL((rba::k_pcg_b1<S>), dim3(NB), dim3(T), 0, stream_, d_p_.get(), d_q_.get(),
                          lambda, n, st, part_pq);
       hipLaunchKernelGGL((rba::k_pcg_b2<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
@@ -2214,7 +2261,7 @@ class Solver final : public rba_solver {
       if (it % 10 == 0) {
         // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
         launch_hx(d_x_.get(), d_tmp_.get(), done);
-        if (!ex_active_) all_reduce(d_tmp_.get(), n);
+        if (!ex_active_ || split_) all_reduce(d_tmp_.get(), n);
         hipLaunchKernelGGL((rba::k_pcg_c1<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
                            d_r_.get(), d_tmp_.get(), lambda, n, st, part_q1);
         hipLaunchKernelGGL((rba::k_pcg_fin), dim3(1), dim3(1), 0, stream_, st, part_q1, 1, eta, min_it,
@@ -2821,6 +2868,8 @@ class Solver final : public rba_solver {
     int sort_by_camera = -1;           // RBA_SORT_BY_CAMERA=0/1: override the automatic choice
     int verify_assembled = 1;          // RBA_VERIFY_ASSEMBLED=0: skip the one-product check of assembled-operator solves
     double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
+    int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
+                                       // over the ranks (default: where the estimate says it pays)
     int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: earlier neighbours above which a camera's row of
                                               // the assembled matrix is stored in full (tests of that path)
   };
@@ -2841,6 +2890,7 @@ class Solver final : public rba_solver {
     env_.verify_assembled = geti("RBA_VERIFY_ASSEMBLED", 1);
     if (const char* ev = std::getenv("RBA_VERIFY_TOLERANCE")) env_.verify_tolerance = std::atof(ev);
     env_.half_lower_max = geti("RBA_HALF_LOWER_MAX", rba::kHalfLowerMax);
+    env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }
 
@@ -2926,6 +2976,8 @@ class Solver final : public rba_solver {
   DevBuf<double> d_ex_vals_;  // always double (assemble_values), half storage (kernels_pcg.hpp)
   DevBuf<double> d_tpart_;    // [9 nnz] transposed contributions of the blocks right of the diagonal, per product
   DevBuf<int> d_low_ptr_, d_tdst_;
+  bool split_ = false, split_partial_ = false;  // products on the assembled matrix split over the ranks (decide_product_split)
+  int split_item0_ = 0, split_item1_ = 0;
   // float solver: double re-derivation of the factors for the assembled matrix (kernels_a64.hpp)
   static constexpr bool kA64 = std::is_same<S, float>::value;
   DevBuf<double> d_a64_lq_, d_a64_A_, d_a64_rec_;

@@ -4,7 +4,9 @@ RCCL refuses two ranks on one device, so the ranks all-reduce through the
 library's callback transport (`rba_comm_init_callback`, here backed by gloo).
 Everything else is the production multi-GPU path: per-rank landmark shards, the
 all-reduce points of SURVEY.md §8e inside the library, the lambda*I bookkeeping,
-the lazily polled PCG state that must stay identical on all ranks."""
+the lazily polled PCG state that must stay identical on all ranks. The "-split-products" cases force what large
+problems do by themselves (Solver::decide_product_split): after two matrix-free iterations a solve runs on the assembled
+matrix with each rank multiplying HALF of the block work items and the product vector all-reduced per iteration."""
 import os
 import sys
 
@@ -57,15 +59,19 @@ def _worker(rank, world, port, dtype_name, env, ret):
     log, term = g2.optimize_lm()
     ret[rank] = dict(err=(err.all_error, err.all_num_obs), b=b, blocks=blocks, hx=hx, inc=inc,
                      cg=cg.num_iterations, l_diff=l_diff, cams=cams,
-                     lm=[(r.cost, r.cg_iterations, r.step_is_successful) for r in log], term=term)
+                     lm=[(r.cost, r.cg_iterations, r.step_is_successful) for r in log], term=term,
+                     pcg=g2.pcg_counters())
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("dtype,env", [(np.float64, {}), (np.float32, {}),
-                                       (np.float32, {"RBA_HX_LDS": "2", "RBA_HX_WIN": "9"}), ("mixed", {})],
-                         ids=["float64", "float32", "float32-lds-window", "mixed"])
+                                       (np.float32, {"RBA_HX_LDS": "2", "RBA_HX_WIN": "9"}), ("mixed", {}),
+                                       (np.float64, {"RBA_PCG_SPLIT": "1", "RBA_EXPLICIT_AFTER": "2"}),
+                                       (np.float32, {"RBA_PCG_SPLIT": "1", "RBA_EXPLICIT_AFTER": "2"})],
+                         ids=["float64", "float32", "float32-lds-window", "mixed", "float64-split-products",
+                              "float32-split-products"])
 def test_two_ranks_one_gpu_match_unsharded(dtype, env, monkeypatch):
     import torch  # noqa: F401
     import torch.multiprocessing as mp
@@ -87,6 +93,8 @@ def test_two_ranks_one_gpu_match_unsharded(dtype, env, monkeypatch):
     for key in ("b", "blocks", "hx", "inc", "cams"):
         assert np.array_equal(r0[key], r1[key]), key
     assert r0["cg"] == r1["cg"] and r0["lm"] == r1["lm"] and r0["term"] == r1["term"]
+    if "RBA_PCG_SPLIT" in env:  # (the split products did run: most iterations of the LM run's solves used them)
+        assert r0["pcg"]["products_assembled"] > r0["pcg"]["products_matrix_free"] > 0, r0["pcg"]
 
     prob = P.preprocess(P.named_synthetic("ladybug-49"), translation_sigma=0.5, point_sigma=0.5)
     g = LinearizorHIP(prob, dtype, L.default_options(robust_norm=1, max_num_iterations=6))
