@@ -189,6 +189,78 @@ def cpu_baseline(prob, n_iter: int, gpu_rows):
     }
 
 
+def pmc_child(args):
+    """Child of measure_product_traffic(), run under `rocprofv3 --pmc ...`: calibration reads of a known byte count, then
+    `args.pmc_child` matrix-free products of the workload (what `roofline.achieved` times)."""
+    import ctypes as C
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    prob, _ = make_problem(args.workload, args)
+    g = LinearizorHIP(prob, GPU_DTYPE, solver_options(L, 2), device=0)
+    nbytes = C.c_int64(0)
+    for _ in range(3):
+        L.check(g.lib.rba_debug_read_blocks(g.h, 4, C.byref(nbytes)), "calibration read")
+    assert g.linearize() == 0
+    g.stage2(1e-4)
+    x = np.random.default_rng(0).uniform(-1, 1, 9 * prob.n_cams).astype(DTYPE)
+    for _ in range(args.pmc_child):
+        g.right_multiply(x)
+    print("PMC_CHILD " + json.dumps({"calib_bytes": nbytes.value, "products": args.pmc_child}), flush=True)
+    g.close()
+
+
+def measure_product_traffic(argv):
+    """HBM traffic of ONE matrix-free product, measured in this run: rocprofv3 PMC counters FETCH_SIZE and WRITE_SIZE in
+    SEPARATE passes with --kernel-trace only (MI355X_MICROARCH.md, HBM section) over a child process that repeats the
+    product on the same workload; FETCH_SIZE is corrected by the factor measured on a streaming read of a known byte
+    count in the same pass (gfx950 reports half the bytes of a wide coalesced read), WRITE_SIZE taken as reported
+    (KiB). Returns (bytes per product or None, description)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this process already runs under rocprofv3 (no nested counter collection)"
+    n_prod = 12
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", str(n_prod)] + \
+        [a for a in argv if a not in ("--no-reference-semantics",)]
+    per = {}
+    meta = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rba_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+            for ln in r.stdout.splitlines():
+                if ln.startswith("PMC_CHILD "):
+                    meta = json.loads(ln[len("PMC_CHILD "):])
+            if r.returncode != 0 or meta is None:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-300:]}"
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter:
+                        a = acc.setdefault(row["Kernel_Name"], [0.0, 0])
+                        a[0] += float(row["Counter_Value"])
+                        a[1] += 1
+            per[counter] = acc
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    calib = [v for k, v in per["FETCH_SIZE"].items() if "k_calib_read<4>" in k]
+    if not calib:
+        return None, "no calibration kernel in the counter output"
+    corr = meta["calib_bytes"] / (calib[0][0] / calib[0][1] * 1024.0)
+    fetch = sum(v[0] for k, v in per["FETCH_SIZE"].items() if "k_hx_implicit" in k) * 1024.0 * corr
+    write = sum(v[0] for k, v in per["WRITE_SIZE"].items() if "k_hx_implicit" in k) * 1024.0
+    return (fetch + write) / meta["products"], (
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
+        f"{meta['products']} products of a child process on the same workload; FETCH_SIZE x {corr:.4f} (calibrated on a "
+        f"streaming read of {meta['calib_bytes']} bytes in the same pass), WRITE_SIZE as reported; KiB x 1024")
+
+
 def self_launch(args_list, n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks on this node."""
     with socket.socket() as s:
@@ -259,6 +331,10 @@ def main():
                     help="RBA_MIXED: double state / observations / costs, float linear algebra (BASELINE config 5)")
     ap.add_argument("--no-reference-semantics", action="store_true",
                     help="skip the second run with the reference's function_tolerance stopping rule")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 counter passes over a child process, "
+                         "~30 s); the committed profiles/hx_traffic.json is quoted instead")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
@@ -269,6 +345,9 @@ def main():
         raise SystemExit("--mixed and --use-double exclude each other")
     _SOLVER_KW.update(preconditioner_type=PRECOND[args.preconditioner], power_order=args.power_order)
     _GPU_KW.update(solver_type=int(args.solver_type == "SCHUR_COMPLEMENT"))
+    if args.pmc_child:
+        pmc_child(args)
+        return
 
     import torch
     import torch.distributed as dist
@@ -409,8 +488,16 @@ def main():
         avg_hx = hx_time / hx_calls if hx_calls else None
         achieved = stats["hx_bytes"] / avg_hx / 1e9 if avg_hx else None
         traffic, traffic_source = None, None
+        if world == 1 and not sc and not args.no_pmc:
+            try:
+                traffic, traffic_source = measure_product_traffic(sys.argv[1:])
+                if traffic is None:
+                    log(f"[roofline.traffic] not measured in this run: {traffic_source}")
+            except Exception as e:  # the counter passes must never take the bench line down
+                log(f"[roofline.traffic] in-run measurement failed: {e!r}")
+                traffic = None
         tpath = os.path.join(ROOT, "profiles", "hx_traffic.json")
-        if os.path.exists(tpath) and world == 1 and not sc:
+        if traffic is None and os.path.exists(tpath) and world == 1 and not sc:
             try:
                 with open(tpath) as f:
                     traffic = json.load(f).get(args.workload + "/implicit_q", {}).get("traffic_bytes_per_launch")

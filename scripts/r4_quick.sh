@@ -5,7 +5,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 if [ -n "$2" ]; then timeout 900 python -m pytest tests -m gpu -q -x -k "$2" > $O/pytest.log 2>&1; tail -15 $O/pytest.log; fi
-RBA_VERBOSE=1 python bench.py --steps 20 --warmup 5 --cpu-baseline-iters 0 > $O/venice.json 2> $O/venice.log
+RBA_VERBOSE=1 python bench.py --steps 20 --warmup 5 --cpu-baseline-iters 0 --no-pmc > $O/venice.json 2> $O/venice.log
 python - <<PY
 import json
 d=json.loads(open('$O/venice.json').read().strip().splitlines()[-1])
@@ -13,7 +13,7 @@ print('VALUE', d['value'], d['value_repeats']['values'], 'ms/step', d['ms_per_st
 print('stages', {k:(round(v.get('ms',v.get('ms_per_step',0)),3), round(v['frac'],3)) for k,v in d['roofline']['stages'].items()})
 PY
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-baseline-iters 0 --no-reference-semantics --repeats 1 > $O/prof.json 2> $O/prof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-baseline-iters 0 --no-reference-semantics --repeats 1 --no-pmc > $O/prof.json 2> $O/prof.log
 cd $GRAFT_REPO_ROOT
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 rm -rf $O/prof
