@@ -1958,13 +1958,13 @@ class Solver final : public rba_solver {
     rba_cg_summary cg = pcg(sc_ ? S(0) : lambda);  // SC: the damping is inside the matrix
     bool redo = pcg_used_explicit_ && !sc_ && (cg.termination_type == 2 || pcg_indefinite_ || env_.force_explicit_fallback);
     if (pcg_used_explicit_ && !sc_ && !redo && env_.verify_assembled) {
-      // Trust, but verify: a solve that ran on the assembled float32 matrix S + E (|E| ~ eps |S|: step lengths along
-      // near-null directions are off) is checked with ONE product of the reference's operator: the
-      // Q model -x.(b + r)/2 that the stopping rule watched against its true value. Measured (venice / trafalgar /
-      // final-13682): 1e-5 ... 1e-3 relative for solves of up to ~150 iterations, 1.5e-2 at 350, ~1e-1 for the
-      // noise-limited solves that run into max_iterations (which do so matrix-free as well, and in the reference). The
-      // check is a SAFETY NET against an operator that misjudged the system altogether (a step that would raise the
-      // cost many-fold): beyond `verify_tolerance` the solve is repeated with the reference's operator.
+      // Diagnostic (RBA_VERIFY_ASSEMBLED=1; rounds 2-3: always on): a solve that ran on the assembled matrix is checked
+      // with ONE product of the reference's operator - the Q model -x.(b + r)/2 that the stopping rule watched against its
+      // true value; beyond `verify_tolerance` the solve is repeated with the reference's operator. With the FLOAT matrix of
+      // round 3 (S + E, |E| ~ eps |S|) the two differed by 1e-5 ... 1e-3 for solves of up to ~150 iterations, 1.5e-2 at
+      // 350, ~1e-1 at 500, and the check was a safety net worth a product and a host synchronisation per solve; with the
+      // DOUBLE matrix (kernels_a64.hpp) they agree to 1e-7 ... 2e-5 on venice-1778 and final-13682 up to 500 iterations
+      // (profiles/r4_assembled_solve_q_model_check.log), so it is off unless asked for.
       d_tmp_.zero(stream_);
       launch_hx_implicit(d_x_.get(), d_tmp_.get(), nullptr);
       all_reduce(d_tmp_.get(), nvec_);
@@ -2866,7 +2866,7 @@ class Solver final : public rba_solver {
     int hx_win = 0;                    // RBA_HX_WIN=n: cap of the camera window of the LDS-private products
     int hx_timing_stride = -1;         // RBA_HX_TIMING_STRIDE=n: HIP events around every n-th matrix-free product
     int sort_by_camera = -1;           // RBA_SORT_BY_CAMERA=0/1: override the automatic choice
-    int verify_assembled = 1;          // RBA_VERIFY_ASSEMBLED=0: skip the one-product check of assembled-operator solves
+    int verify_assembled = 0;          // RBA_VERIFY_ASSEMBLED=1: one-product check of assembled-operator solves (diagnostic)
     double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
                                        // over the ranks (default: where the estimate says it pays)
@@ -2887,7 +2887,7 @@ class Solver final : public rba_solver {
     env_.hx_win = geti("RBA_HX_WIN", 0);
     env_.hx_timing_stride = geti("RBA_HX_TIMING_STRIDE", -1);
     env_.sort_by_camera = geti("RBA_SORT_BY_CAMERA", -1);
-    env_.verify_assembled = geti("RBA_VERIFY_ASSEMBLED", 1);
+    env_.verify_assembled = geti("RBA_VERIFY_ASSEMBLED", 0);
     if (const char* ev = std::getenv("RBA_VERIFY_TOLERANCE")) env_.verify_tolerance = std::atof(ev);
     env_.half_lower_max = geti("RBA_HALF_LOWER_MAX", rba::kHalfLowerMax);
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
