@@ -28,6 +28,7 @@ GROUPS = [
     ("k_hx_implicit", "product_matrix_free"), ("k_scale_vec", "product_matrix_free"),
     ("k_pcgs_spmv", "product_assembled"),
     ("k_ex_offdiag", "assembly"), ("k_s12_cols", "assembly"), ("k_ex_set_diag", "assembly"), ("k_ex_copy_diag", "assembly"),
+    ("k_a64_", "assembly"),
     ("k_pcgs_update", "pcg_vectors"), ("k_pcg_", "pcg_vectors"), ("k_pcgs_", "pcg_vectors"),
     ("k_bs_", "back_substitution"), ("k_sum_ldiff", "back_substitution"), ("k_reduce_rows<1>", "back_substitution"),
     ("k_update_cameras", "back_substitution"),

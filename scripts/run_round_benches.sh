@@ -1,10 +1,10 @@
 # Round bench set: every line that DESIGN.md / BASELINE.md / profiles/README.md quote. Run on the GPU box:
 #   gpurun -- 'bash scripts/run_round_benches.sh <tag>'   -> gpurun_out/<tag>/
 set -x
-TAG=${1:-r3b}
+TAG=${1:-r4}
 O=gpurun_out/$TAG
 mkdir -p $O
-B="python bench.py --cpu-baseline-iters 0"
+B="python bench.py --cpu-baseline-iters 0 --no-pmc"
 python bench.py --steps 20 --warmup 5 > $O/venice.json 2> $O/venice.log
 RBA_EXPLICIT_AFTER=0 $B --steps 20 --warmup 5 --no-reference-semantics > $O/venice_matrix_free.json 2> $O/venice_matrix_free.log
 $B --steps 20 --warmup 5 --mixed > $O/venice_mixed.json 2> $O/venice_mixed.log
