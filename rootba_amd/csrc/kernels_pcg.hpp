@@ -53,10 +53,19 @@ constexpr int kSpmvChunksPerItem = 4;  // 64-block chunks walked by one wavefron
 // pcgs_gather_q: bitwise reproducible, identical on all ranks of a sharded run - an atomic scatter would not be).
 // p.q needs no complete q: it is the sum over stored blocks of w p_c^T S_cj p_j with w = 2 off the diagonal.
 // Half the bytes per product (venice-1778: 35 instead of 70 MB), half the all-reduce of a sharded assembly.
-// A camera with very many neighbours it does not own would gather very many slots in one work-item: above
-// kHalfLowerMax such blocks are stored in BOTH rows instead (flag bit 31 of the column index: no slot, weight 1).
+// A camera with very many neighbours it does not own (dense co-visibility: a landmark seen by most cameras connects them
+// all) would have one work-item gather hundreds of slots: above kHalfLowerMax the slots of such a HEAVY row are summed by
+// a wavefront of its own right behind the product (k_pcgs_reduce_slots) into one more "further item" of the row.
+// (Round 4's first form stored such blocks in both rows instead: on a nearly dense matrix - venice with heavy-tailed
+// track lengths - that was full storage, 2 GB per product instead of 1 GB.)
 constexpr int kHalfLowerMax = 192;
-constexpr int kColDup = int(0x80000000u);
+
+struct HeavyRow {
+  int row;    // camera
+  int slot0;  // its run of received slots in tpart
+  int slot1;
+  int extra;  // index of its "further item" in qextra
+};
 
 // where the pieces of a product q = M v lie
 template <class S>
@@ -65,7 +74,7 @@ struct QPieces {
   const S* __restrict__ qextra;        // [9 n_extra] sums of the further items of long rows ...
   const int* __restrict__ extra_ptr;   // [n_c + 1]    ... of row c: extra_ptr[c] .. extra_ptr[c + 1]
   const double* __restrict__ tpart;    // [9 n_slots] half storage: transposed contributions, grouped by RECEIVING row
-  const int* __restrict__ low_ptr;     // [n_c + 1]   (nullptr tpart: full storage) ... row c: low_ptr[c] .. low_ptr[c + 1]
+  const int* __restrict__ low_ptr;     // [2 n_c]     (nullptr tpart: full storage) ... row c: low_ptr[2 c] .. low_ptr[2 c + 1]
 };
 
 struct SpmvItem {
@@ -202,8 +211,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
   static_assert((81 * CB + 2 * (Vec16<MT>::N - 1)) / Vec16<MT>::N <= 64 * kSpmvPass, "a chunk is one pass of loads");
   const int nb0 = min(CB, item.slot1 - item.slot0);
   const bool act0 = lane < nb0;
-  const int colraw0 = cols[item.slot0 + min(lane, nb0 - 1)];
-  const int col0 = HALF ? (colraw0 & ~kColDup) : colraw0;
+  const int col0 = cols[item.slot0 + min(lane, nb0 - 1)];
   const int td0 = HALF ? tdst[item.slot0 + min(lane, nb0 - 1)] : -1;  // slot of the transposed product (-1: none)
   double prho = 0, pq1 = 0;
   if (MODE == 0) {
@@ -318,8 +326,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
     __syncthreads();  // the staging buffer is overwritten
     const int nb = min(CB, item.slot1 - chunk);
     const bool act = lane < nb;
-    const int colraw = act ? cols[chunk + lane] : 0;
-    const int col = HALF ? (colraw & ~kColDup) : colraw;
+    const int col = act ? cols[chunk + lane] : 0;
     const int td = (HALF && act) ? tdst[chunk + lane] : -1;
     cs.setup(vals, chunk, nb);
     cs.issue(0, lane, tmp);
@@ -381,8 +388,8 @@ __device__ __forceinline__ S pcgs_gather_q(const QPieces<S>& qp, S qm, int e0, i
 template <class S>
 __device__ __forceinline__ S pcgs_gather_q(const QPieces<S>& qp, int c, int row) {
   const bool half = qp.tpart != nullptr;
-  return pcgs_gather_q(qp, qp.qmain[9 * c + row], qp.extra_ptr[c], qp.extra_ptr[c + 1], half ? qp.low_ptr[c] : 0,
-                       half ? qp.low_ptr[c + 1] : 0, row);
+  return pcgs_gather_q(qp, qp.qmain[9 * c + row], qp.extra_ptr[c], qp.extra_ptr[c + 1], half ? qp.low_ptr[2 * c] : 0,
+                       half ? qp.low_ptr[2 * c + 1] : 0, row);
 }
 
 // phase 0: after the direction product; phase 1: after the refresh product.
@@ -459,8 +466,8 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
       e0 = qp.extra_ptr[c];
       e1 = qp.extra_ptr[c + 1];
       if (half) {
-        l0 = qp.low_ptr[c];
-        l1 = qp.low_ptr[c + 1];
+        l0 = qp.low_ptr[2 * c];
+        l1 = qp.low_ptr[2 * c + 1];
       }
     }
 #pragma unroll
@@ -529,8 +536,8 @@ __global__ __launch_bounds__(256) void k_pcgs_update(const S* __restrict__ inv, 
           e0 = qp.extra_ptr[c];
           e1 = qp.extra_ptr[c + 1];
           if (half) {
-            l0 = qp.low_ptr[c];
-            l1 = qp.low_ptr[c + 1];
+            l0 = qp.low_ptr[2 * c];
+            l1 = qp.low_ptr[2 * c + 1];
           }
         }
 #pragma unroll
@@ -827,6 +834,31 @@ __global__ __launch_bounds__(256) void k_pcgs_series_step(const S* __restrict__ 
   if (lane == 0) sm[wave] = t0;
   __syncthreads();
   if (tid == 0) part_rho[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// Half storage, heavy rows (see the top of the file): one wavefront sums the received slots of a row in a fixed order
+// (lane-strided partial sums, then the DPP tree) into the row's additional "further item". Same early-out conditions as
+// the product it follows.
+template <class S>
+__global__ __launch_bounds__(256) void k_pcgs_reduce_slots(const HeavyRow* __restrict__ rows, int n_rows,
+                                                           const double* __restrict__ tpart, S* __restrict__ qextra,
+                                                           const CgState* st, int mode, int period) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int h = blockIdx.x * 4 + wave;
+  if (h >= n_rows) return;
+  if (st->done || (mode == 1 && st->cur % period != 0)) return;
+  const HeavyRow r = rows[h];
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = r.slot0 + lane; s < r.slot1; s += 64) {
+    const double* t = tpart + size_t(9) * s;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) acc[a] += t[a];
+  }
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+    const double tot = wave_sum(acc[a]);
+    if (lane == a) qextra[9 * r.extra + a] = S(tot);
+  }
 }
 
 }  // namespace rba

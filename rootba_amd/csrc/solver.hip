@@ -773,30 +773,41 @@ class Solver final : public rba_solver {
     for (size_t c = 0; c < nc; ++c) {
       row_ptr[c] = nnz;
       for (size_t d = 0; d < nc; ++d) {
-        const bool present = d == c || (pair_mark_[c * nc + d] && (owner_is_first(c, d) || heavy[c]));
+        const bool present = d == c || (pair_mark_[c * nc + d] && owner_is_first(c, d));
         if (!present) continue;
         if (c == d) diag[c] = nnz;
         slot[c * nc + d] = nnz++;
-        // both copies of a duplicated block carry the flag: (c, d) that c does not own exists only for a heavy c; one
-        // that c owns is duplicated when d is heavy
-        const bool dup = d != c && (!owner_is_first(c, d) || heavy[d]);
-        cols.push_back(int(d) | (dup ? rba::kColDup : 0));
+        cols.push_back(int(d));
       }
     }
     row_ptr[nc] = nnz;
     // slots of the transposed products, grouped by receiving row (ascending sender): tdst[slot of (c, d)] = position in
-    // row d's run, for the blocks stored once
+    // row d's run. A HEAVY row (more than kHalfLowerMax slots: dense co-visibility, e.g. a landmark seen by most
+    // cameras) is not gathered by the work-items that consume q - one of them would walk hundreds of slots - but
+    // summed by a wavefront of its own right behind the product (k_pcgs_reduce_slots) into one more "further item" of
+    // that row: its run is hidden from the consumers (low_ptr: empty) and listed in heavy_rows.
     std::vector<int> low_ptr(nc + 1, 0), tdst(size_t(nnz), -1);
+    std::vector<rba::HeavyRow> heavy_rows;
     {
       int n_slots = 0;
+      std::vector<int> run_begin(nc + 1, 0);
       for (size_t d = 0; d < nc; ++d) {
-        low_ptr[d] = n_slots;
-        if (!heavy[d])
-          for (size_t c = 0; c < nc; ++c)
-            if (c != d && slot[c * nc + d] >= 0 && slot[d * nc + c] < 0) tdst[slot[c * nc + d]] = n_slots++;
+        run_begin[d] = n_slots;
+        for (size_t c = 0; c < nc; ++c)
+          if (c != d && slot[c * nc + d] >= 0) tdst[slot[c * nc + d]] = n_slots++;
       }
-      low_ptr[nc] = n_slots;
-      d_low_ptr_.alloc(low_ptr.size());
+      run_begin[nc] = n_slots;
+      // consumers see the runs of the light rows only (a heavy row's run is [n, n): low_ptr stays monotone per row pair)
+      for (size_t d = 0; d < nc; ++d) {
+        if (heavy[d]) heavy_rows.push_back(rba::HeavyRow{int(d), run_begin[d], run_begin[d + 1], -1});
+      }
+      d_low_ptr_.alloc(2 * nc);
+      std::vector<int> low2(2 * nc);
+      for (size_t d = 0; d < nc; ++d) {
+        low2[2 * d] = run_begin[d];
+        low2[2 * d + 1] = heavy[d] ? run_begin[d] : run_begin[d + 1];
+      }
+      low_ptr = low2;
       d_low_ptr_.upload(low_ptr.data(), low_ptr.size(), stream_);
       d_tdst_.alloc(tdst.size());
       d_tdst_.upload(tdst.data(), tdst.size(), stream_);
@@ -844,8 +855,11 @@ class Solver final : public rba_solver {
     }
     ex_nnz_ = nnz;
     ex_n_upper_ = n_upper;
-    // one chunk of 32 double blocks per item: every wavefront is one pass of loads (kernels_pcg.hpp)
-    build_spmv_items(row_ptr, rba::spmv_chunk_blocks<double>());
+    // one chunk of 33 double blocks per item: every wavefront is one pass of loads (kernels_pcg.hpp)
+    build_spmv_items(row_ptr, rba::spmv_chunk_blocks<double>(), &heavy_rows);
+    n_heavy_ = int(heavy_rows.size());
+    d_heavy_.alloc(std::max<size_t>(1, heavy_rows.size()));
+    if (n_heavy_ > 0) d_heavy_.upload(heavy_rows.data(), heavy_rows.size(), stream_);
     d_ex_rowptr_.alloc(row_ptr.size());
     d_ex_cols_.alloc(cols.size());
     d_ex_diag_.alloc(diag.size());
@@ -880,16 +894,19 @@ class Solver final : public rba_solver {
 
   // work items of the fused PCG's SpMV (kernels_pcg.hpp): one wavefront per block row, rows with
   // more than 64 * kSpmvChunksPerItem blocks are split (their partial sums are added in item order)
-  void build_spmv_items(const std::vector<int>& row_ptr, int span) {
+  void build_spmv_items(const std::vector<int>& row_ptr, int span, std::vector<rba::HeavyRow>* heavy) {
     destroy_pcg_graphs();  // they hold the addresses of the buffers (re)allocated here
     std::vector<rba::SpmvItem> items;
     std::vector<int> extra_ptr(size_t(n_cams_) + 1, 0);
     int n_extra = 0;
+    size_t hi = 0;
     for (int c = 0; c < n_cams_; ++c) {
       extra_ptr[c] = n_extra;
       items.push_back(rba::SpmvItem{c, row_ptr[c], std::min(row_ptr[c] + span, row_ptr[c + 1]), -1});
       for (int s0 = row_ptr[c] + span; s0 < row_ptr[c + 1]; s0 += span)
         items.push_back(rba::SpmvItem{c, s0, std::min(s0 + span, row_ptr[c + 1]), n_extra++});
+      // (half storage: the sum of a heavy row's received slots is one more "further item" of the row)
+      if (heavy && hi < heavy->size() && (*heavy)[hi].row == c) (*heavy)[hi++].extra = n_extra++;
     }
     extra_ptr[n_cams_] = n_extra;
     n_items_ = int(items.size());
@@ -1037,6 +1054,9 @@ class Solver final : public rba_solver {
                          H ? d_tpart_.get() : static_cast<double*>(nullptr),
                          H ? d_tdst_.get() : static_cast<const int*>(nullptr), d_cg_.get(), part_rho, part_q, part_pq, q_tol,
                          min_it, max_it, period, progress);
+      if (H && n_heavy_ > 0)
+        hipLaunchKernelGGL((rba::k_pcgs_reduce_slots<S>), dim3((n_heavy_ + 3) / 4), dim3(256), 0, stream_, d_heavy_.get(),
+                           n_heavy_, d_tpart_.get(), d_qpart_.get(), d_cg_.get(), MODE, period);
     });
   }
 
@@ -1071,7 +1091,7 @@ class Solver final : public rba_solver {
     }
     row_ptr[nc] = nnz;
     sc_nnz_ = nnz;
-    build_spmv_items(row_ptr, rba::spmv_chunk_blocks<S>() * rba::kSpmvChunksPerItem);
+    build_spmv_items(row_ptr, rba::spmv_chunk_blocks<S>() * rba::kSpmvChunksPerItem, nullptr);
     // upper blocks (ci <= cj; cameras ascend inside a landmark, so i <= j) and, per upper
     // block, the list of contributing observation pairs (counting sort, landmark order)
     std::vector<int> upper_of(size_t(nnz), -1), upper_slot, mirror_slot;
@@ -2976,6 +2996,8 @@ class Solver final : public rba_solver {
   DevBuf<double> d_ex_vals_;  // always double (assemble_values), half storage (kernels_pcg.hpp)
   DevBuf<double> d_tpart_;    // [9 nnz] transposed contributions of the blocks right of the diagonal, per product
   DevBuf<int> d_low_ptr_, d_tdst_;
+  DevBuf<rba::HeavyRow> d_heavy_;  // rows whose received slots are summed by a wavefront of their own
+  int n_heavy_ = 0;
   bool split_ = false, split_partial_ = false;  // products on the assembled matrix split over the ranks (decide_product_split)
   int split_item0_ = 0, split_item1_ = 0;
   // float solver: double re-derivation of the factors for the assembled matrix (kernels_a64.hpp)

@@ -69,9 +69,11 @@ def _worker(rank, world, port, dtype_name, env, ret):
 @pytest.mark.parametrize("dtype,env", [(np.float64, {}), (np.float32, {}),
                                        (np.float32, {"RBA_HX_LDS": "2", "RBA_HX_WIN": "9"}), ("mixed", {}),
                                        (np.float64, {"RBA_PCG_SPLIT": "1", "RBA_EXPLICIT_AFTER": "2"}),
-                                       (np.float32, {"RBA_PCG_SPLIT": "1", "RBA_EXPLICIT_AFTER": "2"})],
+                                       (np.float32, {"RBA_PCG_SPLIT": "1", "RBA_EXPLICIT_AFTER": "2"}),
+                                       (np.float32, {"RBA_PCG_SPLIT": "1", "RBA_EXPLICIT_AFTER": "2",
+                                                     "RBA_HALF_LOWER_MAX": "3"})],
                          ids=["float64", "float32", "float32-lds-window", "mixed", "float64-split-products",
-                              "float32-split-products"])
+                              "float32-split-products", "float32-split-products-heavy-rows"])
 def test_two_ranks_one_gpu_match_unsharded(dtype, env, monkeypatch):
     import torch  # noqa: F401
     import torch.multiprocessing as mp
