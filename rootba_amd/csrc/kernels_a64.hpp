@@ -69,24 +69,42 @@ __device__ __forceinline__ void a64_store_lq(const A64Params& p, int s, const do
   lq[6] = lq[7] = 0.0;
 }
 
-// short tracks: one work-item per landmark walks its 2k rows (16 bytes each, consecutive)
-__global__ __launch_bounds__(256) void k_a64_landmark(A64Params p, int lm_begin, int lm_end) {
-  const int s = lm_begin + blockIdx.x * 256 + threadIdx.x;
-  if (s >= lm_end) return;
-  const int nrows = 2 * p.lm_k[s];
-  const float4* __restrict__ vh = reinterpret_cast<const float4*>(p.Vh) + 2 * p.lm_obs[s];
-  double n[3] = {0, 0, 0}, g10 = 0, g20 = 0, g21 = 0;
-  for (int r = 0; r < nrows; ++r) {
-    const float4 v = vh[r];
-    const double v0 = v.x, v1 = v.y, v2 = v.z;
-    n[0] += v0 * v0;
-    n[1] += v1 * v1;
-    n[2] += v2 * v2;
-    g10 += v1 * v0;
-    g20 += v2 * v0;
-    g21 += v2 * v1;
+// short tracks (k <= 32): one lane per block row on the wave tiles of the QR pass (kernels_s1.hpp: a landmark = an aligned
+// group of P2 lanes), six segmented sums in double. (A work-item per landmark walking its rows fetched every cache line
+// four times - 686 MB for 160 MB of rows, 150 us: profiles/r4_pmc_stage_traffic.csv, first half of round 4.)
+template <int P2>
+__device__ __forceinline__ void a64_landmark_tile(const A64Params& p, const int* __restrict__ RT, size_t T, int t_in_class,
+                                                  int lm_begin, int lm_end, int lane) {
+  constexpr int LPW = 64 / P2;
+  const int seg = lane / P2, r = lane - P2 * seg;
+  const int s = lm_begin + t_in_class * LPW + seg;
+  const int64_t row = RT[T * 64 + lane];  // -1: padding lane
+  double v0 = 0, v1 = 0, v2 = 0;
+  if (row >= 0) {
+    const float4 v = reinterpret_cast<const float4*>(p.Vh)[row];
+    v0 = v.x;
+    v1 = v.y;
+    v2 = v.z;
   }
-  a64_store_lq(p, s, n, g10, g20, g21);
+  double n[3] = {seg_sum<double, P2>(v0 * v0), seg_sum<double, P2>(v1 * v1), seg_sum<double, P2>(v2 * v2)};
+  const double g10 = seg_sum<double, P2>(v1 * v0), g20 = seg_sum<double, P2>(v2 * v0), g21 = seg_sum<double, P2>(v2 * v1);
+  if (r == 0 && s < lm_end) a64_store_lq(p, s, n, g10, g20, g21);
+}
+
+__global__ __launch_bounds__(256) void k_a64_landmark(A64Params p, const int* __restrict__ RT, ImplicitTiles it) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int T = blockIdx.x * 4 + wave;
+  if (T >= it.tile_begin[5]) return;
+  if (T >= it.tile_begin[4])
+    a64_landmark_tile<64>(p, RT, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], lane);
+  else if (T >= it.tile_begin[3])
+    a64_landmark_tile<32>(p, RT, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], lane);
+  else if (T >= it.tile_begin[2])
+    a64_landmark_tile<16>(p, RT, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], lane);
+  else if (T >= it.tile_begin[1])
+    a64_landmark_tile<8>(p, RT, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], lane);
+  else
+    a64_landmark_tile<4>(p, RT, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], lane);
 }
 
 // long tracks: one wavefront per landmark

@@ -986,9 +986,10 @@ class Solver final : public rba_solver {
     if constexpr (kA64) {
       init_a64();
       if (!a64_lm_valid_) {  // per linearisation point: tau and the reflector cross products in double
-        const int short_end = imp_end_[4];  // k <= 32: a work-item per landmark; longer tracks: a wavefront each
-        if (short_end > 0)
-          hipLaunchKernelGGL(rba::k_a64_landmark, dim3((short_end + 255) / 256), dim3(256), 0, stream_, a64_, 0, short_end);
+        const int short_end = n_tiles_ > 0 ? imp_end_[4] : 0;  // k <= 32: the wave tiles; longer tracks: a wavefront each
+        if (n_tiles_ > 0)
+          hipLaunchKernelGGL(rba::k_a64_landmark, dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, a64_, prm_.RT,
+                             implicit_tiles());
         if (n_lms_ > short_end)
           hipLaunchKernelGGL(rba::k_a64_landmark_wave, dim3((n_lms_ - short_end + 3) / 4), dim3(256), 0, stream_, a64_,
                              short_end, n_lms_);
@@ -2743,7 +2744,13 @@ class Solver final : public rba_solver {
     const int64_t nnz = sc_ ? sc_nnz_ : ex_nnz_;
     const int64_t ms = sc_ ? s : int64_t(sizeof(double));  // the assembled matrix of the square-root solver is double
     m->product_assembled = nnz * (81 * ms + 4) + nc * 18 * s;
-    if (!sc_) m->product_assembled += int64_t(nnz) * (2 * 9 * 8 + 4);  // half storage: the transposed parts out and back in
+    m->pcg_vectors = nc * (81 + 10 * 9) * s;
+    if (!sc_) {
+      // half storage: the transposed parts (9 doubles per block off the diagonal) + their slot index go out with the
+      // product and come back in with the vector kernel that consumes q
+      m->product_assembled += int64_t(nnz - nc) * (9 * 8) + int64_t(nnz) * 4;
+      m->pcg_vectors += int64_t(nnz - nc) * (9 * 8);
+    }
     // assembly, COMPULSORY bytes: the pair list (8 B per pair), every 32-scalar record once, the blocks out. The
     // gather itself requests two records per pair (256 B in float); what L2 does not keep of that is re-read traffic
     // and shows up as measured / model > 1 (profiles/r3_pmc_stage_traffic.csv), not as algorithmic bytes.
@@ -2753,7 +2760,6 @@ class Solver final : public rba_solver {
     if (!sc_ && kA64)  // float solver (kernels_a64.hpp): + the landmark pass (Vh 8 in), the factor A (4 doubles) out and
       m->assembly += int64_t(n_obs_) * (8 * s + 4 * ms + 18 * s + 4 * ms + 4);  // back in with JpS 18 + the CSC index
 
-    m->pcg_vectors = nc * (81 + 10 * 9) * s;
   }
   void get_pcg_counters(rba_pcg_counters* out) override { *out = pcg_counters_; }
   void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) override {
