@@ -29,8 +29,9 @@
  *  - environment: the library reads a handful of DEBUG / TEST variables once per rba_create (none is needed in
  *    production, none changes results beyond rounding): RBA_VERBOSE, RBA_EXPLICIT_AFTER (overrides
  *    rba_options.explicit_after), RBA_EX_PAIR_BUDGET_GB, RBA_FORCE_EXPLICIT_FALLBACK, RBA_HX_LDS, RBA_HX_WIN,
- *    RBA_HX_TIMING_STRIDE, RBA_SORT_BY_CAMERA, RBA_VERIFY_ASSEMBLED, RBA_VERIFY_TOLERANCE (rootba_amd/csrc/solver.hip:
- *    Solver::DebugEnv). The ~25 kernel-selection
+ *    RBA_HX_TIMING_STRIDE, RBA_SORT_BY_CAMERA, RBA_VERIFY_ASSEMBLED (diagnostic, default off since round 4),
+ *    RBA_VERIFY_TOLERANCE, RBA_PCG_SPLIT, RBA_HALF_LOWER_MAX (rootba_amd/csrc/solver.hip: Solver::DebugEnv).
+ *    The ~25 kernel-selection
  *    switches of rounds 1-2 are gone with the kernels they selected.
  *  - camera state: 10 scalars (qx,qy,qz,qw,tx,ty,tz,f,k1,k2) = Camera::params()
  *    (bal_problem.hpp:84-95); pose/intrinsics increments: 9 per camera.
@@ -102,11 +103,15 @@ typedef struct rba_options {
                                      1 SCHUR_COMPLEMENT (LinearizorSC, linearizor_sc.cpp:70-211:
                                      explicit block-sparse reduced camera matrix + SpMV; preconditioners
                                      SCHUR_JACOBI and POWER_SCHUR_COMPLEMENT like the reference, one GPU) */
-  int explicit_after;             /* square-root solver with SCHUR_JACOBI: after this many matrix-free
-                                     products a PCG solve assembles S = sum_l A_l^T A_l explicitly
-                                     (block-CSR) and continues with S x; 0 = never; -1 (default) = 6 for
-                                     the first long solve, then the measured break-even
-                                     (assembly time / product time, clamped to 2..32)           */
+  int explicit_after;             /* square-root solver: after this many matrix-free products a PCG solve
+                                     assembles S = sum_l A_l^T A_l explicitly (block-CSR, DOUBLE values in
+                                     half storage since round 4 - for a float solver derived in double from
+                                     the float factors, rootba_amd/csrc/kernels_a64.hpp: a float matrix costs
+                                     the PCG the accuracy the square-root form exists for) and continues with
+                                     S x; 0 = never; -1 (default) = 6 for the first long solve, then the
+                                     measured break-even (assembly time / product time, clamped to 2..32),
+                                     left early - at iteration 5 - by solves whose stopping quantity rises
+                                     from iteration 3 to 4                         */
 } rba_options;
 
 /* ResidualInfo (src/rootba/bal/residual_info.hpp:57-96), sums in double */

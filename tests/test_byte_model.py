@@ -1,15 +1,16 @@
 """The library's byte model (rba_get_byte_model: compulsory HBM bytes per launch group, the numerator of the per-stage
 rooflines bench.py prints) against the traffic MEASURED with rocprofv3 PMC counters on an MI355X
-(profiles/r3_pmc_stage_traffic.json, made by scripts/run_pmc_stage_traffic.sh from the same run that recorded the
+(profiles/r4_pmc_stage_traffic.json, made by scripts/run_pmc_stage_traffic.sh from the same run that recorded the
 model). A compulsory-bytes model can never exceed what the hardware moved; round 2's back-substitution model did
- and nothing checked it."""
+ and nothing checked it. The LIVE model of the library is held to the recorded one on the GPU
+(the table alone cannot fail when rba_get_byte_model changes)."""
 import json
 import os
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "profiles", "r3_pmc_stage_traffic.json")
+PATH = os.path.join(ROOT, "profiles", "r4_pmc_stage_traffic.json")
 
 
 @pytest.fixture(scope="module")
@@ -27,14 +28,15 @@ def test_model_never_exceeds_measured_traffic(table):
 
 def test_measured_traffic_is_close_to_the_model_where_the_kernels_stream(table):
     """Streams (cost evaluation, stage 1, the products, the back-substitution) move within 15 % of the model; the
-    camera-major gather of stage 2 fetches whole cache lines for 72-byte rows and stays below 2 x; the pair gather of
-    the assembly re-reads a record once per pair it takes part in, of which L2 absorbs about half: below 2.5 x of the
-    compulsory bytes (DESIGN.md 4 discusses both)."""
+    camera-major gather of stage 2 fetches whole cache lines for 72-byte rows (1.38 x); the assembly of the double
+    matrix gathers one-cache-line records, of which L2 serves most repeats (round 3's float assembly: 2.26 x; VERDICT
+    round 3 asked for < 1.6); the vector kernels of a PCG iteration include the slots of half storage read back."""
     g = table["groups"]
     for name in ("compute_error", "stage1", "product_matrix_free", "product_assembled", "back_substitution"):
         assert g[name]["measured_over_model"] < 1.15, (name, g[name])
-    assert g["stage2"]["measured_over_model"] < 2.0, g["stage2"]
-    assert g["assembly"]["measured_over_model"] < 2.5, g["assembly"]
+    assert g["stage2"]["measured_over_model"] < 1.5, g["stage2"]
+    assert g["assembly"]["measured_over_model"] < 1.5, g["assembly"]
+    assert g["pcg_vectors"]["measured_over_model"] < 1.5, g["pcg_vectors"]
 
 
 def test_fetch_size_calibration_matches_the_guide(table):
@@ -49,3 +51,19 @@ def test_bench_traffic_file_comes_from_the_same_pass(table):
         hx = json.load(f)["venice-1778/implicit_q"]
     assert hx["traffic_bytes_per_launch"] == table["groups"]["product_matrix_free"]["measured_bytes_per_launch"]
     assert hx["model_bytes_per_launch"] == table["groups"]["product_matrix_free"]["model_bytes_per_launch"]
+
+
+@pytest.mark.gpu
+def test_live_byte_model_is_the_recorded_one(table):
+    """rba_get_byte_model of the library as built, for the workload of the committed table."""
+    import numpy as np
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd import problem as P
+    from rootba_amd.linearizor import LinearizorHIP
+    prob = P.preprocess(P.named_synthetic("venice-1778"), translation_sigma=0.01, point_sigma=0.01)
+    g = LinearizorHIP(prob, np.float32, L.default_options(robust_norm=1, huber_parameter=1.0))
+    live = g.byte_model()
+    g.close()
+    for k, v in table["meta"]["byte_model"].items():
+        assert live[k] == v, (k, live[k], v)
