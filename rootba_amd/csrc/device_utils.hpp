@@ -114,6 +114,15 @@ __device__ __forceinline__ bool is_finite(S v) {
   return isfinite(v);
 }
 
+// 1-ulp reciprocal / square root of the hardware (v_rcp_f32, v_sqrt_f32) for float; exact operations for double. The
+// IEEE-correct float division and square root the compiler emits by default are ten-instruction sequences (scale,
+// reciprocal, four FMAs, fix-up): a quarter of the instructions of the VALU-bound QR pass (kernels_s1.hpp), whose
+// results are compared at 1e-5 ... 1e-6, not bit for bit (the reflector conventions are not even unique).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+
 // unit quaternion (x,y,z,w) -> rotation matrix, row-major
 template <class S>
 __device__ __forceinline__ void quat_to_rot(S x, S y, S z, S w, S R[9]) {

@@ -129,7 +129,7 @@ __device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_i
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const S ss = seg_sum<S, P2>(jl[c] * jl[c]);
-    const S sc = S(1) / (p.eps + sqrt(ss));
+    const S sc = fast_rcp(p.eps + fast_sqrt(ss));
     jl[c] *= sc;
     if (r == 0 && lm_ok) p.jl_scale[3 * s + c] = sc;
   }
@@ -146,10 +146,10 @@ __device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_i
       beta = c0;
       inv = S(0);
     } else {
-      beta = sqrt(c0 * c0 + tail);
+      beta = fast_sqrt(c0 * c0 + tail);
       if (c0 >= S(0)) beta = -beta;
-      inv = S(1) / (c0 - beta);
-      tau[m] = (beta - c0) / beta;
+      inv = fast_rcp(c0 - beta);
+      tau[m] = (beta - c0) * fast_rcp(beta);
     }
     vm[m] = (r == m) ? S(1) : ((r > m && rvalid) ? jl[m] * inv : S(0));
 #pragma unroll

@@ -331,6 +331,8 @@ static inline int hipemu_readfirstlane(int v) {
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_sqrtf(x) sqrtf(x)
 #define amdgpu_waves_per_eu(...)  // (__attribute__((amdgpu_waves_per_eu(n))) -> __attribute__(()))
 template <class T>
 static inline T __shfl(T v, int src, int width = 64) {
