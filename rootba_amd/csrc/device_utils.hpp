@@ -116,8 +116,9 @@ __device__ __forceinline__ bool is_finite(S v) {
 
 // 1-ulp reciprocal / square root of the hardware (v_rcp_f32, v_sqrt_f32) for float; exact operations for double. The
 // IEEE-correct float division and square root the compiler emits by default are ten-instruction sequences (scale,
-// reciprocal, four FMAs, fix-up): a quarter of the instructions of the VALU-bound QR pass (kernels_s1.hpp), whose
-// results are compared at 1e-5 ... 1e-6, not bit for bit (the reflector conventions are not even unique).
+// reciprocal, four FMAs, fix-up). ONLY for pure scalings that are stored and re-used consistently (the Jl column scale
+// of the QR pass): used for the reflector scalars (beta, 1 / (c0 - beta), tau) they cost orthogonality of
+// H = I - tau v v^T and, on an ill-conditioned final-13682 state, accuracy of a long matrix-free solve (kernels_s1.hpp).
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }

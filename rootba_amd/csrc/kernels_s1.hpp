@@ -146,10 +146,13 @@ __device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_i
       beta = c0;
       inv = S(0);
     } else {
-      beta = fast_sqrt(c0 * c0 + tail);
+      // (IEEE operations here: beta, the reflector's scaling and tau decide how orthogonal H = I - tau v v^T is, and the
+      //  1-ulp hardware reciprocal / square root doubled the distance of a 137-iteration matrix-free solve on an
+      //  ill-conditioned final-13682 state from the float64 iterate - 3.1e-2 against the oracle's 1.2e-2)
+      beta = sqrt(c0 * c0 + tail);
       if (c0 >= S(0)) beta = -beta;
-      inv = fast_rcp(c0 - beta);
-      tau[m] = (beta - c0) * fast_rcp(beta);
+      inv = S(1) / (c0 - beta);
+      tau[m] = (beta - c0) / beta;
     }
     vm[m] = (r == m) ? S(1) : ((r > m && rvalid) ? jl[m] * inv : S(0));
 #pragma unroll
