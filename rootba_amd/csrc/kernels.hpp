@@ -1147,7 +1147,7 @@ __global__ void k_mixed_round(const double* __restrict__ src, float* __restrict_
 // SB = scalar of the blocks and of the factorisation (double blocks of a float solver: kernels_a64.hpp, k_a64_diag<true>),
 // `damp` is added to their diagonal; the inverse is stored in the solver scalar.
 template <class S, class SB = S>
-__global__ void k_invert_blocks(const SB* __restrict__ blocks, S* __restrict__ inv, int n_cams,
+__global__ __launch_bounds__(64) void k_invert_blocks(const SB* __restrict__ blocks, S* __restrict__ inv, int n_cams,
                                 int* fail_flag, SB damp = SB(0)) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cams) return;

@@ -148,7 +148,7 @@ __device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_i
     } else {
       // (IEEE operations here: beta, the reflector's scaling and tau decide how orthogonal H = I - tau v v^T is, and the
       //  1-ulp hardware reciprocal / square root doubled the distance of a 137-iteration matrix-free solve on an
-      //  ill-conditioned final-13682 state from the float64 iterate - 3.1e-2 against the oracle's 1.2e-2)
+      //  ill-conditioned final-13682 state from the float64 iterate - 3.1e-2 against the 1.2e-2 of the float32 CPU run)
       beta = sqrt(c0 * c0 + tail);
       if (c0 >= S(0)) beta = -beta;
       inv = S(1) / (c0 - beta);

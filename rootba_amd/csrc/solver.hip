@@ -1649,10 +1649,8 @@ class Solver final : public rba_solver {
     }
     if (ex_active_ || sc_) {
       // y = (sum_l A_l^T A_l) x from the assembled matrix (SC backend: y = S x, the pose damping is part of S);
-      // overwrites y. (The row-staged SpMV of the fused PCG in its plain-product mode is 2.4 x faster on final-13682
-      // - 75 against 183 us - and was tried here: on venice-1778 with the float32 power series one solve at
-      // lambda = 1.4e-7 then needs the matrix-free repeat, reproducibly, where this kernel's summation order converges
-      // in 200 iterations - 106 against 215 LM it/s. Both are float32 roundings of the same product; kept as it was.)
+      // overwrites y. (Callers: the round-1 PCG loop, which still serves the repeat of a solve whose products went
+      // back to matrix-free, the power series without an assembled matrix, and the products split over ranks.)
       if (sc_) {
         hipLaunchKernelGGL((rba::k_sc_spmv<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_, x, y, done_flag);
       } else {
