@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
                                                      int n_upper) {
   using M = Mfma<double>;
   using Acc = typename M::acc;
-  constexpr int U = 4;
+  constexpr int U = 4;  // (2: same time, 8: 1.6 x slower - registers)
   __shared__ double tile[4][16][16];
   __shared__ __attribute__((aligned(16))) double stage[4][U][8][kA64Rec];
   const int lane = threadIdx.x & 63;
