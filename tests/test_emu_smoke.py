@@ -65,3 +65,16 @@ def test_bench_with_two_ranks_on_the_cpu_harness():
     assert line1["n_gpus"] == 1 and line1["config"]["comm_per_step"] is None
     assert abs(line2["config"]["final_cost"] - line1["config"]["final_cost"]) <= 2e-6 * line1["config"]["final_cost"]
     assert line2["config"]["cg_iterations_per_step"] == line1["config"]["cg_iterations_per_step"]
+    # ... and with the products on the assembled matrix split over the two ranks (what large problems do by themselves,
+    # Solver::decide_product_split: one all-reduce of the product vector per PCG iteration through the communicator)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    split = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), harness, "--gpus", "2", *common],
+                           cwd=ROOT, env=dict(env, RBA_PCG_SPLIT="1", RBA_EXPLICIT_AFTER="2"), capture_output=True, text=True,
+                           timeout=1500)
+    assert split.returncode == 0, split.stderr[-3000:]
+    line3 = json.loads([ln for ln in split.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line3["config"]["comm_per_step"]["all_reduces"] > line2["config"]["comm_per_step"]["all_reduces"]
+    assert abs(line3["config"]["final_cost"] - line1["config"]["final_cost"]) <= 2e-6 * line1["config"]["final_cost"]
