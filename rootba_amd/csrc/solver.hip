@@ -214,6 +214,9 @@ class Solver final : public rba_solver {
     const int n_cams = n_cams_, n_lms = n_lms_;
     HIP_CHECK(hipSetDevice(device_));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     n_obs_ = lm_off[n_lms];
     nvec_ = 9 * n_cams_;
     sc_ = opt_.solver_type == 1;
@@ -567,6 +570,7 @@ class Solver final : public rba_solver {
     d_fail_.alloc(1);
     d_lm_ldiff_.alloc(n_lms);
     d_partials_.alloc(size_t(kReduceBlocks) * 8 + 16);
+    d_partials_side_.alloc(size_t(kReduceBlocks) * 8 + 16);
     d_cg_.alloc(1);
     d_pcg_partials_.alloc(3 * rba::kPcgBlocks);
     for (auto* v : {&d_x_, &d_r_, &d_p_, &d_z_, &d_q_, &d_tmp_, &d_inc_, &d_vin_, &d_pw_t_, &d_pw_e_})
@@ -1185,7 +1189,7 @@ class Solver final : public rba_solver {
     for (auto& e : timer_pool_)
       if (e) (void)hipEventDestroy(e);
     timer_pool_.clear();
-    for (hipEvent_t* e : {&ev_asm0_, &ev_asm1_}) {
+    for (hipEvent_t* e : {&ev_asm0_, &ev_asm1_, &ev_fork_, &ev_join_}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
     }
@@ -1193,6 +1197,11 @@ class Solver final : public rba_solver {
     h_pinned_ = nullptr;
     if (h_progress_) (void)hipHostFree(h_progress_);
     h_progress_ = nullptr;
+    if (side_stream_) {
+      (void)hipStreamSynchronize(side_stream_);
+      (void)hipStreamDestroy(side_stream_);
+    }
+    side_stream_ = nullptr;
     if (stream_) (void)hipStreamDestroy(stream_);
     stream_ = nullptr;
   }
@@ -1471,25 +1480,44 @@ class Solver final : public rba_solver {
     compute_error_parse(h, out);
   }
   // kernels + the copy of the eight sums into pinned host memory `h`; valid after the next synchronisation
-  void compute_error_enqueue(double* h) {
-    time_begin();
+  // `side`: on the side stream, concurrently with what follows on the solver stream (rba_lm_step: the cost of the current
+  // state - which the reference re-evaluates at every outer iteration - needs nothing but the state, like the
+  // linearisation that is queued right behind it: a 0.3-of-roofline gather pass beside a streaming one); joined before the
+  // state is touched again (join_side) and at every synchronisation. One rank only (no collective on the side stream).
+  void compute_error_enqueue(double* h, bool side = false) {
+    side = side && results_go_direct();
+    hipStream_t st = side ? side_stream_ : stream_;
+    double* part = side ? d_partials_side_.get() : d_partials_.get();
+    if (side) {
+      HIP_CHECK(hipEventRecord(ev_fork_, stream_));
+      HIP_CHECK(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+    }
+    time_begin(st);
     const int blocks = int(std::min<int64_t>(kReduceBlocks, (n_obs_ + 255) / 256));
     if (mixed_)
-      hipLaunchKernelGGL((rba::k_compute_error<double>), dim3(blocks), dim3(256), 0, stream_, prm64_, n_obs_,
-                         d_partials_.get());
+      hipLaunchKernelGGL((rba::k_compute_error<double>), dim3(blocks), dim3(256), 0, st, prm64_, n_obs_, part);
     else
-      hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, stream_, prm_,
-                         n_obs_, d_partials_.get());
-    double* red = d_partials_.get() + size_t(kReduceBlocks) * 8;
+      hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, st, prm_, n_obs_, part);
+    double* red = part + size_t(kReduceBlocks) * 8;
     const bool direct = results_go_direct();
-    hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, stream_, d_partials_.get(), int64_t(blocks), red,
+    hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, st, part, int64_t(blocks), red,
                        direct ? h : static_cast<double*>(nullptr), static_cast<int*>(nullptr),
                        static_cast<int*>(nullptr), 0);
     if (!direct) {
       all_reduce(red, 8);
       HIP_CHECK(hipMemcpyAsync(h, red, 8 * sizeof(double), hipMemcpyDeviceToHost, stream_));
     }
-    time_end(&timings_.residual_evaluation_time, true);
+    time_end(&timings_.residual_evaluation_time, true, st);
+    if (side) {
+      HIP_CHECK(hipEventRecord(ev_join_, side_stream_));
+      side_pending_ = true;
+    }
+  }
+  // the solver stream waits for the side stream's work (a no-op when there is none)
+  void join_side() {
+    if (!side_pending_) return;
+    HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
+    side_pending_ = false;
   }
   static void compute_error_parse(const double* h, rba_residual_info* out) {
     out->all_num_obs = int(std::llround(h[0]));
@@ -2467,7 +2495,7 @@ class Solver final : public rba_solver {
     // the reference re-evaluates the error at every outer iteration (bal_bundle_adjustment.cpp:297-301,
     // with a TODO to avoid it); so does this loop - the metric of SURVEY.md 8d includes both evaluations
     const bool fresh_cost = lm_.it == 0 || lm_.need_linearize;
-    if (fresh_cost) compute_error_enqueue(pinned_doubles(kPinCe0));
+    if (fresh_cost) compute_error_enqueue(pinned_doubles(kPinCe0), /*side=*/lm_async_ && lm_.it > 0);
     auto cost_is_valid = [&]() {  // (after a synchronisation)
       if (fresh_cost) compute_error_parse(pinned_doubles(kPinCe0), &lm_.ri);
       return lm_.ri.is_numerically_valid != 0;
@@ -2519,6 +2547,7 @@ class Solver final : public rba_solver {
     }
     double l_diff_d = 0;
     bool applied = false;
+    join_side();  // (the cost evaluation of the current state has read it: from here on it changes)
     if (one_sync) {
       backup();
       apply(nullptr, &l_diff_d, true);
@@ -2778,7 +2807,10 @@ class Solver final : public rba_solver {
                           kPinFailApply = 1024 + 140, kPinCheck = 1024 + 192, kPinInc = 1024 + 256;
   double* pinned_doubles(size_t off) { return reinterpret_cast<double*>(h_pinned_ + off); }
   int* pinned_int(size_t off) { return reinterpret_cast<int*>(h_pinned_ + off); }
-  void sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+  void sync() {
+    join_side();
+    HIP_CHECK(hipStreamSynchronize(stream_));
+  }
   // Host side of the run-ahead throttles: spin on pinned words the device publishes its progress to, with a pause per
   // turn (the sibling hardware thread - possibly the one that feeds another rank's stream - gets the core). Every
   // 16384 turns the stream is queried: an idle stream ends the wait (everything queued has run: the caller queues
@@ -2811,13 +2843,13 @@ class Solver final : public rba_solver {
     }
     return timer_pool_[timer_pool_used_++];
   }
-  void time_begin() {
+  void time_begin(hipStream_t st = nullptr) {
     timer_t0_ = timer_event();
-    HIP_CHECK(hipEventRecord(timer_t0_, stream_));
+    HIP_CHECK(hipEventRecord(timer_t0_, st ? st : stream_));
   }
-  void time_end(double* field, bool accumulate = false) {
+  void time_end(double* field, bool accumulate = false, hipStream_t st = nullptr) {
     hipEvent_t e1 = timer_event();
-    HIP_CHECK(hipEventRecord(e1, stream_));
+    HIP_CHECK(hipEventRecord(e1, st ? st : stream_));
     pending_timers_.push_back(PendingTimer{timer_t0_, e1, field, accumulate});
     if (!lm_async_) {
       HIP_CHECK(hipEventSynchronize(e1));
@@ -2924,6 +2956,10 @@ class Solver final : public rba_solver {
   int nvec_ = 0;
   rba_options opt_;
   hipStream_t stream_ = nullptr;
+  hipStream_t side_stream_ = nullptr;  // cost evaluation beside the linearisation (compute_error_enqueue)
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  bool side_pending_ = false;
+  DevBuf<double> d_partials_side_;
   std::vector<int> perm_;
   int cls_begin_[kNumClasses], cls_end_[kNumClasses];
   int big_begin_ = 0, n_big_ = 0, big_kmax_ = 0;
