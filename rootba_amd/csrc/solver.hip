@@ -516,8 +516,7 @@ class Solver final : public rba_solver {
       explicit_auto_ = true;
       explicit_after_ = 6;
     }
-    // (needs the SCHUR_JACOBI blocks of stage 2 as its diagonal; the dense n_c x n_c host tables used
-    //  to build the structure bound the camera count: 20000 cameras = 0.4 GB of marks + 1.6 GB transient)
+    // (needs the SCHUR_JACOBI blocks of stage 2 as its diagonal)
     // The assembly gathers over per-block lists of observation pairs: sum_l k_l (k_l - 1) / 2 pairs of
     // 8 bytes (plus the 81-scalar blocks). Heavy-tailed track lengths make that O(sum k^2); it is
     // bounded here: above the budget (RBA_EX_PAIR_BUDGET_GB, default 24 GB of the 288) the solver stays
@@ -530,17 +529,10 @@ class Solver final : public rba_solver {
     if (!pairs_fit && env_.verbose)
       std::fprintf(stderr, "[rootba_hip] pair lists of the reduced matrix would take %.1f GB (> %.1f GB): "
                            "products stay matrix-free\n", ex_pair_bytes_ * 1e-9, pair_budget_gb);
-    if (!sc_ && explicit_after_ > 0 && n_cams_ <= 20000 && pairs_fit) {
+    if (!sc_ && explicit_after_ > 0 && pairs_fit) {
       h_lm_obs_ = lm_obs;
       h_obs_cam_ = s_obs_cam;
-      pair_mark_.assign(size_t(n_cams_) * n_cams_, 0);
-      for (int l = 0; l < n_lms; ++l) {
-        const int64_t o0 = lm_obs[l];
-        for (int i = 0; i < lm_k[l]; ++i) {
-          uint8_t* row = pair_mark_.data() + size_t(s_obs_cam[o0 + i]) * n_cams_;
-          for (int j = 0; j < lm_k[l]; ++j) row[s_obs_cam[o0 + j]] = 1;
-        }
-      }
+      ex_nb_ = co_observing_cameras(lm_obs, s_obs_cam);
       build_explicit_structure();
       // only the first explicit_after products of a solve are matrix-free: sample them densely
       if (env_.hx_timing_stride < 0) hx_timing_stride_ = 2;
@@ -703,85 +695,123 @@ class Solver final : public rba_solver {
   // Block-CSR structure for the explicit reduced matrix of the square-root solver, from the
   // co-observation marks (the union over ranks when landmarks are sharded), and the per-block
   // lists of the LOCAL observation pairs (i < j) that contribute to each strictly upper block
-  void build_explicit_structure() {
-    // HALF storage (kernels_pcg.hpp): every off-diagonal block {c, d} lives in the row of its owner - the smaller
-    // index when c + d is even, the larger when it is odd: every row owns about half of its blocks -, as the owner
-    // sees it; the product's contribution to the OTHER row travels through a 9-double slot, and the slots a row
-    // receives are contiguous (low_ptr). A camera that would receive more than kHalfLowerMax slots stores those
-    // blocks too (both copies flagged in their column index: no slot, weight 1 in p.q), so that no work-item gathers
-    // an unbounded run.
+  // nb[c] = the cameras that observe a landmark together with camera c (ascending, without c): the block structure of
+  // the reduced camera matrix. Camera by camera over its landmarks with one row of marks - sum_l k_l^2 steps like the
+  // pair lists, O(n_c + blocks) memory (rounds 1-3 kept dense n_c x n_c tables and capped the camera count at 20000).
+  std::vector<std::vector<int>> co_observing_cameras(const std::vector<int64_t>& lm_obs,
+                                                     const std::vector<int>& s_obs_cam) const {
     const size_t nc = size_t(n_cams_);
+    std::vector<int64_t> cam_ptr(nc + 1, 0);
+    for (int l = 0; l < n_lms_; ++l)
+      for (int64_t o = lm_obs[l]; o < lm_obs[l + 1]; ++o) ++cam_ptr[size_t(s_obs_cam[o]) + 1];
+    for (size_t c = 0; c < nc; ++c) cam_ptr[c + 1] += cam_ptr[c];
+    std::vector<int> cam_lm(static_cast<size_t>(cam_ptr[nc]), 0);
+    {
+      std::vector<int64_t> fill(cam_ptr.begin(), cam_ptr.end() - 1);
+      for (int l = 0; l < n_lms_; ++l)
+        for (int64_t o = lm_obs[l]; o < lm_obs[l + 1]; ++o) cam_lm[size_t(fill[s_obs_cam[o]]++)] = l;
+    }
+    std::vector<std::vector<int>> nb(nc);
+    std::vector<uint8_t> mark(nc, 0);
+    for (size_t c = 0; c < nc; ++c) {
+      std::vector<int>& list = nb[c];
+      mark[c] = 1;
+      for (int64_t q = cam_ptr[c]; q < cam_ptr[c + 1]; ++q) {
+        const int l = cam_lm[size_t(q)];
+        for (int64_t o = lm_obs[l]; o < lm_obs[l + 1]; ++o) {
+          const int d = s_obs_cam[o];
+          if (!mark[d]) {
+            mark[d] = 1;
+            list.push_back(d);
+          }
+        }
+      }
+      std::sort(list.begin(), list.end());
+      mark[c] = 0;
+      for (int d : list) mark[d] = 0;
+    }
+    return nb;
+  }
+
+  void build_explicit_structure() {
+    // HALF storage (kernels_pcg.hpp): every off-diagonal block {c, d} lives in the row of its OWNER, as the owner sees
+    // it; the product's contribution to the OTHER row travels through a 9-double slot, and the slots a row receives
+    // are contiguous. Everything here works on the sorted neighbour lists of co_observing_cameras().
+    const size_t nc = size_t(n_cams_);
+    constexpr int CB = rba::spmv_chunk_blocks<double>();
+    const std::vector<std::vector<int>>& nb = ex_nb_;  // neighbours, ascending
+    std::vector<std::vector<uint8_t>> own(nc);         // own[c][k] = 1: row c owns {c, nb[c][k]}
+    std::vector<int> cnt(nc, 1);                       // blocks row c owns (incl. the diagonal one)
+    for (size_t c = 0; c < nc; ++c) own[c].assign(nb[c].size(), 0);
+    auto find = [&](int c, int d) {  // position of d in nb[c]
+      return int(std::lower_bound(nb[c].begin(), nb[c].end(), d) - nb[c].begin());
+    };
     // Ownership. Start: parity of c + d (every row owns about half of its blocks). Then blocks are handed over from
     // rows that own more than one wavefront's worth (CB blocks incl. the diagonal one: such a row needs a second
     // work item) to neighbours with room, directly or through a full neighbour (chains of two) - venice-1778: 2308
     // -> ~1890 work items for 55 K blocks, against 1792 wavefronts the chip holds at once. Deterministic: every rank
     // of a sharded run derives the same table from the same (united) structure.
-    std::vector<uint8_t> own(nc * nc, 0);  // own[c * nc + d] = 1: row c owns {c, d}
-    {
-      constexpr int CB = rba::spmv_chunk_blocks<double>();
-      std::vector<int> cnt(nc, 1);
-      std::vector<std::vector<int>> nb(nc);  // neighbours
-      for (size_t c = 0; c < nc; ++c)
-        for (size_t d = 0; d < nc; ++d)
-          if (d != c && pair_mark_[c * nc + d]) {
-            nb[c].push_back(int(d));
-            if (((c + d) & 1) == 0 ? c < d : c > d) {
-              own[c * nc + d] = 1;
-              ++cnt[c];
+    for (size_t c = 0; c < nc; ++c)
+      for (size_t k = 0; k < nb[c].size(); ++k) {
+        const size_t d = size_t(nb[c][k]);
+        if (((c + d) & 1) == 0 ? c < d : c > d) {
+          own[c][k] = 1;
+          ++cnt[c];
+        }
+      }
+    auto hand_over = [&](int from, int k_from, int to) {  // {from, to}: from -> to
+      own[from][k_from] = 0;
+      own[to][find(to, from)] = 1;
+      --cnt[from];
+      ++cnt[to];
+    };
+    for (int sweep = 0; sweep < 8; ++sweep) {
+      int moved = 0;
+      for (size_t o = 0; o < nc; ++o) {
+        while (cnt[o] > CB) {
+          bool done = false;
+          for (size_t k = 0; k < nb[o].size() && !done; ++k)
+            if (own[o][k] && cnt[nb[o][k]] < CB) {
+              hand_over(int(o), int(k), nb[o][k]);
+              done = true;
             }
-          }
-      auto hand_over = [&](int from, int to) {
-        own[size_t(from) * nc + to] = 0;
-        own[size_t(to) * nc + from] = 1;
-        --cnt[from];
-        ++cnt[to];
-      };
-      for (int sweep = 0; sweep < 8; ++sweep) {
-        int moved = 0;
-        for (size_t o = 0; o < nc; ++o) {
-          while (cnt[o] > CB) {
-            bool done = false;
-            for (int t : nb[o])
-              if (own[o * nc + t] && cnt[t] < CB) {
-                hand_over(int(o), t);
+          for (size_t q = 0; !done && q < nb[o].size(); ++q) {
+            const int t = nb[o][q];
+            if (!own[o][q] || cnt[t] != CB) continue;
+            for (size_t k2 = 0; k2 < nb[t].size(); ++k2) {
+              const int u = nb[t][k2];
+              if (u != int(o) && own[t][k2] && cnt[u] < CB) {
+                hand_over(t, int(k2), u);
+                hand_over(int(o), int(q), t);
                 done = true;
                 break;
               }
-            for (size_t q = 0; !done && q < nb[o].size(); ++q) {
-              const int t = nb[o][q];
-              if (!own[o * nc + t] || cnt[t] != CB) continue;
-              for (int u : nb[t])
-                if (u != int(o) && own[size_t(t) * nc + u] && cnt[u] < CB) {
-                  hand_over(t, u);
-                  hand_over(int(o), t);
-                  done = true;
-                  break;
-                }
             }
-            if (!done) break;
-            ++moved;
           }
+          if (!done) break;
+          ++moved;
         }
-        if (!moved) break;
       }
+      if (!moved) break;
     }
-    auto owner_is_first = [&](size_t c, size_t d) { return own[c * nc + d] != 0; };  // does c own {c, d}?
-    std::vector<int> slot(nc * nc, -1), row_ptr(nc + 1, 0), cols, diag(nc), upper_slot, mirror_slot;
-    std::vector<uint8_t> heavy(nc, 0);
-    for (size_t c = 0; c < nc; ++c) {
-      int received = 0;
-      for (size_t d = 0; d < nc; ++d) received += (d != c && pair_mark_[c * nc + d] && !owner_is_first(c, d)) ? 1 : 0;
-      heavy[c] = received > env_.half_lower_max ? 1 : 0;
-    }
+    // rows: the diagonal block and the owned ones, ascending column; slot_nb[c][k] = slot of {c, nb[c][k]} in row c (-1)
+    std::vector<int> row_ptr(nc + 1, 0), cols, diag(nc), upper_slot, mirror_slot;
+    std::vector<std::vector<int>> slot_nb(nc);
     int nnz = 0;
     for (size_t c = 0; c < nc; ++c) {
       row_ptr[c] = nnz;
-      for (size_t d = 0; d < nc; ++d) {
-        const bool present = d == c || (pair_mark_[c * nc + d] && owner_is_first(c, d));
-        if (!present) continue;
-        if (c == d) diag[c] = nnz;
-        slot[c * nc + d] = nnz++;
-        cols.push_back(int(d));
+      slot_nb[c].assign(nb[c].size(), -1);
+      bool diag_done = false;
+      for (size_t k = 0; k <= nb[c].size(); ++k) {
+        if (!diag_done && (k == nb[c].size() || nb[c][k] > int(c))) {
+          diag[c] = nnz++;
+          cols.push_back(int(c));
+          diag_done = true;
+        }
+        if (k < nb[c].size() && own[c][k]) {
+          slot_nb[c][k] = nnz++;
+          cols.push_back(nb[c][k]);
+        }
       }
     }
     row_ptr[nc] = nnz;
@@ -790,28 +820,23 @@ class Solver final : public rba_solver {
     // cameras) is not gathered by the work-items that consume q - one of them would walk hundreds of slots - but
     // summed by a wavefront of its own right behind the product (k_pcgs_reduce_slots) into one more "further item" of
     // that row: its run is hidden from the consumers (low_ptr: empty) and listed in heavy_rows.
-    std::vector<int> low_ptr(nc + 1, 0), tdst(size_t(nnz), -1);
+    std::vector<int> low_ptr(2 * nc, 0), tdst(size_t(nnz), -1);
     std::vector<rba::HeavyRow> heavy_rows;
     {
       int n_slots = 0;
-      std::vector<int> run_begin(nc + 1, 0);
       for (size_t d = 0; d < nc; ++d) {
-        run_begin[d] = n_slots;
-        for (size_t c = 0; c < nc; ++c)
-          if (c != d && slot[c * nc + d] >= 0) tdst[slot[c * nc + d]] = n_slots++;
+        const int begin = n_slots;
+        for (size_t k = 0; k < nb[d].size(); ++k)
+          if (!own[d][k]) {  // {c, d} lives in row c = nb[d][k]
+            const int c = nb[d][k];
+            tdst[slot_nb[c][find(c, int(d))]] = n_slots++;
+          }
+        const bool heavy = n_slots - begin > env_.half_lower_max;
+        if (heavy) heavy_rows.push_back(rba::HeavyRow{int(d), begin, n_slots, -1});
+        low_ptr[2 * d] = begin;
+        low_ptr[2 * d + 1] = heavy ? begin : n_slots;
       }
-      run_begin[nc] = n_slots;
-      // consumers see the runs of the light rows only (a heavy row's run is [n, n): low_ptr stays monotone per row pair)
-      for (size_t d = 0; d < nc; ++d) {
-        if (heavy[d]) heavy_rows.push_back(rba::HeavyRow{int(d), run_begin[d], run_begin[d + 1], -1});
-      }
-      d_low_ptr_.alloc(2 * nc);
-      std::vector<int> low2(2 * nc);
-      for (size_t d = 0; d < nc; ++d) {
-        low2[2 * d] = run_begin[d];
-        low2[2 * d + 1] = heavy[d] ? run_begin[d] : run_begin[d + 1];
-      }
-      low_ptr = low2;
+      d_low_ptr_.alloc(low_ptr.size());
       d_low_ptr_.upload(low_ptr.data(), low_ptr.size(), stream_);
       d_tdst_.alloc(tdst.size());
       d_tdst_.upload(tdst.data(), tdst.size(), stream_);
@@ -819,43 +844,51 @@ class Solver final : public rba_solver {
       d_tpart_.zero(stream_);
     }
     // the blocks as the assembly produces them: (c, d) with c < d from the observation pairs (i, j > i) of a landmark;
-    // written straight into row c and / or transposed into row d, wherever it is stored
-    std::vector<int> upper_index(nc * nc, -1);
-    for (size_t c = 0; c < nc; ++c)
-      for (size_t d = c + 1; d < nc; ++d)
-        if (pair_mark_[c * nc + d]) {
-          upper_index[c * nc + d] = int(upper_slot.size());
-          upper_slot.push_back(slot[c * nc + d]);   // -1: stored in row d only
-          mirror_slot.push_back(slot[d * nc + c]);  // -1: stored in row c only
-        }
-    const int n_upper = int(upper_slot.size());
-    std::vector<int64_t> pair_ptr(size_t(n_upper) + 1, 0);
-    for (int l = 0; l < n_lms_; ++l) {
-      const int64_t o0 = h_lm_obs_[l];
-      const int k = int(h_lm_obs_[l + 1] - o0);
-      for (int i = 0; i < k; ++i) {  // (cameras ascend inside a landmark: (i, j > i) is a block right of the diagonal)
-        const int* row = upper_index.data() + size_t(h_obs_cam_[o0 + i]) * nc;
-        for (int j = i + 1; j < k; ++j) ++pair_ptr[size_t(row[h_obs_cam_[o0 + j]]) + 1];
+    // written straight into row c and / or transposed into row d, wherever it is stored. up_nb[c][k] = index of the
+    // block {c, nb[c][k] > c}
+    std::vector<std::vector<int>> up_nb(nc);
+    for (size_t c = 0; c < nc; ++c) {
+      up_nb[c].assign(nb[c].size(), -1);
+      for (size_t k = 0; k < nb[c].size(); ++k) {
+        const int d = nb[c][k];
+        if (d < int(c)) continue;
+        up_nb[c][k] = int(upper_slot.size());
+        upper_slot.push_back(slot_nb[c][k]);                 // -1: stored in row d only
+        mirror_slot.push_back(slot_nb[d][find(d, int(c))]);  // -1: stored in row c only
       }
     }
+    const int n_upper = int(upper_slot.size());
+    std::vector<int64_t> pair_ptr(size_t(n_upper) + 1, 0);
+    // (cameras ascend inside a landmark, and so do the neighbours of a camera: for a fixed i the blocks (i, j > i) are
+    //  found by one forward walk of nb[cam_i])
+    auto for_each_pair = [&](auto&& f) {
+      for (int l = 0; l < n_lms_; ++l) {
+        const int64_t o0 = h_lm_obs_[l];
+        const int k = int(h_lm_obs_[l + 1] - o0);
+        for (int i = 0; i < k; ++i) {
+          const int ci = h_obs_cam_[o0 + i];
+          const std::vector<int>& ni = nb[ci];
+          size_t pos = 0;
+          for (int j = i + 1; j < k; ++j) {
+            const int cj = h_obs_cam_[o0 + j];
+            while (ni[pos] < cj) ++pos;  // (cj is a neighbour of ci: the lists come from these very pairs)
+            f(up_nb[ci][pos], int(o0 + i), int(o0 + j));
+          }
+        }
+      }
+    };
+    for_each_pair([&](int u, int, int) { ++pair_ptr[size_t(u) + 1]; });
     for (int t = 0; t < n_upper; ++t) pair_ptr[t + 1] += pair_ptr[t];
     const int64_t n_pairs = pair_ptr[n_upper];
     ex_pairs_ = n_pairs;
     std::vector<int> pair_oi(n_pairs), pair_oj(n_pairs);
     {
       std::vector<int64_t> fill(pair_ptr.begin(), pair_ptr.end() - 1);
-      for (int l = 0; l < n_lms_; ++l) {
-        const int64_t o0 = h_lm_obs_[l];
-        const int k = int(h_lm_obs_[l + 1] - o0);
-        for (int i = 0; i < k; ++i) {
-          const int* row = upper_index.data() + size_t(h_obs_cam_[o0 + i]) * nc;
-          for (int j = i + 1; j < k; ++j) {
-            const int64_t d = fill[row[h_obs_cam_[o0 + j]]]++;
-            pair_oi[d] = int(o0 + i);
-            pair_oj[d] = int(o0 + j);
-          }
-        }
-      }
+      for_each_pair([&](int u, int oi, int oj) {
+        const int64_t d = fill[u]++;
+        pair_oi[d] = oi;
+        pair_oj[d] = oj;
+      });
     }
     ex_nnz_ = nnz;
     ex_n_upper_ = n_upper;
@@ -1067,72 +1100,66 @@ class Solver final : public rba_solver {
 
   // Block structure of the reduced camera matrix: every ordered pair of cameras that
   // observe a common landmark (what BlockSparseMatrix::add ends up holding,
-  // block_sparse_matrix.hpp), as block-CSR + a dense (camera, camera) -> slot table.
+  // block_sparse_matrix.hpp), as block-CSR.
   void build_sc_structure(const std::vector<int>& lm_k, const std::vector<int64_t>& lm_obs,
                           const std::vector<int>& s_obs_cam) {
-    if (n_cams_ > 20000)
-      throw HipError{"SCHUR_COMPLEMENT solver: more than 20000 cameras (dense camera-pair table on the host)",
-                     RBA_ERR_UNSUPPORTED};
     const size_t nc = size_t(n_cams_);
-    std::vector<int> slot(nc * nc, -1);
-    for (int l = 0; l < n_lms_; ++l) {
-      const int64_t o0 = lm_obs[l];
-      for (int i = 0; i < lm_k[l]; ++i) {
-        int* row = slot.data() + size_t(s_obs_cam[o0 + i]) * nc;
-        for (int j = 0; j < lm_k[l]; ++j) row[s_obs_cam[o0 + j]] = 0;
-      }
-    }
-    for (size_t c = 0; c < nc; ++c) slot[c * nc + c] = 0;  // diagonal always present (pose damping)
+    const std::vector<std::vector<int>> nb = co_observing_cameras(lm_obs, s_obs_cam);
+    // full rows: the neighbours and the diagonal block (always present: pose damping), ascending column
     std::vector<int> row_ptr(nc + 1, 0), cols, diag(nc);
-    int nnz = 0;
     for (size_t c = 0; c < nc; ++c) {
-      row_ptr[c] = nnz;
-      for (size_t d = 0; d < nc; ++d)
-        if (slot[c * nc + d] == 0) {
-          if (d == c) diag[c] = nnz;
-          slot[c * nc + d] = nnz++;
-          cols.push_back(int(d));
-        }
+      row_ptr[c] = int(cols.size());
+      const auto mid = std::lower_bound(nb[c].begin(), nb[c].end(), int(c));
+      cols.insert(cols.end(), nb[c].begin(), mid);
+      diag[c] = int(cols.size());
+      cols.push_back(int(c));
+      cols.insert(cols.end(), mid, nb[c].end());
     }
+    const int nnz = int(cols.size());
     row_ptr[nc] = nnz;
+    auto slot_of = [&](int c, int d) {
+      return int(std::lower_bound(cols.begin() + row_ptr[c], cols.begin() + row_ptr[c + 1], d) - cols.begin());
+    };
     sc_nnz_ = nnz;
     build_spmv_items(row_ptr, rba::spmv_chunk_blocks<S>() * rba::kSpmvChunksPerItem, nullptr);
     // upper blocks (ci <= cj; cameras ascend inside a landmark, so i <= j) and, per upper
     // block, the list of contributing observation pairs (counting sort, landmark order)
     std::vector<int> upper_of(size_t(nnz), -1), upper_slot, mirror_slot;
     for (size_t c = 0; c < nc; ++c)
-      for (size_t d = c; d < nc; ++d)
-        if (slot[c * nc + d] >= 0) {
-          upper_of[slot[c * nc + d]] = int(upper_slot.size());
-          upper_slot.push_back(slot[c * nc + d]);
-          mirror_slot.push_back(d == c ? -1 : slot[d * nc + c]);
-        }
+      for (int t = diag[c]; t < row_ptr[c + 1]; ++t) {
+        upper_of[t] = int(upper_slot.size());
+        upper_slot.push_back(t);
+        mirror_slot.push_back(cols[t] == int(c) ? -1 : slot_of(cols[t], int(c)));
+      }
     const int n_upper = int(upper_slot.size());
     sc_n_upper_ = n_upper;
     std::vector<int64_t> pair_ptr(size_t(n_upper) + 1, 0);
-    for (int l = 0; l < n_lms_; ++l) {
-      const int64_t o0 = lm_obs[l];
-      for (int i = 0; i < lm_k[l]; ++i) {
-        const int* row = slot.data() + size_t(s_obs_cam[o0 + i]) * nc;
-        for (int j = i; j < lm_k[l]; ++j) ++pair_ptr[size_t(upper_of[row[s_obs_cam[o0 + j]]]) + 1];
+    // (for a fixed i the blocks (cam_i, cam_j), j >= i, are found by one forward walk of row cam_i)
+    auto for_each_pair = [&](auto&& f) {
+      for (int l = 0; l < n_lms_; ++l) {
+        const int64_t o0 = lm_obs[l];
+        for (int i = 0; i < lm_k[l]; ++i) {
+          const int ci = s_obs_cam[o0 + i];
+          int t = diag[ci];
+          for (int j = i; j < lm_k[l]; ++j) {
+            const int cj = s_obs_cam[o0 + j];
+            while (cols[t] < cj) ++t;
+            f(upper_of[t], int(o0 + i), int(o0 + j));
+          }
+        }
       }
-    }
+    };
+    for_each_pair([&](int u, int, int) { ++pair_ptr[size_t(u) + 1]; });
     for (int t = 0; t < n_upper; ++t) pair_ptr[t + 1] += pair_ptr[t];
     const int64_t n_pairs = pair_ptr[n_upper];
     std::vector<int> pair_oi(n_pairs), pair_oj(n_pairs);
     {
       std::vector<int64_t> fill(pair_ptr.begin(), pair_ptr.end() - 1);
-      for (int l = 0; l < n_lms_; ++l) {
-        const int64_t o0 = lm_obs[l];
-        for (int i = 0; i < lm_k[l]; ++i) {
-          const int* row = slot.data() + size_t(s_obs_cam[o0 + i]) * nc;
-          for (int j = i; j < lm_k[l]; ++j) {
-            const int64_t d = fill[upper_of[row[s_obs_cam[o0 + j]]]]++;
-            pair_oi[d] = int(o0 + i);
-            pair_oj[d] = int(o0 + j);
-          }
-        }
-      }
+      for_each_pair([&](int u, int oi, int oj) {
+        const int64_t d = fill[u]++;
+        pair_oi[d] = oi;
+        pair_oj[d] = oj;
+      });
     }
     d_sc_upper_.alloc(n_upper);
     d_sc_mirror_.alloc(n_upper);
@@ -1247,8 +1274,8 @@ class Solver final : public rba_solver {
       ex_ready_ = false;
       ex_valid_ = false;
       prm_.want_sdiag = 0;
-      pair_mark_.clear();
-      pair_mark_.shrink_to_fit();
+      ex_nb_.clear();
+      ex_nb_.shrink_to_fit();
     }
   }
 
@@ -1257,14 +1284,47 @@ class Solver final : public rba_solver {
   void union_structure_over_ranks() {
     agree_on_explicit_matrix();
     if (!ex_ready_ || nranks_ <= 1) return;
-    std::vector<int> marks(pair_mark_.begin(), pair_mark_.end());
+    // an all-gather of the ranks' upper pairs (c < d) written as two sum all-reduces (the collective the callback
+    // transport has): the pair counts, then one buffer in which every rank fills its own segment
+    const size_t nc = size_t(n_cams_);
+    std::vector<int> counts(size_t(nranks_), 0);
+    for (size_t c = 0; c < nc; ++c)
+      counts[size_t(rank_)] += int(ex_nb_[c].end() - std::upper_bound(ex_nb_[c].begin(), ex_nb_[c].end(), int(c)));
     DevBuf<int> d;
-    d.alloc(marks.size());
-    d.upload(marks.data(), marks.size(), stream_);
-    all_reduce(d.get(), marks.size(), kNcclMax);
-    d.download(marks.data(), marks.size(), stream_);
+    d.alloc(std::max<size_t>(counts.size(), 1));
+    d.upload(counts.data(), counts.size(), stream_);
+    all_reduce(d.get(), counts.size());
+    d.download(counts.data(), counts.size(), stream_);
     sync();
-    for (size_t i = 0; i < marks.size(); ++i) pair_mark_[i] = uint8_t(marks[i] != 0);
+    size_t total = 0, mine = 0;
+    for (int r = 0; r < nranks_; ++r) {
+      if (r == rank_) mine = total;
+      total += size_t(counts[size_t(r)]);
+    }
+    std::vector<int> pairs(2 * total, 0);
+    {
+      size_t w = 2 * mine;
+      for (size_t c = 0; c < nc; ++c)
+        for (int e : ex_nb_[c])
+          if (e > int(c)) {
+            pairs[w++] = int(c);
+            pairs[w++] = e;
+          }
+    }
+    d.alloc(std::max<size_t>(pairs.size(), 1));
+    d.upload(pairs.data(), pairs.size(), stream_);
+    all_reduce(d.get(), pairs.size());
+    d.download(pairs.data(), pairs.size(), stream_);
+    sync();
+    for (auto& list : ex_nb_) list.clear();
+    for (size_t t = 0; t < total; ++t) {
+      ex_nb_[size_t(pairs[2 * t])].push_back(pairs[2 * t + 1]);
+      ex_nb_[size_t(pairs[2 * t + 1])].push_back(pairs[2 * t]);
+    }
+    for (auto& list : ex_nb_) {
+      std::sort(list.begin(), list.end());
+      list.erase(std::unique(list.begin(), list.end()), list.end());
+    }
     build_explicit_structure();
   }
 
@@ -3027,7 +3087,7 @@ class Solver final : public rba_solver {
   hipEvent_t ev_asm0_ = nullptr, ev_asm1_ = nullptr;
   DevBuf<int> d_scratch_int_;
   int ex_nnz_ = 0, ex_n_upper_ = 0;
-  std::vector<uint8_t> pair_mark_;
+  std::vector<std::vector<int>> ex_nb_;  // co-observing cameras per camera (structure of the reduced matrix)
   rba::ScParams<S> exp_{};
   std::vector<int64_t> h_lm_obs_;  // host copies of the (sorted) topology for the pair lists
   std::vector<int> h_obs_cam_;
