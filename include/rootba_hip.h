@@ -102,7 +102,7 @@ typedef struct rba_options {
   int solver_type;                /* SolverOptions::SolverType: 0 SQUARE_ROOT (default, LinearizorQR),
                                      1 SCHUR_COMPLEMENT (LinearizorSC, linearizor_sc.cpp:70-211:
                                      explicit block-sparse reduced camera matrix + SpMV; preconditioners
-                                     SCHUR_JACOBI and POWER_SCHUR_COMPLEMENT like the reference, one GPU) */
+                                     SCHUR_JACOBI and POWER_SCHUR_COMPLEMENT like the reference) */
   int explicit_after;             /* square-root solver: after this many matrix-free products a PCG solve
                                      assembles S = sum_l A_l^T A_l explicitly (block-CSR, DOUBLE values in
                                      half storage since round 4 - for a float solver derived in double from

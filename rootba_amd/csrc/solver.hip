@@ -508,7 +508,21 @@ class Solver final : public rba_solver {
     d_bsO_.alloc(5 * qr_obs);
     d_givens_.alloc(sc_ ? 0 : 16 * size_t(n_lms));
     d_Vh_.alloc(8 * qr_obs);
-    if (sc_) build_sc_structure(lm_k, lm_obs, s_obs_cam);
+    if (sc_) {
+      h_lm_obs_ = lm_obs;
+      h_obs_cam_ = s_obs_cam;
+      ex_nb_ = co_observing_cameras(lm_obs, s_obs_cam);
+      build_sc_structure();
+      d_sc_JlS_.alloc(6 * size_t(n_obs_));
+      d_sc_rS_.alloc(2 * size_t(n_obs_));
+      d_sc_M_.alloc(6 * size_t(n_lms_));
+      d_sc_v_.alloc(3 * size_t(n_lms_));
+      d_sc_Hinv_.alloc(9 * size_t(n_lms_));
+      d_sc_hb_.alloc(3 * size_t(n_lms_));
+      d_sc_W_.alloc(27 * size_t(n_obs_));
+      d_sc_T_.alloc(27 * size_t(n_obs_));
+      d_sc_bO_.alloc(9 * size_t(n_obs_));
+    }
     // square-root solver: explicit reduced matrix for long PCG solves (see pcg())
     explicit_after_ = opt_.explicit_after;
     if (env_.explicit_after != INT_MIN) explicit_after_ = env_.explicit_after;
@@ -675,11 +689,7 @@ class Solver final : public rba_solver {
       scp_.W = d_sc_W_.get();
       scp_.T = d_sc_T_.get();
       scp_.bO = d_sc_bO_.get();
-      scp_.row_ptr = d_sc_rowptr_.get();
-      scp_.cols = d_sc_cols_.get();
-      scp_.diag_slot = d_sc_diag_.get();
-      scp_.vals = d_sc_vals_.get();
-      scp_.b = prm_.b;
+      scp_.b = prm_.b;  // (row_ptr, cols, diag_slot, vals: build_sc_structure)
       scp_.blocks = prm_.blocks;
       scp_.fail_flag = prm_.fail_flag;
       scp_.lm_ldiff = prm_.lm_ldiff;
@@ -1101,10 +1111,12 @@ class Solver final : public rba_solver {
   // Block structure of the reduced camera matrix: every ordered pair of cameras that
   // observe a common landmark (what BlockSparseMatrix::add ends up holding,
   // block_sparse_matrix.hpp), as block-CSR.
-  void build_sc_structure(const std::vector<int>& lm_k, const std::vector<int64_t>& lm_obs,
-                          const std::vector<int>& s_obs_cam) {
+  // (the union over the ranks' landmark shards when sharded; the pair lists are the LOCAL observation pairs)
+  void build_sc_structure() {
+    const std::vector<int64_t>& lm_obs = h_lm_obs_;
+    const std::vector<int>& s_obs_cam = h_obs_cam_;
+    const std::vector<std::vector<int>>& nb = ex_nb_;
     const size_t nc = size_t(n_cams_);
-    const std::vector<std::vector<int>> nb = co_observing_cameras(lm_obs, s_obs_cam);
     // full rows: the neighbours and the diagonal block (always present: pose damping), ascending column
     std::vector<int> row_ptr(nc + 1, 0), cols, diag(nc);
     for (size_t c = 0; c < nc; ++c) {
@@ -1138,10 +1150,11 @@ class Solver final : public rba_solver {
     auto for_each_pair = [&](auto&& f) {
       for (int l = 0; l < n_lms_; ++l) {
         const int64_t o0 = lm_obs[l];
-        for (int i = 0; i < lm_k[l]; ++i) {
+        const int k = int(lm_obs[l + 1] - o0);
+        for (int i = 0; i < k; ++i) {
           const int ci = s_obs_cam[o0 + i];
           int t = diag[ci];
-          for (int j = i; j < lm_k[l]; ++j) {
+          for (int j = i; j < k; ++j) {
             const int cj = s_obs_cam[o0 + j];
             while (cols[t] < cj) ++t;
             f(upper_of[t], int(o0 + i), int(o0 + j));
@@ -1179,15 +1192,10 @@ class Solver final : public rba_solver {
     d_sc_cols_.upload(cols.data(), cols.size(), stream_);
     d_sc_diag_.upload(diag.data(), diag.size(), stream_);
     d_sc_vals_.alloc(size_t(81) * nnz + 4);
-    d_sc_JlS_.alloc(6 * size_t(n_obs_));
-    d_sc_rS_.alloc(2 * size_t(n_obs_));
-    d_sc_M_.alloc(6 * size_t(n_lms_));
-    d_sc_v_.alloc(3 * size_t(n_lms_));
-    d_sc_Hinv_.alloc(9 * size_t(n_lms_));
-    d_sc_hb_.alloc(3 * size_t(n_lms_));
-    d_sc_W_.alloc(27 * size_t(n_obs_));
-    d_sc_T_.alloc(27 * size_t(n_obs_));
-    d_sc_bO_.alloc(9 * size_t(n_obs_));
+    scp_.row_ptr = d_sc_rowptr_.get();
+    scp_.cols = d_sc_cols_.get();
+    scp_.diag_slot = d_sc_diag_.get();
+    scp_.vals = d_sc_vals_.get();
     HIP_CHECK(hipStreamSynchronize(stream_));  // the host vectors above go out of scope
     // algorithmic traffic of one S x: the blocks, their column indices, x and y
     hx_bytes_ = int64_t(sizeof(S)) * 81 * nnz + int64_t(4) * nnz + int64_t(sizeof(S)) * 2 * 9 * n_cams_;
@@ -1238,9 +1246,6 @@ class Solver final : public rba_solver {
     // nranks == 1 is allowed on purpose: a one-rank communicator exercises the whole
     // RCCL call path (dlopen, unique id, every all-reduce site) on a single-GPU box
     if (nranks < 1) return;
-    if (sc_ && nranks > 1)
-      throw HipError{"SCHUR_COMPLEMENT solver: landmark sharding is not implemented (single GPU only)",
-                     RBA_ERR_UNSUPPORTED};
     if (!g_rccl.load()) throw HipError{"cannot load librccl.so", RBA_ERR_COMM};
     Rccl::UniqueId id;
     std::memcpy(&id, uid, sizeof(id));
@@ -1282,8 +1287,11 @@ class Solver final : public rba_solver {
   // every rank must hold the SAME block structure for the explicit reduced matrix: union of
   // the co-observation marks of all landmark shards
   void union_structure_over_ranks() {
-    agree_on_explicit_matrix();
-    if (!ex_ready_ || nranks_ <= 1) return;
+    if (nranks_ <= 1) return;
+    if (!sc_) {
+      agree_on_explicit_matrix();
+      if (!ex_ready_) return;
+    }
     // an all-gather of the ranks' upper pairs (c < d) written as two sum all-reduces (the collective the callback
     // transport has): the pair counts, then one buffer in which every rank fills its own segment
     const size_t nc = size_t(n_cams_);
@@ -1325,7 +1333,10 @@ class Solver final : public rba_solver {
       std::sort(list.begin(), list.end());
       list.erase(std::unique(list.begin(), list.end()), list.end());
     }
-    build_explicit_structure();
+    if (sc_)
+      build_sc_structure();
+    else
+      build_explicit_structure();
   }
 
   // Products on the assembled matrix SPLIT over the ranks (more than one rank, large matrices). Replicated, every rank
@@ -1361,9 +1372,6 @@ class Solver final : public rba_solver {
   }
 
   void comm_init_callback(int rank, int nranks, rba_allreduce_fn fn, void* ctx) override {
-    if (sc_ && nranks > 1)
-      throw HipError{"SCHUR_COMPLEMENT solver: landmark sharding is not implemented (single GPU only)",
-                     RBA_ERR_UNSUPPORTED};
     rank_ = rank;
     nranks_ = nranks;
     cb_fn_ = fn;
@@ -1669,6 +1677,13 @@ class Solver final : public rba_solver {
                          stream_, scp_);
       launch_sc_assemble(scp_);
       hipLaunchKernelGGL((rba::k_sc_cam_gradient<S>), dim3(n_cams_), dim3(256), 0, stream_, scp_);
+      if (comm_ || cb_fn_) {
+        // landmarks sharded: H_pp - sum_l W_l H_ll^-1 W_l^T and the gradient are sums over landmarks - every rank holds
+        // the sums of its shard in the united structure; the PCG on the summed matrix then runs replicated on all ranks
+        // with no further collective (LinearizationSC sums the same terms, linearization_sc.hpp:232-347)
+        all_reduce(d_sc_vals_.get(), size_t(81) * sc_nnz_);
+        all_reduce(d_bb_.get(), nvec_);
+      }
       hipLaunchKernelGGL((rba::k_sc_damp_and_extract_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0,
                          stream_, scp_, lambda);
       if (opt_.preconditioner_type == 2) {
@@ -1679,6 +1694,7 @@ class Solver final : public rba_solver {
         gp.JpS = scp_.JpS;
         gp.jp_diag2 = d_tmp_.get();
         launch_cam_gram(gp);
+        all_reduce(d_mid_.get(), size_t(81) * n_cams_);
         hipLaunchKernelGGL((rba::k_sc_jacobi_blocks<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
                            prm_.B_mid, lambda, scp_.blocks, n_cams_);
       }
@@ -1892,7 +1908,7 @@ class Solver final : public rba_solver {
     d_vin_.upload(static_cast<const S*>(x), nvec_, stream_);
     d_tmp_.zero(stream_);
     launch_hx(d_vin_.get(), d_tmp_.get());
-    all_reduce(d_tmp_.get(), nvec_);
+    if (!sc_) all_reduce(d_tmp_.get(), nvec_);  // (SC backend: the summed matrix is on every rank)
     hipLaunchKernelGGL((rba::k_axpy_lambda<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                        d_vin_.get(), d_tmp_.get(), sc_ ? S(0) : pose_damping_, nvec_);
     d_tmp_.download(static_cast<S*>(y), nvec_, stream_);
@@ -2272,12 +2288,12 @@ class Solver final : public rba_solver {
         }
         launch_hx(d_p_.get(), d_q_.get(), done);
         operand_prescaled_ = false;
-        if (!ex_active_ || split_) all_reduce(d_q_.get(), n);
+        if ((!sc_ && !ex_active_) || split_) all_reduce(d_q_.get(), n);
         update(0, d_q_.get());
         if (it % kPcgPeriod == 0) {
           // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
           launch_hx(d_x_.get(), d_tmp_.get(), done);
-          if (!ex_active_ || split_) all_reduce(d_tmp_.get(), n);
+          if ((!sc_ && !ex_active_) || split_) all_reduce(d_tmp_.get(), n);
           update(1, d_tmp_.get());
         }
         mf_open = true;
@@ -2357,7 +2373,7 @@ class Solver final : public rba_solver {
       operand_prescaled_ = pre;
       launch_hx(d_p_.get(), d_q_.get(), done);
       operand_prescaled_ = false;
-      if (!ex_active_ || split_) all_reduce(d_q_.get(), n);
+      if ((!sc_ && !ex_active_) || split_) all_reduce(d_q_.get(), n);
       hipLaunchKernelGGL((rba::k_pcg_b1<S>), dim3(NB), dim3(T), 0, stream_, d_p_.get(), d_q_.get(),
                          lambda, n, st, part_pq);
       hipLaunchKernelGGL((rba::k_pcg_b2<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
@@ -2368,7 +2384,7 @@ class Solver final : public rba_solver {
       if (it % 10 == 0) {
         // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
         launch_hx(d_x_.get(), d_tmp_.get(), done);
-        if (!ex_active_ || split_) all_reduce(d_tmp_.get(), n);
+        if ((!sc_ && !ex_active_) || split_) all_reduce(d_tmp_.get(), n);
         hipLaunchKernelGGL((rba::k_pcg_c1<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
                            d_r_.get(), d_tmp_.get(), lambda, n, st, part_q1);
         hipLaunchKernelGGL((rba::k_pcg_fin), dim3(1), dim3(1), 0, stream_, st, part_q1, 1, eta, min_it,

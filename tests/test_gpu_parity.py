@@ -648,9 +648,6 @@ def test_schur_complement_unsupported_combinations(small_problem):
     from rootba_amd.linearizor import LinearizorHIP
     with pytest.raises(RuntimeError, match="SCHUR_JACOBI"):
         LinearizorHIP(small_problem, np.float32, L.default_options(solver_type=1, preconditioner_type=0))
-    g = LinearizorHIP(small_problem, np.float32, L.default_options(solver_type=1))
-    with pytest.raises(RuntimeError, match="single GPU"):
-        g.comm_init_callback(0, 2, lambda *a: None)
 
 
 # ---- explicit reduced matrix of the square-root solver (rba_options.explicit_after) -------------

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, dtype_name, env, ret):
+def _worker(rank, world, port, dtype_name, env, opts, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, dtype_name, env, ret):
     prob = P.preprocess(P.named_synthetic("ladybug-49"), translation_sigma=0.5, point_sigma=0.5)
     lo, hi = shard_ranges(prob.obs_per_lm(), world)[rank]
     g = LinearizorHIP(take_landmarks(prob, lo, hi), dtype,
-                      L.default_options(robust_norm=1, max_num_iterations=6), device=0)
+                      L.default_options(robust_norm=1, max_num_iterations=6, **opts), device=0)
 
     def allreduce(arr, op):
         t = torch.from_numpy(arr)
@@ -54,7 +54,7 @@ def _worker(rank, world, port, dtype_name, env, ret):
     l_diff = g.apply(inc)
     cams, _ = g.get_state()
     g2 = LinearizorHIP(take_landmarks(prob, lo, hi), dtype,
-                       L.default_options(robust_norm=1, max_num_iterations=6), device=0)
+                       L.default_options(robust_norm=1, max_num_iterations=6, **opts), device=0)
     g2.comm_init_callback(rank, world, allreduce)
     log, term = g2.optimize_lm()
     ret[rank] = dict(err=(err.all_error, err.all_num_obs), b=b, blocks=blocks, hx=hx, inc=inc,
@@ -71,9 +71,13 @@ def _worker(rank, world, port, dtype_name, env, ret):
                                        (np.float64, {"RBA_PCG_SPLIT": "1", "RBA_EXPLICIT_AFTER": "2"}),
                                        (np.float32, {"RBA_PCG_SPLIT": "1", "RBA_EXPLICIT_AFTER": "2"}),
                                        (np.float32, {"RBA_PCG_SPLIT": "1", "RBA_EXPLICIT_AFTER": "2",
-                                                     "RBA_HALF_LOWER_MAX": "3"})],
+                                                     "RBA_HALF_LOWER_MAX": "3"}),
+                                       (np.float64, {"_opts": "schur_complement"}),
+                                       (np.float32, {"_opts": "schur_complement"}),
+                                       (np.float32, {"_opts": "schur_complement_power"})],
                          ids=["float64", "float32", "float32-lds-window", "mixed", "float64-split-products",
-                              "float32-split-products", "float32-split-products-heavy-rows"])
+                              "float32-split-products", "float32-split-products-heavy-rows",
+                              "float64-schur-complement", "float32-schur-complement", "float32-schur-complement-power"])
 def test_two_ranks_one_gpu_match_unsharded(dtype, env, monkeypatch):
     import torch  # noqa: F401
     import torch.multiprocessing as mp
@@ -84,11 +88,17 @@ def test_two_ranks_one_gpu_match_unsharded(dtype, env, monkeypatch):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
+    env = dict(env)
+    # the explicit Schur-complement backend sharded over landmarks (the reference's LinearizationSC sums the same
+    # per-landmark terms, linearization_sc.hpp:232-347): the ranks' sums of S and b are all-reduced in the united
+    # structure, the PCG on S is replicated
+    opts = {"schur_complement": dict(solver_type=1),
+            "schur_complement_power": dict(solver_type=1, preconditioner_type=2, power_order=4)}.get(env.pop("_opts", ""), {})
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     mixed = isinstance(dtype, str)
     vec_dtype = np.float32 if mixed else dtype
-    mp.spawn(_worker, args=(world, 29600 + os.getpid() % 2000, dtype if mixed else np.dtype(dtype).name, env, ret),
+    mp.spawn(_worker, args=(world, 29600 + os.getpid() % 2000, dtype if mixed else np.dtype(dtype).name, env, opts, ret),
              nprocs=world, join=True)
     r0, r1 = ret[0], ret[1]
     # replicated quantities are bit-identical on both ranks
@@ -99,7 +109,7 @@ def test_two_ranks_one_gpu_match_unsharded(dtype, env, monkeypatch):
         assert r0["pcg"]["products_assembled"] > r0["pcg"]["products_matrix_free"] > 0, r0["pcg"]
 
     prob = P.preprocess(P.named_synthetic("ladybug-49"), translation_sigma=0.5, point_sigma=0.5)
-    g = LinearizorHIP(prob, dtype, L.default_options(robust_norm=1, max_num_iterations=6))
+    g = LinearizorHIP(prob, dtype, L.default_options(robust_norm=1, max_num_iterations=6, **opts))
     tol = 1e-5 if vec_dtype == np.float32 else 1e-12
     err = g.compute_error()
     assert r0["err"][1] == err.all_num_obs and \
@@ -112,7 +122,7 @@ def test_two_ranks_one_gpu_match_unsharded(dtype, env, monkeypatch):
     inc, cg = g.solve(1e-4)
     assert abs(cg.num_iterations - r0["cg"]) <= (1 if vec_dtype == np.float32 else 0)
     assert rel_err(r0["inc"], inc) < (1e-3 if vec_dtype == np.float32 else 1e-9)
-    g3 = LinearizorHIP(prob, dtype, L.default_options(robust_norm=1, max_num_iterations=6))
+    g3 = LinearizorHIP(prob, dtype, L.default_options(robust_norm=1, max_num_iterations=6, **opts))
     log, term = g3.optimize_lm()
     assert len(log) == len(r0["lm"])
     for a, (cost, cgi, ok) in zip(log, r0["lm"]):
