@@ -39,12 +39,12 @@ namespace rba {
 // pass G
 // ---------------------------------------------------------------------------
 template <class S>
-__global__ __launch_bounds__(256) void k_s1_geometry(Params<S> p, int64_t n_obs) {
+__global__ __launch_bounds__(256) void k_s1_geometry(Params<S> p, int64_t o_begin, int64_t n_obs) {
   extern __shared__ __attribute__((aligned(16))) char smem_s1[];
   S* sj = reinterpret_cast<S*>(smem_s1);  // [256][18]
   S* sv = sj + 256 * 18;                  // [256][8]
   const int tid = threadIdx.x;
-  const int64_t o_base = int64_t(blockIdx.x) * 256;
+  const int64_t o_base = o_begin + int64_t(blockIdx.x) * 256;  // (o_begin: a multiple of 2 - 16-byte aligned streams)
   const int64_t o = o_base + tid;
   const int n_here = int(min<int64_t>(256, n_obs - o_base));
   if (tid < n_here) {
@@ -107,9 +107,14 @@ __global__ void k_scale_gram(Params<S> p) {
 // pass Q: Householder QR of [Jl | r], lane per block row
 // ---------------------------------------------------------------------------
 // per-landmark scalars handed to the column pass: LQ[s][12] = tau[3], g10 g20 g21, d[3], pad
-template <class S, int P2>
+// FUSED: the rows come from the geometry of their observation, evaluated here per block row (linearize_row) instead
+// of being read back from Vh - one pass over Vh instead of two (k_s1_geometry writes 32 bytes per observation that
+// this kernel reads again), no index loads (the tile knows camera and landmark of every lane). The weighted pose
+// Jacobian rows of the wavefront - contiguous in JpS: consecutive landmarks, consecutive observations - are staged in
+// `stage` (64 x 9 scalars of this wavefront) and stored as one contiguous stream.
+template <class S, int P2, bool FUSED = false>
 __device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_in_class, int lm_begin, int lm_end,
-                                           int lane) {
+                                           int lane, S* __restrict__ stage = nullptr) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
   constexpr int LPW = 64 / P2;
   const int seg = lane / P2, r = lane - P2 * seg, base = lane - r;
@@ -118,7 +123,52 @@ __device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_i
   const int64_t row = p.RT[T * 64 + lane];  // -1: padding lane
   const bool rvalid = row >= 0;
   S jl[3] = {S(0), S(0), S(0)}, rs = S(0);
-  if (rvalid) {
+  if constexpr (FUSED) {
+    const uint64_t live = __ballot(rvalid);
+    const int first = __builtin_ctzll(live | (uint64_t(1) << 63));
+    const int64_t row_first = __shfl(row, first);
+    {
+      // branch-free (padding lanes evaluate a clamped observation and are masked at the end): inside a conditional
+      // the compiler sinks the index and point loads behind the wait for `row` - three round trips instead of two
+      const int cam = max(p.CT[T * 64 + lane], 0);
+      const S* __restrict__ lp = p.lms + 3 * size_t(min(s, lm_end - 1));
+      const int64_t o = (rvalid ? row : int64_t(0)) >> 1;
+      const bool second = (row & 1) != 0;
+      S res[2], jp[9];
+      const bool valid = linearize_row<S>(p.cams + 10 * cam, lp[0], lp[1], lp[2], p.obs_xy[2 * o], p.obs_xy[2 * o + 1],
+                                          second, res, jp, jl);
+      S sw = S(0);
+      if (!p.valid_only || valid) {
+        bool fin = is_finite(res[0]) && is_finite(res[1]);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fin = fin && is_finite(jp[i]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fin = fin && is_finite(jl[i]);
+        if (!fin && rvalid) atomicOr(p.fail_flag, 1);  // non-finite check of linearize_landmark (ipp:123-146)
+        S err, w;
+        error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
+        sw = sqrt(w);
+      }
+      if (!rvalid) sw = S(0);
+      if (rvalid) {
+        S* mine = stage + 9 * int(row - row_first);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) mine[c] = sw * jp[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) jl[c] = rvalid ? sw * jl[c] : S(0);
+      rs = rvalid ? sw * res[second ? 1 : 0] : S(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      // (9 * row_first scalars = 18 per observation: an even count - pairs of scalars are 8-byte aligned for float)
+      const int total = 9 * __popcll(live);
+      S* __restrict__ dst = p.JpS + 9 * row_first;
+      for (int i = lane; i < total; i += 64) dst[i] = stage[i];
+    }
+  } else if (rvalid) {
     const V4 v = reinterpret_cast<const V4*>(p.Vh)[row];
     jl[0] = v.x;
     jl[1] = v.y;
@@ -208,6 +258,24 @@ __global__ __launch_bounds__(256) void k_s1_qr_tile(Params<S> p, ImplicitTiles i
     s1_qr_tile<S, 8>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], lane);
   else
     s1_qr_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], lane);
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void k_s1_fused_tile(Params<S> p, ImplicitTiles it) {
+  __shared__ S stage[4][64 * 9];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int T = blockIdx.x * 4 + wave;
+  if (T >= it.tile_begin[5]) return;
+  if (T >= it.tile_begin[4])
+    s1_qr_tile<S, 64, true>(p, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], lane, stage[wave]);
+  else if (T >= it.tile_begin[3])
+    s1_qr_tile<S, 32, true>(p, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], lane, stage[wave]);
+  else if (T >= it.tile_begin[2])
+    s1_qr_tile<S, 16, true>(p, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], lane, stage[wave]);
+  else if (T >= it.tile_begin[1])
+    s1_qr_tile<S, 8, true>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], lane, stage[wave]);
+  else
+    s1_qr_tile<S, 4, true>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], lane, stage[wave]);
 }
 
 // 32 < k <= 112: one landmark per wavefront, rows rc * 64 + lane

@@ -1603,10 +1603,21 @@ class Solver final : public rba_solver {
     time_begin();
     sub_begin();
     // (the failure word is clean here: whoever publishes it to the host resets the bits of its phase)
+    // (sub-stage timers: the reference's stages one by one - the unfused kernels)
+    const bool fuse = !sc_ && n_tiles_ > 0 && env_.s1_fused && !sub_timing();
     if (!sc_) {
-      // geometry once per observation; Jp_diag2 falls out of the camera-major Gram pass
-      hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256),
-                         256 * 26 * sizeof(S), stream_, prm_, int64_t(n_obs_));
+      // geometry once per observation; Jp_diag2 falls out of the camera-major Gram pass. Wave-tile landmarks
+      // (k <= 32): geometry and QR in ONE kernel, a block row per lane (k_s1_fused_tile) - the geometry kernel then
+      // only serves the observations of the longer tracks
+      // (rounded down to an even observation: the kernel's 16-byte stores stay aligned; the fused kernel, later in the
+      //  stream, writes that observation again)
+      const int64_t o_begin = fuse ? (n_obs_tiled_ & ~int64_t(1)) : 0;
+      if (o_begin < n_obs_)
+        hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ - o_begin + 255) / 256)), dim3(256),
+                           256 * 26 * sizeof(S), stream_, prm_, o_begin, int64_t(n_obs_));
+      if (fuse)
+        hipLaunchKernelGGL((rba::k_s1_fused_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_,
+                           implicit_tiles());
       sub_mark(&sub_.jacobian_evaluation_time);  // linearize_problem()
       // One GPU: the Gram pass (Jp_diag2, pose scaling, B_mid) is folded into the camera-major pass of the first
       // stage 2, which gathers the same Jacobian rows anyway (k_cam_pass*<0>, GRAM). Not when the caller wants
@@ -1627,7 +1638,7 @@ class Solver final : public rba_solver {
       if (!gram_pending_)
         hipLaunchKernelGGL((rba::k_scale_gram<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_, prm_);
       sub_mark(&sub_.stage1_preconditioner_time);  // get_Jp_T_Jp_blockdiag() (JACOBI blocks)
-      if (n_tiles_ > 0)
+      if (n_tiles_ > 0 && !fuse)
         hipLaunchKernelGGL((rba::k_s1_qr_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_,
                            implicit_tiles());
       if (imp_end_[5] > imp_begin_[5])
@@ -3002,6 +3013,7 @@ class Solver final : public rba_solver {
     double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
                                        // over the ranks (default: where the estimate says it pays)
+    int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels
     int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: earlier neighbours above which a camera's row of
                                               // the assembled matrix is stored in full (tests of that path)
   };
@@ -3022,6 +3034,7 @@ class Solver final : public rba_solver {
     env_.verify_assembled = geti("RBA_VERIFY_ASSEMBLED", 0);
     if (const char* ev = std::getenv("RBA_VERIFY_TOLERANCE")) env_.verify_tolerance = std::atof(ev);
     env_.half_lower_max = geti("RBA_HALF_LOWER_MAX", rba::kHalfLowerMax);
+    env_.s1_fused = geti("RBA_S1_FUSED", 1);
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }
