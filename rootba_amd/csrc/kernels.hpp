@@ -172,12 +172,15 @@ __global__ __launch_bounds__(256) void k_compute_error(Params<S> p, int64_t n_ob
 // bytes is a blit kernel of its own (4.8 us each on the profile, eight to ten per LM iteration). `flag`: the numerical
 // failure word of the phase that ends here is published and its bits `flag_clear` are reset for the next phase.
 // Null host pointers (more than one rank: the values are all-reduced on the device first) leave that to the caller.
+// (256 or 1024 work-items: the eight sums of the cost evaluation over 2048 rows are a chain of eight loads per
+//  work-item at 256 - 12 us, twice per LM iteration - and of two at 1024)
 template <int W>
-__global__ __launch_bounds__(256) void k_reduce_rows(const double* __restrict__ in, int64_t n,
-                                                     double* __restrict__ out, double* __restrict__ out_host,
-                                                     int* __restrict__ flag, int* __restrict__ flag_host,
-                                                     int flag_clear) {
-  if (flag_host && threadIdx.x == 255) {
+__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ in, int64_t n,
+                                                      double* __restrict__ out, double* __restrict__ out_host,
+                                                      int* __restrict__ flag, int* __restrict__ flag_host,
+                                                      int flag_clear) {
+  const int nt = int(blockDim.x), n_waves = nt >> 6;
+  if (flag_host && int(threadIdx.x) == nt - 1) {
     const int f = *flag;
     *flag_host = f;
     if (f & flag_clear) *flag = f & ~flag_clear;
@@ -185,11 +188,11 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const double* __restrict__ 
   double acc[W];
 #pragma unroll
   for (int i = 0; i < W; ++i) acc[i] = 0;
-  for (int64_t r = threadIdx.x; r < n; r += 256) {
+  for (int64_t r = threadIdx.x; r < n; r += nt) {
 #pragma unroll
     for (int i = 0; i < W; ++i) acc[i] += in[r * W + i];
   }
-  __shared__ double sm[4][W];
+  __shared__ double sm[16][W];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int i = 0; i < W; ++i) {
@@ -198,7 +201,8 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const double* __restrict__ 
   }
   __syncthreads();
   if (threadIdx.x < W) {
-    const double t = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    double t = sm[0][threadIdx.x];
+    for (int w = 1; w < n_waves; ++w) t += sm[w][threadIdx.x];
     out[threadIdx.x] = t;
     if (out_host) out_host[threadIdx.x] = t;
   }

@@ -1568,7 +1568,7 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, st, prm_, n_obs_, part);
     double* red = part + size_t(kReduceBlocks) * 8;
     const bool direct = results_go_direct();
-    hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, st, part, int64_t(blocks), red,
+    hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(1024), 0, st, part, int64_t(blocks), red,
                        direct ? h : static_cast<double*>(nullptr), static_cast<int*>(nullptr),
                        static_cast<int*>(nullptr), 0);
     if (!direct) {
@@ -1598,13 +1598,15 @@ class Solver final : public rba_solver {
   }
 
   // ---- stage 1 ------------------------------------------------------------------
+  bool s1_fused() const { return !sc_ && n_tiles_ > 0 && env_.s1_fused && !sub_timing(); }
+
   int linearize(void* jp_diag2_out) override {
     use_device();
     time_begin();
     sub_begin();
     // (the failure word is clean here: whoever publishes it to the host resets the bits of its phase)
     // (sub-stage timers: the reference's stages one by one - the unfused kernels)
-    const bool fuse = !sc_ && n_tiles_ > 0 && env_.s1_fused && !sub_timing();
+    const bool fuse = s1_fused();
     if (!sc_) {
       // geometry once per observation; Jp_diag2 falls out of the camera-major Gram pass. Wave-tile landmarks
       // (k <= 32): geometry and QR in ONE kernel, a block row per lane (k_s1_fused_tile) - the geometry kernel then
@@ -2838,6 +2840,9 @@ class Solver final : public rba_solver {
       // stage 1: geometry writes JpS 18 + Vh 8; the QR pass reads Vh 8 (+ the row map, 4 B per block row) and writes
       // Vh 8 (+ JlS 6 + rS 2 for the untiled landmarks) per observation, R0 6 + tau 3 + LQ 12 + Jl_col_scale 3 per landmark
       m->stage1 = geometry_in + no * ((18 + 8) + (8 + 8)) * s + no_untiled * 8 * s + no * 8 + nl * 24 * s;
+      // fused geometry + QR of the tiled landmarks (k_s1_fused_tile): no Vh 8 written and read back, the camera map
+      // of the tile (4 B per block row) instead of the two indices of the observation
+      if (s1_fused()) m->stage1 -= (no - no_untiled) * 16 * s;
       // the Gram pass on its own (JpS 18 + CSC index in, G 81 + Jp_diag2 9 out): not on one GPU, where it rides on the
       // camera pass of the first stage 2, which reads those rows anyway (already counted there)
       if (comm_ || cb_fn_ || !opt_.staged_execution) m->stage1 += no * (18 * s + 4) + nc * 90 * s;
