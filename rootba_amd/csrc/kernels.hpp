@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256) void k_compute_error(Params<S> p, int64_t n_ob
 // bytes is a blit kernel of its own (4.8 us each on the profile, eight to ten per LM iteration). `flag`: the numerical
 // failure word of the phase that ends here is published and its bits `flag_clear` are reset for the next phase.
 // Null host pointers (more than one rank: the values are all-reduced on the device first) leave that to the caller.
-// (256 or 1024 work-items: the eight sums of the cost evaluation over 2048 rows are a chain of eight loads per
-//  work-item at 256 - 12 us, twice per LM iteration - and of two at 1024)
+// (any multiple of 64 work-items up to 1024. The cost evaluation's reduction runs with 256: with 1024 it waits for a
+//  compute unit with sixteen free wave slots - on the side stream, beside the stage-1 kernels, 94 us instead of 12)
 template <int W>
 __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ in, int64_t n,
                                                       double* __restrict__ out, double* __restrict__ out_host,
@@ -301,7 +301,7 @@ template <class S, int P2>
 __device__ __forceinline__ S seg_sum(S v) {
   // all lanes of each aligned P2-lane group receive the group sum
   v += dpp_mov0<0xb1>(v);  // quad_perm:[1,0,3,2]
-  v += dpp_mov0<0x4e>(v);  // quad_perm:[2,3,0,1]
+  if (P2 >= 4) v += dpp_mov0<0x4e>(v);  // quad_perm:[2,3,0,1]
   if (P2 >= 8) v += dpp_mov0<0x141>(v);   // row_half_mirror
   if (P2 >= 16) v += dpp_mov0<0x140>(v);  // row_mirror
   if (P2 >= 32) v += __shfl_xor(v, 16);
@@ -313,6 +313,11 @@ struct ImplicitTiles {
   int tile_begin[6];  // first tile of class c (P2 = 4 << c); [5] = total
   int lm_begin[5];    // first landmark of class c
   int lm_end[5];
+};
+
+// wavefronts of k_s1_fused_obs (kernels_s1.hpp): pairs of row tiles, class by class; [5] = total
+struct FusedObsWaves {
+  int wave_begin[6];
 };
 
 template <class S, int P2>

@@ -278,6 +278,183 @@ __global__ __launch_bounds__(256) void k_s1_fused_tile(Params<S> p, ImplicitTile
     s1_qr_tile<S, 4, true>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], lane, stage[wave]);
 }
 
+// ---------------------------------------------------------------------------
+// passes G + Q in one kernel, an OBSERVATION (two block rows) per lane
+// ---------------------------------------------------------------------------
+// k_s1_fused_tile above is bound by its instruction count (a wavefront covers 32 observations: the projection is
+// evaluated in both lanes of an observation, every segment reduction serves 2k lanes). Here a lane holds both rows
+// of its observation: the geometry runs once per observation, a landmark is an aligned group of P = 1/2 P2 lanes
+// (one reduction step less), and a wavefront covers TWO consecutive row tiles of a class (lane j: row tile
+// 2 t + (j >> 5), its lanes 2 (j & 31) and 2 (j & 31) + 1) - the lane maps of the row tiles (RT, CT) serve both.
+// Same operations per value as the two-kernel stage 1 except that the two rows of a lane are added before the
+// cross-lane part of a sum.
+template <class S, int P>
+__device__ __forceinline__ void s1_fused_obs(const Params<S>& p, int T0, int n_tiles_class, int t_pair, int lm_begin,
+                                             int lm_end, int lane, S* __restrict__ stage) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  constexpr int P2 = 2 * P, LPW = 64 / P2;  // (row-tile quantities)
+  const int h = lane >> 5, q = lane & 31;
+  const int t_in_class = 2 * t_pair + h;
+  const bool tile_ok = t_in_class < n_tiles_class;
+  const size_t T = size_t(T0) + size_t(tile_ok ? t_in_class : 2 * t_pair);
+  const int seg = q / P, r = q - P * seg, base = lane - r;
+  const int s = lm_begin + t_in_class * LPW + seg;
+  const bool lm_ok = tile_ok && s < lm_end;
+  const int row_of_tile = p.RT[T * 64 + 2 * q];                 // (unconditional load of a valid address, then masked)
+  const int64_t row = tile_ok ? int64_t(row_of_tile) : int64_t(-1);  // first row of the observation; -1: padding
+  const bool valid_lane = row >= 0;
+  const uint64_t live = __ballot(valid_lane);
+  const int first = __builtin_ctzll(live | (uint64_t(1) << 63));
+  const int64_t o_first = __shfl(row, first) >> 1;
+  S ja[3], jb[3], ra, rb;
+  {
+    // branch-free: padding lanes evaluate a clamped observation and are masked at the end (see s1_qr_tile)
+    const int cam = max(p.CT[T * 64 + 2 * q], 0);
+    const S* __restrict__ lp = p.lms + 3 * size_t(min(max(s, lm_begin), lm_end - 1));
+    const int64_t o = (valid_lane ? row : int64_t(0)) >> 1;
+    S res[2], Jp[18], Jl[6];
+    const bool valid = linearize_obs<S>(p.cams + 10 * cam, lp[0], lp[1], lp[2], p.obs_xy[2 * o], p.obs_xy[2 * o + 1],
+                                        res, Jp, Jl);
+    S sw = S(0);
+    if (!p.valid_only || valid) {
+      // non-finite check of linearize_landmark (ipp:123-146): 0 * v is 0 for every finite v and NaN otherwise - one
+      // multiply-add per value and one test instead of a class test per value
+      S z = S(0) * res[0] + S(0) * res[1];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) z += S(0) * Jp[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) z += S(0) * Jl[i];
+      if (!(z == S(0)) && valid_lane) atomicOr(p.fail_flag, 1);
+      S err, w;
+      error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
+      sw = sqrt(w);
+    }
+    if (!valid_lane) sw = S(0);
+    if (valid_lane) {
+      S* mine = stage + 18 * int(o - o_first);
+#pragma unroll
+      for (int c = 0; c < 18; ++c) mine[c] = sw * Jp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ja[c] = valid_lane ? sw * Jl[c] : S(0);
+      jb[c] = valid_lane ? sw * Jl[3 + c] : S(0);
+    }
+    ra = valid_lane ? sw * res[0] : S(0);
+    rb = valid_lane ? sw * res[1] : S(0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  {
+    // (18 scalars per observation: pairs of scalars are 8-byte aligned in float, 16-byte in double)
+    using V2 = typename std::conditional<sizeof(S) == 4, float2, double2>::type;
+    const int total = 9 * __popcll(live);
+    V2* __restrict__ dst = reinterpret_cast<V2*>(p.JpS + 18 * o_first);
+    const V2* __restrict__ src = reinterpret_cast<const V2*>(stage);
+    for (int i = lane; i < total; i += 64) dst[i] = src[i];
+  }
+  // scale_Jl_cols
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const S ss = seg_sum<S, P>(ja[c] * ja[c] + jb[c] * jb[c]);
+    const S sc = fast_rcp(p.eps + fast_sqrt(ss));
+    ja[c] *= sc;
+    jb[c] *= sc;
+    if (r == 0 && lm_ok) p.jl_scale[3 * s + c] = sc;
+  }
+  // Householder QR of the 2k x 3 block, rows 2r (a) and 2r + 1 (b) in this lane
+  const int row_a = 2 * r, row_b = 2 * r + 1;
+  S va[3], vb[3], tau[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const S c0 = __shfl((m & 1) ? jb[m] : ja[m], base + (m >> 1));
+    const S tail = seg_sum<S, P>(((row_a > m && valid_lane) ? ja[m] * ja[m] : S(0)) +
+                                 ((row_b > m && valid_lane) ? jb[m] * jb[m] : S(0)));
+    S beta, inv;
+    if (tail <= Eps<S>::tiny) {
+      tau[m] = S(0);
+      beta = c0;
+      inv = S(0);
+    } else {
+      // (IEEE operations: see s1_qr_tile)
+      beta = sqrt(c0 * c0 + tail);
+      if (c0 >= S(0)) beta = -beta;
+      inv = S(1) / (c0 - beta);
+      tau[m] = (beta - c0) / beta;
+    }
+    va[m] = (row_a == m) ? S(1) : ((row_a > m && valid_lane) ? ja[m] * inv : S(0));
+    vb[m] = (row_b == m) ? S(1) : ((row_b > m && valid_lane) ? jb[m] * inv : S(0));
+#pragma unroll
+    for (int c2 = m + 1; c2 < 3; ++c2) {
+      const S d = tau[m] * seg_sum<S, P>(va[m] * ja[c2] + vb[m] * jb[c2]);
+      ja[c2] -= d * va[m];
+      jb[c2] -= d * vb[m];
+    }
+    {
+      const S d = tau[m] * seg_sum<S, P>(va[m] * ra + vb[m] * rb);
+      ra -= d * va[m];
+      rb -= d * vb[m];
+    }
+    if (row_a == m) ja[m] = beta;
+    if (row_a > m) ja[m] = S(0);
+    if (row_b == m) jb[m] = beta;
+    if (row_b > m) jb[m] = S(0);
+  }
+  const S g10 = seg_sum<S, P>(va[1] * va[0] + vb[1] * vb[0]), g20 = seg_sum<S, P>(va[2] * va[0] + vb[2] * vb[0]),
+          g21 = seg_sum<S, P>(va[2] * va[1] + vb[2] * vb[1]);
+  const bool low_a = row_a >= 3 && valid_lane, low_b = row_b >= 3 && valid_lane;
+  const S d0 = seg_sum<S, P>((low_a ? va[0] * ra : S(0)) + (low_b ? vb[0] * rb : S(0))),
+          d1 = seg_sum<S, P>((low_a ? va[1] * ra : S(0)) + (low_b ? vb[1] * rb : S(0))),
+          d2 = seg_sum<S, P>((low_a ? va[2] * ra : S(0)) + (low_b ? vb[2] * rb : S(0)));
+  // R: rows 0 and 1 in the first lane of the landmark, row 2 in the second (a padding lane - zero - for k = 1)
+  const S r00 = __shfl(ja[0], base), r01 = __shfl(ja[1], base), r02 = __shfl(ja[2], base), r11 = __shfl(jb[1], base),
+          r12 = __shfl(jb[2], base), r22 = __shfl(ja[2], base + 1);
+  if (r == 0 && lm_ok) {
+    S* R = p.R0 + 6 * s;
+    R[0] = r00;
+    R[1] = r01;
+    R[2] = r02;
+    R[3] = r11;
+    R[4] = r12;
+    R[5] = r22;
+    p.tauH[3 * s + 0] = tau[0];
+    p.tauH[3 * s + 1] = tau[1];
+    p.tauH[3 * s + 2] = tau[2];
+    V4* lq = reinterpret_cast<V4*>(p.LQ + 12 * size_t(s));
+    lq[0] = V4{tau[0], tau[1], tau[2], g10};
+    lq[1] = V4{g20, g21, d0, d1};
+    lq[2] = V4{d2, S(0), S(0), S(0)};
+  }
+  if (valid_lane) {
+    reinterpret_cast<V4*>(p.Vh)[row] = V4{va[0], va[1], va[2], ra};
+    reinterpret_cast<V4*>(p.Vh)[row + 1] = V4{vb[0], vb[1], vb[2], rb};
+  }
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void k_s1_fused_obs(Params<S> p, ImplicitTiles it, FusedObsWaves fw) {
+  __shared__ __attribute__((aligned(16))) S stage[4][64 * 18];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int W = blockIdx.x * 4 + wave;  // wavefront = a pair of row tiles of one class
+  if (W >= fw.wave_begin[5]) return;
+  if (W >= fw.wave_begin[4])
+    s1_fused_obs<S, 32>(p, it.tile_begin[4], it.tile_begin[5] - it.tile_begin[4], W - fw.wave_begin[4], it.lm_begin[4],
+                        it.lm_end[4], lane, stage[wave]);
+  else if (W >= fw.wave_begin[3])
+    s1_fused_obs<S, 16>(p, it.tile_begin[3], it.tile_begin[4] - it.tile_begin[3], W - fw.wave_begin[3], it.lm_begin[3],
+                        it.lm_end[3], lane, stage[wave]);
+  else if (W >= fw.wave_begin[2])
+    s1_fused_obs<S, 8>(p, it.tile_begin[2], it.tile_begin[3] - it.tile_begin[2], W - fw.wave_begin[2], it.lm_begin[2],
+                       it.lm_end[2], lane, stage[wave]);
+  else if (W >= fw.wave_begin[1])
+    s1_fused_obs<S, 4>(p, it.tile_begin[1], it.tile_begin[2] - it.tile_begin[1], W - fw.wave_begin[1], it.lm_begin[1],
+                       it.lm_end[1], lane, stage[wave]);
+  else
+    s1_fused_obs<S, 2>(p, it.tile_begin[0], it.tile_begin[1] - it.tile_begin[0], W - fw.wave_begin[0], it.lm_begin[0],
+                       it.lm_end[0], lane, stage[wave]);
+}
+
 // 32 < k <= 112: one landmark per wavefront, rows rc * 64 + lane
 template <class S, int RCH>
 __global__ __launch_bounds__(256) void k_s1_qr_wide(Params<S> p, int lm_begin, int lm_end) {

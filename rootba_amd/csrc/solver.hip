@@ -1568,7 +1568,7 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, st, prm_, n_obs_, part);
     double* red = part + size_t(kReduceBlocks) * 8;
     const bool direct = results_go_direct();
-    hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(1024), 0, st, part, int64_t(blocks), red,
+    hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, st, part, int64_t(blocks), red,
                        direct ? h : static_cast<double*>(nullptr), static_cast<int*>(nullptr),
                        static_cast<int*>(nullptr), 0);
     if (!direct) {
@@ -1617,9 +1617,14 @@ class Solver final : public rba_solver {
       if (o_begin < n_obs_)
         hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ - o_begin + 255) / 256)), dim3(256),
                            256 * 26 * sizeof(S), stream_, prm_, o_begin, int64_t(n_obs_));
-      if (fuse)
+      if (fuse && env_.s1_fused == 2) {
         hipLaunchKernelGGL((rba::k_s1_fused_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_,
                            implicit_tiles());
+      } else if (fuse) {
+        const rba::FusedObsWaves fw = fused_obs_waves();
+        hipLaunchKernelGGL((rba::k_s1_fused_obs<S>), dim3((fw.wave_begin[5] + 3) / 4), dim3(256), 0, stream_, prm_,
+                           implicit_tiles(), fw);
+      }
       sub_mark(&sub_.jacobian_evaluation_time);  // linearize_problem()
       // One GPU: the Gram pass (Jp_diag2, pose scaling, B_mid) is folded into the camera-major pass of the first
       // stage 2, which gathers the same Jacobian rows anyway (k_cam_pass*<0>, GRAM). Not when the caller wants
@@ -1872,6 +1877,17 @@ class Solver final : public rba_solver {
     }
     it.tile_begin[5] = n_tiles_;
     return it;
+  }
+
+  rba::FusedObsWaves fused_obs_waves() const {
+    rba::FusedObsWaves fw;
+    int w = 0;
+    for (int c = 0; c < 5; ++c) {
+      fw.wave_begin[c] = w;
+      w += (imp_tiles_[c] + 1) / 2;
+    }
+    fw.wave_begin[5] = w;
+    return fw;
   }
 
   // H x from the factors; long tracks use the workgroup-per-landmark kernel.
@@ -3018,7 +3034,8 @@ class Solver final : public rba_solver {
     double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
                                        // over the ranks (default: where the estimate says it pays)
-    int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels
+    int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels;
+                                       // 2: one kernel with a block row per lane (default 1: an observation per lane)
     int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: earlier neighbours above which a camera's row of
                                               // the assembled matrix is stored in full (tests of that path)
   };

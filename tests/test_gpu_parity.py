@@ -208,17 +208,18 @@ def test_power_series_preconditioner(ladybug_far, dtype):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("which", ["small", "mixed", "long"])
 def test_fused_stage1_is_the_two_kernel_stage1(small_problem, mixed_k_problem, long_track_problem, dtype, which, monkeypatch):
-    """Geometry + QR of the wave-tile landmarks in one kernel (k_s1_fused_tile, a block row per lane; the default)
-    against the geometry kernel followed by the QR kernel (RBA_S1_FUSED=0): the same operations per value, so stage 1
-    (Jp_diag2), stage 2 (b, blocks), the product and the back-substitution agree to rounding of differently
-    contracted multiply-adds. "mixed" / "long" also hold landmarks of the wider classes, which keep the geometry kernel
-    (an observation range that starts behind the tiled ones)."""
+    """Geometry + QR of the wave-tile landmarks in one kernel - an observation per lane (k_s1_fused_obs, the default) or
+    a block row per lane (k_s1_fused_tile, RBA_S1_FUSED=2) - against the geometry kernel followed by the QR kernel
+    (RBA_S1_FUSED=0): the same operations per value (the default adds the two rows of a lane before the cross-lane part
+    of a sum), so stage 1, stage 2 (b, blocks), the product and the back-substitution agree to rounding. "mixed" /
+    "long" also hold landmarks of the wider classes, which keep the geometry kernel (an observation range that starts
+    behind the tiled ones)."""
     import torch  # noqa: F401
     from rootba_amd import _lib as L
     from rootba_amd.linearizor import LinearizorHIP
     prob = {"small": small_problem, "mixed": mixed_k_problem, "long": long_track_problem}[which]
     out = []
-    for fused in ("1", "0"):
+    for fused in ("0", "1", "2"):
         monkeypatch.setenv("RBA_S1_FUSED", fused)
         g = LinearizorHIP(prob, dtype, _opts(L))
         assert g.linearize() == 0
@@ -230,11 +231,12 @@ def test_fused_stage1_is_the_two_kernel_stage1(small_problem, mixed_k_problem, l
         out.append((b, blocks, hx, inc, cg.num_iterations, l_diff))
         g.close()
     tol = 2e-5 if dtype == np.float32 else 1e-12
-    for a, c in zip(out[0][:3], out[1][:3]):
-        assert rel_err(a, c) < tol
-    assert abs(out[0][4] - out[1][4]) <= (1 if dtype == np.float32 else 0)
-    assert rel_err(out[0][3], out[1][3]) < (2e-3 if dtype == np.float32 else 1e-9)
-    assert abs(out[0][5] - out[1][5]) <= (1e-4 if dtype == np.float32 else 1e-10) * abs(out[1][5])
+    for other in out[1:]:
+        for a, c in zip(out[0][:3], other[:3]):
+            assert rel_err(c, a) < tol
+        assert abs(out[0][4] - other[4]) <= (1 if dtype == np.float32 else 0)
+        assert rel_err(other[3], out[0][3]) < (2e-3 if dtype == np.float32 else 1e-9)
+        assert abs(out[0][5] - other[5]) <= (1e-4 if dtype == np.float32 else 1e-10) * abs(out[0][5])
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
