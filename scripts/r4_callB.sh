@@ -4,9 +4,9 @@ TAG=${1:-r4B}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests -m gpu -q -x -k "fused_stage1 or lm_trajectory" > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+timeout 600 python -m pytest tests -m gpu -q -x -k "fused_stage1 or lm_trajectory or (explicit_reduced and float32) or venice" > $O/pytest.log 2>&1; tail -5 $O/pytest.log
 B="python bench.py --steps 20 --warmup 5 --cpu-baseline-iters 0 --no-pmc"
-for F in 1 0 2 1; do
+for F in 1 1; do
   RBA_S1_FUSED=$F $B > $O/venice_fused$F.json 2> $O/venice_fused$F.log
   python - <<PY
 import json
