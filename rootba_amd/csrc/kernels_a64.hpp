@@ -51,9 +51,6 @@ struct A64Params {
   double* LQ;    // [n_lms][8]  tau0 tau1 tau2 g10 g20 g21 - -   (double re-derivation of Params::LQ)
   double* A;     // [n_obs][4]  2x2 factor A, A^T A = I - W'^T W'
   double* rec;   // [n_obs][16] one cache line per observation: Jp (18 float = 9 double slots) | W' (3x2 double, row-major) | pad
-                 // in CAMERA-MAJOR order (record of observation o at rec_pos[o]): the pairs of a block {c, d} then
-                 // walk two contiguous regions (the records of camera c, of camera d), both in ascending order
-  const int* __restrict__ rec_pos;  // [n_obs] position of the observation in the camera-major order (inverse of cam_obs)
 };
 
 constexpr int kA64Lq = 8;
@@ -275,12 +272,9 @@ __global__ __launch_bounds__(kA64Threads) void k_a64_obs(A64Params p, int64_t n_
   }
   __syncthreads();
   {
-    // (a record = a cache line = eight lanes of one store instruction)
+    double2* dst = reinterpret_cast<double2*>(p.rec + size_t(kA64Rec) * o_base);
     const double2* src = reinterpret_cast<const double2*>(sRec);
-    for (int q = tid; q < n_here * (kA64Rec / 2); q += NT) {
-      const int r = q >> 3, piece = q & 7;
-      reinterpret_cast<double2*>(p.rec + size_t(kA64Rec) * p.rec_pos[o_base + r])[piece] = src[q];
-    }
+    for (int q = tid; q < n_here * (kA64Rec / 2); q += NT) dst[q] = src[q];
   }
 }
 
@@ -376,8 +370,7 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   __syncthreads();
   if (threadIdx.x < 81 && q1 > q0) {
     const int a = threadIdx.x / 9, b = threadIdx.x - 9 * a;
-    // (the pair lists hold record positions: cam_obs maps a position back to its observation)
-    const int ci = p.obs_cam[p.cam_obs[pair_oi[q0]]], cj = p.obs_cam[p.cam_obs[pair_oj[q0]]];
+    const int ci = p.obs_cam[pair_oi[q0]], cj = p.obs_cam[pair_oj[q0]];
     const double t = ((tile[0][a][b] + tile[1][a][b]) + tile[2][a][b]) + tile[3][a][b];
     const double v = -t * double(p.pose_scaling[9 * ci + a]) * double(p.pose_scaling[9 * cj + b]);
     const int us = upper_slot[u], m = mirror_slot[u];

@@ -921,20 +921,6 @@ class Solver final : public rba_solver {
       d_a64_lq_.alloc(size_t(rba::kA64Lq) * n_lms_);
       d_a64_A_.alloc(size_t(4) * n_obs_);
       d_a64_rec_.alloc(size_t(rba::kA64Rec) * n_obs_);
-      // the records live in camera-major order (kernels_a64.hpp: A64Params::rec): the pair lists address them by
-      // position
-      std::vector<int64_t> cur(size_t(n_cams_) + 1, 0);
-      for (int64_t o = 0; o < n_obs_; ++o) ++cur[size_t(h_obs_cam_[o]) + 1];
-      for (int c = 0; c < n_cams_; ++c) cur[size_t(c) + 1] += cur[c];
-      std::vector<int> pos(size_t(n_obs_), 0);
-      for (int64_t o = 0; o < n_obs_; ++o) pos[size_t(o)] = int(cur[h_obs_cam_[o]]++);
-      for (int64_t q = 0; q < n_pairs; ++q) {
-        pair_oi[q] = pos[size_t(pair_oi[q])];
-        pair_oj[q] = pos[size_t(pair_oj[q])];
-      }
-      d_a64_pos_.alloc(pos.size());
-      d_a64_pos_.upload(pos.data(), pos.size(), stream_);
-      HIP_CHECK(hipStreamSynchronize(stream_));  // (`pos` goes out of scope)
     }
     d_ex_rowptr_.upload(row_ptr.data(), row_ptr.size(), stream_);
     d_ex_cols_.upload(cols.data(), cols.size(), stream_);
@@ -1019,7 +1005,6 @@ class Solver final : public rba_solver {
       a64_.LQ = d_a64_lq_.get();
       a64_.A = d_a64_A_.get();
       a64_.rec = d_a64_rec_.get();
-      a64_.rec_pos = d_a64_pos_.get();
     }
   }
   // JACOBI / power-series preconditioners of a float solver: Hpp^-1 from blocks summed AND factored in double
@@ -3169,7 +3154,6 @@ class Solver final : public rba_solver {
   // float solver: double re-derivation of the factors for the assembled matrix (kernels_a64.hpp)
   static constexpr bool kA64 = std::is_same<S, float>::value;
   DevBuf<double> d_a64_lq_, d_a64_A_, d_a64_rec_;
-  DevBuf<int> d_a64_pos_;
   rba::A64Params a64_{};
   bool a64_lm_valid_ = false;  // per linearisation point
   DevBuf<double> d_gram64_;    // [81 n_c] D Hpp D in double (JACOBI / power-series preconditioners)
