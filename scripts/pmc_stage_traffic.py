@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 GROUPS = [
     ("k_calib_read<1>", "calib1"), ("k_calib_read<4>", "calib4"),
     ("k_compute_error", "compute_error"), ("k_reduce_rows<8>", "compute_error"),
-    ("k_s1_geometry", "stage1"), ("k_s1_qr", "stage1"), ("k_cam_pass_mfma<float, 1>", "stage1"), ("k_cam_pass_mfma<double, 1>", "stage1"),
+    ("k_s1_geometry", "stage1"), ("k_s1_qr", "stage1"), ("k_s1_fused", "stage1"), ("k_cam_pass_mfma<float, 1>", "stage1"), ("k_cam_pass_mfma<double, 1>", "stage1"),
     ("k_scale_gram", "stage1"), ("k_pose_scaling", "stage1"),
     ("k_s2_obs", "stage2"), ("k_cam_pass_mfma<float, 0>", "stage2"), ("k_cam_pass_mfma<double, 0>", "stage2"), ("k_invert_blocks", "stage2"),
     ("k_hx_implicit", "product_matrix_free"), ("k_scale_vec", "product_matrix_free"),
