@@ -227,7 +227,7 @@ def test_config3_trafalgar257_f32_increment_vectors_default_configuration():
     assert len(rows) == 6
     for r in rows:
         # (PCG counts of the 186 / 274 / 272-iteration solves: the oracle's - 186, 274 and 270 ... 272 in most runs; one
-        #  run in four of the LAST solve stops at 250, with either form of stage 1 (gpurun_out/r4E, four runs: the first
+        #  run in four of the LAST solve stops at 250, with either form of stage 1 (profiles/r4_trafalgar_default_lockstep_runs.log, four runs: the first
         #  products of a solve are matrix-free and flush with float atomics, and the Q-model quantity hovers around its
         #  threshold for the last twenty iterations) - its increment is then 1.55e-3 from the float64 iterate against the
         #  float32 oracle's 1.39e-3, inside the accuracy assertions below, which are what this test is about. Counts
