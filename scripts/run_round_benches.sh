@@ -22,3 +22,7 @@ for f in $O/*.json; do python -c "
 import json,sys
 d=json.loads(open('$f').read().strip().splitlines()[-1])
 print('$f', round(d['value'],2), (d.get('value_repeats') or {}).get('values'), d['config'].get('successful_steps'), round(d['roofline']['frac'] or 0,3), (d['config'].get('value_reference_semantics') or {}).get('value'))"; done
+# kernel statistics of the default line (rocprofv3 --kernel-trace --stats)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-baseline-iters 0 --no-reference-semantics --repeats 1 --no-pmc > $GRAFT_REPO_ROOT/$O/prof.json 2> $GRAFT_REPO_ROOT/$O/prof.log)
+find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
+rm -rf $O/prof
