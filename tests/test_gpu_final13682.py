@@ -105,3 +105,30 @@ def test_final13682_one_iteration_vectors_and_two_step_lockstep(final_problem, o
         assert rel_err(cg_, c6) < 1e-6 and rel_err(co_, c6) < 1e-6
         assert rel_err(lg_, l6) < 2e-5 and rel_err(lo_, l6) < 2e-5
     g.close()
+
+
+def test_final13682_power_series_follows_the_oracle_run(final_problem):
+    """Config 5's solver path (power-series preconditioner on the square-root solver) at config 5's size against the
+    float32 CPU oracle's own LM run of it, which takes 2 h 47 min and is therefore a committed log
+    (profiles/r4_final13682_oracle_f32_power_lm.log, made with the options below): over the first four iterations -
+    before the trajectories of two float32 runs of this ill-conditioned problem part - every step is
+    accepted, the PCG needs the oracle's 2 / 2 / 11 / 3 iterations and the costs agree to 5e-5 (measured 3e-8 ... 1.4e-5)."""
+    import os
+
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                        "r4_final13682_oracle_f32_power_lm.log")
+    rows = [ln.split() for ln in open(path) if ln[0].isdigit()]
+    oracle = [(int(r[1]), int(r[2]), float(r[3])) for r in rows[:5]]
+    assert [r[1] for r in oracle] == [0, 2, 2, 11, 3]
+    g = LinearizorHIP(final_problem, np.float32,
+                      L.default_options(robust_norm=1, huber_parameter=1.0, max_num_iterations=4, function_tolerance=0.0,
+                                        preconditioner_type=2, power_order=10))
+    log, _ = g.optimize_lm()
+    assert len(log) == 5
+    for a, (ok, cg, cost) in zip(log, oracle):
+        assert a.step_is_successful == ok == 1
+        assert abs(a.cg_iterations - cg) <= (1 if cg > 5 else 0), (a.iteration, a.cg_iterations, cg)
+        assert abs(a.cost - cost) <= 5e-5 * cost, (a.iteration, a.cost, cost)
