@@ -219,7 +219,10 @@ int rba_destroy(rba_handle h);
  * thread-level reductions become all-reduces). Each rank creates
  * a handle for ITS landmarks and ALL cameras; `unique_id` is the 128-byte
  * ncclUniqueId produced by rank 0 with rba_comm_unique_id and distributed by
- * the caller's launcher. */
+ * the caller's launcher. Both solver types: SQUARE_ROOT all-reduces camera-sized
+ * vectors and, per assembly, the reduced matrix; SCHUR_COMPLEMENT (since round 4)
+ * all-reduces S, b (and Hpp for the power series) once per stage 2 in the united
+ * block structure and runs its PCG replicated. */
 int rba_comm_unique_id(void* out128);
 int rba_comm_init(rba_handle h, int rank, int nranks, const void* unique_id128);
 /* Same sharding with a caller-provided collective instead of RCCL (MPI, gloo,
