@@ -299,10 +299,7 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   using Acc = typename M::acc;
   constexpr int U = 4;  // (2: same time, 8: 1.6 x slower - registers)
   __shared__ double tile[4][16][16];
-  // (a staged record takes 18 doubles: at the 16 of the record itself - 128 bytes, the span of the 32 LDS banks - the
-  //  four (pair, top row) groups of lanes of an operand read would hit the same banks)
-  constexpr int kRow = kA64Rec + 2;
-  __shared__ __attribute__((aligned(16))) double stage[4][U][8][kRow];
+  __shared__ __attribute__((aligned(16))) double stage[4][U][8][kA64Rec];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int u = WPB == 4 ? xcd_swizzled_camera(n_upper) : 4 * xcd_swizzled_camera((n_upper + 3) / 4) + wave;

@@ -3040,7 +3040,7 @@ class Solver final : public rba_solver {
                                        // over the ranks (default: where the estimate says it pays)
     int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels;
                                        // 2: one kernel with a block row per lane (default 1: an observation per lane)
-    int a64_wpb = 4;                   // RBA_A64_WPB=1: off-diagonal blocks of the double assembly by a wavefront each (4: a workgroup)
+    int a64_wpb = 1;                   // RBA_A64_WPB=4: off-diagonal blocks of the double assembly by a workgroup each (1: a wavefront)
     int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: earlier neighbours above which a camera's row of
                                               // the assembled matrix is stored in full (tests of that path)
   };
@@ -3062,7 +3062,7 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_VERIFY_TOLERANCE")) env_.verify_tolerance = std::atof(ev);
     env_.half_lower_max = geti("RBA_HALF_LOWER_MAX", rba::kHalfLowerMax);
     env_.s1_fused = geti("RBA_S1_FUSED", 1);
-    env_.a64_wpb = geti("RBA_A64_WPB", 4) == 1 ? 1 : 4;
+    env_.a64_wpb = geti("RBA_A64_WPB", 1) == 4 ? 4 : 1;
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }

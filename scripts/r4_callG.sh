@@ -5,7 +5,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 300 python -m pytest tests -m gpu -q -x -k "(explicit_reduced and float32) or (explicit_switch and float32)" > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-for W in 4 1; do
+for W in 1 4; do
 cd /tmp && export TMPDIR=/tmp
 RBA_A64_WPB=$W rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof$W -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-baseline-iters 0 --no-reference-semantics --repeats 1 --no-pmc > $O/prof$W.json 2> $O/prof$W.log
 cd $GRAFT_REPO_ROOT
