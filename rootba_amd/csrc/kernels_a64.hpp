@@ -284,11 +284,6 @@ __global__ __launch_bounds__(kA64Threads) void k_a64_obs(A64Params p, int64_t n_
 // lines, fetched with one 16-byte load per lane (lane = record x piece) and staged in LDS; an operand of the
 // instruction is two FMAs on two doubles (W') and two floats (Jp) of a staged record. The block is written where it
 // is stored: as S_cd in row c and / or transposed in row d (half storage, kernels_pcg.hpp).
-// WPB = 4: the four wavefronts of a workgroup share a block (its pairs interleaved in steps of 4 U, partial sums added
-// through LDS behind a barrier); WPB = 1: a block per WAVEFRONT - half of venice-1778's 53 500 blocks have 36 pairs or
-// fewer (two steps of one wavefront), and the fixed cost of a block (three dependent loads in, barrier and reduction
-// out) is paid by one wavefront instead of four.
-template <int WPB>
 __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __restrict__ vals,
                                                      const int* __restrict__ upper_slot,
                                                      const int* __restrict__ mirror_slot,
@@ -302,9 +297,8 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   __shared__ __attribute__((aligned(16))) double stage[4][U][8][kA64Rec];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int u = WPB == 4 ? xcd_swizzled_camera(n_upper) : 4 * xcd_swizzled_camera((n_upper + 3) / 4) + wave;
-  if (u >= n_upper) return;  // (WPB = 1: per wavefront - no workgroup barrier below)
-  constexpr int kStride = 4 * U * WPB;  // pairs between two steps of a wavefront
+  const int u = xcd_swizzled_camera(n_upper);
+  if (u >= n_upper) return;
   const int i = lane & 15, kk = lane >> 4;
   Acc acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
   const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
@@ -314,7 +308,7 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   // in front of 12 matrix-core instructions; without it the kernel ran at a third of the matrix rate with the matrix
   // pipe idle two thirds of the time, profiles/r4_pmc_mfma_float32.csv): the records of step s + 1 and the indices of
   // step s + 2 are in flight while step s is staged and multiplied. Clamped, not predicated: every load is issued.
-  const int64_t qw = q0 + (WPB == 4 ? wave * (4 * U) : 0);
+  const int64_t qw = q0 + wave * (4 * U);
   auto load_idx = [&](int64_t q, int o[U]) {
 #pragma unroll
     for (int uq = 0; uq < U; ++uq) o[uq] = pair_side[max(q0, min(q + 4 * uq + (rec & 3), q1 - 1))];
@@ -328,14 +322,14 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   if (q1 > q0) {
     int o_cur[U];
     load_idx(qw, o_cur);
-    load_idx(qw + kStride, o_next);
+    load_idx(qw + 16 * U, o_next);
     load_rec(o_cur, v_cur);
   }
-  for (int64_t q = qw; q < q1; q += kStride) {
+  for (int64_t q = qw; q < q1; q += 16 * U) {
     double2 v_next[U];
     int o_next2[U];
     load_rec(o_next, v_next);
-    load_idx(q + 2 * kStride, o_next2);
+    load_idx(q + 32 * U, o_next2);
 #pragma unroll
     for (int uq = 0; uq < U; ++uq) {
       const bool ok = q + 4 * uq + (rec & 3) < q1;
@@ -373,30 +367,15 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][M::row(lane, r)][i] = acc[r];
-  if constexpr (WPB == 4) {
-    __syncthreads();
-    if (threadIdx.x < 81 && q1 > q0) {
-      const int a = threadIdx.x / 9, b = threadIdx.x - 9 * a;
-      const int ci = p.obs_cam[pair_oi[q0]], cj = p.obs_cam[pair_oj[q0]];
-      const double t = ((tile[0][a][b] + tile[1][a][b]) + tile[2][a][b]) + tile[3][a][b];
-      const double v = -t * double(p.pose_scaling[9 * ci + a]) * double(p.pose_scaling[9 * cj + b]);
-      const int us = upper_slot[u], m = mirror_slot[u];
-      if (us >= 0) vals[size_t(81) * us + threadIdx.x] = v;
-      if (m >= 0) vals[size_t(81) * m + 9 * b + a] = v;
-    }
-  } else {
-    wave_lds_fence();
-    if (q1 > q0) {
-      const int ci = p.obs_cam[pair_oi[q0]], cj = p.obs_cam[pair_oj[q0]];
-      const int us = upper_slot[u], m = mirror_slot[u];
-#pragma unroll
-      for (int e = lane; e < 81; e += 64) {
-        const int a = e / 9, b = e - 9 * a;
-        const double v = -tile[wave][a][b] * double(p.pose_scaling[9 * ci + a]) * double(p.pose_scaling[9 * cj + b]);
-        if (us >= 0) vals[size_t(81) * us + e] = v;
-        if (m >= 0) vals[size_t(81) * m + 9 * b + a] = v;
-      }
-    }
+  __syncthreads();
+  if (threadIdx.x < 81 && q1 > q0) {
+    const int a = threadIdx.x / 9, b = threadIdx.x - 9 * a;
+    const int ci = p.obs_cam[pair_oi[q0]], cj = p.obs_cam[pair_oj[q0]];
+    const double t = ((tile[0][a][b] + tile[1][a][b]) + tile[2][a][b]) + tile[3][a][b];
+    const double v = -t * double(p.pose_scaling[9 * ci + a]) * double(p.pose_scaling[9 * cj + b]);
+    const int us = upper_slot[u], m = mirror_slot[u];
+    if (us >= 0) vals[size_t(81) * us + threadIdx.x] = v;
+    if (m >= 0) vals[size_t(81) * m + 9 * b + a] = v;
   }
 }
 

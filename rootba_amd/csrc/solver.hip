@@ -1046,13 +1046,9 @@ class Solver final : public rba_solver {
                          dim3(rba::kA64Threads), 0, stream_, a64_, int64_t(n_obs_), double(pose_damping_));
       hipLaunchKernelGGL(rba::k_a64_diag<false>, dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, a64_,
                          d_ex_diag_.get(), d_ex_vals_.get());
-      if (ex_n_upper_ > 0 && env_.a64_wpb == 4)
-        hipLaunchKernelGGL(rba::k_a64_offdiag<4>, dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_, a64_,
+      if (ex_n_upper_ > 0)
+        hipLaunchKernelGGL(rba::k_a64_offdiag, dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_, a64_,
                            d_ex_vals_.get(), d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(),
-                           d_ex_pair_oi_.get(), d_ex_pair_oj_.get(), ex_n_upper_);
-      else if (ex_n_upper_ > 0)
-        hipLaunchKernelGGL(rba::k_a64_offdiag<1>, dim3(rba::xcd_swizzled_grid((ex_n_upper_ + 3) / 4)), dim3(256), 0,
-                           stream_, a64_, d_ex_vals_.get(), d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(),
                            d_ex_pair_oi_.get(), d_ex_pair_oj_.get(), ex_n_upper_);
       all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);  // (diagonal blocks included: local sums so far)
     } else {
@@ -3040,7 +3036,6 @@ class Solver final : public rba_solver {
                                        // over the ranks (default: where the estimate says it pays)
     int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels;
                                        // 2: one kernel with a block row per lane (default 1: an observation per lane)
-    int a64_wpb = 1;                   // RBA_A64_WPB=4: off-diagonal blocks of the double assembly by a workgroup each (1: a wavefront)
     int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: earlier neighbours above which a camera's row of
                                               // the assembled matrix is stored in full (tests of that path)
   };
@@ -3062,7 +3057,6 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_VERIFY_TOLERANCE")) env_.verify_tolerance = std::atof(ev);
     env_.half_lower_max = geti("RBA_HALF_LOWER_MAX", rba::kHalfLowerMax);
     env_.s1_fused = geti("RBA_S1_FUSED", 1);
-    env_.a64_wpb = geti("RBA_A64_WPB", 1) == 4 ? 4 : 1;
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }
