@@ -28,6 +28,15 @@ def test_a_slice_of_the_gpu_suite_on_the_cpu_harness():
     tail = out.stdout[-1500:] + out.stderr[-500:]
     assert out.returncode == 0, tail
     assert " passed" in out.stdout and "failed" not in out.stdout, tail
+    # the three forms of stage 1 (two kernels / fused with an observation per lane / fused with a block row per lane)
+    # and the assembled reduced matrix built on the neighbour lists, on small problems
+    sel = "(test_fused_stage1 and small) or (test_explicit_reduced_matrix_is_the_same_operator and small-float32)"
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-k", sel,
+                          os.path.join(ROOT, "tests", "test_gpu_parity.py")],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    tail = out.stdout[-1500:] + out.stderr[-500:]
+    assert out.returncode == 0, tail
+    assert " passed" in out.stdout and "failed" not in out.stdout, tail
 
 
 def test_bench_with_two_ranks_on_the_cpu_harness():
