@@ -224,46 +224,6 @@ __device__ __forceinline__ bool linearize_obs(const S* __restrict__ cam, S pwx, 
   return pz >= Eps<S>::eps_sqrt;
 }
 
-// One ROW of the same linearisation (row = 0 / 1 of the observation), for kernels that hold a block row per lane
-// (k_s1_fused_tile): the projection is shared, the Jacobian row is evaluated with the operations of linearize_obs in
-// the same order. res: BOTH residuals (the robust weight needs them), Jp: the 9 entries of the row, Jl: its 3.
-template <class S>
-__device__ __forceinline__ bool linearize_row(const S* __restrict__ cam, S pwx, S pwy, S pwz, S ox, S oy, bool second,
-                                              S res[2], S Jp[9], S Jl[3]) {
-  S R[9];
-  quat_to_rot(cam[0], cam[1], cam[2], cam[3], R);
-  const S f = cam[7], k1 = cam[8], k2 = cam[9];
-  const S px = R[0] * pwx + R[1] * pwy + R[2] * pwz + cam[4];
-  const S py = R[3] * pwx + R[4] * pwy + R[5] * pwz + cam[5];
-  const S pz = R[6] * pwx + R[7] * pwy + R[8] * pwz + cam[6];
-  const S iz = S(1) / pz;
-  const S mx = px * iz, my = py * iz;
-  const S r2 = mx * mx + my * my;
-  const S r4 = r2 * r2;
-  const S rp = S(1) + k1 * r2 + k2 * r4;
-  res[0] = f * mx * rp - ox;
-  res[1] = f * my * rp - oy;
-  const S tmp = k1 + S(2) * k2 * r2;
-  const S m = second ? my : mx;
-  const S jd = f * (rp + S(2) * m * m * tmp) * iz;
-  const S jo = S(2) * f * mx * my * tmp * iz;
-  const S j2 = -f * m * (rp + S(2) * r2 * tmp) * iz;
-  const S j0 = second ? jo : jd, j1 = second ? jd : jo;
-  Jp[0] = j0;
-  Jp[1] = j1;
-  Jp[2] = j2;
-  Jp[3] = j2 * py - j1 * pz;
-  Jp[4] = j0 * pz - j2 * px;
-  Jp[5] = j1 * px - j0 * py;
-  Jl[0] = j0 * R[0] + j1 * R[3] + j2 * R[6];
-  Jl[1] = j0 * R[1] + j1 * R[4] + j2 * R[7];
-  Jl[2] = j0 * R[2] + j1 * R[5] + j2 * R[8];
-  Jp[6] = m * rp;
-  Jp[7] = f * m * r2;
-  Jp[8] = f * m * r4;
-  return pz >= Eps<S>::eps_sqrt;
-}
-
 // Eigen-style Givens coefficients: G^T [p; q] = [r; 0] (Eigen's makeGivens: the larger of |p|, |q|
 // is the divisor). Branch-free: the two general cases differ only in which operand is the divisor and where the
 // results go, so ONE division, one square root and one reciprocal serve both (as four-way branches the lanes of a wave

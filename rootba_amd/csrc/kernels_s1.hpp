@@ -16,6 +16,9 @@
 //                   Householder QR of the 2k x 3 Jl (perform_qr_householder, ipp:717-743), Q^T r, and the
 //                   per-landmark scalars of the compact reflector application. Only the 4 columns
 //                   [Jl | r] are transformed here - Q depends on Jl alone.
+//   k_s1_fused_obs  (round 4, the default for the wave-tile landmarks) geometry AND QR in one kernel with one lane per
+//                   OBSERVATION: [Jl | r] stays in registers between the two, a landmark is an aligned group of
+//                   2..32 lanes; k_s1_geometry then serves only the longer tracks, k_s1_qr_tile the sub-stage timers.
 //   k_s2_obs        stage 2, one THREAD per observation: the six damping rotations of its landmark
 //                   (set_landmark_damping, ipp:165-210) and the observation's stage-2 record WA.
 //   k_s12_cols      one THREAD per observation, ON DEMAND (assembly of the reduced matrix, matrix-free E0
@@ -107,14 +110,9 @@ __global__ void k_scale_gram(Params<S> p) {
 // pass Q: Householder QR of [Jl | r], lane per block row
 // ---------------------------------------------------------------------------
 // per-landmark scalars handed to the column pass: LQ[s][12] = tau[3], g10 g20 g21, d[3], pad
-// FUSED: the rows come from the geometry of their observation, evaluated here per block row (linearize_row) instead
-// of being read back from Vh - one pass over Vh instead of two (k_s1_geometry writes 32 bytes per observation that
-// this kernel reads again), no index loads (the tile knows camera and landmark of every lane). The weighted pose
-// Jacobian rows of the wavefront - contiguous in JpS: consecutive landmarks, consecutive observations - are staged in
-// `stage` (64 x 9 scalars of this wavefront) and stored as one contiguous stream.
-template <class S, int P2, bool FUSED = false>
+template <class S, int P2>
 __device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_in_class, int lm_begin, int lm_end,
-                                           int lane, S* __restrict__ stage = nullptr) {
+                                           int lane) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
   constexpr int LPW = 64 / P2;
   const int seg = lane / P2, r = lane - P2 * seg, base = lane - r;
@@ -123,52 +121,7 @@ __device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_i
   const int64_t row = p.RT[T * 64 + lane];  // -1: padding lane
   const bool rvalid = row >= 0;
   S jl[3] = {S(0), S(0), S(0)}, rs = S(0);
-  if constexpr (FUSED) {
-    const uint64_t live = __ballot(rvalid);
-    const int first = __builtin_ctzll(live | (uint64_t(1) << 63));
-    const int64_t row_first = __shfl(row, first);
-    {
-      // branch-free (padding lanes evaluate a clamped observation and are masked at the end): inside a conditional
-      // the compiler sinks the index and point loads behind the wait for `row` - three round trips instead of two
-      const int cam = max(p.CT[T * 64 + lane], 0);
-      const S* __restrict__ lp = p.lms + 3 * size_t(min(s, lm_end - 1));
-      const int64_t o = (rvalid ? row : int64_t(0)) >> 1;
-      const bool second = (row & 1) != 0;
-      S res[2], jp[9];
-      const bool valid = linearize_row<S>(p.cams + 10 * cam, lp[0], lp[1], lp[2], p.obs_xy[2 * o], p.obs_xy[2 * o + 1],
-                                          second, res, jp, jl);
-      S sw = S(0);
-      if (!p.valid_only || valid) {
-        bool fin = is_finite(res[0]) && is_finite(res[1]);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) fin = fin && is_finite(jp[i]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) fin = fin && is_finite(jl[i]);
-        if (!fin && rvalid) atomicOr(p.fail_flag, 1);  // non-finite check of linearize_landmark (ipp:123-146)
-        S err, w;
-        error_weight<S>(p.robust_norm, p.huber, res[0] * res[0] + res[1] * res[1], err, w);
-        sw = sqrt(w);
-      }
-      if (!rvalid) sw = S(0);
-      if (rvalid) {
-        S* mine = stage + 9 * int(row - row_first);
-#pragma unroll
-        for (int c = 0; c < 9; ++c) mine[c] = sw * jp[c];
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) jl[c] = rvalid ? sw * jl[c] : S(0);
-      rs = rvalid ? sw * res[second ? 1 : 0] : S(0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-      // (9 * row_first scalars = 18 per observation: an even count - pairs of scalars are 8-byte aligned for float)
-      const int total = 9 * __popcll(live);
-      S* __restrict__ dst = p.JpS + 9 * row_first;
-      for (int i = lane; i < total; i += 64) dst[i] = stage[i];
-    }
-  } else if (rvalid) {
+  if (rvalid) {
     const V4 v = reinterpret_cast<const V4*>(p.Vh)[row];
     jl[0] = v.x;
     jl[1] = v.y;
@@ -260,30 +213,12 @@ __global__ __launch_bounds__(256) void k_s1_qr_tile(Params<S> p, ImplicitTiles i
     s1_qr_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], lane);
 }
 
-template <class S>
-__global__ __launch_bounds__(256) void k_s1_fused_tile(Params<S> p, ImplicitTiles it) {
-  __shared__ S stage[4][64 * 9];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int T = blockIdx.x * 4 + wave;
-  if (T >= it.tile_begin[5]) return;
-  if (T >= it.tile_begin[4])
-    s1_qr_tile<S, 64, true>(p, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], lane, stage[wave]);
-  else if (T >= it.tile_begin[3])
-    s1_qr_tile<S, 32, true>(p, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], lane, stage[wave]);
-  else if (T >= it.tile_begin[2])
-    s1_qr_tile<S, 16, true>(p, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], lane, stage[wave]);
-  else if (T >= it.tile_begin[1])
-    s1_qr_tile<S, 8, true>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], lane, stage[wave]);
-  else
-    s1_qr_tile<S, 4, true>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], lane, stage[wave]);
-}
-
 // ---------------------------------------------------------------------------
 // passes G + Q in one kernel, an OBSERVATION (two block rows) per lane
 // ---------------------------------------------------------------------------
-// k_s1_fused_tile above is bound by its instruction count (a wavefront covers 32 observations: the projection is
-// evaluated in both lanes of an observation, every segment reduction serves 2k lanes). Here a lane holds both rows
-// of its observation: the geometry runs once per observation, a landmark is an aligned group of P = 1/2 P2 lanes
+// The QR kernel above is bound by its instruction count, and fusing the geometry into it with a lane per block ROW
+// (tried: 224 us against 262 for the two kernels on venice-1778) evaluates the projection in both lanes of an
+// observation while every segment reduction serves 2k lanes. Here a lane holds both rows of its observation: the geometry runs once per observation, a landmark is an aligned group of P = 1/2 P2 lanes
 // (one reduction step less), and a wavefront covers TWO consecutive row tiles of a class (lane j: row tile
 // 2 t + (j >> 5), its lanes 2 (j & 31) and 2 (j & 31) + 1) - the lane maps of the row tiles (RT, CT) serve both.
 // Same operations per value as the two-kernel stage 1 except that the two rows of a lane are added before the
@@ -308,7 +243,8 @@ __device__ __forceinline__ void s1_fused_obs(const Params<S>& p, int T0, int n_t
   const int64_t o_first = __shfl(row, first) >> 1;
   S ja[3], jb[3], ra, rb;
   {
-    // branch-free: padding lanes evaluate a clamped observation and are masked at the end (see s1_qr_tile)
+    // branch-free (padding lanes evaluate a clamped observation and are masked at the end): inside a conditional the
+    // compiler sinks the index and point loads behind the wait for `row` - three round trips instead of two
     const int cam = max(p.CT[T * 64 + 2 * q], 0);
     const S* __restrict__ lp = p.lms + 3 * size_t(min(max(s, lm_begin), lm_end - 1));
     const int64_t o = (valid_lane ? row : int64_t(0)) >> 1;

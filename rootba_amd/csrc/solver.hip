@@ -1609,7 +1609,7 @@ class Solver final : public rba_solver {
     const bool fuse = s1_fused();
     if (!sc_) {
       // geometry once per observation; Jp_diag2 falls out of the camera-major Gram pass. Wave-tile landmarks
-      // (k <= 32): geometry and QR in ONE kernel, a block row per lane (k_s1_fused_tile) - the geometry kernel then
+      // (k <= 32): geometry and QR in ONE kernel, an observation per lane (k_s1_fused_obs) - the geometry kernel then
       // only serves the observations of the longer tracks
       // (rounded down to an even observation: the kernel's 16-byte stores stay aligned; the fused kernel, later in the
       //  stream, writes that observation again)
@@ -1617,10 +1617,7 @@ class Solver final : public rba_solver {
       if (o_begin < n_obs_)
         hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ - o_begin + 255) / 256)), dim3(256),
                            256 * 26 * sizeof(S), stream_, prm_, o_begin, int64_t(n_obs_));
-      if (fuse && env_.s1_fused == 2) {
-        hipLaunchKernelGGL((rba::k_s1_fused_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_,
-                           implicit_tiles());
-      } else if (fuse) {
+      if (fuse) {
         const rba::FusedObsWaves fw = fused_obs_waves();
         hipLaunchKernelGGL((rba::k_s1_fused_obs<S>), dim3((fw.wave_begin[5] + 3) / 4), dim3(256), 0, stream_, prm_,
                            implicit_tiles(), fw);
@@ -2856,7 +2853,7 @@ class Solver final : public rba_solver {
       // stage 1: geometry writes JpS 18 + Vh 8; the QR pass reads Vh 8 (+ the row map, 4 B per block row) and writes
       // Vh 8 (+ JlS 6 + rS 2 for the untiled landmarks) per observation, R0 6 + tau 3 + LQ 12 + Jl_col_scale 3 per landmark
       m->stage1 = geometry_in + no * ((18 + 8) + (8 + 8)) * s + no_untiled * 8 * s + no * 8 + nl * 24 * s;
-      // fused geometry + QR of the tiled landmarks (k_s1_fused_tile): no Vh 8 written and read back, the camera map
+      // fused geometry + QR of the tiled landmarks (k_s1_fused_obs): no Vh 8 written and read back, the camera map
       // of the tile (4 B per block row) instead of the two indices of the observation
       if (s1_fused()) m->stage1 -= (no - no_untiled) * 16 * s;
       // the Gram pass on its own (JpS 18 + CSC index in, G 81 + Jp_diag2 9 out): not on one GPU, where it rides on the
@@ -3034,8 +3031,7 @@ class Solver final : public rba_solver {
     double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
                                        // over the ranks (default: where the estimate says it pays)
-    int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels;
-                                       // 2: one kernel with a block row per lane (default 1: an observation per lane)
+    int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels
     int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: earlier neighbours above which a camera's row of
                                               // the assembled matrix is stored in full (tests of that path)
   };

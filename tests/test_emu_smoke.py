@@ -28,8 +28,7 @@ def test_a_slice_of_the_gpu_suite_on_the_cpu_harness():
     tail = out.stdout[-1500:] + out.stderr[-500:]
     assert out.returncode == 0, tail
     assert " passed" in out.stdout and "failed" not in out.stdout, tail
-    # the three forms of stage 1 (two kernels / fused with an observation per lane / fused with a block row per lane)
-    # and the assembled reduced matrix built on the neighbour lists, on small problems
+    # the two forms of stage 1 (two kernels / fused with an observation per lane) and the assembled reduced matrix built on the neighbour lists, on small problems
     sel = "(test_fused_stage1 and small) or (test_explicit_reduced_matrix_is_the_same_operator and small-float32)"
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-k", sel,
                           os.path.join(ROOT, "tests", "test_gpu_parity.py")],

@@ -208,10 +208,10 @@ def test_power_series_preconditioner(ladybug_far, dtype):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("which", ["small", "mixed", "long"])
 def test_fused_stage1_is_the_two_kernel_stage1(small_problem, mixed_k_problem, long_track_problem, dtype, which, monkeypatch):
-    """Geometry + QR of the wave-tile landmarks in one kernel - an observation per lane (k_s1_fused_obs, the default) or
-    a block row per lane (k_s1_fused_tile, RBA_S1_FUSED=2) - against the geometry kernel followed by the QR kernel
-    (RBA_S1_FUSED=0): the same operations per value (the default adds the two rows of a lane before the cross-lane part
-    of a sum), so stage 1, stage 2 (b, blocks), the product and the back-substitution agree to rounding. "mixed" /
+    """Geometry + QR of the wave-tile landmarks in one kernel with an observation per lane (k_s1_fused_obs, the default)
+    against the geometry kernel followed by the QR kernel (RBA_S1_FUSED=0): the same operations per value (the fused
+    kernel adds the two rows of a lane before the cross-lane part of a sum), so stage 1, stage 2 (b, blocks), the
+    product and the back-substitution agree to rounding. "mixed" /
     "long" also hold landmarks of the wider classes, which keep the geometry kernel (an observation range that starts
     behind the tiled ones)."""
     import torch  # noqa: F401
@@ -219,7 +219,7 @@ def test_fused_stage1_is_the_two_kernel_stage1(small_problem, mixed_k_problem, l
     from rootba_amd.linearizor import LinearizorHIP
     prob = {"small": small_problem, "mixed": mixed_k_problem, "long": long_track_problem}[which]
     out = []
-    for fused in ("0", "1", "2"):
+    for fused in ("0", "1"):
         monkeypatch.setenv("RBA_S1_FUSED", fused)
         g = LinearizorHIP(prob, dtype, _opts(L))
         assert g.linearize() == 0
