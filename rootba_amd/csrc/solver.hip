@@ -702,9 +702,6 @@ class Solver final : public rba_solver {
     if (n_items_ > 0 && (sc_ || ex_ready_)) build_pcg_graphs();
   }
 
-  // Block-CSR structure for the explicit reduced matrix of the square-root solver, from the
-  // co-observation marks (the union over ranks when landmarks are sharded), and the per-block
-  // lists of the LOCAL observation pairs (i < j) that contribute to each strictly upper block
   // nb[c] = the cameras that observe a landmark together with camera c (ascending, without c): the block structure of
   // the reduced camera matrix. Camera by camera over its landmarks with one row of marks - sum_l k_l^2 steps like the
   // pair lists, O(n_c + blocks) memory (rounds 1-3 kept dense n_c x n_c tables and capped the camera count at 20000).
@@ -743,6 +740,9 @@ class Solver final : public rba_solver {
     return nb;
   }
 
+  // Block-CSR structure for the explicit reduced matrix of the square-root solver, from the neighbour lists (the union
+  // over ranks when landmarks are sharded), and the per-block lists of the LOCAL observation pairs (i < j) that
+  // contribute to each strictly upper block
   void build_explicit_structure() {
     // HALF storage (kernels_pcg.hpp): every off-diagonal block {c, d} lives in the row of its OWNER, as the owner sees
     // it; the product's contribution to the OTHER row travels through a 9-double slot, and the slots a row receives
