@@ -582,12 +582,23 @@ __device__ __forceinline__ int hx_chunk_tile(const HxChunk& ch, int v, int n_tot
 
 // NT threads per workgroup: 1024 caps a lane at 128 VGPRs - enough for float (114), 104 bytes of scratch per lane
 // for double; the 512-thread instance has 256 and spills nothing, at half the waves per CU (RBA_HX_THREADS).
+// (defined below, with the kernel of its own that the non-persistent product uses)
+template <class S, int RCH>
+__device__ __forceinline__ void hx_wide_landmark(const Params<S>& p, int s, const S* __restrict__ x, S* __restrict__ y,
+                                                 const S* __restrict__ dout, S* yb, int* cb, int lane);
+constexpr int kHxWideScalars = 32 * 9 + 8;  // LDS scalars of a wavefront in hx_wide_landmark (+ 32 ints)
+
+// range of the landmarks with 32 < k <= 64 (RCH = 2)
+struct HxWideRanges {
+  int begin[1], end[1];
+};
+
 template <class S, int NT>
 __global__ __launch_bounds__(NT) void k_hx_implicit_lds(Params<S> p, ImplicitTiles it,
                                                         const HxChunk* __restrict__ chunks, int win,
                                                         const S* __restrict__ x, S* __restrict__ y,
                                                         const S* __restrict__ dout,
-                                                        const int* __restrict__ done_flag) {
+                                                        const int* __restrict__ done_flag, HxWideRanges wide) {
   // `dout` (compact stage 2: the Jacobian rows are unscaled, x arrives pre-multiplied by the pose scaling D):
   // the result is multiplied by D where it leaves the workgroup; nullptr = rows already scaled
   extern __shared__ __align__(16) unsigned char hx_lds_raw[];
@@ -654,21 +665,28 @@ __global__ __launch_bounds__(NT) void k_hx_implicit_lds(Params<S> p, ImplicitTil
     const double v = ylds[j];
     if (v != 0.0) atomic_add(yw + j, dw ? S(v * double(dw[j])) : S(v));
   }
+  // The landmarks with 32 < k <= 64 observations (a wavefront each, straight into y with atomics): a few hundred on
+  // venice-1778 - as a kernel of their own they cost a launch of 8 us per product, mostly latency; here the wavefronts
+  // that are done with their tiles take them (64 < k <= 112 keep their kernel: four rows per lane do not fit the
+  // 128 registers of this one). Their LDS buffers reuse the window (the launch reserves at least
+  // W * (kHxWideScalars * sizeof(S) + 128) bytes).
+  if (wide.end[0] > wide.begin[0]) {
+    __syncthreads();  // the flush has read the window
+    S* yb = reinterpret_cast<S*>(hx_lds_raw) + wave * kHxWideScalars;
+    int* cb = reinterpret_cast<int*>(hx_lds_raw + size_t(W) * kHxWideScalars * sizeof(S)) + wave * 32;
+    const int stride = int(gridDim.x) * W;
+    for (int s = wide.begin[0] + int(blockIdx.x) * W + wave; s < wide.end[0]; s += stride)
+      hx_wide_landmark<S, 2>(p, s, x, y, dout, yb, cb, lane);
+  }
 }
 
 // rows of one landmark spread over RCH x 64 lanes (32 < k <= 112): one landmark
 // per wavefront, reflector sums via wave_sum
+// One landmark with 32 < k <= 32 RCH observations on one wavefront (rows rc * 64 + lane): H x contribution added to y
+// with atomics; `yb` (32 * 9 + 8 scalars) and `cb` (32 ints) are LDS buffers of this wavefront.
 template <class S, int RCH>
-__global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_begin, int lm_end,
-                                                          const S* __restrict__ x,
-                                                          S* __restrict__ y, const S* __restrict__ dout,
-                                                          const int* __restrict__ done_flag) {
-  __shared__ S ybuf[4][32 * 9 + 8];
-  __shared__ int cbuf[4][32];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s = lm_begin + blockIdx.x * 4 + wave;
-  if (s >= lm_end) return;
-  if (done_flag && *done_flag) return;
+__device__ __forceinline__ void hx_wide_landmark(const Params<S>& p, int s, const S* __restrict__ x, S* __restrict__ y,
+                                                 const S* __restrict__ dout, S* yb, int* cb, int lane) {
   const int k = p.lm_k[s];
   const int64_t o0 = p.lm_obs[s];
   S jp[RCH][9], u[RCH], v[3][RCH];
@@ -722,8 +740,6 @@ __global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_be
   reflect(2);
   reflect(1);
   reflect(0);
-  S* yb = ybuf[wave];
-  int* cb = cbuf[wave];
   const int obs_local = lane >> 1;
 #pragma unroll
   for (int rc = 0; rc < RCH; ++rc) {
@@ -746,6 +762,20 @@ __global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_be
     }
     wave_lds_fence();
   }
+}
+
+template <class S, int RCH>
+__global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_begin, int lm_end,
+                                                          const S* __restrict__ x,
+                                                          S* __restrict__ y, const S* __restrict__ dout,
+                                                          const int* __restrict__ done_flag) {
+  __shared__ S ybuf[4][kHxWideScalars];
+  __shared__ int cbuf[4][32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = lm_begin + blockIdx.x * 4 + wave;
+  if (s >= lm_end) return;
+  if (done_flag && *done_flag) return;
+  hx_wide_landmark<S, RCH>(p, s, x, y, dout, ybuf[wave], cbuf[wave], lane);
 }
 
 // ===========================================================================

@@ -1896,13 +1896,15 @@ class Solver final : public rba_solver {
     if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_hx_implicit_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
                          d_big_scratch_.get(), d_big_off_.get(), xin, y, dout, done_flag);
+    const bool use_lds = n_tiles_ > 0 && env_.hx_lds && (env_.hx_lds == 2 || (n_tiles_ >= 16 * n_cus_ && hx_coverage_ >= 0.9));
+    // (landmarks with 32 < k <= 64: inside the persistent kernel when that one runs - one launch less per product)
+    const bool wide_inside = use_lds && env_.hx_wide_inside;
     if (imp_end_[6] > imp_begin_[6])
       hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 4>), dim3((imp_end_[6] - imp_begin_[6] + 3) / 4),
                          dim3(256), 0, stream_, prm_, imp_begin_[6], imp_end_[6], xin, y, dout, done_flag);
-    if (imp_end_[5] > imp_begin_[5])
+    if (imp_end_[5] > imp_begin_[5] && !wide_inside)
       hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 2>), dim3((imp_end_[5] - imp_begin_[5] + 3) / 4),
                          dim3(256), 0, stream_, prm_, imp_begin_[5], imp_end_[5], xin, y, dout, done_flag);
-    const bool use_lds = n_tiles_ > 0 && env_.hx_lds && (env_.hx_lds == 2 || (n_tiles_ >= 16 * n_cus_ && hx_coverage_ >= 0.9));
     rba::ImplicitTiles it = implicit_tiles();
     if (n_tiles_ > 0 && !use_lds)
       hipLaunchKernelGGL((rba::k_hx_implicit<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, it, xin, y,
@@ -1912,20 +1914,24 @@ class Solver final : public rba_solver {
       const size_t ylds_bytes = size_t(9) * hx_win_ * sizeof(double);
       // double needs 156 VGPRs: 512-thread workgroups (no scratch; venice: 254 us against 428 with 1024 threads capped
       // at 128 VGPRs); float runs 1024 threads at 114 VGPRs
-      launch_hx_lds<(sizeof(S) == 8 ? 512 : 1024)>(it, ylds_bytes, xin, y, dout, done_flag);
+      rba::HxWideRanges wide{{0}, {0}};
+      if (wide_inside) wide = rba::HxWideRanges{{imp_begin_[5]}, {imp_end_[5]}};
+      launch_hx_lds<(sizeof(S) == 8 ? 512 : 1024)>(it, ylds_bytes, xin, y, dout, done_flag, wide);
     }
   }
 
   template <int NT>
   void launch_hx_lds(const rba::ImplicitTiles& it, size_t ylds_bytes, const S* xin, S* y, const S* dout,
-                     const int* done_flag) {
+                     const int* done_flag, const rba::HxWideRanges& wide) {
+    // (the wavefronts' buffers of the wide landmarks reuse the window)
+    ylds_bytes = std::max(ylds_bytes, size_t(NT / 64) * (rba::kHxWideScalars * sizeof(S) + 128));
     if (!hx_lds_attr_set_) {
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_implicit_lds<S, NT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(kHxLdsMaxBytes)));
       hx_lds_attr_set_ = true;
     }
     hipLaunchKernelGGL((rba::k_hx_implicit_lds<S, NT>), dim3(n_hx_chunks_), dim3(NT), ylds_bytes, stream_, prm_, it,
-                       d_hx_chunks_.get(), hx_win_, xin, y, dout, done_flag);
+                       d_hx_chunks_.get(), hx_win_, xin, y, dout, done_flag, wide);
   }
 
   void right_multiply(const void* x, void* y) override {
@@ -3031,6 +3037,7 @@ class Solver final : public rba_solver {
     double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
                                        // over the ranks (default: where the estimate says it pays)
+    int hx_wide_inside = 1;            // RBA_HX_WIDE_INSIDE=0: landmarks with 32 < k <= 64 in a kernel of their own
     int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels
     int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: earlier neighbours above which a camera's row of
                                               // the assembled matrix is stored in full (tests of that path)
@@ -3053,6 +3060,7 @@ class Solver final : public rba_solver {
     if (const char* ev = std::getenv("RBA_VERIFY_TOLERANCE")) env_.verify_tolerance = std::atof(ev);
     env_.half_lower_max = geti("RBA_HALF_LOWER_MAX", rba::kHalfLowerMax);
     env_.s1_fused = geti("RBA_S1_FUSED", 1);
+    env_.hx_wide_inside = geti("RBA_HX_WIDE_INSIDE", 1);
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }

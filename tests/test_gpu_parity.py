@@ -266,15 +266,17 @@ def test_implicit_q_operator(small_problem, mixed_k_problem, long_track_problem,
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("which", ["small", "mixed"])
-@pytest.mark.parametrize("env", [{"RBA_HX_LDS": "2"}, {"RBA_HX_LDS": "2", "RBA_HX_WIN": "7"},
+@pytest.mark.parametrize("env", [{"RBA_HX_LDS": "2"}, {"RBA_HX_LDS": "2", "RBA_HX_WIDE_INSIDE": "0"},
+                                 {"RBA_HX_LDS": "2", "RBA_HX_WIN": "7"},
                                  {"RBA_HX_LDS": "2", "RBA_HX_WIN": "7", "RBA_SORT_BY_CAMERA": "0"}, {"RBA_HX_LDS": "0"}],
-                         ids=["lds-private", "lds-window", "lds-window-unsorted", "tile-per-wave"])
+                         ids=["lds-private", "lds-private-wide-kernel", "lds-window", "lds-window-unsorted", "tile-per-wave"])
 def test_implicit_q_product_kernels(small_problem, mixed_k_problem, dtype, which, env, monkeypatch):
     """The two evaluations of the product from the factors for k <= 32 (persistent pipelined waves with a
     workgroup-private double copy of y in LDS - of all cameras, or of a 7-camera window with the rest going
     to y directly, as on problems whose cameras do not fit; one tile per wave with device-scope atomics)
     against the oracle: the test problems are too small for the automatic choice to pick the first, so it is
-    forced."""
+    forced. The landmarks with 32 < k <= 64 of "mixed" are taken by the persistent kernel's wavefronts after their
+    tiles (the default) or by a kernel of their own ("lds-private-wide-kernel")."""
     prob = {"small": small_problem, "mixed": mixed_k_problem}[which]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
