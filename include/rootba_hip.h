@@ -347,6 +347,8 @@ typedef struct rba_pcg_counters {
   int64_t iterations;
   int64_t solves_repeated_matrix_free; /* solves whose assembled operator broke down (S + E lost definiteness) */
   int64_t early_switches;              /* solves switched to the assembled matrix at iteration 5 (rising zeta) */
+  int64_t solves_persistent;           /* solves whose iterations on the assembled matrix ran as ONE persistent kernel
+                                          with the matrix in the register files (kernels_pcgp.hpp) */
 } rba_pcg_counters;
 int rba_get_pcg_counters(rba_handle h, rba_pcg_counters* out);
 

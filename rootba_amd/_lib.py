@@ -132,7 +132,7 @@ class RbaByteModel(C.Structure):
 
 class RbaPcgCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("products_matrix_free", "products_assembled", "assemblies", "iterations",
-                                         "solves_repeated_matrix_free", "early_switches")]
+                                         "solves_repeated_matrix_free", "early_switches", "solves_persistent")]
 
 _lib = None
 

@@ -30,6 +30,7 @@
 #include "kernels_s1.hpp"
 #include "kernels_sc.hpp"
 #include "kernels_pcg.hpp"
+#include "kernels_pcgp.hpp"
 #include "kernels_a64.hpp"
 
 namespace {
@@ -904,6 +905,7 @@ class Solver final : public rba_solver {
     ex_n_upper_ = n_upper;
     // one chunk of 33 double blocks per item: every wavefront is one pass of loads (kernels_pcg.hpp)
     build_spmv_items(row_ptr, rba::spmv_chunk_blocks<double>(), &heavy_rows);
+    build_pcgp_structure(nb, slot_nb, diag);
     n_heavy_ = int(heavy_rows.size());
     d_heavy_.alloc(std::max<size_t>(1, heavy_rows.size()));
     if (n_heavy_ > 0) d_heavy_.upload(heavy_rows.data(), heavy_rows.size(), stream_);
@@ -937,6 +939,115 @@ class Solver final : public rba_solver {
     exp_.cols = d_ex_cols_.get();
     exp_.vals = nullptr;  // the values are double for either solver scalar: with_matrix()
     ex_ready_ = true;
+  }
+
+  // Persistent PCG (kernels_pcgp.hpp): consecutive block rows in FULL storage per workgroup, one block per lane, rows
+  // padded to whole quads of lanes; a workgroup holds at most 512 lanes and 56 rows. Not every matrix fits the chip's
+  // register files (n_cus_ workgroups): `pg_ready_` says whether this one does. Deterministic from the (united)
+  // structure: every rank of a sharded run derives the same tables.
+  void build_pcgp_structure(const std::vector<std::vector<int>>& nb, const std::vector<std::vector<int>>& slot_nb,
+                            const std::vector<int>& diag) {
+    pg_ready_ = false;
+    pg_G_ = 0;
+    if (env_.pcg_persistent == 0) return;
+    const int nc = n_cams_;
+    constexpr int T = rba::kPgThreads;
+    auto padded = [&](int c) { return (int(nb[c].size()) + 1 + 3) & ~3; };
+    std::vector<rba::PgWorkgroup> wgs;
+    {
+      int c = 0;
+      while (c < nc) {
+        rba::PgWorkgroup w{c, 0, 0, 0};
+        int lanes = 0;
+        while (c < nc && w.nrows < rba::kPgMaxRows && lanes + padded(c) <= T) {
+          lanes += padded(c);
+          ++w.nrows;
+          ++c;
+        }
+        if (w.nrows == 0) return;  // a row with more than 512 blocks: two-launch path
+        wgs.push_back(w);
+      }
+    }
+    const int G = int(wgs.size());
+    if (G > std::min(n_cus_, rba::kPgMaxGroups)) {
+      if (env_.verbose)
+        std::fprintf(stderr, "[rootba_hip] persistent PCG: the matrix needs %d workgroups, the chip holds %d - two-launch path\n",
+                     G, n_cus_);
+      return;
+    }
+    std::vector<int> lane_src(size_t(G) * T, -1), stage_col(size_t(G) * T, -1), row_info(size_t(3) * nc, 0);
+    std::vector<unsigned short> lane_col(size_t(G) * T, 0);
+    std::vector<int> where(size_t(nc), -1);  // staged index of a camera in the current workgroup
+    for (int g = 0; g < G; ++g) {
+      rba::PgWorkgroup& w = wgs[g];
+      // the distinct columns of the workgroup's rows, ascending
+      std::vector<int> cols;
+      for (int c = w.row0; c < w.row0 + w.nrows; ++c) {
+        cols.push_back(c);
+        cols.insert(cols.end(), nb[c].begin(), nb[c].end());
+      }
+      std::sort(cols.begin(), cols.end());
+      cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+      w.ncols = int(cols.size());  // (<= the workgroup's lanes <= 512)
+      for (int t = 0; t < w.ncols; ++t) {
+        stage_col[size_t(g) * T + t] = cols[t];
+        where[cols[t]] = t;
+      }
+      int lane = 0;
+      for (int c = w.row0; c < w.row0 + w.nrows; ++c) {
+        row_info[3 * c] = lane / 4;
+        row_info[3 * c + 1] = padded(c) / 4;
+        row_info[3 * c + 2] = where[c];
+        bool diag_done = false;
+        auto put = [&](int col, int src) {
+          lane_src[size_t(g) * T + lane] = src;
+          lane_col[size_t(g) * T + lane] = static_cast<unsigned short>(where[col]);
+          ++lane;
+        };
+        for (size_t k = 0; k <= nb[c].size(); ++k) {
+          if (!diag_done && (k == nb[c].size() || nb[c][k] > c)) {
+            put(c, 2 * diag[c]);
+            diag_done = true;
+          }
+          if (k == nb[c].size()) break;
+          const int d = nb[c][k];
+          if (slot_nb[c][k] >= 0) {
+            put(d, 2 * slot_nb[c][k]);  // stored in row c as row c sees it
+          } else {
+            const int kk = int(std::lower_bound(nb[d].begin(), nb[d].end(), c) - nb[d].begin());
+            put(d, 2 * slot_nb[d][kk] + 1);  // stored in row d: S_cd = S_dc^T
+          }
+        }
+        lane = (lane + 3) & ~3;
+      }
+      for (int t = 0; t < w.ncols; ++t) where[cols[t]] = -1;
+    }
+    d_pg_wg_.alloc(wgs.size());
+    d_pg_lane_src_.alloc(lane_src.size());
+    d_pg_lane_col_.alloc(lane_col.size());
+    d_pg_stage_col_.alloc(stage_col.size());
+    d_pg_row_info_.alloc(row_info.size());
+    d_pg_wg_.upload(wgs.data(), wgs.size(), stream_);
+    d_pg_lane_src_.upload(lane_src.data(), lane_src.size(), stream_);
+    d_pg_lane_col_.upload(lane_col.data(), lane_col.size(), stream_);
+    d_pg_stage_col_.upload(stage_col.data(), stage_col.size(), stream_);
+    d_pg_row_info_.upload(row_info.data(), row_info.size(), stream_);
+    constexpr int W = rba::pg_words<S>();
+    d_pg_zg_.alloc(size_t(nvec_) * W);
+    d_pg_xg_.alloc(size_t(nvec_) * W);
+    d_pg_part_.alloc(size_t(6) * G);
+    d_pg_zg_.zero(stream_);
+    d_pg_xg_.zero(stream_);
+    d_pg_part_.zero(stream_);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_pcgp<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  int(rba::pgp_lds_bytes<S>())));
+    pg_G_ = G;
+    pg_epoch_ = 1;
+    pg_ready_ = true;
+    if (env_.verbose)
+      std::fprintf(stderr, "[rootba_hip] persistent PCG: %d workgroups of %d lanes for %d blocks in full storage\n", G, T,
+                   2 * ex_nnz_ - nc);
   }
 
   // work items of the fused PCG's SpMV (kernels_pcg.hpp): one wavefront per block row, rows with
@@ -2093,6 +2204,54 @@ class Solver final : public rba_solver {
     HIP_CHECK(hipGetLastError());
   }
 
+  // The PCG from iteration `it_start` on as ONE persistent kernel with the assembled matrix in the register files
+  // (kernels_pcgp.hpp). Same hand-over of the state as pcg_fused().
+  bool pcg_persistent_possible() const {
+    // (two ranks that share a device - the callback transport of the tests - would each wait for workgroups the other
+    //  one's resident workgroups keep off the CUs; the power series and the explicit-SC backend keep the two-launch path)
+    return pg_ready_ && !pg_broken_ && !sc_ && !series_fused() && !split_ && !cb_fn_;
+  }
+  void pcg_persistent(int it_start) {
+    rba::PgParams<S> P{};
+    P.wg = d_pg_wg_.get();
+    P.lane_src = d_pg_lane_src_.get();
+    P.lane_col = d_pg_lane_col_.get();
+    P.stage_col = d_pg_stage_col_.get();
+    P.row_info = d_pg_row_info_.get();
+    P.vals = d_ex_vals_.get();
+    P.inv = d_inv_.get();
+    P.b = prm_.b;
+    P.x = d_x_.get();
+    P.r_in = d_r_.get();
+    P.p_in = d_p_.get();
+    P.zg = d_pg_zg_.get();
+    P.xg = d_pg_xg_.get();
+    P.part_rq = d_pg_part_.get();
+    P.part_pq = d_pg_part_.get() + size_t(4) * pg_G_;
+    P.st = d_cg_.get();
+    P.host_progress = h_progress_;
+    const unsigned span = unsigned(opt_.max_cg_it) + 4;  // tags of a solve: tag_base + iteration
+    if (pg_epoch_ > 0xffffffffu - 2 * span) {
+      d_pg_zg_.zero(stream_);
+      d_pg_xg_.zero(stream_);
+      d_pg_part_.zero(stream_);
+      pg_epoch_ = 1;
+    }
+    P.tag_base = pg_epoch_;
+    pg_epoch_ += span;
+    P.G = pg_G_;
+    P.switch_operator = it_start > 1 ? 1 : 0;
+    P.q_tolerance = opt_.eta;
+    P.min_it = opt_.min_cg_it;
+    P.max_it = opt_.max_cg_it;
+    P.period = kPcgPeriod;
+    volatile int* hp = h_progress_;
+    hp[1] = 0;
+    hp[4] = 0;
+    hipLaunchKernelGGL((rba::k_pcgp<S>), dim3(pg_G_), dim3(rba::kPgThreads), rba::pgp_lds_bytes<S>(), stream_, P);
+    HIP_CHECK(hipGetLastError());
+  }
+
   // ---- solve = stage 2 + preconditioner + PCG ------------------------------------
   int solve(double lambda_d, void* inc_out, rba_cg_summary* cg_out) override {
     use_device();
@@ -2431,9 +2590,26 @@ class Solver final : public rba_solver {
       }
     }
     if (go_fused) {
-      pcg_fused(lambda, it);
-      HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
-      sync();
+      bool persistent = pcg_persistent_possible();
+      if (persistent) {
+        pcg_persistent(it);
+        HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
+        sync();
+        if (h_progress_[4] != 0) {
+          // a workgroup waited ~1 s for a granule (not every workgroup resident? another process on the device?): nothing
+          // of the state was written - continue in two launches per iteration and keep to them
+          std::fprintf(stderr, "[rootba_hip] persistent PCG gave up waiting (%d workgroups); two-launch path from now on\n", pg_G_);
+          pg_broken_ = true;
+          persistent = false;
+        } else {
+          ++pcg_counters_.solves_persistent;
+        }
+      }
+      if (!persistent) {
+        pcg_fused(lambda, it);
+        HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
+        sync();
+      }
     }
     ex_active_ = false;
     pcg_collect(&summary, it_first_assembled);
@@ -3035,6 +3211,8 @@ class Solver final : public rba_solver {
     int sort_by_camera = -1;           // RBA_SORT_BY_CAMERA=0/1: override the automatic choice
     int verify_assembled = 0;          // RBA_VERIFY_ASSEMBLED=1: one-product check of assembled-operator solves (diagnostic)
     double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
+    int pcg_persistent = 1;            // RBA_PCG_PERSISTENT=0: PCG on the assembled matrix always in two launches per
+                                       // iteration (kernels_pcg.hpp; the test of the two forms)
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
                                        // over the ranks (default: where the estimate says it pays)
     int hx_wide_inside = 1;            // RBA_HX_WIDE_INSIDE=0: landmarks with 32 < k <= 64 in a kernel of their own
@@ -3062,6 +3240,7 @@ class Solver final : public rba_solver {
     env_.s1_fused = geti("RBA_S1_FUSED", 1);
     env_.hx_wide_inside = geti("RBA_HX_WIDE_INSIDE", 1);
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
+    env_.pcg_persistent = geti("RBA_PCG_PERSISTENT", 1);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }
 
@@ -3172,6 +3351,14 @@ class Solver final : public rba_solver {
   bool pcg_used_explicit_ = false, pcg_indefinite_ = false, explicit_off_for_solve_ = false;
   rba_pcg_counters pcg_counters_{};
   hipGraphExec_t pcg_graph_exec_[2] = {nullptr, nullptr};
+  // persistent PCG with the matrix in the register files (kernels_pcgp.hpp)
+  bool pg_ready_ = false, pg_broken_ = false;
+  int pg_G_ = 0;
+  unsigned pg_epoch_ = 1;  // tag base of the next solve: tags never repeat between launches
+  DevBuf<rba::PgWorkgroup> d_pg_wg_;
+  DevBuf<int> d_pg_lane_src_, d_pg_stage_col_, d_pg_row_info_;
+  DevBuf<unsigned short> d_pg_lane_col_;
+  DevBuf<unsigned long long> d_pg_zg_, d_pg_xg_, d_pg_part_;
   // explicit Schur-complement backend (solver_type = 1)
   bool sc_ = false;
   int sc_nnz_ = 0;

@@ -117,6 +117,7 @@ struct Self {
 Self* self();                  // the running work-item
 void block_barrier();          // __syncthreads
 void wave_barrier();           // all live lanes of the wavefront
+void spin_yield();             // s_sleep in a spin loop: let the other work-items (and workgroups) run
 uint64_t* wave_slots();        // 64 exchange slots of the running wavefront (+ 6 x 64 more for the matrix-core emulation)
 int first_live_lane();         // lowest lane of the wavefront that has not returned
 void launch(dim3 grid, dim3 block, size_t shmem, hipStream_t stream, std::function<void()> body);
@@ -329,7 +330,7 @@ static inline int hipemu_readfirstlane(int v) {
 #define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
-#define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) hipemu::spin_yield()
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)

@@ -140,6 +140,14 @@ void wave_barrier() {
   f->wait = WAIT_WAVE;
   yield();
 }
+// s_sleep inside a spin loop (persistent kernels that wait for another workgroup's data): the work-item gives way to
+// the other work-items of its workgroup - the one it waits for may be among them - and, now and then, the OS thread to the
+// threads that run the other workgroups
+void spin_yield() {
+  static thread_local unsigned n = 0;
+  if ((++n & 0xfff) == 0) std::this_thread::yield();
+  if (g_block->alive > 1) yield();  // (state stays RUN: the scheduler loop comes back to it)
+}
 void block_barrier() {
   Fiber* f = g_cur;
   Block& b = *g_block;
@@ -364,7 +372,13 @@ hipError_t hipGetDevice(int* d) {
   return hipSuccess;
 }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
-  *v = 4;  // "compute units": keeps the persistent kernels' grids small
+  // "compute units": keeps the persistent kernels' grids small. A kernel whose workgroups wait for each other
+  // (kernels_pcgp.hpp) needs them all running at once: HIPEMU_CUS <= HIPEMU_THREADS
+  static const int cus = [] {
+    const char* e = std::getenv("HIPEMU_CUS");
+    return e ? std::max(1, std::atoi(e)) : 4;
+  }();
+  *v = cus;
   return hipSuccess;
 }
 // Stream capture (the product captures with hipStreamCaptureModeThreadLocal): while THIS thread captures, the calls the real
@@ -549,4 +563,5 @@ alignas(16) thread_local char smem_pcgs[160 * 1024];
 alignas(16) thread_local char smem_s1[160 * 1024];
 alignas(16) thread_local char smem_s1c[160 * 1024];
 alignas(16) thread_local char smem_a64[160 * 1024];
+alignas(16) thread_local char smem_pg[160 * 1024];
 }  // namespace rba

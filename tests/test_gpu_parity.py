@@ -915,3 +915,46 @@ def test_matrix_free_repeat_after_assembled_operator_breakdown(ladybug_far, prec
     assert c0.termination_type == 1 and c1.termination_type == 1
     assert abs(c1.num_iterations - c0.num_iterations) <= max(2, c0.num_iterations // 5), (c0.num_iterations, c1.num_iterations)
     assert rel_err(inc, ref) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("which", ["ladybug", "small", "mixed"])
+def test_persistent_pcg_is_the_two_launch_pcg(ladybug_far, small_problem, mixed_k_problem, dtype, which, monkeypatch):
+    """The PCG on the assembled matrix as ONE persistent kernel with the matrix in the register files
+    (kernels_pcgp.hpp) against the two-launch form (kernels_pcg.hpp, RBA_PCG_PERSISTENT=0): same recurrence, same
+    operator, other summation orders - identical iteration counts, increments equal to rounding (float64) / to what
+    float32 resolves, over solves that cross the residual refresh; and the same LM run."""
+    from rootba_amd import _lib as L
+    prob = {"ladybug": ladybug_far, "small": small_problem, "mixed": mixed_k_problem}[which]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RBA_PCG_PERSISTENT", mode)
+        rows = []
+        for eta, lam in ((1e-3, 1e-5), (1e-7 if dtype == np.float64 else 1e-4, 1e-4)):
+            g, _ = _pair(prob, dtype, explicit_after=1, eta=eta, max_cg_it=60)
+            assert g.linearize() == 0
+            inc, cg = g.solve(lam)
+            cnt = g.pcg_counters()
+            assert cnt["solves_persistent"] == (1 if mode == "1" else 0), (mode, cnt)
+            rows.append((inc, cg.num_iterations, cg.termination_type))
+        g2, _ = _pair(prob, dtype, explicit_after=1, max_num_iterations=5)
+        out[mode] = (rows, g2.optimize_lm()[0])
+    for (i0, n0, t0), (i1, n1, t1) in zip(out["0"][0], out["1"][0]):
+        assert t0 == t1
+        if dtype == np.float64:
+            # (a solve that has NOT converged when it stops at max_cg_it is as sensitive to rounding as a long CG
+            #  recurrence gets: the two-launch path itself moves by 4e-6 when the operator switch comes one product later)
+            assert n0 == n1 and rel_err(i0, i1) < (1e-9 if t0 == 1 else 1e-4), (n0, n1, t0, rel_err(i0, i1))
+        else:
+            assert abs(n0 - n1) <= max(1, n0 // 10), (n0, n1)
+            if n0 == n1:
+                assert rel_err(i0, i1) < 2e-3, (n0, rel_err(i0, i1))
+    assert max(n for _, n, _ in out["1"][0]) > 10  # (the residual refresh ran)
+    # (float64: two equivalent CG recurrences agree to 1e-14 after 20 iterations, 1e-12 after 30, 1e-9 after 40 and 1e-6
+    #  after 50 on the `small` problem - the two-launch path against itself with the operator switch one product later
+    #  just the same - so rows behind a solve of more than 30 iterations are held to 1e-5)
+    long_before = False
+    for a, b in zip(out["0"][1], out["1"][1]):
+        long_before |= max(a.cg_iterations, b.cg_iterations) > 30
+        ctol = (1e-5 if long_before else 1e-9) if dtype == np.float64 else 2e-5
+        assert abs(a.cost - b.cost) <= ctol * b.cost, (a.cost, b.cost, a.cg_iterations, b.cg_iterations)
