@@ -14,12 +14,16 @@
 //     the registers of the row's nine work-items for the whole solve, and the ONLY data that crosses workgroups per
 //     iteration are the 9 n_c entries of z (each workgroup needs the rows its blocks multiply: its "staged columns",
 //     ~100 for a banded matrix) and the workgroups' partial sums of the two dot products;
-//   * there is NO grid barrier. Every exchanged word travels as an 8-byte {value, tag} granule written by one
-//     write-through store (sc1) and read by L1-bypassing loads until its tag is this iteration's (the data is the flag;
-//     scripts/microbench/grid_barrier.hip: an all-gather of 256 partial sums 3.2 us against 7.1 us for the cheapest
-//     counter barrier pair and 14-17 us with release / acquire fences). Overwriting is safe without double buffering:
-//     the two all-gathers of an iteration guard each other - nobody publishes exchange k + 1 before it has read EVERY
-//     workgroup's granule of exchange k, which those workgroups wrote after reading exchange k - 1;
+//   * there is NO grid barrier. Everything exchanged travels as 16-byte self-validating RECORDS - {double, tag, check} or
+//     {three floats, tag ^ check} - written by ONE write-through store (sc1) and read by L1-bypassing loads until tag and
+//     check are this iteration's (the data is the flag; a record torn into its 8-byte halves fails the check). The
+//     workgroups' partial sums are published in EIGHT replicas (one store instruction) and a workgroup polls replica
+//     (g mod 8): 230 workgroups hammering the same 58 cache lines was the largest cost of a first version
+//     (scripts/microbench/allgather.hip: 3.3 us per all-gather with 8-byte granules, 2.3 us with 16-byte records,
+//     1.75 us with replicas; scripts/microbench/grid_barrier.hip: 7.1 us for the cheapest counter barrier pair, 14-17 us
+//     with release / acquire fences). Overwriting is safe without double buffering: the two all-gathers of an iteration
+//     guard each other - nobody publishes exchange k + 1 before it has read EVERY workgroup's record of exchange k,
+//     which those workgroups wrote after reading exchange k - 1;
 //   * every sum has a fixed order (quad sums on the DPP network, the row's quads in ascending order, the waves of a
 //     workgroup, the workgroups' partial sums lane-strided then the DPP tree): bitwise reproducible and identical on all
 //     ranks of a sharded run, like the two-launch path;
@@ -37,18 +41,27 @@ namespace rba {
 
 using pg_u32 = unsigned int;
 using pg_u64 = unsigned long long;
+typedef pg_u32 pg_rec __attribute__((ext_vector_type(4)));  // a 16-byte record
 
 constexpr int kPgThreads = 512;               // 8 wavefronts: two per SIMD, one workgroup per CU
-constexpr int kPgMaxRows = kPgThreads / 9;    // nine row work-items per camera
+constexpr int kPgMaxRows = kPgThreads / 9;    // nine row outputs per camera
 constexpr int kPgQuads = kPgThreads / 4;
-constexpr int kPgMaxGroups = 256;             // workgroups whose partial sums one wavefront gathers (4 per lane)
+constexpr int kPgMaxGroups = 256;             // workgroups (a record per lane of four polling wavefronts)
+constexpr int kPgReplicas = 8;                // copies of every workgroup's partial sums
 constexpr pg_u32 kPgSpinLimit = 1u << 20;     // sweeps of ~1 us before a workgroup gives up
+constexpr int kPgTraceIts = 64;
 
 struct PgWorkgroup {
   int row0, nrows;  // cameras row0 .. row0 + nrows - 1
   int ncols;        // distinct columns its blocks multiply (staged in LDS by work-items 0 .. ncols - 1)
   int pad;
 };
+
+// records per camera of an exchanged vector: three floats or one double per record
+template <class S>
+constexpr int pg_vec_records() {
+  return sizeof(S) == 4 ? 3 : 9;
+}
 
 template <class S>
 struct PgParams {
@@ -63,55 +76,156 @@ struct PgParams {
   S* x;                            // in: iterate after `iter` iterations; out: the solution
   const S* r_in;                   // residual (not read when the operator is switched: recomputed)
   const S* p_in;                   // direction of the last completed iteration
-  pg_u64* zg;                      // [9 n_c W] granules of z
-  pg_u64* xg;                      // [9 n_c W] granules of x (refresh product)
-  pg_u64* part_rq;                 // [G][4]    partial sums of rho and Q
-  pg_u64* part_pq;                 // [G][2]    partial sums of p.q
+  pg_rec* zg;                      // [n_c][3 | 9] records of z
+  pg_rec* xg;                      // [n_c][3 | 9] records of x (refresh product)
+  pg_rec* part_rq;                 // [8][G][2]  partial sums of rho and Q, eight replicas
+  pg_rec* part_pq;                 // [8][G]     partial sums of p.q
   CgState* st;
   int* host_progress;              // pinned: [1] done, [4] aborted
   pg_u32 tag_base;
-  int G;
+  int G, n_cams;
   int switch_operator;             // the solve ran matrix-free so far: r = b - (S + lambda I) x first (like the refresh)
   double q_tolerance;
   int min_it, max_it, period;
+  long long* trace;                // debug (RBA_PCGP_TRACE): 100 MHz real-time stamps of the first kPgTraceIts iterations, 8 per
+                                   // iteration and workgroup; nullptr in production
 };
 
-#define PG_AGENT __HIP_MEMORY_SCOPE_AGENT
-__device__ __forceinline__ pg_u64 pg_ld(const pg_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, PG_AGENT); }
-__device__ __forceinline__ void pg_st(pg_u64* p, pg_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, PG_AGENT); }
+// The kernel keeps 162 registers of matrix per lane; every loop-invariant address the compiler hoists out of the
+// iteration loop (a record address per exchange and lane ...) is a spilled pair. An index made opaque at its use is
+// recomputed there (one multiply-add) instead.
+#ifdef HIPEMU
+#define PG_OPAQUE(x) ((void)0)
+#else
+#define PG_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
 
-// a scalar as tagged granules: float = one, double = two (high / low word)
-__device__ __forceinline__ void pg_store(pg_u64* g, size_t i, float v, pg_u32 tag) {
-  pg_st(g + i, (pg_u64(tag) << 32) | pg_u64(__float_as_uint(v)));
+// ---- 16-byte records: write-through store, L1-bypassing loads (sc1) ---------------------------------------------------
+// (inline assembly: no builtin emits a 16-byte access of agent scope. The loads of a sweep and their wait are ONE
+//  statement - the compiler does not count the memory operations of an asm statement.)
+#ifdef HIPEMU
+// CPU execution harness of the tests: two 8-byte atomics per record - a record CAN be torn there, as the check expects
+__device__ __forceinline__ void pg_rec_store(pg_rec* p, pg_rec v) {
+  pg_u64* q = reinterpret_cast<pg_u64*>(p);
+  __hip_atomic_store(q, pg_u64(v.x) | (pg_u64(v.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, pg_u64(v.z) | (pg_u64(v.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void pg_store(pg_u64* g, size_t i, double v, pg_u32 tag) {
+__device__ __forceinline__ pg_rec pg_rec_load1(const pg_rec* p) {
+  const pg_u64* q = reinterpret_cast<const pg_u64*>(p);
+  const pg_u64 a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const pg_u64 b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  pg_rec v;
+  v.x = pg_u32(a);
+  v.y = pg_u32(a >> 32);
+  v.z = pg_u32(b);
+  v.w = pg_u32(b >> 32);
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[N]) {
+  for (int i = 0; i < N; ++i) v[i] = pg_rec_load1(p + i * stride);
+}
+#else
+__device__ __forceinline__ void pg_rec_store(pg_rec* p, pg_rec v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// N records at p, p + stride, ...: all loads in flight, one wait
+__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int, pg_rec (&v)[1]) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[2]) {
+  const pg_rec* p1 = p + stride;
+  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1])
+               : "v"(p), "v"(p1)
+               : "memory");
+}
+__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[3]) {
+  const pg_rec *p1 = p + stride, *p2 = p + 2 * stride;
+  asm volatile(
+      "global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+      : "v"(p), "v"(p1), "v"(p2)
+      : "memory");
+}
+__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[4]) {
+  const pg_rec *p1 = p + stride, *p2 = p + 2 * stride, *p3 = p + 3 * stride;
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+      "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+      : "v"(p), "v"(p1), "v"(p2), "v"(p3)
+      : "memory");
+}
+__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[9]) {
+  // (the double solver's vectors: nine records per camera, immediate offsets of 16 bytes - stride is 1)
+  asm volatile(
+      "global_load_dwordx4 %0, %9, off sc1\n\tglobal_load_dwordx4 %1, %9, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %9, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %9, off offset:48 sc1\n\t"
+      "global_load_dwordx4 %4, %9, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %9, off offset:80 sc1\n\t"
+      "global_load_dwordx4 %6, %9, off offset:96 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:112 sc1\n\t"
+      "global_load_dwordx4 %8, %9, off offset:128 sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8])
+      : "v"(p)
+      : "memory");
+}
+#endif
+
+// {double, tag, check}: check = tag ^ hi ^ lo, so a record torn into its halves does not pass
+__device__ __forceinline__ pg_rec pg_pack(double v, pg_u32 tag) {
   const pg_u64 bits = pg_u64(__double_as_longlong(v));
-  pg_st(g + 2 * i, (pg_u64(tag) << 32) | (bits >> 32));
-  pg_st(g + 2 * i + 1, (pg_u64(tag) << 32) | (bits & 0xffffffffull));
+  const pg_u32 lo = pg_u32(bits), hi = pg_u32(bits >> 32);
+  pg_rec r;
+  r.x = lo;
+  r.y = hi;
+  r.z = tag;
+  r.w = tag ^ hi ^ lo;
+  return r;
 }
-__device__ __forceinline__ void pg_load(const pg_u64* g, size_t i, pg_u32 tag, bool& ok, float& v) {
-  const pg_u64 x = pg_ld(g + i);
-  ok &= pg_u32(x >> 32) == tag;
-  v = __uint_as_float(pg_u32(x));
+__device__ __forceinline__ bool pg_unpack(pg_rec r, pg_u32 tag, double& v) {
+  v = __longlong_as_double((long long)((pg_u64(r.y) << 32) | pg_u64(r.x)));
+  return r.z == tag && r.w == (tag ^ r.y ^ r.x);
 }
-__device__ __forceinline__ void pg_load(const pg_u64* g, size_t i, pg_u32 tag, bool& ok, double& v) {
-  const pg_u64 h = pg_ld(g + 2 * i), l = pg_ld(g + 2 * i + 1);
-  ok &= pg_u32(h >> 32) == tag && pg_u32(l >> 32) == tag;
-  v = __longlong_as_double((long long)((h << 32) | (l & 0xffffffffull)));
+// {f0, f1, f2, tag ^ f0 ^ f1 ^ f2}: old and new halves mixed pass only if the mixed-in words did not change (or by a
+// 2^-32 coincidence)
+__device__ __forceinline__ pg_rec pg_pack3(float a, float b, float c, pg_u32 tag) {
+  pg_rec r;
+  r.x = __float_as_uint(a);
+  r.y = __float_as_uint(b);
+  r.z = __float_as_uint(c);
+  r.w = tag ^ r.x ^ r.y ^ r.z;
+  return r;
 }
-template <class S>
-constexpr int pg_words() {
-  return int(sizeof(S) / 4);
+__device__ __forceinline__ bool pg_unpack3(pg_rec r, pg_u32 tag, float& a, float& b, float& c) {
+  a = __uint_as_float(r.x);
+  b = __uint_as_float(r.y);
+  c = __uint_as_float(r.z);
+  return (r.w ^ r.x ^ r.y ^ r.z) == tag;
+}
+// the nine entries of a camera <-> its records
+__device__ __forceinline__ bool pg_unpack_vec(const pg_rec (&r)[3], pg_u32 tag, float (&v)[9]) {
+  bool ok = pg_unpack3(r[0], tag, v[0], v[1], v[2]);
+  ok &= pg_unpack3(r[1], tag, v[3], v[4], v[5]);
+  ok &= pg_unpack3(r[2], tag, v[6], v[7], v[8]);
+  return ok;
+}
+__device__ __forceinline__ bool pg_unpack_vec(const pg_rec (&r)[9], pg_u32 tag, double (&v)[9]) {
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 9; ++a) ok &= pg_unpack(r[a], tag, v[a]);
+  return ok;
 }
 
 template <class S>
 constexpr size_t pgp_lds_bytes() {
-  return size_t(2) * kPgThreads * 9 * sizeof(S)  // pst, opx
+  return size_t(3) * kPgThreads * 9 * sizeof(S)   // pst, zst, minv
+         + size_t(5) * kPgThreads * sizeof(S)     // xs, rs, bs, pcs, qss
+         + size_t(kPgThreads) * sizeof(double)    // pqd
          + size_t(kPgQuads) * 9 * sizeof(double)  // red
-         + size_t(kPgThreads) * sizeof(S)         // rl
-         + size_t(kPgThreads) * 9 * sizeof(S)     // minv
-         + 16 * sizeof(double)                    // smw
-         + 4 * sizeof(double)                     // bc
+         + 16 * sizeof(double)                    // bc, gs
+         + size_t(3) * kPgMaxRows * sizeof(int)   // rowtab
+         + 8 * sizeof(int)                        // endi
          + 16;                                    // flags
 }
 
@@ -121,18 +235,37 @@ __device__ __forceinline__ double pg_quad_sum(double v) {
   v += dpp_mov0<0x4e>(v);  // quad_perm:[2,3,0,1]
   return v;
 }
+__device__ __forceinline__ int pg_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// Roles inside a workgroup (three workgroup barriers per iteration: exchange 1 done / quad sums written / row sums written):
+//   every lane        one block of the matrix: forms the direction p_j = z_j + beta p_j of ITS column on the fly from the
+//                     staged z and the previous direction (LDS), multiplies, quad sums into LDS
+//   work-items 0 ..   "stagers": one staged column each - poll its z records into LDS, keep its direction p in LDS
+//   waves 4 - 7       gather the workgroups' partial sums of rho and Q (a workgroup per lane); everybody then takes the
+//                     decisions from the four wave sums
+//   four per output   the row sums of the product: output j = 9 row + a is summed by four work-items over the row's quads
+//                     (interleaved, then the quad's DPP sum), with p_c q_c for the dot product
+//   the last wave     "row wave": x, r, b, M^-1 of the workgroup's rows in LDS; p.q with its gather, the step, z = M^-1 r,
+//                     the workgroup's partial sums. One wavefront, two outputs per lane and pass: no workgroup barrier.
 template <class S>
 __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
+  constexpr int NR = pg_vec_records<S>();
   extern __shared__ __attribute__((aligned(16))) char smem_pg[];
-  S* pst = reinterpret_cast<S*>(smem_pg);                       // [512][9] direction p of the staged columns (kept across iterations)
-  S* opx = pst + kPgThreads * 9;                                // [512][9] operand of the refresh product (x)
-  double* red = reinterpret_cast<double*>(opx + kPgThreads * 9);  // [128][9] quad sums of the block products
-  S* rl = reinterpret_cast<S*>(red + kPgQuads * 9);             // [512]   residual of the row work-items (z = M^-1 r)
-  S* minv = rl + kPgThreads;                                    // [512][9] row `ra` of M^-1 of the row work-items
-  double* smw = reinterpret_cast<double*>(minv + kPgThreads * 9);  // [8][2] wave sums
-  double* bc = smw + 16;                                        // [4]     broadcast scalars
-  int* sflag = reinterpret_cast<int*>(bc + 4);                  // [0] abort
+  S* pst = reinterpret_cast<S*>(smem_pg);   // [512][9] direction p of the staged columns (kept across iterations)
+  S* zst = pst + kPgThreads * 9;            // [512][9] z of the staged columns; x during a refresh product
+  S* minv = zst + kPgThreads * 9;           // [512][9] row a of M^-1 of row output j = 9 row + a
+  S* xs = minv + kPgThreads * 9;            // [512]    x, r, b of the row outputs; p_c and q_c of the current iteration
+  S* rs = xs + kPgThreads;
+  S* bs = rs + kPgThreads;
+  S* pcs = bs + kPgThreads;                 //          (also: z of the row outputs on its way into the records)
+  S* qss = pcs + kPgThreads;
+  double* pqd = reinterpret_cast<double*>(qss + kPgThreads);  // [512] p_c q_c of the row outputs
+  double* red = pqd + kPgThreads;                             // [128][9] quad sums of the block products
+  double* bc = red + kPgQuads * 9;                            // [3] rho_prev [4] q_prev; at the end [0] beta [1] rho [2] q1 [5] p.q [6] alpha
+  double* gs = bc + 8;                                        // [4][2] sums of rho and Q partial sums of the four polling waves
+  int* rowtab = reinterpret_cast<int*>(gs + 8);               // [56][3] first quad, quads, staged index of the own column
+  int* endi = rowtab + 3 * kPgMaxRows;                        // end of the solve: [0] termination [1] result_iter [2] indefinite [3] stepped
+  int* sflag = endi + 8;                                      // [0] abort, [1] the row wave has ended the solve
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
   const PgWorkgroup W = P.wg[g];
@@ -142,13 +275,13 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   const int mycol = P.stage_col[size_t(g) * kPgThreads + tid];
   const bool stager = mycol >= 0;
   const bool wave_stages = wave * 64 < W.ncols;  // (the staged columns are work-items 0 .. ncols - 1)
-  const bool gatherer = wave == kPgThreads / 64 - 1;  // the last wavefront gathers the workgroups' partial sums
-  const bool rowt = tid < 9 * W.nrows;
-  const int rr = rowt ? tid / 9 : 0, ra = rowt ? tid - 9 * rr : 0;
-  const int c = W.row0 + rr;
+  const bool roww = wave == kPgThreads / 64 - 1;
+  const bool poller = wave >= 4;
+  const int nout = 9 * W.nrows;
+  const int G = P.G;
   CgState* st = P.st;
   if (st->done) return;  // (uniform over the grid: nobody writes the state before the end)
-  if (tid == 0) sflag[0] = 0;
+  if (tid < 2) sflag[tid] = 0;
 
   // ---- the lane's block: 81 doubles, for the whole solve -----------------------------------------------------------
   double blk[81];
@@ -165,90 +298,145 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   }
   // ---- state -----------------------------------------------------------------------------------------------------
   int it = st->iter, need_test = st->need_test;
-  double rho_prev = st->rho_hist[(it + 1) & 1], q_prev = st->q_hist[(it + 1) & 1];
+  if (tid == 0) {
+    bc[3] = st->rho_hist[(it + 1) & 1];
+    bc[4] = st->q_hist[(it + 1) & 1];
+  }
   const S lambda = S(st->lambda);
-  int q0 = 0, nq = 0, self = 0;
-  S x_i = S(0), r_i = S(0), b_i = S(0);
-  if (rowt) {
-    q0 = P.row_info[3 * c];
-    nq = P.row_info[3 * c + 1];
-    self = P.row_info[3 * c + 2];
-    x_i = P.x[9 * c + ra];
-    b_i = P.b[9 * c + ra];
-    if (!P.switch_operator) r_i = P.r_in[9 * c + ra];
+  if (roww) {
+    for (int j = lane; j < nout; j += 64) {
+      const int row = j / 9, a = j - 9 * row, c = W.row0 + row;
+      xs[j] = P.x[9 * c + a];
+      bs[j] = P.b[9 * c + a];
+      rs[j] = P.switch_operator ? S(0) : P.r_in[9 * c + a];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) minv[9 * tid + j] = P.inv[81 * c + 9 * ra + j];
+      for (int b2 = 0; b2 < 9; ++b2) minv[9 * j + b2] = P.inv[81 * c + 9 * a + b2];
+    }
+    for (int row = lane; row < W.nrows; row += 64) {
+      rowtab[3 * row] = P.row_info[3 * (W.row0 + row)];
+      rowtab[3 * row + 1] = P.row_info[3 * (W.row0 + row) + 1];
+      rowtab[3 * row + 2] = P.row_info[3 * (W.row0 + row) + 2];
+    }
   }
   if (stager) {
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
       pst[9 * tid + a] = it > 0 ? P.p_in[9 * mycol + a] : S(0);
-      if (P.switch_operator) opx[9 * tid + a] = P.x[9 * mycol + a];
+      zst[9 * tid + a] = P.switch_operator ? P.x[9 * mycol + a] : S(0);
     }
   }
 
-  // q_c[ra] = sum_j S_cj v_j for the row work-items, v = the staged operand (LDS); ends behind a workgroup barrier
-  auto product = [&](const S* opnd) -> double {
+  // the lane's share of q = S v: quad sums into `red` (the caller puts the barrier). DIRECTION: v_j = z_j + beta p_j (the
+  // first iteration: z_j) formed here from the staged vectors, the arithmetic of the stager's own update below bit for
+  // bit; otherwise v = the staged vector itself (x of a refresh product).
+  auto product = [&](bool direction, bool first, S bs2) {
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (act) {
       // (column by column: nine accumulators and ONE operand entry live beside the 162 registers of the block)
 #pragma unroll
       for (int bb = 0; bb < 9; ++bb) {
-        const double pv = double(opnd[9 * scol + bb]);
+        S v = zst[9 * scol + bb];
+        if (direction && !first) v = v + bs2 * pst[9 * scol + bb];
+        const double pv = double(v);
 #pragma unroll
         for (int a = 0; a < 9; ++a) acc[a] += blk[9 * a + bb] * pv;
       }
     }
 #pragma unroll
     for (int a = 0; a < 9; ++a) acc[a] = pg_quad_sum(acc[a]);
-    if ((lane & 3) == 0) {
+    // every lane of the quad holds the sums: lane q writes entries q, q + 4, q + 8
+    double* dst = red + 9 * (tid >> 2);
+    const int ql = lane & 3;
+    dst[ql] = ql == 0 ? acc[0] : ql == 1 ? acc[1] : ql == 2 ? acc[2] : acc[3];
+    dst[ql + 4] = ql == 0 ? acc[4] : ql == 1 ? acc[5] : ql == 2 ? acc[6] : acc[7];
+    if (ql == 0) dst[8] = acc[8];
+  };
+  // the row sums of a product, by ALL work-items: four per output over the row's quads (interleaved), the quad's DPP sum
+  // closes them (fixed order). DIRECTION: q_c = sum + lambda p_c with p_c as the product formed it, and p_c q_c for the
+  // dot product; otherwise (refresh) q_c = sum + lambda x_c. The caller puts the barrier.
+  auto rowsums = [&](bool direction, bool first, S bs2) {
+    const int part = tid & 3;
+    for (int cb = 0; cb < nout; cb += kPgThreads / 4) {
+      const int j = cb + (tid >> 2);
+      const bool on = j < nout;
+      const int jj = on ? j : 0;
+      const int row = jj / 9, a = jj - 9 * row;
+      const int q0 = rowtab[3 * row], nq = rowtab[3 * row + 1], self = rowtab[3 * row + 2];
+      double q = 0.0;
+      for (int k0 = part; k0 < nq; k0 += 16) {
+        double v[4];
 #pragma unroll
-      for (int a = 0; a < 9; ++a) red[9 * (tid >> 2) + a] = acc[a];
+        for (int u = 0; u < 4; ++u) v[u] = red[9 * (q0 + min(k0 + 4 * u, nq - 1)) + a] * (k0 + 4 * u < nq ? 1.0 : 0.0);
+        q += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      q = pg_quad_sum(q);
+      if (on && part == 0) {
+        if (direction) {
+          S pc = zst[9 * self + a];
+          if (!first) pc = pc + bs2 * pst[9 * self + a];
+          S qs = S(q);
+          qs += lambda * pc;  // pose damping term of right_multiply
+          pcs[j] = pc;
+          qss[j] = qs;
+          pqd[j] = double(pc) * double(qs);
+        } else {
+          S qs = S(q);
+          qs += lambda * xs[j];
+          qss[j] = qs;
+        }
+      }
     }
-    __syncthreads();
-    double q = 0.0;
-    if (rowt)
-      for (int k = 0; k < nq; ++k) q += red[9 * (q0 + k) + ra];
-    return q;
   };
-  // sums over the workgroup of two per-work-item values; valid in work-item 0 (behind a workgroup barrier)
-  auto wg_sum2 = [&](double v0, double v1, double& s0, double& s1) {
-    const double t0 = wave_sum(v0), t1 = wave_sum(v1);
-    if (lane == 0) {
-      smw[2 * wave] = t0;
-      smw[2 * wave + 1] = t1;
+  // row wave: the entries of a vector of the workgroup's rows (LDS, [9 nrows]) as records, published with `tagn`
+  auto publish_vec = [&](pg_rec* dst, const S* v, pg_u32 tagn) {
+    wave_lds_fence();  // (v of the other lanes)
+    for (int t = lane; t < NR * W.nrows; t += 64) {
+      const int row = t / NR, k = t - NR * row;
+      pg_rec r;
+      if constexpr (NR == 3)
+        r = pg_pack3(float(v[9 * row + 3 * k]), float(v[9 * row + 3 * k + 1]), float(v[9 * row + 3 * k + 2]), tagn);
+      else
+        r = pg_pack(double(v[9 * row + k]), tagn);
+      pg_rec_store(dst + size_t(NR) * size_t(W.row0 + row) + k, r);
     }
-    __syncthreads();
-    s0 = ((smw[0] + smw[2]) + (smw[4] + smw[6])) + ((smw[8] + smw[10]) + (smw[12] + smw[14]));
-    s1 = ((smw[1] + smw[3]) + (smw[5] + smw[7])) + ((smw[9] + smw[11]) + (smw[13] + smw[15]));
   };
-  // z = M^-1 r, partial sums of rho = r.z and Q = -x.(b + r); published for the iteration with tag `tagn`
+  // row wave: z = M^-1 r, partial sums of rho = r.z and Q = -x.(b + r), published for the iteration with tag `tagn`
   auto close_residual = [&](pg_u32 tagn) {
-    rl[tid] = r_i;
-    __syncthreads();
+    wave_lds_fence();  // (rs of the other lanes)
     double acc_rho = 0.0, acc_q = 0.0;
-    if (rowt) {
-      const S* rc = rl + 9 * rr;
-      S zc = S(0);
+    for (int j0 = lane; j0 < nout; j0 += 128) {
 #pragma unroll
-      for (int j = 0; j < 9; ++j) zc += minv[9 * tid + j] * rc[j];
-      pg_store(P.zg, size_t(9) * c + ra, zc, tagn);
-      acc_rho = double(r_i) * double(zc);
-      acc_q = -double(x_i) * double(b_i + r_i);
+      for (int u = 0; u < 2; ++u) {  // (two outputs per pass: their LDS round trips overlap)
+        const int j = j0 + 64 * u;
+        if (j < nout) {
+          const int row = j / 9;
+          const S* rc = rs + 9 * row;
+          S zc = S(0);
+#pragma unroll
+          for (int b2 = 0; b2 < 9; ++b2) zc += minv[9 * j + b2] * rc[b2];
+          pcs[j] = zc;
+          const S r_i = rs[j], x_i = xs[j];
+          acc_rho += double(r_i) * double(zc);
+          acc_q -= double(x_i) * double(bs[j] + r_i);
+        }
+      }
     }
-    double s0, s1;
-    wg_sum2(acc_rho, acc_q, s0, s1);
-    if (tid == 0) {
-      pg_store(P.part_rq, size_t(2) * g, s0, tagn);
-      pg_store(P.part_rq, size_t(2) * g + 1, s1, tagn);
+    publish_vec(P.zg, pcs, tagn);
+    const double s0 = wave_sum(acc_rho), s1 = wave_sum(acc_q);
+    if (lane < 2 * kPgReplicas) {
+      const int rep = lane >> 1, k = lane & 1;
+      pg_rec_store(P.part_rq + (size_t(rep) * G + g) * 2 + k, pg_pack(k ? s1 : s0, tagn));
     }
   };
-  // what a wavefront does when its sweep did not find this exchange's tags: wait a little, give up after ~1 s
-  auto spin_failed = [&](pg_u32& spins) -> bool {
+  // what a wavefront does when its sweep did not find this exchange's tags: wait a little; 0 = sweep again, 1 = the row
+  // wave has ended the solve (nothing more will come), 2 = give up (after ~1 s, or somebody else did). Wave-uniform.
+  auto poll_again = [&](pg_u32& spins) -> int {
     __builtin_amdgcn_s_sleep(1);
     ++spins;
-    if ((spins & 1023u) == 0 && __hip_atomic_load(P.host_progress + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return true;
-    return spins > kPgSpinLimit;
+    int code = pg_flag(sflag + 1) != 0 ? 1 : 0;
+    if (pg_flag(sflag) != 0 || spins > kPgSpinLimit) code = 2;
+    if ((spins & 1023u) == 0 && __hip_atomic_load(P.host_progress + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) code = 2;
+    return __ballot(code == 2) != 0 ? 2 : __ballot(code == 1) != 0 ? 1 : 0;
   };
   auto raise_abort = [&]() {
     if (lane == 0) {
@@ -256,178 +444,235 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       __hip_atomic_store(sflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   };
-  // the solution and the final state (every workgroup takes the same decisions from the same sums). `stepped`: the
-  // iteration it + 1 was started (direction and product done) when the step length came out unusable.
-  auto finish = [&](int termination, int result_iter, int indefinite, bool stepped, double rho, double q1, double beta,
-                    double pq, double alpha) {
-    if (rowt) P.x[9 * c + ra] = x_i;
-    if (g == 0 && tid == 0) {
-      if (need_test) st->q_hist[it & 1] = q1;
-      if (stepped) {
-        st->rho_hist[it & 1] = rho;
-        st->beta = beta;
+  // stagers: the records of the staged column from `src` into zst (wave-uniform call)
+  auto stage_vector = [&](const pg_rec* srcv, pg_u32 tag) {
+    pg_u32 spins = 0;
+    S zv[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) zv[a] = S(0);
+    for (;;) {
+      bool ok = true;
+      if (stager) {
+        unsigned mc = unsigned(mycol);
+        PG_OPAQUE(mc);
+        pg_rec r[NR];
+        pg_rec_load(srcv + size_t(NR) * mc, 1, r);
+        ok = pg_unpack_vec(r, tag, zv);
+      }
+      if (__ballot(!ok) == 0) break;
+      const int pa = poll_again(spins);  // (1: the row wave ended the solve at the step length - nothing will come)
+      if (pa == 2) raise_abort();
+      if (pa) break;
+    }
+    if (stager) {
+#pragma unroll
+      for (int a = 0; a < 9; ++a) zst[9 * tid + a] = zv[a];
+    }
+  };
+  // the end of the solve: the final state is parked in LDS by whoever decides, written out by the row wave
+  int my_stop = 0;
+  auto finish = [&]() {  // row wave
+    for (int j = lane; j < nout; j += 64) {
+      const int row = j / 9, a = j - 9 * row;
+      P.x[9 * (W.row0 + row) + a] = xs[j];
+    }
+    if (g == 0 && lane == 0) {
+      if (need_test) st->q_hist[it & 1] = bc[2];
+      if (endi[3]) {  // iteration it + 1 was started (direction and product done) when the step came out unusable
+        st->rho_hist[it & 1] = bc[1];
+        st->beta = bc[0];
         st->cur = it + 1;
-        st->pq = pq;
-        st->alpha = alpha;
+        st->pq = bc[5];
+        st->alpha = bc[6];
       }
       st->iter = it;
       st->need_test = need_test;
-      st->termination = termination;
-      st->indefinite = indefinite;
-      st->result_iter = result_iter;
+      st->termination = endi[0];
+      st->indefinite = endi[2];
+      st->result_iter = endi[1];
       st->done = 1;
       __hip_atomic_store(P.host_progress + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   };
+  const int it_first = it;
+  auto stamp = [&](int k) {
+    if (P.trace && tid == kPgThreads - 64 && it - it_first < kPgTraceIts)
+      P.trace[(size_t(g) * kPgTraceIts + size_t(it - it_first)) * 8 + k] =
+          wall_clock64();  // (s_memrealtime: 100 MHz, ONE counter for the chip - stamps of different workgroups compare)
+  };
 
-  __syncthreads();  // pst / opx / sflag
+  __syncthreads();  // staged vectors / row state / flags
   if (P.switch_operator) {
     // operator switch inside a running solve: the residual is recomputed with the operator used from here on,
     // r = b - (S + lambda I) x, exactly like the periodic refresh (Solver::pcg_fused)
-    const double q = product(opx);
-    if (rowt) {
-      S qs = S(q);
-      qs += lambda * x_i;
-      r_i = b_i - qs;
-    }
+    product(false, false, S(0));
+    __syncthreads();
+    rowsums(false, false, S(0));
+    __syncthreads();
+    if (roww)
+      for (int j = lane; j < nout; j += 64) rs[j] = bs[j] - qss[j];
   }
-  close_residual(P.tag_base + pg_u32(it + 1));
+  if (roww) close_residual(P.tag_base + pg_u32(it + 1));
 
   for (;;) {
     const int cur = it + 1;
     const pg_u32 tag = P.tag_base + pg_u32(cur);
-    // ---- exchange 1: z of the staged columns, partial sums of rho and Q ---------------------------------------------
-    S zv[9];
-#pragma unroll
-    for (int a = 0; a < 9; ++a) zv[a] = S(0);
-    if (wave_stages || gatherer) {
-      pg_u32 spins = 0;
-      double a_rho = 0.0, a_q = 0.0;
-      for (;;) {
-        bool ok = true;
-        if (stager) {
-#pragma unroll
-          for (int a = 0; a < 9; ++a) pg_load(P.zg, size_t(9) * mycol + a, tag, ok, zv[a]);
+    const bool refresh = (cur % P.period) == 0, first = it == 0;
+    stamp(0);
+    // ---- exchange 1: z of the staged columns (stagers); partial sums of rho and Q (waves 4 - 7, a workgroup per lane) ---
+    if (!my_stop) {
+      if (poller) {
+        pg_u32 spins = 0;
+        unsigned gg = unsigned(64 * (wave - 4) + lane);
+        PG_OPAQUE(gg);
+        const bool on = int(gg) < G;
+        double v0 = 0.0, v1 = 0.0;
+        for (;;) {
+          pg_rec r[2];
+          pg_rec_load(P.part_rq + (size_t(g % kPgReplicas) * G + (on ? gg : 0u)) * 2, 1, r);
+          bool ok = pg_unpack(r[0], tag, v0);
+          ok &= pg_unpack(r[1], tag, v1);
+          if (__ballot(on && !ok) == 0) break;
+          const int pa = poll_again(spins);
+          if (pa == 2) raise_abort();
+          if (pa) break;
         }
-        if (gatherer) {
-          a_rho = 0.0;
-          a_q = 0.0;
-#pragma unroll
-          for (int k = 0; k < kPgMaxGroups / 64; ++k) {
-            const int gg = lane + 64 * k;
-            if (gg < P.G) {
-              double v0, v1;
-              pg_load(P.part_rq, size_t(2) * gg, tag, ok, v0);
-              pg_load(P.part_rq, size_t(2) * gg + 1, tag, ok, v1);
-              a_rho += v0;
-              a_q += v1;
-            }
-          }
-        }
-        if (__ballot(!ok) == 0) break;
-        if (spin_failed(spins)) {
-          raise_abort();
-          break;
-        }
-      }
-      if (gatherer) {
-        const double t0 = wave_sum(a_rho), t1 = wave_sum(a_q);
+        const double t0 = wave_sum(on ? v0 : 0.0), t1 = wave_sum(on ? v1 : 0.0);
         if (lane == 0) {
-          bc[0] = t0;
-          bc[1] = t1;
+          gs[2 * (wave - 4)] = t0;
+          gs[2 * (wave - 4) + 1] = t1;
         }
       }
+      if (wave_stages) stage_vector(P.zg, tag);
     }
-    __syncthreads();
-    if (sflag[0]) return;
-    const double rho = bc[0], q1 = bc[1];
-    // ---- decisions (k_pcgs_spmv<0> prologue): test of the previous iteration, rho, beta ------------------------------
-    int own_stop = 0, term = 0, res_it = it;
-    double beta = 0.0;
-    if (need_test) {
-      // Q-model test (conjugate_gradient.hpp:239-276); residual-based test is off (r_tolerance = -1)
-      const double zeta = it * (q1 - q_prev) / q1;
-      if (zeta < P.q_tolerance && it >= P.min_it) {
-        own_stop = 1;
-        term = 1;
-      } else if (it >= P.max_it) {
-        own_stop = 1;
-        term = 0;
-      }
-    }
-    if (!own_stop) {
-      if (rho == 0.0 || isinf(rho) || rho != rho) {
-        own_stop = 1;
-        term = 2;  // "Numerical failure. rho / beta"
-        res_it = it + 1;
-      } else if (it > 0) {
-        beta = rho / rho_prev;
-        if (beta == 0.0 || isinf(beta)) {
-          own_stop = 1;
-          term = 2;
-          res_it = it + 1;
-        }
-      }
-    }
-    if (own_stop) {
-      finish(term, res_it, 0, false, rho, q1, 0.0, 0.0, 0.0);
+    stamp(1);
+    __syncthreads();  // #1: z is staged, the sums are gathered
+    if (pg_flag(sflag) != 0) return;
+    if (pg_flag(sflag + 1) != 0) {
+      if (roww) finish();
       return;
     }
-    if (need_test) q_prev = q1;
-    // ---- direction p = z + beta p of the staged columns, product, p.q -------------------------------------------------
-    if (stager) {
-      const S bs = S(beta);
-#pragma unroll
-      for (int a = 0; a < 9; ++a) {
-        const S po = pst[9 * tid + a];
-        pst[9 * tid + a] = it == 0 ? zv[a] : zv[a] + bs * po;
+    // ---- decisions (k_pcgs_spmv<0> prologue), by everybody alike: test of the previous iteration, rho, beta --------------
+    const double rho = (gs[0] + gs[2]) + (gs[4] + gs[6]), q1 = (gs[1] + gs[3]) + (gs[5] + gs[7]);
+    double beta = 0.0;
+    {
+      const double rho_prev = bc[3], q_prev = bc[4];
+      int own_stop = 0, term = 0, res_it = it;
+      if (need_test) {
+        // Q-model test (conjugate_gradient.hpp:239-276); residual-based test is off (r_tolerance = -1)
+        const double zeta = it * (q1 - q_prev) / q1;
+        if (zeta < P.q_tolerance && it >= P.min_it) {
+          own_stop = 1;
+          term = 1;
+        } else if (it >= P.max_it) {
+          own_stop = 1;
+          term = 0;
+        }
+      }
+      if (!own_stop) {
+        if (rho == 0.0 || isinf(rho) || rho != rho) {
+          own_stop = 1;
+          term = 2;  // "Numerical failure. rho / beta"
+          res_it = it + 1;
+        } else if (it > 0) {
+          beta = rho / rho_prev;
+          if (beta == 0.0 || isinf(beta)) {
+            own_stop = 1;
+            term = 2;
+            res_it = it + 1;
+          }
+        }
+      }
+      if (own_stop) {
+        if (roww) {
+          if (lane == 0) {
+            bc[2] = q1;
+            endi[0] = term;
+            endi[1] = res_it;
+            endi[2] = 0;
+            endi[3] = 0;
+          }
+          finish();
+        }
+        return;
       }
     }
-    __syncthreads();
-    const double qd = product(pst);
-    S pc = S(0), qs = S(0);
-    double my_pq = 0.0;
-    if (rowt) {
-      pc = pst[9 * self + ra];
-      qs = S(qd);
-      qs += lambda * pc;  // pose damping term of right_multiply
-      my_pq = double(pc) * double(qs);
+    const S bs2 = S(beta);
+    stamp(2);
+    product(true, first, bs2);
+    __syncthreads();  // #2: the quad sums are written
+    stamp(3);
+    if (tid == 0) {  // (everybody has read them before barrier #2)
+      bc[3] = rho;
+      if (need_test) bc[4] = q1;
     }
-    {
-      double s0, s1;
-      wg_sum2(my_pq, 0.0, s0, s1);
-      if (tid == 0) pg_store(P.part_pq, size_t(g), s0, tag);
+    rowsums(true, first, bs2);
+    __syncthreads();  // #3: the row sums are written
+    // ---- the stagers keep the direction of their column: p = z + beta p, in place (nobody reads it before the next product)
+    if (stager && !first) {
+#pragma unroll
+      for (int a = 0; a < 9; ++a) pst[9 * tid + a] = zst[9 * tid + a] + bs2 * pst[9 * tid + a];
+    } else if (stager) {
+#pragma unroll
+      for (int a = 0; a < 9; ++a) pst[9 * tid + a] = zst[9 * tid + a];
     }
-    // ---- exchange 2: partial sums of p.q -------------------------------------------------------------------------------
-    if (gatherer) {
+    if (roww) {
+      // ---- p.q ------------------------------------------------------------------------------------------------------------
+      double my_pq = 0.0;
+      for (int j0 = lane; j0 < nout; j0 += 128) {
+        const int j1 = j0 + 64;
+        const double v0 = pqd[j0], v1 = pqd[min(j1, nout - 1)];
+        my_pq += v0;
+        my_pq += j1 < nout ? v1 : 0.0;
+      }
+      const double s0 = wave_sum(my_pq);
+      if (lane < kPgReplicas) pg_rec_store(P.part_pq + size_t(lane) * G + g, pg_pack(s0, tag));
+      stamp(4);
+      // ---- exchange 2: partial sums of p.q (four workgroups per lane) ---------------------------------------------------
       pg_u32 spins = 0;
       double a_pq = 0.0;
       for (;;) {
+        unsigned l0 = unsigned(lane);
+        PG_OPAQUE(l0);
+        const pg_rec* base = P.part_pq + size_t(g % kPgReplicas) * G;
+        pg_rec r[4];
+        // (clamped, masked below: lanes beyond G re-read the last record)
+        const int last = G - 1;
+        const int i0 = min(int(l0), last), i1 = min(int(l0) + 64, last), i2 = min(int(l0) + 128, last), i3 = min(int(l0) + 192, last);
+#ifdef HIPEMU
+        r[0] = pg_rec_load1(base + i0);
+        r[1] = pg_rec_load1(base + i1);
+        r[2] = pg_rec_load1(base + i2);
+        r[3] = pg_rec_load1(base + i3);
+#else
+        {
+          const pg_rec *p0 = base + i0, *p1 = base + i1, *p2 = base + i2, *p3 = base + i3;
+          asm volatile(
+              "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off "
+              "sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+              : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+              : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+              : "memory");
+        }
+#endif
         bool ok = true;
-        a_pq = 0.0;
+        double v[4];
 #pragma unroll
-        for (int k = 0; k < kPgMaxGroups / 64; ++k) {
-          const int gg = lane + 64 * k;
-          if (gg < P.G) {
-            double v0;
-            pg_load(P.part_pq, size_t(gg), tag, ok, v0);
-            a_pq += v0;
-          }
+        for (int k = 0; k < 4; ++k) {
+          const bool on = int(l0) + 64 * k < G;
+          const bool good = pg_unpack(r[k], tag, v[k]);
+          ok &= good || !on;
+          if (!on) v[k] = 0.0;
         }
+        a_pq = ((v[0] + v[1]) + (v[2] + v[3]));
         if (__ballot(!ok) == 0) break;
-        if (spin_failed(spins)) {
-          raise_abort();
-          break;
-        }
+        const int pa = poll_again(spins);
+        if (pa == 2) raise_abort();
+        if (pa) break;
       }
-      const double t0 = wave_sum(a_pq);
-      if (lane == 0) bc[2] = t0;
-    }
-    __syncthreads();
-    if (sflag[0]) return;
-    const double pq = bc[2];
-    // ---- step (k_pcgs_update) ------------------------------------------------------------------------------------------
-    {
+      const double pq = wave_sum(a_pq);
+      stamp(5);
+      // ---- step (k_pcgs_update) ----------------------------------------------------------------------------------------------
       int stop2 = 0, term2 = 0;
       double alpha = 0.0;
       if (pq != pq) {
@@ -443,55 +688,49 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
         }
       }
       if (stop2) {
-        // (the state of an iteration that was started: iter = it, cur = it + 1)
-        finish(term2, cur, term2 == 0 ? 1 : 0, true, rho, q1, beta, pq, alpha);
+        my_stop = 1;
+        if (lane == 0) {
+          bc[0] = beta;
+          bc[1] = rho;
+          bc[2] = q1;
+          bc[5] = pq;
+          bc[6] = alpha;
+          endi[0] = term2;
+          endi[1] = cur;
+          endi[2] = term2 == 0 ? 1 : 0;
+          endi[3] = 1;
+          __hip_atomic_store(sflag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        const S a_s = S(alpha);
+        for (int j = lane; j < nout; j += 64) {
+          xs[j] += a_s * pcs[j];
+          if (!refresh) rs[j] -= a_s * qss[j];
+        }
+        // residual refresh r = b - H x (conjugate_gradient.hpp:230-235): x travels like z
+        if (refresh) publish_vec(P.xg, xs, tag);
+      }
+      stamp(6);
+    }
+    if (refresh) {
+      if (wave_stages) stage_vector(P.xg, tag);
+      __syncthreads();  // #4: x is staged
+      if (pg_flag(sflag) != 0) return;
+      if (pg_flag(sflag + 1) != 0) {
+        if (roww) finish();
         return;
       }
-      const S a = S(alpha);
-      const bool refresh = (cur % P.period) == 0;
-      if (rowt) {
-        x_i += a * pc;
-        if (!refresh) r_i -= a * qs;
-      }
-      if (refresh) {
-        // residual refresh r = b - H x (conjugate_gradient.hpp:230-235): x travels like z
-        if (rowt) pg_store(P.xg, size_t(9) * c + ra, x_i, tag);
-        if (wave_stages) {
-          pg_u32 spins = 0;
-          S xv[9];
-#pragma unroll
-          for (int a2 = 0; a2 < 9; ++a2) xv[a2] = S(0);
-          for (;;) {
-            bool ok = true;
-            if (stager) {
-#pragma unroll
-              for (int a2 = 0; a2 < 9; ++a2) pg_load(P.xg, size_t(9) * mycol + a2, tag, ok, xv[a2]);
-            }
-            if (__ballot(!ok) == 0) break;
-            if (spin_failed(spins)) {
-              raise_abort();
-              break;
-            }
-          }
-          if (stager) {
-#pragma unroll
-            for (int a2 = 0; a2 < 9; ++a2) opx[9 * tid + a2] = xv[a2];
-          }
-        }
-        __syncthreads();
-        if (sflag[0]) return;
-        const double q2 = product(opx);
-        if (rowt) {
-          S q2s = S(q2);
-          q2s += lambda * x_i;
-          r_i = b_i - q2s;
-        }
-      }
+      product(false, false, S(0));
+      __syncthreads();  // #5
+      rowsums(false, false, S(0));
+      __syncthreads();  // #6
+      if (roww)
+        for (int j = lane; j < nout; j += 64) rs[j] = bs[j] - qss[j];
     }
-    rho_prev = rho;
+    if (roww && !my_stop) close_residual(tag + 1);
+    stamp(7);
     it = cur;
     need_test = 1;
-    close_residual(tag + 1);
   }
 }
 

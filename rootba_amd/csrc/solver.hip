@@ -1032,10 +1032,10 @@ class Solver final : public rba_solver {
     d_pg_lane_col_.upload(lane_col.data(), lane_col.size(), stream_);
     d_pg_stage_col_.upload(stage_col.data(), stage_col.size(), stream_);
     d_pg_row_info_.upload(row_info.data(), row_info.size(), stream_);
-    constexpr int W = rba::pg_words<S>();
-    d_pg_zg_.alloc(size_t(nvec_) * W);
-    d_pg_xg_.alloc(size_t(nvec_) * W);
-    d_pg_part_.alloc(size_t(6) * G);
+    constexpr int NR = rba::pg_vec_records<S>();
+    d_pg_zg_.alloc(size_t(NR) * n_cams_);
+    d_pg_xg_.alloc(size_t(NR) * n_cams_);
+    d_pg_part_.alloc(size_t(3) * rba::kPgReplicas * G);
     d_pg_zg_.zero(stream_);
     d_pg_xg_.zero(stream_);
     d_pg_part_.zero(stream_);
@@ -2227,7 +2227,7 @@ class Solver final : public rba_solver {
     P.zg = d_pg_zg_.get();
     P.xg = d_pg_xg_.get();
     P.part_rq = d_pg_part_.get();
-    P.part_pq = d_pg_part_.get() + size_t(4) * pg_G_;
+    P.part_pq = d_pg_part_.get() + size_t(2) * rba::kPgReplicas * pg_G_;
     P.st = d_cg_.get();
     P.host_progress = h_progress_;
     const unsigned span = unsigned(opt_.max_cg_it) + 4;  // tags of a solve: tag_base + iteration
@@ -2240,6 +2240,7 @@ class Solver final : public rba_solver {
     P.tag_base = pg_epoch_;
     pg_epoch_ += span;
     P.G = pg_G_;
+    P.n_cams = n_cams_;
     P.switch_operator = it_start > 1 ? 1 : 0;
     P.q_tolerance = opt_.eta;
     P.min_it = opt_.min_cg_it;
@@ -2248,8 +2249,30 @@ class Solver final : public rba_solver {
     volatile int* hp = h_progress_;
     hp[1] = 0;
     hp[4] = 0;
+    const char* trace_path = std::getenv("RBA_PCGP_TRACE");  // debug: phase stamps of the first iterations -> text file
+    DevBuf<long long> d_trace;
+    if (trace_path) {
+      d_trace.alloc(size_t(pg_G_) * rba::kPgTraceIts * 8);
+      d_trace.zero(stream_);
+      P.trace = d_trace.get();
+    }
     hipLaunchKernelGGL((rba::k_pcgp<S>), dim3(pg_G_), dim3(rba::kPgThreads), rba::pgp_lds_bytes<S>(), stream_, P);
     HIP_CHECK(hipGetLastError());
+    if (trace_path) {
+      std::vector<long long> h(size_t(pg_G_) * rba::kPgTraceIts * 8);
+      d_trace.download(h.data(), h.size(), stream_);
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      if (FILE* f = std::fopen(trace_path, "a")) {
+        std::fprintf(f, "solve G %d it_start %d\n", pg_G_, it_start);
+        for (int g = 0; g < pg_G_; ++g)
+          for (int i = 0; i < rba::kPgTraceIts; ++i) {
+            const long long* t = &h[(size_t(g) * rba::kPgTraceIts + i) * 8];
+            if (t[0] == 0) break;
+            std::fprintf(f, "%d %d %lld %lld %lld %lld %lld %lld %lld %lld\n", g, i, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+          }
+        std::fclose(f);
+      }
+    }
   }
 
   // ---- solve = stage 2 + preconditioner + PCG ------------------------------------
@@ -3358,7 +3381,7 @@ class Solver final : public rba_solver {
   DevBuf<rba::PgWorkgroup> d_pg_wg_;
   DevBuf<int> d_pg_lane_src_, d_pg_stage_col_, d_pg_row_info_;
   DevBuf<unsigned short> d_pg_lane_col_;
-  DevBuf<unsigned long long> d_pg_zg_, d_pg_xg_, d_pg_part_;
+  DevBuf<rba::pg_rec> d_pg_zg_, d_pg_xg_, d_pg_part_;  // 16-byte records of the exchanged vectors and partial sums
   // explicit Schur-complement backend (solver_type = 1)
   bool sc_ = false;
   int sc_nnz_ = 0;

@@ -331,6 +331,8 @@ static inline int hipemu_readfirstlane(int v) {
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) hipemu::spin_yield()
+static inline long long clock64() { return (long long)__builtin_ia32_rdtsc(); }
+static inline long long wall_clock64() { return (long long)__builtin_ia32_rdtsc(); }
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)

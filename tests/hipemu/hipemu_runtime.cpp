@@ -17,6 +17,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include <dlfcn.h>
 #include <sched.h>
 
 #include "hip/hip_runtime.h"
@@ -64,6 +65,7 @@ struct Fiber {
   Wait wait = RUN;
   Self self;
   Wave* wave = nullptr;
+  void* site = nullptr;          // return address of the last barrier call (deadlock report)
   void* asan_fake = nullptr;     // AddressSanitizer builds (HIPEMU_SANITIZE=address): the fiber's fake-stack handle
   const void* stack_lo = nullptr;
 };
@@ -131,6 +133,7 @@ static void release_block(Block& b) {
 
 void wave_barrier() {
   Fiber* f = g_cur;
+  f->site = __builtin_return_address(0);
   Wave* w = f->wave;
   if (w->alive <= 1) return;
   if (++w->arrived == w->alive) {
@@ -150,6 +153,7 @@ void spin_yield() {
 }
 void block_barrier() {
   Fiber* f = g_cur;
+  f->site = __builtin_return_address(0);
   Block& b = *g_block;
   if (b.alive <= 1) return;
   if (++b.arrived == b.alive) {
@@ -244,6 +248,32 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
                    "hipemu: deadlock in block (%u,%u,%u): %d work-items alive, %d wait at a wave-level operation, %d at "
                    "__syncthreads (divergent synchronisation?)\n",
                    bid.x, bid.y, bid.z, b.alive, ww, wb);
+      if (ww <= 64) {
+        std::fprintf(stderr, "hipemu: work-items waiting at the wave-level operation:");
+        for (size_t t = 0; t < n; ++t)
+          if (b.fibers[t].wait == WAIT_WAVE) std::fprintf(stderr, " %zu", t);
+        std::fprintf(stderr, "\n");
+      }
+      {
+        // where they wait: return addresses into the library (addr2line -e <lib> <address - load base>)
+        std::vector<std::pair<void*, int>> sites;
+        for (auto& f : b.fibers) {
+          if (f.wait != WAIT_WAVE && f.wait != WAIT_BLOCK) continue;
+          bool found = false;
+          for (auto& s : sites)
+            if (s.first == f.site) {
+              ++s.second;
+              found = true;
+            }
+          if (!found) sites.push_back({f.site, 1});
+        }
+        Dl_info info;
+        for (auto& s : sites) {
+          const bool ok = dladdr(s.first, &info) != 0;
+          std::fprintf(stderr, "hipemu:   %d work-items behind the call at %p (%s + 0x%zx)\n", s.second, s.first,
+                       ok ? info.dli_fname : "?", ok ? size_t(static_cast<char*>(s.first) - static_cast<char*>(info.dli_fbase)) : size_t(0));
+        }
+      }
       std::abort();
     }
   }
