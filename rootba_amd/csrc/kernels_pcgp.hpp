@@ -221,13 +221,16 @@ template <class S>
 constexpr size_t pgp_lds_bytes() {
   return size_t(3) * kPgThreads * 9 * sizeof(S)   // pst, zst, minv
          + size_t(5) * kPgThreads * sizeof(S)     // xs, rs, bs, pcs, qss
-         + size_t(kPgThreads) * sizeof(double)    // pqd
          + size_t(kPgQuads) * 9 * sizeof(double)  // red
-         + 16 * sizeof(double)                    // bc, gs
+         + 24 * sizeof(double)                    // bc, gs, wpq
          + size_t(3) * kPgMaxRows * sizeof(int)   // rowtab
          + 8 * sizeof(int)                        // endi
          + 16;                                    // flags
 }
+
+// p = z + beta p_old as ONE fused multiply-add - the block lanes, the row sums and the stagers all form it, bit for bit
+__device__ __forceinline__ float pg_dir(float z, float b, float p) { return __builtin_fmaf(b, p, z); }
+__device__ __forceinline__ double pg_dir(double z, double b, double p) { return __builtin_fma(b, p, z); }
 
 // sum over the four lanes of a quad, every lane receives it (fixed order: (l0 + l1) + (l2 + l3) up to commutation)
 __device__ __forceinline__ double pg_quad_sum(double v) {
@@ -259,11 +262,11 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   S* bs = rs + kPgThreads;
   S* pcs = bs + kPgThreads;                 //          (also: z of the row outputs on its way into the records)
   S* qss = pcs + kPgThreads;
-  double* pqd = reinterpret_cast<double*>(qss + kPgThreads);  // [512] p_c q_c of the row outputs
-  double* red = pqd + kPgThreads;                             // [128][9] quad sums of the block products
+  double* red = reinterpret_cast<double*>(qss + kPgThreads);  // [128][9] quad sums of the block products
   double* bc = red + kPgQuads * 9;                            // [3] rho_prev [4] q_prev; at the end [0] beta [1] rho [2] q1 [5] p.q [6] alpha
   double* gs = bc + 8;                                        // [4][2] sums of rho and Q partial sums of the four polling waves
-  int* rowtab = reinterpret_cast<int*>(gs + 8);               // [56][3] first quad, quads, staged index of the own column
+  double* wpq = gs + 8;                                       // [8] p.q of the row outputs summed by the waves that formed them
+  int* rowtab = reinterpret_cast<int*>(wpq + 8);              // [56][3] first quad, quads, staged index of the own column
   int* endi = rowtab + 3 * kPgMaxRows;                        // end of the solve: [0] termination [1] result_iter [2] indefinite [3] stepped
   int* sflag = endi + 8;                                      // [0] abort, [1] the row wave has ended the solve
 
@@ -326,20 +329,30 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
     }
   }
 
-  // the lane's share of q = S v: quad sums into `red` (the caller puts the barrier). DIRECTION: v_j = z_j + beta p_j (the
-  // first iteration: z_j) formed here from the staged vectors, the arithmetic of the stager's own update below bit for
-  // bit; otherwise v = the staged vector itself (x of a refresh product).
-  auto product = [&](bool direction, bool first, S bs2) {
+  int rcon = 0;
+  // the lane's share of q = S v: quad sums into `red` (the caller puts the barrier). v_j = z_j + bsel p_j formed here from the
+  // staged vectors: bsel = beta for a direction product (0 in the first iteration, whose staged p is 0), 0 for the
+  // refresh product of x. No branch on that: a conditional around an LDS read is a round trip of its own - nine of them
+  // in a first version (0.96 us for a product whose arithmetic takes 0.3).
+  auto product = [&](S bsel) {
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (act) {
-      // (column by column: nine accumulators and ONE operand entry live beside the 162 registers of the block)
+      // (three columns at a time: six LDS reads in flight, nine accumulators and three operand entries live beside the
+      //  162 registers of the block)
 #pragma unroll
-      for (int bb = 0; bb < 9; ++bb) {
-        S v = zst[9 * scol + bb];
-        if (direction && !first) v = v + bs2 * pst[9 * scol + bb];
-        const double pv = double(v);
+      for (int b0 = 0; b0 < 9; b0 += 3) {
+        S zz[3], pp[3];
 #pragma unroll
-        for (int a = 0; a < 9; ++a) acc[a] += blk[9 * a + bb] * pv;
+        for (int u = 0; u < 3; ++u) {
+          zz[u] = zst[9 * scol + b0 + u];
+          pp[u] = pst[9 * scol + b0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const double pv = double(pg_dir(zz[u], bsel, pp[u]));
+#pragma unroll
+          for (int a = 0; a < 9; ++a) acc[a] += blk[9 * a + b0 + u] * pv;
+        }
       }
     }
 #pragma unroll
@@ -353,15 +366,30 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   };
   // the row sums of a product, by ALL work-items: four per output over the row's quads (interleaved), the quad's DPP sum
   // closes them (fixed order). DIRECTION: q_c = sum + lambda p_c with p_c as the product formed it, and p_c q_c for the
-  // dot product; otherwise (refresh) q_c = sum + lambda x_c. The caller puts the barrier.
-  auto rowsums = [&](bool direction, bool first, S bs2) {
+  // dot product, summed per wave (wpq); otherwise (refresh) q_c = sum + lambda x_c. The caller puts the barrier.
+  // (`rcon`: first quad | quads << 8 | staged own column << 16 | a << 28 of the work-item's output in the first chunk -
+  //  the table lookup would be an LDS round trip ahead of the sums)
+  auto rowsums = [&](bool direction, S bsel) {
     const int part = tid & 3;
+    double my_pq = 0.0;
     for (int cb = 0; cb < nout; cb += kPgThreads / 4) {
       const int j = cb + (tid >> 2);
       const bool on = j < nout;
       const int jj = on ? j : 0;
-      const int row = jj / 9, a = jj - 9 * row;
-      const int q0 = rowtab[3 * row], nq = rowtab[3 * row + 1], self = rowtab[3 * row + 2];
+      int a, q0, nq, self;
+      if (cb == 0) {
+        q0 = rcon & 0xff;
+        nq = (rcon >> 8) & 0xff;
+        self = (rcon >> 16) & 0xfff;
+        a = (rcon >> 28) & 0xf;
+      } else {
+        const int row = jj / 9;
+        a = jj - 9 * row;
+        q0 = rowtab[3 * row];
+        nq = rowtab[3 * row + 1];
+        self = rowtab[3 * row + 2];
+      }
+      const S zc = zst[9 * self + a], po = pst[9 * self + a], xc = xs[jj];  // (all loads ahead of the sums)
       double q = 0.0;
       for (int k0 = part; k0 < nq; k0 += 16) {
         double v[4];
@@ -371,20 +399,19 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       }
       q = pg_quad_sum(q);
       if (on && part == 0) {
+        const S pc = direction ? pg_dir(zc, bsel, po) : xc;
+        S qs = S(q);
+        qs += lambda * pc;  // pose damping term of right_multiply
+        qss[j] = qs;
         if (direction) {
-          S pc = zst[9 * self + a];
-          if (!first) pc = pc + bs2 * pst[9 * self + a];
-          S qs = S(q);
-          qs += lambda * pc;  // pose damping term of right_multiply
           pcs[j] = pc;
-          qss[j] = qs;
-          pqd[j] = double(pc) * double(qs);
-        } else {
-          S qs = S(q);
-          qs += lambda * xs[j];
-          qss[j] = qs;
+          my_pq += double(pc) * double(qs);
         }
       }
+    }
+    if (direction) {
+      const double t = wave_sum(my_pq);
+      if (lane == 0) wpq[wave] = t;
     }
   };
   // row wave: the entries of a vector of the workgroup's rows (LDS, [9 nrows]) as records, published with `tagn`
@@ -502,12 +529,16 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   };
 
   __syncthreads();  // staged vectors / row state / flags
+  {
+    const int j = tid >> 2, jj = j < nout ? j : 0, row = jj / 9;
+    rcon = rowtab[3 * row] | (rowtab[3 * row + 1] << 8) | (rowtab[3 * row + 2] << 16) | ((jj - 9 * row) << 28);
+  }
   if (P.switch_operator) {
     // operator switch inside a running solve: the residual is recomputed with the operator used from here on,
     // r = b - (S + lambda I) x, exactly like the periodic refresh (Solver::pcg_fused)
-    product(false, false, S(0));
+    product(S(0));
     __syncthreads();
-    rowsums(false, false, S(0));
+    rowsums(false, S(0));
     __syncthreads();
     if (roww)
       for (int j = lane; j < nout; j += 64) rs[j] = bs[j] - qss[j];
@@ -517,7 +548,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   for (;;) {
     const int cur = it + 1;
     const pg_u32 tag = P.tag_base + pg_u32(cur);
-    const bool refresh = (cur % P.period) == 0, first = it == 0;
+    const bool refresh = (cur % P.period) == 0;
     stamp(0);
     // ---- exchange 1: z of the staged columns (stagers); partial sums of rho and Q (waves 4 - 7, a workgroup per lane) ---
     if (!my_stop) {
@@ -547,21 +578,31 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
     }
     stamp(1);
     __syncthreads();  // #1: z is staged, the sums are gathered
-    if (pg_flag(sflag) != 0) return;
-    if (pg_flag(sflag + 1) != 0) {
+    // (ONE LDS round trip for everything the decisions read: loads behind a branch would each be one of their own)
+    int f_abort = pg_flag(sflag), f_end = pg_flag(sflag + 1);
+    double g8[8], rho_prev = bc[3], q_prev = bc[4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) g8[u] = gs[u];
+#ifndef HIPEMU
+    asm volatile("" : "+v"(f_abort), "+v"(f_end), "+v"(rho_prev), "+v"(q_prev), "+v"(g8[0]), "+v"(g8[1]), "+v"(g8[2]), "+v"(g8[3]),
+                 "+v"(g8[4]), "+v"(g8[5]), "+v"(g8[6]), "+v"(g8[7]));
+#endif
+    if (f_abort != 0) return;
+    if (f_end != 0) {
       if (roww) finish();
       return;
     }
-    // ---- decisions (k_pcgs_spmv<0> prologue), by everybody alike: test of the previous iteration, rho, beta --------------
-    const double rho = (gs[0] + gs[2]) + (gs[4] + gs[6]), q1 = (gs[1] + gs[3]) + (gs[5] + gs[7]);
+    const double rho = (g8[0] + g8[2]) + (g8[4] + g8[6]), q1 = (g8[1] + g8[3]) + (g8[5] + g8[7]);
     double beta = 0.0;
     {
-      const double rho_prev = bc[3], q_prev = bc[4];
       int own_stop = 0, term = 0, res_it = it;
       if (need_test) {
         // Q-model test (conjugate_gradient.hpp:239-276); residual-based test is off (r_tolerance = -1)
-        const double zeta = it * (q1 - q_prev) / q1;
-        if (zeta < P.q_tolerance && it >= P.min_it) {
+        // zeta = it (q1 - q_prev) / q1 < tolerance, without the division (40 dependent double-precision instructions on
+        // everybody's critical path): multiplied through by q1, the inequality turned for q1 < 0; q1 = 0 (x = 0) never passes
+        const double num = it * (q1 - q_prev), bound = P.q_tolerance * q1;
+        const bool small = q1 > 0.0 ? num < bound : (q1 < 0.0 && num > bound);
+        if (small && it >= P.min_it) {
           own_stop = 1;
           term = 1;
         } else if (it >= P.max_it) {
@@ -598,34 +639,29 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       }
     }
     const S bs2 = S(beta);
+    if (roww && lane == 0) {  // (needed again behind exchange 2: parked in LDS, not in registers across the product)
+      bc[0] = beta;
+      bc[1] = rho;
+      bc[2] = q1;
+    }
     stamp(2);
-    product(true, first, bs2);
+    product(bs2);
     __syncthreads();  // #2: the quad sums are written
     stamp(3);
-    if (tid == 0) {  // (everybody has read them before barrier #2)
-      bc[3] = rho;
-      if (need_test) bc[4] = q1;
+    if (roww && lane == 0) {  // (everybody has read them before barrier #2)
+      bc[3] = bc[1];
+      if (need_test) bc[4] = bc[2];
     }
-    rowsums(true, first, bs2);
+    rowsums(true, bs2);
     __syncthreads();  // #3: the row sums are written
     // ---- the stagers keep the direction of their column: p = z + beta p, in place (nobody reads it before the next product)
-    if (stager && !first) {
+    if (stager) {
 #pragma unroll
-      for (int a = 0; a < 9; ++a) pst[9 * tid + a] = zst[9 * tid + a] + bs2 * pst[9 * tid + a];
-    } else if (stager) {
-#pragma unroll
-      for (int a = 0; a < 9; ++a) pst[9 * tid + a] = zst[9 * tid + a];
+      for (int a = 0; a < 9; ++a) pst[9 * tid + a] = pg_dir(zst[9 * tid + a], bs2, pst[9 * tid + a]);
     }
     if (roww) {
-      // ---- p.q ------------------------------------------------------------------------------------------------------------
-      double my_pq = 0.0;
-      for (int j0 = lane; j0 < nout; j0 += 128) {
-        const int j1 = j0 + 64;
-        const double v0 = pqd[j0], v1 = pqd[min(j1, nout - 1)];
-        my_pq += v0;
-        my_pq += j1 < nout ? v1 : 0.0;
-      }
-      const double s0 = wave_sum(my_pq);
+      // ---- p.q: the waves' sums of their outputs' p_c q_c ---------------------------------------------------------------
+      const double s0 = ((wpq[0] + wpq[1]) + (wpq[2] + wpq[3])) + ((wpq[4] + wpq[5]) + (wpq[6] + wpq[7]));
       if (lane < kPgReplicas) pg_rec_store(P.part_pq + size_t(lane) * G + g, pg_pack(s0, tag));
       stamp(4);
       // ---- exchange 2: partial sums of p.q (four workgroups per lane) ---------------------------------------------------
@@ -681,7 +717,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       } else if (pq <= 0.0 || isinf(pq)) {
         stop2 = 1;  // "Matrix is indefinite, no more progress can be made." -> NO_CONVERGENCE
       } else {
-        alpha = rho / pq;
+        alpha = bc[1] / pq;
         if (isinf(alpha)) {
           stop2 = 1;
           term2 = 2;
@@ -690,9 +726,6 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       if (stop2) {
         my_stop = 1;
         if (lane == 0) {
-          bc[0] = beta;
-          bc[1] = rho;
-          bc[2] = q1;
           bc[5] = pq;
           bc[6] = alpha;
           endi[0] = term2;
@@ -720,9 +753,9 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
         if (roww) finish();
         return;
       }
-      product(false, false, S(0));
+      product(S(0));
       __syncthreads();  // #5
-      rowsums(false, false, S(0));
+      rowsums(false, S(0));
       __syncthreads();  // #6
       if (roww)
         for (int j = lane; j < nout; j += 64) rs[j] = bs[j] - qss[j];
