@@ -1571,6 +1571,7 @@ class Solver final : public rba_solver {
 
   // ---- state ------------------------------------------------------------------
   void set_state(const void* cams, const void* lms) override {
+    lm_.ri_is_current = false;  // (the error cached by the LM loop belongs to another state)
     use_device();
     if (mixed_) {
       // RBA_MIXED: the state crosses the boundary in double; the float state is its rounding
@@ -2801,7 +2802,10 @@ class Solver final : public rba_solver {
     };
     // the reference re-evaluates the error at every outer iteration (bal_bundle_adjustment.cpp:297-301,
     // with a TODO to avoid it); so does this loop - the metric of SURVEY.md 8d includes both evaluations
-    const bool fresh_cost = lm_.it == 0 || lm_.need_linearize;
+    // - except where the state has not changed since its error was evaluated: after an accepted step `lm_.ri` IS the
+    // trial evaluation of the state that is now current (same kernel, same inputs, same fixed summation order: the
+    // re-evaluation would return it bit for bit), so it is reused
+    const bool fresh_cost = lm_.it == 0 || (lm_.need_linearize && !lm_.ri_is_current);
     if (fresh_cost) compute_error_enqueue(pinned_doubles(kPinCe0), /*side=*/lm_async_ && lm_.it > 0);
     auto cost_is_valid = [&]() {  // (after a synchronisation)
       if (fresh_cost) compute_error_parse(pinned_doubles(kPinCe0), &lm_.ri);
