@@ -125,6 +125,14 @@ template <int N>
 __device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[N]) {
   for (int i = 0; i < N; ++i) v[i] = pg_rec_load1(p + i * stride);
 }
+__device__ __forceinline__ void pg_rec_load_pairs(const pg_rec* p0, const pg_rec* p1, const pg_rec* p2, const pg_rec* p3,
+                                                  pg_rec (&v)[8]) {
+  const pg_rec* p[4] = {p0, p1, p2, p3};
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = pg_rec_load1(p[i]);
+    v[2 * i + 1] = pg_rec_load1(p[i] + 1);
+  }
+}
 #else
 __device__ __forceinline__ void pg_rec_store(pg_rec* p, pg_rec v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
@@ -156,6 +164,18 @@ __device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec 
       "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
       : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
       : "v"(p), "v"(p1), "v"(p2), "v"(p3)
+      : "memory");
+}
+// four PAIRS of adjacent records (the rho and Q partial sums of four workgroups)
+__device__ __forceinline__ void pg_rec_load_pairs(const pg_rec* p0, const pg_rec* p1, const pg_rec* p2, const pg_rec* p3,
+                                                  pg_rec (&v)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %9, off sc1\n\tglobal_load_dwordx4 %3, %9, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %4, %10, off sc1\n\tglobal_load_dwordx4 %5, %10, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %6, %11, off sc1\n\tglobal_load_dwordx4 %7, %11, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
       : "memory");
 }
 __device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[9]) {
@@ -233,9 +253,17 @@ __device__ __forceinline__ float pg_dir(float z, float b, float p) { return __bu
 __device__ __forceinline__ double pg_dir(double z, double b, double p) { return __builtin_fma(b, p, z); }
 
 // sum over the four lanes of a quad, every lane receives it (fixed order: (l0 + l1) + (l2 + l3) up to commutation)
+// (a quad permutation writes every lane: no initial value for the destination - dpp_mov0 spends a v_mov on it per word)
+template <int CTRL>
+__device__ __forceinline__ double pg_dpp_perm(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_mov_dpp(int(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(int(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
 __device__ __forceinline__ double pg_quad_sum(double v) {
-  v += dpp_mov0<0xb1>(v);  // quad_perm:[1,0,3,2]
-  v += dpp_mov0<0x4e>(v);  // quad_perm:[2,3,0,1]
+  v += pg_dpp_perm<0xb1>(v);  // quad_perm:[1,0,3,2]
+  v += pg_dpp_perm<0x4e>(v);  // quad_perm:[2,3,0,1]
   return v;
 }
 __device__ __forceinline__ int pg_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -279,7 +307,6 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   const bool stager = mycol >= 0;
   const bool wave_stages = wave * 64 < W.ncols;  // (the staged columns are work-items 0 .. ncols - 1)
   const bool roww = wave == kPgThreads / 64 - 1;
-  const bool poller = wave >= 4;
   const int nout = 9 * W.nrows;
   const int G = P.G;
   CgState* st = P.st;
@@ -391,11 +418,11 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       }
       const S zc = zst[9 * self + a], po = pst[9 * self + a], xc = xs[jj];  // (all loads ahead of the sums)
       double q = 0.0;
-      for (int k0 = part; k0 < nq; k0 += 16) {
-        double v[4];
+      for (int k0 = part; k0 < nq; k0 += 24) {  // (six loads in flight: ONE pass for rows of up to 96 blocks)
+        double v[6];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = red[9 * (q0 + min(k0 + 4 * u, nq - 1)) + a] * (k0 + 4 * u < nq ? 1.0 : 0.0);
-        q += (v[0] + v[1]) + (v[2] + v[3]);
+        for (int u = 0; u < 6; ++u) v[u] = red[9 * (q0 + min(k0 + 4 * u, nq - 1)) + a] * (k0 + 4 * u < nq ? 1.0 : 0.0);
+        q += ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
       }
       q = pg_quad_sum(q);
       if (on && part == 0) {
@@ -550,108 +577,107 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
     const pg_u32 tag = P.tag_base + pg_u32(cur);
     const bool refresh = (cur % P.period) == 0;
     stamp(0);
-    // ---- exchange 1: z of the staged columns (stagers); partial sums of rho and Q (waves 4 - 7, a workgroup per lane) ---
+    // ---- exchange 1: z of the staged columns (stagers); partial sums of rho and Q and the decisions (row wave) ----------
     if (!my_stop) {
-      if (poller) {
+      if (roww) {
         pg_u32 spins = 0;
-        unsigned gg = unsigned(64 * (wave - 4) + lane);
-        PG_OPAQUE(gg);
-        const bool on = int(gg) < G;
-        double v0 = 0.0, v1 = 0.0;
+        double a_rho = 0.0, a_q = 0.0;
         for (;;) {
-          pg_rec r[2];
-          pg_rec_load(P.part_rq + (size_t(g % kPgReplicas) * G + (on ? gg : 0u)) * 2, 1, r);
-          bool ok = pg_unpack(r[0], tag, v0);
-          ok &= pg_unpack(r[1], tag, v1);
-          if (__ballot(on && !ok) == 0) break;
+          unsigned l0 = unsigned(lane);
+          PG_OPAQUE(l0);
+          const pg_rec* base = P.part_rq + size_t(g % kPgReplicas) * G * 2;
+          const int last = G - 1;  // (clamped, masked below: lanes beyond G re-read the last pair)
+          pg_rec r[8];
+          pg_rec_load_pairs(base + 2 * min(int(l0), last), base + 2 * min(int(l0) + 64, last), base + 2 * min(int(l0) + 128, last),
+                            base + 2 * min(int(l0) + 192, last), r);
+          bool ok = true;
+          double v[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool on = int(l0) + 64 * k < G;
+            const bool good0 = pg_unpack(r[2 * k], tag, v[2 * k]), good1 = pg_unpack(r[2 * k + 1], tag, v[2 * k + 1]);
+            ok &= (good0 && good1) || !on;
+            if (!on) v[2 * k] = v[2 * k + 1] = 0.0;
+          }
+          a_rho = (v[0] + v[2]) + (v[4] + v[6]);
+          a_q = (v[1] + v[3]) + (v[5] + v[7]);
+          if (__ballot(!ok) == 0) break;
           const int pa = poll_again(spins);
           if (pa == 2) raise_abort();
           if (pa) break;
         }
-        const double t0 = wave_sum(on ? v0 : 0.0), t1 = wave_sum(on ? v1 : 0.0);
-        if (lane == 0) {
-          gs[2 * (wave - 4)] = t0;
-          gs[2 * (wave - 4) + 1] = t1;
+        // ---- decisions (k_pcgs_spmv<0> prologue): test of the previous iteration, rho, beta - by ONE wave, ahead of
+        //      the barrier (by everybody behind it they were 0.6 us of every iteration: eight waves, two per SIMD, each
+        //      through a double-precision division and a dozen branches) ---------------------------------------------------
+        const double rho_prev = bc[3], q_prev = bc[4];  // (read by every lane BEFORE lane 0 replaces them below)
+        const double rho = wave_sum(a_rho), q1 = wave_sum(a_q);
+        double beta = 0.0;
+        int own_stop = 0, term = 0, res_it = it;
+        if (need_test) {
+          // Q-model test (conjugate_gradient.hpp:239-276); residual-based test is off (r_tolerance = -1)
+          // zeta = it (q1 - q_prev) / q1 < tolerance without the division: multiplied through by q1, the inequality
+          // turned for q1 < 0; q1 = 0 (x = 0) never passes
+          const double num = it * (q1 - q_prev), bound = P.q_tolerance * q1;
+          const bool small = q1 > 0.0 ? num < bound : (q1 < 0.0 && num > bound);
+          if (small && it >= P.min_it) {
+            own_stop = 1;
+            term = 1;
+          } else if (it >= P.max_it) {
+            own_stop = 1;
+            term = 0;
+          }
         }
+        if (!own_stop) {
+          if (rho == 0.0 || isinf(rho) || rho != rho) {
+            own_stop = 1;
+            term = 2;  // "Numerical failure. rho / beta"
+            res_it = it + 1;
+          } else if (it > 0) {
+            beta = rho / rho_prev;
+            if (beta == 0.0 || isinf(beta)) {
+              own_stop = 1;
+              term = 2;
+              res_it = it + 1;
+            }
+          }
+        }
+        if (lane == 0) {
+          bc[0] = beta;
+          bc[1] = rho;
+          bc[2] = q1;
+          if (!own_stop) {
+            bc[3] = rho;
+            if (need_test) bc[4] = q1;
+          } else {
+            endi[0] = term;
+            endi[1] = res_it;
+            endi[2] = 0;
+            endi[3] = 0;
+            __hip_atomic_store(sflag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        if (own_stop) my_stop = 1;
       }
       if (wave_stages) stage_vector(P.zg, tag);
     }
     stamp(1);
-    __syncthreads();  // #1: z is staged, the sums are gathered
-    // (ONE LDS round trip for everything the decisions read: loads behind a branch would each be one of their own)
+    __syncthreads();  // #1: z is staged, beta is known
+    // (ONE LDS round trip for what everybody reads: loads behind a branch would each be one of their own)
     int f_abort = pg_flag(sflag), f_end = pg_flag(sflag + 1);
-    double g8[8], rho_prev = bc[3], q_prev = bc[4];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) g8[u] = gs[u];
+    double beta = bc[0];
 #ifndef HIPEMU
-    asm volatile("" : "+v"(f_abort), "+v"(f_end), "+v"(rho_prev), "+v"(q_prev), "+v"(g8[0]), "+v"(g8[1]), "+v"(g8[2]), "+v"(g8[3]),
-                 "+v"(g8[4]), "+v"(g8[5]), "+v"(g8[6]), "+v"(g8[7]));
+    asm volatile("" : "+v"(f_abort), "+v"(f_end), "+v"(beta));
 #endif
     if (f_abort != 0) return;
     if (f_end != 0) {
       if (roww) finish();
       return;
     }
-    const double rho = (g8[0] + g8[2]) + (g8[4] + g8[6]), q1 = (g8[1] + g8[3]) + (g8[5] + g8[7]);
-    double beta = 0.0;
-    {
-      int own_stop = 0, term = 0, res_it = it;
-      if (need_test) {
-        // Q-model test (conjugate_gradient.hpp:239-276); residual-based test is off (r_tolerance = -1)
-        // zeta = it (q1 - q_prev) / q1 < tolerance, without the division (40 dependent double-precision instructions on
-        // everybody's critical path): multiplied through by q1, the inequality turned for q1 < 0; q1 = 0 (x = 0) never passes
-        const double num = it * (q1 - q_prev), bound = P.q_tolerance * q1;
-        const bool small = q1 > 0.0 ? num < bound : (q1 < 0.0 && num > bound);
-        if (small && it >= P.min_it) {
-          own_stop = 1;
-          term = 1;
-        } else if (it >= P.max_it) {
-          own_stop = 1;
-          term = 0;
-        }
-      }
-      if (!own_stop) {
-        if (rho == 0.0 || isinf(rho) || rho != rho) {
-          own_stop = 1;
-          term = 2;  // "Numerical failure. rho / beta"
-          res_it = it + 1;
-        } else if (it > 0) {
-          beta = rho / rho_prev;
-          if (beta == 0.0 || isinf(beta)) {
-            own_stop = 1;
-            term = 2;
-            res_it = it + 1;
-          }
-        }
-      }
-      if (own_stop) {
-        if (roww) {
-          if (lane == 0) {
-            bc[2] = q1;
-            endi[0] = term;
-            endi[1] = res_it;
-            endi[2] = 0;
-            endi[3] = 0;
-          }
-          finish();
-        }
-        return;
-      }
-    }
     const S bs2 = S(beta);
-    if (roww && lane == 0) {  // (needed again behind exchange 2: parked in LDS, not in registers across the product)
-      bc[0] = beta;
-      bc[1] = rho;
-      bc[2] = q1;
-    }
     stamp(2);
     product(bs2);
     __syncthreads();  // #2: the quad sums are written
     stamp(3);
-    if (roww && lane == 0) {  // (everybody has read them before barrier #2)
-      bc[3] = bc[1];
-      if (need_test) bc[4] = bc[2];
-    }
     rowsums(true, bs2);
     __syncthreads();  // #3: the row sums are written
     // ---- the stagers keep the direction of their column: p = z + beta p, in place (nobody reads it before the next product)
