@@ -215,6 +215,23 @@ int rba_create(int dtype, int device, int32_t n_cams, int32_t n_lms,
                const void* obs_xy, const rba_options* options, rba_handle* out);
 int rba_destroy(rba_handle h);
 
+/* The same for `n_gpus` devices of THIS process behind ONE handle ("..., int n_gpus, handle*"). The
+ * reference builds one Linearizor for the whole problem in one process (src/rootba/solver/linearizor.cpp:133-150,
+ * bal_bundle_adjustment.cpp:249-254), so this is the entry a drop-in binding can reach several GPUs through: the
+ * library shards the landmarks itself - contiguous ranges in the caller's order, balanced by the bytes a landmark moves
+ * per LM iteration in this layout (~120 per observation + 100) - creates one solver per device on a host thread of its
+ * own, joins them (RCCL over the devices; devices that REPEAT in `device_ids` - a single-GPU test box - exchange
+ * through host memory instead) and fans every call of this header out to all of them. State and per-landmark outputs
+ * keep the caller's landmark order; replicated results (costs, b, increments, LM rows) are bit-identical on all
+ * devices and reported from the first. `device_ids` NULL = devices 0 .. n_gpus - 1. rba_comm_init* do not apply to
+ * such a handle (RBA_ERR_UNSUPPORTED). */
+int rba_create_sharded(int dtype, int n_gpus, const int* device_ids, int32_t n_cams, int32_t n_lms,
+                       const int64_t* lm_obs_offsets, const int32_t* obs_cam_idx, const void* obs_xy,
+                       const rba_options* options, rba_handle* out);
+/* The landmark ranges of a sharded handle: device r holds landmarks cuts[r] .. cuts[r + 1] - 1 (n_ranks + 1 entries;
+ * a handle of rba_create reports one rank and writes nothing). */
+int rba_get_shard_ranges(rba_handle h, int* n_ranks_out, int32_t* cuts_out, int max_cuts);
+
 /* Landmark sharding across GPUs (no reference equivalent; the reference's
  * thread-level reductions become all-reduces). Each rank creates
  * a handle for ITS landmarks and ALL cameras; `unique_id` is the 128-byte

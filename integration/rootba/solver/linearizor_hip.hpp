@@ -13,6 +13,8 @@
 //   on CPU:     the same object code runs against a test double of the C ABI (oracle/mock_rootba_hip.cpp).
 #pragma once
 
+#include <cstdlib>
+
 #include <limits>
 #include <string>
 #include <type_traits>
@@ -32,9 +34,17 @@ class LinearizorHIP : public LinearizorBase<Scalar_>, public HostStateSync {
   using Base = LinearizorBase<Scalar>;
   using VecX = typename Base::VecX;
 
+  // `n_gpus` > 1: devices device .. device + n_gpus - 1 of THIS process behind the one handle (rba_create_sharded: the
+  // library shards the landmarks itself). The reference is one process with one Linearizor for the whole problem
+  // (linearizor.cpp:133-150), so this is how its unchanged driver reaches several GPUs. A maintainer would feed it from
+  // a SolverOptions field (e.g. `num_gpus` beside `num_threads`); here: the constructor argument or ROOTBA_HIP_GPUS.
   LinearizorHIP(BalProblem<Scalar>& bal_problem, const SolverOptions& options, SolverSummary* summary = nullptr,
-                int device = 0)
+                int device = 0, int n_gpus = 0)
       : Base(bal_problem, options, summary) {
+    if (n_gpus <= 0) {
+      const char* ev = std::getenv("ROOTBA_HIP_GPUS");
+      n_gpus = ev ? std::max(1, std::atoi(ev)) : 1;
+    }
     // CSR topology from the std::map of every landmark (ascending camera index = map order,
     // landmark_block_dynamic.hpp:52-54)
     std::vector<int64_t> off(1, 0);
@@ -70,8 +80,17 @@ class LinearizorHIP : public LinearizorBase<Scalar_>, public HostStateSync {
     o.staged_execution = options.staged_execution;
     // (the LM-loop fields of rba_options - trust region, vee, tolerances - are used by rba_optimize_lm only; here
     //  the reference's own loop runs)
-    const int st = rba_create(std::is_same<Scalar, float>::value ? RBA_F32 : RBA_F64, device, bal_problem.num_cameras(),
-                              bal_problem.num_landmarks(), off.data(), cam.data(), xy.data(), &o, &h_);
+    const int dt = std::is_same<Scalar, float>::value ? RBA_F32 : RBA_F64;
+    int st;
+    if (n_gpus > 1) {
+      std::vector<int> ids(static_cast<size_t>(n_gpus));
+      for (int i = 0; i < n_gpus; ++i) ids[static_cast<size_t>(i)] = device + i;
+      st = rba_create_sharded(dt, n_gpus, ids.data(), bal_problem.num_cameras(), bal_problem.num_landmarks(), off.data(),
+                              cam.data(), xy.data(), &o, &h_);
+    } else {
+      st = rba_create(dt, device, bal_problem.num_cameras(), bal_problem.num_landmarks(), off.data(), cam.data(), xy.data(), &o,
+                      &h_);
+    }
     CHECK(st == RBA_OK) << "rba_create: " << rba_last_error();
     cams_.resize(size_t(10) * bal_problem.num_cameras());
     lms_.resize(size_t(3) * bal_problem.num_landmarks());

@@ -115,6 +115,15 @@ int rba_create(int dtype, int /*device*/, int32_t n_cams, int32_t n_lms, const i
     return int(RBA_OK);
   });
 }
+// (the test double has no devices: a "sharded" handle is the plain one)
+int rba_create_sharded(int dtype, int /*n_gpus*/, const int* /*device_ids*/, int32_t n_cams, int32_t n_lms, const int64_t* off,
+                       const int32_t* cam, const void* xy, const rba_options* options, rba_handle* out) {
+  return rba_create(dtype, 0, n_cams, n_lms, off, cam, xy, options, out);
+}
+int rba_get_shard_ranges(rba_handle, int* n_ranks_out, int32_t*, int) {
+  if (n_ranks_out) *n_ranks_out = 1;
+  return RBA_OK;
+}
 int rba_destroy(rba_handle h) {
   auto* m = reinterpret_cast<Mock*>(h);
   delete m->f;

@@ -115,7 +115,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, 
 
 # every symbol include/rootba_hip.h declares
 EXPORTS = [
-    "rba_default_options", "rba_last_error", "rba_device_count", "rba_create", "rba_destroy",
+    "rba_default_options", "rba_last_error", "rba_device_count", "rba_create", "rba_create_sharded", "rba_get_shard_ranges",
+    "rba_destroy",
     "rba_comm_unique_id", "rba_comm_init", "rba_comm_init_callback", "rba_comm_info", "rba_get_comm_stats",
     "rba_set_state", "rba_get_state", "rba_backup",
     "rba_restore", "rba_compute_error", "rba_linearize", "rba_solve", "rba_stage2",

@@ -36,6 +36,7 @@ void usage() {
       "  --optimized-cost ERROR|ERROR_VALID|ERROR_VALID_AVG\n"
       "  --eta <e> --max-linear-solver-iterations <n> --function-tolerance <t>\n"
       "  --jacobi-scaling-epsilon <e> --log-path <ba_log.json> --device <n>\n"
+      "  --gpus <N>   shard the landmarks over devices n .. n + N - 1 of this process (rba_create_sharded)\n"
       "  --solver-type SQUARE_ROOT|SCHUR_COMPLEMENT   (default SQUARE_ROOT)\n"
       "  --save-log-flags <JSON,UBJSON>         (default JSON; UBJSON writes <log>.ubjson next to it)\n"
       "  --input-type <AUTO|ROOTBA|BAL|BUNDLER> AUTO: '*.cereal' = rootba problem cache, '*bundle*' = Bundler, else BAL text\n"
@@ -49,7 +50,7 @@ void usage() {
 static int g_save_log_flags = rootba_hip::SAVE_LOG_JSON;  // BaLogOptions::save_log_flags (ba_log_options.hpp:48-50)
 
 template <class Scalar>
-int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string& log_path, bool dry_run, int device) {
+int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string& log_path, bool dry_run, int device, int n_gpus) {
   const auto t_load = std::chrono::steady_clock::now();
   double load_only_seconds = 0, preprocess_seconds = 0;
   auto prob = load_normalized_bal_problem<Scalar>(ds, &load_only_seconds, &preprocess_seconds);
@@ -85,7 +86,7 @@ int run(const BalDatasetOptions& ds, const SolverOptions& so, const std::string&
   }
   SolverSummary summary;
   const auto t_opt = std::chrono::steady_clock::now();
-  bundle_adjust_manual(prob, so, &summary, device);
+  bundle_adjust_manual(prob, so, &summary, device, n_gpus);
   PipelineTimingSummary timing;
   timing.load_time = load_only_seconds;
   timing.preprocess_time = preprocess_seconds;
@@ -188,7 +189,7 @@ int main(int argc, char** argv) {
   SolverOptions so;
   std::string log_path = "ba_log.json";
   bool dry_run = false, dump_options = false;
-  int device = 0;
+  int device = 0, n_gpus = 1;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto val = [&]() -> std::string {
@@ -269,6 +270,7 @@ int main(int argc, char** argv) {
       }
     }
     else if (a == "--device") device = std::stoi(val());
+    else if (a == "--gpus") n_gpus = std::stoi(val());
     else if (a == "--dry-run") dry_run = true;
     else if (a == "--dump-options") dump_options = true;
     else if (a == "--self-test-parser") return self_test_parser(std::stol(val()));
@@ -294,7 +296,7 @@ int main(int argc, char** argv) {
   }
   if (ds.input.empty()) { usage(); return 1; }
   try {
-    return so.use_double ? run<double>(ds, so, log_path, dry_run, device) : run<float>(ds, so, log_path, dry_run, device);
+    return so.use_double ? run<double>(ds, so, log_path, dry_run, device, n_gpus) : run<float>(ds, so, log_path, dry_run, device, n_gpus);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FATAL: %s\n", e.what());
     return 2;

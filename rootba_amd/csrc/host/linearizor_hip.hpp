@@ -147,8 +147,8 @@ class LinearizorHIP {
   using VecX = std::vector<Scalar>;
 
   static std::unique_ptr<LinearizorHIP> create(BalProblem<Scalar>& bal_problem, const SolverOptions& options,
-                                               SolverSummary* summary = nullptr, int device = 0) {
-    return std::unique_ptr<LinearizorHIP>(new LinearizorHIP(bal_problem, options, summary, device));
+                                               SolverSummary* summary = nullptr, int device = 0, int n_gpus = 1) {
+    return std::unique_ptr<LinearizorHIP>(new LinearizorHIP(bal_problem, options, summary, device, n_gpus));
   }
   ~LinearizorHIP() { rba_destroy(h_); }
 
@@ -203,18 +203,26 @@ class LinearizorHIP {
   rba_handle handle() { return h_; }
 
  private:
-  LinearizorHIP(BalProblem<Scalar>& bal_problem, const SolverOptions& options, SolverSummary* summary, int device)
+  LinearizorHIP(BalProblem<Scalar>& bal_problem, const SolverOptions& options, SolverSummary* summary, int device, int n_gpus)
       : bal_problem_(bal_problem), options_(options), summary_(summary),
         mixed_(options.mixed_precision && std::is_same<Scalar, double>::value) {
     if (options.mixed_precision && !mixed_)
       throw std::runtime_error("mixed_precision needs use_double (the host problem is double)");
     const rba_options o = options.to_rba();
     // BalProblem already stores the CSR topology the C ABI takes
-    check_rba(rba_create(mixed_ ? RBA_MIXED : std::is_same<Scalar, float>::value ? RBA_F32 : RBA_F64, device,
-                         bal_problem.num_cameras(),
-                         bal_problem.num_landmarks(), bal_problem.lm_off.data(), bal_problem.obs_cam.data(),
-                         bal_problem.obs_xy.data(), &o, &h_),
-              "rba_create");
+    const int dt = mixed_ ? RBA_MIXED : std::is_same<Scalar, float>::value ? RBA_F32 : RBA_F64;
+    if (n_gpus > 1) {
+      // ONE handle over devices device .. device + n_gpus - 1: the library shards the landmarks itself (rba_create_sharded)
+      std::vector<int> ids(static_cast<size_t>(n_gpus));
+      for (int i = 0; i < n_gpus; ++i) ids[static_cast<size_t>(i)] = device + i;
+      check_rba(rba_create_sharded(dt, n_gpus, ids.data(), bal_problem.num_cameras(), bal_problem.num_landmarks(),
+                                   bal_problem.lm_off.data(), bal_problem.obs_cam.data(), bal_problem.obs_xy.data(), &o, &h_),
+                "rba_create_sharded");
+    } else {
+      check_rba(rba_create(dt, device, bal_problem.num_cameras(), bal_problem.num_landmarks(), bal_problem.lm_off.data(),
+                           bal_problem.obs_cam.data(), bal_problem.obs_xy.data(), &o, &h_),
+                "rba_create");
+    }
     VecX cams, lms;
     bal_problem.copy_to_state(cams, lms);
     check_rba(rba_set_state(h_, cams.data(), lms.data()), "rba_set_state");
@@ -232,7 +240,7 @@ class LinearizorHIP {
 // console lines follow the reference's format (bal_bundle_adjustment.cpp:303-460).
 template <class Scalar>
 void bundle_adjust_manual(BalProblem<Scalar>& bal_problem, const SolverOptions& options, SolverSummary* summary_out,
-                          int device = 0) {
+                          int device = 0, int n_gpus = 1) {
   SolverSummary local;
   SolverSummary& summary = summary_out ? *summary_out : local;
   summary = SolverSummary();
@@ -242,7 +250,7 @@ void bundle_adjust_manual(BalProblem<Scalar>& bal_problem, const SolverOptions& 
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   };
   // preprocessor = building the linearizor: device allocation, topology and state upload
-  auto lin = LinearizorHIP<Scalar>::create(bal_problem, options, &summary, device);
+  auto lin = LinearizorHIP<Scalar>::create(bal_problem, options, &summary, device, n_gpus);
   summary.preprocessor_time_in_seconds = seconds_since(t_total);
   const auto t_minimizer = std::chrono::steady_clock::now();
   check_rba(rba_lm_begin(lin->handle()), "rba_lm_begin");

@@ -11,6 +11,9 @@
 #include <algorithm>
 #include <chrono>
 #include <climits>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -3437,6 +3440,384 @@ int guarded(F&& f) {
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+namespace {
+
+// what rba_create checks before any HIP resource exists (the options the reference CHECKs, the arguments)
+int validate_create(const char* who, int32_t n_cams, int32_t n_lms, const int64_t* lm_obs_offsets, const int32_t* obs_cam_idx,
+                    const void* obs_xy, const rba_options* options, rba_handle* out) {
+  if (!out || !lm_obs_offsets || !obs_cam_idx || !obs_xy || !options || n_cams <= 0 || n_lms <= 0) {
+    g_last_error = std::string(who) + ": invalid argument";
+    return RBA_ERR_INVALID_ARGUMENT;
+  }
+  if (options->preconditioner_type < 0 || options->preconditioner_type > 2) {
+    // the reference LOG(FATAL)s for anything but JACOBI / SCHUR_JACOBI in the QR
+    // solver (linearizor_qr.cpp:208-240); POWER_SCHUR_COMPLEMENT (2) is the new
+    // combination of BASELINE.json config 5
+    g_last_error = "preconditioner_type must be JACOBI (0), SCHUR_JACOBI (1) or POWER_SCHUR_COMPLEMENT (2)";
+    return RBA_ERR_UNSUPPORTED;
+  }
+  {
+    const rba_options& o = *options;
+    const char* bad = nullptr;
+    if (o.max_cg_it < 1) bad = "max_cg_it (max_linear_solver_iterations) must be >= 1";
+    else if (o.min_cg_it < 0 || o.min_cg_it > o.max_cg_it) bad = "0 <= min_cg_it <= max_cg_it required";
+    else if (!(o.eta >= 0.0)) bad = "eta must be >= 0";
+    else if (o.power_order < 0) bad = "power_order must be >= 0";
+    else if (!(o.min_trust_region_radius > 0.0) || !(o.initial_trust_region_radius >= o.min_trust_region_radius) ||
+             !(o.max_trust_region_radius >= o.initial_trust_region_radius))
+      bad = "0 < min_trust_region_radius <= initial_trust_region_radius <= max_trust_region_radius required";
+    else if (o.max_num_iterations < 0) bad = "max_num_iterations must be >= 0";
+    else if (!(o.initial_vee > 0.0) || !(o.vee_factor > 0.0)) bad = "initial_vee and vee_factor must be > 0";
+    else if (o.robust_norm < 0 || o.robust_norm > 1) bad = "robust_norm must be NONE (0) or HUBER (1)";
+    else if (o.robust_norm == 1 && !(o.huber_parameter > 0.0)) bad = "huber_parameter must be > 0";
+    else if (o.optimized_cost < 0 || o.optimized_cost > 2) bad = "optimized_cost must be 0, 1 or 2";
+    else if (o.solver_type < 0 || o.solver_type > 1) bad = "solver_type must be SQUARE_ROOT (0) or SCHUR_COMPLEMENT (1)";
+    else if (!(o.jacobi_scaling_eps >= 0.0)) bad = "jacobi_scaling_eps must be >= 0";
+    if (bad) {
+      g_last_error = std::string(who) + ": " + bad;
+      return RBA_ERR_INVALID_ARGUMENT;
+    }
+  }
+  if (options->implicit_q == 0) {
+    static bool warned = false;
+    if (!warned)
+      std::fprintf(stderr, "[rootba_hip] rba_options.implicit_q = 0 is ignored: the dense-block products were removed in "
+                           "round 3, H*x is always evaluated from the factors\n");
+    warned = true;
+  }
+  return RBA_OK;
+}
+
+// one solver on one device for the landmarks [lm0, lm1) of the caller's problem
+rba_solver* make_solver(int dtype, int device, int32_t n_cams, int32_t lm0, int32_t lm1, const int64_t* lm_obs_offsets,
+                        const int32_t* obs_cam_idx, const void* obs_xy, const rba_options& options) {
+  const int32_t n_lms = lm1 - lm0;
+  const int64_t o0 = lm_obs_offsets[lm0];
+  std::vector<int64_t> off;
+  const int64_t* offp = lm_obs_offsets;
+  if (lm0 != 0) {  // (a shard: offsets relative to its first observation)
+    off.resize(size_t(n_lms) + 1);
+    for (int32_t l = 0; l <= n_lms; ++l) off[l] = lm_obs_offsets[lm0 + l] - o0;
+    offp = off.data();
+  }
+  const int32_t* cam = obs_cam_idx + o0;
+  if (dtype == RBA_F32) return new Solver<float>(device, n_cams, n_lms, offp, cam, static_cast<const float*>(obs_xy) + 2 * o0, options);
+  if (dtype == RBA_F64) return new Solver<double>(device, n_cams, n_lms, offp, cam, static_cast<const double*>(obs_xy) + 2 * o0, options);
+  if (dtype == RBA_MIXED) {
+    const double* xy64 = static_cast<const double*>(obs_xy) + 2 * o0;
+    std::vector<float> xy32(size_t(2) * size_t(lm_obs_offsets[lm1] - o0));
+    for (size_t i = 0; i < xy32.size(); ++i) xy32[i] = float(xy64[i]);
+    return new Solver<float>(device, n_cams, n_lms, offp, cam, xy32.data(), options, xy64);
+  }
+  throw HipError{"dtype must be RBA_F32, RBA_F64 or RBA_MIXED", RBA_ERR_INVALID_ARGUMENT};
+}
+
+// ---------------------------------------------------------------------------
+// ONE handle over several devices of ONE process (rba_create_sharded; SURVEY.md 8b: "..., int n_gpus, handle*").
+// The reference is one process (linearizor.cpp:133-150 builds ONE Linearizor for the whole problem), so the drop-in
+// path can only reach more than one GPU if the library shards by itself: contiguous landmark ranges balanced by THIS
+// layout's bytes per landmark, one Solver per device, one host thread per Solver (the Solvers' collectives have to be
+// entered concurrently), every call of the C ABI fanned out to all of them. The ranks' replicated results (cost sums,
+// b, increments, LM decisions) are bit-identical by construction (fixed-order reductions on all-reduced data), so the
+// handle reports rank 0's.
+// Transport: RCCL (one communicator over the devices, ncclCommInitRank from the rank's own thread) when the devices are
+// distinct; devices that repeat (a single-GPU test box) exchange through host memory instead - an in-process all-reduce
+// behind the callback transport (every rank copies in, rank order is the summation order, everybody copies out).
+// ---------------------------------------------------------------------------
+class ShardedSolver final : public rba_solver {
+ public:
+  ShardedSolver(int dtype, int n, const int* devices, int32_t n_cams, int32_t n_lms, const int64_t* lm_off,
+                const int32_t* obs_cam, const void* obs_xy, const rba_options& opt)
+      : n_(n), n_cams_(n_cams), n_lms_(n_lms), es_state_(dtype == RBA_F32 ? 4 : 8), es_vec_(dtype == RBA_F64 ? 8 : 4) {
+    // ---- landmark ranges: bytes a landmark of k observations moves per LM iteration in this layout ~ 120 k + 100
+    //      (rows, records and reflectors per observation + the landmark's own records), never an empty range
+    {
+      std::vector<double> w(size_t(n_lms) + 1, 0.0);
+      for (int32_t l = 0; l < n_lms; ++l) w[l + 1] = w[l] + 120.0 * double(lm_off[l + 1] - lm_off[l]) + 100.0;
+      cuts_.assign(size_t(n) + 1, 0);
+      for (int r = 1; r < n; ++r) {
+        const int32_t c = int32_t(std::lower_bound(w.begin(), w.end(), w[n_lms] * r / n) - w.begin());
+        cuts_[r] = std::min(std::max(c, cuts_[r - 1] + 1), n_lms - (n - r));
+      }
+      cuts_[n] = n_lms;
+    }
+    bool distinct = true;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < i; ++j) distinct &= devices[i] != devices[j];
+    rccl_ = distinct && n > 1;
+    Rccl::UniqueId uid{};
+    if (rccl_) {
+      if (!g_rccl.load()) throw HipError{"librccl.so not found: rba_create_sharded over distinct devices needs RCCL", RBA_ERR_HIP};
+      if (g_rccl.GetUniqueId(&uid) != 0) throw HipError{"ncclGetUniqueId failed", RBA_ERR_HIP};
+    }
+    ranks_.resize(n);
+    hctx_.resize(n);
+    for (int r = 0; r < n; ++r) hctx_[r] = HostCtx{this, r};
+    hbufs_.assign(n, nullptr);
+    workers_.reserve(n);
+    for (int r = 0; r < n; ++r) workers_.emplace_back([this, r] { worker(r); });
+    try {
+      run_all([&](int r) {
+        ranks_[r].reset(make_solver(dtype, devices[r], n_cams, cuts_[r], cuts_[r + 1], lm_off, obs_cam, obs_xy, opt));
+        if (n_ > 1) {
+          if (rccl_)
+            ranks_[r]->comm_init(r, n_, &uid);
+          else
+            ranks_[r]->comm_init_callback(r, n_, &ShardedSolver::host_allreduce, &hctx_[r]);
+        }
+      });
+    } catch (...) {
+      stop_workers();
+      throw;
+    }
+  }
+  ~ShardedSolver() override {
+    try {
+      run_all([&](int r) { ranks_[r].reset(); });
+    } catch (...) {
+    }
+    stop_workers();
+  }
+
+  int n_ranks() const { return n_; }
+  const std::vector<int32_t>& cuts() const { return cuts_; }
+
+  void comm_init(int, int, const void*) override {
+    throw HipError{"a sharded handle owns its communicator: rba_comm_init does not apply", RBA_ERR_UNSUPPORTED};
+  }
+  void comm_init_callback(int, int, rba_allreduce_fn, void*) override {
+    throw HipError{"a sharded handle owns its communicator: rba_comm_init_callback does not apply", RBA_ERR_UNSUPPORTED};
+  }
+  void comm_info(int* rank, int* nranks, int* transport) override { ranks_[0]->comm_info(rank, nranks, transport); }
+  void comm_stats(int64_t* calls, int64_t* bytes, double* seconds) override { ranks_[0]->comm_stats(calls, bytes, seconds); }
+  void set_state(const void* cams, const void* lms) override {
+    run_all([&](int r) { ranks_[r]->set_state(cams, static_cast<const char*>(lms) + size_t(3) * cuts_[r] * es_state_); });
+  }
+  void get_state(void* cams, void* lms) override {
+    std::vector<char> scratch(size_t(10) * n_cams_ * es_state_ * (n_ > 1 ? n_ - 1 : 0));
+    run_all([&](int r) {
+      void* c = r == 0 ? cams : static_cast<void*>(scratch.data() + size_t(r - 1) * 10 * n_cams_ * es_state_);
+      ranks_[r]->get_state(c, static_cast<char*>(lms) + size_t(3) * cuts_[r] * es_state_);
+    });
+  }
+  void backup() override { run_all([&](int r) { ranks_[r]->backup(); }); }
+  void restore() override { run_all([&](int r) { ranks_[r]->restore(); }); }
+  void compute_error(rba_residual_info* out) override {
+    std::vector<rba_residual_info> o(n_);
+    run_all([&](int r) { ranks_[r]->compute_error(&o[r]); });
+    *out = o[0];
+  }
+  int linearize(void* jp_diag2_out) override {
+    std::vector<char> scratch(jp_diag2_out ? size_t(9) * n_cams_ * es_vec_ * (n_ - 1) : 0);
+    return run_all_status([&](int r) {
+      void* o = !jp_diag2_out ? nullptr : r == 0 ? jp_diag2_out : static_cast<void*>(scratch.data() + size_t(r - 1) * 9 * n_cams_ * es_vec_);
+      return ranks_[r]->linearize(o);
+    });
+  }
+  int solve(double lambda, void* inc_out, rba_cg_summary* cg) override {
+    std::vector<char> scratch(inc_out ? size_t(9) * n_cams_ * es_vec_ * (n_ - 1) : 0);
+    std::vector<rba_cg_summary> c(n_);
+    const int st = run_all_status([&](int r) {
+      void* o = !inc_out ? nullptr : r == 0 ? inc_out : static_cast<void*>(scratch.data() + size_t(r - 1) * 9 * n_cams_ * es_vec_);
+      return ranks_[r]->solve(lambda, o, &c[r]);
+    });
+    if (cg) *cg = c[0];
+    return st;
+  }
+  int stage2(double lambda, void* b_out, void* blocks_out) override {
+    std::vector<char> sb(b_out ? size_t(9) * n_cams_ * es_vec_ * (n_ - 1) : 0), sk(blocks_out ? size_t(81) * n_cams_ * es_vec_ * (n_ - 1) : 0);
+    return run_all_status([&](int r) {
+      void* b = !b_out ? nullptr : r == 0 ? b_out : static_cast<void*>(sb.data() + size_t(r - 1) * 9 * n_cams_ * es_vec_);
+      void* k = !blocks_out ? nullptr : r == 0 ? blocks_out : static_cast<void*>(sk.data() + size_t(r - 1) * 81 * n_cams_ * es_vec_);
+      return ranks_[r]->stage2(lambda, b, k);
+    });
+  }
+  void right_multiply(const void* x, void* y) override {
+    std::vector<char> scratch(size_t(9) * n_cams_ * es_vec_ * (n_ - 1));
+    run_all([&](int r) { ranks_[r]->right_multiply(x, r == 0 ? y : static_cast<void*>(scratch.data() + size_t(r - 1) * 9 * n_cams_ * es_vec_)); });
+  }
+  void right_multiply_explicit(const void* x, void* y) override {
+    std::vector<char> scratch(size_t(9) * n_cams_ * es_vec_ * (n_ - 1));
+    run_all([&](int r) {
+      ranks_[r]->right_multiply_explicit(x, r == 0 ? y : static_cast<void*>(scratch.data() + size_t(r - 1) * 9 * n_cams_ * es_vec_));
+    });
+  }
+  int apply(const void* inc, double* l_diff, bool update_cams) override {
+    std::vector<double> ld(n_, 0.0);
+    const int st = run_all_status([&](int r) { return ranks_[r]->apply(inc, &ld[r], update_cams); });
+    if (l_diff) *l_diff = ld[0];
+    return st;
+  }
+  int optimize_lm(rba_lm_iteration* log, int max_rows, int* n_rows, int* term) override {
+    std::vector<std::vector<rba_lm_iteration>> logs(n_, std::vector<rba_lm_iteration>(size_t(std::max(max_rows, 1))));
+    std::vector<int> nr(n_, 0), tm(n_, 0);
+    const int st = run_all_status([&](int r) { return ranks_[r]->optimize_lm(logs[r].data(), max_rows, &nr[r], &tm[r]); });
+    for (int i = 0; i < std::min(nr[0], max_rows); ++i) log[i] = logs[0][i];
+    *n_rows = nr[0];
+    *term = tm[0];
+    return st;
+  }
+  void lm_begin() override { run_all([&](int r) { ranks_[r]->lm_begin(); }); }
+  int lm_step(rba_lm_iteration* out) override {
+    std::vector<rba_lm_iteration> rows(n_);
+    std::vector<int> more(n_, 0);
+    run_all([&](int r) { more[r] = ranks_[r]->lm_step(&rows[r]); });
+    *out = rows[0];
+    return more[0];
+  }
+  int lm_termination() const override { return ranks_[0]->lm_termination(); }
+  void device_sync() override { run_all([&](int r) { ranks_[r]->device_sync(); }); }
+  int64_t debug_read_A(int vec) override {
+    std::vector<int64_t> b(n_, 0);
+    run_all([&](int r) { b[r] = ranks_[r]->debug_read_A(vec); });
+    return std::accumulate(b.begin(), b.end(), int64_t(0));
+  }
+  void get_timings(rba_iter_timings* out) override { ranks_[0]->get_timings(out); }
+  void get_substage_timings(rba_substage_timings* out) override { ranks_[0]->get_substage_timings(out); }
+  void get_jl_col_scale(void* out) override {
+    run_all([&](int r) { ranks_[r]->get_jl_col_scale(static_cast<char*>(out) + size_t(3) * cuts_[r] * es_vec_); });
+  }
+  void get_pose_scaling(void* out) override {
+    std::vector<char> scratch(size_t(9) * n_cams_ * es_vec_ * (n_ - 1));
+    run_all([&](int r) { ranks_[r]->get_pose_scaling(r == 0 ? out : static_cast<void*>(scratch.data() + size_t(r - 1) * 9 * n_cams_ * es_vec_)); });
+  }
+  void get_landmark_R(int damped, void* R6, void* q3) override {
+    run_all([&](int r) {
+      ranks_[r]->get_landmark_R(damped, static_cast<char*>(R6) + size_t(6) * cuts_[r] * es_vec_,
+                                static_cast<char*>(q3) + size_t(3) * cuts_[r] * es_vec_);
+    });
+  }
+  void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) override {
+    std::vector<int64_t> a(n_), b(n_), c(n_);
+    run_all([&](int r) { ranks_[r]->get_problem_stats(&a[r], &b[r], &c[r]); });
+    *storage = std::accumulate(a.begin(), a.end(), int64_t(0));
+    *hx_bytes = std::accumulate(b.begin(), b.end(), int64_t(0));
+    *hx_flops = std::accumulate(c.begin(), c.end(), int64_t(0));
+  }
+  void get_byte_model(rba_byte_model* out) override { ranks_[0]->get_byte_model(out); }  // (rank 0's shard)
+  void get_pcg_counters(rba_pcg_counters* out) override { ranks_[0]->get_pcg_counters(out); }
+
+ private:
+  // ---- one host thread per rank: the Solvers' collectives must be entered by all ranks at once --------------------
+  void worker(int r) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void(int)> f;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_job_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        f = job_;
+      }
+      try {
+        f(r);
+      } catch (const HipError& e) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!failed_) err_ = e;
+        failed_ = true;
+      } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!failed_) err_ = HipError{e.what(), RBA_ERR_HIP};
+        failed_ = true;
+      }
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--busy_ == 0) cv_done_.notify_all();
+      }
+    }
+  }
+  void run_all(const std::function<void(int)>& f) {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = f;
+      busy_ = n_;
+      failed_ = false;
+      ++gen_;
+    }
+    cv_job_.notify_all();
+    std::unique_lock<std::mutex> lk(m_);
+    cv_done_.wait(lk, [&] { return busy_ == 0; });
+    if (failed_) throw err_;
+  }
+  int run_all_status(const std::function<int(int)>& f) {
+    std::vector<int> st(n_, RBA_OK);
+    run_all([&](int r) { st[r] = f(r); });
+    return st[0];  // (the ranks agree: failure flags are max-reduced)
+  }
+  void stop_workers() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_job_.notify_all();
+    for (auto& t : workers_)
+      if (t.joinable()) t.join();
+  }
+  // ---- all-reduce through host memory for ranks that share a device (rba_allreduce_fn) -------------------------------
+  struct HostCtx {
+    ShardedSolver* self;
+    int rank;
+  };
+  static int host_allreduce(void* ctx, void* buf, int64_t count, int dtype, int op) {
+    const HostCtx* c = static_cast<const HostCtx*>(ctx);
+    return c->self->host_allreduce_impl(c->rank, buf, count, dtype, op);
+  }
+  template <class T>
+  static void reduce_into(T* dst, const T* src, int64_t n, int op) {
+    if (op == 0)
+      for (int64_t i = 0; i < n; ++i) dst[i] += src[i];
+    else
+      for (int64_t i = 0; i < n; ++i) dst[i] = std::max(dst[i], src[i]);
+  }
+  int host_allreduce_impl(int rank, void* buf, int64_t count, int dtype, int op) {
+    const size_t es = dtype == 1 ? 8 : 4;
+    std::unique_lock<std::mutex> lk(hm_);
+    const uint64_t my_gen = hgen_;
+    hbufs_[rank] = buf;
+    if (++harrived_ == n_) {
+      // the last one in reduces, in rank order (the summation order of every call), and hands the result to everybody
+      hacc_.resize(size_t(count) * es);
+      std::memcpy(hacc_.data(), hbufs_[0], size_t(count) * es);
+      for (int r = 1; r < n_; ++r) {
+        if (dtype == 0) reduce_into(reinterpret_cast<float*>(hacc_.data()), static_cast<const float*>(hbufs_[r]), count, op);
+        else if (dtype == 1) reduce_into(reinterpret_cast<double*>(hacc_.data()), static_cast<const double*>(hbufs_[r]), count, op);
+        else reduce_into(reinterpret_cast<int*>(hacc_.data()), static_cast<const int*>(hbufs_[r]), count, op);
+      }
+      for (int r = 0; r < n_; ++r) std::memcpy(hbufs_[r], hacc_.data(), size_t(count) * es);
+      harrived_ = 0;
+      ++hgen_;
+      hcv_.notify_all();
+    } else {
+      hcv_.wait(lk, [&] { return hgen_ != my_gen; });
+    }
+    return 0;
+  }
+
+  int n_, n_cams_, n_lms_;
+  size_t es_state_, es_vec_;
+  bool rccl_ = false;
+  std::vector<int32_t> cuts_;
+  std::vector<std::unique_ptr<rba_solver>> ranks_;
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_job_, cv_done_;
+  std::function<void(int)> job_;
+  uint64_t gen_ = 0;
+  int busy_ = 0;
+  bool stop_ = false, failed_ = false;
+  HipError err_{"", 0};
+  std::mutex hm_;
+  std::condition_variable hcv_;
+  std::vector<HostCtx> hctx_;
+  std::vector<void*> hbufs_;
+  std::vector<char> hacc_;
+  int harrived_ = 0;
+  uint64_t hgen_ = 0;
+};
+
+}  // namespace
+
 extern "C" {
 
 void rba_default_options(rba_options* o) {
@@ -3481,51 +3862,12 @@ int rba_device_count(int* out) {
   return RBA_OK;
 }
 
+
 int rba_create(int dtype, int device, int32_t n_cams, int32_t n_lms,
                const int64_t* lm_obs_offsets, const int32_t* obs_cam_idx, const void* obs_xy,
                const rba_options* options, rba_handle* out) {
   return guarded([&]() -> int {
-    if (!out || !lm_obs_offsets || !obs_cam_idx || !obs_xy || !options || n_cams <= 0 ||
-        n_lms <= 0) {
-      g_last_error = "rba_create: invalid argument";
-      return RBA_ERR_INVALID_ARGUMENT;
-    }
-    if (options->preconditioner_type < 0 || options->preconditioner_type > 2) {
-      // the reference LOG(FATAL)s for anything but JACOBI / SCHUR_JACOBI in the QR
-      // solver (linearizor_qr.cpp:208-240); POWER_SCHUR_COMPLEMENT (2) is the new
-      // combination of BASELINE.json config 5
-      g_last_error = "preconditioner_type must be JACOBI (0), SCHUR_JACOBI (1) or POWER_SCHUR_COMPLEMENT (2)";
-      return RBA_ERR_UNSUPPORTED;
-    }
-    {
-      const rba_options& o = *options;
-      const char* bad = nullptr;
-      if (o.max_cg_it < 1) bad = "max_cg_it (max_linear_solver_iterations) must be >= 1";
-      else if (o.min_cg_it < 0 || o.min_cg_it > o.max_cg_it) bad = "0 <= min_cg_it <= max_cg_it required";
-      else if (!(o.eta >= 0.0)) bad = "eta must be >= 0";
-      else if (o.power_order < 0) bad = "power_order must be >= 0";
-      else if (!(o.min_trust_region_radius > 0.0) || !(o.initial_trust_region_radius >= o.min_trust_region_radius) ||
-               !(o.max_trust_region_radius >= o.initial_trust_region_radius))
-        bad = "0 < min_trust_region_radius <= initial_trust_region_radius <= max_trust_region_radius required";
-      else if (o.max_num_iterations < 0) bad = "max_num_iterations must be >= 0";
-      else if (!(o.initial_vee > 0.0) || !(o.vee_factor > 0.0)) bad = "initial_vee and vee_factor must be > 0";
-      else if (o.robust_norm < 0 || o.robust_norm > 1) bad = "robust_norm must be NONE (0) or HUBER (1)";
-      else if (o.robust_norm == 1 && !(o.huber_parameter > 0.0)) bad = "huber_parameter must be > 0";
-      else if (o.optimized_cost < 0 || o.optimized_cost > 2) bad = "optimized_cost must be 0, 1 or 2";
-      else if (o.solver_type < 0 || o.solver_type > 1) bad = "solver_type must be SQUARE_ROOT (0) or SCHUR_COMPLEMENT (1)";
-      else if (!(o.jacobi_scaling_eps >= 0.0)) bad = "jacobi_scaling_eps must be >= 0";
-      if (bad) {
-        g_last_error = std::string("rba_create: ") + bad;
-        return RBA_ERR_INVALID_ARGUMENT;
-      }
-    }
-    if (options->implicit_q == 0) {
-      static bool warned = false;
-      if (!warned)
-        std::fprintf(stderr, "[rootba_hip] rba_options.implicit_q = 0 is ignored: the dense-block products were removed in "
-                             "round 3, H*x is always evaluated from the factors\n");
-      warned = true;
-    }
+    if (const int st = validate_create("rba_create", n_cams, n_lms, lm_obs_offsets, obs_cam_idx, obs_xy, options, out)) return st;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
       g_last_error = "no HIP device available: the solver has no CPU fallback";
@@ -3535,21 +3877,53 @@ int rba_create(int dtype, int device, int32_t n_cams, int32_t n_lms,
       g_last_error = "device index out of range";
       return RBA_ERR_INVALID_ARGUMENT;
     }
-    if (dtype == RBA_F32)
-      *out = new Solver<float>(device, n_cams, n_lms, lm_obs_offsets, obs_cam_idx,
-                               static_cast<const float*>(obs_xy), *options);
-    else if (dtype == RBA_F64)
-      *out = new Solver<double>(device, n_cams, n_lms, lm_obs_offsets, obs_cam_idx,
-                                static_cast<const double*>(obs_xy), *options);
-    else if (dtype == RBA_MIXED) {
-      const double* xy64 = static_cast<const double*>(obs_xy);
-      std::vector<float> xy32(size_t(2) * size_t(lm_obs_offsets[n_lms]));
-      for (size_t i = 0; i < xy32.size(); ++i) xy32[i] = float(xy64[i]);
-      *out = new Solver<float>(device, n_cams, n_lms, lm_obs_offsets, obs_cam_idx, xy32.data(), *options, xy64);
-    } else {
+    *out = make_solver(dtype, device, n_cams, 0, n_lms, lm_obs_offsets, obs_cam_idx, obs_xy, *options);
+    return RBA_OK;
+  });
+}
+
+int rba_create_sharded(int dtype, int n_gpus, const int* device_ids, int32_t n_cams, int32_t n_lms,
+                       const int64_t* lm_obs_offsets, const int32_t* obs_cam_idx, const void* obs_xy,
+                       const rba_options* options, rba_handle* out) {
+  return guarded([&]() -> int {
+    if (const int st = validate_create("rba_create_sharded", n_cams, n_lms, lm_obs_offsets, obs_cam_idx, obs_xy, options, out))
+      return st;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      g_last_error = "no HIP device available: the solver has no CPU fallback";
+      return RBA_ERR_HIP;
+    }
+    if (n_gpus < 1 || n_gpus > 64 || n_gpus > n_lms) {
+      g_last_error = "rba_create_sharded: 1 <= n_gpus <= min(64, n_lms) required";
+      return RBA_ERR_INVALID_ARGUMENT;
+    }
+    std::vector<int> dev(n_gpus);
+    for (int i = 0; i < n_gpus; ++i) {
+      dev[i] = device_ids ? device_ids[i] : i;  // (null: devices 0 .. n_gpus - 1)
+      if (dev[i] < 0 || dev[i] >= ndev) {
+        g_last_error = "rba_create_sharded: device index out of range";
+        return RBA_ERR_INVALID_ARGUMENT;
+      }
+    }
+    if (dtype != RBA_F32 && dtype != RBA_F64 && dtype != RBA_MIXED) {
       g_last_error = "dtype must be RBA_F32, RBA_F64 or RBA_MIXED";
       return RBA_ERR_INVALID_ARGUMENT;
     }
+    *out = new ShardedSolver(dtype, n_gpus, dev.data(), n_cams, n_lms, lm_obs_offsets, obs_cam_idx, obs_xy, *options);
+    return RBA_OK;
+  });
+}
+
+int rba_get_shard_ranges(rba_handle h, int* n_ranks_out, int32_t* cuts_out, int max_cuts) {
+  return guarded([&]() -> int {
+    auto* s = dynamic_cast<ShardedSolver*>(h);
+    if (!s) {
+      if (n_ranks_out) *n_ranks_out = 1;
+      return RBA_OK;
+    }
+    if (n_ranks_out) *n_ranks_out = s->n_ranks();
+    if (cuts_out)
+      for (int i = 0; i < std::min<int>(max_cuts, int(s->cuts().size())); ++i) cuts_out[i] = s->cuts()[i];
     return RBA_OK;
   });
 }

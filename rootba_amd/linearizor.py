@@ -26,7 +26,9 @@ class LinearizorHIP:
     """One `LinearizorQR<Scalar>` worth of state, resident on one MI355X."""
 
     def __init__(self, prob: BalProblem, dtype=np.float32, options: L.RbaOptions | None = None,
-                 device: int = 0):
+                 device: int = 0, devices=None):
+        """`devices`: a list of device indices -> ONE handle over several GPUs of this process (rba_create_sharded: the
+        library shards the landmarks itself; an index may repeat, e.g. [0, 0] on a single-GPU box)."""
         # "mixed" (RBA_MIXED): double state / observations / costs, float linear algebra; camera-sized
         # vectors cross the boundary as float32, the state as float64
         self.mixed = isinstance(dtype, str) and dtype == "mixed"
@@ -43,11 +45,16 @@ class LinearizorHIP:
         cam = np.ascontiguousarray(prob.obs_cam_idx, dtype=np.int32)
         xy = np.ascontiguousarray(prob.obs_xy, dtype=self.state_dtype)
         self.h = C.c_void_p()
-        L.check(self.lib.rba_create(
-            C.c_int(L.RBA_MIXED if self.mixed else L.RBA_F32 if self.dtype == np.float32 else L.RBA_F64),
-            C.c_int(device),
-            C.c_int32(self.n_cams), C.c_int32(self.n_lms), _ptr(off), _ptr(cam), _ptr(xy),
-            C.byref(self.options), C.byref(self.h)), "rba_create")
+        dt_code = C.c_int(L.RBA_MIXED if self.mixed else L.RBA_F32 if self.dtype == np.float32 else L.RBA_F64)
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*devices)
+            L.check(self.lib.rba_create_sharded(dt_code, C.c_int(len(devices)), ids, C.c_int32(self.n_cams),
+                                                C.c_int32(self.n_lms), _ptr(off), _ptr(cam), _ptr(xy),
+                                                C.byref(self.options), C.byref(self.h)), "rba_create_sharded")
+        else:
+            L.check(self.lib.rba_create(dt_code, C.c_int(device), C.c_int32(self.n_cams), C.c_int32(self.n_lms),
+                                        _ptr(off), _ptr(cam), _ptr(xy), C.byref(self.options), C.byref(self.h)),
+                    "rba_create")
         self.set_state(prob.cams, prob.lms)
         self.it_summary = None
 
@@ -77,6 +84,14 @@ class LinearizorHIP:
         if a.size != n:
             raise ValueError(f"expected {n} scalars, got {a.size}")
         return a
+
+    def shard_ranges(self):
+        """Landmark ranges of a sharded handle: device r holds landmarks cuts[r] .. cuts[r + 1] - 1."""
+        n = C.c_int(0)
+        L.check(self.lib.rba_get_shard_ranges(self.h, C.byref(n), None, C.c_int(0)), "rba_get_shard_ranges")
+        cuts = (C.c_int32 * (n.value + 1))()
+        L.check(self.lib.rba_get_shard_ranges(self.h, C.byref(n), cuts, C.c_int(n.value + 1)), "rba_get_shard_ranges")
+        return list(cuts) if n.value > 1 else [0, self.n_lms]
 
     # -- multi-GPU ----------------------------------------------------------------
     @staticmethod

@@ -372,6 +372,9 @@ static int pool_threads() {
   return std::max(1, std::min(16, n));
 }
 static void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
+  // (one grid at a time: several HOST threads may launch - rba_create_sharded runs a thread per device)
+  static std::mutex launch_mutex;
+  std::lock_guard<std::mutex> launch_lock(launch_mutex);
   static const int threads = pool_threads();
   const uint64_t total = uint64_t(grid.x) * grid.y * grid.z;
   if (threads == 1 || total == 1) {

@@ -155,3 +155,82 @@ def test_rccl_call_path_with_one_rank(ladybug_problem):
     # two float32 runs differ by the order of the atomic scatter-adds: cost resolution ~1e-6 (see
     # test_lm_trajectory_matches_oracle)
     assert np.allclose([r.cost for r in la], [r.cost for r in lb], rtol=3e-6)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, "mixed"], ids=["float64", "float32", "mixed"])
+@pytest.mark.parametrize("n_dev", [2, 3])
+def test_single_process_sharded_handle(dtype, n_dev):
+    """rba_create_sharded (ONE process, n_gpus devices behind one handle - the entry the reference's one-process
+    driver can reach several GPUs through): the library shards the landmarks itself and fans the calls out on a host
+    thread per device. Here the devices repeat (one GPU: the ranks exchange through host memory); every call of the
+    Linearizor interface and whole LM runs must equal the unsharded handle's, state and per-landmark outputs in the
+    caller's landmark order."""
+    import torch  # noqa: F401
+    from conftest import rel_err
+    from rootba_amd import _lib as L
+    from rootba_amd import problem as P
+    from rootba_amd.linearizor import LinearizorHIP
+    mixed = isinstance(dtype, str)
+    vec_dtype = np.float32 if mixed else dtype
+    prob = P.preprocess(P.named_synthetic("ladybug-49"), translation_sigma=0.5, point_sigma=0.5)
+    opts = dict(robust_norm=1, max_num_iterations=6)
+    g = LinearizorHIP(prob, dtype, L.default_options(**opts))
+    s = LinearizorHIP(prob, dtype, L.default_options(**opts), devices=[0] * n_dev)
+    cuts = s.shard_ranges()
+    assert len(cuts) == n_dev + 1 and cuts[0] == 0 and cuts[-1] == prob.n_lms and all(b > a for a, b in zip(cuts, cuts[1:]))
+    # (balanced by bytes per landmark: 120 per observation + 100)
+    w = 120.0 * prob.obs_per_lm() + 100.0
+    shares = [w[a:b].sum() / w.sum() for a, b in zip(cuts, cuts[1:])]
+    assert max(shares) - min(shares) < 0.02, shares
+    tol = 1e-5 if vec_dtype == np.float32 else 1e-12
+    eg, es = g.compute_error(), s.compute_error()
+    assert es.all_num_obs == eg.all_num_obs and abs(es.all_error - eg.all_error) < (1e-12 if mixed else tol) * eg.all_error
+    assert g.linearize() == 0 and s.linearize() == 0
+    assert rel_err(s.jl_col_scale(), g.jl_col_scale()) < tol  # (per landmark, in the caller's order)
+    (bg, kg), (bs, ks) = g.stage2(0.1), s.stage2(0.1)
+    assert rel_err(bs, bg) < tol and rel_err(ks, kg) < tol
+    x = np.random.default_rng(0).uniform(-1, 1, 9 * prob.n_cams).astype(vec_dtype)
+    assert rel_err(s.right_multiply(x), g.right_multiply(x)) < tol
+    (ig, cg), (is_, cs) = g.solve(1e-4), s.solve(1e-4)
+    assert abs(cg.num_iterations - cs.num_iterations) <= (1 if vec_dtype == np.float32 else 0)
+    assert rel_err(is_, ig) < (1e-3 if vec_dtype == np.float32 else 1e-9)
+    ld_g, ld_s = g.apply(ig), s.apply(ig)
+    assert abs(ld_g - ld_s) <= (1e-4 if vec_dtype == np.float32 else 1e-10) * abs(ld_g)
+    (cg_, lg_), (cs_, ls_) = g.get_state(), s.get_state()
+    assert rel_err(cs_, cg_) < tol and rel_err(ls_, lg_) < tol and ls_.shape == lg_.shape
+    s.set_state(prob.cams, prob.lms)  # (the caller's arrays, sliced per device inside)
+    g.set_state(prob.cams, prob.lms)
+    lg, tg = g.optimize_lm()
+    lsh, ts = s.optimize_lm()
+    assert tg == ts and len(lg) == len(lsh)
+    for a, b in zip(lg, lsh):
+        assert a.step_is_successful == b.step_is_successful
+        assert abs(a.cost - b.cost) <= ((1e-5 if a.iteration <= 2 else 5e-5) if vec_dtype == np.float32 else 1e-9) * a.cost
+    _, lms_g = g.get_state()
+    _, lms_s = s.get_state()
+    assert rel_err(lms_s, lms_g) < (1e-4 if vec_dtype == np.float32 else 1e-9)
+    info = s.comm_info()
+    assert info["nranks"] == n_dev and info["transport"] == "callback", info  # (the devices repeat: host memory)
+    s.close()
+    g.close()
+
+
+def test_single_process_sharded_handle_over_distinct_devices(small_problem):
+    """The same entry over DISTINCT devices: one RCCL communicator inside the process (ncclCommInitRank from the ranks'
+    own host threads). Needs two devices - the MI355X development boxes have one; on the CPU execution harness of
+    tests/hipemu (eight stand-in devices, file-based stand-in for RCCL) this is where the path runs."""
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    if L.device_count() < 2:
+        pytest.skip("one device: the RCCL transport of rba_create_sharded needs two")
+    opts = dict(robust_norm=1, max_num_iterations=4)
+    g = LinearizorHIP(small_problem, np.float64, L.default_options(**opts))
+    s = LinearizorHIP(small_problem, np.float64, L.default_options(**opts), devices=[0, 1])
+    assert s.comm_info()["transport"] == "rccl" and s.comm_info()["nranks"] == 2
+    a, ta = g.optimize_lm()
+    b, tb = s.optimize_lm()
+    assert ta == tb and len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x.step_is_successful == y.step_is_successful and abs(x.cost - y.cost) <= 1e-9 * x.cost
