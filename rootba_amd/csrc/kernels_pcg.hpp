@@ -54,7 +54,7 @@ constexpr int kSpmvChunksPerItem = 4;  // 64-block chunks walked by one wavefron
 // p.q needs no complete q: it is the sum over stored blocks of w p_c^T S_cj p_j with w = 2 off the diagonal.
 // Half the bytes per product (venice-1778: 35 instead of 70 MB), half the all-reduce of a sharded assembly.
 // A camera with very many neighbours it does not own (dense co-visibility: a landmark seen by most cameras connects them
-// all) would have one work-item gather hundreds of slots: above kHalfLowerMax the slots of such a HEAVY row are summed by
+// all) would have one work-item gather hundreds of slots: above kHalfLowerMax (RBA_HALF_LOWER_MAX) the slots of such a HEAVY row are summed by
 // a wavefront of its own right behind the product (k_pcgs_reduce_slots) into one more "further item" of the row.
 // (Round 4's first form stored such blocks in both rows instead: on a nearly dense matrix - venice with heavy-tailed
 // track lengths - that was full storage, 2 GB per product instead of 1 GB.)
@@ -663,7 +663,9 @@ __global__ __launch_bounds__(256) void k_pcgs_direction(const S* __restrict__ z,
           st->beta = beta;
           st->cur = it + 1;
         }
-        if (host_progress) __hip_atomic_store(host_progress, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (RELEASE: the zeta words above are visible to a host that has seen this progress value - it reads them behind an
+        //  acquire fence, Solver::pcg; all ranks must take the same early-switch decision)
+        if (host_progress) __hip_atomic_store(host_progress, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }

@@ -595,8 +595,8 @@ __global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const S* __restrict__ t
   if (threadIdx.x < 81) {
     const int a = threadIdx.x / 9, b = threadIdx.x - 9 * a;
     const S v = -(((tile[0][a][b] + tile[1][a][b]) + tile[2][a][b]) + tile[3][a][b]);
-    // (half storage, kernels_pcg.hpp: the block lives in the row of its owner - as S_cd in row c, as S_dc in row d -
-    //  or, for very dense rows, in both; -1 = not stored there)
+    // (half storage, kernels_pcg.hpp: the block lives in the row of its owner - as S_cd in row c OR as S_dc in row d;
+    //  -1 = not stored there. Full storage of the explicit-SC backend: both.)
     const int us = upper_slot[u], m = mirror_slot[u];
     if (us >= 0) vals[size_t(81) * us + threadIdx.x] = v;
     if (m >= 0) vals[size_t(81) * m + 9 * b + a] = v;

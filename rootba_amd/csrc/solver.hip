@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <condition_variable>
@@ -2475,6 +2476,7 @@ class Solver final : public rba_solver {
           if (!(running = started(it))) break;
           tested = true;
           float z3, z4;
+          std::atomic_thread_fence(std::memory_order_acquire);  // (pairs with the release store of the progress word)
           const int b3 = hp[2], b4 = hp[3];
           std::memcpy(&z3, &b3, sizeof z3);
           std::memcpy(&z4, &b4, sizeof z4);
@@ -3247,8 +3249,8 @@ class Solver final : public rba_solver {
                                        // over the ranks (default: where the estimate says it pays)
     int hx_wide_inside = 1;            // RBA_HX_WIDE_INSIDE=0: landmarks with 32 < k <= 64 in a kernel of their own
     int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels
-    int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: earlier neighbours above which a camera's row of
-                                              // the assembled matrix is stored in full (tests of that path)
+    int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: received slots above which a row of the assembled
+                                              // matrix has them summed by a wavefront of its own (k_pcgs_reduce_slots)
   };
   DebugEnv env_;
   void read_debug_env() {
@@ -3358,7 +3360,7 @@ class Solver final : public rba_solver {
   DevBuf<int> d_ex_rowptr_, d_ex_cols_, d_ex_diag_, d_ex_upper_, d_ex_mirror_, d_ex_pair_oi_, d_ex_pair_oj_;
   DevBuf<int64_t> d_ex_pair_ptr_;
   DevBuf<double> d_ex_vals_;  // always double (assemble_values), half storage (kernels_pcg.hpp)
-  DevBuf<double> d_tpart_;    // [9 nnz] transposed contributions of the blocks right of the diagonal, per product
+  DevBuf<double> d_tpart_;    // [9 n_slots] transposed contributions of the blocks other rows own, per product
   DevBuf<int> d_low_ptr_, d_tdst_;
   DevBuf<rba::HeavyRow> d_heavy_;  // rows whose received slots are summed by a wavefront of their own
   int n_heavy_ = 0;

@@ -232,7 +232,9 @@ def test_config3_trafalgar257_f32_increment_vectors_default_configuration():
         #  threshold for the last twenty iterations) - its increment is then 1.55e-3 from the float64 iterate against the
         #  float32 oracle's 1.39e-3, inside the accuracy assertions below, which are what this test is about. Counts
         #  within 10 %, the bound VERDICT round 3 set for counts at this length.)
-        assert r["termination"] == 1 and abs(r["cg_gpu"] - r["cg_oracle"]) <= max(1, r["cg_oracle"] // 10), r
+        #  Solves of up to 60 iterations: the oracle's count exactly.
+        band = 0 if r["cg_oracle"] <= 60 else max(1, r["cg_oracle"] // 10)
+        assert r["termination"] == 1 and abs(r["cg_gpu"] - r["cg_oracle"]) <= band, r
         assert r["cost_rel"] < 2e-6 and r["hx_rel"] < 1e-5 and r["l_diff_rel"] < 2e-3, r
         assert r["inc_rel"] <= 2 * r["oracle32_vs_f64"] + 2e-4, r
         assert r["gpu_vs_f64"] <= 1.5 * r["oracle32_vs_f64"] + 1e-4, r

@@ -688,14 +688,15 @@ def test_schur_complement_unsupported_combinations(small_problem):
 
 # ---- explicit reduced matrix of the square-root solver (rba_options.explicit_after) -------------
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("which", ["small", "mixed", "long", "small-full-rows"])
+@pytest.mark.parametrize("which", ["small", "mixed", "long", "small-heavy-rows"])
 def test_explicit_reduced_matrix_is_the_same_operator(small_problem, mixed_k_problem, long_track_problem, dtype, which,
                                                       monkeypatch):
     """S = sum_l A_l^T A_l assembled block-wise in double (float solver: from the float factors, kernels_a64.hpp) in
     HALF storage (a block right of the diagonal is multiplied twice, its transposed product travels through a slot:
-    kernels_pcg.hpp) applies like the matrix-free product and like the oracle. "small-full-rows": cameras with more
-    than three earlier neighbours keep their blocks left of the diagonal as well (the path of very dense rows)."""
-    if which == "small-full-rows":
+    kernels_pcg.hpp) applies like the matrix-free product and like the oracle. "small-heavy-rows": a camera that receives
+    more than three slots has them summed by a wavefront of its own right behind the product (k_pcgs_reduce_slots: the
+    path of very dense rows; no block is stored twice)."""
+    if which == "small-heavy-rows":
         monkeypatch.setenv("RBA_HALF_LOWER_MAX", "3")
         which = "small"
     prob = {"small": small_problem, "mixed": mixed_k_problem, "long": long_track_problem}[which]

@@ -108,8 +108,9 @@ def test_shard_ranges_balance_bytes():
     for n in (1, 2, 4, 8):
         r = shard_ranges(k, n)
         assert r[0][0] == 0 and r[-1][1] == k.size and all(a[1] == b[0] for a, b in zip(r, r[1:]))
-        w = np.array([(k[a:b].astype(float) ** 2).sum() for a, b in r])
-        assert w.max() / w.mean() < 1.05
+        # (the layout's bytes per landmark: ~120 per observation + ~100, as rba_create_sharded balances inside the library)
+        w = np.array([(120.0 * k[a:b].astype(float) + 100.0).sum() for a, b in r])
+        assert w.max() / w.mean() < 1.01
 
 
 def test_shard_ranges_never_empty():
