@@ -293,6 +293,12 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   using M = Mfma<double>;
   using Acc = typename M::acc;
   constexpr int U = 4;  // (2: same time, 8: 1.6 x slower - registers)
+  // Counters (profiles/r5_pmc_a64_offdiag.csv, round 5): per v_mfma_f64_16x16x4 the kernel issues 23 VALU, 4.4 LDS and
+  // 3 scalar instructions; the LDS is its busiest unit (SQ_LDS_IDX_ACTIVE 59 % of the CU cycles, 9 % of that bank
+  // conflicts), the VALU ~46 %, the matrix pipe 32 % (a v_mfma_f64_16x16x4 holds it for 64 cycles: 12.5 M of them are
+  // exactly the 803 M busy cycles counted) - no unit is saturated, a wavefront is a chain of LDS round trip -> operand
+  // arithmetic -> dependent matrix instruction. Four accumulator chains instead of two (160 instead of 128 + 16 registers,
+  // one wavefront per SIMD less): 1160 -> 1287 us, reverted.
   __shared__ double tile[4][16][16];
   __shared__ __attribute__((aligned(16))) double stage[4][U][8][kA64Rec];
   const int lane = threadIdx.x & 63;
@@ -300,9 +306,7 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   const int u = xcd_swizzled_camera(n_upper);
   if (u >= n_upper) return;
   const int i = lane & 15, kk = lane >> 4;
-  // (four accumulators: a v_mfma_f64_16x16x4 holds its SIMD's matrix pipe for 64 cycles and its result for about as
-  //  long again - with two chains a wavefront alone kept the pipe a third busy, profiles/r5_pmc_a64_offdiag.csv)
-  Acc accs[U] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  Acc acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
   const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
   const int rec = lane >> 3, vec = lane & 7;
   const int* __restrict__ pair_side = rec < 4 ? pair_oi : pair_oj;
@@ -353,7 +357,10 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
           av = fma(ri[kA64RecW + 2 * c], double(fi[i]), ri[kA64RecW + 2 * c + 1] * double(fi[9 + i]));
           bv = fma(rj[kA64RecW + 2 * c], double(fj[i]), rj[kA64RecW + 2 * c + 1] * double(fj[9 + i]));
         }
-        accs[uq] = M::mma(av, bv, accs[uq]);
+        if (uq & 1)
+          acc2 = M::mma(av, bv, acc2);
+        else
+          acc = M::mma(av, bv, acc);
       }
     wave_lds_fence();  // the next step overwrites the staging buffer
 #pragma unroll
@@ -362,9 +369,8 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
       o_next[uq] = o_next2[uq];
     }
   }
-  Acc acc;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = (accs[0][r] + accs[1][r]) + (accs[2][r] + accs[3][r]);
+  for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][M::row(lane, r)][i] = acc[r];
   __syncthreads();
