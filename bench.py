@@ -520,14 +520,21 @@ def main():
         t_err = sum(r.residual_time for r in timed)
         t_pcg = sum(r.pcg_time for r in timed)
         n_cg = sum(r.cg_iterations for r in timed)
-        n_err = sum(2 if r.stage1_time > 0 else 1 for r in timed)
+        # (cost evaluations the timed steps launched, counted by the library: since round 5 the LM loop reuses the trial
+        #  evaluation of an accepted step - one per step)
+        n_err = pcg_cnt.get("cost_evaluations") or sum(2 if r.stage1_time > 0 else 1 for r in timed)
         b_iter = (bytes_model["stage1"] * n_lin + bytes_model["stage2"] * n_t + bytes_model["back_substitution"] * n_t +
                   bytes_model["compute_error"] * n_err)
         # the PCG phase priced with what it executed (rba_get_pcg_counters): products on either operator, assemblies
         # of the reduced matrix, the vector / preconditioner work of every iteration
+        # (products the persistent kernel executed out of the register files move no matrix bytes: such a solve is
+        #  priced with the one load of the matrix and the records its iterations exchange)
+        res_p, res_i = pcg_cnt.get("products_assembled_resident", 0), pcg_cnt.get("iterations_resident", 0)
         b_pcg = (pcg_cnt["products_matrix_free"] * bytes_model["product_matrix_free"] +
-                 pcg_cnt["products_assembled"] * bytes_model["product_assembled"] +
-                 pcg_cnt["assemblies"] * bytes_model["assembly"] + pcg_cnt["iterations"] * bytes_model["pcg_vectors"])
+                 (pcg_cnt["products_assembled"] - res_p) * bytes_model["product_assembled"] +
+                 pcg_cnt.get("solves_persistent", 0) * bytes_model.get("persistent_solve", 0) +
+                 res_i * bytes_model.get("persistent_iteration", 0) +
+                 pcg_cnt["assemblies"] * bytes_model["assembly"] + (pcg_cnt["iterations"] - res_i) * bytes_model["pcg_vectors"])
         stages = {
             "stage1": {"bytes_per_launch": bytes_model["stage1"], "ms": 1e3 * t_s1 / max(1, n_lin),
                        "frac": frac(bytes_model["stage1"] * n_lin, t_s1)},

@@ -352,6 +352,9 @@ typedef struct rba_byte_model {
   int64_t assembly;            /* one assembly of the reduced camera matrix                   */
   int64_t pcg_vectors;         /* vector / preconditioner work of one PCG iteration           */
   int64_t back_substitution;   /* back-substitution + landmark update                         */
+  int64_t persistent_solve;    /* persistent PCG kernel (kernels_pcgp.hpp), once per solve: the matrix into the
+                                  register files (full storage), row state, M^-1; 0 when the matrix does not fit */
+  int64_t persistent_iteration;/* ... and per iteration: the exchanged records of z and of the partial sums */
 } rba_byte_model;
 int rba_get_byte_model(rba_handle h, rba_byte_model* out);
 /* What the PCG solves since rba_create actually executed (launches queued past a solve's termination are no-ops and
@@ -366,6 +369,10 @@ typedef struct rba_pcg_counters {
   int64_t early_switches;              /* solves switched to the assembled matrix at iteration 5 (rising zeta) */
   int64_t solves_persistent;           /* solves whose iterations on the assembled matrix ran as ONE persistent kernel
                                           with the matrix in the register files (kernels_pcgp.hpp) */
+  int64_t products_assembled_resident; /* ... the part of products_assembled those solves executed (no matrix bytes moved) */
+  int64_t iterations_resident;         /* ... and of iterations (their vector work stays on chip) */
+  int64_t cost_evaluations;            /* cost evaluations launched (the LM loop reuses the trial evaluation of an
+                                          accepted step instead of repeating it) */
 } rba_pcg_counters;
 int rba_get_pcg_counters(rba_handle h, rba_pcg_counters* out);
 

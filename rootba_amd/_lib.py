@@ -129,11 +129,13 @@ EXPORTS = [
 
 class RbaByteModel(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("compute_error", "stage1", "stage2", "product_matrix_free",
-                                         "product_assembled", "assembly", "pcg_vectors", "back_substitution")]
+                                         "product_assembled", "assembly", "pcg_vectors", "back_substitution",
+                                         "persistent_solve", "persistent_iteration")]
 
 class RbaPcgCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("products_matrix_free", "products_assembled", "assemblies", "iterations",
-                                         "solves_repeated_matrix_free", "early_switches", "solves_persistent")]
+                                         "solves_repeated_matrix_free", "early_switches", "solves_persistent",
+                                         "products_assembled_resident", "iterations_resident", "cost_evaluations")]
 
 _lib = None
 

@@ -1669,6 +1669,7 @@ class Solver final : public rba_solver {
   // linearisation that is queued right behind it: a 0.3-of-roofline gather pass beside a streaming one); joined before the
   // state is touched again (join_side) and at every synchronisation. One rank only (no collective on the side stream).
   void compute_error_enqueue(double* h, bool side = false) {
+    ++pcg_counters_.cost_evaluations;
     side = side && results_go_direct();
     hipStream_t st = side ? side_stream_ : stream_;
     double* part = side ? d_partials_side_.get() : d_partials_.get();
@@ -2632,6 +2633,7 @@ class Solver final : public rba_solver {
           persistent = false;
         } else {
           ++pcg_counters_.solves_persistent;
+          pcg_last_persistent_ = true;
         }
       }
       if (!persistent) {
@@ -2642,6 +2644,7 @@ class Solver final : public rba_solver {
     }
     ex_active_ = false;
     pcg_collect(&summary, it_first_assembled);
+    pcg_last_persistent_ = false;
     return summary;
   }
 
@@ -2661,8 +2664,14 @@ class Solver final : public rba_solver {
       const int64_t series = opt_.preconditioner_type == 2 ? opt_.power_order : 0;  // products of the preconditioner
       pcg_counters_.iterations += n_it;
       pcg_counters_.products_matrix_free += mf_it + mf_it / 10 + (pcg_used_explicit_ || sc_ ? 0 : series * mf_it);
-      pcg_counters_.products_assembled += as_it > 0 ? as_it + (n_it / 10 - mf_it / 10) + (it_switch > 1 ? 1 : 0) + series * as_it
-                                                    : 0;
+      const int64_t as_products = as_it > 0 ? as_it + (n_it / 10 - mf_it / 10) + (it_switch > 1 ? 1 : 0) + series * as_it : 0;
+      pcg_counters_.products_assembled += as_products;
+      // (persistent kernel: the matrix is read ONCE per solve and multiplied out of the register files - these products
+      //  move no matrix bytes; rba_byte_model.persistent_solve / .persistent_iteration price such a solve)
+      if (pcg_last_persistent_) {
+        pcg_counters_.products_assembled_resident += as_products;
+        pcg_counters_.iterations_resident += as_it > 0 ? as_it : 0;
+      }
     }
     *out = summary;
   }
@@ -3091,6 +3100,11 @@ class Solver final : public rba_solver {
     const int64_t ms = sc_ ? s : int64_t(sizeof(double));  // the assembled matrix of the square-root solver is double
     m->product_assembled = nnz * (81 * ms + 4) + nc * 18 * s;
     m->pcg_vectors = nc * (81 + 10 * 9) * s;
+    // persistent kernel (kernels_pcgp.hpp): per solve the FULL-storage matrix once (2 nnz - n_c blocks of 81 doubles out
+    // of the half-storage one), the row state and M^-1; per iteration only the exchanged records - 16 bytes per three
+    // entries of z (one per entry in double), the partial sums in their replicas
+    m->persistent_solve = pg_ready_ ? (2 * nnz - nc) * 81 * 8 + nc * (81 + 4 * 9) * s : 0;
+    m->persistent_iteration = pg_ready_ ? nc * rba::pg_vec_records<S>() * 16 * 2 + int64_t(pg_G_) * 3 * 16 * (1 + rba::kPgReplicas) : 0;
     if (!sc_) {
       // half storage: the transposed parts (9 doubles per block off the diagonal) + their slot index go out with the
       // product and come back in with the vector kernel that consumes q
@@ -3384,7 +3398,7 @@ class Solver final : public rba_solver {
   rba_pcg_counters pcg_counters_{};
   hipGraphExec_t pcg_graph_exec_[2] = {nullptr, nullptr};
   // persistent PCG with the matrix in the register files (kernels_pcgp.hpp)
-  bool pg_ready_ = false, pg_broken_ = false;
+  bool pg_ready_ = false, pg_broken_ = false, pcg_last_persistent_ = false;
   int pg_G_ = 0;
   unsigned pg_epoch_ = 1;  // tag base of the next solve: tags never repeat between launches
   DevBuf<rba::PgWorkgroup> d_pg_wg_;
