@@ -237,9 +237,16 @@ __device__ __forceinline__ bool pg_unpack_vec(const pg_rec (&r)[9], pg_u32 tag, 
   return ok;
 }
 
+// Block rows kept in LDS instead of registers (float solver: two of the nine - 36 registers that the row wave's step needs
+// to hold the row's state across the gather of p.q; the double solver's vectors leave no LDS for them)
+template <class S>
+constexpr int pg_lds_rows() {
+  return sizeof(S) == 4 ? 2 : 0;
+}
 template <class S>
 constexpr size_t pgp_lds_bytes() {
-  return size_t(3) * kPgThreads * 9 * sizeof(S)   // pst, zst, minv
+  return size_t(pg_lds_rows<S>()) * 9 * kPgThreads * sizeof(double)  // blkl
+         + size_t(3) * kPgThreads * 9 * sizeof(S)   // pst, zst, minv
          + size_t(5) * kPgThreads * sizeof(S)     // xs, rs, bs, pcs, qss
          + size_t(kPgQuads) * 9 * sizeof(double)  // red
          + 24 * sizeof(double)                    // bc, gs, wpq
@@ -282,7 +289,9 @@ template <class S>
 __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   constexpr int NR = pg_vec_records<S>();
   extern __shared__ __attribute__((aligned(16))) char smem_pg[];
-  S* pst = reinterpret_cast<S*>(smem_pg);   // [512][9] direction p of the staged columns (kept across iterations)
+  constexpr int LR = pg_lds_rows<S>(), RR = 9 - LR;  // block rows in LDS / in registers
+  double* blkl = reinterpret_cast<double*>(smem_pg);  // [LR * 9][512] the last LR rows of every lane's block, entry-major
+  S* pst = reinterpret_cast<S*>(blkl + LR * 9 * kPgThreads);  // [512][9] direction p of the staged columns (kept across iterations)
   S* zst = pst + kPgThreads * 9;            // [512][9] z of the staged columns; x during a refresh product
   S* minv = zst + kPgThreads * 9;           // [512][9] row a of M^-1 of row output j = 9 row + a
   S* xs = minv + kPgThreads * 9;            // [512]    x, r, b of the row outputs; p_c and q_c of the current iteration
@@ -313,8 +322,8 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   if (st->done) return;  // (uniform over the grid: nobody writes the state before the end)
   if (tid < 2) sflag[tid] = 0;
 
-  // ---- the lane's block: 81 doubles, for the whole solve -----------------------------------------------------------
-  double blk[81];
+  // ---- the lane's block: 81 doubles for the whole solve - rows 0 .. RR - 1 in registers, the rest in LDS -----------------
+  double blk[9 * RR];
   {
     const double* v = P.vals + size_t(81) * size_t(act ? (src >> 1) : 0);
     const bool tr = (src & 1) != 0;
@@ -323,7 +332,11 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
 #pragma unroll
       for (int bb = 0; bb < 9; ++bb) {
         const double t = v[tr ? 9 * bb + a : 9 * a + bb];
-        blk[9 * a + bb] = act ? t : 0.0;
+        const double e = act ? t : 0.0;
+        if (a < RR)
+          blk[9 * a + bb] = e;
+        else
+          blkl[(9 * (a - RR) + bb) * kPgThreads + tid] = e;
       }
   }
   // ---- state -----------------------------------------------------------------------------------------------------
@@ -378,7 +391,9 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
         for (int u = 0; u < 3; ++u) {
           const double pv = double(pg_dir(zz[u], bsel, pp[u]));
 #pragma unroll
-          for (int a = 0; a < 9; ++a) acc[a] += blk[9 * a + b0 + u] * pv;
+          for (int a = 0; a < RR; ++a) acc[a] += blk[9 * a + b0 + u] * pv;
+#pragma unroll
+          for (int a = RR; a < 9; ++a) acc[a] += blkl[(9 * (a - RR) + b0 + u) * kPgThreads + tid] * pv;
         }
       }
     }
@@ -690,6 +705,27 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       const double s0 = ((wpq[0] + wpq[1]) + (wpq[2] + wpq[3])) + ((wpq[4] + wpq[5]) + (wpq[6] + wpq[7]));
       if (lane < kPgReplicas) pg_rec_store(P.part_pq + size_t(lane) * G + g, pg_pack(s0, tag));
       stamp(4);
+      // ---- while the partial sums travel: what the step needs of the row's state, into registers (float solver, every
+      //      record of the workgroup in one pass). Behind the gather the step is then nine fused multiply-adds, the row's
+      //      M^-1 (one LDS round trip) and the records - not three LDS round trips in a row.
+      const bool fast = NR == 3 && !refresh && NR * W.nrows <= 64;
+      unsigned fl = unsigned(lane);
+      PG_OPAQUE(fl);  // (or every LDS address of this path is computed ahead of the loop and kept - i.e. spilled)
+      const int ft = int(fl) < NR * W.nrows ? int(fl) : 0, frow = ft / 3, fk = ft - 3 * frow, fj0 = 9 * frow + 3 * fk;
+      S rr[9], qq[9], xx[3], pp[3], bb[3];
+      if (fast) {
+#pragma unroll
+        for (int b2 = 0; b2 < 9; ++b2) {
+          rr[b2] = rs[9 * frow + b2];
+          qq[b2] = qss[9 * frow + b2];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          xx[u] = xs[fj0 + u];
+          pp[u] = pcs[fj0 + u];
+          bb[u] = bs[fj0 + u];
+        }
+      }
       // ---- exchange 2: partial sums of p.q (four workgroups per lane) ---------------------------------------------------
       pg_u32 spins = 0;
       double a_pq = 0.0;
@@ -760,6 +796,38 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
           endi[3] = 1;
           __hip_atomic_store(sflag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+      } else if (fast) {
+        if constexpr (NR == 3) {
+          const S a_s = S(alpha);
+          S zc[3];
+#pragma unroll
+          for (int b2 = 0; b2 < 9; ++b2) rr[b2] -= a_s * qq[b2];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            xx[u] += a_s * pp[u];
+            S z = S(0);
+#pragma unroll
+            for (int b2 = 0; b2 < 9; ++b2) z += minv[9 * (fj0 + u) + b2] * rr[b2];
+            zc[u] = z;
+          }
+          double acc_rho = 0.0, acc_q = 0.0;
+          if (lane < NR * W.nrows) {
+            pg_rec_store(P.zg + size_t(NR) * size_t(W.row0 + frow) + fk, pg_pack3(float(zc[0]), float(zc[1]), float(zc[2]), tag + 1));
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const S r_i = fk == 0 ? rr[u] : fk == 1 ? rr[3 + u] : rr[6 + u];
+              acc_rho += double(r_i) * double(zc[u]);
+              acc_q -= double(xx[u]) * double(bb[u] + r_i);
+              xs[fj0 + u] = xx[u];
+              rs[fj0 + u] = r_i;
+            }
+          }
+          const double s0r = wave_sum(acc_rho), s1r = wave_sum(acc_q);
+          if (lane < 2 * kPgReplicas) {
+            const int rep = lane >> 1, k2 = lane & 1;
+            pg_rec_store(P.part_rq + (size_t(rep) * G + g) * 2 + k2, pg_pack(k2 ? s1r : s0r, tag + 1));
+          }
+        }
       } else {
         const S a_s = S(alpha);
         for (int j = lane; j < nout; j += 64) {
@@ -786,7 +854,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       if (roww)
         for (int j = lane; j < nout; j += 64) rs[j] = bs[j] - qss[j];
     }
-    if (roww && !my_stop) close_residual(tag + 1);
+    if (roww && !my_stop && !(NR == 3 && !refresh && NR * W.nrows <= 64)) close_residual(tag + 1);
     stamp(7);
     it = cur;
     need_test = 1;
