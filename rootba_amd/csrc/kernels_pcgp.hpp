@@ -70,7 +70,8 @@ struct PgParams {
   const unsigned short* lane_col;  // [G][512]  staged column (index into the workgroup's list) of the lane's block
   const int* stage_col;            // [G][512]  camera of staged column t; -1 beyond ncols
   const int* row_info;             // [n_c][3]  first quad of the row in its workgroup, quads, staged index of its own column
-  const double* vals;              // half storage [nnz][81]
+  const void* vals;                // [nnz][81]: double (half storage of the square-root solver) or the solver's scalar
+  int vals_solver_scalar;          //            (full storage of the explicit-SC backend)
   const S* inv;                    // M^-1 [n_c][81]
   const S* b;
   S* x;                            // in: iterate after `iter` iterations; out: the solution
@@ -325,13 +326,16 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   // ---- the lane's block: 81 doubles for the whole solve - rows 0 .. RR - 1 in registers, the rest in LDS -----------------
   double blk[9 * RR];
   {
-    const double* v = P.vals + size_t(81) * size_t(act ? (src >> 1) : 0);
-    const bool tr = (src & 1) != 0;
+    const size_t v0 = size_t(81) * size_t(act ? (src >> 1) : 0);
+    const double* vd = static_cast<const double*>(P.vals) + v0;
+    const S* vs = static_cast<const S*>(P.vals) + v0;
+    const bool tr = (src & 1) != 0, vss = P.vals_solver_scalar != 0;
 #pragma unroll
     for (int a = 0; a < 9; ++a)
 #pragma unroll
       for (int bb = 0; bb < 9; ++bb) {
-        const double t = v[tr ? 9 * bb + a : 9 * a + bb];
+        const int ei = tr ? 9 * bb + a : 9 * a + bb;
+        const double t = vss ? double(vs[ei]) : vd[ei];
         const double e = act ? t : 0.0;
         if (a < RR)
           blk[9 * a + bb] = e;

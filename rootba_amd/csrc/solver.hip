@@ -949,8 +949,19 @@ class Solver final : public rba_solver {
   // padded to whole quads of lanes; a workgroup holds at most 512 lanes and 56 rows. Not every matrix fits the chip's
   // register files (n_cus_ workgroups): `pg_ready_` says whether this one does. Deterministic from the (united)
   // structure: every rank of a sharded run derives the same tables.
+  // half storage of the square-root solver's assembled matrix: a block lives in the row of its owner
   void build_pcgp_structure(const std::vector<std::vector<int>>& nb, const std::vector<std::vector<int>>& slot_nb,
                             const std::vector<int>& diag) {
+    build_pcgp_structure(nb, [&](int c, int k) {  // 2 * slot + transposed of the block {c, nb[c][k]}; k < 0: the diagonal one
+      if (k < 0) return 2 * diag[c];
+      if (slot_nb[c][k] >= 0) return 2 * slot_nb[c][k];  // stored in row c as row c sees it
+      const int d = nb[c][k];
+      const int kk = int(std::lower_bound(nb[d].begin(), nb[d].end(), c) - nb[d].begin());
+      return 2 * slot_nb[d][kk] + 1;  // stored in row d: S_cd = S_dc^T
+    });
+  }
+  template <class SrcOf>
+  void build_pcgp_structure(const std::vector<std::vector<int>>& nb, SrcOf&& src_of) {
     pg_ready_ = false;
     pg_G_ = 0;
     if (env_.pcg_persistent == 0) return;
@@ -1010,17 +1021,11 @@ class Solver final : public rba_solver {
         };
         for (size_t k = 0; k <= nb[c].size(); ++k) {
           if (!diag_done && (k == nb[c].size() || nb[c][k] > c)) {
-            put(c, 2 * diag[c]);
+            put(c, src_of(c, -1));
             diag_done = true;
           }
           if (k == nb[c].size()) break;
-          const int d = nb[c][k];
-          if (slot_nb[c][k] >= 0) {
-            put(d, 2 * slot_nb[c][k]);  // stored in row c as row c sees it
-          } else {
-            const int kk = int(std::lower_bound(nb[d].begin(), nb[d].end(), c) - nb[d].begin());
-            put(d, 2 * slot_nb[d][kk] + 1);  // stored in row d: S_cd = S_dc^T
-          }
+          put(nb[c][k], src_of(c, int(k)));
         }
         lane = (lane + 3) & ~3;
       }
@@ -1051,7 +1056,7 @@ class Solver final : public rba_solver {
     pg_ready_ = true;
     if (env_.verbose)
       std::fprintf(stderr, "[rootba_hip] persistent PCG: %d workgroups of %d lanes for %d blocks in full storage\n", G, T,
-                   2 * ex_nnz_ - nc);
+                   sc_ ? sc_nnz_ : 2 * ex_nnz_ - nc);
   }
 
   // work items of the fused PCG's SpMV (kernels_pcg.hpp): one wavefront per block row, rows with
@@ -1249,6 +1254,8 @@ class Solver final : public rba_solver {
     };
     sc_nnz_ = nnz;
     build_spmv_items(row_ptr, rba::spmv_chunk_blocks<S>() * rba::kSpmvChunksPerItem, nullptr);
+    // (persistent PCG: the Schur complement is stored in full, in the solver's scalar)
+    build_pcgp_structure(nb, [&](int c, int k) { return 2 * (k < 0 ? diag[c] : slot_of(int(c), nb[c][k])); });
     // upper blocks (ci <= cj; cameras ascend inside a landmark, so i <= j) and, per upper
     // block, the list of contributing observation pairs (counting sort, landmark order)
     std::vector<int> upper_of(size_t(nnz), -1), upper_slot, mirror_slot;
@@ -2215,7 +2222,7 @@ class Solver final : public rba_solver {
   bool pcg_persistent_possible() const {
     // (two ranks that share a device - the callback transport of the tests - would each wait for workgroups the other
     //  one's resident workgroups keep off the CUs; the power series and the explicit-SC backend keep the two-launch path)
-    return pg_ready_ && !pg_broken_ && !sc_ && !series_fused() && !split_ && !cb_fn_;
+    return pg_ready_ && !pg_broken_ && !series_fused() && !split_ && !cb_fn_;
   }
   void pcg_persistent(int it_start) {
     rba::PgParams<S> P{};
@@ -2224,7 +2231,8 @@ class Solver final : public rba_solver {
     P.lane_col = d_pg_lane_col_.get();
     P.stage_col = d_pg_stage_col_.get();
     P.row_info = d_pg_row_info_.get();
-    P.vals = d_ex_vals_.get();
+    P.vals = sc_ ? static_cast<const void*>(scp_.vals) : static_cast<const void*>(d_ex_vals_.get());
+    P.vals_solver_scalar = sc_ ? 1 : 0;
     P.inv = d_inv_.get();
     P.b = prm_.b;
     P.x = d_x_.get();
@@ -2622,6 +2630,8 @@ class Solver final : public rba_solver {
     if (go_fused) {
       bool persistent = pcg_persistent_possible();
       if (persistent) {
+        // (explicit-SC backend: the state comes from k_pcg_init, the damping is inside the matrix)
+        if (sc_) hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, st, double(lambda), 0);
         pcg_persistent(it);
         HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
         sync();

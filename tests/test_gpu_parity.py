@@ -919,26 +919,29 @@ def test_matrix_free_repeat_after_assembled_operator_breakdown(ladybug_far, prec
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("which", ["ladybug", "small", "mixed"])
+@pytest.mark.parametrize("which", ["ladybug", "small", "mixed", "ladybug-schur-complement"])
 def test_persistent_pcg_is_the_two_launch_pcg(ladybug_far, small_problem, mixed_k_problem, dtype, which, monkeypatch):
     """The PCG on the assembled matrix as ONE persistent kernel with the matrix in the register files
     (kernels_pcgp.hpp) against the two-launch form (kernels_pcg.hpp, RBA_PCG_PERSISTENT=0): same recurrence, same
     operator, other summation orders - identical iteration counts, increments equal to rounding (float64) / to what
     float32 resolves, over solves that cross the residual refresh; and the same LM run."""
     from rootba_amd import _lib as L
-    prob = {"ladybug": ladybug_far, "small": small_problem, "mixed": mixed_k_problem}[which]
+    # ("-schur-complement": the explicit-SC backend - its matrix is stored in full, in the solver's scalar, and the PCG
+    #  runs on it from the first iteration)
+    extra = dict(solver_type=1) if which.endswith("-schur-complement") else {}
+    prob = {"ladybug": ladybug_far, "small": small_problem, "mixed": mixed_k_problem}[which.split("-")[0]]
     out = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("RBA_PCG_PERSISTENT", mode)
         rows = []
         for eta, lam in ((1e-3, 1e-5), (1e-7 if dtype == np.float64 else 1e-4, 1e-4)):
-            g, _ = _pair(prob, dtype, explicit_after=1, eta=eta, max_cg_it=60)
+            g, _ = _pair(prob, dtype, explicit_after=1, eta=eta, max_cg_it=60, **extra)
             assert g.linearize() == 0
             inc, cg = g.solve(lam)
             cnt = g.pcg_counters()
             assert cnt["solves_persistent"] == (1 if mode == "1" else 0), (mode, cnt)
             rows.append((inc, cg.num_iterations, cg.termination_type))
-        g2, _ = _pair(prob, dtype, explicit_after=1, max_num_iterations=5)
+        g2, _ = _pair(prob, dtype, explicit_after=1, max_num_iterations=5, **extra)
         out[mode] = (rows, g2.optimize_lm()[0])
     for (i0, n0, t0), (i1, n1, t1) in zip(out["0"][0], out["1"][0]):
         assert t0 == t1
