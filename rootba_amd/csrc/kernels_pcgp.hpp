@@ -79,11 +79,14 @@ struct PgParams {
   const S* p_in;                   // direction of the last completed iteration
   pg_rec* zg;                      // [n_c][3 | 9] records of z
   pg_rec* xg;                      // [n_c][3 | 9] records of x (refresh product)
+  pg_rec* tg;                      // [2][n_c][3 | 9] records of the power-series term t, two buffers by the parity of the term
   pg_rec* part_rq;                 // [8][G][2]  partial sums of rho and Q, eight replicas
   pg_rec* part_pq;                 // [8][G]     partial sums of p.q
   CgState* st;
   int* host_progress;              // pinned: [1] done, [4] aborted
   pg_u32 tag_base;
+  int tag_stride;                  // tags per iteration: 1 + series + 1 (tag_base + iteration * stride: z, sums, x; + i: term i)
+  int series;                      // terms of the power-series preconditioner behind z = M^-1 r (0: block-diagonal M^-1 alone)
   int G, n_cams;
   int switch_operator;             // the solve ran matrix-free so far: r = b - (S + lambda I) x first (like the refresh)
   double q_tolerance;
@@ -248,7 +251,7 @@ template <class S>
 constexpr size_t pgp_lds_bytes() {
   return size_t(pg_lds_rows<S>()) * 9 * kPgThreads * sizeof(double)  // blkl
          + size_t(3) * kPgThreads * 9 * sizeof(S)   // pst, zst, minv
-         + size_t(5) * kPgThreads * sizeof(S)     // xs, rs, bs, pcs, qss
+         + size_t(6) * kPgThreads * sizeof(S)     // xs, rs, bs, pcs, qss, ts
          + size_t(kPgQuads) * 9 * sizeof(double)  // red
          + 24 * sizeof(double)                    // bc, gs, wpq
          + size_t(3) * kPgMaxRows * sizeof(int)   // rowtab
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   S* bs = rs + kPgThreads;
   S* pcs = bs + kPgThreads;                 //          (also: z of the row outputs on its way into the records)
   S* qss = pcs + kPgThreads;
-  double* red = reinterpret_cast<double*>(qss + kPgThreads);  // [128][9] quad sums of the block products
+  S* ts = qss + kPgThreads;                 //          the current term of the power series
+  double* red = reinterpret_cast<double*>(ts + kPgThreads);  // [128][9] quad sums of the block products
   double* bc = red + kPgQuads * 9;                            // [3] rho_prev [4] q_prev; at the end [0] beta [1] rho [2] q1 [5] p.q [6] alpha
   double* gs = bc + 8;                                        // [4][2] sums of rho and Q partial sums of the four polling waves
   double* wpq = gs + 8;                                       // [8] p.q of the row outputs summed by the waves that formed them
@@ -415,7 +419,8 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
   // dot product, summed per wave (wpq); otherwise (refresh) q_c = sum + lambda x_c. The caller puts the barrier.
   // (`rcon`: first quad | quads << 8 | staged own column << 16 | a << 28 of the work-item's output in the first chunk -
   //  the table lookup would be an LDS round trip ahead of the sums)
-  auto rowsums = [&](bool direction, S bsel) {
+  auto rowsums = [&](int mode, S bsel) {  // 0: direction, 1: refresh (operand x), 2: term of the power series (operand t)
+    const bool direction = mode == 0;
     const int part = tid & 3;
     double my_pq = 0.0;
     for (int cb = 0; cb < nout; cb += kPgThreads / 4) {
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
         nq = rowtab[3 * row + 1];
         self = rowtab[3 * row + 2];
       }
-      const S zc = zst[9 * self + a], po = pst[9 * self + a], xc = xs[jj];  // (all loads ahead of the sums)
+      const S zc = zst[9 * self + a], po = pst[9 * self + a], xc = mode == 2 ? ts[jj] : xs[jj];  // (all loads ahead of the sums)
       double q = 0.0;
       for (int k0 = part; k0 < nq; k0 += 24) {  // (six loads in flight: ONE pass for rows of up to 96 blocks)
         double v[6];
@@ -473,26 +478,31 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       pg_rec_store(dst + size_t(NR) * size_t(W.row0 + row) + k, r);
     }
   };
-  // row wave: z = M^-1 r, partial sums of rho = r.z and Q = -x.(b + r), published for the iteration with tag `tagn`
-  auto close_residual = [&](pg_u32 tagn) {
+  // row wave: z = M^-1 r (the power series: its first term t as well)
+  auto close_first_term = [&]() {
     wave_lds_fence();  // (rs of the other lanes)
-    double acc_rho = 0.0, acc_q = 0.0;
     for (int j0 = lane; j0 < nout; j0 += 128) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {  // (two outputs per pass: their LDS round trips overlap)
         const int j = j0 + 64 * u;
         if (j < nout) {
-          const int row = j / 9;
-          const S* rc = rs + 9 * row;
+          const S* rc = rs + 9 * (j / 9);
           S zc = S(0);
 #pragma unroll
           for (int b2 = 0; b2 < 9; ++b2) zc += minv[9 * j + b2] * rc[b2];
           pcs[j] = zc;
-          const S r_i = rs[j], x_i = xs[j];
-          acc_rho += double(r_i) * double(zc);
-          acc_q -= double(x_i) * double(bs[j] + r_i);
+          ts[j] = zc;
         }
       }
+    }
+  };
+  // row wave: the partial sums of rho = r.z and Q = -x.(b + r) and z itself, published for the iteration with tag `tagn`
+  auto close_publish = [&](pg_u32 tagn) {
+    double acc_rho = 0.0, acc_q = 0.0;
+    for (int j = lane; j < nout; j += 64) {
+      const S r_i = rs[j], x_i = xs[j];
+      acc_rho += double(r_i) * double(pcs[j]);
+      acc_q -= double(x_i) * double(bs[j] + r_i);
     }
     publish_vec(P.zg, pcs, tagn);
     const double s0 = wave_sum(acc_rho), s1 = wave_sum(acc_q);
@@ -574,6 +584,46 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
           wall_clock64();  // (s_memrealtime: 100 MHz, ONE counter for the chip - stamps of different workgroups compare)
   };
 
+  // EVERYBODY: z = M^-1 r of the workgroup's rows for the iteration with tag `tagn`. With the power-series preconditioner
+  // (PowerSCPreconditioner::solve_assign, src/rootba/cg/preconditioner.hpp:180-192, through the matrix as in
+  // k_pcgs_series_step): z = sum_i t_i, t_0 = Hpp^-1 r, t_i = t_i-1 - Hpp^-1 (S + lambda I) t_i-1 - a product per term,
+  // whose operand travels like z in one of TWO record buffers (parity of the term: a workgroup that writes term i + 2
+  // has read term i + 1 of all its neighbours, who wrote it after reading its term i - the matrix is structurally
+  // symmetric, so whoever reads my rows is read by me). Returns false when the kernel has to end.
+  auto close_all = [&](pg_u32 tagn) -> bool {
+    const bool live = roww && !my_stop;
+    if (live) close_first_term();
+    for (int i = 1; i <= P.series; ++i) {
+      const pg_u32 ttag = tagn - pg_u32(P.tag_stride) + pg_u32(i);
+      pg_rec* tb = P.tg + ((i & 1) ? size_t(0) : size_t(NR) * size_t(P.n_cams));
+      if (live) publish_vec(tb, ts, ttag);
+      if (wave_stages) stage_vector(tb, ttag);
+      __syncthreads();
+      if (pg_flag(sflag) != 0) return false;
+      if (pg_flag(sflag + 1) != 0) {
+        if (roww) finish();
+        return false;
+      }
+      product(S(0));
+      __syncthreads();
+      rowsums(2, S(0));
+      __syncthreads();
+      if (live) {
+        for (int j = lane; j < nout; j += 64) {
+          const S* wc = qss + 9 * (j / 9);
+          S v = S(0);
+#pragma unroll
+          for (int b2 = 0; b2 < 9; ++b2) v += minv[9 * j + b2] * wc[b2];
+          const S tn = ts[j] - v;
+          ts[j] = tn;
+          pcs[j] += tn;
+        }
+      }
+    }
+    if (live) close_publish(tagn);
+    return true;
+  };
+
   __syncthreads();  // staged vectors / row state / flags
   {
     const int j = tid >> 2, jj = j < nout ? j : 0, row = jj / 9;
@@ -584,16 +634,16 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
     // r = b - (S + lambda I) x, exactly like the periodic refresh (Solver::pcg_fused)
     product(S(0));
     __syncthreads();
-    rowsums(false, S(0));
+    rowsums(1, S(0));
     __syncthreads();
     if (roww)
       for (int j = lane; j < nout; j += 64) rs[j] = bs[j] - qss[j];
   }
-  if (roww) close_residual(P.tag_base + pg_u32(it + 1));
+  if (!close_all(P.tag_base + pg_u32(it + 1) * pg_u32(P.tag_stride))) return;
 
   for (;;) {
     const int cur = it + 1;
-    const pg_u32 tag = P.tag_base + pg_u32(cur);
+    const pg_u32 tag = P.tag_base + pg_u32(cur) * pg_u32(P.tag_stride);
     const bool refresh = (cur % P.period) == 0;
     stamp(0);
     // ---- exchange 1: z of the staged columns (stagers); partial sums of rho and Q and the decisions (row wave) ----------
@@ -697,7 +747,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
     product(bs2);
     __syncthreads();  // #2: the quad sums are written
     stamp(3);
-    rowsums(true, bs2);
+    rowsums(0, bs2);
     __syncthreads();  // #3: the row sums are written
     // ---- the stagers keep the direction of their column: p = z + beta p, in place (nobody reads it before the next product)
     if (stager) {
@@ -712,7 +762,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       // ---- while the partial sums travel: what the step needs of the row's state, into registers (float solver, every
       //      record of the workgroup in one pass). Behind the gather the step is then nine fused multiply-adds, the row's
       //      M^-1 (one LDS round trip) and the records - not three LDS round trips in a row.
-      const bool fast = NR == 3 && !refresh && NR * W.nrows <= 64;
+      const bool fast = NR == 3 && !refresh && NR * W.nrows <= 64 && P.series == 0;
       unsigned fl = unsigned(lane);
       PG_OPAQUE(fl);  // (or every LDS address of this path is computed ahead of the loop and kept - i.e. spilled)
       const int ft = int(fl) < NR * W.nrows ? int(fl) : 0, frow = ft / 3, fk = ft - 3 * frow, fj0 = 9 * frow + 3 * fk;
@@ -816,7 +866,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
           }
           double acc_rho = 0.0, acc_q = 0.0;
           if (lane < NR * W.nrows) {
-            pg_rec_store(P.zg + size_t(NR) * size_t(W.row0 + frow) + fk, pg_pack3(float(zc[0]), float(zc[1]), float(zc[2]), tag + 1));
+            pg_rec_store(P.zg + size_t(NR) * size_t(W.row0 + frow) + fk, pg_pack3(float(zc[0]), float(zc[1]), float(zc[2]), tag + pg_u32(P.tag_stride)));
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
               const S r_i = fk == 0 ? rr[u] : fk == 1 ? rr[3 + u] : rr[6 + u];
@@ -829,7 +879,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
           const double s0r = wave_sum(acc_rho), s1r = wave_sum(acc_q);
           if (lane < 2 * kPgReplicas) {
             const int rep = lane >> 1, k2 = lane & 1;
-            pg_rec_store(P.part_rq + (size_t(rep) * G + g) * 2 + k2, pg_pack(k2 ? s1r : s0r, tag + 1));
+            pg_rec_store(P.part_rq + (size_t(rep) * G + g) * 2 + k2, pg_pack(k2 ? s1r : s0r, tag + pg_u32(P.tag_stride)));
           }
         }
       } else {
@@ -853,12 +903,13 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       }
       product(S(0));
       __syncthreads();  // #5
-      rowsums(false, S(0));
+      rowsums(1, S(0));
       __syncthreads();  // #6
       if (roww)
         for (int j = lane; j < nout; j += 64) rs[j] = bs[j] - qss[j];
     }
-    if (roww && !my_stop && !(NR == 3 && !refresh && NR * W.nrows <= 64)) close_residual(tag + 1);
+    if (!(NR == 3 && !refresh && NR * W.nrows <= 64 && P.series == 0))
+      if (!close_all(tag + pg_u32(P.tag_stride))) return;
     stamp(7);
     it = cur;
     need_test = 1;

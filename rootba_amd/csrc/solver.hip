@@ -1044,9 +1044,11 @@ class Solver final : public rba_solver {
     constexpr int NR = rba::pg_vec_records<S>();
     d_pg_zg_.alloc(size_t(NR) * n_cams_);
     d_pg_xg_.alloc(size_t(NR) * n_cams_);
+    d_pg_tg_.alloc(size_t(2) * NR * n_cams_);
     d_pg_part_.alloc(size_t(3) * rba::kPgReplicas * G);
     d_pg_zg_.zero(stream_);
     d_pg_xg_.zero(stream_);
+    d_pg_tg_.zero(stream_);
     d_pg_part_.zero(stream_);
     HIP_CHECK(hipStreamSynchronize(stream_));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_pcgp<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2221,8 +2223,8 @@ class Solver final : public rba_solver {
   // (kernels_pcgp.hpp). Same hand-over of the state as pcg_fused().
   bool pcg_persistent_possible() const {
     // (two ranks that share a device - the callback transport of the tests - would each wait for workgroups the other
-    //  one's resident workgroups keep off the CUs; the power series and the explicit-SC backend keep the two-launch path)
-    return pg_ready_ && !pg_broken_ && !series_fused() && !split_ && !cb_fn_;
+    //  one's resident workgroups keep off the CUs)
+    return pg_ready_ && !pg_broken_ && !split_ && !cb_fn_;
   }
   void pcg_persistent(int it_start) {
     rba::PgParams<S> P{};
@@ -2244,10 +2246,14 @@ class Solver final : public rba_solver {
     P.part_pq = d_pg_part_.get() + size_t(2) * rba::kPgReplicas * pg_G_;
     P.st = d_cg_.get();
     P.host_progress = h_progress_;
-    const unsigned span = unsigned(opt_.max_cg_it) + 4;  // tags of a solve: tag_base + iteration
+    P.series = series_fused() ? opt_.power_order : 0;
+    P.tag_stride = P.series + 2;
+    P.tg = d_pg_tg_.get();
+    const unsigned span = (unsigned(opt_.max_cg_it) + 4) * unsigned(P.tag_stride);  // tags of a solve: tag_base + iteration * stride (+ term)
     if (pg_epoch_ > 0xffffffffu - 2 * span) {
       d_pg_zg_.zero(stream_);
       d_pg_xg_.zero(stream_);
+      d_pg_tg_.zero(stream_);
       d_pg_part_.zero(stream_);
       pg_epoch_ = 1;
     }
@@ -2631,7 +2637,8 @@ class Solver final : public rba_solver {
       bool persistent = pcg_persistent_possible();
       if (persistent) {
         // (explicit-SC backend: the state comes from k_pcg_init, the damping is inside the matrix)
-        if (sc_) hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, st, double(lambda), 0);
+        // (and the power series: its solves come here from k_pcg_init as well)
+        if (sc_ || series_fused()) hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, st, double(lambda), 0);
         pcg_persistent(it);
         HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
         sync();
@@ -3414,7 +3421,7 @@ class Solver final : public rba_solver {
   DevBuf<rba::PgWorkgroup> d_pg_wg_;
   DevBuf<int> d_pg_lane_src_, d_pg_stage_col_, d_pg_row_info_;
   DevBuf<unsigned short> d_pg_lane_col_;
-  DevBuf<rba::pg_rec> d_pg_zg_, d_pg_xg_, d_pg_part_;  // 16-byte records of the exchanged vectors and partial sums
+  DevBuf<rba::pg_rec> d_pg_zg_, d_pg_xg_, d_pg_tg_, d_pg_part_;  // 16-byte records of the exchanged vectors and partial sums
   // explicit Schur-complement backend (solver_type = 1)
   bool sc_ = false;
   int sc_nnz_ = 0;
