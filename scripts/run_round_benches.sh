@@ -1,7 +1,7 @@
 # Round bench set: every line that DESIGN.md / BASELINE.md / profiles/README.md quote. Run on the GPU box:
 #   gpurun -- 'bash scripts/run_round_benches.sh <tag>'   -> gpurun_out/<tag>/
 set -x
-TAG=${1:-r4}
+TAG=${1:-r5}
 O=gpurun_out/$TAG
 mkdir -p $O
 B="python bench.py --cpu-baseline-iters 0 --no-pmc"
