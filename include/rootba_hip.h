@@ -30,7 +30,9 @@
  *    production, none changes results beyond rounding): RBA_VERBOSE, RBA_EXPLICIT_AFTER (overrides
  *    rba_options.explicit_after), RBA_EX_PAIR_BUDGET_GB, RBA_FORCE_EXPLICIT_FALLBACK, RBA_HX_LDS, RBA_HX_WIN,
  *    RBA_HX_TIMING_STRIDE, RBA_SORT_BY_CAMERA, RBA_VERIFY_ASSEMBLED (diagnostic, default off since round 4),
- *    RBA_VERIFY_TOLERANCE, RBA_PCG_SPLIT, RBA_HALF_LOWER_MAX, RBA_S1_FUSED, RBA_HX_WIDE_INSIDE (rootba_amd/csrc/solver.hip: Solver::DebugEnv).
+ *    RBA_VERIFY_TOLERANCE, RBA_PCG_SPLIT, RBA_HALF_LOWER_MAX, RBA_S1_FUSED, RBA_HX_WIDE_INSIDE, RBA_PCG_PERSISTENT (0: the PCG on
+ *    the assembled matrix in two launches per iteration instead of the persistent kernel), RBA_PCGP_TRACE (file for that
+ *    kernel's phase stamps) (rootba_amd/csrc/solver.hip: Solver::DebugEnv).
  *    The ~25 kernel-selection
  *    switches of rounds 1-2 are gone with the kernels they selected.
  *  - camera state: 10 scalars (qx,qy,qz,qw,tx,ty,tz,f,k1,k2) = Camera::params()

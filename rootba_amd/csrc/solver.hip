@@ -3125,8 +3125,10 @@ class Solver final : public rba_solver {
     if (!sc_) {
       // half storage: the transposed parts (9 doubles per block off the diagonal) + their slot index go out with the
       // product and come back in with the vector kernel that consumes q
-      m->product_assembled += int64_t(nnz - nc) * (9 * 8) + int64_t(nnz) * 4;
-      m->pcg_vectors += int64_t(nnz - nc) * (9 * 8);
+      // (round 5: BOTH directions of the slots are priced with the product - the vector work of an iteration is then the
+      //  same number for an iteration on either operator, which is what `iterations - iterations_resident` multiplies:
+      //  with the persistent kernel those are the matrix-free iterations, which have no slots)
+      m->product_assembled += int64_t(nnz - nc) * (9 * 8) * 2 + int64_t(nnz) * 4;
     }
     // assembly, COMPULSORY bytes: the pair list (8 B per pair), every 32-scalar record once, the blocks out. The
     // gather itself requests two records per pair (256 B in float); what L2 does not keep of that is re-read traffic

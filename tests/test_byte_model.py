@@ -1,6 +1,6 @@
 """The library's byte model (rba_get_byte_model: compulsory HBM bytes per launch group, the numerator of the per-stage
 rooflines bench.py prints) against the traffic MEASURED with rocprofv3 PMC counters on an MI355X
-(profiles/r4_pmc_stage_traffic.json, made by scripts/run_pmc_stage_traffic.sh from the same run that recorded the
+(profiles/r5_pmc_stage_traffic.json, made by scripts/run_pmc_stage_traffic.sh from the same run that recorded the
 model). A compulsory-bytes model can never exceed what the hardware moved; round 2's back-substitution model did
  and nothing checked it. The LIVE model of the library is held to the recorded one on the GPU
 (the table alone cannot fail when rba_get_byte_model changes)."""
@@ -10,7 +10,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "profiles", "r4_pmc_stage_traffic.json")
+PATH = os.path.join(ROOT, "profiles", "r5_pmc_stage_traffic.json")
 
 
 @pytest.fixture(scope="module")
@@ -21,6 +21,10 @@ def table():
 
 def test_model_never_exceeds_measured_traffic(table):
     for name, g in table["groups"].items():
+        if name == "product_assembled" and g["launches"] == 0:
+            # (round 5: every solve of the recorded run that reached the assembled matrix ran in the persistent kernel -
+            #  no product of the two-launch form was executed; its model row is checked on final-13682 size elsewhere)
+            continue
         assert g["launches"] > 0, name
         # 3 %: FETCH_SIZE is calibrated on a streaming read, per-kernel access patterns deviate slightly
         assert g["model_bytes_per_launch"] <= 1.03 * g["measured_bytes_per_launch"], (name, g)
@@ -32,11 +36,18 @@ def test_measured_traffic_is_close_to_the_model_where_the_kernels_stream(table):
     matrix gathers one-cache-line records, of which L2 serves most repeats (round 3's float assembly: 2.26 x; VERDICT
     round 3 asked for < 1.6); the vector kernels of a PCG iteration include the slots of half storage read back."""
     g = table["groups"]
-    for name in ("compute_error", "stage1", "product_matrix_free", "product_assembled", "back_substitution"):
+    for name in ("compute_error", "stage1", "product_matrix_free", "back_substitution"):
         assert g[name]["measured_over_model"] < 1.15, (name, g[name])
     assert g["stage2"]["measured_over_model"] < 1.5, g["stage2"]
     assert g["assembly"]["measured_over_model"] < 1.5, g["assembly"]
-    assert g["pcg_vectors"]["measured_over_model"] < 1.5, g["pcg_vectors"]
+    # the vector kernels of a MATRIX-FREE iteration (what is left outside the persistent kernel since round 5): three
+    # launches of a few hundred KB each + the start / closing kernels of short solves - 2.8 MB measured for 1.2 MB of
+    # vectors and M^-1 per iteration, of a 4 GB LM iteration
+    assert g["pcg_vectors"]["measured_over_model"] < 2.6, g["pcg_vectors"]
+    # the persistent PCG kernel: the model is the matrix once per solve + the exchanged records; MEASURED traffic includes
+    # every polling sweep of every workgroup (L1-bypassing loads of records that are not there yet): 3.4 x - the kernel is
+    # a latency chain (DESIGN.md 3e), the price of no grid barrier is read traffic nobody waits for
+    assert 1.0 <= g["persistent_solve"]["measured_over_model"] < 4.5, g["persistent_solve"]
 
 
 def test_fetch_size_calibration_matches_the_guide(table):
