@@ -324,7 +324,7 @@ template <class S, int P2>
 __device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, int t_in_class,
                                                  int lm_begin, int lm_end, const S* __restrict__ x,
                                                  S* __restrict__ y, S* yb, int* cb, int lane,
-                                                 int done, const S* __restrict__ dout) {
+                                                 int done, const S* __restrict__ dout, S* __restrict__ hx_u) {
   constexpr int LPW = 64 / P2;  // landmarks per wavefront (= per tile)
   const int seg = lane / P2, r = lane - P2 * seg;
   const int s = lm_begin + t_in_class * LPW + seg;
@@ -378,6 +378,11 @@ __device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, i
   u -= t2 * seg_sum<S, P2>(v2 * u) * v2;
   u -= t1 * seg_sum<S, P2>(v1 * u) * v1;
   u -= t0 * seg_sum<S, P2>(v0 * u) * v0;
+  if (hx_u) {
+    // deterministic form (k_hx_det_gather below): the row's entry of (I - Q1 Q1^T)-projected J x, summed camera-major
+    if (act) hx_u[row] = u;
+    return;
+  }
   // y_obs = Jp_obs^T u_obs: add the two rows of an observation (lanes r, r^1),
   // transpose through LDS so that 9 consecutive lanes hold one observation
 #pragma unroll
@@ -409,7 +414,7 @@ template <class S>
 __global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, ImplicitTiles it,
                                                      const S* __restrict__ x, S* __restrict__ y,
                                                      const S* __restrict__ dout,
-                                                     const int* __restrict__ done_flag) {
+                                                     const int* __restrict__ done_flag, S* __restrict__ hx_u) {
   __shared__ S ybuf[4][32 * 9 + 8];
   __shared__ int cbuf[4][32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -421,15 +426,15 @@ __global__ __launch_bounds__(256) void k_hx_implicit(Params<S> p, ImplicitTiles 
   S* yb = ybuf[wave];
   int* cb = cbuf[wave];
   if (T >= it.tile_begin[4])
-    hx_implicit_tile<S, 64>(p, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], x, y, yb, cb, lane, done, dout);
+    hx_implicit_tile<S, 64>(p, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], x, y, yb, cb, lane, done, dout, hx_u);
   else if (T >= it.tile_begin[3])
-    hx_implicit_tile<S, 32>(p, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], x, y, yb, cb, lane, done, dout);
+    hx_implicit_tile<S, 32>(p, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], x, y, yb, cb, lane, done, dout, hx_u);
   else if (T >= it.tile_begin[2])
-    hx_implicit_tile<S, 16>(p, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], x, y, yb, cb, lane, done, dout);
+    hx_implicit_tile<S, 16>(p, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], x, y, yb, cb, lane, done, dout, hx_u);
   else if (T >= it.tile_begin[1])
-    hx_implicit_tile<S, 8>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], x, y, yb, cb, lane, done, dout);
+    hx_implicit_tile<S, 8>(p, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], x, y, yb, cb, lane, done, dout, hx_u);
   else
-    hx_implicit_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], x, y, yb, cb, lane, done, dout);
+    hx_implicit_tile<S, 4>(p, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], x, y, yb, cb, lane, done, dout, hx_u);
 }
 
 // ---------------------------------------------------------------------------
@@ -585,7 +590,8 @@ __device__ __forceinline__ int hx_chunk_tile(const HxChunk& ch, int v, int n_tot
 // (defined below, with the kernel of its own that the non-persistent product uses)
 template <class S, int RCH>
 __device__ __forceinline__ void hx_wide_landmark(const Params<S>& p, int s, const S* __restrict__ x, S* __restrict__ y,
-                                                 const S* __restrict__ dout, S* yb, int* cb, int lane);
+                                                 const S* __restrict__ dout, S* yb, int* cb, int lane,
+                                                 S* __restrict__ hx_u = nullptr);
 constexpr int kHxWideScalars = 32 * 9 + 8;  // LDS scalars of a wavefront in hx_wide_landmark (+ 32 ints)
 
 // range of the landmarks with 32 < k <= 64 (RCH = 2)
@@ -686,7 +692,8 @@ __global__ __launch_bounds__(NT) void k_hx_implicit_lds(Params<S> p, ImplicitTil
 // with atomics; `yb` (32 * 9 + 8 scalars) and `cb` (32 ints) are LDS buffers of this wavefront.
 template <class S, int RCH>
 __device__ __forceinline__ void hx_wide_landmark(const Params<S>& p, int s, const S* __restrict__ x, S* __restrict__ y,
-                                                 const S* __restrict__ dout, S* yb, int* cb, int lane) {
+                                                 const S* __restrict__ dout, S* yb, int* cb, int lane,
+                                                 S* __restrict__ hx_u) {
   const int k = p.lm_k[s];
   const int64_t o0 = p.lm_obs[s];
   S jp[RCH][9], u[RCH], v[3][RCH];
@@ -740,6 +747,12 @@ __device__ __forceinline__ void hx_wide_landmark(const Params<S>& p, int s, cons
   reflect(2);
   reflect(1);
   reflect(0);
+  if (hx_u) {  // deterministic form: see k_hx_det_gather
+#pragma unroll
+    for (int rc = 0; rc < RCH; ++rc)
+      if (act[rc]) hx_u[2 * o0 + rc * 64 + lane] = u[rc];
+    return;
+  }
   const int obs_local = lane >> 1;
 #pragma unroll
   for (int rc = 0; rc < RCH; ++rc) {
@@ -768,14 +781,57 @@ template <class S, int RCH>
 __global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_begin, int lm_end,
                                                           const S* __restrict__ x,
                                                           S* __restrict__ y, const S* __restrict__ dout,
-                                                          const int* __restrict__ done_flag) {
+                                                          const int* __restrict__ done_flag, S* __restrict__ hx_u) {
   __shared__ S ybuf[4][kHxWideScalars];
   __shared__ int cbuf[4][32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s = lm_begin + blockIdx.x * 4 + wave;
   if (s >= lm_end) return;
   if (done_flag && *done_flag) return;
-  hx_wide_landmark<S, RCH>(p, s, x, y, dout, ybuf[wave], cbuf[wave], lane);
+  hx_wide_landmark<S, RCH>(p, s, x, y, dout, ybuf[wave], cbuf[wave], lane, hx_u);
+}
+
+// ---------------------------------------------------------------------------
+// The DETERMINISTIC form of the matrix-free product (RBA_DETERMINISTIC=1). The forms above
+// add into y in whatever order the hardware serves their atomics (ds_add_f64 into the workgroup's window, then float
+// atomics into y): two runs of the same float32 solve differ in the last bits of every product, and a 300-iteration
+// PCG amplifies that into +- 1 % of its iteration count. Ordering the flush of the windows alone would not do - the
+// additions INTO a window race as well. Here the landmark-major kernels stop after the reflector chain and store the
+// row entries u = P J x (one scalar per block row, `hx_u`), and this kernel - one workgroup per camera over the
+// camera's observation list, the CSC index of the camera-major passes - sums y_c = D_c sum_o Jp_o^T u_o in double in a
+// fixed order. Costs a second pass over the Jacobian rows (+ 80 B per observation): about twice the product's time;
+// it is a mode for reproducing a run bit by bit, not the default.
+// ---------------------------------------------------------------------------
+template <class S>
+__global__ __launch_bounds__(256) void k_hx_det_gather(Params<S> p, const S* __restrict__ hx_u, S* __restrict__ y,
+                                                       const S* __restrict__ dout,
+                                                       const int* __restrict__ done_flag) {
+  __shared__ double sm[4][9];
+  const int c = xcd_swizzled_camera(p.n_cams);
+  if (c >= p.n_cams) return;
+  if (done_flag && *done_flag) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t t = t0 + tid; t < t1; t += 256) {
+    const int64_t o = p.cam_obs[t];
+    const double u0 = double(hx_u[2 * o]), u1 = double(hx_u[2 * o + 1]);
+    const S* __restrict__ jp = p.JpS + 18 * o;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = fma(double(jp[9 + j]), u1, fma(double(jp[j]), u0, acc[j]));
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) acc[j] = wave_sum(acc[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) sm[wave][j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < 9) {
+    const double t = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
+    const int i = 9 * c + tid;
+    y[i] += dout ? S(t * double(dout[i])) : S(t);
+  }
 }
 
 // ===========================================================================
@@ -789,7 +845,7 @@ __global__ __launch_bounds__(256) void k_hx_implicit_wide(Params<S> p, int lm_be
 template <class S, int CH>
 __global__ __launch_bounds__(256) void k_e0(Params<S> p, int lm_begin, int lm_end,
                                             const S* __restrict__ v, S* __restrict__ y,
-                                            const int* __restrict__ done_flag) {
+                                            const int* __restrict__ done_flag, S* __restrict__ e0_w) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s = lm_begin + blockIdx.x * 4 + wave;
   if (s >= lm_end) return;
@@ -817,9 +873,44 @@ __global__ __launch_bounds__(256) void k_e0(Params<S> p, int lm_begin, int lm_en
   }
 #pragma unroll
   for (int m = 0; m < 3; ++m) w[m] = wave_sum(w[m]);
+  if (e0_w) {  // deterministic form: the landmark's three sums, applied camera-major by k_e0_det_gather
+    if (lane < 3) e0_w[3 * size_t(s) + lane] = lane == 0 ? w[0] : (lane == 1 ? w[1] : w[2]);
+    return;
+  }
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch)
     if (act[ch]) atomic_add(y + yidx[ch], t[0][ch] * w[0] + t[1][ch] * w[1] + t[2][ch] * w[2]);
+}
+
+// deterministic E0 v (RBA_DETERMINISTIC=1, see k_hx_det_gather): y_c += sum_o topd_o^T w_{l(o)} over the camera's
+// observation list, double, fixed order
+template <class S>
+__global__ __launch_bounds__(256) void k_e0_det_gather(Params<S> p, const S* __restrict__ e0_w, S* __restrict__ y,
+                                                       const int* __restrict__ done_flag) {
+  __shared__ double sm[4][9];
+  const int c = xcd_swizzled_camera(p.n_cams);
+  if (c >= p.n_cams) return;
+  if (done_flag && *done_flag) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t t = t0 + tid; t < t1; t += 256) {
+    const int64_t o = p.cam_obs[t];
+    const S* __restrict__ w = e0_w + 3 * size_t(p.obs_lm[o]);
+    const double w0 = double(w[0]), w1 = double(w[1]), w2 = double(w[2]);
+    const S* __restrict__ td = p.topd + kTd * o;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+      acc[j] = fma(double(td[18 + j]), w2, fma(double(td[9 + j]), w1, fma(double(td[j]), w0, acc[j])));
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) acc[j] = wave_sum(acc[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) sm[wave][j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < 9) y[9 * c + tid] += S((sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]));
 }
 
 // ===========================================================================

@@ -27,7 +27,7 @@ __device__ __forceinline__ S big_block_sum(S v, S* sm) {
 template <class S>
 __global__ __launch_bounds__(256) void k_e0_big(Params<S> p, int lm_begin, const S* __restrict__ v,
                                                 S* __restrict__ y,
-                                                const int* __restrict__ done_flag) {
+                                                const int* __restrict__ done_flag, S* __restrict__ e0_w) {
   __shared__ S sm[4];
   if (done_flag && *done_flag) return;
   const int tid = threadIdx.x;
@@ -45,6 +45,10 @@ __global__ __launch_bounds__(256) void k_e0_big(Params<S> p, int lm_begin, const
   }
 #pragma unroll
   for (int m = 0; m < 3; ++m) w[m] = big_block_sum(w[m], sm);
+  if (e0_w) {  // deterministic form (k_e0_det_gather)
+    if (tid < 3) e0_w[3 * size_t(s) + tid] = tid == 0 ? w[0] : (tid == 1 ? w[1] : w[2]);
+    return;
+  }
   for (int j = tid; j < ncols; j += 256) {
     const int i = j / 9, comp = j - 9 * i;
     const S* t = Td + kTd * i + comp;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) void k_hx_implicit_big(Params<S> p, int lm_beg
                                                          const int64_t* __restrict__ scratch_off,
                                                          const S* __restrict__ x, S* __restrict__ y,
                                                          const S* __restrict__ dout,
-                                                         const int* __restrict__ done_flag) {
+                                                         const int* __restrict__ done_flag, S* __restrict__ hx_u) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
   __shared__ S sm[12];
   if (done_flag && *done_flag) return;
@@ -304,6 +308,10 @@ __global__ __launch_bounds__(256) void k_hx_implicit_big(Params<S> p, int lm_beg
     }
   }
   __syncthreads();
+  if (hx_u) {  // deterministic form (k_hx_det_gather, kernels.hpp)
+    for (int r = tid; r < nrows; r += 256) hx_u[row0 + r] = U[r];
+    return;
+  }
   // y_obs = Jp_obs^T u_obs
   for (int j = tid; j < 9 * (nrows / 2); j += 256) {
     const int i = j / 9, c = j - 9 * i;

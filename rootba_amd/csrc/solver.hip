@@ -507,6 +507,11 @@ class Solver final : public rba_solver {
       HIP_CHECK(hipStreamSynchronize(stream_));
     }
     d_topd_.alloc(rba::kTd * qr_obs);
+    if (env_.deterministic && !sc_) {
+      // the row entries / landmark sums of the deterministic products (kernels.hpp: k_hx_det_gather, k_e0_det_gather)
+      d_hx_u_.alloc(2 * size_t(n_obs_));
+      d_e0_w_.alloc(3 * size_t(n_lms_));
+    }
     d_JpS_.alloc(18 * size_t(n_obs_));
     d_JlS_.alloc(6 * qr_obs);
     d_rS_.alloc(2 * qr_obs);
@@ -1984,11 +1989,14 @@ class Solver final : public rba_solver {
     for_each_class([&](auto ch_tag, int begin, int end) {
       constexpr int CH = decltype(ch_tag)::value;
       hipLaunchKernelGGL((rba::k_e0<S, CH>), dim3((end - begin + 3) / 4), dim3(256), 0, stream_,
-                         prm_, begin, end, v, y, done_flag);
+                         prm_, begin, end, v, y, done_flag, d_e0_w_.get());
     });
     if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_e0_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_, v, y,
-                         done_flag);
+                         done_flag, d_e0_w_.get());
+    if (d_e0_w_.get())  // RBA_DETERMINISTIC=1: the kernels above stored the landmark sums; applied camera-major
+      hipLaunchKernelGGL((rba::k_e0_det_gather<S>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm_,
+                         d_e0_w_.get(), y, done_flag);
   }
 
   rba::ImplicitTiles implicit_tiles() const {
@@ -2019,22 +2027,27 @@ class Solver final : public rba_solver {
   void launch_hx_implicit(const S* x, S* y, const int* done_flag) {
     const S* xin = scaled_operand(x);
     const S* dout = prm_.pose_scaling;
+    S* hx_u = d_hx_u_.get();  // RBA_DETERMINISTIC=1: the landmark-major kernels store row entries, summed camera-major
     if (n_big_ > 0)
       hipLaunchKernelGGL((rba::k_hx_implicit_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_,
-                         d_big_scratch_.get(), d_big_off_.get(), xin, y, dout, done_flag);
-    const bool use_lds = n_tiles_ > 0 && env_.hx_lds && (env_.hx_lds == 2 || (n_tiles_ >= 16 * n_cus_ && hx_coverage_ >= 0.9));
+                         d_big_scratch_.get(), d_big_off_.get(), xin, y, dout, done_flag, hx_u);
+    const bool use_lds = !hx_u && n_tiles_ > 0 && env_.hx_lds &&
+                         (env_.hx_lds == 2 || (n_tiles_ >= 16 * n_cus_ && hx_coverage_ >= 0.9));
     // (landmarks with 32 < k <= 64: inside the persistent kernel when that one runs - one launch less per product)
     const bool wide_inside = use_lds && env_.hx_wide_inside;
     if (imp_end_[6] > imp_begin_[6])
       hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 4>), dim3((imp_end_[6] - imp_begin_[6] + 3) / 4),
-                         dim3(256), 0, stream_, prm_, imp_begin_[6], imp_end_[6], xin, y, dout, done_flag);
+                         dim3(256), 0, stream_, prm_, imp_begin_[6], imp_end_[6], xin, y, dout, done_flag, hx_u);
     if (imp_end_[5] > imp_begin_[5] && !wide_inside)
       hipLaunchKernelGGL((rba::k_hx_implicit_wide<S, 2>), dim3((imp_end_[5] - imp_begin_[5] + 3) / 4),
-                         dim3(256), 0, stream_, prm_, imp_begin_[5], imp_end_[5], xin, y, dout, done_flag);
+                         dim3(256), 0, stream_, prm_, imp_begin_[5], imp_end_[5], xin, y, dout, done_flag, hx_u);
     rba::ImplicitTiles it = implicit_tiles();
     if (n_tiles_ > 0 && !use_lds)
       hipLaunchKernelGGL((rba::k_hx_implicit<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, it, xin, y,
-                         dout, done_flag);
+                         dout, done_flag, hx_u);
+    if (hx_u)
+      hipLaunchKernelGGL((rba::k_hx_det_gather<S>), dim3(rba::xcd_swizzled_grid(n_cams_)), dim3(256), 0, stream_, prm_,
+                         hx_u, y, dout, done_flag);
     if (use_lds) {
       // workgroup-private window of y in LDS (double accumulators, ds_add_f64), one persistent workgroup per CU
       const size_t ylds_bytes = size_t(9) * hx_win_ * sizeof(double);
@@ -2393,6 +2406,12 @@ class Solver final : public rba_solver {
     }
     timings_.hx_time = hx_ms * 1e-3;  // sum over the TIMED products
     timings_.hx_calls = timed;
+    // (RBA_DETERMINISTIC=1: the switch stays at its initial product count - a measured break-even differs from run
+    //  to run, and with it the iteration from which a solve continues on the assembled matrix)
+    if (asm_pending_ && env_.deterministic) {
+      asm_pending_ = false;
+      asm_measured_ = true;
+    }
     if (asm_pending_ && timed > 0) {
       // break-even of the switch (ski rental): as many matrix-free products as one assembly costs.
       // Identical on all ranks? No - timings differ, so rank 0's value is broadcast (max is enough:
@@ -3281,6 +3300,8 @@ class Solver final : public rba_solver {
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
                                        // over the ranks (default: where the estimate says it pays)
     int hx_wide_inside = 1;            // RBA_HX_WIDE_INSIDE=0: landmarks with 32 < k <= 64 in a kernel of their own
+    int deterministic = 0;             // RBA_DETERMINISTIC=1: matrix-free products summed camera-major in a fixed order
+                                       // (no floating-point atomics anywhere: runs repeat bit by bit; ~2 x per product)
     int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels
     int half_lower_max = rba::kHalfLowerMax;  // RBA_HALF_LOWER_MAX=n: received slots above which a row of the assembled
                                               // matrix has them summed by a wavefront of its own (k_pcgs_reduce_slots)
@@ -3304,6 +3325,7 @@ class Solver final : public rba_solver {
     env_.half_lower_max = geti("RBA_HALF_LOWER_MAX", rba::kHalfLowerMax);
     env_.s1_fused = geti("RBA_S1_FUSED", 1);
     env_.hx_wide_inside = geti("RBA_HX_WIDE_INSIDE", 1);
+    env_.deterministic = geti("RBA_DETERMINISTIC", 0);
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     env_.pcg_persistent = geti("RBA_PCG_PERSISTENT", 1);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
@@ -3338,6 +3360,7 @@ class Solver final : public rba_solver {
   DevBuf<int> d_CT_, d_RT_;
   int64_t n_obs_small_ = 0, n_obs_tiled_ = 0;
   DevBuf<S> d_big_scratch_;
+  DevBuf<S> d_hx_u_, d_e0_w_;  // RBA_DETERMINISTIC=1: [2 n_obs] row entries of P J x, [3 n_lms] landmark sums of E0 v
   DevBuf<int64_t> d_big_off_;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;
   DevBuf<S> d_obs_xy_, d_cams_, d_lms_, d_cams_bak_, d_lms_bak_;
@@ -3563,7 +3586,7 @@ class ShardedSolver final : public rba_solver {
  public:
   ShardedSolver(int dtype, int n, const int* devices, int32_t n_cams, int32_t n_lms, const int64_t* lm_off,
                 const int32_t* obs_cam, const void* obs_xy, const rba_options& opt)
-      : n_(n), n_cams_(n_cams), n_lms_(n_lms), es_state_(dtype == RBA_F32 ? 4 : 8), es_vec_(dtype == RBA_F64 ? 8 : 4) {
+      : n_(n), n_cams_(n_cams), es_state_(dtype == RBA_F32 ? 4 : 8), es_vec_(dtype == RBA_F64 ? 8 : 4) {
     // ---- landmark ranges: bytes a landmark of k observations moves per LM iteration in this layout ~ 120 k + 100
     //      (rows, records and reflectors per observation + the landmark's own records), never an empty range
     {
@@ -3829,7 +3852,7 @@ class ShardedSolver final : public rba_solver {
     return 0;
   }
 
-  int n_, n_cams_, n_lms_;
+  int n_, n_cams_;
   size_t es_state_, es_vec_;
   bool rccl_ = false;
   std::vector<int32_t> cuts_;

@@ -966,3 +966,56 @@ def test_persistent_pcg_is_the_two_launch_pcg(ladybug_far, small_problem, mixed_
         long_before |= max(a.cg_iterations, b.cg_iterations) > 30
         ctol = (1e-5 if long_before else 1e-9) if dtype == np.float64 else 2e-5
         assert abs(a.cost - b.cost) <= ctol * b.cost, (a.cost, b.cost, a.cg_iterations, b.cg_iterations)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("which", ["small", "mixed", "long", "very-long"])
+def test_deterministic_products_are_the_operator_and_repeat_bitwise(small_problem, mixed_k_problem, long_track_problem,
+                                                                    very_long_track_problem, dtype, which, monkeypatch):
+    """RBA_DETERMINISTIC=1: the matrix-free product stores the row entries of P J x and sums
+    them camera-major in a fixed order (kernels.hpp: k_hx_det_gather) instead of adding into y with floating-point
+    atomics. Same operator as the oracle's; the SAME BITS from two evaluations and from two handles (the default form's
+    bits depend on the order in which the hardware serves the atomics); all track-length classes: wave tiles, wavefront
+    per landmark (32 < k <= 112), workgroup per landmark."""
+    prob = {"small": small_problem, "mixed": mixed_k_problem, "long": long_track_problem,
+            "very-long": very_long_track_problem}[which]
+    monkeypatch.setenv("RBA_DETERMINISTIC", "1")
+    g, o = _pair(prob, dtype)
+    g2, _ = _pair(prob, dtype)
+    assert g.linearize() == 0 and o.linearize() == 0 and g2.linearize() == 0
+    rng = np.random.default_rng(11)
+    for lam in (LAMBDA, 1e-6):
+        o.set_pose_damping(lam)
+        o.stage2(lam, o.pose_scaling() if lam == LAMBDA else None)
+        g.stage2(lam)
+        g2.stage2(lam)
+        for _ in range(2):
+            x = rng.uniform(-1, 1, 9 * prob.n_cams).astype(dtype)
+            y = g.right_multiply(x)
+            assert rel_err(y, o.right_multiply(x)) < TOL[dtype]
+            assert np.array_equal(y, g.right_multiply(x)) and np.array_equal(y, g2.right_multiply(x))
+
+
+@pytest.mark.parametrize("precond", [1, 2])
+def test_deterministic_lm_run_repeats_bitwise(ladybug_far, precond, monkeypatch):
+    """Two float32 LM runs with RBA_DETERMINISTIC=1 on two handles: identical PCG counts, costs and final states, bit by
+    bit - every product matrix-free (explicit_after = 0; precond 2: the power series' E0 products too, summed
+    camera-major by k_e0_det_gather), and in the default configuration (long solves on the assembled matrix: no atomics
+    there in either mode). The run is also the float32 oracle's within the usual bounds."""
+    monkeypatch.setenv("RBA_DETERMINISTIC", "1")
+    for explicit_after in (0, None):
+        kw = dict(max_num_iterations=6, function_tolerance=0.0, preconditioner_type=precond)
+        if explicit_after is not None:
+            kw["explicit_after"] = explicit_after
+        runs = []
+        for _ in range(2):
+            g, o = _pair(ladybug_far, np.float32, **kw)
+            rows, _ = g.optimize_lm()
+            runs.append((rows, g.get_state()))
+        (ra, sa), (rb, sb) = runs
+        assert [r.cg_iterations for r in ra] == [r.cg_iterations for r in rb]
+        assert [r.cost for r in ra] == [r.cost for r in rb]
+        assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+        lo, _ = o.optimize_lm()
+        assert len(lo) == len(ra)
+        assert abs(ra[-1].cost - lo[-1].cost) <= 1e-5 * lo[-1].cost
