@@ -292,13 +292,19 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
                                                      int n_upper) {
   using M = Mfma<double>;
   using Acc = typename M::acc;
-  constexpr int U = 4;  // (2: same time, 8: 1.6 x slower - registers)
+  constexpr int U = 2;  // quads of pairs per step and wavefront (round-5 form: 4 -> 999 us at 116 registers, 2 -> 915 us at
+                        // 72 registers = seven wavefronts per SIMD; round-4 form: 2 and 4 the same, 8 1.6 x slower)
   // Counters (profiles/r5_pmc_a64_offdiag.csv, round 5): per v_mfma_f64_16x16x4 the kernel issues 23 VALU, 4.4 LDS and
   // 3 scalar instructions; the LDS is its busiest unit (SQ_LDS_IDX_ACTIVE 59 % of the CU cycles, 9 % of that bank
   // conflicts), the VALU ~46 %, the matrix pipe 32 % (a v_mfma_f64_16x16x4 holds it for 64 cycles: 12.5 M of them are
   // exactly the 803 M busy cycles counted) - no unit is saturated, a wavefront is a chain of LDS round trip -> operand
-  // arithmetic -> dependent matrix instruction. Four accumulator chains instead of two (160 instead of 128 + 16 registers,
-  // one wavefront per SIMD less): 1160 -> 1287 us, reverted.
+  // arithmetic -> dependent matrix instruction. Four accumulator chains instead of two (160 instead of 128 registers,
+  // one wavefront per SIMD less): 1160 -> 1287 us, reverted. The ISA of that form (scripts/pcgp_regs.sh writes
+  // /tmp/solver.s) showed where the 23 VALU instructions came from: ~10 of operand arithmetic, the rest 64-bit index
+  // clamps, the zero-selects of the staging in EVERY step, copies of the second accumulator between VGPRs and AGPRs,
+  // and an exec-masked branch around every operand - the form below has one accumulator, 32-bit positions, selects
+  // in a list's last step only, no predicate on the operands and two register sets instead of copies of load results:
+  // ~11 VALU instructions per matrix instruction, 1152 -> 999 us; with two quads per step instead of four 915 us.
   __shared__ double tile[4][16][16];
   __shared__ __attribute__((aligned(16))) double stage[4][U][8][kA64Rec];
   const int lane = threadIdx.x & 63;
@@ -306,40 +312,40 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   const int u = xcd_swizzled_camera(n_upper);
   if (u >= n_upper) return;
   const int i = lane & 15, kk = lane >> 4;
-  Acc acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+  // operand rows / columns 9 .. 15 of the 16 x 16 tile are never read back: their lanes build operands from the entries
+  // of column 8 instead of zeros - no predicate, no branch around the operand arithmetic (round 5: the predicated form
+  // compiled to an exec-masked block per matrix instruction - LDS reads, wait, arithmetic, instruction, twelve times in
+  // a row with nothing hoisted across)
+  const int i9 = min(i, 8);
+  Acc acc = {0, 0, 0, 0};
   const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
+  const int n = int(q1 - q0);  // pairs of this block; positions below are relative to q0 (32-bit index arithmetic)
   const int rec = lane >> 3, vec = lane & 7;
-  const int* __restrict__ pair_side = rec < 4 ? pair_oi : pair_oj;
+  const int* __restrict__ pair_side = (rec < 4 ? pair_oi : pair_oj) + q0;
+  const int rsub = rec & 3;
   // Software pipeline (a wavefront's step is two DEPENDENT gathers - pair indices, then records that mostly miss L2 -
   // in front of 12 matrix-core instructions; without it the kernel ran at a third of the matrix rate with the matrix
   // pipe idle two thirds of the time, profiles/r4_pmc_mfma_float32.csv): the records of step s + 1 and the indices of
   // step s + 2 are in flight while step s is staged and multiplied. Clamped, not predicated: every load is issued.
-  const int64_t qw = q0 + wave * (4 * U);
-  auto load_idx = [&](int64_t q, int o[U]) {
+  const int qw = wave * (4 * U);
+  auto load_idx = [&](int q, int o[U]) {
 #pragma unroll
-    for (int uq = 0; uq < U; ++uq) o[uq] = pair_side[max(q0, min(q + 4 * uq + (rec & 3), q1 - 1))];
+    for (int uq = 0; uq < U; ++uq) o[uq] = pair_side[min(q + 4 * uq + rsub, n - 1)];
   };
   auto load_rec = [&](const int o[U], double2 v[U]) {
 #pragma unroll
     for (int uq = 0; uq < U; ++uq) v[uq] = reinterpret_cast<const double2*>(p.rec + size_t(kA64Rec) * o[uq])[vec];
   };
-  int o_next[U];
-  double2 v_cur[U] = {};
-  if (q1 > q0) {
-    int o_cur[U];
-    load_idx(qw, o_cur);
-    load_idx(qw + 16 * U, o_next);
-    load_rec(o_cur, v_cur);
-  }
-  for (int64_t q = qw; q < q1; q += 16 * U) {
-    double2 v_next[U];
-    int o_next2[U];
-    load_rec(o_next, v_next);
-    load_idx(q + 32 * U, o_next2);
+  auto step = [&](int q, const double2 v[U]) {
+    if (q + 4 * U > n) {  // (wave-uniform) the last step of the list: pairs beyond its end are staged as zeros
 #pragma unroll
-    for (int uq = 0; uq < U; ++uq) {
-      const bool ok = q + 4 * uq + (rec & 3) < q1;
-      *reinterpret_cast<double2*>(&stage[wave][uq][rec][2 * vec]) = ok ? v_cur[uq] : double2{0.0, 0.0};
+      for (int uq = 0; uq < U; ++uq) {
+        const bool ok = q + 4 * uq + rsub < n;
+        *reinterpret_cast<double2*>(&stage[wave][uq][rec][2 * vec]) = ok ? v[uq] : double2{0.0, 0.0};
+      }
+    } else {
+#pragma unroll
+      for (int uq = 0; uq < U; ++uq) *reinterpret_cast<double2*>(&stage[wave][uq][rec][2 * vec]) = v[uq];
     }
     wave_lds_fence();
 #pragma unroll
@@ -348,29 +354,33 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
       for (int m = 0; m < 3; ++m) {
         const int g = 4 * m + kk;  // inner index 0..11 = (pair of the quad, top row)
         const int pp = g / 3, c = g - 3 * pp;
-        double av = 0.0, bv = 0.0;
-        if (i < 9) {
-          const double* ri = stage[wave][uq][pp];
-          const double* rj = stage[wave][uq][4 + pp];
-          const float* fi = reinterpret_cast<const float*>(ri);
-          const float* fj = reinterpret_cast<const float*>(rj);
-          av = fma(ri[kA64RecW + 2 * c], double(fi[i]), ri[kA64RecW + 2 * c + 1] * double(fi[9 + i]));
-          bv = fma(rj[kA64RecW + 2 * c], double(fj[i]), rj[kA64RecW + 2 * c + 1] * double(fj[9 + i]));
-        }
-        if (uq & 1)
-          acc2 = M::mma(av, bv, acc2);
-        else
-          acc = M::mma(av, bv, acc);
+        const double* ri = stage[wave][uq][pp];
+        const double* rj = stage[wave][uq][4 + pp];
+        const float* fi = reinterpret_cast<const float*>(ri);
+        const float* fj = reinterpret_cast<const float*>(rj);
+        const double av = fma(ri[kA64RecW + 2 * c], double(fi[i9]), ri[kA64RecW + 2 * c + 1] * double(fi[9 + i9]));
+        const double bv = fma(rj[kA64RecW + 2 * c], double(fj[i9]), rj[kA64RecW + 2 * c + 1] * double(fj[9 + i9]));
+        acc = M::mma(av, bv, acc);
       }
     wave_lds_fence();  // the next step overwrites the staging buffer
-#pragma unroll
-    for (int uq = 0; uq < U; ++uq) {
-      v_cur[uq] = v_next[uq];
-      o_next[uq] = o_next2[uq];
-    }
+  };
+  // two register sets, the loop unrolled by two: no load result is ever copied (a copy waits for its load)
+  int o_a[U], o_b[U];
+  double2 v_a[U] = {}, v_b[U] = {};
+  if (n > 0) {
+    load_idx(qw, o_a);
+    load_idx(qw + 16 * U, o_b);
+    load_rec(o_a, v_a);
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+  for (int q = qw; q < n; q += 32 * U) {
+    load_rec(o_b, v_b);
+    load_idx(q + 32 * U, o_a);
+    step(q, v_a);
+    if (q + 16 * U >= n) break;
+    load_rec(o_a, v_a);
+    load_idx(q + 48 * U, o_b);
+    step(q + 16 * U, v_b);
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][M::row(lane, r)][i] = acc[r];
   __syncthreads();
