@@ -2658,10 +2658,38 @@ class Solver final : public rba_solver {
         // (explicit-SC backend: the state comes from k_pcg_init, the damping is inside the matrix)
         // (and the power series: its solves come here from k_pcg_init as well)
         if (sc_ || series_fused()) hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, st, double(lambda), 0);
+        if (comm_) {
+          // (sharded run: the solve's entry state, in case another rank's kernel gives up - see below)
+          if (!d_pg_xsave_.get()) {
+            d_pg_xsave_.alloc(size_t(n));
+            d_pg_stsave_.alloc(1);
+          }
+          HIP_CHECK(hipMemcpyAsync(d_pg_xsave_.get(), d_x_.get(), size_t(n) * sizeof(S), hipMemcpyDeviceToDevice, stream_));
+          HIP_CHECK(hipMemcpyAsync(d_pg_stsave_.get(), st, sizeof(rba::CgState), hipMemcpyDeviceToDevice, stream_));
+        }
         pcg_persistent(it);
         HIP_CHECK(hipMemcpyAsync(hst, st, sizeof(rba::CgState), hipMemcpyDeviceToHost, stream_));
         sync();
-        if (h_progress_[4] != 0) {
+        const bool finished = h_progress_[4] == 0;
+        // (RBA_PCGP_TEST_GIVE_UP=1, sharded runs: behave as if this rank's kernel had given up - the test of the path below)
+        const bool mine_gave_up = !finished || (env_.pcgp_test_give_up && comm_);
+        int gave_up = mine_gave_up ? 1 : 0;
+        if (comm_) {
+          // sharded run: the ranks hold replicas of this solve and must continue alike - one rank falling back to the
+          // two-launch path on its own would round differently, and a different iteration count on one rank is a
+          // mismatched collective in the next solve. All fall back if any gave up.
+          d_scratch_int_.upload(&gave_up, 1, stream_);
+          all_reduce(d_scratch_int_.get(), 1, kNcclMax);
+          d_scratch_int_.download(&gave_up, 1, stream_);
+          sync();
+          if (gave_up && finished) {
+            // this rank's kernel finished, another's did not: back to the entry state (the kernel writes x and the state
+            // only at its end; r, z, p are inputs), then everybody takes the two-launch path
+            HIP_CHECK(hipMemcpyAsync(d_x_.get(), d_pg_xsave_.get(), size_t(n) * sizeof(S), hipMemcpyDeviceToDevice, stream_));
+            HIP_CHECK(hipMemcpyAsync(st, d_pg_stsave_.get(), sizeof(rba::CgState), hipMemcpyDeviceToDevice, stream_));
+          }
+        }
+        if (gave_up) {
           // a workgroup waited ~1 s for a granule (not every workgroup resident? another process on the device?): nothing
           // of the state was written - continue in two launches per iteration and keep to them
           std::fprintf(stderr, "[rootba_hip] persistent PCG gave up waiting (%d workgroups); two-launch path from now on\n", pg_G_);
@@ -3300,6 +3328,7 @@ class Solver final : public rba_solver {
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
                                        // over the ranks (default: where the estimate says it pays)
     int hx_wide_inside = 1;            // RBA_HX_WIDE_INSIDE=0: landmarks with 32 < k <= 64 in a kernel of their own
+    int pcgp_test_give_up = 0;         // RBA_PCGP_TEST_GIVE_UP=1: test hook of the collective fallback of a sharded run
     int deterministic = 0;             // RBA_DETERMINISTIC=1: matrix-free products summed camera-major in a fixed order
                                        // (no floating-point atomics anywhere: runs repeat bit by bit; ~2 x per product)
     int s1_fused = 1;                  // RBA_S1_FUSED=0: geometry and QR of the wave-tile landmarks as two kernels
@@ -3326,6 +3355,7 @@ class Solver final : public rba_solver {
     env_.s1_fused = geti("RBA_S1_FUSED", 1);
     env_.hx_wide_inside = geti("RBA_HX_WIDE_INSIDE", 1);
     env_.deterministic = geti("RBA_DETERMINISTIC", 0);
+    env_.pcgp_test_give_up = geti("RBA_PCGP_TEST_GIVE_UP", 0);
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     env_.pcg_persistent = geti("RBA_PCG_PERSISTENT", 1);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
@@ -3360,6 +3390,8 @@ class Solver final : public rba_solver {
   DevBuf<int> d_CT_, d_RT_;
   int64_t n_obs_small_ = 0, n_obs_tiled_ = 0;
   DevBuf<S> d_big_scratch_;
+  DevBuf<S> d_pg_xsave_;                  // sharded runs: x and the PCG state at the entry of a persistent solve
+  DevBuf<rba::CgState> d_pg_stsave_;
   DevBuf<S> d_hx_u_, d_e0_w_;  // RBA_DETERMINISTIC=1: [2 n_obs] row entries of P J x, [3 n_lms] landmark sums of E0 v
   DevBuf<int64_t> d_big_off_;
   int imp_tile_begin_[5] = {0, 0, 0, 0, 0}, imp_tiles_[5] = {0, 0, 0, 0, 0}, n_tiles_ = 0;

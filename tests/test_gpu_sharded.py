@@ -234,3 +234,32 @@ def test_single_process_sharded_handle_over_distinct_devices(small_problem):
     assert ta == tb and len(a) == len(b)
     for x, y in zip(a, b):
         assert x.step_is_successful == y.step_is_successful and abs(x.cost - y.cost) <= 1e-9 * x.cost
+
+
+def test_persistent_pcg_fallback_is_collective(ladybug_problem, monkeypatch):
+    """A sharded run replicates the PCG on the assembled matrix on every rank; should ONE rank's persistent kernel give up
+    waiting (kernels_pcgp.hpp: bounded polling), all ranks must continue alike - the ranks whose kernel finished go back
+    to the solve's entry state and everybody takes the two-launch path (Solver::pcg). Test hook RBA_PCGP_TEST_GIVE_UP=1
+    on a one-rank RCCL communicator: the kernel finishes, the rank behaves as if it had given up; the LM run must be,
+    bit by bit, the run with RBA_PCG_PERSISTENT=0 (deterministic mode: no floating-point atomics in either)."""
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    opts = dict(robust_norm=1, max_num_iterations=6, function_tolerance=0.0)
+    monkeypatch.setenv("RBA_DETERMINISTIC", "1")
+    runs = []
+    for env in ({"RBA_PCGP_TEST_GIVE_UP": "1"}, {"RBA_PCG_PERSISTENT": "0"}):
+        for k in ("RBA_PCGP_TEST_GIVE_UP", "RBA_PCG_PERSISTENT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = LinearizorHIP(ladybug_problem, np.float32, L.default_options(**opts))
+        g.comm_init(0, 1, LinearizorHIP.comm_unique_id())
+        rows, _ = g.optimize_lm()
+        runs.append((rows, g.get_state(), g.pcg_counters()))
+        g.close()
+    (ra, sa, ca), (rb, sb, cb) = runs
+    assert ca["products_assembled"] > 0 and ca["solves_persistent"] == 0 and cb["solves_persistent"] == 0, (ca, cb)
+    assert [r.cg_iterations for r in ra] == [r.cg_iterations for r in rb]
+    assert [r.cost for r in ra] == [r.cost for r in rb]
+    assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
