@@ -415,8 +415,8 @@ __global__ __launch_bounds__(256) void k_a64_diag(A64Params p, const int* __rest
   if (c >= p.n_cams) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t t0 = p.cam_obs_off[c], t1 = p.cam_obs_off[c + 1];
-  Acc accK = {0, 0, 0, 0}, accK2 = {0, 0, 0, 0};
-  const int i = lane & 15, kk = lane >> 4;
+  Acc accK = {0, 0, 0, 0};
+  const int i = lane & 15, kk = lane >> 4, i9 = min(i, 8);
   double* lds = stage[wave];
   int idxreg = t1 > t0 ? p.cam_obs[min<int64_t>(t0 + CH * wave + lane, t1 - 1)] : 0;
   for (int64_t base = t0 + CH * wave; base < t1; base += 4 * CH) {
@@ -447,27 +447,22 @@ __global__ __launch_bounds__(256) void k_a64_diag(A64Params p, const int* __rest
       if (r < cnt) *reinterpret_cast<double2*>(lds + r * RW + 18 + 2 * h) = w;
     }
     wave_lds_fence();
+    // (operands unpredicated, as in k_a64_offdiag: lanes of the tile's rows 9 .. 15 repeat column 8, records past the
+    //  chunk's end are read - stale LDS - and replaced by zeros with a select)
     for (int s = 0; s < cnt; s += 4) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int so = s + 2 * h + (kk >> 1);
-        double v = 0.0;
-        if (i < 9 && so < cnt) {
-          const double* rec = lds + so * RW;
-          const double* arow = rec + 18 + 2 * (kk & 1);
-          v = GRAM ? rec[9 * (kk & 1) + i] : fma(arow[0], rec[i], arow[1] * rec[9 + i]);
-        }
-        if (h == 0)
-          accK = M::mma(v, v, accK);
-        else
-          accK2 = M::mma(v, v, accK2);
+        const double* rec = lds + so * RW;
+        const double* arow = rec + 18 + 2 * (kk & 1);
+        double v = GRAM ? rec[9 * (kk & 1) + i9] : fma(arow[0], rec[i9], arow[1] * rec[9 + i9]);
+        v = so < cnt ? v : 0.0;
+        accK = M::mma(v, v, accK);
       }
     }
     wave_lds_fence();  // the next chunk overwrites the staging buffer
     idxreg = idxnext;
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) accK[r] += accK2[r];
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][M::row(lane, r)][lane & 15] = accK[r];
   __syncthreads();

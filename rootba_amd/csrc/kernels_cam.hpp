@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<S> p, S lambda, in
   const bool want_G = MODE == 1 || (GRAM && p.jacobi);
   const bool want_d = MODE == 1 || GRAM;
   Acc accK = {0, 0, 0, 0}, accK2 = {0, 0, 0, 0}, accG = {0, 0, 0, 0};
-  const int i = lane & 15, kk = lane >> 4;
+  const int i = lane & 15, kk = lane >> 4, i9 = min(i, 8);
   const int g = lane / 9, a = lane - 9 * g;
   double accb = 0, accd = 0;
   S* lds = stage[wave];
@@ -113,12 +113,12 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<S> p, S lambda, in
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int so = s + 2 * h + (kk >> 1);
-          S v = S(0);
-          if (i < 9 && so < cnt) {
-            const S* rec = lds + so * RW;
-            const S* arow = rec + 18 + kRecA + 2 * (kk & 1);
-            v = fma(arow[0], rec[i], M::mul_rn(arow[1], rec[9 + i]));
-          }
+          // (unpredicated: the tile's rows 9 .. 15 repeat column 8 and are never read back; records past the chunk's
+          //  end - stale LDS - are replaced by zeros with a select instead of a branch around the LDS reads)
+          const S* rec = lds + so * RW;
+          const S* arow = rec + 18 + kRecA + 2 * (kk & 1);
+          S v = fma(arow[0], rec[i9], M::mul_rn(arow[1], rec[9 + i9]));
+          v = so < cnt ? v : S(0);
           if (h == 0)
             accK = M::mma(v, v, accK);
           else
@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<S> p, S lambda, in
     if (want_G) {
       for (int s = 0; s < cnt; s += 2) {
         const int so = s + (kk >> 1);
-        const S v = (i < 9 && so < cnt) ? lds[so * RW + 9 * (kk & 1) + i] : S(0);
+        const S vg = lds[so * RW + 9 * (kk & 1) + i9];
+        const S v = so < cnt ? vg : S(0);
         accG = M::mma(v, v, accG);
       }
     }
