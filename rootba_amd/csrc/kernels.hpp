@@ -510,7 +510,8 @@ __device__ __forceinline__ void hx_tile_load(const Params<S>& p, const ImplicitT
 // coalesced atomics: 256 x 9 n_c instead of 9 n_obs. The two rows of an observation share the nine adds
 // (row 2i takes components 0,2,4,6,8, row 2i+1 takes 1,3,5,7).
 // ---------------------------------------------------------------------------
-template <class S, int P2>
+// ALL: the window holds every camera (venice-1778 and smaller) - no test, no path of global atomics in the tile loop
+template <class S, int P2, bool ALL>
 __device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int cam, int lane, double* ylds,
                                                     int cam_lo, int win, S* __restrict__ y,
                                                     const S* __restrict__ dout) {
@@ -536,7 +537,7 @@ __device__ __forceinline__ void hx_tile_compute_lds(const HxTileData<S>& d, int 
   // cameras outside the workgroup's window [cam_lo, cam_lo + win) go straight to y (rare: wrap-around
   // and long tracks when the landmarks are sorted by camera; never when the window holds every camera)
   const int rel = (act ? cam : cam_lo) - cam_lo;
-  const bool inside = unsigned(rel) < unsigned(win);
+  const bool inside = ALL || unsigned(rel) < unsigned(win);
   double* yc = ylds + 9 * (inside ? rel : 0) + par;
   S* yg = y + 9 * (act ? cam : 0) + par;
 #pragma unroll
@@ -599,7 +600,7 @@ struct HxWideRanges {
   int begin[1], end[1];
 };
 
-template <class S, int NT>
+template <class S, int NT, bool ALL>
 __global__ __launch_bounds__(NT) void k_hx_implicit_lds(Params<S> p, ImplicitTiles it,
                                                         const HxChunk* __restrict__ chunks, int win,
                                                         const S* __restrict__ x, S* __restrict__ y,
@@ -631,11 +632,11 @@ __global__ __launch_bounds__(NT) void k_hx_implicit_lds(Params<S> p, ImplicitTil
     hx_tile_load(p, it, TA, camA, rowA, lane, x, dA);
     auto compute = [&](int T, const HxTileData<S>& d, int cam) {
       switch (hx_tile_class(it, T)) {
-        case 0: hx_tile_compute_lds<S, 4>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
-        case 1: hx_tile_compute_lds<S, 8>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
-        case 2: hx_tile_compute_lds<S, 16>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
-        case 3: hx_tile_compute_lds<S, 32>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
-        default: hx_tile_compute_lds<S, 64>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
+        case 0: hx_tile_compute_lds<S, 4, ALL>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
+        case 1: hx_tile_compute_lds<S, 8, ALL>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
+        case 2: hx_tile_compute_lds<S, 16, ALL>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
+        case 3: hx_tile_compute_lds<S, 32, ALL>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
+        default: hx_tile_compute_lds<S, 64, ALL>(d, cam, lane, ylds, cam_lo, win, y, dout); break;
       }
     };
     for (;;) {

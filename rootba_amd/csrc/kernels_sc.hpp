@@ -546,30 +546,44 @@ __global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const S* __restrict__ t
   const int u = xcd_swizzled_camera(n_upper);
   if (u >= n_upper) return;
   const int i = lane & 15, kk = lane >> 4;
+  const int i9 = min(i, 8);  // (rows / columns 9 .. 15 of the tile repeat column 8 and are never read back: no predicate)
   Acc acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
   const int64_t q0 = pair_ptr[u], q1 = pair_ptr[u + 1];
+  const int n = int(q1 - q0);  // pairs of this block; positions below are relative to q0
   // 16 pairs per wave and step. A record (one observation's damped top rows) is ONE 128-byte cache line in float: the
   // eight records of a quad of pairs are fetched with one four-scalar load per lane (lane = record x piece), staged in LDS and
   // read back in the operand layout of the matrix-core instruction. (Round 2 gathered 4 bytes per lane straight into
   // the operand registers: six 36-of-64-lane gather instructions per quad kept the kernel on the texture-address
   // path - 0.95 ms on venice whatever the record size or the block order.)
-  constexpr int U = 4;
+  // Round 5, as k_a64_offdiag (kernels_a64.hpp): the records of step s + 1 and the pair indices of step s + 2 are in
+  // flight while step s is multiplied (two register sets, the loop unrolled by two), zero-selects of the staging in
+  // a list's last step only.
+  constexpr int U = sizeof(S) == 8 ? 2 : 4;
   __shared__ __attribute__((aligned(16))) S stage[4][U][8][kTd];
   const int rec = lane >> 3, vec = lane & 7;
-  const int* __restrict__ pair_side = rec < 4 ? pair_oi : pair_oj;
-  for (int64_t q = q0 + wave * (4 * U); q < q1; q += 16 * U) {
-    // (clamped, not predicated: the U index loads go out together, then the U record loads - a load inside a
-    //  conditional is a basic block of its own that waits for its operand and for everything issued before it)
-    V4 v[U];
-    int o[U];
+  const int* __restrict__ pair_side = (rec < 4 ? pair_oi : pair_oj) + q0;
+  const int rsub = rec & 3;
+  const int qw = wave * (4 * U);
+  // (clamped, not predicated: the U index loads go out together, then the U record loads - a load inside a
+  //  conditional is a basic block of its own that waits for its operand and for everything issued before it)
+  auto load_idx = [&](int q, int o[U]) {
 #pragma unroll
-    for (int uq = 0; uq < U; ++uq) o[uq] = pair_side[min(q + 4 * uq + (rec & 3), q1 - 1)];
+    for (int uq = 0; uq < U; ++uq) o[uq] = pair_side[min(q + 4 * uq + rsub, n - 1)];
+  };
+  auto load_rec = [&](const int o[U], V4 v[U]) {
 #pragma unroll
     for (int uq = 0; uq < U; ++uq) v[uq] = reinterpret_cast<const V4*>(topd + kTd * int64_t(o[uq]))[vec];
+  };
+  auto step = [&](int q, const V4 v[U]) {
+    if (q + 4 * U > n) {  // (wave-uniform) the last step of the list
 #pragma unroll
-    for (int uq = 0; uq < U; ++uq) {
-      const bool ok = q + 4 * uq + (rec & 3) < q1;
-      *reinterpret_cast<V4*>(&stage[wave][uq][rec][4 * vec]) = ok ? v[uq] : V4{0, 0, 0, 0};
+      for (int uq = 0; uq < U; ++uq) {
+        const bool ok = q + 4 * uq + rsub < n;
+        *reinterpret_cast<V4*>(&stage[wave][uq][rec][4 * vec]) = ok ? v[uq] : V4{0, 0, 0, 0};
+      }
+    } else {
+#pragma unroll
+      for (int uq = 0; uq < U; ++uq) *reinterpret_cast<V4*>(&stage[wave][uq][rec][4 * vec]) = v[uq];
     }
     wave_lds_fence();
 #pragma unroll
@@ -578,14 +592,30 @@ __global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const S* __restrict__ t
       for (int m = 0; m < 3; ++m) {
         const int g = 4 * m + kk;  // inner index 0..11 = (pair of the quad, factor row)
         const int pp = g / 3, c = g - 3 * pp;
-        const S av = i < 9 ? stage[wave][uq][pp][9 * c + i] : S(0);
-        const S bv = i < 9 ? stage[wave][uq][4 + pp][9 * c + i] : S(0);
-        if (uq & 1)
-          acc2 = M::mma(av, bv, acc2);
+        const S av = stage[wave][uq][pp][9 * c + i9];
+        const S bv = stage[wave][uq][4 + pp][9 * c + i9];
+        if (sizeof(S) == 4 && (uq & 1))
+          acc2 = M::mma(av, bv, acc2);  // (float: two chains; a double instruction holds the pipe for its whole latency)
         else
           acc = M::mma(av, bv, acc);
       }
     wave_lds_fence();  // the next step overwrites the staging buffer
+  };
+  int o_a[U], o_b[U];
+  V4 v_a[U] = {}, v_b[U] = {};
+  if (n > 0) {
+    load_idx(qw, o_a);
+    load_idx(qw + 16 * U, o_b);
+    load_rec(o_a, v_a);
+  }
+  for (int q = qw; q < n; q += 32 * U) {
+    load_rec(o_b, v_b);
+    load_idx(q + 32 * U, o_a);
+    step(q, v_a);
+    if (q + 16 * U >= n) break;
+    load_rec(o_a, v_a);
+    load_idx(q + 48 * U, o_b);
+    step(q + 16 * U, v_b);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] += acc2[r];

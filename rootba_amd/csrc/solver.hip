@@ -2065,12 +2065,18 @@ class Solver final : public rba_solver {
     // (the wavefronts' buffers of the wide landmarks reuse the window)
     ylds_bytes = std::max(ylds_bytes, size_t(NT / 64) * (rba::kHxWideScalars * sizeof(S) + 128));
     if (!hx_lds_attr_set_) {
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_implicit_lds<S, NT>),
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_implicit_lds<S, NT, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kHxLdsMaxBytes)));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rba::k_hx_implicit_lds<S, NT, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(kHxLdsMaxBytes)));
       hx_lds_attr_set_ = true;
     }
-    hipLaunchKernelGGL((rba::k_hx_implicit_lds<S, NT>), dim3(n_hx_chunks_), dim3(NT), ylds_bytes, stream_, prm_, it,
-                       d_hx_chunks_.get(), hx_win_, xin, y, dout, done_flag, wide);
+    if (hx_win_ >= n_cams_)  // every camera in the window: the instance without the path of global atomics
+      hipLaunchKernelGGL((rba::k_hx_implicit_lds<S, NT, true>), dim3(n_hx_chunks_), dim3(NT), ylds_bytes, stream_, prm_, it,
+                         d_hx_chunks_.get(), hx_win_, xin, y, dout, done_flag, wide);
+    else
+      hipLaunchKernelGGL((rba::k_hx_implicit_lds<S, NT, false>), dim3(n_hx_chunks_), dim3(NT), ylds_bytes, stream_, prm_, it,
+                         d_hx_chunks_.get(), hx_win_, xin, y, dout, done_flag, wide);
   }
 
   void right_multiply(const void* x, void* y) override {

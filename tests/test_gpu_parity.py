@@ -950,8 +950,12 @@ def test_persistent_pcg_is_the_two_launch_pcg(ladybug_far, small_problem, mixed_
         assert t0 == t1
         if dtype == np.float64:
             # (a solve that has NOT converged when it stops at max_cg_it is as sensitive to rounding as a long CG
-            #  recurrence gets: the two-launch path itself moves by 4e-6 when the operator switch comes one product later)
-            assert n0 == n1 and rel_err(i0, i1) < (1e-9 if t0 == 1 else 1e-4), (n0, n1, t0, rel_err(i0, i1))
+            #  recurrence gets. Measured on "small", float64, 60 of the 214 iterations convergence takes - the iterate is
+            #  3.6e-2 from the solution: a perturbation of lambda by 1e-13 relative moves the two-launch path's iterate by
+            #  5e-6 ... 1.4e-5 and the persistent kernel's by 2e-4 ... 4.7e-4; either path moves as much when the
+            #  assembly sums a block's pairs in another order. Held to 1e-3: a wrong operator or recurrence shows in the
+            #  CONVERGED solves, which agree to 1e-9.)
+            assert n0 == n1 and rel_err(i0, i1) < (1e-9 if t0 == 1 else 1e-3), (n0, n1, t0, rel_err(i0, i1))
         else:
             assert abs(n0 - n1) <= max(1, n0 // 10), (n0, n1)
             if n0 == n1:
