@@ -85,7 +85,17 @@ struct Params {
   int jacobi;  // preconditioner_type == JACOBI / POWER_SCHUR_COMPLEMENT: blocks = Hpp + lambda I
   S huber;
   S eps;  // jacobi scaling epsilon
+  // stage timers of rba_lm_step (solver.hip: time_begin / time_end): the FIRST kernel of a stage leaves the chip-wide
+  // 100 MHz clock here when it starts (nullptr otherwise) - a HIP event per stage boundary is a marker packet of ~4 us
+  // on the queue, 50 us per LM iteration (15 % of a trafalgar-257 iteration)
+  unsigned long long* stamp;
 };
+
+__device__ __forceinline__ void stage_stamp(unsigned long long* s) {
+  if (s && blockIdx.x == 0 && threadIdx.x == 0) *s = wall_clock64();
+}
+// a stage boundary that no kernel takes with it (before a synchronisation)
+__global__ void k_stamp(unsigned long long* s) { *s = wall_clock64(); }
 
 // End of a landmark's back-substitution: model-cost term, non-finite check, and the update (ipp:279-283): lms +=
 // Jl_col_scale * inc, or - mixed precision - the scaled increment is handed to the double master state
@@ -125,6 +135,7 @@ __device__ __forceinline__ void finish_landmark(const Params<S>& p, int s, const
 template <class S>
 __global__ __launch_bounds__(256) void k_compute_error(Params<S> p, int64_t n_obs,
                                                        double* __restrict__ partials) {
+  stage_stamp(p.stamp);
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   // (the two indices of the work-item's NEXT observation are requested before the current one is gathered: one memory
   //  round trip per observation instead of two dependent ones)
@@ -178,7 +189,7 @@ template <int W>
 __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ in, int64_t n,
                                                       double* __restrict__ out, double* __restrict__ out_host,
                                                       int* __restrict__ flag, int* __restrict__ flag_host,
-                                                      int flag_clear) {
+                                                      int flag_clear, unsigned long long* __restrict__ end_stamp) {
   const int nt = int(blockDim.x), n_waves = nt >> 6;
   if (flag_host && int(threadIdx.x) == nt - 1) {
     const int f = *flag;
@@ -205,6 +216,7 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
     for (int w = 1; w < n_waves; ++w) t += sm[w][threadIdx.x];
     out[threadIdx.x] = t;
     if (out_host) out_host[threadIdx.x] = t;
+    if (end_stamp && threadIdx.x == 0) *end_stamp = wall_clock64();  // (the last kernel of its stage: see stage_stamp)
   }
 }
 
@@ -1149,6 +1161,7 @@ __device__ __forceinline__ void bs_tile_compute(const Params<S>& p, const BsTile
 
 template <class S>
 __global__ __launch_bounds__(256) void k_bs_tile(Params<S> p, ImplicitTiles it, const S* __restrict__ x) {
+  stage_stamp(p.stamp);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int T = blockIdx.x * 4 + wave;
   if (T >= it.tile_begin[5]) return;
@@ -1220,6 +1233,7 @@ __device__ __forceinline__ void retract_camera(S* cam, const S inc[9]) {
 
 template <class S>
 __global__ void k_update_cameras(Params<S> p, const S* __restrict__ inc_scaled) {
+  stage_stamp(p.stamp);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= p.n_cams) return;
   S inc[9];
@@ -1236,7 +1250,8 @@ __global__ void k_update_cameras(Params<S> p, const S* __restrict__ inc_scaled) 
 // ---------------------------------------------------------------------------
 __global__ void k_mixed_update_cameras(double* __restrict__ cams64, float* __restrict__ cams32,
                                        const float* __restrict__ inc_scaled, const float* __restrict__ pose_scaling,
-                                       int n_cams) {
+                                       int n_cams, unsigned long long* __restrict__ stamp) {
+  stage_stamp(stamp);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cams) return;
   double inc[9];
@@ -1279,7 +1294,8 @@ __global__ void k_mixed_round(const double* __restrict__ src, float* __restrict_
 // `damp` is added to their diagonal; the inverse is stored in the solver scalar.
 template <class S, class SB = S>
 __global__ __launch_bounds__(64) void k_invert_blocks(const SB* __restrict__ blocks, S* __restrict__ inv, int n_cams,
-                                int* fail_flag, SB damp = SB(0)) {
+                                int* fail_flag, SB damp = SB(0), unsigned long long* __restrict__ stamp = nullptr) {
+  stage_stamp(stamp);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cams) return;
   using T = SB;
@@ -1442,7 +1458,9 @@ __global__ __launch_bounds__(1024) void k_solve_check(const S* __restrict__ x, c
 // x = 0, r = b, state reset, |b|^2   (single workgroup)
 template <class S>
 __global__ __launch_bounds__(1024) void k_pcg_init(const S* __restrict__ bvec, S* __restrict__ x,
-                                                  S* __restrict__ r, int n, CgState* st) {
+                                                  S* __restrict__ r, int n, CgState* st,
+                                                  unsigned long long* __restrict__ stamp) {
+  stage_stamp(stamp);
   __shared__ double sm[16];
   double acc = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1754,7 +1772,9 @@ __global__ void k_sub_diag(S* __restrict__ blocks, S excess, int n_cams) {
 
 // out[i] = d[i] * v[i] (out may alias v): the pose scaling applied to a camera-sized vector (compact stage 2)
 template <class S>
-__global__ void k_scale_vec(const S* __restrict__ v, const S* __restrict__ d, S* __restrict__ out, int n) {
+__global__ void k_scale_vec(const S* __restrict__ v, const S* __restrict__ d, S* __restrict__ out, int n,
+                            unsigned long long* __restrict__ stamp) {
+  stage_stamp(stamp);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = d[i] * v[i];
 }

@@ -686,7 +686,8 @@ template <class S>
 __global__ __launch_bounds__(256) void k_pcgs_start(const S* __restrict__ inv, const S* __restrict__ bvec,
                                                     S* __restrict__ x, S* __restrict__ r, S* __restrict__ z, int n_cams,
                                                     CgState* st, double* __restrict__ part_rho, double lambda,
-                                                    int pswap) {
+                                                    int pswap, unsigned long long* __restrict__ stamp) {
+  stage_stamp(stamp);
   __shared__ double sm[4];
   __shared__ S rl[252];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

@@ -43,6 +43,7 @@ namespace rba {
 // ---------------------------------------------------------------------------
 template <class S>
 __global__ __launch_bounds__(256) void k_s1_geometry(Params<S> p, int64_t o_begin, int64_t n_obs) {
+  stage_stamp(p.stamp);
   extern __shared__ __attribute__((aligned(16))) char smem_s1[];
   S* sj = reinterpret_cast<S*>(smem_s1);  // [256][18]
   S* sv = sj + 256 * 18;                  // [256][8]
@@ -370,6 +371,7 @@ __device__ __forceinline__ void s1_fused_obs(const Params<S>& p, int T0, int n_t
 
 template <class S>
 __global__ __launch_bounds__(256) void k_s1_fused_obs(Params<S> p, ImplicitTiles it, FusedObsWaves fw) {
+  stage_stamp(p.stamp);
   __shared__ __attribute__((aligned(16))) S stage[4][64 * 18];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int W = blockIdx.x * 4 + wave;  // wavefront = a pair of row tiles of one class
@@ -659,6 +661,7 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
 // ---------------------------------------------------------------------------
 template <class S>
 __global__ __launch_bounds__(256) void k_s2_obs(Params<S> p, int64_t n_obs, S lambda) {
+  stage_stamp(p.stamp);
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
   // The landmark records (rotations 16, damped triangle 6, damped Q1^T r 3, damping-row residual 3, Z 9) of the
   // landmarks whose FIRST observation lies in this workgroup - consecutive landmarks sA .. sA + nH - 1, at most 128

@@ -598,6 +598,14 @@ class Solver final : public rba_solver {
     d_p2_.alloc(nvec_);
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 4096));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_progress_), 64));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_stamps_), kMaxStamps * sizeof(unsigned long long)));
+    {
+      int khz = 0;  // (the clock of wall_clock64() / s_memrealtime: 100 MHz on gfx950)
+      if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_) == hipSuccess && khz > 0)
+        stamp_hz_ = double(khz) * 1e3;
+      else
+        (void)hipGetLastError();
+    }
     h_progress_[0] = h_progress_[1] = 0;
     HIP_CHECK(hipEventCreate(&ev_asm0_));
     HIP_CHECK(hipEventCreate(&ev_asm1_));
@@ -1148,13 +1156,19 @@ class Solver final : public rba_solver {
           all_reduce(d_gram64_.get(), size_t(81) * n_cams_);
           gram64_valid_ = true;
         }
-        hipLaunchKernelGGL((rba::k_invert_blocks<S, double>), dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_,
-                           d_gram64_.get(), d_inv_.get(), n_cams_, d_fail_.get(), double(lambda));
+        {  // (evaluated once, ahead of the launch macro)
+          unsigned long long* const stamp_ptr_ = stamp();
+          hipLaunchKernelGGL((rba::k_invert_blocks<S, double>), dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_,
+                             d_gram64_.get(), d_inv_.get(), n_cams_, d_fail_.get(), double(lambda), stamp_ptr_);
+        }
         return;
       }
     }
-    hipLaunchKernelGGL((rba::k_invert_blocks<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_, prm_.blocks,
-                       d_inv_.get(), n_cams_, d_fail_.get(), S(0));
+    {  // (evaluated once, ahead of the launch macro)
+      unsigned long long* const stamp_ptr_ = stamp();
+      hipLaunchKernelGGL((rba::k_invert_blocks<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_, prm_.blocks,
+                         d_inv_.get(), n_cams_, d_fail_.get(), S(0), stamp_ptr_);
+    }
   }
   void assemble_values() {
     if constexpr (kA64) {
@@ -1360,6 +1374,8 @@ class Solver final : public rba_solver {
     if (h_pinned_) (void)hipHostFree(h_pinned_);
     h_pinned_ = nullptr;
     if (h_progress_) (void)hipHostFree(h_progress_);
+    if (h_stamps_) (void)hipHostFree(h_stamps_);
+    h_stamps_ = nullptr;
     h_progress_ = nullptr;
     if (side_stream_) {
       (void)hipStreamSynchronize(side_stream_);
@@ -1692,21 +1708,32 @@ class Solver final : public rba_solver {
       HIP_CHECK(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
     }
     time_begin(st);
+    // (device stamps: the evaluation kernel stamps its start - the pending boundary of the solver stream, or the side
+    //  stream's own - and the reduction kernel, a single workgroup, the stage's end)
+    unsigned long long* s_begin = side ? stamp_side_ : stamp();
+    stamp_side_ = nullptr;
+    const int end_slot = stamps_on() ? stamp_slot() : -1;
+    unsigned long long* s_end = end_slot >= 0 ? h_stamps_ + end_slot : nullptr;
     const int blocks = int(std::min<int64_t>(kReduceBlocks, (n_obs_ + 255) / 256));
-    if (mixed_)
-      hipLaunchKernelGGL((rba::k_compute_error<double>), dim3(blocks), dim3(256), 0, st, prm64_, n_obs_, part);
-    else
-      hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, st, prm_, n_obs_, part);
+    if (mixed_) {
+      rba::Params<double> p64 = prm64_;
+      p64.stamp = s_begin;
+      hipLaunchKernelGGL((rba::k_compute_error<double>), dim3(blocks), dim3(256), 0, st, p64, n_obs_, part);
+    } else {
+      rba::Params<S> ps = prm_;
+      ps.stamp = s_begin;
+      hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, st, ps, n_obs_, part);
+    }
     double* red = part + size_t(kReduceBlocks) * 8;
     const bool direct = results_go_direct();
     hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, st, part, int64_t(blocks), red,
                        direct ? h : static_cast<double*>(nullptr), static_cast<int*>(nullptr),
-                       static_cast<int*>(nullptr), 0);
+                       static_cast<int*>(nullptr), 0, s_end);
     if (!direct) {
       all_reduce(red, 8);
       HIP_CHECK(hipMemcpyAsync(h, red, 8 * sizeof(double), hipMemcpyDeviceToHost, stream_));
     }
-    time_end(&timings_.residual_evaluation_time, true, st);
+    time_end(&timings_.residual_evaluation_time, true, st, end_slot);
     if (side) {
       HIP_CHECK(hipEventRecord(ev_join_, side_stream_));
       side_pending_ = true;
@@ -1745,13 +1772,18 @@ class Solver final : public rba_solver {
       // (rounded down to an even observation: the kernel's 16-byte stores stay aligned; the fused kernel, later in the
       //  stream, writes that observation again)
       const int64_t o_begin = fuse ? (n_obs_tiled_ & ~int64_t(1)) : 0;
-      if (o_begin < n_obs_)
+      if (o_begin < n_obs_) {
+        const rba::Params<S> prm_st_ = prm_stamped();
         hipLaunchKernelGGL((rba::k_s1_geometry<S>), dim3(unsigned((n_obs_ - o_begin + 255) / 256)), dim3(256),
-                           256 * 26 * sizeof(S), stream_, prm_, o_begin, int64_t(n_obs_));
+                           256 * 26 * sizeof(S), stream_, prm_st_, o_begin, int64_t(n_obs_));
+      }
       if (fuse) {
         const rba::FusedObsWaves fw = fused_obs_waves();
-        hipLaunchKernelGGL((rba::k_s1_fused_obs<S>), dim3((fw.wave_begin[5] + 3) / 4), dim3(256), 0, stream_, prm_,
-                           implicit_tiles(), fw);
+        {  // (evaluated once, ahead of the launch macro)
+          const rba::Params<S> prm_st_ = prm_stamped();
+          hipLaunchKernelGGL((rba::k_s1_fused_obs<S>), dim3((fw.wave_begin[5] + 3) / 4), dim3(256), 0, stream_,
+                             prm_st_, implicit_tiles(), fw);
+        }
       }
       sub_mark(&sub_.jacobian_evaluation_time);  // linearize_problem()
       // One GPU: the Gram pass (Jp_diag2, pose scaling, B_mid) is folded into the camera-major pass of the first
@@ -1851,8 +1883,11 @@ class Solver final : public rba_solver {
     sub_begin();
     // landmark side: the six damping rotations per landmark and the stage-2 record of every observation
     // (set_landmark_damping + scale_Jp_cols + the per-column part of the damping, kernels_s1.hpp)
-    hipLaunchKernelGGL((rba::k_s2_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0, stream_, prm_,
-                       int64_t(n_obs_), lambda);
+    {  // (evaluated once, ahead of the launch macro)
+      const rba::Params<S> prm_st_ = prm_stamped();
+      hipLaunchKernelGGL((rba::k_s2_obs<S>), dim3(unsigned((n_obs_ + 255) / 256)), dim3(256), 0, stream_, prm_st_,
+                         int64_t(n_obs_), lambda);
+    }
     topd_valid_ = false;
     sub_mark(&sub_.scale_pose_jacobian_time);
     launch_cam_stage2(prm_, lambda);
@@ -1978,8 +2013,9 @@ class Solver final : public rba_solver {
   // x -> D x for the kernels that read the unscaled Jacobian rows
   const S* scaled_operand(const S* x) {
     if (operand_prescaled_) return d_xs_.get();  // the producer of x wrote D x already (k_pcg_a2)
+    unsigned long long* const stamp_ptr_ = stamp();  // (evaluated once, ahead of the launch macro)
     hipLaunchKernelGGL((rba::k_scale_vec<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, x, prm_.pose_scaling,
-                       d_xs_.get(), nvec_);
+                       d_xs_.get(), nvec_, stamp_ptr_);
     return d_xs_.get();
   }
 
@@ -2383,6 +2419,7 @@ class Solver final : public rba_solver {
     solve_cg_ = cg;
     if (solve_defer_) return RBA_OK;  // rba_lm_step calls solve_collect() after its synchronisation
     if (lm_async_) {  // the caller reads the increment, and the product timers below need their events completed
+      stamp_close();
       sync();
       flush_timers();
     }
@@ -2456,11 +2493,16 @@ class Solver final : public rba_solver {
     const double eta = opt_.eta;
     rba::CgState* hst = reinterpret_cast<rba::CgState*>(h_pinned_);
     const bool mf_protocol = !sc_ && opt_.preconditioner_type != 2;
-    if (mf_protocol)
+    if (mf_protocol) {
+      unsigned long long* const stamp_ptr_ = stamp();
       hipLaunchKernelGGL((rba::k_pcgs_start<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), b, d_x_.get(),
-                         d_r_.get(), d_z_.get(), n_cams_, st, part_rho, double(lambda), 0);
-    else
-      hipLaunchKernelGGL((rba::k_pcg_init<S>), dim3(1), dim3(1024), 0, stream_, b, d_x_.get(), d_r_.get(), n, st);
+                         d_r_.get(), d_z_.get(), n_cams_, st, part_rho, double(lambda), 0, stamp_ptr_);
+    }
+    else {
+      unsigned long long* const stamp_ptr_ = stamp();
+      hipLaunchKernelGGL((rba::k_pcg_init<S>), dim3(1), dim3(1024), 0, stream_, b, d_x_.get(), d_r_.get(), n, st,
+                         stamp_ptr_);
+    }
     // The host polls the device state lazily: every iteration at first (many
     // solves need 2-3 iterations), every 4th later; kernels queued past the end
     // are no-ops (`done`).
@@ -2761,8 +2803,11 @@ class Solver final : public rba_solver {
       int64_t o0 = 0;
       const S* xin = scaled_operand(d_inc_.get());  // D inc for the unscaled Jacobian rows
       if (n_tiles_ > 0) {
-        hipLaunchKernelGGL((rba::k_bs_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_, implicit_tiles(),
-                           xin);
+        {  // (evaluated once, ahead of the launch macro)
+          const rba::Params<S> prm_st_ = prm_stamped();
+          hipLaunchKernelGGL((rba::k_bs_tile<S>), dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, prm_st_,
+                             implicit_tiles(), xin);
+        }
         lm0 = imp_end_[4];
         o0 = n_obs_tiled_;
       }
@@ -2788,10 +2833,11 @@ class Solver final : public rba_solver {
     if (results_go_direct()) {
       // l_diff and the failure word (bits 2: back-substitution, 4: block inversion of the solve) land in the pinned page
       hipLaunchKernelGGL((rba::k_reduce_rows<1>), dim3(1), dim3(256), 0, stream_, d_partials_.get(), int64_t(blocks),
-                         red, l_diff, d_fail_.get(), fail, 2 | 4);
+                         red, l_diff, d_fail_.get(), fail, 2 | 4, static_cast<unsigned long long*>(nullptr));
     } else {
       hipLaunchKernelGGL((rba::k_reduce_rows<1>), dim3(1), dim3(256), 0, stream_, d_partials_.get(), int64_t(blocks),
-                         red, static_cast<double*>(nullptr), static_cast<int*>(nullptr), static_cast<int*>(nullptr), 0);
+                         red, static_cast<double*>(nullptr), static_cast<int*>(nullptr), static_cast<int*>(nullptr), 0,
+                         static_cast<unsigned long long*>(nullptr));
       all_reduce(red, 1);
       all_reduce(d_fail_.get(), 1, kNcclMax);
       HIP_CHECK(hipMemcpyAsync(l_diff, red, sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -2813,14 +2859,18 @@ class Solver final : public rba_solver {
     }
     if (update_cams) {
       time_begin();
-      if (mixed_)
+      if (mixed_) {
+        unsigned long long* const stamp_ptr_ = stamp();
         hipLaunchKernelGGL(rba::k_mixed_update_cameras, dim3((n_cams_ + 63) / 64), dim3(64), 0, stream_,
                            d_cams64_.get(), reinterpret_cast<float*>(d_cams_.get()),
                            reinterpret_cast<const float*>(d_inc_.get()),
-                           reinterpret_cast<const float*>(prm_.pose_scaling), n_cams_);
-      else
+                           reinterpret_cast<const float*>(prm_.pose_scaling), n_cams_, stamp_ptr_);
+      }
+      else {
+        const rba::Params<S> prm_st_ = prm_stamped();
         hipLaunchKernelGGL((rba::k_update_cameras<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0,
-                           stream_, prm_, d_inc_.get());
+                           stream_, prm_st_, d_inc_.get());
+      }
       time_end(&timings_.update_cameras_time);
     }
     return RBA_OK;
@@ -2870,6 +2920,7 @@ class Solver final : public rba_solver {
     FlagScope async_scope(lm_async_, !sub_timing());
     auto finish = [&](bool keep_going) {
       if (lm_async_) {
+        stamp_close();
         sync();
         flush_timers();
       }
@@ -2947,6 +2998,7 @@ class Solver final : public rba_solver {
       backup();
       apply(nullptr, &l_diff_d, true);
       compute_error_enqueue(pinned_doubles(kPinCe1));
+      stamp_close();
       sync();
       flush_timers();
       solve_collect(&cg);
@@ -2981,6 +3033,7 @@ class Solver final : public rba_solver {
       backup();
       apply(nullptr, &l_diff_d, true);
       compute_error_enqueue(pinned_doubles(kPinCe1));
+      stamp_close();
       sync();
       flush_timers();
     }
@@ -3248,11 +3301,76 @@ class Solver final : public rba_solver {
     }
     return timer_pool_[timer_pool_used_++];
   }
+  // Inside rba_lm_step (lm_async_) the stage boundaries are DEVICE stamps instead of events: the first kernel of a stage
+  // writes the chip-wide 100 MHz clock into a pinned slot when it starts (kernels.hpp: stage_stamp) - the end of a stage
+  // is the start of the next one's first kernel on the same stream, or the end of its own last kernel where that is a
+  // single workgroup (k_reduce_rows) - and the slots are read after the iteration's synchronisation. (A HIP event is a
+  // marker packet of ~4 us on the queue: the twelve of an LM iteration cost 50 us - 3.5 % of a venice iteration, 15 % of
+  // a trafalgar-257 iteration, measured with RBA_STAGE_TIMERS=0.) RBA_STAGE_TIMERS=2: events everywhere, as before.
+  static constexpr int kMaxStamps = 256;
+  struct PendingStamp {
+    int s0, s1;
+    double* field;
+    bool accumulate;
+  };
+  bool stamps_on() const { return lm_async_ && env_.stage_timers == 1 && h_stamps_; }
+  int stamp_slot() {
+    if (stamp_n_ >= kMaxStamps) return -1;
+    h_stamps_[stamp_n_] = 0;
+    return stamp_n_++;
+  }
+  // the pending stage boundary, for the kernel that is launched next on the solver stream (nullptr: none pending)
+  unsigned long long* stamp() {
+    if (!stamps_on() || stamp_pending_ < 0) return nullptr;
+    unsigned long long* p = h_stamps_ + stamp_pending_;
+    stamp_pending_ = -1;
+    return p;
+  }
+  rba::Params<S> prm_stamped() {
+    rba::Params<S> p = prm_;
+    p.stamp = stamp();
+    return p;
+  }
+  // a boundary that no kernel has taken before the stream is synchronised
+  void stamp_close() {
+    if (unsigned long long* p = stamp()) hipLaunchKernelGGL(rba::k_stamp, dim3(1), dim3(1), 0, stream_, p);
+  }
   void time_begin(hipStream_t st = nullptr) {
+    if (!env_.stage_timers) return;
+    if (stamps_on()) {
+      if (st && st != stream_) {  // (side stream: a pair of its own, see time_end)
+        stamp_side_slot_ = stamp_slot();
+        stamp_side_ = stamp_side_slot_ >= 0 ? h_stamps_ + stamp_side_slot_ : nullptr;
+        return;
+      }
+      if (stamp_pending_ < 0) stamp_pending_ = stamp_slot();
+      stamp_begin_ = stamp_pending_;
+      return;
+    }
     timer_t0_ = timer_event();
     HIP_CHECK(hipEventRecord(timer_t0_, st ? st : stream_));
   }
-  void time_end(double* field, bool accumulate = false, hipStream_t st = nullptr) {
+  // `end_slot` >= 0: the stage's last kernel has stamped its own end there (stamp_end_slot())
+  void time_end(double* field, bool accumulate = false, hipStream_t st = nullptr, int end_slot = -1) {
+    if (!env_.stage_timers) return;
+    if (stamps_on()) {
+      int e = end_slot;
+      if (st && st != stream_) {  // side stream: begin stamped by the stage's first kernel, end by its last
+        if (stamp_side_slot_ >= 0 && e >= 0) pending_stamps_.push_back(PendingStamp{stamp_side_slot_, e, field, accumulate});
+        stamp_side_slot_ = -1;
+        return;
+      }
+      if (e < 0) {
+        if (stamp_pending_ >= 0 && stamp_pending_ == stamp_begin_) {
+          e = stamp_begin_;  // no kernel took the begin boundary: an empty stage
+        } else {
+          e = stamp_slot();
+          stamp_pending_ = e;
+        }
+      }
+      if (stamp_begin_ >= 0 && e >= 0) pending_stamps_.push_back(PendingStamp{stamp_begin_, e, field, accumulate});
+      return;
+    }
     hipEvent_t e1 = timer_event();
     HIP_CHECK(hipEventRecord(e1, st ? st : stream_));
     pending_timers_.push_back(PendingTimer{timer_t0_, e1, field, accumulate});
@@ -3270,6 +3388,16 @@ class Solver final : public rba_solver {
     }
     pending_timers_.clear();
     timer_pool_used_ = 0;
+    for (const PendingStamp& t : pending_stamps_) {
+      const unsigned long long a = h_stamps_[t.s0], b = h_stamps_[t.s1];
+      const double sec = (a && b && b >= a) ? double(b - a) / stamp_hz_ : 0.0;  // (0: a boundary nobody stamped)
+      *t.field = (t.accumulate ? *t.field : 0.0) + sec;
+    }
+    pending_stamps_.clear();
+    stamp_n_ = 0;
+    stamp_pending_ = -1;
+    stamp_begin_ = -1;
+    stamp_side_slot_ = -1;
   }
   void reset_timings() {
     timings_ = rba_iter_timings{};
@@ -3334,6 +3462,7 @@ class Solver final : public rba_solver {
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
                                        // over the ranks (default: where the estimate says it pays)
     int hx_wide_inside = 1;            // RBA_HX_WIDE_INSIDE=0: landmarks with 32 < k <= 64 in a kernel of their own
+    int stage_timers = 1;              // RBA_STAGE_TIMERS=0: no HIP events around the stages (rba_iter_timings stays zero)
     int pcgp_test_give_up = 0;         // RBA_PCGP_TEST_GIVE_UP=1: test hook of the collective fallback of a sharded run
     int deterministic = 0;             // RBA_DETERMINISTIC=1: matrix-free products summed camera-major in a fixed order
                                        // (no floating-point atomics anywhere: runs repeat bit by bit; ~2 x per product)
@@ -3362,6 +3491,7 @@ class Solver final : public rba_solver {
     env_.hx_wide_inside = geti("RBA_HX_WIDE_INSIDE", 1);
     env_.deterministic = geti("RBA_DETERMINISTIC", 0);
     env_.pcgp_test_give_up = geti("RBA_PCGP_TEST_GIVE_UP", 0);
+    env_.stage_timers = geti("RBA_STAGE_TIMERS", 1);
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     env_.pcg_persistent = geti("RBA_PCG_PERSISTENT", 1);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
@@ -3417,6 +3547,11 @@ class Solver final : public rba_solver {
   std::vector<hipEvent_t> timer_pool_;
   size_t timer_pool_used_ = 0;
   std::vector<PendingTimer> pending_timers_;
+  unsigned long long* h_stamps_ = nullptr;  // pinned: stage boundaries of rba_lm_step (time_begin / time_end)
+  unsigned long long* stamp_side_ = nullptr;
+  int stamp_n_ = 0, stamp_pending_ = -1, stamp_begin_ = -1, stamp_side_slot_ = -1;
+  double stamp_hz_ = 1e8;
+  std::vector<PendingStamp> pending_stamps_;
   bool lm_async_ = false;  // inside rba_lm_step: results and timers are collected at the iteration's own sync points
   std::vector<hipEvent_t> hx_events_;
   std::vector<int> hx_event_call_;  // which H*x call of the solve each event pair brackets

@@ -404,7 +404,11 @@ hipError_t hipGetDevice(int* d) {
   *d = 0;
   return hipSuccess;
 }
-hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
+  if (a == hipDeviceAttributeWallClockRate) {  // (wall_clock64() is the time-stamp counter here: a nominal 3 GHz, in kHz)
+    *v = 3000000;
+    return hipSuccess;
+  }
   // "compute units": keeps the persistent kernels' grids small. A kernel whose workgroups wait for each other
   // (kernels_pcgp.hpp) needs them all running at once: HIPEMU_CUS <= HIPEMU_THREADS
   static const int cus = [] {
