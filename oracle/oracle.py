@@ -42,7 +42,7 @@ class Options(C.Structure):
         ("optimized_cost", C.c_int),
         ("staged_execution", C.c_int),
         ("implicit_q", C.c_int),  # product-only switch; the oracle has one operator
-        ("solver_type", C.c_int),  # 0 SQUARE_ROOT, 1 SCHUR_COMPLEMENT
+        ("solver_type", C.c_int),  # 0 SQUARE_ROOT, 1 SCHUR_COMPLEMENT, 2 SCHUR_COMPLEMENT matrix-free (large-problem referee; oracle only)
         ("explicit_after", C.c_int),  # product-only
     ]
 
@@ -221,6 +221,8 @@ class Oracle:
         return int(self._fn("linearize")(self.h))
 
     def solve(self, lam):
+        if self.options.solver_type == 2 and self.options.preconditioner_type != 1:
+            raise ValueError("solver_type 2 (matrix-free Schur complement, the large-problem referee): SCHUR_JACOBI only")
         inc = self._vec(9 * self.n_cams)
         cg = CgSummary()
         self._fn("solve")(self.h, self.ct(lam), _ptr(inc, self.ct), C.byref(cg))

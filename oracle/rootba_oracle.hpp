@@ -47,6 +47,7 @@
 #ifdef _OPENMP
 #include <omp.h>
 #include <memory>
+#include <stdexcept>
 #include <cstdlib>
 #endif
 
@@ -467,7 +468,8 @@ class Oracle {
     size_t off = 0;
     for (int l = 0; l < n_lms; ++l) {
       blk_off_[l] = off;
-      off += size_t(rows(l)) * cols(l);
+      // (solver_type 2, the matrix-free Schur-complement referee: no dense landmark blocks - that is its point)
+      if (opt_.solver_type != 2) off += size_t(rows(l)) * cols(l);
     }
     blk_off_[n_lms] = off;
 #ifdef _OPENMP
@@ -480,7 +482,7 @@ class Oracle {
     // on the NUMA node of its worker (a zero-filling std::vector would put all of it on the
     // constructing thread's node - on a two-socket host every product then crosses the socket link).
     storage_size_ = off;
-    storage_.reset(static_cast<S*>(std::aligned_alloc(64, (off * sizeof(S) + 63) / 64 * 64)));
+    storage_.reset(static_cast<S*>(std::aligned_alloc(64, (std::max<size_t>(off, 8) * sizeof(S) + 63) / 64 * 64)));
     if (!storage_) throw std::bad_alloc();
 #pragma omp parallel for num_threads(n_threads_) schedule(static)
     for (int l = 0; l < n_lms; ++l)
@@ -979,6 +981,22 @@ class Oracle {
   // (linearization_qr.hpp:406-429, 821-825)
   void right_multiply(const S* x, S* y) const {
     const size_t n = size_t(P) * n_cams_;
+    if (opt_.solver_type == 2) {
+      // the same system without its matrix: (S + lambda I) x = (Hpp + lambda I) x - E0 x from the per-observation
+      // Jacobians (sc_mf_prepare)
+      power_e0_mult(x, y);
+#pragma omp parallel for num_threads(n_threads_) schedule(static)
+      for (int c = 0; c < n_cams_; ++c) {
+        const S* B = &mf_Hpp_[size_t(81) * c];
+        const S* xc = x + size_t(P) * c;
+        for (int a = 0; a < P; ++a) {
+          S v = 0;
+          for (int bb = 0; bb < P; ++bb) v += B[a * P + bb] * xc[bb];
+          y[size_t(P) * c + a] = v - y[size_t(P) * c + a];
+        }
+      }
+      return;
+    }
     if (opt_.solver_type == 1) {
       // BlockSparseMatrix::right_multiply on H_pp (block_sparse_matrix.hpp); H already
       // holds the pose damping (linearization_sc.hpp:323-327)
@@ -1102,37 +1120,118 @@ class Oracle {
     build_preconditioner(Hpp, diag.data());  // inv_blocks_ = Hpp^-1
   }
 
-  // right_mul_e0 (preconditioner.hpp:223-245)
+  // right_mul_e0 (preconditioner.hpp:223-245); landmarks in parallel into the per-thread accumulators of the products
+  // (static schedule, combined in thread order: the result does not depend on timing)
   void power_e0_mult(const S* x, S* res) const {
-    std::fill(res, res + size_t(P) * n_cams_, S(0));
-    for (int l = 0; l < n_lms_; ++l) {
-      const int K = k(l);
-      const int64_t o0 = lm_off_[l];
-      const S* Jp = &pw_Jp_[18 * o0];
-      const S* Jl = &pw_Jl_[6 * o0];
-      const S* Hi = &pw_Hll_inv_[size_t(9) * l];
-      std::vector<S> Jp_x(2 * K);
-      S JlT[3] = {0, 0, 0};
-      for (int i = 0; i < K; ++i) {
-        const S* v = x + P * obs_cam_[o0 + i];
-        for (int rr = 0; rr < 2; ++rr) {
-          S acc = 0;
-          for (int a = 0; a < P; ++a) acc += Jp[(2 * i + rr) * P + a] * v[a];
-          Jp_x[2 * i + rr] = acc;
-          for (int c = 0; c < 3; ++c) JlT[c] += Jl[(2 * i + rr) * 3 + c] * acc;
+    const size_t n = size_t(P) * n_cams_;
+    // (the power-series preconditioner of solver types 0 / 1 keeps the serial landmark order its golden vectors were
+    //  made with; the matrix-free referee, solver_type 2, runs this product on all threads)
+    const int nt = opt_.solver_type == 2 ? n_threads_ : 1;
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+      const int tid = omp_get_thread_num();
+#else
+      const int tid = 0;
+#endif
+      S* acc = acc_[tid].data();
+      std::fill(acc, acc + n, S(0));
+      std::vector<S> Jp_x;
+#pragma omp for schedule(static)
+      for (int l = 0; l < n_lms_; ++l) {
+        const int K = k(l);
+        const int64_t o0 = lm_off_[l];
+        const S* Jp = &pw_Jp_[18 * o0];
+        const S* Jl = &pw_Jl_[6 * o0];
+        const S* Hi = &pw_Hll_inv_[size_t(9) * l];
+        Jp_x.assign(2 * K, S(0));
+        S JlT[3] = {0, 0, 0};
+        for (int i = 0; i < K; ++i) {
+          const S* v = x + P * obs_cam_[o0 + i];
+          for (int rr = 0; rr < 2; ++rr) {
+            S a2 = 0;
+            for (int a = 0; a < P; ++a) a2 += Jp[(2 * i + rr) * P + a] * v[a];
+            Jp_x[2 * i + rr] = a2;
+            for (int c = 0; c < 3; ++c) JlT[c] += Jl[(2 * i + rr) * 3 + c] * a2;
+          }
+        }
+        S h[3];
+        for (int a = 0; a < 3; ++a) h[a] = Hi[a * 3] * JlT[0] + Hi[a * 3 + 1] * JlT[1] + Hi[a * 3 + 2] * JlT[2];
+        for (int i = 0; i < K; ++i) {
+          S* out = acc + P * obs_cam_[o0 + i];
+          for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * i + rr;
+            const S t = Jl[row * 3] * h[0] + Jl[row * 3 + 1] * h[1] + Jl[row * 3 + 2] * h[2];
+            for (int a = 0; a < P; ++a) out[a] += Jp[row * P + a] * t;
+          }
         }
       }
-      S h[3];
-      for (int a = 0; a < 3; ++a) h[a] = Hi[a * 3] * JlT[0] + Hi[a * 3 + 1] * JlT[1] + Hi[a * 3 + 2] * JlT[2];
+#pragma omp for schedule(static)
+      for (int64_t i = 0; i < int64_t(n); ++i) {
+        S v = 0;
+        for (int t = 0; t < nt; ++t) v += acc_[t][i];
+        res[i] = v;
+      }
+    }
+  }
+
+  // -------------------------------------------------------------------------
+  // solver_type 2: the Schur-complement system of solver_type 1 (LinearizorSC, linearizor_sc.cpp:101-186) WITHOUT its
+  // matrix - the dense H_pp of sc_build is 9 n_c x 9 n_c scalars (121 GB for final-13682 in double) and the dense
+  // landmark blocks of the square-root solver 55 GB, while the per-observation Jacobians are 24 scalars per observation
+  // (5.6 GB). (S + lambda I) x = (Hpp + lambda I) x - E0 x with E0 as in the power series above; SCHUR_JACOBI
+  // preconditioner = the inverted diagonal blocks of S + lambda I. Same system, same PCG recurrence: in exact arithmetic
+  // the iterates are those of solver types 0 and 1 - in float64 this is the INDEPENDENT referee of the float32 runs at
+  // sizes where the other two do not fit the host (tests/test_gpu_baseline_configs.py).
+  // -------------------------------------------------------------------------
+  void sc_mf_prepare(S lambda) {
+    pw_Jp_.assign(size_t(18) * n_obs_, S(0));
+    pw_Jl_.assign(size_t(6) * n_obs_, S(0));
+    pw_Hll_inv_.assign(size_t(9) * n_lms_, S(0));
+    mf_Hpp_.assign(size_t(81) * n_cams_, S(0));
+    precond_blocks_.assign(size_t(81) * n_cams_, S(0));
+    std::vector<S> Jp, Jl, r;
+    for (int l = 0; l < n_lms_; ++l) {
+      const int K = k(l);
+      Jp.assign(size_t(2 * K) * P, S(0));
+      Jl.assign(size_t(2 * K) * 3, S(0));
+      r.assign(2 * K, S(0));
+      sc_linearize(l, pose_scaling_.data(), Jp, Jl, r, nullptr, nullptr);
+      S Hll[9] = {0}, Hinv[9];
+      for (int row = 0; row < 2 * K; ++row)
+        for (int a = 0; a < 3; ++a)
+          for (int c = 0; c < 3; ++c) Hll[a * 3 + c] += Jl[row * 3 + a] * Jl[row * 3 + c];
+      for (int d = 0; d < 3; ++d) Hll[d * 3 + d] += lambda;
+      inverse3(Hll, Hinv);
+      const int64_t o0 = lm_off_[l];
+      std::copy(Hinv, Hinv + 9, pw_Hll_inv_.begin() + size_t(9) * l);
+      std::copy(Jp.begin(), Jp.end(), pw_Jp_.begin() + 18 * o0);
+      std::copy(Jl.begin(), Jl.end(), pw_Jl_.begin() + 6 * o0);
       for (int i = 0; i < K; ++i) {
-        S* out = res + P * obs_cam_[o0 + i];
-        for (int rr = 0; rr < 2; ++rr) {
-          const int row = 2 * i + rr;
-          const S t = Jl[row * 3] * h[0] + Jl[row * 3 + 1] * h[1] + Jl[row * 3 + 2] * h[2];
-          for (int a = 0; a < P; ++a) out[a] += Jp[row * P + a] * t;
+        const int ci = obs_cam_[o0 + i];
+        S W[27];  // W_i = Jp_i^T Jl_i (9 x 3)
+        for (int a = 0; a < P; ++a)
+          for (int c = 0; c < 3; ++c)
+            W[a * 3 + c] = Jp[(2 * i) * P + a] * Jl[(2 * i) * 3 + c] + Jp[(2 * i + 1) * P + a] * Jl[(2 * i + 1) * 3 + c];
+        S* G = &mf_Hpp_[size_t(81) * ci];
+        S* D = &precond_blocks_[size_t(81) * ci];
+        for (int a = 0; a < P; ++a) {
+          S wa[3];
+          for (int c = 0; c < 3; ++c) wa[c] = W[a * 3] * Hinv[c] + W[a * 3 + 1] * Hinv[3 + c] + W[a * 3 + 2] * Hinv[6 + c];
+          for (int bb = 0; bb < P; ++bb) {
+            const S g = Jp[(2 * i) * P + a] * Jp[(2 * i) * P + bb] + Jp[(2 * i + 1) * P + a] * Jp[(2 * i + 1) * P + bb];
+            G[a * P + bb] += g;
+            D[a * P + bb] += g - (wa[0] * W[bb * 3] + wa[1] * W[bb * 3 + 1] + wa[2] * W[bb * 3 + 2]);
+          }
         }
       }
     }
+    for (int c = 0; c < n_cams_; ++c)
+      for (int a = 0; a < P; ++a) {
+        mf_Hpp_[size_t(81) * c + a * P + a] += lambda;
+        precond_blocks_[size_t(81) * c + a * P + a] += lambda;
+      }
+    build_preconditioner(precond_blocks_, nullptr);
   }
 
   // solve_assign (preconditioner.hpp:180-192)
@@ -1243,7 +1342,7 @@ class Oracle {
   // (reference CHECK-aborts, :121-122).
   bool linearize(LmIteration* it = nullptr) {
     const double t0 = now_seconds();
-    if (opt_.solver_type == 1) {
+    if (opt_.solver_type >= 1) {
       // LinearizorSC::linearize (linearizor_sc.cpp:70-99): linearize_problem, get_Jp_diag2,
       // scale_Jl_cols, pose scaling from the UNSCALED Jp column norms
       const size_t n = size_t(P) * n_cams_;
@@ -1282,17 +1381,21 @@ class Oracle {
   std::vector<S> solve(S lambda, CgSummary* cg_out = nullptr,
                        LmIteration* it = nullptr) {
     double t0 = now_seconds();
-    if (opt_.solver_type == 1) {
+    if (opt_.solver_type >= 1) {
       // LinearizorSC::solve (linearizor_sc.cpp:101-186): H_pp, b_p with pose + landmark
       // damping lambda, SCHUR_JACOBI = inverted diagonal blocks of H_pp, PCG
       const size_t n = size_t(P) * n_cams_;
       sc_lambda_ = lambda;
       std::vector<S> b;
-      sc_build(lambda, lambda, pose_scaling_.data(), &sc_H_, b, nullptr);
+      sc_build(lambda, lambda, pose_scaling_.data(), opt_.solver_type == 2 ? nullptr : &sc_H_, b, nullptr);
       b_ = b;
       if (it) it->stage2_time = now_seconds() - t0;
       t0 = now_seconds();
-      if (opt_.preconditioner_type == 2) {
+      if (opt_.solver_type == 2) {
+        if (opt_.preconditioner_type != 1)
+          throw std::invalid_argument("solver_type 2 (matrix-free Schur complement): SCHUR_JACOBI only");
+        sc_mf_prepare(lambda);
+      } else if (opt_.preconditioner_type == 2) {
         // POWER_SCHUR_COMPLEMENT (linearizor_sc.cpp:163-170): PowerSCPreconditioner on the JACOBI blocks
         // (get_jacobi) and the landmark blocks; pcg() applies it through power_precond_solve
         power_precond_prepare(lambda);
@@ -1356,7 +1459,7 @@ class Oracle {
   S apply(std::vector<S> inc, LmIteration* it = nullptr) {
     const double t0 = now_seconds();
     bool ok = true;
-    const S l_diff = opt_.solver_type == 1
+    const S l_diff = opt_.solver_type >= 1
                          ? sc_back_substitute(sc_lambda_, pose_scaling_.data(), inc.data())
                          : back_substitute_all(inc.data(), &ok);
     if (it) it->backsub_time = now_seconds() - t0;
@@ -1735,6 +1838,7 @@ class Oracle {
   std::vector<S> jp_diag2_, pose_scaling_, precond_blocks_, inv_blocks_, b_;
   std::vector<S> pw_Jp_, pw_Jl_, pw_Hll_inv_;
   mutable std::vector<S> sc_H_;  // dense reduced camera matrix of the SC solver mode
+  std::vector<S> mf_Hpp_;        // solver_type 2: the diagonal blocks Hpp + lambda I
   S sc_lambda_ = 0;
   bool new_linearization_point_ = false;
 };
