@@ -508,7 +508,7 @@ def main():
             except Exception:
                 traffic = None
 
-        # per-stage and whole-iteration rooflines from the HIP-event stage timers of the timed rows and
+        # per-stage and whole-iteration rooflines from the stage timers of the timed rows (device clock stamps, solver.hip: time_begin) and
         # the library's byte model (include/rootba_hip.h: rba_byte_model)
         def frac(nbytes, secs):
             return nbytes / secs / 1e9 / HBM_PEAK_GBS if secs > 0 else None
@@ -598,6 +598,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                # context, not the roofline: what a plain 16-byte-load read kernel streams on this part
+                # (scripts/microbench/stream_read.hip, profiles/r5_microbench_stream_read.txt: 6.5 TB/s; copy 5.9)
+                "frac_of_measured_stream_read": achieved / 6500.0 if achieved else None,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": stats["hx_bytes"],
@@ -607,7 +610,8 @@ def main():
                     "what": "EVERYTHING an LM iteration launches: stage 1, stage 2, the PCG (executed products on "
                             "either operator, assemblies, vector work - rba_get_pcg_counters), back-substitution, "
                             "cost evaluations: the bytes each must move in this layout (rba_get_byte_model) / their "
-                            "summed HIP-event times / 8 TB/s",
+                            "summed stage times (rba_iter_timings: device clock stamps at the stage boundaries inside "
+                            "rba_lm_step) / 8 TB/s",
                     "frac": frac(b_iter + b_pcg, t_s1 + t_s2 + t_bs + t_err + t_pcg),
                     "bytes_per_step": (b_iter + b_pcg) / n_t,
                     "frac_without_pcg": frac(b_iter, t_s1 + t_s2 + t_bs + t_err),

@@ -32,7 +32,8 @@
  *    RBA_HX_TIMING_STRIDE, RBA_SORT_BY_CAMERA, RBA_VERIFY_ASSEMBLED (diagnostic, default off since round 4),
  *    RBA_VERIFY_TOLERANCE, RBA_PCG_SPLIT, RBA_HALF_LOWER_MAX, RBA_S1_FUSED, RBA_HX_WIDE_INSIDE, RBA_PCG_PERSISTENT (0: the PCG on
  *    the assembled matrix in two launches per iteration instead of the persistent kernel), RBA_PCGP_TRACE (file for that
- *    kernel's phase stamps), RBA_DETERMINISTIC (1: the matrix-free products are summed camera-major in a fixed order
+ *    kernel's phase stamps), RBA_STAGE_TIMERS (0: rba_iter_timings stays zero; 1, default: device clock stamps at the stage
+ *    boundaries inside rba_lm_step, HIP events around single calls; 2: HIP events everywhere), RBA_DETERMINISTIC (1: the matrix-free products are summed camera-major in a fixed order
  *    instead of with floating-point atomics and the measured break-even of the operator switch is frozen - float32
  *    runs repeat bit by bit, a product costs about twice as much) (rootba_amd/csrc/solver.hip: Solver::DebugEnv).
  *    The ~25 kernel-selection

@@ -5,7 +5,9 @@ SCHUR_JACOBI block diagonal, one H x from the factors and one through the assemb
 and a two-iteration LM lock-step from identical states with the increment VECTORS compared (VERDICT round 2,
 "next round" 1a; reference test: src/rootba/qr/linearization_qr.test.cpp:125-211).
 
-What float32 resolves at this size is measured, not assumed: a FLOAT64 run of the HIP library from the same state
+What float32 resolves at this size is measured, not assumed. The increments are refereed by the CPU: the float64 PCG
+iterate of the same index by the oracle's matrix-free Schur-complement solver (solver_type 2 - 5.6 GB where the dense
+float64 oracle would need 55; round 5). For the intermediate vectors a FLOAT64 run of the HIP library from the same state
 (with the float Jacobian-scaling epsilon; the float64 path is held to the float64 oracle at 1e-10 by
 tests/test_gpu_parity.py - the float64 oracle itself would need 55 GB here) is the referee, and every float32 vector
 must be as close to it as the float32 oracle's: `|gpu32 - f64| <= 1.5 |oracle32 - f64| + floor`. Measured on an
@@ -50,6 +52,28 @@ def referee64(final_problem):
                                                                       jacobi_scaling_eps=EPS_SQRT_FLOAT))
 
 
+_CPU_REFEREE = {}
+
+
+def _cpu_referee_increment(prob, it, cams, lms, lam, n_it):
+    """The INDEPENDENT float64 referee of the increments: the oracle's matrix-free
+    Schur-complement solver on the CPU (oracle solver_type 2, tests/test_oracle_referee.py), same state, same iteration
+    count; computed once per LM iteration for both precisions of the test (~45 s each on the GPU box's host cores)."""
+    if it not in _CPU_REFEREE:
+        from lockstep import EPS_SQRT_FLOAT
+        from oracle import oracle as O
+        o = O.Oracle(prob, np.float64, O.default_options(robust_norm=1, huber_parameter=1.0, solver_type=2, max_cg_it=n_it,
+                                                        eta=0.0, jacobi_scaling_eps=EPS_SQRT_FLOAT))
+        o.set_state(cams.astype(np.float64), lms.astype(np.float64))
+        assert o.linearize() == 0
+        inc, cg = o.solve(lam)
+        assert cg.num_iterations == n_it
+        _CPU_REFEREE[it] = (np.asarray(inc).copy(), cams.copy(), lms.copy())
+    inc, c, l = _CPU_REFEREE[it]
+    assert np.array_equal(c, cams) and np.array_equal(l, lms)  # (both precisions of the test start from the oracle's states)
+    return inc
+
+
 def _as_accurate(x_gpu, x_oracle, x_ref, floor):
     """the float32 GPU result is as close to the float64 referee as the float32 oracle's, and the two float32 results are
     no further apart than two results of that accuracy can be"""
@@ -92,6 +116,10 @@ def test_final13682_one_iteration_vectors_and_two_step_lockstep(final_problem, o
         _as_accurate(bl_g, o.precond_blocks(), bl_64, 2e-6)
         assert cg.termination_type == 1 and cg.num_iterations == co.num_iterations == c64.num_iterations
         _as_accurate(ig, io, i64, 5e-5)
+        # ... and against the referee that shares no code with the library: the CPU's float64 iterate of the same index
+        i64_cpu = _cpu_referee_increment(prob, it, c_, l_, lam, co.num_iterations)
+        assert rel_err(i64, i64_cpu) < 1e-6, rel_err(i64, i64_cpu)  # (the two float64 referees agree)
+        _as_accurate(ig, io, i64_cpu, 5e-5)
         if it == 1:
             h_64 = g64.right_multiply(x.astype(np.float64))
             h_o = o.right_multiply(x)
