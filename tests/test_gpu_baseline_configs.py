@@ -438,8 +438,8 @@ def test_config5_final13682_f32_lockstep_iterations_3_to_7(monkeypatch):
                 # (iteration 6: the replay's own step 5 - 5 PCG iterations at lambda 1.2e-6 - sends a few ill-conditioned
                 #  landmarks to |p| ~ 7e4 and RAISES the cost, 5.72e6 -> 6.61e6: the LM loop would reject it, the
                 #  fixed-schedule replay goes on from there. At that state float32 does not resolve the cost: the float64
-                #  cost (oracle, CPU) is 6 615 231.8, the float32 oracle's 6 607 272.8 - 1.2e-3 low - and the GPU's is
-                #  1.5e-3 from the float32 oracle's (iterations 5 and 7: 2.7e-10 and 1.6e-4 for the oracle, 1e-8 and
+                #  cost (oracle, CPU) is 6 615 231.8, the float32 oracle's 6 607 272.8 - 1.2e-3 low - and the GPU's
+                #  6 617 444.1 - 3.3e-4 high, 1.5e-3 from the float32 oracle's (iterations 5 and 7: 2.7e-10 and 1.6e-4 for the oracle, 1e-8 and
                 #  1.5e-6 between the two float32 costs). Re-examined with the independent referee, as VERDICT round 4
                 #  asked: the GPU's 3-iteration increment is 1.41e-2 from the float64 iterate, the float32 oracle's 9e-4
                 #  - the same two numbers the HIP referee gave. Counts and termination only.)
