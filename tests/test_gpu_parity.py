@@ -1023,3 +1023,31 @@ def test_deterministic_lm_run_repeats_bitwise(ladybug_far, precond, monkeypatch)
         lo, _ = o.optimize_lm()
         assert len(lo) == len(ra)
         assert abs(ra[-1].cost - lo[-1].cost) <= 1e-5 * lo[-1].cost
+
+
+@pytest.mark.parametrize("mode", ["1", "2", "0"], ids=["device-stamps", "hip-events", "off"])
+def test_stage_timers_inside_the_lm_loop(ladybug_far, mode, monkeypatch):
+    """rba_iter_timings of rba_lm_step (the reference's IterationSummary stage times): device clock stamps written by the
+    first kernel of every stage (default) or HIP events around every stage (RBA_STAGE_TIMERS=2, the form
+    of rounds 2-5a) - every stage of every solved iteration has a time, and the stages do not add up to more than the
+    iteration took on the host's clock; RBA_STAGE_TIMERS=0: all zero. The LM run itself does not depend on the mode."""
+    monkeypatch.setenv("RBA_STAGE_TIMERS", mode)
+    monkeypatch.setenv("RBA_DETERMINISTIC", "1")  # (the three runs are then the same run)
+    g, _ = _pair(ladybug_far, np.float32, max_num_iterations=5, function_tolerance=0.0)
+    rows, _ = g.optimize_lm()
+    solved = [r for r in rows if r.iteration >= 1]
+    assert len(solved) == 5
+    for r in solved:
+        stages = (r.stage1_time, r.stage2_time, r.pcg_time, r.backsub_time, r.residual_time)
+        if mode == "0":
+            assert all(t == 0.0 for t in stages), stages
+        else:
+            assert all(t > 0.0 for t in stages), (r.iteration, stages)
+            if os.environ.get("RBA_EMU") != "1":  # (the harness's "device clock" is the host's time-stamp counter)
+                assert sum(stages) + r.precond_time <= 1.05 * r.iteration_time + 2e-5, (stages, r.iteration_time)
+    key = [(r.cg_iterations, r.cost) for r in rows]
+    _STAGE_TIMER_RUNS.setdefault("run", key)
+    assert _STAGE_TIMER_RUNS["run"] == key
+
+
+_STAGE_TIMER_RUNS = {}
