@@ -442,7 +442,13 @@ def test_config5_final13682_f32_lockstep_iterations_3_to_7(monkeypatch):
                 #  6 617 444.1 - 3.3e-4 high, 1.5e-3 from the float32 oracle's (iterations 5 and 7: 2.7e-10 and 1.6e-4 for the oracle, 1e-8 and
                 #  1.5e-6 between the two float32 costs). Re-examined with the independent referee, as VERDICT round 4
                 #  asked: the GPU's 3-iteration increment is 1.41e-2 from the float64 iterate, the float32 oracle's 9e-4
-                #  - the same two numbers the HIP referee gave. Counts and termination only.)
+                #  - the same two numbers the HIP referee gave. What separates the two float32 results is the
+                #  summation order inside the Householder QR of a few nearly rank-deficient landmark blocks: with the
+                #  two-kernel form of stage 1 (RBA_S1_FUSED=0, the oracle's order) the GPU is 6.1e-3 from float64 and its
+                #  model cost change agrees with the oracle's to 3.6e-7 (fused form: 9.6e-3) -
+                #  profiles/r5_final13682_iteration6_stage1_forms.txt; at iterations 3 and 7 the order is the other way
+                #  round or immaterial (fused 4.9e-3 / 6.5e-3, two-kernel 1.0e-3 / 5.6e-3, oracle 8.5e-3 / 6.2e-3).
+                #  Counts and termination only.)
                 assert r["gpu_vs_f64"] <= 1.5 * r["oracle32_vs_f64"] + 2e-4, r
                 assert r["cost_rel"] < 3e-6 and r["l_diff_rel"] < 5e-3, r
 
