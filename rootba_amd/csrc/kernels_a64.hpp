@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   // clamps, the zero-selects of the staging in EVERY step, copies of the second accumulator between VGPRs and AGPRs,
   // and an exec-masked branch around every operand - the form below has one accumulator, 32-bit positions, selects
   // in a list's last step only, no predicate on the operands and two register sets instead of copies of load results:
-  // ~11 VALU instructions per matrix instruction, 1152 -> 999 us; with two quads per step instead of four 915 us.
+  // 14.5 VALU instructions per matrix instruction measured (~11 in the loop body), 1152 -> 999 us; with two quads per
+  // step instead of four 890-915 us - and the LDS 72 % busy: the bound now (profiles/r5_pmc_a64_offdiag_after.csv).
   __shared__ double tile[4][16][16];
   __shared__ __attribute__((aligned(16))) double stage[4][U][8][kA64Rec];
   const int lane = threadIdx.x & 63;
