@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   // step instead of four 890-915 us - and the LDS 72 % busy: the bound now (profiles/r5_pmc_a64_offdiag_after.csv).
   __shared__ double tile[4][16][16];
   __shared__ __attribute__((aligned(16))) double stage[4][U][8][kA64Rec];
+  __shared__ __attribute__((aligned(16))) double mbuf[4][U][4][4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int u = xcd_swizzled_camera(n_upper);
@@ -337,6 +338,12 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
 #pragma unroll
     for (int uq = 0; uq < U; ++uq) v[uq] = reinterpret_cast<const double2*>(p.rec + size_t(kA64Rec) * o[uq])[vec];
   };
+  // Formulation (second step of round 5, after the counters showed the LDS as the bound at 4.4 instructions per matrix
+  // instruction): sum_pairs (W'_i Jp_i)^T (W'_j Jp_j) = sum_pairs Jp_i^T M_ij Jp_j with the 2 x 2 matrix
+  // M_ij = W'_i^T W'_j formed ONCE per pair (32 lanes, one value each, through LDS) - the inner dimension of a pair is
+  // 2 instead of 3 (two matrix instructions per quad of pairs instead of three), the A operand is Jp_i^T M (two converted
+  // floats, two doubles of M), the B operand a converted float of Jp_j with no arithmetic.
+  static_assert(U == 2, "the M_ij of a step are formed by 16 U = 32 lanes");
   auto step = [&](int q, const double2 v[U]) {
     if (q + 4 * U > n) {  // (wave-uniform) the last step of the list: pairs beyond its end are staged as zeros
 #pragma unroll
@@ -349,21 +356,30 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
       for (int uq = 0; uq < U; ++uq) *reinterpret_cast<double2*>(&stage[wave][uq][rec][2 * vec]) = v[uq];
     }
     wave_lds_fence();
+    {
+      // M[r][e] = sum_c W'_i[c][r] W'_j[c][e] of pair (uqm, pm): lane -> (quad, pair, r, e); lanes 32 .. 63 repeat
+      const int l5 = lane & 31;
+      const int uqm = l5 >> 4, pm = (l5 >> 2) & 3, rm = (l5 >> 1) & 1, em = l5 & 1;
+      const double* wi = stage[wave][uqm][pm] + kA64RecW;
+      const double* wj = stage[wave][uqm][4 + pm] + kA64RecW;
+      const double mv = fma(wi[rm], wj[em], fma(wi[2 + rm], wj[2 + em], wi[4 + rm] * wj[4 + em]));
+      if (lane < 32) mbuf[wave][uqm][pm][2 * rm + em] = mv;
+    }
+    wave_lds_fence();
 #pragma unroll
     for (int uq = 0; uq < U; ++uq)
 #pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const int g = 4 * m + kk;  // inner index 0..11 = (pair of the quad, top row)
-        const int pp = g / 3, c = g - 3 * pp;
-        const double* ri = stage[wave][uq][pp];
-        const double* rj = stage[wave][uq][4 + pp];
-        const float* fi = reinterpret_cast<const float*>(ri);
-        const float* fj = reinterpret_cast<const float*>(rj);
-        const double av = fma(ri[kA64RecW + 2 * c], double(fi[i9]), ri[kA64RecW + 2 * c + 1] * double(fi[9 + i9]));
-        const double bv = fma(rj[kA64RecW + 2 * c], double(fj[i9]), rj[kA64RecW + 2 * c + 1] * double(fj[9 + i9]));
+      for (int m = 0; m < 2; ++m) {
+        const int g = 4 * m + kk;  // inner index 0..7 = (pair of the quad, row e of Jp_j)
+        const int pp = g >> 1, e = g & 1;
+        const float* fi = reinterpret_cast<const float*>(stage[wave][uq][pp]);
+        const float* fj = reinterpret_cast<const float*>(stage[wave][uq][4 + pp]);
+        const double* mm = mbuf[wave][uq][pp];
+        const double av = fma(double(fi[i9]), mm[e], double(fi[9 + i9]) * mm[2 + e]);
+        const double bv = double(fj[9 * e + i9]);
         acc = M::mma(av, bv, acc);
       }
-    wave_lds_fence();  // the next step overwrites the staging buffer
+    wave_lds_fence();  // the next step overwrites the staging buffers
   };
   // two register sets, the loop unrolled by two: no load result is ever copied (a copy waits for its load)
   int o_a[U], o_b[U];
