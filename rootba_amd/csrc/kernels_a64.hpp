@@ -305,7 +305,8 @@ __global__ __launch_bounds__(256) void k_a64_offdiag(A64Params p, double* __rest
   // and an exec-masked branch around every operand - the form below has one accumulator, 32-bit positions, selects
   // in a list's last step only, no predicate on the operands and two register sets instead of copies of load results:
   // 14.5 VALU instructions per matrix instruction measured (~11 in the loop body), 1152 -> 999 us; with two quads per
-  // step instead of four 890-915 us - and the LDS 72 % busy: the bound now (profiles/r5_pmc_a64_offdiag_after.csv).
+  // step instead of four 890-915 us - and the LDS 72 % busy: the bound then (profiles/r5_pmc_a64_offdiag_after.csv);
+  // with the 2 x 2 matrix per pair (below) 681-686 us.
   __shared__ double tile[4][16][16];
   __shared__ __attribute__((aligned(16))) double stage[4][U][8][kA64Rec];
   __shared__ __attribute__((aligned(16))) double mbuf[4][U][4][4];
