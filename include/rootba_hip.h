@@ -341,6 +341,10 @@ int rba_get_pose_scaling(rba_handle h, void* out9_per_cam);
  * undamped (damped = 0) or with the current landmark damping (damped = 1). */
 int rba_get_landmark_R(rba_handle h, int damped, void* R6_per_lm,
                        void* q1tr3_per_lm);
+/* |Q2^T r| per landmark of the current linearisation point (undamped; the part of the residual that stays after
+ * the landmark is marginalised, landmark_block_base.ipp:717-743 applied to the last column) - with R and Q1^T r the
+ * whole of what the landmark QR hands on; the accuracy ensemble of tests/test_gpu_qr_accuracy.py compares it. */
+int rba_get_landmark_q2tr_norm(rba_handle h, void* out1_per_lm);
 /* Algorithmic byte/flop counts of the resident topology. */
 int rba_get_problem_stats(rba_handle h, int64_t* block_storage_bytes,
                           int64_t* hx_algorithmic_bytes, int64_t* hx_flops);

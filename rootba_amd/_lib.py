@@ -122,7 +122,7 @@ EXPORTS = [
     "rba_restore", "rba_compute_error", "rba_linearize", "rba_solve", "rba_stage2",
     "rba_right_multiply", "rba_right_multiply_explicit", "rba_apply", "rba_back_substitute", "rba_optimize_lm", "rba_lm_begin", "rba_lm_step", "rba_lm_termination", "rba_synchronize",
     "rba_get_timings", "rba_get_substage_timings", "rba_debug_read_blocks",
-    "rba_get_jl_col_scale", "rba_get_pose_scaling", "rba_get_landmark_R", "rba_get_problem_stats",
+    "rba_get_jl_col_scale", "rba_get_pose_scaling", "rba_get_landmark_R", "rba_get_landmark_q2tr_norm", "rba_get_problem_stats",
     "rba_get_byte_model", "rba_get_pcg_counters",
 ]
 

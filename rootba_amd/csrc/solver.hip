@@ -177,6 +177,7 @@ struct rba_solver {
   virtual void get_jl_col_scale(void* out) = 0;
   virtual void get_pose_scaling(void* out) = 0;
   virtual void get_landmark_R(int damped, void* R6, void* q3) = 0;
+  virtual void get_landmark_q2tr_norm(void* out) = 0;
   virtual void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) = 0;
   virtual void get_byte_model(rba_byte_model* out) = 0;
   virtual void get_pcg_counters(rba_pcg_counters* out) = 0;
@@ -3180,6 +3181,22 @@ class Solver final : public rba_solver {
       for (int c = 0; c < 3; ++c) qo[3 * size_t(perm_[s]) + c] = q[3 * size_t(s) + c];
     }
   }
+  // |Q2^T r| per landmark (undamped): the rows >= 3 of the fourth entry of the reflector records
+  void get_landmark_q2tr_norm(void* out) override {
+    if (sc_) throw HipError{"the SCHUR_COMPLEMENT solver has no triangular factors", RBA_ERR_UNSUPPORTED};
+    use_device();
+    std::vector<S> vh(8 * size_t(n_obs_));
+    std::vector<int64_t> lm_obs(n_lms_ + 1);
+    d_Vh_.download(vh.data(), vh.size(), stream_);
+    d_lm_obs_.download(lm_obs.data(), lm_obs.size(), stream_);
+    sync();
+    S* o = static_cast<S*>(out);
+    for (int s = 0; s < n_lms_; ++s) {
+      double ss = 0;
+      for (int64_t r = 2 * lm_obs[s] + 3; r < 2 * lm_obs[s + 1]; ++r) ss += double(vh[4 * r + 3]) * double(vh[4 * r + 3]);
+      o[perm_[s]] = S(std::sqrt(ss));
+    }
+  }
   // compulsory HBM bytes per launch group in this layout (include/rootba_hip.h: rba_byte_model): every record read
   // or written once by the kernel group that needs it, per-landmark and camera-sized data once per kernel. The
   // measured traffic (rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/) can only be larger: gathers fetch whole cache
@@ -3918,6 +3935,9 @@ class ShardedSolver final : public rba_solver {
                                 static_cast<char*>(q3) + size_t(3) * cuts_[r] * es_vec_);
     });
   }
+  void get_landmark_q2tr_norm(void* out) override {
+    run_all([&](int r) { ranks_[r]->get_landmark_q2tr_norm(static_cast<char*>(out) + size_t(cuts_[r]) * es_vec_); });
+  }
   void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) override {
     std::vector<int64_t> a(n_), b(n_), c(n_);
     run_all([&](int r) { ranks_[r]->get_problem_stats(&a[r], &b[r], &c[r]); });
@@ -4344,6 +4364,13 @@ int rba_get_pose_scaling(rba_handle h, void* out) {
 int rba_get_landmark_R(rba_handle h, int damped, void* R6, void* q3) {
   return guarded([&]() -> int {
     h->get_landmark_R(damped, R6, q3);
+    return RBA_OK;
+  });
+}
+int rba_get_landmark_q2tr_norm(rba_handle h, void* out) {
+  return guarded([&]() -> int {
+    if (!out) return RBA_ERR_INVALID_ARGUMENT;
+    h->get_landmark_q2tr_norm(out);
     return RBA_OK;
   });
 }

@@ -266,6 +266,11 @@ class LinearizorHIP:
                 "rba_get_landmark_R")
         return R.reshape(-1, 6), q.reshape(-1, 3)
 
+    def landmark_q2tr_norm(self):
+        out = self._vec(self.n_lms)
+        L.check(self.lib.rba_get_landmark_q2tr_norm(self.h, _ptr(out)), "rba_get_landmark_q2tr_norm")
+        return out
+
     def byte_model(self) -> dict:
         m = L.RbaByteModel()
         L.check(self.lib.rba_get_byte_model(self.h, C.byref(m)), "rba_get_byte_model")
