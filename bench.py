@@ -276,6 +276,29 @@ def self_launch(args_list, n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def dense_companion(args):
+    """The headline workload's other regime: `venice-1778+tail` - the same cameras,
+    landmark count and observation count with heavy-tailed (Pareto) track lengths, whose reduced camera matrix is nearly
+    dense (524 MB in half storage) and does NOT fit the register files: long PCG solves stream it from HBM in two
+    launches per iteration. The synthetic scene of SURVEY.md 8d gives a banded matrix; real BAL venice is an internet
+    photo collection and may be in either regime. One repetition of the same warm-up + steps in a child process."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "venice-1778+tail", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--cpu-baseline-iters", "0", "--no-pmc", "--no-reference-semantics",
+           "--repeats", "1", "--no-dense-companion", "--preconditioner", args.preconditioner,
+           "--power-order", str(args.power_order)] + (["--mixed"] if args.mixed else [])
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        c = d["config"]
+        return {"value": d["value"], "unit": d["unit"], "workload": c["workload"], "ms_per_step": d["ms_per_step"],
+                "reduced_matrix": c["reduced_matrix"], "solves_persistent": c["solves_persistent"],
+                "successful_steps": c["successful_steps"], "cg_iterations_per_step": c["cg_iterations_per_step"],
+                "executed": d["roofline"]["stages"]["pcg"]["executed"]}
+    except Exception as e:  # the companion must never take the headline down
+        log(f"[value_dense_covisibility] failed: {e!r}")
+        return None
+
+
 def reference_semantics_run(local, prob_name, rank, world, local_rank, comm_setup):
     """The same LM run with the reference's own stopping rule (function_tolerance = 1e-6,
     bal_bundle_adjustment.cpp:174-201, 476-481): it/s over iterations 1..(iteration where it fires)."""
@@ -336,7 +359,11 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic in this run (two rocprofv3 counter passes over a child process, "
                          "~30 s); the committed profiles/hx_traffic.json is quoted instead")
+    ap.add_argument("--no-dense-companion", action="store_true",
+                    help="skip `value_dense_covisibility` (the same workload with heavy-tailed track lengths, whose reduced "
+                         "camera matrix is nearly dense and does not fit the register files; one repetition)")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--companion-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
@@ -385,6 +412,11 @@ def main():
     for key, val in _GPU_KW.items():
         setattr(gpu_opts, key, val)
     t0 = time.perf_counter()
+    # HIP events around the matrix-free products (rba_iter_timings.hx_time -> roofline.avg_launch_ms) are marker packets
+    # on the solver stream: the timed repetitions run WITHOUT them, a separate pass on a second handle measures the
+    # product's launch time. An explicit RBA_HX_TIMING_STRIDE in the environment wins.
+    stride_env = os.environ.get("RBA_HX_TIMING_STRIDE")
+    os.environ["RBA_HX_TIMING_STRIDE"] = stride_env if stride_env is not None else "0"
     lin = LinearizorHIP(local, GPU_DTYPE, gpu_opts, device=local_rank)
     log(f"[rank {rank}] solver set up in {time.perf_counter() - t0:.2f}s (rba_create: sort by track length, "
         f"CSC index, block structure of the reduced matrix, launch graphs, device allocation)")
@@ -434,7 +466,7 @@ def main():
 
     state0 = lin.get_state()
 
-    def measure():
+    def measure(lin=lin):
         """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides."""
         rows, hx_time, hx_calls = [], 0.0, 0
         lin.set_state(*state0)
@@ -473,7 +505,21 @@ def main():
     med = reps[order[len(order) // 2]]  # the median repetition is the one reported in detail
     elapsed, rows, hx_time, hx_calls = med["elapsed"], med["rows"], med["hx_time"], med["hx_calls"]
     comm0, comm1, pcg_cnt = med["comm0"], med["comm1"], med["pcg"]
+    matrix_info = lin.reduced_matrix_info()
     lin.close()
+    hx_pass = "events around every product of the timed repetitions (RBA_HX_TIMING_STRIDE from the environment)"
+    if stride_env is None:
+        # the product's launch time: the same warm-up + steps once more on a handle with HIP events around every 8th
+        # matrix-free product (not part of `value`)
+        os.environ["RBA_HX_TIMING_STRIDE"] = "8"
+        lin_t = LinearizorHIP(local, GPU_DTYPE, gpu_opts, device=local_rank)
+        comm_setup(lin_t)
+        tp = measure(lin_t)
+        hx_time, hx_calls = tp["hx_time"], tp["hx_calls"]
+        lin_t.close()
+        os.environ["RBA_HX_TIMING_STRIDE"] = "0"
+        hx_pass = ("a separate pass of the same warm-up + steps on a second handle with HIP events on the solver stream "
+                   "around every 8th matrix-free product; the timed repetitions carry no events")
 
     ref_sem = None
     if not args.no_reference_semantics:
@@ -579,8 +625,22 @@ def main():
                     "bytes": (comm1["bytes"] - comm0["bytes"]) / args.steps,
                     "ms": 1e3 * (comm1["seconds"] - comm0["seconds"]) / args.steps},
                 "explicit_after": int(os.environ.get("RBA_EXPLICIT_AFTER", gpu_opts.explicit_after)),
+                # which regime this workload is in: a banded reduced camera matrix that fits the
+                # register files (long PCG solves = one persistent kernel) or a nearly dense one that streams from HBM
+                "reduced_matrix": {"blocks": matrix_info["blocks_full"], "blocks_stored": matrix_info["blocks_stored"],
+                                   "density": matrix_info["density"], "bytes": matrix_info["bytes_stored"],
+                                   "resident_in_registers": bool(matrix_info["resident_in_registers"]),
+                                   "persistent_workgroups": matrix_info["persistent_workgroups"]},
+                "solves_persistent": pcg_cnt.get("solves_persistent", 0),
+                "solves_assembled": pcg_cnt.get("assemblies", 0),
                 "function_tolerance": 0.0,
-                "compute_error_per_iteration": "2 (start of every outer iteration + after the step, as the reference)",
+                "compute_error_per_iteration": {
+                    "launched": n_err / n_t,
+                    "what": "cost evaluations LAUNCHED per timed step (rba_pcg_counters.cost_evaluations). The reference "
+                            "evaluates twice per iteration (start of every outer iteration + after the step, "
+                            "bal_bundle_adjustment.cpp:297-301, 417); here the evaluation at the start of an iteration "
+                            "that follows an accepted step IS the trial evaluation of that step - same kernel, same "
+                            "state, same fixed summation order, bit-identical - and is reused, not repeated"},
                 "cg_iterations_per_step": sum(r.cg_iterations for r in timed) / max(1, len(timed)),
                 "successful_steps": sum(r.step_is_successful for r in timed),
                 "initial_cost": rows[0].cost,
@@ -606,6 +666,7 @@ def main():
                 "algorithmic_bytes_per_launch": stats["hx_bytes"],
                 "avg_launch_ms": avg_hx * 1e3 if avg_hx else None,
                 "launches_timed": hx_calls,
+                "launch_timing": hx_pass,
                 "whole_iteration": {
                     "what": "EVERYTHING an LM iteration launches: stage 1, stage 2, the PCG (executed products on "
                             "either operator, assemblies, vector work - rba_get_pcg_counters), back-substitution, "
@@ -619,6 +680,9 @@ def main():
                 "stages": stages,
             },
         }
+        if (world == 1 and args.workload == "venice-1778" and data == "synthetic" and not args.no_dense_companion
+                and not args.use_double and args.solver_type == "SQUARE_ROOT"):
+            out["config"]["value_dense_covisibility"] = dense_companion(args)
         if world == 1 and args.cpu_baseline_iters > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(prob, args.cpu_baseline_iters, rows)

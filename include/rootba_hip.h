@@ -384,6 +384,20 @@ typedef struct rba_pcg_counters {
                                           accepted step instead of repeating it) */
 } rba_pcg_counters;
 int rba_get_pcg_counters(rba_handle h, rba_pcg_counters* out);
+/* The block structure of the reduced camera matrix S a long PCG solve assembles (rba_options.explicit_after; for
+ * solver_type SCHUR_COMPLEMENT the matrix of LinearizorSC, linearizor_sc.cpp:101-140) - i.e. which regime a workload is
+ * in: a banded S of a few per cent density fits the register files and its PCG runs as one persistent kernel; a nearly
+ * dense S (heavy-tailed co-visibility) streams from HBM in two launches per iteration. All zero when no matrix is ever
+ * assembled (explicit_after = 0, or the pair lists exceed their budget). */
+typedef struct rba_reduced_matrix_info {
+  int64_t blocks_stored;      /* 9x9 blocks held in memory (square-root solver: half storage, diagonal included) */
+  int64_t blocks_full;        /* structural non-zero blocks of the full symmetric matrix */
+  double density;             /* blocks_full / n_cams^2 */
+  int64_t bytes_stored;       /* blocks_stored x 81 x sizeof(value): double for the square-root solver */
+  int resident_in_registers;  /* 1: PCG solves on S run as ONE persistent kernel, S in the register files */
+  int persistent_workgroups;  /* workgroups of that kernel (one per compute unit), 0 if the matrix does not fit */
+} rba_reduced_matrix_info;
+int rba_get_reduced_matrix_info(rba_handle h, rba_reduced_matrix_info* out);
 
 #ifdef __cplusplus
 }

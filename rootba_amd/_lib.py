@@ -123,7 +123,7 @@ EXPORTS = [
     "rba_right_multiply", "rba_right_multiply_explicit", "rba_apply", "rba_back_substitute", "rba_optimize_lm", "rba_lm_begin", "rba_lm_step", "rba_lm_termination", "rba_synchronize",
     "rba_get_timings", "rba_get_substage_timings", "rba_debug_read_blocks",
     "rba_get_jl_col_scale", "rba_get_pose_scaling", "rba_get_landmark_R", "rba_get_landmark_q2tr_norm", "rba_get_problem_stats",
-    "rba_get_byte_model", "rba_get_pcg_counters",
+    "rba_get_byte_model", "rba_get_pcg_counters", "rba_get_reduced_matrix_info",
 ]
 
 
@@ -136,6 +136,11 @@ class RbaPcgCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("products_matrix_free", "products_assembled", "assemblies", "iterations",
                                          "solves_repeated_matrix_free", "early_switches", "solves_persistent",
                                          "products_assembled_resident", "iterations_resident", "cost_evaluations")]
+
+class RbaReducedMatrixInfo(C.Structure):
+    _fields_ = [("blocks_stored", C.c_int64), ("blocks_full", C.c_int64), ("density", C.c_double),
+                ("bytes_stored", C.c_int64), ("resident_in_registers", C.c_int), ("persistent_workgroups", C.c_int)]
+
 
 _lib = None
 

@@ -36,12 +36,10 @@
 #pragma once
 
 #include "kernels_pcg.hpp"
+#include "pg_record_io.hpp"
 
 namespace rba {
 
-using pg_u32 = unsigned int;
-using pg_u64 = unsigned long long;
-typedef pg_u32 pg_rec __attribute__((ext_vector_type(4)));  // a 16-byte record
 
 constexpr int kPgThreads = 512;               // 8 wavefronts: two per SIMD, one workgroup per CU
 constexpr int kPgMaxRows = kPgThreads / 9;    // nine row outputs per camera
@@ -94,107 +92,6 @@ struct PgParams {
   long long* trace;                // debug (RBA_PCGP_TRACE): 100 MHz real-time stamps of the first kPgTraceIts iterations, 8 per
                                    // iteration and workgroup; nullptr in production
 };
-
-// The kernel keeps 162 registers of matrix per lane; every loop-invariant address the compiler hoists out of the
-// iteration loop (a record address per exchange and lane ...) is a spilled pair. An index made opaque at its use is
-// recomputed there (one multiply-add) instead.
-#ifdef HIPEMU
-#define PG_OPAQUE(x) ((void)0)
-#else
-#define PG_OPAQUE(x) asm volatile("" : "+v"(x))
-#endif
-
-// ---- 16-byte records: write-through store, L1-bypassing loads (sc1) ---------------------------------------------------
-// (inline assembly: no builtin emits a 16-byte access of agent scope. The loads of a sweep and their wait are ONE
-//  statement - the compiler does not count the memory operations of an asm statement.)
-#ifdef HIPEMU
-// CPU execution harness of the tests: two 8-byte atomics per record - a record CAN be torn there, as the check expects
-__device__ __forceinline__ void pg_rec_store(pg_rec* p, pg_rec v) {
-  pg_u64* q = reinterpret_cast<pg_u64*>(p);
-  __hip_atomic_store(q, pg_u64(v.x) | (pg_u64(v.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(q + 1, pg_u64(v.z) | (pg_u64(v.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ pg_rec pg_rec_load1(const pg_rec* p) {
-  const pg_u64* q = reinterpret_cast<const pg_u64*>(p);
-  const pg_u64 a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const pg_u64 b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  pg_rec v;
-  v.x = pg_u32(a);
-  v.y = pg_u32(a >> 32);
-  v.z = pg_u32(b);
-  v.w = pg_u32(b >> 32);
-  return v;
-}
-template <int N>
-__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[N]) {
-  for (int i = 0; i < N; ++i) v[i] = pg_rec_load1(p + i * stride);
-}
-__device__ __forceinline__ void pg_rec_load_pairs(const pg_rec* p0, const pg_rec* p1, const pg_rec* p2, const pg_rec* p3,
-                                                  pg_rec (&v)[8]) {
-  const pg_rec* p[4] = {p0, p1, p2, p3};
-  for (int i = 0; i < 4; ++i) {
-    v[2 * i] = pg_rec_load1(p[i]);
-    v[2 * i + 1] = pg_rec_load1(p[i] + 1);
-  }
-}
-#else
-__device__ __forceinline__ void pg_rec_store(pg_rec* p, pg_rec v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-// N records at p, p + stride, ...: all loads in flight, one wait
-__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int, pg_rec (&v)[1]) {
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[2]) {
-  const pg_rec* p1 = p + stride;
-  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(v[0]), "=&v"(v[1])
-               : "v"(p), "v"(p1)
-               : "memory");
-}
-__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[3]) {
-  const pg_rec *p1 = p + stride, *p2 = p + 2 * stride;
-  asm volatile(
-      "global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
-      : "v"(p), "v"(p1), "v"(p2)
-      : "memory");
-}
-__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[4]) {
-  const pg_rec *p1 = p + stride, *p2 = p + 2 * stride, *p3 = p + 3 * stride;
-  asm volatile(
-      "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
-      "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-      : "v"(p), "v"(p1), "v"(p2), "v"(p3)
-      : "memory");
-}
-// four PAIRS of adjacent records (the rho and Q partial sums of four workgroups)
-__device__ __forceinline__ void pg_rec_load_pairs(const pg_rec* p0, const pg_rec* p1, const pg_rec* p2, const pg_rec* p3,
-                                                  pg_rec (&v)[8]) {
-  asm volatile(
-      "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
-      "global_load_dwordx4 %2, %9, off sc1\n\tglobal_load_dwordx4 %3, %9, off offset:16 sc1\n\t"
-      "global_load_dwordx4 %4, %10, off sc1\n\tglobal_load_dwordx4 %5, %10, off offset:16 sc1\n\t"
-      "global_load_dwordx4 %6, %11, off sc1\n\tglobal_load_dwordx4 %7, %11, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-      : "memory");
-}
-__device__ __forceinline__ void pg_rec_load(const pg_rec* p, int stride, pg_rec (&v)[9]) {
-  // (the double solver's vectors: nine records per camera, immediate offsets of 16 bytes - stride is 1)
-  asm volatile(
-      "global_load_dwordx4 %0, %9, off sc1\n\tglobal_load_dwordx4 %1, %9, off offset:16 sc1\n\t"
-      "global_load_dwordx4 %2, %9, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %9, off offset:48 sc1\n\t"
-      "global_load_dwordx4 %4, %9, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %9, off offset:80 sc1\n\t"
-      "global_load_dwordx4 %6, %9, off offset:96 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:112 sc1\n\t"
-      "global_load_dwordx4 %8, %9, off offset:128 sc1\n\ts_waitcnt vmcnt(0)"
-      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8])
-      : "v"(p)
-      : "memory");
-}
-#endif
 
 // {double, tag, check}: check = tag ^ hi ^ lo, so a record torn into its halves does not pass
 __device__ __forceinline__ pg_rec pg_pack(double v, pg_u32 tag) {
@@ -734,9 +631,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
     // (ONE LDS round trip for what everybody reads: loads behind a branch would each be one of their own)
     int f_abort = pg_flag(sflag), f_end = pg_flag(sflag + 1);
     double beta = bc[0];
-#ifndef HIPEMU
-    asm volatile("" : "+v"(f_abort), "+v"(f_end), "+v"(beta));
-#endif
+    pg_keep(f_abort, f_end, beta);
     if (f_abort != 0) return;
     if (f_end != 0) {
       if (roww) finish();
@@ -791,22 +686,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
         // (clamped, masked below: lanes beyond G re-read the last record)
         const int last = G - 1;
         const int i0 = min(int(l0), last), i1 = min(int(l0) + 64, last), i2 = min(int(l0) + 128, last), i3 = min(int(l0) + 192, last);
-#ifdef HIPEMU
-        r[0] = pg_rec_load1(base + i0);
-        r[1] = pg_rec_load1(base + i1);
-        r[2] = pg_rec_load1(base + i2);
-        r[3] = pg_rec_load1(base + i3);
-#else
-        {
-          const pg_rec *p0 = base + i0, *p1 = base + i1, *p2 = base + i2, *p3 = base + i3;
-          asm volatile(
-              "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off "
-              "sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-              : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
-              : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-              : "memory");
-        }
-#endif
+        pg_rec_load4(base + i0, base + i1, base + i2, base + i3, r);
         bool ok = true;
         double v[4];
 #pragma unroll

@@ -181,6 +181,7 @@ struct rba_solver {
   virtual void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) = 0;
   virtual void get_byte_model(rba_byte_model* out) = 0;
   virtual void get_pcg_counters(rba_pcg_counters* out) = 0;
+  virtual void get_reduced_matrix_info(rba_reduced_matrix_info* out) = 0;
 };
 
 namespace {
@@ -3264,6 +3265,16 @@ class Solver final : public rba_solver {
 
   }
   void get_pcg_counters(rba_pcg_counters* out) override { *out = pcg_counters_; }
+  void get_reduced_matrix_info(rba_reduced_matrix_info* out) override {
+    const int64_t nc = n_cams_;
+    const bool have = sc_ ? sc_nnz_ > 0 : ex_ready_;
+    out->blocks_stored = have ? (sc_ ? sc_nnz_ : ex_nnz_) : 0;
+    out->blocks_full = have ? (sc_ ? int64_t(sc_nnz_) : 2 * int64_t(ex_nnz_) - nc) : 0;
+    out->density = have && nc > 0 ? double(out->blocks_full) / (double(nc) * double(nc)) : 0.0;
+    out->bytes_stored = out->blocks_stored * 81 * int64_t(sc_ ? sizeof(S) : sizeof(double));
+    out->resident_in_registers = pcg_persistent_possible() ? 1 : 0;
+    out->persistent_workgroups = pg_ready_ ? pg_G_ : 0;
+  }
   void get_problem_stats(int64_t* storage, int64_t* hx_bytes, int64_t* hx_flops) override {
     *storage = storage_bytes_;
     *hx_bytes = sc_ ? hx_bytes_ : hx_implicit_bytes_;
@@ -3947,6 +3958,7 @@ class ShardedSolver final : public rba_solver {
   }
   void get_byte_model(rba_byte_model* out) override { ranks_[0]->get_byte_model(out); }  // (rank 0's shard)
   void get_pcg_counters(rba_pcg_counters* out) override { ranks_[0]->get_pcg_counters(out); }
+  void get_reduced_matrix_info(rba_reduced_matrix_info* out) override { ranks_[0]->get_reduced_matrix_info(out); }
 
  private:
   // ---- one host thread per rank: the Solvers' collectives must be entered by all ranks at once --------------------
@@ -4384,6 +4396,13 @@ int rba_get_pcg_counters(rba_handle h, rba_pcg_counters* out) {
   return guarded([&]() -> int {
     if (!out) return RBA_ERR_INVALID_ARGUMENT;
     h->get_pcg_counters(out);
+    return RBA_OK;
+  });
+}
+int rba_get_reduced_matrix_info(rba_handle h, rba_reduced_matrix_info* out) {
+  return guarded([&]() -> int {
+    if (!out) return RBA_ERR_INVALID_ARGUMENT;
+    h->get_reduced_matrix_info(out);
     return RBA_OK;
   });
 }

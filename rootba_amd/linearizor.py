@@ -281,6 +281,11 @@ class LinearizorHIP:
         L.check(self.lib.rba_get_pcg_counters(self.h, C.byref(m)), "rba_get_pcg_counters")
         return {n: getattr(m, n) for n, _ in L.RbaPcgCounters._fields_}
 
+    def reduced_matrix_info(self) -> dict:
+        m = L.RbaReducedMatrixInfo()
+        L.check(self.lib.rba_get_reduced_matrix_info(self.h, C.byref(m)), "rba_get_reduced_matrix_info")
+        return {n: getattr(m, n) for n, _ in m._fields_}
+
     def problem_stats(self) -> dict:
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         L.check(self.lib.rba_get_problem_stats(self.h, C.byref(a), C.byref(b), C.byref(c)),

@@ -1,5 +1,6 @@
 """Builds tests/hipemu/_build/librootba_hip_emu.so: the product's solver.hip + kernel headers, UNCHANGED except for one
-textual rewrite (`extern __shared__` -> `extern thread_local`: the dynamic-LDS arrays are defined by the harness), compiled as plain
+textual rewrite (`extern __shared__` -> `extern thread_local`: the dynamic-LDS arrays are defined by the harness) and one
+substituted header (pg_record_io.hpp: the inline-assembly record accesses of the persistent PCG kernel), compiled as plain
 C++ against tests/hipemu/hip/hip_runtime.h. TEST INFRASTRUCTURE ONLY - see that header.
 
     python tests/hipemu/build_emu.py
@@ -30,7 +31,7 @@ def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     deps = sources() + [os.path.join(ROOT, "include", "rootba_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
-                        os.path.join(HERE, "hipemu_runtime.cpp"), os.path.join(HERE, "fake_rccl.cpp"), os.path.abspath(__file__)]
+                        os.path.join(HERE, "hipemu_runtime.cpp"), os.path.join(HERE, "fake_rccl.cpp"), os.path.join(HERE, "pg_record_io.hpp"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
@@ -44,6 +45,8 @@ def build(force: bool = False) -> str:
     for path in sources():
         txt = open(path).read().replace("extern __shared__", "extern thread_local")
         open(os.path.join(src_dir, os.path.basename(path)), "w").write(txt)
+    # the one product header the harness replaces: the inline-assembly record accesses of the persistent PCG kernel
+    shutil.copy(os.path.join(HERE, "pg_record_io.hpp"), os.path.join(src_dir, "pg_record_io.hpp"))
     cmd = [CXX, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-mavx2", "-mfma", "-ffp-contract=fast",
            "-Wno-unused-value", "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-DHIPEMU=1",
            "-I", HERE, os.path.join(src_dir, "solver.hip"), "-x", "c++", os.path.join(HERE, "hipemu_runtime.cpp"),
