@@ -122,6 +122,7 @@ struct Rccl {
   int (*GetUniqueId)(UniqueId*) = nullptr;
   int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommAbort)(void*) = nullptr;
   int (*CommCount)(void*, int*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -133,6 +134,7 @@ struct Rccl {
     GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
     CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
@@ -155,6 +157,9 @@ struct rba_solver {
   virtual void comm_init_callback(int rank, int nranks, rba_allreduce_fn fn, void* ctx) = 0;
   virtual void comm_info(int* rank, int* nranks, int* transport) = 0;
   virtual void comm_stats(int64_t* calls, int64_t* bytes, double* seconds) = 0;
+  // called from ANOTHER thread when a sibling rank of a sharded handle has failed: this rank's pending and future
+  // collectives must fail instead of waiting for the missing rank
+  virtual void comm_abort() {}
   virtual void set_state(const void* cams, const void* lms) = 0;
   virtual void get_state(void* cams, void* lms) = 0;
   virtual void backup() = 0;
@@ -1355,7 +1360,7 @@ class Solver final : public rba_solver {
     (void)hipSetDevice(device_);
     destroy_pcg_graphs();
     if (stream_) (void)hipStreamSynchronize(stream_);
-    if (comm_ && g_rccl.CommDestroy) g_rccl.CommDestroy(comm_);
+    if (comm_ && g_rccl.CommDestroy && !comm_aborted_.load()) g_rccl.CommDestroy(comm_);  // (an aborted one is gone)
     comm_ = nullptr;
     for (auto& e : hx_events_)
       if (e) (void)hipEventDestroy(e);
@@ -1404,7 +1409,27 @@ class Solver final : public rba_solver {
     comm_events_.assign(2 * kCommEvents, nullptr);  // (not lazily inside a timed stage)
     for (auto& e : comm_events_) HIP_CHECK(hipEventCreate(&e));
     union_structure_over_ranks();
+    agree_on_persistent_kernel();
     decide_product_split();
+  }
+
+  // Whether PCG solves on the assembled matrix run as the persistent kernel is decided per rank from ITS device (the
+  // matrix must fit one workgroup per compute unit: n_cus_) - ranks on devices with different CU counts or masks would
+  // disagree, and the collective fallback of such a solve (all_reduce of the "gave up" flags) is entered only by ranks
+  // that run the kernel: a mismatched collective. One min-reduce makes the decision common.
+  void agree_on_persistent_kernel() {
+    if (nranks_ <= 1) return;
+    int not_ready = pg_ready_ ? 0 : 1;
+    d_scratch_int_.upload(&not_ready, 1, stream_);
+    all_reduce(d_scratch_int_.get(), 1, kNcclMax);
+    d_scratch_int_.download(&not_ready, 1, stream_);
+    sync();
+    if (not_ready && pg_ready_) {
+      if (env_.verbose)
+        std::fprintf(stderr, "[rootba_hip] rank %d: the assembled matrix does not fit another rank's register files: all ranks "
+                             "use the two-launch PCG\n", rank_);
+      pg_ready_ = false;
+    }
   }
 
   // Whether the reduced matrix is assembled at all is decided per rank from ITS shard (pair-list budget): ranks that
@@ -1524,6 +1549,7 @@ class Solver final : public rba_solver {
     cb_fn_ = fn;
     cb_ctx_ = ctx;
     union_structure_over_ranks();
+    agree_on_persistent_kernel();
     decide_product_split();
   }
 
@@ -1562,9 +1588,15 @@ class Solver final : public rba_solver {
     }
   }
 
+  void comm_abort() override {
+    if (comm_aborted_.exchange(true)) return;
+    if (comm_ && g_rccl.CommAbort) (void)g_rccl.CommAbort(comm_);  // (in-flight collectives of this rank return)
+  }
+
   template <class T>
   void all_reduce(T* buf, size_t count, int op = kNcclSum) {
     if (!comm_ && !cb_fn_) return;
+    if (comm_aborted_.load()) throw HipError{"the communicator was aborted: another rank of this handle failed", RBA_ERR_COMM};
     ++comm_calls_;
     comm_bytes_ += int64_t(count * sizeof(T));
     if (cb_fn_) {
@@ -1674,6 +1706,7 @@ class Solver final : public rba_solver {
                        reinterpret_cast<float*>(d_lms_.get()), nl);
   }
   void restore() override {
+    if (!in_lm_step_) lm_.ri_is_current = false;  // (see apply())
     use_device();
     HIP_CHECK(hipMemcpyAsync(d_cams_.get(), d_cams_bak_.get(), d_cams_.size() * sizeof(S),
                              hipMemcpyDeviceToDevice, stream_));
@@ -1761,6 +1794,8 @@ class Solver final : public rba_solver {
   bool s1_fused() const { return !sc_ && n_tiles_ > 0 && env_.s1_fused && !sub_timing(); }
 
   int linearize(void* jp_diag2_out) override {
+    if (env_.test_fail_rank >= 0 && nranks_ > 1 && rank_ == env_.test_fail_rank)
+      throw HipError{"RBA_TEST_FAIL_RANK: rank " + std::to_string(rank_) + " fails on purpose", RBA_ERR_HIP};
     use_device();
     time_begin();
     sub_begin();
@@ -2708,8 +2743,11 @@ class Solver final : public rba_solver {
         // (explicit-SC backend: the state comes from k_pcg_init, the damping is inside the matrix)
         // (and the power series: its solves come here from k_pcg_init as well)
         if (sc_ || series_fused()) hipLaunchKernelGGL(rba::k_pcgs_begin, dim3(1), dim3(1), 0, stream_, st, double(lambda), 0);
-        if (comm_) {
-          // (sharded run: the solve's entry state, in case another rank's kernel gives up - see below)
+        {
+          // the solve's entry state (x, the PCG scalars; r, z, p are inputs the kernel never writes): restored before the
+          // two-launch path takes over when the kernel - this rank's or, in a sharded run, any rank's - gave up. Always
+          // saved: a workgroup that finished before another one's bounded wait expired has written x and `done`
+          // 
           if (!d_pg_xsave_.get()) {
             d_pg_xsave_.alloc(size_t(n));
             d_pg_stsave_.alloc(1);
@@ -2732,14 +2770,13 @@ class Solver final : public rba_solver {
           all_reduce(d_scratch_int_.get(), 1, kNcclMax);
           d_scratch_int_.download(&gave_up, 1, stream_);
           sync();
-          if (gave_up && finished) {
-            // this rank's kernel finished, another's did not: back to the entry state (the kernel writes x and the state
-            // only at its end; r, z, p are inputs), then everybody takes the two-launch path
-            HIP_CHECK(hipMemcpyAsync(d_x_.get(), d_pg_xsave_.get(), size_t(n) * sizeof(S), hipMemcpyDeviceToDevice, stream_));
-            HIP_CHECK(hipMemcpyAsync(st, d_pg_stsave_.get(), sizeof(rba::CgState), hipMemcpyDeviceToDevice, stream_));
-          }
         }
         if (gave_up) {
+          // back to the entry state - whether this rank's kernel finished (another rank's did not) or some of its
+          // workgroups had already written the end of the solve when another one gave up -, then everybody takes the
+          // two-launch path
+          HIP_CHECK(hipMemcpyAsync(d_x_.get(), d_pg_xsave_.get(), size_t(n) * sizeof(S), hipMemcpyDeviceToDevice, stream_));
+          HIP_CHECK(hipMemcpyAsync(st, d_pg_stsave_.get(), sizeof(rba::CgState), hipMemcpyDeviceToDevice, stream_));
           // a workgroup waited ~1 s for a granule (not every workgroup resident? another process on the device?): nothing
           // of the state was written - continue in two launches per iteration and keep to them
           std::fprintf(stderr, "[rootba_hip] persistent PCG gave up waiting (%d workgroups); two-launch path from now on\n", pg_G_);
@@ -2792,6 +2829,7 @@ class Solver final : public rba_solver {
 
   // ---- apply ------------------------------------------------------------------------
   int apply(const void* inc, double* l_diff_out, bool update_cams) override {
+    if (!in_lm_step_) lm_.ri_is_current = false;  // (a caller changes the state between two rba_lm_step calls: the cached cost is another state's)
     use_device();
     if (!landmark_damping_valid_) run_stage2(S(0));
     time_begin();
@@ -2919,6 +2957,7 @@ class Solver final : public rba_solver {
     // Inside this function stage results and timers are collected at the iteration's own synchronisation points (the
     // PCG's polls, the increment after the solve, the end) instead of after every stage; the unstaged sub-stage timers
     // keep the per-stage synchronisation they are read at.
+    FlagScope step_scope(in_lm_step_, true);
     FlagScope async_scope(lm_async_, !sub_timing());
     auto finish = [&](bool keep_going) {
       if (lm_async_) {
@@ -3491,6 +3530,7 @@ class Solver final : public rba_solver {
                                        // over the ranks (default: where the estimate says it pays)
     int hx_wide_inside = 1;            // RBA_HX_WIDE_INSIDE=0: landmarks with 32 < k <= 64 in a kernel of their own
     int stage_timers = 1;              // RBA_STAGE_TIMERS=0: no HIP events around the stages (rba_iter_timings stays zero)
+    int test_fail_rank = -1;           // RBA_TEST_FAIL_RANK=r: rank r of a sharded run throws at its next linearisation (test of the abort path)
     int pcgp_test_give_up = 0;         // RBA_PCGP_TEST_GIVE_UP=1: test hook of the collective fallback of a sharded run
     int deterministic = 0;             // RBA_DETERMINISTIC=1: matrix-free products summed camera-major in a fixed order
                                        // (no floating-point atomics anywhere: runs repeat bit by bit; ~2 x per product)
@@ -3519,6 +3559,7 @@ class Solver final : public rba_solver {
     env_.hx_wide_inside = geti("RBA_HX_WIDE_INSIDE", 1);
     env_.deterministic = geti("RBA_DETERMINISTIC", 0);
     env_.pcgp_test_give_up = geti("RBA_PCGP_TEST_GIVE_UP", 0);
+    env_.test_fail_rank = geti("RBA_TEST_FAIL_RANK", -1);
     env_.stage_timers = geti("RBA_STAGE_TIMERS", 1);
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     env_.pcg_persistent = geti("RBA_PCG_PERSISTENT", 1);
@@ -3580,6 +3621,7 @@ class Solver final : public rba_solver {
   int stamp_n_ = 0, stamp_pending_ = -1, stamp_begin_ = -1, stamp_side_slot_ = -1;
   double stamp_hz_ = 1e8;
   std::vector<PendingStamp> pending_stamps_;
+  bool in_lm_step_ = false;  // rba_lm_step is running: apply / restore are ITS calls (the cached cost stays valid)
   bool lm_async_ = false;  // inside rba_lm_step: results and timers are collected at the iteration's own sync points
   std::vector<hipEvent_t> hx_events_;
   std::vector<int> hx_event_call_;  // which H*x call of the solve each event pair brackets
@@ -3670,6 +3712,7 @@ class Solver final : public rba_solver {
   LmState lm_;
   // multi-GPU
   void* comm_ = nullptr;
+  std::atomic<bool> comm_aborted_{false};
   int rank_ = 0, nranks_ = 1;
   rba_allreduce_fn cb_fn_ = nullptr;
   void* cb_ctx_ = nullptr;
@@ -3816,23 +3859,30 @@ class ShardedSolver final : public rba_solver {
     workers_.reserve(n);
     for (int r = 0; r < n; ++r) workers_.emplace_back([this, r] { worker(r); });
     try {
+      // two phases: every Solver first - a rank whose construction fails (out of memory, a HIP error)
+      // must not leave its peers waiting inside ncclCommInitRank or a collective of the structure union
       run_all([&](int r) {
         ranks_[r].reset(make_solver(dtype, devices[r], n_cams, cuts_[r], cuts_[r + 1], lm_off, obs_cam, obs_xy, opt));
-        if (n_ > 1) {
+      });
+      if (n_ > 1)
+        run_all([&](int r) {
           if (rccl_)
             ranks_[r]->comm_init(r, n_, &uid);
           else
             ranks_[r]->comm_init_callback(r, n_, &ShardedSolver::host_allreduce, &hctx_[r]);
-        }
-      });
+        });
     } catch (...) {
+      try {
+        run_all([&](int r) { ranks_[r].reset(); }, /*even_if_broken=*/true);  // (on the ranks' own threads, like the destructor)
+      } catch (...) {
+      }
       stop_workers();
       throw;
     }
   }
   ~ShardedSolver() override {
     try {
-      run_all([&](int r) { ranks_[r].reset(); });
+      run_all([&](int r) { ranks_[r].reset(); }, /*even_if_broken=*/true);
     } catch (...) {
     }
     stop_workers();
@@ -3976,13 +4026,9 @@ class ShardedSolver final : public rba_solver {
       try {
         f(r);
       } catch (const HipError& e) {
-        std::lock_guard<std::mutex> lk(m_);
-        if (!failed_) err_ = e;
-        failed_ = true;
+        fail(r, e);
       } catch (const std::exception& e) {
-        std::lock_guard<std::mutex> lk(m_);
-        if (!failed_) err_ = HipError{e.what(), RBA_ERR_HIP};
-        failed_ = true;
+        fail(r, HipError{e.what(), RBA_ERR_HIP});
       }
       {
         std::lock_guard<std::mutex> lk(m_);
@@ -3990,9 +4036,30 @@ class ShardedSolver final : public rba_solver {
       }
     }
   }
-  void run_all(const std::function<void(int)>& f) {
+  // A rank threw while its peers may be inside a collective that now never completes: record the first
+  // error, wake the waiters of the host transport (they return an error), abort the peers' RCCL communicators (their
+  // pending collectives return), and mark the handle broken - every later call fails at once instead of hanging.
+  void fail(int r, const HipError& e) {
     {
       std::lock_guard<std::mutex> lk(m_);
+      if (!failed_) err_ = e;
+      failed_ = true;
+      broken_ = true;
+    }
+    {
+      std::lock_guard<std::mutex> lk(hm_);
+      habort_ = true;
+    }
+    hcv_.notify_all();
+    if (rccl_)
+      for (int q = 0; q < n_; ++q)
+        if (q != r && ranks_[q]) ranks_[q]->comm_abort();
+  }
+  void run_all(const std::function<void(int)>& f, bool even_if_broken = false) {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      if (broken_ && !even_if_broken)
+        throw HipError{"this sharded handle is broken: a rank failed earlier (" + err_.msg + ")", err_.code ? err_.code : RBA_ERR_HIP};
       job_ = f;
       busy_ = n_;
       failed_ = false;
@@ -4036,6 +4103,7 @@ class ShardedSolver final : public rba_solver {
   int host_allreduce_impl(int rank, void* buf, int64_t count, int dtype, int op) {
     const size_t es = dtype == 1 ? 8 : 4;
     std::unique_lock<std::mutex> lk(hm_);
+    if (habort_) return 1;
     const uint64_t my_gen = hgen_;
     hbufs_[rank] = buf;
     if (++harrived_ == n_) {
@@ -4052,7 +4120,8 @@ class ShardedSolver final : public rba_solver {
       ++hgen_;
       hcv_.notify_all();
     } else {
-      hcv_.wait(lk, [&] { return hgen_ != my_gen; });
+      hcv_.wait(lk, [&] { return hgen_ != my_gen || habort_; });
+      if (hgen_ == my_gen) return 1;  // (aborted: a sibling rank failed and will never arrive)
     }
     return 0;
   }
@@ -4068,7 +4137,7 @@ class ShardedSolver final : public rba_solver {
   std::function<void(int)> job_;
   uint64_t gen_ = 0;
   int busy_ = 0;
-  bool stop_ = false, failed_ = false;
+  bool stop_ = false, failed_ = false, broken_ = false, habort_ = false;
   HipError err_{"", 0};
   std::mutex hm_;
   std::condition_variable hcv_;

@@ -1051,3 +1051,32 @@ def test_stage_timers_inside_the_lm_loop(ladybug_far, mode, monkeypatch):
 
 
 _STAGE_TIMER_RUNS = {}
+
+
+def test_cached_cost_is_dropped_when_the_caller_changes_the_state(ladybug_far):
+    """rba_lm_step reuses the trial cost of an accepted step as the cost of the next iteration's start
+    (bal_bundle_adjustment.cpp:297-301 re-evaluates it; same kernel, same state: bit-identical). A caller that moves the
+    state between two rba_lm_step calls - rba_apply, rba_restore - invalidates that cache: the next
+    step must evaluate the cost of the state it actually starts from."""
+    from rootba_amd import _lib as L
+    from rootba_amd.linearizor import LinearizorHIP
+    opts = dict(robust_norm=1, max_num_iterations=8, function_tolerance=0.0)
+    g = LinearizorHIP(ladybug_far, np.float64, L.default_options(**opts))
+    g.lm_begin()
+    g.lm_step()
+    row1, _ = g.lm_step()
+    assert row1.step_is_successful == 1
+    n0 = g.pcg_counters()["cost_evaluations"]
+    # the caller moves the cameras (a step along a random direction) between two LM steps
+    rng = np.random.default_rng(3)
+    g.apply(1e-3 * rng.standard_normal(9 * ladybug_far.n_cams))
+    moved = g.compute_error().all_error
+    assert abs(moved - row1.cost) > 1e-6 * row1.cost
+    n1 = g.pcg_counters()["cost_evaluations"]
+    row2, _ = g.lm_step()
+    # the step evaluated the start cost afresh (+ its trial cost): with the stale cache it launched one evaluation only
+    assert g.pcg_counters()["cost_evaluations"] - n1 == 2, (n0, n1, g.pcg_counters())
+    # and judged its decrease against the moved state's cost, not against row1.cost
+    if row2.step_is_successful:
+        assert row2.cost < moved
+    g.close()

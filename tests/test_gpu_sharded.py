@@ -267,3 +267,24 @@ def test_persistent_pcg_fallback_is_collective(ladybug_problem, monkeypatch):
     assert [r.cg_iterations for r in ra] == [r.cg_iterations for r in rb]
     assert [r.cost for r in ra] == [r.cost for r in rb]
     assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+
+
+@pytest.mark.timeout(120)
+def test_sharded_handle_fails_instead_of_hanging_when_one_rank_throws(monkeypatch):
+    """a rank of a sharded handle that throws while its peers are inside a collective must not leave them
+    waiting for ever. Test hook RBA_TEST_FAIL_RANK=1: rank 1 throws at its next linearisation while rank 0 enters the
+    all-reduce of the failure flag; the call returns an error (the waiter of the host transport is woken and fails, an
+    RCCL communicator would be aborted), and every later call on the handle fails at once."""
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd import problem as P
+    from rootba_amd.linearizor import LinearizorHIP
+    prob = P.preprocess(P.named_synthetic("ladybug-49"), translation_sigma=0.5, point_sigma=0.5)
+    monkeypatch.setenv("RBA_TEST_FAIL_RANK", "1")
+    s = LinearizorHIP(prob, np.float32, L.default_options(robust_norm=1), devices=[0, 0])
+    assert s.compute_error().all_error > 0  # (collectives work until the failure)
+    with pytest.raises(RuntimeError, match="fails on purpose|aborted|callback failed"):
+        s.linearize()
+    with pytest.raises(RuntimeError, match="broken"):
+        s.compute_error()
+    s.close()
