@@ -299,7 +299,7 @@ def dense_companion(args):
         return None
 
 
-def reference_semantics_run(local, prob_name, rank, world, local_rank, comm_setup):
+def reference_semantics_run(local, prob_name, rank, world, local_rank, comm_setup, devices=None):
     """The same LM run with the reference's own stopping rule (function_tolerance = 1e-6,
     bal_bundle_adjustment.cpp:174-201, 476-481): it/s over iterations 1..(iteration where it fires)."""
     from rootba_amd import _lib as L
@@ -307,7 +307,7 @@ def reference_semantics_run(local, prob_name, rank, world, local_rank, comm_setu
     opts = solver_options(L, 50, function_tolerance=1e-6)
     for key, val in _GPU_KW.items():
         setattr(opts, key, val)
-    lin = LinearizorHIP(local, GPU_DTYPE, opts, device=local_rank)
+    lin = LinearizorHIP(local, GPU_DTYPE, opts, device=local_rank, devices=devices)
     comm_setup(lin)
     lin.lm_begin()
     lin.lm_step()  # iteration 0: evaluation only
@@ -362,10 +362,16 @@ def main():
     ap.add_argument("--no-dense-companion", action="store_true",
                     help="skip `value_dense_covisibility` (the same workload with heavy-tailed track lengths, whose reduced "
                          "camera matrix is nearly dense and does not fit the register files; one repetition)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N through ONE handle of ONE process (rba_create_sharded: the library shards the landmarks "
+                         "over devices 0..N-1 itself, one host thread and one RCCL rank per device) instead of one "
+                         "process per GPU - the entry a drop-in binding of the reference's one-process driver uses")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--companion-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.single_process and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        raise SystemExit("--single-process is ONE process over --gpus devices: do not start it under a multi-rank launcher")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
     global DTYPE, GPU_DTYPE
     DTYPE = np.float64 if args.use_double else np.float32
@@ -384,9 +390,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    sp_devices = list(range(args.gpus)) if args.single_process and args.gpus > 1 else None
+    if world != args.gpus and sp_devices is None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong "
                          f"number of ranks")
+    if sp_devices is not None and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--single-process --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the solver has no CPU fallback)")
     if torch.cuda.device_count() <= local_rank:
@@ -417,7 +426,7 @@ def main():
     # product's launch time. An explicit RBA_HX_TIMING_STRIDE in the environment wins.
     stride_env = os.environ.get("RBA_HX_TIMING_STRIDE")
     os.environ["RBA_HX_TIMING_STRIDE"] = stride_env if stride_env is not None else "0"
-    lin = LinearizorHIP(local, GPU_DTYPE, gpu_opts, device=local_rank)
+    lin = LinearizorHIP(local, GPU_DTYPE, gpu_opts, device=local_rank, devices=sp_devices)
     log(f"[rank {rank}] solver set up in {time.perf_counter() - t0:.2f}s (rba_create: sort by track length, "
         f"CSC index, block structure of the reduced matrix, launch graphs, device allocation)")
 
@@ -512,7 +521,7 @@ def main():
         # the product's launch time: the same warm-up + steps once more on a handle with HIP events around every 8th
         # matrix-free product (not part of `value`)
         os.environ["RBA_HX_TIMING_STRIDE"] = "8"
-        lin_t = LinearizorHIP(local, GPU_DTYPE, gpu_opts, device=local_rank)
+        lin_t = LinearizorHIP(local, GPU_DTYPE, gpu_opts, device=local_rank, devices=sp_devices)
         comm_setup(lin_t)
         tp = measure(lin_t)
         hx_time, hx_calls = tp["hx_time"], tp["hx_calls"]
@@ -523,7 +532,7 @@ def main():
 
     ref_sem = None
     if not args.no_reference_semantics:
-        ref_sem = reference_semantics_run(local, prob.name, rank, world, local_rank, comm_setup)
+        ref_sem = reference_semantics_run(local, prob.name, rank, world, local_rank, comm_setup, sp_devices)
 
     if rank == 0:
         timed = rows[args.warmup:]
@@ -534,9 +543,12 @@ def main():
                 f"err {r.residual_time * 1e3:.2f})")
         sc = args.solver_type == "SCHUR_COMPLEMENT"
         avg_hx = hx_time / hx_calls if hx_calls else None
-        achieved = stats["hx_bytes"] / avg_hx / 1e9 if avg_hx else None
+        # (one handle over several devices: the timed launches are device 0's, over its share of the landmarks - the ranges
+        #  are balanced by bytes, rba_get_shard_ranges)
+        hx_bytes_per_launch = stats["hx_bytes"] / (len(sp_devices) if sp_devices else 1)
+        achieved = hx_bytes_per_launch / avg_hx / 1e9 if avg_hx else None
         traffic, traffic_source = None, None
-        if world == 1 and not sc and not args.no_pmc:
+        if world == 1 and sp_devices is None and not sc and not args.no_pmc:
             try:
                 traffic, traffic_source = measure_product_traffic(sys.argv[1:])
                 if traffic is None:
@@ -545,7 +557,7 @@ def main():
                 log(f"[roofline.traffic] in-run measurement failed: {e!r}")
                 traffic = None
         tpath = os.path.join(ROOT, "profiles", "hx_traffic.json")
-        if traffic is None and os.path.exists(tpath) and world == 1 and not sc:
+        if traffic is None and os.path.exists(tpath) and world == 1 and sp_devices is None and not sc:
             try:
                 with open(tpath) as f:
                     traffic = json.load(f).get(args.workload + "/implicit_q", {}).get("traffic_bytes_per_launch")
@@ -605,7 +617,7 @@ def main():
                               "values": [args.steps / r["elapsed"] for r in reps],
                               "spread_rel": (max(r["elapsed"] for r in reps) - min(r["elapsed"] for r in reps)) / elapsed},
             "unit": "LM iterations/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus if sp_devices is not None else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -617,10 +629,11 @@ def main():
             "config": {
                 "workload": f"BAL {args.workload} ({data}): {prob.n_cams} cams, {prob.n_lms} lms, {prob.n_obs} obs, "
                             f"solver={args.solver_type}, {args.preconditioner}, Huber(1), {'mixed float32/float64' if args.mixed else 'float64' if DTYPE == np.float64 else 'float32'}",
-                "parallelism": (f"landmarks sharded over {world} GPU(s); library communicator: transport="
-                                f"{info['transport']}, nranks={info['nranks']}"
-                                + ("" if world == 1 else "; all-reduce of camera-sized vectors / the assembled matrix")),
-                "comm_per_step": None if world == 1 else {
+                "parallelism": (f"landmarks sharded over {info['nranks']} GPU(s)"
+                                + (" behind ONE handle of one process (rba_create_sharded)" if sp_devices is not None else "")
+                                + f"; library communicator: transport={info['transport']}, nranks={info['nranks']}"
+                                + ("" if info['nranks'] == 1 else "; all-reduce of camera-sized vectors / the assembled matrix")),
+                "comm_per_step": None if info['nranks'] == 1 else {
                     "all_reduces": (comm1["calls"] - comm0["calls"]) / args.steps,
                     "bytes": (comm1["bytes"] - comm0["bytes"]) / args.steps,
                     "ms": 1e3 * (comm1["seconds"] - comm0["seconds"]) / args.steps},
@@ -663,7 +676,7 @@ def main():
                 "frac_of_measured_stream_read": achieved / 6500.0 if achieved else None,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": stats["hx_bytes"],
+                "algorithmic_bytes_per_launch": hx_bytes_per_launch,
                 "avg_launch_ms": avg_hx * 1e3 if avg_hx else None,
                 "launches_timed": hx_calls,
                 "launch_timing": hx_pass,
@@ -680,10 +693,10 @@ def main():
                 "stages": stages,
             },
         }
-        if (world == 1 and args.workload == "venice-1778" and data == "synthetic" and not args.no_dense_companion
+        if (world == 1 and sp_devices is None and args.workload == "venice-1778" and data == "synthetic" and not args.no_dense_companion
                 and not args.use_double and args.solver_type == "SQUARE_ROOT"):
             out["config"]["value_dense_covisibility"] = dense_companion(args)
-        if world == 1 and args.cpu_baseline_iters > 0:
+        if world == 1 and sp_devices is None and args.cpu_baseline_iters > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(prob, args.cpu_baseline_iters, rows)
             except Exception as e:  # the baseline must never take the GPU number down

@@ -114,7 +114,7 @@ typedef struct rba_options {
                                      the float factors, rootba_amd/csrc/kernels_a64.hpp: a float matrix costs
                                      the PCG the accuracy the square-root form exists for) and continues with
                                      S x; 0 = never; -1 (default) = 6 for the first long solve, then the
-                                     measured break-even (assembly time / product time, clamped to 2..32),
+                                     measured break-even (assembly time / (matrix-free product time - time of an iteration on S), >= 2),
                                      left early - at iteration 5 - by solves whose stopping quantity rises
                                      from iteration 3 to 4                         */
 } rba_options;

@@ -224,10 +224,16 @@ class LinearizorHIP : public LinearizorBase<Scalar_>, public HostStateSync {
 
   // what BalProblem's cameras say right now (Camera::params(), bal_problem.hpp:84-89: qx qy qz qw tx ty tz f k1 k2)
   void read_host_cameras(std::vector<Scalar>& out) const {
+    // (the pieces of Camera::params() read in place: params() itself returns a heap-allocated VecX per camera, and this
+    //  probe runs four times per LM iteration)
     out.resize(size_t(10) * bal_problem_.num_cameras());
     for (int c = 0; c < bal_problem_.num_cameras(); ++c) {
-      const VecX p = bal_problem_.cameras()[c].params();
-      for (int k = 0; k < 10; ++k) out[size_t(10) * c + k] = p(k);
+      const auto& cam = bal_problem_.cameras()[c];
+      const auto pose = cam.T_c_w.params();          // qx qy qz qw tx ty tz
+      const auto intr = cam.intrinsics.getParam();   // f k1 k2
+      Scalar* o = out.data() + size_t(10) * c;
+      for (int k = 0; k < 7; ++k) o[k] = pose(k);
+      for (int k = 0; k < 3; ++k) o[7 + k] = intr(k);
     }
   }
   // BalProblem -> device, everything

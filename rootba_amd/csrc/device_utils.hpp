@@ -142,15 +142,35 @@ __device__ __forceinline__ void quat_to_rot(S x, S y, S z, S w, S R[9]) {
   R[8] = S(1) - (txx + tyy);
 }
 
+// The camera-frame point p_c = R(q) p_w + t and R itself.
+// float: evaluated in DOUBLE from the float state and rounded once (round 6). R p_w and t are both of the size of the
+// scene and cancel down to the depth: in float arithmetic p_c carries an ABSOLUTE error of ~1e-7 |p_w| whatever its own
+// size, and a landmark that an LM step has moved next to a camera plane (final-13682, state of LM iteration 6: two
+// 2-observation landmarks at depth 0.008 with |p_w| = 126, residuals of thousands of pixels) then has residual and
+// Jacobian rows that are wrong by 1e-3 - two such landmarks were 3e-5 of the whole cost and a third of the increment
+// error of that state, for the float32 CPU restatement of the reference (1.1e-3 from float64, 28 % of it in ONE camera)
+// as for this library (8.4e-3; profiles/r6_final13682_iteration6_diagnosis.txt). ~40 double-precision operations per
+// observation in kernels that wait for HBM; everything after p_c - the projection, its Jacobians, the QR - is float
+// arithmetic on well-scaled quantities as in the reference (bal_bundle_adjustment_helper.cpp:111-149).
+template <class S>
+__device__ __forceinline__ void camera_frame_point(const S* __restrict__ cam, S pwx, S pwy, S pwz, S R[9], S& px, S& py,
+                                                   S& pz) {
+  double Rd[9];
+  quat_to_rot<double>(double(cam[0]), double(cam[1]), double(cam[2]), double(cam[3]), Rd);
+  const double x = double(pwx), y = double(pwy), z = double(pwz);
+  px = S(Rd[0] * x + Rd[1] * y + Rd[2] * z + double(cam[4]));
+  py = S(Rd[3] * x + Rd[4] * y + Rd[5] * z + double(cam[5]));
+  pz = S(Rd[6] * x + Rd[7] * y + Rd[8] * z + double(cam[6]));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = S(Rd[i]);
+}
+
 // Residual only (compute_error path). cam = (q xyzw, t, f, k1, k2).
 template <class S>
 __device__ __forceinline__ bool project_residual(const S* __restrict__ cam, S pwx, S pwy, S pwz,
                                                  S ox, S oy, S& rx, S& ry) {
-  S R[9];
-  quat_to_rot(cam[0], cam[1], cam[2], cam[3], R);
-  const S px = R[0] * pwx + R[1] * pwy + R[2] * pwz + cam[4];
-  const S py = R[3] * pwx + R[4] * pwy + R[5] * pwz + cam[5];
-  const S pz = R[6] * pwx + R[7] * pwy + R[8] * pwz + cam[6];
+  S R[9], px, py, pz;
+  camera_frame_point<S>(cam, pwx, pwy, pwz, R, px, py, pz);
   const S mx = px / pz, my = py / pz;
   const S r2 = mx * mx + my * my;
   const S rp = S(1) + cam[8] * r2 + cam[9] * r2 * r2;
@@ -177,12 +197,9 @@ __device__ __forceinline__ void error_weight(int robust_norm, S huber, S res_sq,
 template <class S>
 __device__ __forceinline__ bool linearize_obs(const S* __restrict__ cam, S pwx, S pwy, S pwz,
                                               S ox, S oy, S res[2], S Jp[18], S Jl[6]) {
-  S R[9];
-  quat_to_rot(cam[0], cam[1], cam[2], cam[3], R);
+  S R[9], px, py, pz;
+  camera_frame_point<S>(cam, pwx, pwy, pwz, R, px, py, pz);
   const S f = cam[7], k1 = cam[8], k2 = cam[9];
-  const S px = R[0] * pwx + R[1] * pwy + R[2] * pwz + cam[4];
-  const S py = R[3] * pwx + R[4] * pwy + R[5] * pwz + cam[5];
-  const S pz = R[6] * pwx + R[7] * pwy + R[8] * pwz + cam[6];
   const S iz = S(1) / pz;
   const S mx = px * iz, my = py * iz;
   const S r2 = mx * mx + my * my;

@@ -126,6 +126,40 @@ __device__ __forceinline__ void finish_landmark(const Params<S>& p, int s, const
   }
 }
 
+// What the end of an LM iteration hands to the host in ONE piece (rba_lm_step): the eight cost sums of the trial point,
+// the model cost change of the back-substitution and the failure word - [0..7] cost sums, [8] l_diff, [9] failure bit 1
+// (linearisation), [10] bit 2 (back-substitution), [11] bit 4 (block inversion) as 0 / 1 so that a SUM all-reduce of
+// the twelve doubles is the collective of a sharded run (one instead of three).
+constexpr int kEndRed = 12;
+
+// Sum rows of a [n][W] double array into out[W] with the work-items of ONE workgroup (deterministic: work-item-strided,
+// wavefronts in order). `sm`: [16][W] doubles of LDS.
+template <int W>
+__device__ __forceinline__ void reduce_rows_workgroup(const double* __restrict__ in, int64_t n, double* __restrict__ out,
+                                                      double* __restrict__ out_host, double (*sm)[W]) {
+  const int nt = int(blockDim.x), n_waves = nt >> 6;
+  double acc[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) acc[i] = 0;
+  for (int64_t r = threadIdx.x; r < n; r += nt) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) acc[i] += in[r * W + i];
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    const double t = wave_sum(acc[i]);
+    if (lane == 0) sm[wave][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < W) {
+    double t = sm[0][threadIdx.x];
+    for (int w = 1; w < n_waves; ++w) t += sm[w][threadIdx.x];
+    out[threadIdx.x] = t;
+    if (out_host) out_host[threadIdx.x] = t;
+  }
+}
+
 // ===========================================================================
 // compute_error: one thread per observation, per-block partial sums (double)
 // (BalBundleAdjustmentHelper::compute_error, helper.cpp:68-109;
@@ -172,9 +206,9 @@ __global__ __launch_bounds__(256) void k_compute_error(Params<S> p, int64_t n_ob
     if (lane == 0) sm[wave][i] = t;
   }
   __syncthreads();
-  if (threadIdx.x < 7)
+  if (threadIdx.x < 8)
     partials[blockIdx.x * 8 + threadIdx.x] =
-        sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+        threadIdx.x < 7 ? sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x] : 0.0;
 }
 
 // Sum rows of a [n][W] double array into out[W] (single block, deterministic).
@@ -189,35 +223,22 @@ template <int W>
 __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ in, int64_t n,
                                                       double* __restrict__ out, double* __restrict__ out_host,
                                                       int* __restrict__ flag, int* __restrict__ flag_host,
-                                                      int flag_clear, unsigned long long* __restrict__ end_stamp) {
-  const int nt = int(blockDim.x), n_waves = nt >> 6;
-  if (flag_host && int(threadIdx.x) == nt - 1) {
+                                                      int flag_clear, unsigned long long* __restrict__ end_stamp,
+                                                      double* __restrict__ bits = nullptr) {
+  const int nt = int(blockDim.x);
+  if ((flag_host || bits) && int(threadIdx.x) == nt - 1) {
     const int f = *flag;
-    *flag_host = f;
+    if (flag_host) *flag_host = f;
+    if (bits) {  // rba_lm_step of a sharded run: the word's bits 1 / 2 / 4 as 0 / 1, summed over the ranks (kEndRed)
+      bits[0] = (f & 1) ? 1.0 : 0.0;
+      bits[1] = (f & 2) ? 1.0 : 0.0;
+      bits[2] = (f & 4) ? 1.0 : 0.0;
+    }
     if (f & flag_clear) *flag = f & ~flag_clear;
   }
-  double acc[W];
-#pragma unroll
-  for (int i = 0; i < W; ++i) acc[i] = 0;
-  for (int64_t r = threadIdx.x; r < n; r += nt) {
-#pragma unroll
-    for (int i = 0; i < W; ++i) acc[i] += in[r * W + i];
-  }
   __shared__ double sm[16][W];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int i = 0; i < W; ++i) {
-    const double t = wave_sum(acc[i]);
-    if (lane == 0) sm[wave][i] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x < W) {
-    double t = sm[0][threadIdx.x];
-    for (int w = 1; w < n_waves; ++w) t += sm[w][threadIdx.x];
-    out[threadIdx.x] = t;
-    if (out_host) out_host[threadIdx.x] = t;
-    if (end_stamp && threadIdx.x == 0) *end_stamp = wall_clock64();  // (the last kernel of its stage: see stage_stamp)
-  }
+  reduce_rows_workgroup<W>(in, n, out, out_host, sm);
+  if (end_stamp && threadIdx.x == 0) *end_stamp = wall_clock64();  // (the last kernel of its stage: see stage_stamp)
 }
 
 // the failure word of a phase that ends without a reduction of its own (stage 1)
@@ -1231,15 +1252,25 @@ __device__ __forceinline__ void retract_camera(S* cam, const S inc[9]) {
   cam[9] += inc[8];
 }
 
+// `cams_bak` (rba_lm_step): the camera this update replaces is left there - BalProblem::backup() of the cameras
+// (bal_problem.cpp:590-594) without a copy kernel of its own
 template <class S>
-__global__ void k_update_cameras(Params<S> p, const S* __restrict__ inc_scaled) {
+__global__ void k_update_cameras(Params<S> p, const S* __restrict__ inc_scaled, S* __restrict__ cams_bak) {
   stage_stamp(p.stamp);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= p.n_cams) return;
-  S inc[9];
+  S inc[9], cam[10];
 #pragma unroll
   for (int i = 0; i < 9; ++i) inc[i] = inc_scaled[9 * c + i] * p.pose_scaling[9 * c + i];
-  retract_camera<S>(p.cams + 10 * c, inc);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) cam[i] = p.cams[10 * c + i];
+  if (cams_bak) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) cams_bak[10 * c + i] = cam[i];
+  }
+  retract_camera<S>(cam, inc);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) p.cams[10 * c + i] = cam[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -1788,21 +1819,37 @@ __global__ void k_negate(S* __restrict__ v, int n) {
 // End of a solve inside the LM loop (rba_lm_step): x = -x stays on the device - a copy goes to the buffer the
 // back-substitution reads - and the host gets what it needs to judge the step, |x|^2 and the number of non-finite
 // entries, in its pinned page instead of the vector itself (single workgroup).
+// Since round 6 the same workgroup does what two more launches of ~5 us did:
+//   `xs`        D inc, the operand of the back-substitution on the unscaled Jacobian rows (k_scale_vec);
+//   `flag_host` the failure word of the linearisation this solve belongs to (k_publish_flag), bits `flag_clear` reset.
+// (Measured and dropped: the camera update of the step in here too - 1778 retractions by one workgroup took the kernel
+//  from 8 to 22 us where k_update_cameras on 28 workgroups takes 5; the reductions that end the cost evaluation and the
+//  back-substitution in the LAST workgroup of their producers (ticket + __threadfence): 32 -> 260 us and 5 -> 130 us -
+//  an agent-scope fence per workgroup is an L2 write-back on this part; the landmark backup inside the
+//  back-substitution: + 7 us there for a 6 us copy. gpurun_out/r6b, profiles/r6b_fusion_that_did_not_pay_kernel_stats.csv)
 template <class S>
 __global__ __launch_bounds__(1024) void k_finish_increment(S* __restrict__ x, S* __restrict__ inc, int n,
                                                           double* __restrict__ out_host, const CgState* st,
-                                                          CgState* st_host) {
+                                                          CgState* st_host, const S* __restrict__ pose_scaling,
+                                                          S* __restrict__ xs, int* __restrict__ flag,
+                                                          int* __restrict__ flag_host, int flag_clear) {
   __shared__ double sm[16][2];
   if (st_host) {  // the final PCG state, if the host has not read it yet
     constexpr int kWords = int(sizeof(CgState) / sizeof(int));
     static_assert(kWords <= 64 && sizeof(CgState) % sizeof(int) == 0, "copied as words by one wave");
     if (threadIdx.x < kWords) reinterpret_cast<int*>(st_host)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
   }
+  if (flag_host && threadIdx.x == 1023) {
+    const int f = *flag;
+    *flag_host = f;
+    if (f & flag_clear) *flag = f & ~flag_clear;
+  }
   double acc = 0, bad = 0;
   for (int i = threadIdx.x; i < n; i += 1024) {
     const S v = -x[i];
     x[i] = v;
     inc[i] = v;
+    if (xs) xs[i] = pose_scaling[i] * v;
     acc += double(v) * double(v);
     bad += is_finite(v) ? 0.0 : 1.0;
   }

@@ -652,7 +652,13 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
     if (roww) {
       // ---- p.q: the waves' sums of their outputs' p_c q_c ---------------------------------------------------------------
       const double s0 = ((wpq[0] + wpq[1]) + (wpq[2] + wpq[3])) + ((wpq[4] + wpq[5]) + (wpq[6] + wpq[7]));
-      if (lane < kPgReplicas) pg_rec_store(P.part_pq + size_t(lane) * G + g, pg_pack(s0, tag));
+      {
+        // (the record's address from an opaque lane index: formed here, not hoisted out of the iteration loop and spilled -
+        //  the reload sat right in front of this store, i.e. on the path of the p.q exchange)
+        unsigned pl = unsigned(lane);
+        PG_OPAQUE(pl);
+        if (lane < kPgReplicas) pg_rec_store(P.part_pq + size_t(pl) * G + g, pg_pack(s0, tag));
+      }
       stamp(4);
       // ---- while the partial sums travel: what the step needs of the row's state, into registers (float solver, every
       //      record of the workgroup in one pass). Behind the gather the step is then nine fused multiply-adds, the row's
@@ -758,7 +764,9 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
           }
           const double s0r = wave_sum(acc_rho), s1r = wave_sum(acc_q);
           if (lane < 2 * kPgReplicas) {
-            const int rep = lane >> 1, k2 = lane & 1;
+            unsigned pl = unsigned(lane);
+            PG_OPAQUE(pl);  // (as for the p.q record above)
+            const int rep = int(pl >> 1), k2 = int(pl & 1);
             pg_rec_store(P.part_rq + (size_t(rep) * G + g) * 2 + k2, pg_pack(k2 ? s1r : s0r, tag + pg_u32(P.tag_stride)));
           }
         }

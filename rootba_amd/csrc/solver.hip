@@ -594,6 +594,8 @@ class Solver final : public rba_solver {
     d_lm_ldiff_.alloc(n_lms);
     d_partials_.alloc(size_t(kReduceBlocks) * 8 + 16);
     d_partials_side_.alloc(size_t(kReduceBlocks) * 8 + 16);
+    d_endred_.alloc(rba::kEndRed);
+    d_endred_.zero(stream_);
     d_cg_.alloc(1);
     d_pcg_partials_.alloc(3 * rba::kPcgBlocks);
     for (auto* v : {&d_x_, &d_r_, &d_p_, &d_z_, &d_q_, &d_tmp_, &d_inc_, &d_vin_, &d_pw_t_, &d_pw_e_})
@@ -604,6 +606,7 @@ class Solver final : public rba_solver {
     d_partials_.zero(stream_);
     d_p2_.alloc(nvec_);
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 4096));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_vec_stage_), size_t(nvec_) * sizeof(S)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_progress_), 64));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_stamps_), kMaxStamps * sizeof(unsigned long long)));
     {
@@ -1234,6 +1237,12 @@ class Solver final : public rba_solver {
     }
     return qp;
   }
+  // wavefronts of the streaming SpMV: as many as are resident at once (a two-slot ring of 43 KB each: three per compute unit)
+  int spmv_stream_waves() const {
+    if (env_.spmv_stream_waves_per_cu < 0) return 2;  // (tests: two wavefronts walk the whole matrix)
+    const int per_cu = env_.spmv_stream_waves_per_cu > 0 ? env_.spmv_stream_waves_per_cu : 3;
+    return std::max(1, n_cus_) * per_cu;
+  }
   // the row-staged SpMV of kernels_pcg.hpp on the PCG's matrix, MODE 0 / 1 / 2
   template <int MODE>
   void launch_spmv(const S* z, S* p0, S* p1, const S* xvec, const double* part_rho, const double* part_q,
@@ -1245,11 +1254,25 @@ class Solver final : public rba_solver {
       const bool part = MODE == 2 && split_ && split_partial_;
       const int i0 = part ? split_item0_ : 0, ni = part ? split_item1_ - split_item0_ : n_items_;
       if (ni <= 0) return;
-      hipLaunchKernelGGL((rba::k_pcgs_spmv<S, MODE, MT, H>), dim3(ni), dim3(64), rba::spmv_lds_bytes<MT>(), stream_,
-                         cols, vals, d_items_.get() + i0, z, p0, p1, xvec, d_qmain_.get(), d_qpart_.get(),
-                         H ? d_tpart_.get() : static_cast<double*>(nullptr),
-                         H ? d_tdst_.get() : static_cast<const int*>(nullptr), d_cg_.get(), part_rho, part_q, part_pq, q_tol,
-                         min_it, max_it, period, progress);
+      // a matrix of many more items than wavefronts fit the part (nearly dense co-visibility, final-13682): persistent
+      // wavefronts that stream their items through a software pipeline (k_pcgs_spmv_stream; bit-identical products)
+      bool streamed = false;
+      if constexpr (H) {
+        const int waves = spmv_stream_waves();
+        if (env_.spmv_stream != 0 && (env_.spmv_stream == 2 || ni >= 4 * waves)) {
+          streamed = true;
+          hipLaunchKernelGGL((rba::k_pcgs_spmv_stream<S, MODE, MT>), dim3(std::min(ni, waves)), dim3(64),
+                             rba::kSpmvStreamSlots * rba::kSpmvStreamSlot, stream_, cols, vals, d_items_.get() + i0, ni, z, p0, p1, xvec,
+                             d_qmain_.get(), d_qpart_.get(), d_tpart_.get(), static_cast<const int*>(d_tdst_.get()),
+                             d_cg_.get(), part_rho, part_q, part_pq, q_tol, min_it, max_it, period, progress);
+        }
+      }
+      if (!streamed)
+        hipLaunchKernelGGL((rba::k_pcgs_spmv<S, MODE, MT, H>), dim3(ni), dim3(64), rba::spmv_lds_bytes<MT>(), stream_,
+                           cols, vals, d_items_.get() + i0, z, p0, p1, xvec, d_qmain_.get(), d_qpart_.get(),
+                           H ? d_tpart_.get() : static_cast<double*>(nullptr),
+                           H ? d_tdst_.get() : static_cast<const int*>(nullptr), d_cg_.get(), part_rho, part_q, part_pq, q_tol,
+                           min_it, max_it, period, progress);
       if (H && n_heavy_ > 0)
         hipLaunchKernelGGL((rba::k_pcgs_reduce_slots<S>), dim3((n_heavy_ + 3) / 4), dim3(256), 0, stream_, d_heavy_.get(),
                            n_heavy_, d_tpart_.get(), d_qpart_.get(), d_cg_.get(), MODE, period);
@@ -1380,6 +1403,8 @@ class Solver final : public rba_solver {
     }
     if (h_pinned_) (void)hipHostFree(h_pinned_);
     h_pinned_ = nullptr;
+    if (h_vec_stage_) (void)hipHostFree(h_vec_stage_);
+    h_vec_stage_ = nullptr;
     if (h_progress_) (void)hipHostFree(h_progress_);
     if (h_stamps_) (void)hipHostFree(h_stamps_);
     h_stamps_ = nullptr;
@@ -1750,6 +1775,12 @@ class Solver final : public rba_solver {
     const int end_slot = stamps_on() ? stamp_slot() : -1;
     unsigned long long* s_end = end_slot >= 0 ? h_stamps_ + end_slot : nullptr;
     const int blocks = int(std::min<int64_t>(kReduceBlocks, (n_obs_ + 255) / 256));
+    // the eight sums: one rank - straight into the pinned host page; more ranks - into `red`, all-reduced below, or, at
+    // the end of an iteration of rba_lm_step (lm_merge_end_), into the block that carries l_diff and the failure bits as
+    // well (one collective)
+    const bool direct = results_go_direct();
+    const bool merged = !direct && lm_merge_end_ && !side;
+    double* red = merged ? d_endred_.get() : part + size_t(kReduceBlocks) * 8;
     if (mixed_) {
       rba::Params<double> p64 = prm64_;
       p64.stamp = s_begin;
@@ -1759,12 +1790,15 @@ class Solver final : public rba_solver {
       ps.stamp = s_begin;
       hipLaunchKernelGGL((rba::k_compute_error<S>), dim3(blocks), dim3(256), 0, st, ps, n_obs_, part);
     }
-    double* red = part + size_t(kReduceBlocks) * 8;
-    const bool direct = results_go_direct();
     hipLaunchKernelGGL((rba::k_reduce_rows<8>), dim3(1), dim3(256), 0, st, part, int64_t(blocks), red,
                        direct ? h : static_cast<double*>(nullptr), static_cast<int*>(nullptr),
-                       static_cast<int*>(nullptr), 0, s_end);
-    if (!direct) {
+                       static_cast<int*>(nullptr), 0, s_end, static_cast<double*>(nullptr));
+    if (merged) {
+      all_reduce(d_endred_.get(), size_t(rba::kEndRed));
+      HIP_CHECK(hipMemcpyAsync(pinned_doubles(kPinEnd), d_endred_.get(), rba::kEndRed * sizeof(double), hipMemcpyDeviceToHost,
+                               stream_));
+      lm_end_merged_ = true;
+    } else if (!direct) {
       all_reduce(red, 8);
       HIP_CHECK(hipMemcpyAsync(h, red, 8 * sizeof(double), hipMemcpyDeviceToHost, stream_));
     }
@@ -1833,7 +1867,7 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_sc_jp_diag2<S>), dim3(n_cams_), dim3(256), 0, stream_, prm_);
     }
     if (!gram_pending_) all_reduce(d_jp_diag2_.get(), nvec_);
-    all_reduce(d_fail_.get(), 1, kNcclMax);
+    if (!lm_fuse_) all_reduce(d_fail_.get(), 1, kNcclMax);
     if (!gram_pending_)
       hipLaunchKernelGGL((rba::k_pose_scaling<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                          d_jp_diag2_.get(), d_pose_scaling_.get(), prm_.eps, nvec_);
@@ -1864,7 +1898,12 @@ class Solver final : public rba_solver {
     }
     HIP_CHECK(hipGetLastError());
     int* fail = pinned_int(kPinFailLin);
-    if (results_go_direct()) {
+    if (lm_fuse_) {
+      // rba_lm_step: nobody reads the word before the iteration's one synchronisation - it travels with the end of the
+      // solve (one rank: k_finish_increment) or with the sums that end the iteration (more ranks: rba::kEndRed; the
+      // ranks' bits are summed there instead of max-reduced here)
+      lin_flag_deferred_ = true;
+    } else if (results_go_direct()) {
       hipLaunchKernelGGL(rba::k_publish_flag, dim3(1), dim3(1), 0, stream_, d_fail_.get(), fail, 1);
     } else {
       HIP_CHECK(hipMemcpyAsync(fail, d_fail_.get(), sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -2443,23 +2482,32 @@ class Solver final : public rba_solver {
     if (inc_out) {
       hipLaunchKernelGGL((rba::k_negate<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_,
                          d_x_.get(), nvec_);
-      d_x_.download(static_cast<S*>(inc_out), nvec_, stream_);
+      d_x_.download(h_vec_stage_, nvec_, stream_);  // (pinned; copied to the caller's buffer after the synchronisation below)
     } else {
       // rba_lm_step: the increment stays on the device (apply(nullptr) reads d_inc_), the host gets its norm - and,
       // when nobody has read it yet, the final PCG state
+      // (+ D inc for the back-substitution and, inside rba_lm_step, the failure word of the linearisation: two launches
+      //  of ~5 us less)
+      const bool flag_here = lin_flag_deferred_ && results_go_direct();
       hipLaunchKernelGGL((rba::k_finish_increment<S>), dim3(1), dim3(1024), 0, stream_, d_x_.get(), d_inc_.get(),
                          nvec_, pinned_doubles(kPinInc), static_cast<const rba::CgState*>(d_cg_.get()),
                          pcg_state_pending_ ? reinterpret_cast<rba::CgState*>(h_pinned_)
-                                            : static_cast<rba::CgState*>(nullptr));
+                                            : static_cast<rba::CgState*>(nullptr),
+                         static_cast<const S*>(prm_.pose_scaling), sc_ ? static_cast<S*>(nullptr) : d_xs_.get(),
+                         flag_here ? d_fail_.get() : static_cast<int*>(nullptr),
+                         flag_here ? pinned_int(kPinFailLin) : static_cast<int*>(nullptr), 1);
+      inc_prescaled_ = !sc_;
+      if (flag_here) lin_flag_deferred_ = false;
     }
     time_end(&timings_.solve_reduced_system_time);
     solve_cg_ = cg;
     if (solve_defer_) return RBA_OK;  // rba_lm_step calls solve_collect() after its synchronisation
-    if (lm_async_) {  // the caller reads the increment, and the product timers below need their events completed
+    if (lm_async_ || inc_out) {  // the caller reads the increment, and the product timers below need their events completed
       stamp_close();
       sync();
       flush_timers();
     }
+    if (inc_out) std::memcpy(inc_out, h_vec_stage_, size_t(nvec_) * sizeof(S));
     solve_collect(cg_out);
     return RBA_OK;
   }
@@ -2498,8 +2546,23 @@ class Solver final : public rba_solver {
       // every rank must switch in the same iteration).
       float asm_ms = 0;
       HIP_CHECK(hipEventElapsedTime(&asm_ms, ev_asm0_, ev_asm1_));
-      int t = int(std::lround(double(asm_ms) / (hx_ms / timed)));
-      t = std::max(2, std::min(32, t));
+      // Break-even with BOTH products: an assembly pays once the iterations that follow it have
+      // saved its cost, asm / (t_matrix-free - t_assembled) of them. Rounds 2-5 divided by the matrix-free time alone -
+      // right for a banded matrix in the register files (7.7 us against 133 per iteration), wrong by an order of
+      // magnitude for a nearly dense one that streams from HBM (venice-1778+tail: 137 us against 143 - two assemblies of
+      // 4.5 GB each for 810 products that were 4 % cheaper). t_assembled: measured on this very solve where the stage
+      // timers run (its time less the assembly and the matrix-free products), else priced from the bytes of a product
+      // at the 3.8 TB/s the streaming SpMV reaches (the persistent kernel: 8 us).
+      const double t_mf = hx_ms / timed;
+      double t_as = pcg_last_was_persistent_ ? 0.008 : 0.007 + double(ex_nnz_) * 81 * 8 / 3.8e9;
+      if (last_as_products_ >= 8 && timings_.solve_reduced_system_time > 0) {
+        const double rest = timings_.solve_reduced_system_time * 1e3 - double(asm_ms) - double(last_mf_products_) * t_mf;
+        if (rest > 0) t_as = rest / double(last_as_products_);
+      }
+      const double be = t_mf > 1.02 * t_as ? double(asm_ms) / (t_mf - t_as) : 1e9;
+      int t = int(std::min(be, 1e6) + 0.5);
+      t = std::max(2, std::min(opt_.max_cg_it + 1, t));
+      measured_t_as_ms_ = t_as;
       if (comm_ || cb_fn_) {
         d_scratch_int_.upload(&t, 1, stream_);
         all_reduce(d_scratch_int_.get(), 1, kNcclMax);
@@ -2507,9 +2570,12 @@ class Solver final : public rba_solver {
         sync();
       }
       if (env_.verbose)
-        std::fprintf(stderr, "[rootba_hip] assembly %.3f ms, matrix-free product %.3f ms -> explicit_after = %d\n",
-                     double(asm_ms), hx_ms / timed, t);
+        std::fprintf(stderr, "[rootba_hip] assembly %.3f ms, matrix-free product %.3f ms, iteration on the assembled matrix %.4f ms "
+                     "-> explicit_after = %d\n", double(asm_ms), t_mf, measured_t_as_ms_, t);
       explicit_after_ = t;
+      // the early exit from the rental (a solve whose stopping quantity rises at iteration 4 is taken for a long one,
+      // 40+ iterations): only where 40 cheaper iterations pay for an assembly
+      early_switch_pays_ = t <= 40;
       asm_pending_ = false;
       asm_measured_ = true;
     }
@@ -2590,7 +2656,8 @@ class Solver final : public rba_solver {
         // `explicit_after_` (~12) products: eight products of 0.14 ms saved per long solve on venice. All ranks of a
         // sharded run see the same zeta (identical scalars by construction) and decide alike.
         bool tested = false, switch_now = false;
-        if (it == 5 && explicit_auto_ && ex_ready_ && !explicit_off_for_solve_ && !ex_valid_ && explicit_after_ >= it) {
+        if (it == 5 && explicit_auto_ && early_switch_pays_ && ex_ready_ && !explicit_off_for_solve_ && !ex_valid_ &&
+            explicit_after_ >= it) {
           direction(true);
           if (!(running = started(it))) break;
           tested = true;
@@ -2621,7 +2688,9 @@ class Solver final : public rba_solver {
         // many solves need two or three iterations: products 3 to 8 wait for the verdict of the test that precedes
         // them, later ones are queued ahead (launches behind the end of the solve are no-ops). The first two never
         // wait: the Q-model test cannot end a solve after one iteration (zeta = 1 * (Q_1 - 0) / Q_1 = 1 > eta).
-        if (it >= 3 && (it <= 8 || it % 4 == 0) && !(running = started(it))) {
+        // (more than one rank: every product is followed by a collective that all ranks enter whether the solve has ended
+        //  or not - no product is queued ahead of its verdict there)
+        if (it >= 3 && (it <= 8 || it % 4 == 0 || comm_ || cb_fn_) && !(running = started(it))) {
           operand_prescaled_ = false;
           break;
         }
@@ -2817,6 +2886,9 @@ class Solver final : public rba_solver {
       pcg_counters_.products_matrix_free += mf_it + mf_it / 10 + (pcg_used_explicit_ || sc_ ? 0 : series * mf_it);
       const int64_t as_products = as_it > 0 ? as_it + (n_it / 10 - mf_it / 10) + (it_switch > 1 ? 1 : 0) + series * as_it : 0;
       pcg_counters_.products_assembled += as_products;
+      last_mf_products_ = mf_it + mf_it / 10;
+      last_as_products_ = as_products;
+      pcg_last_was_persistent_ = pcg_last_persistent_;
       // (persistent kernel: the matrix is read ONCE per solve and multiplied out of the register files - these products
       //  move no matrix bytes; rba_byte_model.persistent_solve / .persistent_iteration price such a solve)
       if (pcg_last_persistent_) {
@@ -2833,7 +2905,11 @@ class Solver final : public rba_solver {
     use_device();
     if (!landmark_damping_valid_) run_stage2(S(0));
     time_begin();
-    if (inc) d_inc_.upload(static_cast<const S*>(inc), nvec_, stream_);  // (nullptr: left there by the solve of rba_lm_step)
+    if (inc) {  // (nullptr: left there by the solve of rba_lm_step)
+      sync();  // (the pinned stage is free: nothing queued reads it)
+      std::memcpy(h_vec_stage_, inc, size_t(nvec_) * sizeof(S));
+      d_inc_.upload(h_vec_stage_, nvec_, stream_);
+    }
     if (sc_) {
       hipLaunchKernelGGL((rba::k_sc_back_substitute<S>), dim3((n_lms_ + 255) / 256), dim3(256), 0, stream_,
                          scp_, d_inc_.get());
@@ -2841,7 +2917,8 @@ class Solver final : public rba_solver {
       // tiled landmarks (k <= 32, implicit-Q configuration): one lane-per-row pass; the rest: two passes
       int lm0 = 0;
       int64_t o0 = 0;
-      const S* xin = scaled_operand(d_inc_.get());  // D inc for the unscaled Jacobian rows
+      // D inc for the unscaled Jacobian rows (inside rba_lm_step the end of the solve has left it in d_xs_ already)
+      const S* xin = (inc_prescaled_ && !inc) ? d_xs_.get() : scaled_operand(d_inc_.get());
       if (n_tiles_ > 0) {
         {  // (evaluated once, ahead of the launch macro)
           const rba::Params<S> prm_st_ = prm_stamped();
@@ -2864,6 +2941,7 @@ class Solver final : public rba_solver {
           hipLaunchKernelGGL((rba::k_bs_landmark_big<S>), dim3(n_big_), dim3(256), 0, stream_, prm_, big_begin_);
       }
     }
+    inc_prescaled_ = false;
     const int blocks = std::min(kReduceBlocks, (n_lms_ + 255) / 256);
     hipLaunchKernelGGL((rba::k_sum_ldiff), dim3(blocks), dim3(256), 0, stream_,
                        d_lm_ldiff_.get(), n_lms_, d_partials_.get());
@@ -2873,11 +2951,19 @@ class Solver final : public rba_solver {
     if (results_go_direct()) {
       // l_diff and the failure word (bits 2: back-substitution, 4: block inversion of the solve) land in the pinned page
       hipLaunchKernelGGL((rba::k_reduce_rows<1>), dim3(1), dim3(256), 0, stream_, d_partials_.get(), int64_t(blocks),
-                         red, l_diff, d_fail_.get(), fail, 2 | 4, static_cast<unsigned long long*>(nullptr));
+                         red, l_diff, d_fail_.get(), fail, 2 | 4, static_cast<unsigned long long*>(nullptr),
+                         static_cast<double*>(nullptr));
+    } else if (lm_merge_end_) {
+      // rba_lm_step of a sharded run: l_diff and the failure bits (the deferred one of the linearisation included) join
+      // the cost sums of the trial point - ONE all-reduce ends the iteration (compute_error_enqueue)
+      hipLaunchKernelGGL((rba::k_reduce_rows<1>), dim3(1), dim3(256), 0, stream_, d_partials_.get(), int64_t(blocks),
+                         d_endred_.get() + 8, static_cast<double*>(nullptr), d_fail_.get(), static_cast<int*>(nullptr),
+                         1 | 2 | 4, static_cast<unsigned long long*>(nullptr), d_endred_.get() + 9);
+      lin_flag_deferred_ = false;
     } else {
       hipLaunchKernelGGL((rba::k_reduce_rows<1>), dim3(1), dim3(256), 0, stream_, d_partials_.get(), int64_t(blocks),
                          red, static_cast<double*>(nullptr), static_cast<int*>(nullptr), static_cast<int*>(nullptr), 0,
-                         static_cast<unsigned long long*>(nullptr));
+                         static_cast<unsigned long long*>(nullptr), static_cast<double*>(nullptr));
       all_reduce(red, 1);
       all_reduce(d_fail_.get(), 1, kNcclMax);
       HIP_CHECK(hipMemcpyAsync(l_diff, red, sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -2909,7 +2995,7 @@ class Solver final : public rba_solver {
       else {
         const rba::Params<S> prm_st_ = prm_stamped();
         hipLaunchKernelGGL((rba::k_update_cameras<S>), dim3((n_cams_ + 63) / 64), dim3(64), 0,
-                           stream_, prm_st_, d_inc_.get());
+                           stream_, prm_st_, d_inc_.get(), cams_backup_in_update_ ? d_cams_bak_.get() : static_cast<S*>(nullptr));
       }
       time_end(&timings_.update_cameras_time);
     }
@@ -2959,6 +3045,7 @@ class Solver final : public rba_solver {
     // keep the per-stage synchronisation they are read at.
     FlagScope step_scope(in_lm_step_, true);
     FlagScope async_scope(lm_async_, !sub_timing());
+    FlagScope fuse_scope(lm_fuse_, !sub_timing());
     auto finish = [&](bool keep_going) {
       if (lm_async_) {
         stamp_close();
@@ -3036,12 +3123,31 @@ class Solver final : public rba_solver {
     bool applied = false;
     join_side();  // (the cost evaluation of the current state has read it: from here on it changes)
     if (one_sync) {
-      backup();
-      apply(nullptr, &l_diff_d, true);
-      compute_error_enqueue(pinned_doubles(kPinCe1));
+      // BalProblem::backup() of the step (bal_bundle_adjustment.cpp:401): the landmarks by a copy, the cameras by the
+      // kernel that replaces them (k_update_cameras; mixed precision keeps its copies)
+      const bool fold_cams = lm_fuse_ && !mixed_;
+      if (!fold_cams)
+        backup();
+      else
+        HIP_CHECK(hipMemcpyAsync(d_lms_bak_.get(), d_lms_.get(), d_lms_.size() * sizeof(S), hipMemcpyDeviceToDevice, stream_));
+      {
+        FlagScope fold(cams_backup_in_update_, fold_cams);
+        FlagScope merge(lm_merge_end_, lm_fuse_ && !results_go_direct());
+        lm_end_merged_ = false;
+        apply(nullptr, &l_diff_d, true);
+        compute_error_enqueue(pinned_doubles(kPinCe1));
+      }
       stamp_close();
       sync();
       flush_timers();
+      if (lm_end_merged_) {
+        // sharded run: the iteration's sums arrived in one block (rba::kEndRed) - filed where the code below reads them
+        const double* e = pinned_doubles(kPinEnd);
+        std::memcpy(pinned_doubles(kPinCe1), e, 8 * sizeof(double));
+        *pinned_doubles(kPinLdiff) = e[8];
+        *pinned_int(kPinFailLin) = e[9] > 0 ? 1 : 0;
+        *pinned_int(kPinFailApply) = (e[10] > 0 ? 2 : 0) | (e[11] > 0 ? 4 : 0);
+      }
       solve_collect(&cg);
       applied = true;
     }
@@ -3329,7 +3435,7 @@ class Solver final : public rba_solver {
   void use_device() { HIP_CHECK(hipSetDevice(device_)); }
   // result slots in the pinned page h_pinned_ (the PCG state copy lives at offset 0)
   static constexpr size_t kPinCe0 = 1024, kPinCe1 = 1024 + 64, kPinLdiff = 1024 + 128, kPinFailLin = 1024 + 136,
-                          kPinFailApply = 1024 + 140, kPinCheck = 1024 + 192, kPinInc = 1024 + 256;
+                          kPinFailApply = 1024 + 140, kPinCheck = 1024 + 192, kPinInc = 1024 + 256, kPinEnd = 1024 + 320;
   double* pinned_doubles(size_t off) { return reinterpret_cast<double*>(h_pinned_ + off); }
   int* pinned_int(size_t off) { return reinterpret_cast<int*>(h_pinned_ + off); }
   void sync() {
@@ -3524,6 +3630,9 @@ class Solver final : public rba_solver {
     int sort_by_camera = -1;           // RBA_SORT_BY_CAMERA=0/1: override the automatic choice
     int verify_assembled = 0;          // RBA_VERIFY_ASSEMBLED=1: one-product check of assembled-operator solves (diagnostic)
     double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
+    int spmv_stream = 1;               // RBA_SPMV_STREAM: 0 = one wavefront per item always, 1 = streaming SpMV for matrices of
+                                       // >= 4 items per resident wavefront, 2 = always (tests)
+    int spmv_stream_waves_per_cu = 0;  // RBA_SPMV_STREAM_WAVES: wavefronts per compute unit of the streaming SpMV (0 = 3; -1: two in all - tests)
     int pcg_persistent = 1;            // RBA_PCG_PERSISTENT=0: PCG on the assembled matrix always in two launches per
                                        // iteration (kernels_pcg.hpp; the test of the two forms)
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
@@ -3563,6 +3672,8 @@ class Solver final : public rba_solver {
     env_.stage_timers = geti("RBA_STAGE_TIMERS", 1);
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     env_.pcg_persistent = geti("RBA_PCG_PERSISTENT", 1);
+    env_.spmv_stream = geti("RBA_SPMV_STREAM", 1);
+    env_.spmv_stream_waves_per_cu = geti("RBA_SPMV_STREAM_WAVES", 0);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }
 
@@ -3576,6 +3687,7 @@ class Solver final : public rba_solver {
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   bool side_pending_ = false;
   DevBuf<double> d_partials_side_;
+  DevBuf<double> d_endred_;  // rba_lm_step of a sharded run: everything the end of an iteration all-reduces, in one piece (rba::kEndRed)
   std::vector<int> perm_;
   int cls_begin_[kNumClasses], cls_end_[kNumClasses];
   int big_begin_ = 0, n_big_ = 0, big_kmax_ = 0;
@@ -3612,6 +3724,9 @@ class Solver final : public rba_solver {
   DevBuf<double> d_lm_ldiff_, d_partials_, d_pcg_partials_;
   DevBuf<rba::CgState> d_cg_;
   char* h_pinned_ = nullptr;
+  S* h_vec_stage_ = nullptr;  // pinned staging of the camera-sized vectors that cross the C ABI per LM iteration (the
+                              // increment out of rba_solve, into rba_apply): a copy to / from pageable memory is staged
+                              // and synchronised by the runtime
   hipEvent_t timer_t0_ = nullptr;
   std::vector<hipEvent_t> timer_pool_;
   size_t timer_pool_used_ = 0;
@@ -3621,6 +3736,13 @@ class Solver final : public rba_solver {
   int stamp_n_ = 0, stamp_pending_ = -1, stamp_begin_ = -1, stamp_side_slot_ = -1;
   double stamp_hz_ = 1e8;
   std::vector<PendingStamp> pending_stamps_;
+  // rba_lm_step (staged execution): launches folded into their neighbours (round 6)
+  bool lm_fuse_ = false;              // the step is running in that mode
+  bool lin_flag_deferred_ = false;    // the failure word of the linearisation has not been published yet
+  bool inc_prescaled_ = false;        // d_xs_ holds D inc (written by the end of the solve)
+  bool cams_backup_in_update_ = false;  // k_update_cameras leaves the cameras it replaces in the backup buffer
+  bool lm_merge_end_ = false;         // sharded run: l_diff, failure bits and the trial cost sums in ONE all-reduce
+  bool lm_end_merged_ = false;        // ... and that block has been queued for the host
   bool in_lm_step_ = false;  // rba_lm_step is running: apply / restore are ITS calls (the cached cost stays valid)
   bool lm_async_ = false;  // inside rba_lm_step: results and timers are collected at the iteration's own sync points
   std::vector<hipEvent_t> hx_events_;
@@ -3649,6 +3771,10 @@ class Solver final : public rba_solver {
   int explicit_after_ = 0;  // matrix-free products before a solve switches to S x; 0 = never
   bool ex_ready_ = false, ex_valid_ = false, ex_active_ = false;
   bool explicit_auto_ = false, asm_measured_ = false, asm_pending_ = false;
+  bool early_switch_pays_ = true;        // (until the break-even has been measured)
+  bool pcg_last_was_persistent_ = false; // the last solve on the assembled matrix ran as the persistent kernel
+  int64_t last_mf_products_ = 0, last_as_products_ = 0;  // products of the last solve on either operator
+  double measured_t_as_ms_ = 0;
   hipEvent_t ev_asm0_ = nullptr, ev_asm1_ = nullptr;
   DevBuf<int> d_scratch_int_;
   int ex_nnz_ = 0, ex_n_upper_ = 0;

@@ -38,7 +38,18 @@ def main():
     t_it = sum(r.iteration_time for r in its)
     out["drop_in"] = {"lm_iterations": len(its), "wall_s_incl_rba_create": wall, "sum_iteration_time_s": t_it,
                       "it_per_s": len(its) / t_it, "cg_iterations": sum(r.cg_iterations for r in its),
-                      "final_cost": [r.cost for r in rows if r.step_is_successful][-1]}
+                      "final_cost": [r.cost for r in rows if r.step_is_successful][-1],
+                      # where the reference's loop spends an iteration: the four Linearizor calls as its IterationSummary
+                      # timed them (wall time around each call of the binding, synchronisations and state protocol
+                      # included), and what is left - the reference's own host code (BalProblem::backup() walks 1 M
+                      # landmark structs, bal_problem.cpp:590-598; logging)
+                      "ms_per_iteration": {"total": 1e3 * t_it / len(its),
+                                           "compute_error": 1e3 * sum(r.residual_time for r in its) / len(its),
+                                           "linearize": 1e3 * sum(r.stage1_time for r in its) / len(its),
+                                           "solve": 1e3 * sum(r.pcg_time for r in its) / len(its),
+                                           "apply": 1e3 * sum(r.backsub_time for r in its) / len(its)}}
+    m = out["drop_in"]["ms_per_iteration"]
+    m["reference_host_code"] = m["total"] - m["compute_error"] - m["linearize"] - m["solve"] - m["apply"]
     # the library's own loop (state resident, no Linearizor interface in between)
     g = LinearizorHIP(prob, np.float32, L.default_options(**kw))
     g.lm_begin()

@@ -142,9 +142,14 @@ def test_config3_trafalgar257_f32_full_lm_run(monkeypatch):
     lo0, _ = o0.optimize_lm()
     for a, b in zip(l0[1:], lo0[1:]):
         assert a.step_is_successful == b.step_is_successful == 1
-        assert abs(a.cg_iterations - b.cg_iterations) <= max(1, b.cg_iterations // 50)
+        # (solves of hundreds of iterations: the float atomics of the matrix-free product make two GPU runs differ - the
+        #  last solve of this run stops at 270 ... 272 iterations in three runs of four and at 250 - 252 in the fourth
+        #  (profiles/r4_trafalgar_default_lockstep_runs.log, gpurun_out of round 6: 252 against the oracle's 271); 2 % up
+        #  to 60 iterations, 10 % beyond, as for the lock-step runs below)
+        tol = b.cg_iterations // 50 if b.cg_iterations <= 60 else b.cg_iterations // 10
+        assert abs(a.cg_iterations - b.cg_iterations) <= max(1, tol)
         assert abs(a.cost - b.cost) <= 4e-6 * b.cost
-        assert abs(a.inc_norm - b.inc_norm) <= 1e-2 * b.inc_norm
+        assert abs(a.inc_norm - b.inc_norm) <= (1e-2 if b.cg_iterations <= 60 else 5e-2) * b.inc_norm
 
 
 def test_config4_venice1778_f32_lockstep_four_iterations():
@@ -289,7 +294,7 @@ def test_config4_venice1778_f32_increment_vectors():
 TRACKED_FIXTURES = {"venice-1778-it6": ("lockstep_venice-1778_f32_it6.npz",
                                         "799ec7b158a447787ec9ba052125f806de8a41e17151dbe939e4c331b46c9c8d"),
                     # the CPU float64 referee of the final-13682 lock-step (scripts/make_referee_fixture.py)
-                    "final-13682-referee64": ("referee64_final-13682.npz", "e016a2cd3e980de9a32c2fab7a843fccfdf37c8b4dbccd813949946a5debc633")}
+                    "final-13682-referee64": ("referee64_final-13682.npz", "2541ae685743f409c452c39f35c4367e76afca1ec513f61840978ed03a4ab870")}
 
 
 def _fixture(name):
@@ -361,8 +366,19 @@ def _fixture_rows(name, dts="float32", tag="", **extra):
             # solver on the CPU (solver_type 2, scripts/make_referee_fixture.py; tests/test_oracle_referee.py holds it
             # to the other two oracle solvers where they fit) - independent of the HIP library (rounds 3-4 used a float64
             # run of the library itself here).
-            ref64 = _fixture(f"{name}-referee64")[f"inc64_{it}"]
+            referee = _fixture(f"{name}-referee64")
+            ref64 = referee[f"inc64_{it}"]
             row["referee"] = "cpu float64, matrix-free Schur complement"
+            # the float64 cost of the state: what both float32 costs are held to (round 6)
+            c64 = float(referee[f"cost64_{it}"])
+            row["cost64"] = c64
+            row["cost_gpu_vs_f64"] = abs(row["cost_gpu"] - c64) / c64
+            row["cost_oracle32_vs_f64"] = abs(row["cost_oracle32"] - c64) / c64
+            # where the error of either float32 increment sits: share of |inc - inc64|^2 in its three worst cameras
+            for key, v in (("gpu", same), ("oracle32", fx[f"inc32_{it}"])):
+                d = ((np.asarray(v, np.float64) - ref64).reshape(-1, 9) ** 2).sum(axis=1)
+                j = np.argsort(-d)[:3]
+                row[f"{key}_err_top_cameras"] = [[int(c), round(float(d[c] / d.sum()), 4)] for c in j]
         row["gpu_vs_f64"] = rel(same, ref64)
         row["oracle32_vs_f64"] = rel(fx[f"inc32_{it}"], ref64)
         row["own_vs_f64"] = rel(ig, ref64)  # the increment the solve returned (its own stopping index)
@@ -413,6 +429,8 @@ def test_config5_final13682_f32_lockstep_iterations_3_to_7(monkeypatch):
     iterations 3..7 - the range where the round-3 GPU run left the oracle's trajectory (13 instead of 49 PCG iterations at
     iteration 4, then a rejected step with cost 3.6e14) - from the oracle's states (fixture; the float64 oracle does not
     fit the host: increments are compared with the float32 oracle's iterate of the same index only).
+    Round 6: the fixture is a self-consistent LM run of the oracle driven by scripts/make_lockstep_fixture.py (PCG counts
+    22 / 50 / 5 / 3 / 137, every step accepted); the paragraph below is about the fixture of rounds 4-5.
 
     What the fixture itself shows (profiles/r4_final13682_oracle_f32_lm_and_replay.log): the float32 oracle's PCG counts
     at this size are NOT reproducible between two runs of the oracle - its LM run takes 22 / 49 / 5 / 3 / 2 iterations
@@ -434,23 +452,22 @@ def test_config5_final13682_f32_lockstep_iterations_3_to_7(monkeypatch):
             # Schur-complement solver in float64 (tests/golden/referee64_final-13682.npz; it reproduces the numbers the
             # float64 run of the HIP library gave as referee in round 4 to three digits on iterations 3 - 6 and gives
             # 6.2e-3 instead of 8.8e-3 for the float32 oracle's 137-iteration solve) -, iterate of the oracle's index
-            if r["it"] != 6:
-                # (iteration 6: the replay's own step 5 - 5 PCG iterations at lambda 1.2e-6 - sends a few ill-conditioned
-                #  landmarks to |p| ~ 7e4 and RAISES the cost, 5.72e6 -> 6.61e6: the LM loop would reject it, the
-                #  fixed-schedule replay goes on from there. At that state float32 does not resolve the cost: the float64
-                #  cost (oracle, CPU) is 6 615 231.8, the float32 oracle's 6 607 272.8 - 1.2e-3 low - and the GPU's
-                #  6 617 444.1 - 3.3e-4 high, 1.5e-3 from the float32 oracle's (iterations 5 and 7: 2.7e-10 and 1.6e-4 for the oracle, 1e-8 and
-                #  1.5e-6 between the two float32 costs). Re-examined with the independent referee, as VERDICT round 4
-                #  asked: the GPU's 3-iteration increment is 1.41e-2 from the float64 iterate, the float32 oracle's 9e-4
-                #  - the same two numbers the HIP referee gave. What separates the two float32 results is the
-                #  summation order inside the Householder QR of a few nearly rank-deficient landmark blocks: with the
-                #  two-kernel form of stage 1 (RBA_S1_FUSED=0, the oracle's order) the GPU is 6.1e-3 from float64 and its
-                #  model cost change agrees with the oracle's to 3.6e-7 (fused form: 9.6e-3) -
-                #  profiles/r5_final13682_iteration6_stage1_forms.txt; at iterations 3 and 7 the order is the other way
-                #  round or immaterial (fused 4.9e-3 / 6.5e-3, two-kernel 1.0e-3 / 5.6e-3, oracle 8.5e-3 / 6.2e-3).
-                #  Counts and termination only.)
-                assert r["gpu_vs_f64"] <= 1.5 * r["oracle32_vs_f64"] + 2e-4, r
-                assert r["cost_rel"] < 3e-6 and r["l_diff_rel"] < 5e-3, r
+            # EVERY iteration since round 6. What the exempted state was, by measurement
+            # (profiles/r6_final13682_iteration6_diagnosis.txt): (a) rounds 4-5 replayed the lambda schedule of a SEPARATE
+            # oracle LM run and went on from a step the LM loop would have rejected; scripts/make_lockstep_fixture.py now
+            # drives a self-consistent LM run, every stored state is one the loop visits. (b) The state of iteration 6
+            # STILL separated the two float32 results (GPU 8.4e-3, oracle 1.1e-3 from float64; costs 3e-5 apart): step 5
+            # moves two 2-observation landmarks onto a camera plane (depth +-0.008 at |p_w| = 126, residuals of thousands
+            # of pixels). p_c = R p_w + t in float arithmetic carries an absolute error of 1e-7 |p_w| ~ 1e-5 whatever the
+            # depth: those two landmarks' rows are wrong by 1e-3, they are 2.4e-5 of the float32 oracle's cost error and
+            # 28 % + 4 % of its increment error sits in their two cameras. Not the summation order of the QR (ensemble of
+            # 12288 nearly rank-deficient blocks, tests/test_gpu_qr_accuracy.py: the fused order is not worse). Fixed
+            # where it arises: the library evaluates p_c in double from the float state (device_utils.hpp,
+            # camera_frame_point) - so at such a state it is CLOSER to float64 than the reference's float32 arithmetic,
+            # and both float32 costs are held to the float64 cost of the state, not to each other.
+            assert r["gpu_vs_f64"] <= 1.5 * r["oracle32_vs_f64"] + 2e-4, r
+            assert r["cost_gpu_vs_f64"] <= max(3e-6, 1.5 * r["cost_oracle32_vs_f64"]), r
+            assert r["l_diff_rel"] < 5e-3, r
 
 
 def test_config5_mixed_precision_with_power_series_at_trafalgar_size():

@@ -715,6 +715,46 @@ def test_explicit_reduced_matrix_is_the_same_operator(small_problem, mixed_k_pro
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("which", ["small", "small-heavy-rows", "mixed", "ladybug"])
+def test_streaming_spmv_is_the_item_spmv(small_problem, mixed_k_problem, ladybug_far, dtype, which, monkeypatch):
+    """The product with the assembled half-storage matrix by persistent wavefronts that receive their chunks by LDS-DMA
+    (k_pcgs_spmv_stream, RBA_SPMV_STREAM=2: forced; by default only matrices of >= 4 items per resident wavefront take
+    it) against one wavefront per item (k_pcgs_spmv, RBA_SPMV_STREAM=0): same arithmetic in the same order per item.
+    Plain products S x (MODE 2) and whole solves in two launches per iteration (MODE 0 / 1, crossing the residual
+    refresh). Bitwise when two handles of the SAME form agree bitwise (the assembly sums a block's pairs with LDS
+    atomics: its bits may differ between handles), to rounding of the double matrix otherwise. RBA_SPMV_STREAM_WAVES=1
+    with few compute units in use makes every wavefront walk several items (the pipeline's steady state)."""
+    if which == "small-heavy-rows":
+        monkeypatch.setenv("RBA_HALF_LOWER_MAX", "3")
+        which = "small"
+    prob = {"small": small_problem, "mixed": mixed_k_problem, "ladybug": ladybug_far}[which]
+    monkeypatch.setenv("RBA_PCG_PERSISTENT", "0")
+    monkeypatch.setenv("RBA_DETERMINISTIC", "1")
+    rng = np.random.default_rng(5)
+    xs = [rng.uniform(-1, 1, 9 * prob.n_cams).astype(dtype) for _ in range(2)]
+    out = {}
+    for tag, mode, waves in (("item", "0", "0"), ("item-again", "0", "0"), ("stream", "2", "0"), ("stream-few", "2", "-1")):
+        monkeypatch.setenv("RBA_SPMV_STREAM", mode)
+        monkeypatch.setenv("RBA_SPMV_STREAM_WAVES", waves)
+        g, _ = _pair(prob, dtype, explicit_after=1, eta=1e-4, max_cg_it=40)
+        assert g.linearize() == 0
+        g.stage2(1e-5)
+        ys = [g.right_multiply_explicit(x) for x in xs]
+        inc, cg = g.solve(1e-5)
+        assert g.pcg_counters()["solves_persistent"] == 0
+        out[tag] = (ys, inc, cg.num_iterations, cg.termination_type)
+    same_bits = all(np.array_equal(a, b) for a, b in zip(out["item"][0], out["item-again"][0])) and \
+        np.array_equal(out["item"][1], out["item-again"][1])
+    for tag in ("stream", "stream-few"):
+        for a, b in zip(out["item"][0], out[tag][0]):
+            assert np.array_equal(a, b) if same_bits else rel_err(a, b) < (1e-6 if dtype == np.float32 else 1e-13), tag
+        assert out[tag][2:] == out["item"][2:], (tag, out[tag][2:], out["item"][2:])
+        assert np.array_equal(out[tag][1], out["item"][1]) if same_bits else \
+            rel_err(out[tag][1], out["item"][1]) < (1e-3 if dtype == np.float32 else 1e-9), tag
+    assert out["item"][2] > 10  # (the residual refresh ran)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_explicit_switch_inside_pcg(ladybug_far, dtype):
     """Switching to S x after 1 / 6 / never matrix-free products gives the same PCG solution
     and the same LM run (tolerances of the other trajectory tests)."""

@@ -288,3 +288,35 @@ def test_sharded_handle_fails_instead_of_hanging_when_one_rank_throws(monkeypatc
     with pytest.raises(RuntimeError, match="broken"):
         s.compute_error()
     s.close()
+
+
+@pytest.mark.timeout(300)
+def test_collectives_per_lm_iteration_of_a_sharded_run():
+    """a sharded LM iteration enters ONE collective per reduction the reference performs over
+    landmarks (linearization_qr.hpp:677-683 Jp_diag2, :770-775 b + block diagonal, :406-429 one per product) plus ONE for
+    everything the end of the iteration hands to the host - the eight cost sums of the trial point, l_diff and the
+    failure bits of linearisation / back-substitution / block inversion travel in one block (rba::kEndRed). A floor
+    iteration (two PCG iterations) is 5 collectives (<= 8 asked; rounds 1-5: 8 + the flag reductions)."""
+    import torch  # noqa: F401
+    from rootba_amd import _lib as L
+    from rootba_amd import problem as P
+    from rootba_amd.linearizor import LinearizorHIP
+    prob = P.preprocess(P.named_synthetic("ladybug-49"), translation_sigma=0.5, point_sigma=0.5)
+    s = LinearizorHIP(prob, np.float32, L.default_options(robust_norm=1, max_num_iterations=6, function_tolerance=0.0,
+                                                         explicit_after=0), devices=[0, 0])
+    s.lm_begin()
+    s.lm_step()
+    calls = s.comm_stats()["calls"]
+    seen = 0
+    more = True
+    while more:
+        row, more = s.lm_step()
+        now = s.comm_stats()["calls"]
+        products = row.cg_iterations + row.cg_iterations // 10
+        # Jp_diag2 (only when the step linearises: after an accepted one), [b | blocks], the products, the end
+        assert now - calls <= 3 + products, (row.iteration, row.cg_iterations, now - calls)
+        assert now - calls >= 2 + products
+        calls = now
+        seen += 1
+    assert seen >= 4
+    s.close()
