@@ -36,7 +36,6 @@
 #pragma once
 
 #include "kernels_sc.hpp"
-#include "pg_record_io.hpp"
 
 namespace rba {
 
@@ -132,6 +131,13 @@ struct ChunkStage {
     //  the last vector, the store below is predicated)
 #pragma unroll
     for (int u = 0; u < kSpmvPass; ++u) tmp[u] = src[min(v0 + u * 64 + lane, nvec - 1)];
+  }
+  // every piece, also the lanes past the chunk's end (into the slack of a kSpmvPass KiB slot): straight-line code - the
+  // streaming kernel's two register buffers are told apart by the compiler's wait counts, which are exact only there
+  __device__ __forceinline__ void store_all(int lane, const V tmp[kSpmvPass], S* lds) const {
+    V* dst = reinterpret_cast<V*>(lds);
+#pragma unroll
+    for (int u = 0; u < kSpmvPass; ++u) dst[u * 64 + lane] = tmp[u];
   }
   __device__ __forceinline__ void store(int v0, int lane, const V tmp[kSpmvPass], S* lds) const {
     V* dst = reinterpret_cast<V*>(lds);
@@ -371,40 +377,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
 
 // ---------------------------------------------------------------------------------------------------------------
 // The same product as a STREAM (round 6): half storage, one chunk per item, PERSISTENT
-// single-wavefront workgroups that walk the items w, w + W, w + 2 W, ... with the matrix arriving by LDS-DMA.
+// single-wavefront workgroups - one per SIMD, the whole 512-entry register file each - that walk the items
+// w, w + W, w + 2 W, ... with TWO chunks in flight per wavefront at all times.
 //
-// k_pcgs_spmv above is one short-lived wavefront per item: item descriptor -> (column indices | matrix chunk through
-// 84 staging registers) -> operand gather -> multiply -> exit, i.e. three dependent memory round trips plus the launch
-// of a workgroup around 21.5 KB of matrix, with the chunk in flight for one of the three. That is the 3.8 TB/s the
-// kernel streams a nearly dense matrix at (524 MB in 137 us on venice-1778+tail, 455 MB in ~130 us on final-13682:
-// VERDICT round 5, weak 10). It does not matter for a banded matrix (venice: 36 MB, one wave of workgroups, and long
-// solves run in the register files anyway); it is the whole iteration for a matrix that does not fit them.
-// Here a wavefront stays, and every one of its loads is requested a full iteration before its result is needed:
-// while it multiplies chunk k out of one half of its LDS ring,
-//   * chunk k + 1 is on its way into the other half - `global_load_lds_dwordx4`, 21 x 1 KiB per chunk, no staging
-//     registers (a first form of this kernel kept the next chunk in 84 registers on top of the multiply's ~130 and
-//     spilled 220-436 bytes of scratch at 256);
-//   * the operand entries of chunk k + 1 are being gathered (its column indices arrived during chunk k - 1);
-//   * the column indices of chunk k + 2 and the descriptor of chunk k + 3 are being read.
-// One `s_waitcnt vmcnt(0)` per chunk, behind the multiply. Same arithmetic, same summation order per item as
-// k_pcgs_spmv: bit-identical products (tests/test_gpu_parity.py::test_streaming_spmv_is_the_item_spmv).
-constexpr int kSpmvStreamSlot = kSpmvPass * 1024;  // bytes of one ring slot: the 21 DMA pieces of a chunk
-constexpr int kSpmvStreamSlots = 2;
-static_assert(spmv_lds_bytes<double>() <= size_t(kSpmvStreamSlot), "a ring slot holds a chunk");
-
-// chunk [81 slot0, 81 (slot0 + nb)) of the matrix -> ring slot `buf` (same 16-byte phase as ChunkStage; surplus lanes
-// of the last piece re-read the last vector into the slack of the slot)
-template <class MT>
-__device__ __forceinline__ int spmv_dma_chunk(const MT* __restrict__ vals, int slot0, int nb, int lane, char* buf) {
-  ChunkStage<MT> cs;
-  cs.setup(vals, slot0, nb);
-  const int nvec = __builtin_amdgcn_readfirstlane(cs.nvec);
+// k_pcgs_spmv above is one short-lived wavefront per item: item descriptor -> (column indices | matrix chunk into 84
+// staging registers) -> operand gather -> multiply -> exit, i.e. three dependent memory round trips plus the launch of a
+// workgroup around 21.5 KB of matrix, with the chunk in flight for one of the three: seven wavefronts per compute unit
+// (the staging buffer) hold at most 150 KB in flight and on average about half of it - 4.5 TB/s on a nearly dense matrix
+// (424 MB in 94 us on venice-1778+tail, profiles/r6e_*). It does not matter for a banded matrix (venice: 36 MB, one wave
+// of workgroups, and long solves run in the register files anyway); it is the whole iteration for one that does not fit.
+// What bounds such a stream is the number of bytes in flight, and the largest memory of a compute unit is its register
+// file (512 KB; LDS: 160 KB). Measured first, and dropped: a two-slot LDS ring filled by LDS-DMA (global_load_lds_dwordx4,
+// no staging registers) with one wait per chunk - one chunk in flight per wavefront, three wavefronts per unit (43 KB
+// of LDS each): 119 us, SLOWER than the item kernel (profiles/r6e_tail_kernel_stats_stream_lds_dma.csv); hipcc waits for
+// ALL outstanding memory operations while a DMA is in flight, so a deeper DMA ring needs every other load in assembly too.
+// Here: chunks k + 1 and k + 2 are in flight in two register buffers (2 x 84) while chunk k is multiplied out of the
+// wavefront's LDS slot; the operand entries of chunk k + 1 are gathered, the column indices of chunk k + 3 and the
+// descriptor of chunk k + 4 read, one iteration before they are needed, and requested BEFORE the matrix loads of the
+// same iteration (loads return in order: what the next multiply waits for must not queue behind a chunk that is needed
+// two iterations later). Same arithmetic, same summation order per item as k_pcgs_spmv: bit-identical products
+// (tests/test_gpu_parity.py::test_streaming_spmv_is_the_item_spmv).
+// the nine entries of a camera in few memory operations (4-byte aligned 12- / 16-byte loads)
+__device__ __forceinline__ void load_nine(const float* __restrict__ p, float (&v)[9]) {
+  typedef float f3 __attribute__((ext_vector_type(3), aligned(4)));
 #pragma unroll
-  for (int u = 0; u < kSpmvPass; ++u) {
-    if (u * 64 < nvec)  // (wave-uniform)
-      lds_dma16(cs.src + min(u * 64 + lane, nvec - 1), buf + u * 1024);
+  for (int u = 0; u < 3; ++u) {
+    const f3 t = *reinterpret_cast<const f3*>(p + 3 * u);
+    v[3 * u] = t.x;
+    v[3 * u + 1] = t.y;
+    v[3 * u + 2] = t.z;
   }
-  return cs.off;
+}
+__device__ __forceinline__ void load_nine(const double* __restrict__ p, double (&v)[9]) {
+  typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const d2 t = *reinterpret_cast<const d2*>(p + 2 * u);
+    v[2 * u] = t.x;
+    v[2 * u + 1] = t.y;
+  }
+  v[8] = p[8];
 }
 
 template <class S, int MODE, class MT>
@@ -414,7 +426,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     S* __restrict__ qextra, double* __restrict__ tpart, const int* __restrict__ tdst, CgState* st,
     const double* __restrict__ part_rho, const double* __restrict__ part_q, double* __restrict__ part_pq,
     double q_tolerance, int min_it, int max_it, int period, int* host_progress) {
+  using V = typename Vec16<MT>::type;
   extern __shared__ __attribute__((aligned(16))) char smem_pcgs[];
+  MT* lds = reinterpret_cast<MT*>(smem_pcgs);
   const int lane = threadIdx.x, W = int(gridDim.x);
   constexpr int CB = spmv_chunk_blocks<MT>();
   // ---- prologue: the decisions of k_pcgs_spmv, by every wavefront alike ---------------------------------------------
@@ -427,10 +441,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const double q_prev = st->q_hist[(it + 1) & 1], rho_prev = st->rho_hist[(it + 1) & 1];
   const S lambda = (MODE == 2 && q_tolerance >= 0.0) ? S(q_tolerance) : S(st->lambda);
   int k = int(blockIdx.x);
-  // (descriptors of the first three items: independent of the decisions, requested before them)
-  SpmvItem i0 = items[min(k, n_items - 1)];
-  SpmvItem i1 = items[min(k + W, n_items - 1)];
-  SpmvItem i2 = items[min(k + 2 * W, n_items - 1)];
+  // (descriptors of the first four items: independent of the decisions, requested before them. As four-integer vectors
+  //  {row, slot0, slot1, extra} in registers: a SpmvItem selected between two sources is a stack object, and a scratch
+  //  load in the loop is a wait for EVERYTHING in flight)
+  static_assert(sizeof(SpmvItem) == sizeof(int4), "descriptor = one 16-byte load");
+  const int4* __restrict__ item_vec = reinterpret_cast<const int4*>(items);
+  int4 i0 = item_vec[min(k, n_items - 1)], i1 = item_vec[min(k + W, n_items - 1)];
+  int4 i2 = item_vec[min(k + 2 * W, n_items - 1)], i3 = item_vec[min(k + 3 * W, n_items - 1)];
   int stop = done, term = 0, res_it = it, own_stop = 0;
   double beta = 0.0, rho = 0.0, q1 = 0.0;
   if (MODE == 0) {
@@ -491,48 +508,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const S* __restrict__ v0 = MODE == 0 ? z : xvec;
   const S bs = S(beta);
   const int lc = min(lane, 8);
-  // ---- fill: chunk k on its way into slot 0, its operand into registers; column indices of chunk k + W ------------
-  int nb = min(CB, i0.slot1 - i0.slot0);
-  int off = spmv_dma_chunk<MT>(vals, i0.slot0, nb, lane, smem_pcgs);
-  int col = cols[i0.slot0 + min(lane, nb - 1)], td = tdst[i0.slot0 + min(lane, nb - 1)];
-  int nb1 = min(CB, i1.slot1 - i1.slot0);
-  int col1 = cols[i1.slot0 + min(lane, nb1 - 1)], td1 = tdst[i1.slot0 + min(lane, nb1 - 1)];
+  auto blocks_of = [&](const int4& i) { return min(CB, i.z - i.y); };
+  // ---- fill: column indices of chunks k, k + W, k + 2 W; operand of chunk k; chunks k and k + W on their way ---------
+  int nb0 = blocks_of(i0), nb1 = blocks_of(i1), nb2 = blocks_of(i2);
+  int c0 = cols[i0.y + min(lane, nb0 - 1)], t0 = tdst[i0.y + min(lane, nb0 - 1)];
+  int c1 = cols[i1.y + min(lane, nb1 - 1)], t1 = tdst[i1.y + min(lane, nb1 - 1)];
+  int c2 = cols[i2.y + min(lane, nb2 - 1)], t2 = tdst[i2.y + min(lane, nb2 - 1)];
   S xv[9], xp[9];
+  load_nine(v0 + 9 * c0, xv);
+  if (comb) {
+    load_nine(p_old + 9 * c0, xp);
+  } else {
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    xv[t] = v0[9 * col + t];
-    xp[t] = comb ? p_old[9 * col + t] : S(0);
+    for (int t = 0; t < 9; ++t) xp[t] = S(0);
   }
-  S zc = v0[9 * i0.row + lc], pcold = comb ? p_old[9 * i0.row + lc] : S(0);
-  vmem_wait_all();
-  int cur = 0;
-  for (;;) {
-    const bool has_next = k + W < n_items;
-    // ---- everything of the NEXT chunks that can be requested now ----------------------------------------------------
-    int off1 = 0;
-    S xv1[9], xp1[9], zc1 = S(0), pcold1 = S(0);
-    SpmvItem i3 = i2;
-    int nb2 = 1, col2 = 0, td2 = -1;
-    if (has_next) {  // (wave-uniform)
-      off1 = spmv_dma_chunk<MT>(vals, i1.slot0, nb1, lane, smem_pcgs + (cur ^ 1) * kSpmvStreamSlot);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        xv1[t] = v0[9 * col1 + t];
-        xp1[t] = comb ? p_old[9 * col1 + t] : S(0);
-      }
-      zc1 = v0[9 * i1.row + lc];
-      pcold1 = comb ? p_old[9 * i1.row + lc] : S(0);
-      nb2 = min(CB, i2.slot1 - i2.slot0);
-      col2 = cols[i2.slot0 + min(lane, nb2 - 1)];
-      td2 = tdst[i2.slot0 + min(lane, nb2 - 1)];
-      i3 = items[min(k + 3 * W, n_items - 1)];
+  S zc = v0[9 * i0.x + lc], pcold = comb ? p_old[9 * i0.x + lc] : S(0);
+  __builtin_amdgcn_sched_barrier(0);
+  V bufA[kSpmvPass], bufB[kSpmvPass];
+  ChunkStage<MT> csA, csB;
+  csA.setup(vals, i0.y, nb0);
+  csA.issue(0, lane, bufA);
+  __builtin_amdgcn_sched_barrier(0);  // (A before B here too: the wait counts at the loop head are the minimum over its two entries)
+  csB.setup(vals, i1.y, nb1);
+  csB.issue(0, lane, bufB);  // (a wavefront with one item re-reads it: clamped descriptors, never stored)
+  __builtin_amdgcn_sched_barrier(0);
+
+  // one iteration: chunk k arrives in `buf` (stage `cs`), goes to LDS and is multiplied; `buf` is refilled with chunk
+  // k + 2 W. Returns false behind the wavefront's last chunk.
+  // (straight-line code, ONE copy per buffer: with exact wait counts the wait for one buffer does not include the other's
+  //  loads. The refill is unconditional - behind the wavefront's last item the clamped descriptor names the matrix's
+  //  last chunk, which all wavefronts then re-read from L2 and never store; copies of this step without the request for
+  //  the last two chunks were merged with the loop's by the compiler, and the loop head then waited for everything)
+  auto step = [&](V(&buf)[kSpmvPass], ChunkStage<MT>& cs) __attribute__((always_inline)) {
+    cs.store_all(lane, buf, lds);
+    const int off = cs.off;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- requests of the next iterations: the small ones first, then the matrix chunk k + 2 W. Unconditional (clamped
+    //      descriptors: valid addresses behind the wavefront's last item) and fenced against the instruction scheduler: loads
+    //      return in order, so a small load queued behind the 21 pieces of the chunk would make the next multiply wait for
+    //      a chunk that is needed two iterations later. (A wavefront keeps at most 63 memory operations outstanding: nine
+    //      entries of a camera are three 12-byte loads, not nine.)
+    S xv1[9], xp1[9];
+    load_nine(v0 + 9 * c1, xv1);
+    if (comb) {
+      load_nine(p_old + 9 * c1, xp1);
     } else {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) xv1[t] = xp1[t] = S(0);
+      for (int t = 0; t < 9; ++t) xp1[t] = S(0);
     }
-    // ---- multiply chunk k out of its ring slot ------------------------------------------------------------------------
-    const MT* lds = reinterpret_cast<const MT*>(smem_pcgs + cur * kSpmvStreamSlot);
-    const bool act = lane < nb;
+    const S zc1 = v0[9 * i1.x + lc], pcold1 = comb ? p_old[9 * i1.x + lc] : S(0);
+    const int nb3 = blocks_of(i3);
+    const int c3 = cols[i3.y + min(lane, nb3 - 1)], t3 = tdst[i3.y + min(lane, nb3 - 1)];
+    const int4 i4 = item_vec[min(k + 4 * W, n_items - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    cs.setup(vals, i2.y, nb2);
+    cs.issue(0, lane, buf);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- multiply chunk k out of LDS ----------------------------------------------------------------------------------
+    wave_lds_fence();
+    const bool act = lane < nb0;
 #pragma unroll
     for (int t = 0; t < 9; ++t) xv[t] = comb ? xv[t] + bs * xp[t] : xv[t];
     const S pc = comb ? zc + bs * pcold : zc;  // lane t < 9: entry t of p_c (MODE 0) / x_c
@@ -540,7 +574,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int t = 0; t < 9; ++t) vc[t] = read_lane(pc, t);
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pq = 0.0;
-    spmv_block_times<S, MT, true>(lds, off, lane, act, xv, acc, vc, td >= 0, tpart + size_t(9) * max(td, 0), pq);
+    spmv_block_times<S, MT, true>(lds, off, lane, act, xv, acc, vc, t0 >= 0, tpart + size_t(9) * max(t0, 0), pq);
     S mine = S(0);
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
@@ -548,34 +582,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       if (lane == a) mine = S(tot);
     }
     if (lane < 9) {
-      if (i0.extra < 0) {
+      if (i0.w < 0) {
         mine += lambda * pc;
-        if (MODE == 0) p_new[9 * i0.row + lane] = pc;
-        qmain[9 * i0.row + lane] = mine;
+        if (MODE == 0) p_new[9 * i0.x + lane] = pc;
+        qmain[9 * i0.x + lane] = mine;
         pq += double(lambda) * double(pc) * double(pc);
       } else {
-        qextra[9 * i0.extra + lane] = mine;
+        qextra[9 * i0.w + lane] = mine;
       }
     }
     if (MODE == 0) {
       pq = wave_sum(pq);
       if (lane == 0) part_pq[k] = pq;
     }
-    if (!has_next) break;
-    // ---- chunk k + W becomes the current one: everything requested above has landed behind this wait ---------------
-    vmem_wait_all();
+    wave_lds_fence();  // (the next chunk overwrites the slot)
+    // ---- chunk k + W becomes the current one ----------------------------------------------------------------------------
     k += W;
-    cur ^= 1;
     i0 = i1;
     i1 = i2;
     i2 = i3;
-    nb = nb1;
+    i3 = i4;
+    nb0 = nb1;
     nb1 = nb2;
-    col = col1;
-    col1 = col2;
-    td = td1;
-    td1 = td2;
-    off = off1;
+    nb2 = nb3;
+    c0 = c1;
+    c1 = c2;
+    c2 = c3;
+    t0 = t1;
+    t1 = t2;
+    t2 = t3;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       xv[t] = xv1[t];
@@ -583,6 +618,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     zc = zc1;
     pcold = pcold1;
+  };
+  for (;;) {
+    step(bufA, csA);
+    if (k >= n_items) break;
+    step(bufB, csB);
+    if (k >= n_items) break;
+  }
+}
+
+// float copy of the assembled double matrix (the terms of the power-series preconditioner: Solver::series_f32)
+__global__ __launch_bounds__(256) void k_narrow_matrix(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+  const size_t stride = size_t(gridDim.x) * 256 * 4;
+  for (size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const double4 v = *reinterpret_cast<const double4*>(src + i);
+      *reinterpret_cast<float4*>(dst + i) = float4{float(v.x), float(v.y), float(v.z), float(v.w)};
+    } else {
+      for (size_t j = i; j < n; ++j) dst[j] = float(src[j]);
+    }
   }
 }
 

@@ -1,5 +1,4 @@
-// pg_record_io.hpp - the memory primitives without a C++ spelling: LDS-DMA of the streaming SpMV (kernels_pcg.hpp, end of
-// this file) and those of the persistent PCG kernel (kernels_pcgp.hpp): 16-byte self-validating
+// pg_record_io.hpp - the memory primitives of the persistent PCG kernel (kernels_pcgp.hpp): 16-byte self-validating
 // records written by ONE write-through store and read past L1 (`sc1`), as inline gfx950 assembly - no builtin emits a
 // 16-byte access of agent scope - and the register-allocation hints of that kernel. (The CPU execution harness of the
 // tests substitutes its own file of the same name, tests/hipemu/pg_record_io.hpp: this one has a single code path.)
@@ -89,15 +88,5 @@ __device__ __forceinline__ void pg_rec_load4(const pg_rec* p0, const pg_rec* p1,
       : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
       : "memory");
 }
-
-// ---- LDS-DMA (streaming SpMV, kernels_pcg.hpp) ----------------------------------------------------------------------------
-// global_load_lds_dwordx4: the 16 bytes at every lane's `g` land at `lds + 16 lane` (`lds` wave-uniform) without passing
-// through registers; the request stays in flight until a covering vmcnt wait of the issuing wavefront.
-__device__ __forceinline__ void lds_dma16(const void* g, char* lds) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
-}
-// everything this wavefront has requested from memory has arrived (and the compiler moves no access across)
-__device__ __forceinline__ void vmem_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 }  // namespace rba

@@ -945,6 +945,8 @@ class Solver final : public rba_solver {
     d_ex_pair_oi_.alloc(n_pairs);
     d_ex_pair_oj_.alloc(n_pairs);
     d_ex_vals_.alloc(size_t(81) * nnz + 4);  // + 4: the SpMV's last 16-byte load may run past the end
+    // power-series preconditioner of a float solver: its terms run through a FLOAT copy of the matrix (series_f32())
+    if (series_f32()) d_ex_vals32_.alloc(size_t(81) * nnz + 8);
     if (kA64) {
       // float solver: the matrix is assembled in double from the float factors (kernels_a64.hpp)
       d_a64_lq_.alloc(size_t(rba::kA64Lq) * n_lms_);
@@ -1120,6 +1122,11 @@ class Solver final : public rba_solver {
     if (comm_ || cb_fn_) d_ex_vals_.zero(stream_);  // sharded: blocks without local pairs must be 0
     ++pcg_counters_.assemblies;
     assemble_values();
+    if (d_ex_vals32_.size() > 0) {
+      const size_t n = size_t(81) * ex_nnz_;
+      hipLaunchKernelGGL(rba::k_narrow_matrix, dim3(unsigned(std::min<size_t>((n + 1023) / 1024, 4096))), dim3(256), 0, stream_,
+                         static_cast<const double*>(d_ex_vals_.get()), d_ex_vals32_.get(), n);
+    }
     if (measure) {
       HIP_CHECK(hipEventRecord(ev_asm1_, stream_));
       asm_pending_ = true;
@@ -1237,17 +1244,32 @@ class Solver final : public rba_solver {
     }
     return qp;
   }
-  // wavefronts of the streaming SpMV: as many as are resident at once (a two-slot ring of 43 KB each: three per compute unit)
+  // wavefronts of the streaming SpMV: as many as are resident at once (more than 256 registers each: one per SIMD)
   int spmv_stream_waves() const {
     if (env_.spmv_stream_waves_per_cu < 0) return 2;  // (tests: two wavefronts walk the whole matrix)
-    const int per_cu = env_.spmv_stream_waves_per_cu > 0 ? env_.spmv_stream_waves_per_cu : 3;
+    const int per_cu = env_.spmv_stream_waves_per_cu > 0 ? env_.spmv_stream_waves_per_cu : 4;
     return std::max(1, n_cus_) * per_cu;
   }
   // the row-staged SpMV of kernels_pcg.hpp on the PCG's matrix, MODE 0 / 1 / 2
+  // `series_term`: a product INSIDE the power-series preconditioner z = sum_i (Hpp^-1 E0)^i Hpp^-1 r
+  // (preconditioner.hpp:180-245). The preconditioner is any fixed symmetric positive definite approximation of the
+  // inverse - the float32 reference applies the series in float32 throughout - so those products (ten of the eleven
+  // per PCG iteration at power_order 10) stream a FLOAT copy of the assembled matrix, half the bytes; the operator
+  // product, the residual refresh and p.q stay on the double matrix (series_f32()).
   template <int MODE>
   void launch_spmv(const S* z, S* p0, S* p1, const S* xvec, const double* part_rho, const double* part_q,
-                   double* part_pq, double q_tol, int min_it, int max_it, int period, int* progress) {
-    with_matrix([&](const int* cols, auto* vals, auto half) {
+                   double* part_pq, double q_tol, int min_it, int max_it, int period, int* progress,
+                   bool series_term = false) {
+    auto on_matrix = [&](auto&& f) {
+      if constexpr (sizeof(S) == 4) {
+        if (series_term && !sc_ && d_ex_vals32_.size() > 0) {
+          f(static_cast<const int*>(d_ex_cols_.get()), static_cast<const float*>(d_ex_vals32_.get()), std::true_type{});
+          return;
+        }
+      }
+      with_matrix(f);
+    };
+    on_matrix([&](const int* cols, auto* vals, auto half) {
       using MT = std::remove_cv_t<std::remove_pointer_t<decltype(vals)>>;
       constexpr bool H = decltype(half)::value;
       // (MODE 2 with the products split over the ranks: this rank's range of work items)
@@ -1262,7 +1284,7 @@ class Solver final : public rba_solver {
         if (env_.spmv_stream != 0 && (env_.spmv_stream == 2 || ni >= 4 * waves)) {
           streamed = true;
           hipLaunchKernelGGL((rba::k_pcgs_spmv_stream<S, MODE, MT>), dim3(std::min(ni, waves)), dim3(64),
-                             rba::kSpmvStreamSlots * rba::kSpmvStreamSlot, stream_, cols, vals, d_items_.get() + i0, ni, z, p0, p1, xvec,
+                             size_t(rba::kSpmvPass) * 1024, stream_, cols, vals, d_items_.get() + i0, ni, z, p0, p1, xvec,
                              d_qmain_.get(), d_qpart_.get(), d_tpart_.get(), static_cast<const int*>(d_tdst_.get()),
                              d_cg_.get(), part_rho, part_q, part_pq, q_tol, min_it, max_it, period, progress);
         }
@@ -2262,12 +2284,16 @@ class Solver final : public rba_solver {
   // Power-series preconditioner on the fused path: the terms 1..m of the series behind the kernel that formed
   // z = t = Hpp^-1 r (k_pcgs_update / k_pcg_a1), two launches per term; the last one leaves the partials of rho.
   bool series_fused() const { return opt_.preconditioner_type == 2; }
+  // the series' products through a float copy of the assembled matrix: float solvers (the copy is as accurate as their
+  // vectors), square-root solver (the explicit-SC backend's matrix is in the solver's scalar already); RBA_SERIES_F32=0:
+  // through the double matrix as in rounds 3-5
+  bool series_f32() const { return sizeof(S) == 4 && !sc_ && opt_.preconditioner_type == 2 && env_.series_f32 != 0; }
   S* series_t() { return series_fused() ? d_pw_t_.get() : static_cast<S*>(nullptr); }
   void enqueue_series() {
     if (!series_fused()) return;
     constexpr int NB = rba::kPcgBlocks;
     for (int i = 1; i <= opt_.power_order; ++i) {
-      launch_spmv<2>(nullptr, nullptr, nullptr, d_pw_t_.get(), nullptr, nullptr, nullptr, -1.0, 0, 0, 1, nullptr);
+      launch_spmv<2>(nullptr, nullptr, nullptr, d_pw_t_.get(), nullptr, nullptr, nullptr, -1.0, 0, 0, 1, nullptr, true);
       hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), q_pieces(),
                          d_pw_t_.get(), d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(), i == opt_.power_order ? 1 : 0,
                          d_pcg_partials_.get());
@@ -2754,7 +2780,7 @@ class Solver final : public rba_solver {
           if (series_on_matrix) {
             // through the assembled matrix: (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t), no collective
             // the row-staged SpMV of the fused PCG (kernels_pcg.hpp, plain-product mode) + its collect
-            launch_spmv<2>(nullptr, nullptr, nullptr, t, nullptr, nullptr, nullptr, double(lambda), 0, 0, 1, nullptr);
+            launch_spmv<2>(nullptr, nullptr, nullptr, t, nullptr, nullptr, nullptr, double(lambda), 0, 0, 1, nullptr, true);
             hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, e, q_pieces(), n);
             hipLaunchKernelGGL((rba::k_series_step<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), e, t, d_z_.get(), n,
                                st);
@@ -3632,7 +3658,8 @@ class Solver final : public rba_solver {
     double verify_tolerance = 0.25;    // RBA_VERIFY_TOLERANCE=x: relative agreement of the Q model asked of them
     int spmv_stream = 1;               // RBA_SPMV_STREAM: 0 = one wavefront per item always, 1 = streaming SpMV for matrices of
                                        // >= 4 items per resident wavefront, 2 = always (tests)
-    int spmv_stream_waves_per_cu = 0;  // RBA_SPMV_STREAM_WAVES: wavefronts per compute unit of the streaming SpMV (0 = 3; -1: two in all - tests)
+    int spmv_stream_waves_per_cu = 0;  // RBA_SPMV_STREAM_WAVES: wavefronts per compute unit of the streaming SpMV (0 = 4; -1: two in all - tests)
+    int series_f32 = 1;                // RBA_SERIES_F32=0: the terms of the power-series preconditioner through the double matrix
     int pcg_persistent = 1;            // RBA_PCG_PERSISTENT=0: PCG on the assembled matrix always in two launches per
                                        // iteration (kernels_pcg.hpp; the test of the two forms)
     int pcg_split = -1;                // RBA_PCG_SPLIT=0/1: never / always split the products on the assembled matrix
@@ -3672,6 +3699,7 @@ class Solver final : public rba_solver {
     env_.stage_timers = geti("RBA_STAGE_TIMERS", 1);
     env_.pcg_split = geti("RBA_PCG_SPLIT", -1);
     env_.pcg_persistent = geti("RBA_PCG_PERSISTENT", 1);
+    env_.series_f32 = geti("RBA_SERIES_F32", 1);
     env_.spmv_stream = geti("RBA_SPMV_STREAM", 1);
     env_.spmv_stream_waves_per_cu = geti("RBA_SPMV_STREAM_WAVES", 0);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
@@ -3785,6 +3813,7 @@ class Solver final : public rba_solver {
   DevBuf<int> d_ex_rowptr_, d_ex_cols_, d_ex_diag_, d_ex_upper_, d_ex_mirror_, d_ex_pair_oi_, d_ex_pair_oj_;
   DevBuf<int64_t> d_ex_pair_ptr_;
   DevBuf<double> d_ex_vals_;  // always double (assemble_values), half storage (kernels_pcg.hpp)
+  DevBuf<float> d_ex_vals32_;  // its float copy for the terms of the power-series preconditioner (series_f32())
   DevBuf<double> d_tpart_;    // [9 n_slots] transposed contributions of the blocks other rows own, per product
   DevBuf<int> d_low_ptr_, d_tdst_;
   DevBuf<rba::HeavyRow> d_heavy_;  // rows whose received slots are summed by a wavefront of their own

@@ -50,10 +50,4 @@ __device__ __forceinline__ void pg_rec_load4(const pg_rec* p0, const pg_rec* p1,
   r[3] = pg_rec_load1(p3);
 }
 
-// LDS-DMA of the streaming SpMV: a plain copy by every work-item, complete at once
-__device__ __forceinline__ void lds_dma16(const void* g, char* lds) {
-  __builtin_memcpy(lds + 16 * (threadIdx.x & 63), g, 16);
-}
-__device__ __forceinline__ void vmem_wait_all() {}
-
 }  // namespace rba
