@@ -40,9 +40,10 @@ struct Params {
   S* cams;  // [10 n_cams]
   S* lms;   // [3 n_lms]
   // per-observation / per-row records (landmark-major)
-  S* JpS;       // [n_obs][2][9] weighted pose Jacobian rows, UNSCALED: the Jacobi column scaling D (pose_scaling) is
-                //               applied where a camera index is at hand (operand and result of H x, increment of the
-                //               back-substitution, epilogue of the camera-major pass)
+  S* JpS;       // [2 n_obs][8]  weighted pose Jacobian rows, entries 0..7 of block row w = 2 o + r, UNSCALED: the Jacobi
+                //               column scaling D (pose_scaling) is applied where a camera index is at hand (operand and
+                //               result of H x, increment of the back-substitution, epilogue of the camera-major pass)
+  S* JpT;       // [2 n_obs]     ... and entry 8 of every row (jp_row / JpRows below: why the rows are split)
   S* Vh;        // [2 n_obs][4]  per block row: Householder vectors v0, v1, v2 and (Q^T r)[row]
   S* JlS;       // [n_obs][2][3] sqrt(w) Jl D_l before the QR (back-substitution)
   S* rS;        // [n_obs][2]    sqrt(w) r
@@ -90,6 +91,62 @@ struct Params {
   // on the queue, 50 us per LM iteration (15 % of a trafalgar-257 iteration)
   unsigned long long* stamp;
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Storage of the weighted pose-Jacobian rows, SPLIT since round 6: block row w = 2 o + r keeps its first eight entries
+// at JpS + 8 w and its ninth at JpT[w]. The two rows of an observation are then ONE aligned 64-byte line (float) and
+// the landmark-major kernels read the same 72 bytes per observation as before, as two perfectly coalesced streams
+// (16-byte vectors of the main part, 4 bytes of the tail per lane). Rounds 1-5 kept 18 consecutive scalars per
+// observation: a 72-byte record at a multiple of 72 bytes always straddles TWO 64-byte lines, and the camera-major pass,
+// which gathers one record per observation of a camera, fetched 128 bytes of rows + 64 of its 32-byte stage-2 record
+// for 104 it used - 1.86 x, measured (profiles/r5_pmc_stage_traffic.csv; VERDICT rounds 3-5). With the split the
+// gather is one line of rows + one line that holds the stage-2 record AND the two tail entries (WA[6..7]): 128 bytes.
+// ---------------------------------------------------------------------------------------------------------------------
+template <class S>
+__device__ __forceinline__ void jp_row(const S* __restrict__ J8, const S* __restrict__ JT, int64_t w, S (&jp)[9]) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  const V4* __restrict__ m = reinterpret_cast<const V4*>(J8) + 2 * w;
+  const V4 a = m[0], b = m[1];
+  jp[0] = a.x, jp[1] = a.y, jp[2] = a.z, jp[3] = a.w;
+  jp[4] = b.x, jp[5] = b.y, jp[6] = b.z, jp[7] = b.w;
+  jp[8] = JT[w];
+}
+// both rows of observation o: jp[0..8] row 0, jp[9..17] row 1
+template <class S>
+__device__ __forceinline__ void jp_obs(const S* __restrict__ J8, const S* __restrict__ JT, int64_t o, S (&jp)[18]) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  using V2 = typename std::conditional<sizeof(S) == 4, float2, double2>::type;
+  const V4* __restrict__ m = reinterpret_cast<const V4*>(J8) + 4 * o;
+  const V4 a = m[0], b = m[1], c = m[2], d = m[3];
+  const V2 t = reinterpret_cast<const V2*>(JT)[o];
+  jp[0] = a.x, jp[1] = a.y, jp[2] = a.z, jp[3] = a.w, jp[4] = b.x, jp[5] = b.y, jp[6] = b.z, jp[7] = b.w, jp[8] = t.x;
+  jp[9] = c.x, jp[10] = c.y, jp[11] = c.z, jp[12] = c.w, jp[13] = d.x, jp[14] = d.y, jp[15] = d.z, jp[16] = d.w, jp[17] = t.y;
+}
+// `n` consecutive observations from o_base between an array [n][18] (row-major rows of nine, in LDS) and the split
+// storage, by `nt` work-items with coalesced 16-byte accesses of the main part
+template <class S>
+__device__ __forceinline__ void jp_store_rows(S* __restrict__ J8, S* __restrict__ JT, int64_t o_base, int n,
+                                              const S* __restrict__ rows18, int tid, int nt) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  V4* __restrict__ dst = reinterpret_cast<V4*>(J8) + 4 * o_base;
+  for (int i = tid; i < 4 * n; i += nt) {  // piece i: observation i / 4, row (i / 2) & 1, entries 4 (i & 1) ...
+    const S* __restrict__ src = rows18 + 18 * (i >> 2) + 9 * ((i >> 1) & 1) + 4 * (i & 1);
+    dst[i] = V4{src[0], src[1], src[2], src[3]};
+  }
+  for (int i = tid; i < 2 * n; i += nt) JT[2 * o_base + i] = rows18[9 * i + 8];
+}
+template <class S>
+__device__ __forceinline__ void jp_load_rows(const S* __restrict__ J8, const S* __restrict__ JT, int64_t o_base, int n,
+                                             S* __restrict__ rows18, int tid, int nt) {
+  using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
+  const V4* __restrict__ src = reinterpret_cast<const V4*>(J8) + 4 * o_base;
+  for (int i = tid; i < 4 * n; i += nt) {
+    const V4 v = src[i];
+    S* __restrict__ dst = rows18 + 18 * (i >> 2) + 9 * ((i >> 1) & 1) + 4 * (i & 1);
+    dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+  }
+  for (int i = tid; i < 2 * n; i += nt) rows18[9 * i + 8] = JT[2 * o_base + i];
+}
 
 __device__ __forceinline__ void stage_stamp(unsigned long long* s) {
   if (s && blockIdx.x == 0 && threadIdx.x == 0) *s = wall_clock64();
@@ -369,10 +426,10 @@ __device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, i
   const int row = p.RT[T * 64 + lane];
   const bool act = cam >= 0;
   S jp[9];
-  {
-    const S* __restrict__ jrow = p.JpS + 9 * int64_t(act ? row : 0);
+  jp_row<S>(p.JpS, p.JpT, int64_t(act ? row : 0), jp);
+  if (!act) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) jp[c] = act ? jrow[c] : S(0);
+    for (int c = 0; c < 9; ++c) jp[c] = S(0);
   }
   S v0 = S(0), v1 = S(0), v2 = S(0);
   if (act) {
@@ -511,9 +568,7 @@ __device__ __forceinline__ void hx_tile_load(const Params<S>& p, const ImplicitT
   const int s = min(lb + ((T - tb) << (6 - sh)) + seg, le - 1);  // clamped: padding segments read a valid landmark
   const int64_t rw = cam >= 0 ? row : 0;
   const int cc = cam >= 0 ? cam : 0;
-  const S* __restrict__ jrow = p.JpS + 9 * rw;
-#pragma unroll
-  for (int c = 0; c < 9; ++c) d.jp[c] = jrow[c];
+  jp_row<S>(p.JpS, p.JpT, rw, d.jp);
   const V4 vv = reinterpret_cast<const V4*>(p.Vh)[rw];
   d.v0 = vv.x;
   d.v1 = vv.y;
@@ -745,17 +800,14 @@ __device__ __forceinline__ void hx_wide_landmark(const Params<S>& p, int s, cons
     if (act[rc]) {
       const int64_t obs = o0 + (r >> 1);
       cam[rc] = p.obs_cam[obs];
-      const S* jrow = p.JpS + obs * 18 + 9 * (r & 1);
+      jp_row<S>(p.JpS, p.JpT, 2 * obs + (r & 1), jp[rc]);
       const S* vh = p.Vh + 4 * (2 * o0 + r);
       v[0][rc] = vh[0];
       v[1][rc] = vh[1];
       v[2][rc] = vh[2];
       S acc = S(0);
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        jp[rc][c] = jrow[c];
-        acc += jrow[c] * x[9 * cam[rc] + c];
-      }
+      for (int c = 0; c < 9; ++c) acc += jp[rc][c] * x[9 * cam[rc] + c];
       u[rc] = acc;
     }
   }
@@ -850,7 +902,8 @@ __global__ __launch_bounds__(256) void k_hx_det_gather(Params<S> p, const S* __r
   for (int64_t t = t0 + tid; t < t1; t += 256) {
     const int64_t o = p.cam_obs[t];
     const double u0 = double(hx_u[2 * o]), u1 = double(hx_u[2 * o + 1]);
-    const S* __restrict__ jp = p.JpS + 18 * o;
+    S jp[18];
+    jp_obs<S>(p.JpS, p.JpT, o, jp);
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = fma(double(jp[9 + j]), u1, fma(double(jp[j]), u0, acc[j]));
   }
@@ -965,7 +1018,8 @@ __global__ __launch_bounds__(256) void k_bs_obs(Params<S> p, const S* __restrict
   const int64_t o = o_begin + int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (o >= n_obs) return;
   const S* __restrict__ xc = x + 9 * p.obs_cam[o];
-  const S* __restrict__ jp = p.JpS + 18 * o;
+  S jp[18];
+  jp_obs<S>(p.JpS, p.JpT, o, jp);
   S xv[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) xv[c] = xc[c];
@@ -1095,9 +1149,7 @@ __device__ __forceinline__ void bs_tile_load(const Params<S>& p, const ImplicitT
   const size_t s = size_t(min(lb + ((T - tb) << (6 - sh)) + seg, le - 1));  // clamped: padding segments read a valid landmark
   const int64_t rw = cam >= 0 ? row : 0;
   const int cc = cam >= 0 ? cam : 0;
-  const S* __restrict__ jrow = p.JpS + 9 * rw;
-#pragma unroll
-  for (int c = 0; c < 9; ++c) d.jp[c] = jrow[c];
+  jp_row<S>(p.JpS, p.JpT, rw, d.jp);
   d.vv = reinterpret_cast<const V4*>(p.Vh)[rw];
   const S* __restrict__ xc = x + 9 * cc;
 #pragma unroll

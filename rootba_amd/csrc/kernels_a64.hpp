@@ -43,7 +43,8 @@ struct A64Params {
   const int* __restrict__ obs_lm;
   const int64_t* __restrict__ cam_obs_off;
   const int* __restrict__ cam_obs;
-  const float* __restrict__ JpS;           // [n_obs][18]
+  const float* __restrict__ JpS;           // [2 n_obs][8]  rows, entries 0..7 (split storage: kernels.hpp, jp_row)
+  const float* __restrict__ JpT;           // [2 n_obs]     entry 8
   const float* __restrict__ Vh;            // [2 n_obs][4]
   const float* __restrict__ tauH;          // [3 n_lms] (only its zeros are used: a skipped reflector stays skipped)
   const float* __restrict__ R0;            // [6 n_lms]
@@ -149,22 +150,14 @@ __global__ __launch_bounds__(kA64Threads) void k_a64_obs(A64Params p, int64_t n_
   const bool act = tid < n_here;
   const int64_t o = act ? o_base + tid : o_base;
   {
-    // the workgroup's Jacobian rows: a contiguous stream of 18 n_here floats, scattered into the records
-    const float* src = p.JpS + 18 * o_base;
-    const int total = 18 * n_here, nvec = total / 4;
-    for (int i = tid; i < nvec; i += NT) {
-      const float4 v = reinterpret_cast<const float4*>(src)[i];
-      const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int q = 4 * i + u, r = q / 18;
-        sRecF[2 * kA64Rec * r + (q - 18 * r)] = e[u];
-      }
+    // the workgroup's Jacobian rows: two contiguous streams (main part, tail), scattered into the records
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(p.JpS) + 4 * o_base;
+    for (int i = tid; i < 4 * n_here; i += NT) {  // piece i: observation i / 4, row (i / 2) & 1, entries 4 (i & 1) ...
+      const float4 v = src[i];
+      float* dst = sRecF + 2 * kA64Rec * (i >> 2) + 9 * ((i >> 1) & 1) + 4 * (i & 1);
+      dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
     }
-    for (int q = nvec * 4 + tid; q < total; q += NT) {
-      const int r = q / 18;
-      sRecF[2 * kA64Rec * r + (q - 18 * r)] = src[q];
-    }
+    for (int i = tid; i < 2 * n_here; i += NT) sRecF[2 * kA64Rec * (i >> 1) + 9 * (i & 1) + 8] = p.JpT[2 * o_base + i];
   }
   const int s = p.obs_lm[o];
   const float4* __restrict__ vh = reinterpret_cast<const float4*>(p.Vh);
@@ -440,15 +433,17 @@ __global__ __launch_bounds__(256) void k_a64_diag(A64Params p, const int* __rest
   for (int64_t base = t0 + CH * wave; base < t1; base += 4 * CH) {
     const int cnt = int(min<int64_t>(CH, t1 - base));
     const int idxnext = p.cam_obs[min<int64_t>(base + 4 * CH + lane, t1 - 1)];
-    constexpr int NJ = (CH * 9 + 63) / 64;
-    float2 jv[NJ];
+    // an observation's rows: ONE aligned 64-byte line (four 16-byte pieces) + the two tail entries
+    constexpr int NJ = CH * 4 / 64;
+    static_assert(CH * 4 % 64 == 0 && CH <= 32, "whole passes of 16-byte pieces; one tail pair per lane");
+    float4 jv[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int q = j * 64 + lane;
-      const int r = q / 9, pc = q - 9 * r;
-      const int o = __shfl(idxreg, r & 31);
-      jv[j] = *reinterpret_cast<const float2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
+      const int o = __shfl(idxreg, (q >> 2) & 31);
+      jv[j] = reinterpret_cast<const float4*>(p.JpS)[int64_t(o) * 4 + (q & 3)];
     }
+    const float2 jt = reinterpret_cast<const float2*>(p.JpT)[__shfl(idxreg, lane & 31)];
     double2 w = {0.0, 0.0};
     if (!GRAM) {
       const int o = __shfl(idxreg, (lane >> 1) & 31);
@@ -457,8 +452,15 @@ __global__ __launch_bounds__(256) void k_a64_diag(A64Params p, const int* __rest
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int q = j * 64 + lane;
-      const int r = q / 9, pc = q - 9 * r;
-      if (q < cnt * 9) *reinterpret_cast<double2*>(lds + r * RW + 2 * pc) = double2{double(jv[j].x), double(jv[j].y)};
+      const int r = q >> 2, pc = q & 3;
+      if (r < cnt) {
+        double* d = lds + r * RW + 9 * (pc >> 1) + 4 * (pc & 1);
+        d[0] = double(jv[j].x), d[1] = double(jv[j].y), d[2] = double(jv[j].z), d[3] = double(jv[j].w);
+      }
+    }
+    if (lane < cnt) {
+      lds[lane * RW + 8] = double(jt.x);
+      lds[lane * RW + 17] = double(jt.y);
     }
     if (!GRAM) {
       const int r = lane >> 1, h = lane & 1;

@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void k_hx_implicit_big(Params<S> p, int lm_beg
   S a = S(0), z1 = S(0), z2 = S(0);
   for (int r = tid; r < nrows; r += 256) {
     const int cam = p.obs_cam[o0 + (r >> 1)];
-    const S* __restrict__ jrow = p.JpS + 9 * (row0 + r);
+    S jrow[9];
+    jp_row<S>(p.JpS, p.JpT, row0 + r, jrow);
     S u = S(0);
 #pragma unroll
     for (int c = 0; c < 9; ++c) u += jrow[c] * x[9 * cam + c];
@@ -315,9 +316,11 @@ __global__ __launch_bounds__(256) void k_hx_implicit_big(Params<S> p, int lm_beg
   // y_obs = Jp_obs^T u_obs
   for (int j = tid; j < 9 * (nrows / 2); j += 256) {
     const int i = j / 9, c = j - 9 * i;
-    const S* __restrict__ jp = p.JpS + 18 * (o0 + i);
+    // (entry c of the observation's two rows in the split storage: kernels.hpp, jp_row)
+    const int64_t w0 = 2 * (o0 + i);
+    const S j0 = c < 8 ? p.JpS[8 * w0 + c] : p.JpT[w0], j1 = c < 8 ? p.JpS[8 * w0 + 8 + c] : p.JpT[w0 + 1];
     const int yi = 9 * p.obs_cam[o0 + i] + c;
-    const S w = jp[c] * U[2 * i] + jp[9 + c] * U[2 * i + 1];
+    const S w = j0 * U[2 * i] + j1 * U[2 * i + 1];
     atomic_add(y + yi, dout ? w * dout[yi] : w);
   }
 }

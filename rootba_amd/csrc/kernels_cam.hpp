@@ -7,7 +7,8 @@
 // linearization_qr.hpp:716-815).
 //
 // Data. The pass gathers, per observation of the camera (CSC index), the 72-byte record of unscaled Jacobian rows
-// (JpS, stage 1) and a 32-byte stage-2 record WA = [ g (2) | A (2x2, row-major) | 0 0 ] from landmark-major storage:
+// (JpS, stage 1; split storage - kernels.hpp, jp_row - since round 6: one aligned 64-byte line per observation) and a
+// 32-byte stage-2 record WA = [ g (2) | A (2x2, row-major) | ninth entry of the two rows ] from landmark-major storage:
 //   g    b record:  (Jp D)^T g is the observation's part of b
 //   A    a 2x2 factor A^T A = M of the matrix M = I - W'^T W', where W' (3x2) holds the observation's rows of the
 //        damped Q1 (Cholesky with the larger diagonal entry as pivot - M is singular for a landmark seen twice):
@@ -78,33 +79,50 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<S> p, S lambda, in
     // LDS store and none is conditional (lanes past the chunk re-read one of its first records: `idxreg` is a valid
     // observation in every lane) - a load inside `if (q < ...)` is a basic block of its own that waits for its data
     // before the next one is issued: seven memory round trips per chunk instead of two.
-    constexpr int NJ = (CH * 9 + 63) / 64;
-    V2 jv[NJ];
+    // (split storage of the rows, kernels.hpp: the main part of an observation is ONE aligned line - four 16-byte
+    //  pieces in float - and its two tail entries ride in the stage-2 record, WA[6..7]; the Gram pass on its own, which
+    //  has no stage-2 record yet, reads them from JpT)
+    constexpr int NJ = CH * 4 / 64;
+    static_assert(CH * 4 % 64 == 0 && CH <= 32, "whole passes of 16-byte pieces; one record half per lane");
+    V4 jv[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int q = j * 64 + lane;
-      const int r = q / 9, pc = q - 9 * r;
-      const int o = __shfl(idxreg, r & 31);
-      jv[j] = *reinterpret_cast<const V2*>(p.JpS + int64_t(o) * 18 + 2 * pc);
+      const int o = __shfl(idxreg, (q >> 2) & 31);
+      jv[j] = reinterpret_cast<const V4*>(p.JpS)[int64_t(o) * 4 + (q & 3)];
     }
     V4 w = {0, 0, 0, 0};
+    V2 jt = {0, 0};
     if (MODE == 0) {
       const int o = __shfl(idxreg, (lane >> 1) & 31);
       w = *reinterpret_cast<const V4*>(p.WA + int64_t(o) * kRecW + 4 * (lane & 1));
+    } else {
+      jt = reinterpret_cast<const V2*>(p.JpT)[__shfl(idxreg, lane & 31)];
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int q = j * 64 + lane;
-      const int r = q / 9, pc = q - 9 * r;
-      if (q < cnt * 9) *reinterpret_cast<V2*>(lds + r * RW + 2 * pc) = jv[j];
+      const int r = q >> 2, pc = q & 3;
+      if (r < cnt) {
+        S* d = lds + r * RW + 9 * (pc >> 1) + 4 * (pc & 1);
+        d[0] = jv[j].x, d[1] = jv[j].y, d[2] = jv[j].z, d[3] = jv[j].w;
+      }
     }
     if (MODE == 0) {
       const int r = lane >> 1, h = lane & 1;
       if (r < cnt) {
         S* d = lds + r * RW + 18 + 4 * h;
         *reinterpret_cast<V2*>(d) = V2{w.x, w.y};
-        *reinterpret_cast<V2*>(d + 2) = V2{w.z, w.w};
+        if (h == 0) {
+          *reinterpret_cast<V2*>(d + 2) = V2{w.z, w.w};
+        } else {  // second half of the record: [a10 a11 | tail of row 0, tail of row 1]
+          lds[r * RW + 8] = w.z;
+          lds[r * RW + 17] = w.w;
+        }
       }
+    } else if (lane < cnt) {
+      lds[lane * RW + 8] = jt.x;
+      lds[lane * RW + 17] = jt.y;
     }
     wave_lds_fence();
     if (want_K) {
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<S> p, S lambda, in
 // diagonal entry as pivot: M is (numerically) singular for a landmark with two observations, and dividing by the
 // small pivot would amplify its rounding error eps / m into the other diagonal entry; negative remainders clamp to 0.
 template <class S>
-__device__ __forceinline__ void store_cam_record_stage2(const Params<S>& p, int64_t o, const S out[2][4]) {
+__device__ __forceinline__ void store_cam_record_stage2(const Params<S>& p, int64_t o, const S out[2][4], S jt0, S jt1) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
   const S m00 = S(1) - (out[0][0] * out[0][0] + out[0][1] * out[0][1] + out[0][2] * out[0][2]);
   const S m01 = -(out[0][0] * out[1][0] + out[0][1] * out[1][1] + out[0][2] * out[1][2]);
@@ -234,9 +252,11 @@ __device__ __forceinline__ void store_cam_record_stage2(const Params<S>& p, int6
     a01 = S(0);
     a00 = sqrt(max(m00 - a10 * a10, S(0)));
   }
+  // (+ jt0, jt1: the ninth entry of the observation's two Jacobian rows, JpT[2 o], JpT[2 o + 1] - read by the caller
+  //  with its first loads: the camera-major pass then needs no third line per observation)
   V4* rec = reinterpret_cast<V4*>(p.WA + o * kRecW);
   rec[0] = V4{out[0][3], out[1][3], a00, a01};
-  rec[1] = V4{a10, a11, S(0), S(0)};
+  rec[1] = V4{a10, a11, jt0, jt1};
 }
 
 }  // namespace rba

@@ -85,12 +85,7 @@ __global__ __launch_bounds__(256) void k_s1_geometry(Params<S> p, int64_t o_begi
   // contiguous copy-out (observations of a workgroup are consecutive)
   using V = typename std::conditional<sizeof(S) == 4, float4, double2>::type;
   constexpr int N = 16 / int(sizeof(S));
-  {
-    S* dst = p.JpS + 18 * o_base;
-    const int total = 18 * n_here, nvec = total / N;
-    for (int i = tid; i < nvec; i += 256) reinterpret_cast<V*>(dst)[i] = reinterpret_cast<const V*>(sj)[i];
-    for (int i = nvec * N + tid; i < total; i += 256) dst[i] = sj[i];
-  }
+  jp_store_rows<S>(p.JpS, p.JpT, o_base, n_here, sj, tid, 256);
   {
     S* dst = p.Vh + 8 * o_base;
     const int nvec = 8 * n_here / N;
@@ -268,9 +263,15 @@ __device__ __forceinline__ void s1_fused_obs(const Params<S>& p, int T0, int n_t
     }
     if (!valid_lane) sw = S(0);
     if (valid_lane) {
-      S* mine = stage + 18 * int(o - o_first);
+      // (staged in the split storage of the rows - kernels.hpp, jp_row: eight entries per row, the ninth behind the 64
+      //  observations' main parts - so that the copy-out below is two straight streams)
+      const int oi = int(o - o_first);
 #pragma unroll
-      for (int c = 0; c < 18; ++c) mine[c] = sw * Jp[c];
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) stage[16 * oi + 8 * r + c] = sw * Jp[9 * r + c];
+        stage[16 * 64 + 2 * oi + r] = sw * Jp[9 * r + 8];
+      }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -284,12 +285,12 @@ __device__ __forceinline__ void s1_fused_obs(const Params<S>& p, int T0, int n_t
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   {
-    // (18 scalars per observation: pairs of scalars are 8-byte aligned in float, 16-byte in double)
-    using V2 = typename std::conditional<sizeof(S) == 4, float2, double2>::type;
-    const int total = 9 * __popcll(live);
-    V2* __restrict__ dst = reinterpret_cast<V2*>(p.JpS + 18 * o_first);
-    const V2* __restrict__ src = reinterpret_cast<const V2*>(stage);
-    for (int i = lane; i < total; i += 64) dst[i] = src[i];
+    // (the wavefront's observations are consecutive: two coalesced streams)
+    const int n = __popcll(live);
+    V4* __restrict__ dst = reinterpret_cast<V4*>(p.JpS) + 4 * o_first;
+    const V4* __restrict__ src = reinterpret_cast<const V4*>(stage);
+    for (int i = lane; i < 4 * n; i += 64) dst[i] = src[i];
+    for (int i = lane; i < 2 * n; i += 64) p.JpT[2 * o_first + i] = stage[16 * 64 + i];
   }
   // scale_Jl_cols
 #pragma unroll
@@ -557,12 +558,7 @@ __global__ __launch_bounds__(kS1ColsThreads) void k_s12_cols(Params<S> p, int64_
   const int64_t o = o_base + tid;
   const bool act = tid < n_here;
   // ---- independent loads first ----
-  {
-    const S* src = p.JpS + 18 * o_base;
-    const int total = 18 * n_here, nvec = total / N;
-    for (int i = tid; i < nvec; i += NT) reinterpret_cast<V*>(sJ)[i] = reinterpret_cast<const V*>(src)[i];
-    for (int i = nvec * N + tid; i < total; i += NT) sJ[i] = src[i];
-  }
+  jp_load_rows<S>(p.JpS, p.JpT, o_base, n_here, sJ, tid, NT);
   const int64_t oc = act ? o : o_base;
   const int s = p.obs_lm[oc];
   const int cam = p.obs_cam[oc];
@@ -682,6 +678,8 @@ __global__ __launch_bounds__(256) void k_s2_obs(Params<S> p, int64_t n_obs, S la
   }
   const V4* __restrict__ vh = reinterpret_cast<const V4*>(p.Vh);
   const V4 va = vh[2 * o], vb = vh[2 * o + 1];
+  // (the tail entries of the observation's Jacobian rows, on their way into its stage-2 record: kernels_cam.hpp)
+  const S jt0 = p.JpT[2 * o], jt1 = p.JpT[2 * o + 1];
   const int64_t o0 = p.lm_obs[s];
   const V4* __restrict__ lq = reinterpret_cast<const V4*>(p.LQ + 12 * size_t(s));
   const V4 q0 = lq[0], q1 = lq[1], q2 = lq[2];
@@ -823,7 +821,7 @@ __global__ __launch_bounds__(256) void k_s2_obs(Params<S> p, int64_t n_obs, S la
     out[e][3] = bm + (d[0] * g[12] + d[1] * g[13] + d[2] * g[14]);
   }
   if (valid) {
-    store_cam_record_stage2<S>(p, o, out);
+    store_cam_record_stage2<S>(p, o, out, jt0, jt1);
     if (o >= p.w8_begin) {  // landmarks with k > 32: the two-kernel back-substitution applies W' itself
       V4* dst = reinterpret_cast<V4*>(p.W8 + 8 * (o - p.w8_begin));
       dst[0] = V4{out[0][0], out[1][0], out[0][1], out[1][1]};

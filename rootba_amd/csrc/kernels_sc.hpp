@@ -34,6 +34,11 @@ template <class S>
 struct ScParams {
   int n_cams, n_lms;
   int64_t n_obs;
+  // entry a of row r of observation o: entries 0..7 at JpS + 8 (2 o + r), entry 8 behind the main part
+  __device__ __forceinline__ int64_t jp(int64_t o, int r, int a) const {
+    const int64_t w = 2 * o + r;
+    return a < 8 ? 8 * w + a : 16 * n_obs + w;
+  }
   // topology (shared with the square-root path)
   const int* lm_k;
   const int64_t* lm_obs;
@@ -47,7 +52,7 @@ struct ScParams {
   S* lms;
   const S* pose_scaling;
   // linearisation records
-  S* JpS;   // [obs][18]  sqrt(w) Jp D_p
+  S* JpS;   // [obs][18]  sqrt(w) Jp D_p, in the split storage of the square-root solver's rows (kernels.hpp, jp_row): jp()
   S* JlS;   // [obs][6]   sqrt(w) Jl (column scale applied on use)
   S* rS;    // [obs][2]
   S* M;     // [lm][6]    Jl^T Jl: 00 01 02 11 12 22
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256) void k_sc_linearize_obs(ScParams<S> p) {
   for (int r = 0; r < 2; ++r)
 #pragma unroll
     for (int a = 0; a < 9; ++a)
-      p.JpS[18 * o + 9 * r + a] = sw == S(0) ? S(0) : sw * Jp[9 * r + a] * p.pose_scaling[9 * c + a];
+      p.JpS[p.jp(o, r, a)] = sw == S(0) ? S(0) : sw * Jp[9 * r + a] * p.pose_scaling[9 * c + a];
 #pragma unroll
   for (int i = 0; i < 6; ++i) p.JlS[6 * o + i] = sw == S(0) ? S(0) : sw * Jl[i];
   p.rS[2 * o] = sw == S(0) ? S(0) : sw * res[0];
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256) void k_sc_obs_products(ScParams<S> p) {
   const int l = p.obs_lm[o];
   S jp[18], jl[6], h[9];
 #pragma unroll
-  for (int i = 0; i < 18; ++i) jp[i] = p.JpS[18 * o + i];
+  for (int i = 0; i < 18; ++i) jp[i] = p.JpS[p.jp(o, i / 9, i % 9)];
 #pragma unroll
   for (int i = 0; i < 6; ++i) jl[i] = p.JlS[6 * o + i] * p.scale[3 * l + (i % 3)];
 #pragma unroll
@@ -323,9 +328,10 @@ __global__ __launch_bounds__(256) void k_sc_assemble(ScParams<S> p, const int* _
       acc0 -= t0[r][0] * w0[r][0] + t0[r][1] * w0[r][1] + t0[r][2] * w0[r][2];
       acc1 -= t1[r][0] * w1[r][0] + t1[r][1] * w1[r][1] + t1[r][2] * w1[r][2];
       if (oi[r] >= 0 && oi[r] == oj[r]) {  // wave-uniform: diagonal blocks only
-        const S* __restrict__ J = p.JpS + 18 * int64_t(oi[r]);
-        acc0 += J[a0] * J[b0] + J[9 + a0] * J[9 + b0];
-        if (has1) acc1 += J[a1] * J[b1] + J[9 + a1] * J[9 + b1];
+        const S* __restrict__ J = p.JpS;
+        const int64_t oo = oi[r];
+        acc0 += J[p.jp(oo, 0, a0)] * J[p.jp(oo, 0, b0)] + J[p.jp(oo, 1, a0)] * J[p.jp(oo, 1, b0)];
+        if (has1) acc1 += J[p.jp(oo, 0, a1)] * J[p.jp(oo, 0, b1)] + J[p.jp(oo, 1, a1)] * J[p.jp(oo, 1, b1)];
       }
     }
   }
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256) void k_sc_assemble_mfma(ScParams<float> p, con
         const int g = 4 * m + kk;  // 0..7
         const int pp = g >> 1, row = g & 1;
         const int o = pp == 0 ? oi[0] : pp == 1 ? oi[1] : pp == 2 ? oi[2] : oi[3];
-        const float v = (i < 9 && o >= 0) ? p.JpS[18 * int64_t(o) + 9 * row + i] : 0.f;
+        const float v = (i < 9 && o >= 0) ? p.JpS[p.jp(o, row, i)] : 0.f;
         accP = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, accP, 0, 0, 0);
       }
     }
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(256) void k_sc_back_substitute(ScParams<S> p, const
     for (int r = 0; r < 2; ++r) {
       S jp_inc = S(0);
 #pragma unroll
-      for (int a = 0; a < 9; ++a) jp_inc += p.JpS[18 * o + 9 * r + a] * x[9 * c + a];
+      for (int a = 0; a < 9; ++a) jp_inc += p.JpS[p.jp(o, r, a)] * x[9 * c + a];
       const S t = p.rS[2 * o + r] + jp_inc;
       tmp[0] += p.JlS[6 * o + 3 * r] * s0 * t;
       tmp[1] += p.JlS[6 * o + 3 * r + 1] * s1 * t;
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(256) void k_sc_back_substitute(ScParams<S> p, const
     for (int r = 0; r < 2; ++r) {
       S j_inc = S(0);
 #pragma unroll
-      for (int a = 0; a < 9; ++a) j_inc += p.JpS[18 * o + 9 * r + a] * x[9 * c + a];
+      for (int a = 0; a < 9; ++a) j_inc += p.JpS[p.jp(o, r, a)] * x[9 * c + a];
       j_inc += p.JlS[6 * o + 3 * r] * s0 * d0 + p.JlS[6 * o + 3 * r + 1] * s1 * d1 + p.JlS[6 * o + 3 * r + 2] * s2 * d2;
       acc += j_inc * (S(0.5) * j_inc + p.rS[2 * o + r]);
     }

@@ -125,6 +125,9 @@ struct Rccl {
   int (*CommAbort)(void*) = nullptr;
   int (*CommCount)(void*, int*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;  // (optional: reduce_ranges)
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool load() {
     if (lib) return true;
@@ -137,6 +140,9 @@ struct Rccl {
     CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
     CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    Reduce = reinterpret_cast<decltype(Reduce)>(dlsym(lib, "ncclReduce"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
     return GetUniqueId && CommInitRank && CommDestroy && AllReduce;
   }
@@ -635,6 +641,7 @@ class Solver final : public rba_solver {
     prm_.cam_obs_off = d_cam_off_.get();
     prm_.cam_obs = d_cam_obs_.get();
     prm_.JpS = d_JpS_.get();
+    prm_.JpT = d_JpS_.get() + 16 * size_t(n_obs_);  // (split storage of the rows: kernels.hpp, jp_row)
     prm_.JlS = d_JlS_.get();
     prm_.rS = d_rS_.get();
     prm_.bsO = d_bsO_.get();
@@ -1134,6 +1141,15 @@ class Solver final : public rba_solver {
     ex_valid_ = true;
   }
 
+  // the ranks' partial sums of the assembled matrix: all of it on every rank (replicated products, persistent kernel), or
+  // - products split over the ranks - every rank's own range of block slots only (reduce_ranges)
+  void reduce_assembled_matrix() {
+    if (split_ && split_slot_bounds_.size() == size_t(nranks_) + 1 && env_.verify_assembled == 0)
+      reduce_ranges(d_ex_vals_.get(), split_slot_bounds_);
+    else
+      all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
+  }
+
   // The values of the assembled matrix, always DOUBLE. Double solver: off-diagonal blocks from the records of damped
   // top rows, diagonal blocks = the SCHUR_JACOBI blocks of stage 2 (all-reduced there already). Float solver: every
   // block is re-derived in double from the float factors (kernels_a64.hpp) - a float matrix S + E, |E| ~ eps |S|,
@@ -1150,6 +1166,7 @@ class Solver final : public rba_solver {
       a64_.cam_obs_off = prm_.cam_obs_off;
       a64_.cam_obs = prm_.cam_obs;
       a64_.JpS = prm_.JpS;
+      a64_.JpT = prm_.JpT;
       a64_.Vh = prm_.Vh;
       a64_.tauH = prm_.tauH;
       a64_.R0 = prm_.R0;
@@ -1208,11 +1225,11 @@ class Solver final : public rba_solver {
         hipLaunchKernelGGL(rba::k_a64_offdiag, dim3(rba::xcd_swizzled_grid(ex_n_upper_)), dim3(256), 0, stream_, a64_,
                            d_ex_vals_.get(), d_ex_upper_.get(), d_ex_mirror_.get(), d_ex_pair_ptr_.get(),
                            d_ex_pair_oi_.get(), d_ex_pair_oj_.get(), ex_n_upper_);
-      all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);  // (diagonal blocks included: local sums so far)
+      reduce_assembled_matrix();  // (diagonal blocks included: local sums so far)
     } else {
       ensure_topd();  // the off-diagonal blocks are built from the 27-scalar rows
       if (ex_n_upper_ > 0) launch_offdiag(prm_.topd, d_ex_vals_.get());
-      all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
+      reduce_assembled_matrix();
       // (the diagonal blocks were all-reduced by stage 2 already)
       if (prm_.want_sdiag)
         hipLaunchKernelGGL((rba::k_ex_copy_diag<S>), dim3((81 * n_cams_ + 255) / 256), dim3(256), 0, stream_,
@@ -1585,6 +1602,13 @@ class Solver final : public rba_solver {
     };
     split_item0_ = rank_ == 0 ? 0 : boundary(rank_);
     split_item1_ = rank_ == nranks_ - 1 ? n_items_ : boundary(rank_ + 1);
+    // the ranks' ranges of block slots (work items are in slot order), in matrix scalars: what reduce_ranges sums
+    split_slot_bounds_.assign(size_t(nranks_) + 1, 0);
+    for (int r = 1; r < nranks_; ++r) {
+      const int i = boundary(r);
+      split_slot_bounds_[size_t(r)] = size_t(81) * size_t(i < n_items_ ? items[size_t(i)].slot0 : ex_nnz_);
+    }
+    split_slot_bounds_[size_t(nranks_)] = size_t(81) * size_t(ex_nnz_);
     if (env_.verbose)
       std::fprintf(stderr, "[rootba_hip] rank %d: products on the assembled matrix split over %d ranks: work items %d..%d of %d\n",
                    rank_, nranks_, split_item0_, split_item1_, n_items_);
@@ -1682,6 +1706,32 @@ class Solver final : public rba_solver {
       HIP_CHECK(hipMemcpyAsync(buf, cb_stage_.data(), count * sizeof(T), hipMemcpyHostToDevice, stream_));
       sync();
     }
+  }
+
+  // Sum over the ranks where every rank needs only ITS range of the result: `bounds` (nranks + 1 element offsets into
+  // buf, identical on all ranks) - rank r ends up with the sums of [bounds[r], bounds[r + 1]), the rest of buf keeps this
+  // rank's own partial sums. The assembled matrix of products SPLIT over the ranks (decide_product_split): every rank
+  // multiplies its range of work items only, so an all-reduce of the whole matrix - reduce-scatter + all-gather - moved
+  // twice the bytes it had to (final-13682: 370 MB of half storage per assembly and rank). One ncclReduce per root inside
+  // a group (the ranges are balanced by blocks, not equal in size, which ncclReduceScatter would need). The callback
+  // transport offers an all-reduce only and keeps it.
+  void reduce_ranges(double* buf, const std::vector<size_t>& bounds) {
+    if (!comm_ && !cb_fn_) return;
+    const size_t total = bounds.back();
+    if (cb_fn_ || !g_rccl.Reduce || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
+      all_reduce(buf, total);
+      return;
+    }
+    if (comm_aborted_.load()) throw HipError{"the communicator was aborted: another rank of this handle failed", RBA_ERR_COMM};
+    ++comm_calls_;
+    comm_bytes_ += int64_t((bounds[size_t(rank_) + 1] - bounds[size_t(rank_)]) * sizeof(double));
+    int rc = g_rccl.GroupStart();
+    for (int r = 0; r < nranks_ && rc == 0; ++r) {
+      const size_t n = bounds[size_t(r) + 1] - bounds[size_t(r)];
+      if (n > 0) rc = g_rccl.Reduce(buf + bounds[size_t(r)], buf + bounds[size_t(r)], n, kNcclFloat64, kNcclSum, r, comm_, stream_);
+    }
+    const int rc_end = g_rccl.GroupEnd();
+    if (rc != 0 || rc_end != 0) throw HipError{"ncclReduce (ranges of the assembled matrix) failed: " + std::to_string(rc ? rc : rc_end), RBA_ERR_COMM};
   }
 
   // ---- state ------------------------------------------------------------------
@@ -1968,6 +2018,7 @@ class Solver final : public rba_solver {
         // (pcg). The scaled rows of the SC path give D G D directly; Jp_diag2 of this pass goes to a scratch vector.
         rba::Params<S> gp = prm_;
         gp.JpS = scp_.JpS;
+        gp.JpT = scp_.JpS + 16 * size_t(n_obs_);
         gp.jp_diag2 = d_tmp_.get();
         launch_cam_gram(gp);
         all_reduce(d_mid_.get(), size_t(81) * n_cams_);
@@ -3397,8 +3448,10 @@ class Solver final : public rba_solver {
       // stage 2, landmark side (k_s2_obs): Vh 8 + landmark index in, WA 8 out per observation (+ the eight coefficients
       // of the untiled ones); R0 6 + LQ 12 + the first three reflector rows 12 in, givens 16 + Rd 6 + Q1^T r 3 +
       // damping residual 3 + Z 9 out per landmark. Camera pass: JpS 18 + WA 8 + CSC index in; blocks 81, b 9,
-      // Jp_diag2 9, scaling 9 out
-      m->stage2 = no * (8 * s + 4) + no * 8 * s + no_untiled * 8 * s + nl * (30 + 37) * s + no * (26 * s + 4) +
+      // Jp_diag2 9, scaling 9 out. (Round 6, split storage of the rows: the landmark side reads the two tail entries of
+      // an observation's rows and writes them into WA[6..7]; the camera pass reads the 16 main entries + WA 8 - the
+      // same 42 scalars per observation in all.)
+      m->stage2 = no * (10 * s + 4) + no * 8 * s + no_untiled * 8 * s + nl * (30 + 37) * s + no * (24 * s + 4) +
                   nc * 108 * s;
       // back-substitution, one pass on the wave tiles (k_bs_tile): JpS 18 + Vh 8 and the two lane maps (4 B each per
       // block row) per observation = 120 B in float; tau 3 + givens 16 + R0 6 + Rd 6 + Q1^T r 3 + Jl_col_scale 3 in,
@@ -3819,6 +3872,7 @@ class Solver final : public rba_solver {
   DevBuf<rba::HeavyRow> d_heavy_;  // rows whose received slots are summed by a wavefront of their own
   int n_heavy_ = 0;
   bool split_ = false, split_partial_ = false;  // products on the assembled matrix split over the ranks (decide_product_split)
+  std::vector<size_t> split_slot_bounds_;       // ... and the ranks' ranges of the matrix, in scalars (reduce_ranges)
   int split_item0_ = 0, split_item1_ = 0;
   // float solver: double re-derivation of the factors for the assembled matrix (kernels_a64.hpp)
   static constexpr bool kA64 = std::is_same<S, float>::value;

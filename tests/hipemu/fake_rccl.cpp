@@ -1,5 +1,5 @@
 // tests/hipemu/fake_rccl.cpp - a stand-in for librccl.so.1 for runs on the CPU execution harness (TEST / DEVELOPMENT
-// TOOL ONLY, see hip/hip_runtime.h in this directory): the six entry points the library dlopens, implemented over files
+// TOOL ONLY, see hip/hip_runtime.h in this directory): the entry points the library dlopens, implemented over files
 // in a per-communicator directory so that several PROCESSES on this machine form a communicator without any GPU or
 // network stack. It lets the multi-rank code path of the library (rba_comm_init, the union of the block structure over
 // the ranks, every all-reduce site) and the N > 1 flow of bench.py run where there is no GPU. The sum is formed in rank
@@ -108,4 +108,16 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
   std::memcpy(recv, acc.data(), bytes);
   return 0;
 }
+// ncclReduce: the same exchange, the sum lands on `root` only (in place elsewhere: the buffer keeps the rank's own data)
+int ncclReduce(const void* send, void* recv, size_t count, int dtype, int op, int root, void* comm, void* stream) {
+  auto* c = static_cast<Comm*>(comm);
+  std::vector<char> out(count * elem_size(dtype));
+  const int rc = ncclAllReduce(send, out.data(), count, dtype, op, comm, stream);
+  if (rc != 0) return rc;
+  if (c->rank == root) std::memcpy(recv, out.data(), out.size());
+  return 0;
+}
+// (the calls of a group execute at once, in program order - the same order on every rank)
+int ncclGroupStart() { return 0; }
+int ncclGroupEnd() { return 0; }
 }

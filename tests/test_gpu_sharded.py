@@ -216,7 +216,8 @@ def test_single_process_sharded_handle(dtype, n_dev):
     g.close()
 
 
-def test_single_process_sharded_handle_over_distinct_devices(small_problem):
+@pytest.mark.parametrize("split", [False, True])
+def test_single_process_sharded_handle_over_distinct_devices(small_problem, split, monkeypatch):
     """The same entry over DISTINCT devices: one RCCL communicator inside the process (ncclCommInitRank from the ranks'
     own host threads). Needs two devices - the MI355X development boxes have one; on the CPU execution harness of
     tests/hipemu (eight stand-in devices, file-based stand-in for RCCL) this is where the path runs."""
@@ -231,10 +232,16 @@ def test_single_process_sharded_handle_over_distinct_devices(small_problem):
     #  handles; the first three agree to 1e-14.)
     opts = dict(robust_norm=1, max_num_iterations=3, explicit_after=3)
     g = LinearizorHIP(small_problem, np.float64, L.default_options(**opts))
+    if split:
+        # products on the assembled matrix split over the ranks: every rank receives the sums of ITS range of the matrix
+        # only (Solver::reduce_ranges: one ncclReduce per root in a group instead of an all-reduce of the whole matrix)
+        monkeypatch.setenv("RBA_PCG_SPLIT", "1")
     s = LinearizorHIP(small_problem, np.float64, L.default_options(**opts), devices=[0, 1])
     assert s.comm_info()["transport"] == "rccl" and s.comm_info()["nranks"] == 2
     a, ta = g.optimize_lm()
     b, tb = s.optimize_lm()
+    if split:
+        assert s.pcg_counters()["assemblies"] > 0
     assert ta == tb and len(a) == len(b)
     for x, y in zip(a, b):
         assert x.step_is_successful == y.step_is_successful and abs(x.cost - y.cost) <= 1e-9 * x.cost
