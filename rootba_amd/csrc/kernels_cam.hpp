@@ -79,6 +79,8 @@ __global__ __launch_bounds__(256) void k_cam_pass_mfma(Params<S> p, S lambda, in
     // LDS store and none is conditional (lanes past the chunk re-read one of its first records: `idxreg` is a valid
     // observation in every lane) - a load inside `if (q < ...)` is a basic block of its own that waits for its data
     // before the next one is issued: seven memory round trips per chunk instead of two.
+    // (Measured in round 6 and not kept: the record loads of chunk k + 1 issued ahead of the staging and multiplication
+    //  of chunk k - 153 us against 150: the pass is not bound by the round trips of one wavefront.)
     // (split storage of the rows, kernels.hpp: the main part of an observation is ONE aligned line - four 16-byte
     //  pieces in float - and its two tail entries ride in the stage-2 record, WA[6..7]; the Gram pass on its own, which
     //  has no stage-2 record yet, reads them from JpT)

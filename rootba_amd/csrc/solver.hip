@@ -1261,6 +1261,16 @@ class Solver final : public rba_solver {
     }
     return qp;
   }
+  // workgroups of the cost evaluation that are resident at once (occupancy of the kernel x compute units)
+  int compute_error_blocks() {
+    if (ce_blocks_ == 0) {
+      int per_cu = 0;
+      const hipError_t e = mixed_ ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&rba::k_compute_error<double>), 256, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&rba::k_compute_error<S>), 256, 0);
+      ce_blocks_ = (e == hipSuccess && per_cu > 0) ? std::min(kReduceBlocks, per_cu * std::max(1, n_cus_)) : kReduceBlocks;
+    }
+    return ce_blocks_;
+  }
   // wavefronts of the streaming SpMV: as many as are resident at once (more than 256 registers each: one per SIMD)
   int spmv_stream_waves() const {
     if (env_.spmv_stream_waves_per_cu < 0) return 2;  // (tests: two wavefronts walk the whole matrix)
@@ -1846,7 +1856,10 @@ class Solver final : public rba_solver {
     stamp_side_ = nullptr;
     const int end_slot = stamps_on() ? stamp_slot() : -1;
     unsigned long long* s_end = end_slot >= 0 ? h_stamps_ + end_slot : nullptr;
-    const int blocks = int(std::min<int64_t>(kReduceBlocks, (n_obs_ + 255) / 256));
+    // as many workgroups as are RESIDENT at once (the kernel is a chain of dependent gathers per work-item: with 2048
+    // workgroups at the 6 wavefronts per SIMD its 74 registers allow, a quarter of them ran as a second round on a third of
+    // the part - twenty round trips per work-item's share instead of thirteen)
+    const int blocks = int(std::min<int64_t>(compute_error_blocks(), (n_obs_ + 255) / 256));
     // the eight sums: one rank - straight into the pinned host page; more ranks - into `red`, all-reduced below, or, at
     // the end of an iteration of rba_lm_step (lm_merge_end_), into the block that carries l_diff and the failure bits as
     // well (one collective)
@@ -3506,6 +3519,7 @@ class Solver final : public rba_solver {
   }
 
  private:
+  int ce_blocks_ = 0;  // compute_error_blocks()
   static constexpr int kReduceBlocks = 2048;  // = the wave slots of the chip at 256 threads x 8 waves per SIMD
   static constexpr size_t kSmallLdsBudget = 16 * 1024;
   static constexpr int kSmallBatchesPerBlock = 8;  // LDS batches walked by one workgroup  // bytes of A per small-landmark batch
