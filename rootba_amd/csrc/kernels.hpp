@@ -1500,12 +1500,6 @@ __device__ __forceinline__ double pcg_block_sum(double v, double* sm) {
   __syncthreads();
   return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
-// sum of the per-block partials, same order in every block
-__device__ __forceinline__ double pcg_sum_partials(const double* __restrict__ partial) {
-  double r = 0;
-  for (int b = 0; b < kPcgBlocks; ++b) r += partial[b];
-  return r;
-}
 
 // Verification of a solve that ran on the ASSEMBLED float32 matrix (Solver::solve): with hx = (sum_l A_l^T A_l) x from
 // the matrix-free operator, the Q model -x.(b + r) / 2 is evaluated once with the recursion's residual r and once with
@@ -1597,235 +1591,8 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_a1(const S* __restrict__ in
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-// out = M^-1 in (9x9 block per camera); optionally accum += out; optionally zero a vector
-template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_block_apply(const S* __restrict__ inv,
-                                                            const S* __restrict__ in,
-                                                            S* __restrict__ out, S* __restrict__ accum,
-                                                            S* __restrict__ zero_me, int n,
-                                                            const CgState* st) {
-  if (st->done) return;
-  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
-    const int c = i / 9, row = i - 9 * c;
-    const S* M = inv + 81 * c + 9 * row;
-    const S* rc = in + 9 * c;
-    S v = S(0);
-#pragma unroll
-    for (int j = 0; j < 9; ++j) v += M[j] * rc[j];
-    out[i] = v;
-    if (accum) accum[i] += v;
-  }
-  if (zero_me) {
-    // `in` may alias zero_me only when every block has finished reading: the caller
-    // passes a different buffer (ping-pong)
-    for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads)
-      zero_me[i] = S(0);
-  }
-}
-
-// one term of the power series through the assembled matrix: with E0 = Hpp_damped - (S + lambda I),
-//   (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t);   w = (S + lambda I) t comes from the SpMV + its collect
-template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_series_step(const S* __restrict__ inv, const S* __restrict__ w,
-                                                            S* __restrict__ t, S* __restrict__ z, int n,
-                                                            const CgState* st) {
-  if (st->done) return;
-  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
-    const int c = i / 9, row = i - 9 * c;
-    const S* M = inv + 81 * c + 9 * row;
-    S v = S(0);
-#pragma unroll
-    for (int j = 0; j < 9; ++j) v += M[j] * w[9 * c + j];
-    const S tn = t[i] - v;
-    t[i] = tn;
-    z[i] += tn;
-  }
-}
-
-// per-block partial of rho = r.z
-template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_pcg_rho(const S* __restrict__ r,
-                                                        const S* __restrict__ z, int n,
-                                                        const CgState* st,
-                                                        double* __restrict__ partial) {
-  __shared__ double sm[4];
-  if (st->done) return;
-  double acc = 0;
-  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads)
-    acc += double(r[i]) * double(z[i]);
-  const double t = pcg_block_sum(acc, sm);
-  if (threadIdx.x == 0) partial[blockIdx.x] = t;
-}
-
-template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_pcg_a2(const S* __restrict__ z, S* __restrict__ pvec,
-                                                       S* __restrict__ q, int n, CgState* st,
-                                                       const double* __restrict__ partial,
-                                                       const S* __restrict__ dscale, S* __restrict__ pscaled) {
-  if (st->done) return;
-  const int iter = st->iter;
-  const double rho = pcg_sum_partials(partial);
-  const double rho_prev = st->rho_hist[(iter + 1) & 1];  // written one iteration ago
-  int stop = 0;
-  double beta = 0.0;
-  if (rho == 0.0 || isinf(rho) || rho != rho) {
-    stop = 1;
-  } else if (iter > 0) {
-    beta = rho / rho_prev;
-    if (beta == 0.0 || isinf(beta)) stop = 1;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (stop) {
-      st->termination = 2;  // "Numerical failure. rho / beta"
-      st->done = 1;
-      st->iter = iter + 1;
-      st->result_iter = iter + 1;
-    } else {
-      st->rho_hist[iter & 1] = rho;
-      st->beta = beta;
-    }
-  }
-  if (stop) return;
-  const S bs = S(beta);
-  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
-    const S pn = iter == 0 ? z[i] : z[i] + bs * pvec[i];
-    pvec[i] = pn;
-    if (pscaled) pscaled[i] = dscale[i] * pn;  // compact stage 2: the operand of the matrix-free product is D p
-    q[i] = S(0);
-  }
-}
-
-template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_pcg_b1(const S* __restrict__ pvec, S* __restrict__ q,
-                                                       S lambda, int n, const CgState* st,
-                                                       double* __restrict__ partial) {
-  __shared__ double sm[4];
-  if (st->done) return;
-  double acc = 0;
-  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
-    const S v = q[i] + lambda * pvec[i];  // pose damping term of right_multiply
-    q[i] = v;
-    acc += double(pvec[i]) * double(v);
-  }
-  const double t = pcg_block_sum(acc, sm);
-  if (threadIdx.x == 0) partial[blockIdx.x] = t;
-}
-
-template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_pcg_b2(const S* __restrict__ bvec, S* __restrict__ x,
-                                                       S* __restrict__ r, const S* __restrict__ pvec,
-                                                       const S* __restrict__ q, S* __restrict__ tmp,
-                                                       int n, CgState* st, int residual_reset_period,
-                                                       const double* __restrict__ partial_pq,
-                                                       double* __restrict__ partial_q1) {
-  __shared__ double sm[4];
-  if (st->done) return;
-  const int iter = st->iter;
-  const double pq = pcg_sum_partials(partial_pq);
-  int stop = 0, term = 0;
-  double alpha = 0;
-  if (pq != pq) {
-    stop = 1;  // NaN: the reference would iterate on NaNs up to max_iterations and the LM loop reject the non-finite
-    term = 2;  // increment; ended here as a numerical failure at once (same decision, no wasted iterations)
-  } else if (pq <= 0.0 || isinf(pq)) {
-    stop = 1;  // "Matrix is indefinite, no more progress can be made." -> NO_CONVERGENCE
-  } else {
-    alpha = st->rho_hist[iter & 1] / pq;
-    if (isinf(alpha)) {
-      stop = 1;
-      term = 2;
-    }
-  }
-  const int refresh = ((iter + 1) % residual_reset_period) == 0 ? 1 : 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st->pq = pq;
-    st->alpha = alpha;
-    st->refresh = refresh;
-    if (stop) {
-      st->termination = term;
-      st->indefinite = term == 0 ? 1 : 0;
-      st->done = 1;
-      st->iter = iter + 1;
-      st->result_iter = iter + 1;
-    }
-  }
-  if (stop) return;
-  const S a = S(alpha);
-  double acc1 = 0;
-  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
-    const S xv = x[i] + a * pvec[i];
-    x[i] = xv;
-    if (refresh) {
-      tmp[i] = S(0);
-    } else {
-      const S rv = r[i] - a * q[i];
-      r[i] = rv;
-      acc1 -= double(xv) * double(bvec[i] + rv);
-    }
-  }
-  const double t = pcg_block_sum(acc1, sm);
-  if (threadIdx.x == 0) partial_q1[blockIdx.x] = t;
-}
-
-// residual refresh r = b - (H x) (conjugate_gradient.hpp:230-235), partial of Q
-template <class S>
-__global__ __launch_bounds__(kPcgThreads) void k_pcg_c1(const S* __restrict__ bvec,
-                                                       const S* __restrict__ x, S* __restrict__ r,
-                                                       const S* __restrict__ tmp, S lambda, int n,
-                                                       const CgState* st,
-                                                       double* __restrict__ partial_q1) {
-  __shared__ double sm[4];
-  if (st->done || !st->refresh) return;
-  double acc1 = 0;
-  for (int i = blockIdx.x * kPcgThreads + threadIdx.x; i < n; i += kPcgBlocks * kPcgThreads) {
-    const S rv = bvec[i] - (tmp[i] + lambda * x[i]);
-    r[i] = rv;
-    acc1 -= double(x[i]) * double(bvec[i] + rv);
-  }
-  const double t = pcg_block_sum(acc1, sm);
-  if (threadIdx.x == 0) partial_q1[blockIdx.x] = t;
-}
-
-// Q-model termination (conjugate_gradient.hpp:239-276) and bookkeeping; one thread.
-// `phase` 0: after k_pcg_b2 (skipped on refresh iterations), 1: after k_pcg_c1.
-__device__ __forceinline__ void pcg_fin(CgState* st, const double* __restrict__ partial_q1, int phase,
-                                        double q_tolerance, int min_it, int max_it) {
-  if (st->done) return;
-  if (phase == 0 && st->refresh) return;
-  if (phase == 1 && !st->refresh) return;
-  const double q1 = pcg_sum_partials(partial_q1);
-  st->refresh = 0;
-  const int it = st->iter + 1;
-  st->iter = it;
-  st->result_iter = it;
-  const double zeta = it * (q1 - st->q_hist[(it + 1) & 1]) / q1;
-  st->q_hist[it & 1] = q1;
-  if (zeta < q_tolerance && it >= min_it) {
-    st->termination = 1;
-    st->done = 1;
-    return;
-  }
-  // residual-based termination is off (r_tolerance = -1, linearizor_base.cpp:91)
-  if (it >= max_it) {
-    st->termination = 0;
-    st->done = 1;
-  }
-}
-
-// `host_copy`: the state the host polls goes straight to its pinned page (see k_reduce_rows); one work-item, which
-// reads back its own stores
-__global__ void k_pcg_fin(CgState* st, const double* __restrict__ partial_q1, int phase, double q_tolerance,
-                          int min_it, int max_it, CgState* host_copy) {
-  pcg_fin(st, partial_q1, phase, q_tolerance, min_it, max_it);
-  if (host_copy) {
-    __threadfence();
-    constexpr int kWords = int(sizeof(CgState) / sizeof(int));
-    static_assert(sizeof(CgState) % sizeof(int) == 0, "copied as words");
-#pragma unroll
-    for (int i = 0; i < kWords; ++i)
-      reinterpret_cast<int*>(host_copy)[i] = reinterpret_cast<const volatile int*>(st)[i];
-  }
-}
+// (The seven-kernel PCG loop of round 1 - k_block_apply, k_series_step, k_pcg_rho / a2 / b1 / b2 / c1 / fin - served the
+//  matrix-free power-series solves until round 6; they run in the two-launch protocol of kernels_pcg.hpp now.)
 
 // PMC calibration: stream `n` floats once with dword (VEC = 1) or 16-byte
 // (VEC = 4) loads — a known byte count in this code's own access patterns, to

@@ -1067,7 +1067,10 @@ __global__ __launch_bounds__(256) void k_pcgs_residual(const S* __restrict__ bve
 template <class S>
 __global__ __launch_bounds__(256) void k_pcgs_series_step(const S* __restrict__ inv, QPieces<S> qp, S* __restrict__ t,
                                                           S* __restrict__ z, const S* __restrict__ r, int n_cams,
-                                                          const CgState* st, int last, double* __restrict__ part_rho) {
+                                                          const CgState* st, int last, double* __restrict__ part_rho,
+                                                          int direct = 0) {
+  // `direct`: the product is E0 t itself (matrix-free term, k_e0*: one complete vector in qp.qmain), the next term
+  // Hpp^-1 (E0 t); otherwise it is (S + lambda I) t from the assembled matrix and the next term t - Hpp^-1 of it
   __shared__ double sm[4];
   __shared__ S wl[252];
   if (st->done) return;
@@ -1087,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_pcgs_series_step(const S* __restrict__ 
       ti = t[i];
       zi = z[i];
       if (last) ri = r[i];
-      wi = pcgs_gather_q(qp, c, row);
+      wi = direct ? qp.qmain[i] : pcgs_gather_q(qp, c, row);
     }
     __syncthreads();
     if (tid < 252) wl[tid] = wi;
@@ -1097,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_pcgs_series_step(const S* __restrict__ 
       S v = S(0);
 #pragma unroll
       for (int j = 0; j < 9; ++j) v += Mrow[j] * wc[j];
-      const S tn = ti - v, zn = zi + tn;
+      const S tn = direct ? v : ti - v, zn = zi + tn;
       t[i] = tn;
       z[i] = zn;
       acc_rho += double(ri) * double(zn);

@@ -1144,7 +1144,8 @@ class Solver final : public rba_solver {
   // the ranks' partial sums of the assembled matrix: all of it on every rank (replicated products, persistent kernel), or
   // - products split over the ranks - every rank's own range of block slots only (reduce_ranges)
   void reduce_assembled_matrix() {
-    if (split_ && split_slot_bounds_.size() == size_t(nranks_) + 1 && env_.verify_assembled == 0)
+    // (not with the power-series preconditioner: its terms multiply the WHOLE matrix on every rank)
+    if (split_ && !series_fused() && split_slot_bounds_.size() == size_t(nranks_) + 1 && env_.verify_assembled == 0)
       reduce_ranges(d_ex_vals_.get(), split_slot_bounds_);
     else
       all_reduce(d_ex_vals_.get(), size_t(81) * ex_nnz_);
@@ -2174,7 +2175,7 @@ class Solver final : public rba_solver {
   }
   // x -> D x for the kernels that read the unscaled Jacobian rows
   const S* scaled_operand(const S* x) {
-    if (operand_prescaled_) return d_xs_.get();  // the producer of x wrote D x already (k_pcg_a2)
+    if (operand_prescaled_) return d_xs_.get();  // the producer of x wrote D x already (k_pcgs_direction)
     unsigned long long* const stamp_ptr_ = stamp();  // (evaluated once, ahead of the launch macro)
     hipLaunchKernelGGL((rba::k_scale_vec<S>), dim3((nvec_ + 255) / 256), dim3(256), 0, stream_, x, prm_.pose_scaling,
                        d_xs_.get(), nvec_, stamp_ptr_);
@@ -2361,6 +2362,38 @@ class Solver final : public rba_solver {
       hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), q_pieces(),
                          d_pw_t_.get(), d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(), i == opt_.power_order ? 1 : 0,
                          d_pcg_partials_.get());
+    }
+  }
+
+  // The same terms in the protocol of the MATRIX-FREE products (direction kernel, product, k_pcgs_update): behind the
+  // kernel that left z = t = Hpp^-1 r. Through the assembled matrix where one is valid for this damping - the iterations
+  // of a run whose products are split over the ranks, and the repeat of a solve whose assembled operator lost
+  // definiteness: the PRODUCT is matrix-free again (p.q = |A p|^2 + lambda |p|^2 cannot turn negative) but an approximate
+  // inverse tolerates the eps |S| error of the matrix, and order m costs m SpMVs instead of m matrix-free E0 products
+  // (final-13682, order 10: 2 ms instead of 25 ms per PCG iteration) - else with matrix-free E0 products
+  // (PowerSCPreconditioner::solve_assign, preconditioner.hpp:180-192: t <- Hpp^-1 E0 t, z += t), all-reduced per term.
+  void enqueue_series_terms(S lambda, const int* done) {
+    if (!series_fused()) return;
+    constexpr int NB = rba::kPcgBlocks;
+    const int n = nvec_;
+    const bool on_matrix = ex_active_ || (explicit_off_for_solve_ && ex_ready_ && ex_valid_);
+    S* t = d_pw_t_.get();
+    S* e = d_pw_e_.get();
+    for (int i = 1; i <= opt_.power_order; ++i) {
+      const int last = i == opt_.power_order ? 1 : 0;
+      if (on_matrix) {
+        launch_spmv<2>(nullptr, nullptr, nullptr, t, nullptr, nullptr, nullptr, double(lambda), 0, 0, 1, nullptr, true);
+        hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), q_pieces(), t,
+                           d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(), last, d_pcg_partials_.get(), 0);
+      } else {
+        HIP_CHECK(hipMemsetAsync(e, 0, size_t(n) * sizeof(S), stream_));
+        launch_e0(t, e, done);
+        all_reduce(e, n);
+        rba::QPieces<S> qp{};
+        qp.qmain = e;
+        hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), qp, t,
+                           d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(), last, d_pcg_partials_.get(), 1);
+      }
     }
   }
 
@@ -2678,14 +2711,17 @@ class Solver final : public rba_solver {
     rba::CgState* st = d_cg_.get();
     const int* done = &st->done;
     const S* b = prm_.b;
-    constexpr int NB = rba::kPcgBlocks, T = rba::kPcgThreads;
+    constexpr int NB = rba::kPcgBlocks;
     double* part_rho = d_pcg_partials_.get();
     double* part_pq = part_rho + NB;
     double* part_q1 = part_pq + NB;
     const int max_it = opt_.max_cg_it, min_it = opt_.min_cg_it;
     const double eta = opt_.eta;
     rba::CgState* hst = reinterpret_cast<rba::CgState*>(h_pinned_);
-    const bool mf_protocol = !sc_ && opt_.preconditioner_type != 2;
+    // (since round 6 also the solves with the power-series preconditioner whose products are matrix-free - no assembled
+    //  matrix, or the repeat of a solve whose assembled operator broke down: rounds 1-5 kept the seven-kernel loop of round
+    //  1 for them)
+    const bool mf_protocol = !sc_;
     if (mf_protocol) {
       unsigned long long* const stamp_ptr_ = stamp();
       hipLaunchKernelGGL((rba::k_pcgs_start<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), b, d_x_.get(),
@@ -2729,7 +2765,8 @@ class Solver final : public rba_solver {
         hipLaunchKernelGGL((rba::k_pcgs_update<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), b, d_x_.get(),
                            d_r_.get(), d_z_.get(), d_p_.get(), d_p_.get(), qp, 0, n_cams_, st,
                            static_cast<const double*>(nullptr), part_rho, part_q1, phase, kPcgPeriod, h_progress_, 1,
-                           lambda, d_tmp_.get(), static_cast<S*>(nullptr));
+                           lambda, d_tmp_.get(), series_t());
+        enqueue_series_terms(lambda, done);  // (power series: z = Hpp^-1 r was only its first term)
       };
       // the device publishes the iteration it has started (hp[0]) or the end of the solve (hp[1])
       auto started = [&](int k) {
@@ -2759,7 +2796,9 @@ class Solver final : public rba_solver {
           switch_now = std::isfinite(z3) && std::isfinite(z4) && z4 >= z3;
           if (switch_now) ++pcg_counters_.early_switches;
         }
-        if (ex_ready_ && !ex_active_ && !explicit_off_for_solve_ && (it > explicit_after_ || switch_now)) {
+        // (power series: every iteration costs 1 + power_order products - the assembly pays off at once)
+        if (ex_ready_ && !ex_active_ && !explicit_off_for_solve_ &&
+            (it > (series_fused() ? 0 : explicit_after_) || switch_now)) {
           // (the verdict on the iterations so far first: a solve that ends exactly here must not pay for an assembly)
           if (it >= 3 && !ex_valid_ && !tested) {
             direction(true);
@@ -2773,6 +2812,12 @@ class Solver final : public rba_solver {
             go_fused = true;
             break;
           }
+        }
+        if (it == 1 && series_fused()) {
+          // the series behind the first z = Hpp^-1 b (k_pcgs_start) - here, behind the operator decision of iteration 1:
+          // a solve that goes to the assembled matrix at once never pays for matrix-free terms
+          HIP_CHECK(hipMemcpyAsync(d_pw_t_.get(), d_z_.get(), size_t(n) * sizeof(S), hipMemcpyDeviceToDevice, stream_));
+          enqueue_series_terms(lambda, done);
         }
         operand_prescaled_ = direction();
         // many solves need two or three iterations: products 3 to 8 wait for the verdict of the test that precedes
@@ -2809,93 +2854,8 @@ class Solver final : public rba_solver {
         sync();
       }
     }
-    for (; !mf_protocol && it <= max_it && !go_fused; ++it) {
-      // Long solve: from here on the product is an SpMV with the explicitly assembled
-      // S = sum_l A_l^T A_l (one assembly ~ 16 matrix-free products on venice; S is all-reduced
-      // once, after which the iterations need no collective at all)
-      // (power series: every iteration costs 1 + power_order products, the assembly pays off at once)
-      if (ex_ready_ && !ex_active_ && !explicit_off_for_solve_ &&
-          it > (opt_.preconditioner_type == 2 ? 0 : explicit_after_)) {
-        if (!ex_valid_) assemble_explicit();
-        ex_active_ = true;
-        pcg_used_explicit_ = true;
-        it_first_assembled = it;
-        if (fused) {
-          go_fused = true;
-          break;
-        }
-      }
-      if (opt_.preconditioner_type == 2) {
-        // z = sum_{i=0..order} (Hpp^-1 E0)^i Hpp^-1 r   (PowerSCPreconditioner::solve_assign,
-        // preconditioner.hpp:180-192); d_inv_ holds Hpp^-1
-        S* t = d_pw_t_.get();
-        S* e = d_pw_e_.get();
-        hipLaunchKernelGGL((rba::k_block_apply<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(),
-                           d_r_.get(), t, static_cast<S*>(nullptr), e, n, st);
-        HIP_CHECK(hipMemcpyAsync(d_z_.get(), t, n * sizeof(S), hipMemcpyDeviceToDevice, stream_));
-        // Repeat of a solve whose assembled operator lost definiteness (explicit_off_for_solve_): the PRODUCT is
-        // matrix-free again (p.q = |A p|^2 + lambda |p|^2 cannot turn negative), but the series of the
-        // preconditioner keeps using the assembled matrix, which is still valid for this damping - an approximate
-        // inverse tolerates its eps |S| error, and order m costs m SpMVs instead of m matrix-free E0 products
-        // (final-13682, order 10: 2 ms instead of 25 ms per PCG iteration).
-        const bool series_on_matrix = sc_ || ex_active_ || (explicit_off_for_solve_ && ex_ready_ && ex_valid_);
-        // (SC backend: the damping is inside the matrix, lambda = 0)
-        for (int i = 1; i <= opt_.power_order; ++i) {
-          if (series_on_matrix) {
-            // through the assembled matrix: (Hpp^-1 E0) t = t - Hpp^-1 ((S + lambda I) t), no collective
-            // the row-staged SpMV of the fused PCG (kernels_pcg.hpp, plain-product mode) + its collect
-            launch_spmv<2>(nullptr, nullptr, nullptr, t, nullptr, nullptr, nullptr, double(lambda), 0, 0, 1, nullptr, true);
-            hipLaunchKernelGGL((rba::k_pcgs_collect<S>), dim3((n + 255) / 256), dim3(256), 0, stream_, e, q_pieces(), n);
-            hipLaunchKernelGGL((rba::k_series_step<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), e, t, d_z_.get(), n,
-                               st);
-            continue;
-          }
-          launch_e0(t, e, done);
-          all_reduce(e, n);
-          // t = Hpp^-1 e; z += t; (e is re-zeroed by the next round's first kernel)
-          hipLaunchKernelGGL((rba::k_block_apply<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(), e,
-                             t, d_z_.get(), static_cast<S*>(nullptr), n, st);
-          if (i < opt_.power_order) HIP_CHECK(hipMemsetAsync(e, 0, n * sizeof(S), stream_));
-        }
-        hipLaunchKernelGGL((rba::k_pcg_rho<S>), dim3(NB), dim3(T), 0, stream_, d_r_.get(), d_z_.get(),
-                           n, st, part_rho);
-      } else {
-        hipLaunchKernelGGL((rba::k_pcg_a1<S>), dim3(NB), dim3(T), 0, stream_, d_inv_.get(),
-                           d_r_.get(), d_z_.get(), n, st, part_rho);
-      }
-      // (a matrix-free product next: the direction update also writes D p for it)
-      const bool pre = !sc_ && !ex_active_;
-      hipLaunchKernelGGL((rba::k_pcg_a2<S>), dim3(NB), dim3(T), 0, stream_, d_z_.get(), d_p_.get(),
-                         d_q_.get(), n, st, part_rho, static_cast<const S*>(pre ? prm_.pose_scaling : nullptr),
-                         pre ? d_xs_.get() : static_cast<S*>(nullptr));
-      operand_prescaled_ = pre;
-      launch_hx(d_p_.get(), d_q_.get(), done);
-      operand_prescaled_ = false;
-      if ((!sc_ && !ex_active_) || split_) all_reduce(d_q_.get(), n);
-      hipLaunchKernelGGL((rba::k_pcg_b1<S>), dim3(NB), dim3(T), 0, stream_, d_p_.get(), d_q_.get(),
-                         lambda, n, st, part_pq);
-      hipLaunchKernelGGL((rba::k_pcg_b2<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
-                         d_r_.get(), d_p_.get(), d_q_.get(), d_tmp_.get(), n, st, 10, part_pq, part_q1);
-      // (the iterations the host polls at: the closing kernel leaves a copy of the state in the pinned page)
-      const bool poll = it <= 8 || it % 4 == 0 || it == max_it;
-      rba::CgState* pub = poll ? hst : static_cast<rba::CgState*>(nullptr);
-      if (it % 10 == 0) {
-        // residual refresh r = b - H x (conjugate_gradient.hpp:230-235)
-        launch_hx(d_x_.get(), d_tmp_.get(), done);
-        if ((!sc_ && !ex_active_) || split_) all_reduce(d_tmp_.get(), n);
-        hipLaunchKernelGGL((rba::k_pcg_c1<S>), dim3(NB), dim3(T), 0, stream_, b, d_x_.get(),
-                           d_r_.get(), d_tmp_.get(), lambda, n, st, part_q1);
-        hipLaunchKernelGGL((rba::k_pcg_fin), dim3(1), dim3(1), 0, stream_, st, part_q1, 1, eta, min_it,
-                           max_it, pub);
-      } else {
-        hipLaunchKernelGGL((rba::k_pcg_fin), dim3(1), dim3(1), 0, stream_, st, part_q1, 0, eta, min_it,
-                           max_it, pub);
-      }
-      if (poll) {
-        sync();
-        if (hst->done) break;
-      }
-    }
+    if (!mf_protocol && !go_fused)
+      throw HipError{"the explicit Schur-complement backend has no matrix to iterate on", RBA_ERR_INVALID_ARGUMENT};
     if (go_fused) {
       bool persistent = pcg_persistent_possible();
       if (persistent) {
