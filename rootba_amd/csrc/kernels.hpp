@@ -66,8 +66,11 @@ struct Params {
   S* Zd;        // [9 n_lms]     3x3 map of the top rows through damp / drop-Q1 / undamp (implicit-Q operator)
   // wave tiles for k <= 32 (one lane per block row, landmark = aligned group of P2 lanes, see
   // k_hx_implicit / k_s1_qr_tile): static maps lane -> camera / block row, -1 = padding
-  const int* __restrict__ CT;        // [tiles][64] camera of the row's observation
-  const int* __restrict__ RT;        // [tiles][64] global block row 2 o + r
+  const int2* __restrict__ OT;       // [tiles][32] per OBSERVATION slot of a tile (lanes 2 q, 2 q + 1): {camera, global
+                                     //              block row 2 o of its first row}; camera -1 = padding. (Rounds 1-5: two
+                                     //              maps of an entry per LANE - the second lane's entries were the first's
+                                     //              + {0, 1}: 16 bytes per observation in the product, the back-substitution
+                                     //              and stage 1 where 8 say the same; tile_map below.)
   S* lm_inc;     // mixed precision (RBA_MIXED): the back-substitution stores the scaled landmark increments here
                  // [3 n_lms] instead of adding them to `lms`; they are applied to the double master state
   // camera-sized vectors
@@ -102,6 +105,14 @@ struct Params {
 // for 104 it used - 1.86 x, measured (profiles/r5_pmc_stage_traffic.csv; VERDICT rounds 3-5). With the split the
 // gather is one line of rows + one line that holds the stage-2 record AND the two tail entries (WA[6..7]): 128 bytes.
 // ---------------------------------------------------------------------------------------------------------------------
+// a lane's camera and block row from the tile map (-1, -1: padding)
+template <class S>
+__device__ __forceinline__ void tile_map(const Params<S>& p, size_t T, int lane, int& cam, int& row) {
+  const int2 e = p.OT[T * 32 + (lane >> 1)];
+  cam = e.x;
+  row = e.x >= 0 ? e.y + (lane & 1) : -1;
+}
+
 template <class S>
 __device__ __forceinline__ void jp_row(const S* __restrict__ J8, const S* __restrict__ JT, int64_t w, S (&jp)[9]) {
   using V4 = typename std::conditional<sizeof(S) == 4, float4, double4>::type;
@@ -422,8 +433,8 @@ __device__ __forceinline__ void hx_implicit_tile(const Params<S>& p, size_t T, i
   // static lane maps (tile, lane) -> camera / block row; the Jacobian row (36 bytes) and the
   // reflector entries (16 bytes) are read straight from the stage-1 records: consecutive lanes
   // are consecutive rows, so a wave reads one contiguous 2.3 KB / 1 KB span
-  const int cam = p.CT[T * 64 + lane];
-  const int row = p.RT[T * 64 + lane];
+  int cam, row;
+  tile_map(p, size_t(T), lane, cam, row);
   const bool act = cam >= 0;
   S jp[9];
   jp_row<S>(p.JpS, p.JpT, int64_t(act ? row : 0), jp);
@@ -573,6 +584,9 @@ __device__ __forceinline__ void hx_tile_load(const Params<S>& p, const ImplicitT
   d.v0 = vv.x;
   d.v1 = vv.y;
   d.v2 = vv.z;
+  // (measured in round 6 and not kept: each lane of an observation's pair gathering five of the camera's nine entries
+  //  and a DPP exchange of the halves - 127.9 / 128.6 us against 126.1 / 126.8 on one box: the product is not bound by
+  //  its gather instructions)
   const S* __restrict__ xc = x + 9 * cc;
 #pragma unroll
   for (int c = 0; c < 9; ++c) d.xc[c] = xc[c];
@@ -714,8 +728,9 @@ __global__ __launch_bounds__(NT) void k_hx_implicit_lds(Params<S> p, ImplicitTil
   if (vA < nV) {
     int vB = vA + W;
     int TA = hx_chunk_tile(ch, vA, nV), TB = hx_chunk_tile(ch, vB, nV);
-    int camA = p.CT[size_t(TA) * 64 + lane], rowA = p.RT[size_t(TA) * 64 + lane];
-    int camB = p.CT[size_t(TB) * 64 + lane], rowB = p.RT[size_t(TB) * 64 + lane];
+    int camA, rowA, camB, rowB;
+    tile_map(p, size_t(TA), lane, camA, rowA);
+    tile_map(p, size_t(TB), lane, camB, rowB);
     HxTileData<S> dA, dB;
     hx_tile_load(p, it, TA, camA, rowA, lane, x, dA);
     auto compute = [&](int T, const HxTileData<S>& d, int cam) {
@@ -730,13 +745,15 @@ __global__ __launch_bounds__(NT) void k_hx_implicit_lds(Params<S> p, ImplicitTil
     for (;;) {
       const int vC = vB + W;
       const int TC = hx_chunk_tile(ch, vC, nV);
-      const int camC = p.CT[size_t(TC) * 64 + lane], rowC = p.RT[size_t(TC) * 64 + lane];
+      int camC, rowC;
+      tile_map(p, size_t(TC), lane, camC, rowC);
       hx_tile_load(p, it, TB, camB, rowB, lane, x, dB);
       compute(TA, dA, camA);
       if (vB >= nV) break;
       const int vD = vC + W;
       const int TD = hx_chunk_tile(ch, vD, nV);
-      const int camD = p.CT[size_t(TD) * 64 + lane], rowD = p.RT[size_t(TD) * 64 + lane];
+      int camD, rowD;
+      tile_map(p, size_t(TD), lane, camD, rowD);
       hx_tile_load(p, it, TC, camC, rowC, lane, x, dA);
       compute(TB, dB, camB);
       if (vC >= nV) break;
@@ -1238,7 +1255,8 @@ __global__ __launch_bounds__(256) void k_bs_tile(Params<S> p, ImplicitTiles it, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int T = blockIdx.x * 4 + wave;
   if (T >= it.tile_begin[5]) return;
-  const int cam = p.CT[size_t(T) * 64 + lane], row = p.RT[size_t(T) * 64 + lane];
+  int cam, row;
+  tile_map(p, size_t(T), lane, cam, row);
   BsTileData<S> d;
   bs_tile_load(p, it, T, cam, row, lane, x, d);
   switch (hx_tile_class(it, T)) {

@@ -74,12 +74,13 @@ __device__ __forceinline__ void a64_store_lq(const A64Params& p, int s, const do
 // group of P2 lanes), six segmented sums in double. (A work-item per landmark walking its rows fetched every cache line
 // four times - 686 MB for 160 MB of rows, 150 us: profiles/r4_pmc_stage_traffic.csv, first half of round 4.)
 template <int P2>
-__device__ __forceinline__ void a64_landmark_tile(const A64Params& p, const int* __restrict__ RT, size_t T, int t_in_class,
+__device__ __forceinline__ void a64_landmark_tile(const A64Params& p, const int2* __restrict__ OT, size_t T, int t_in_class,
                                                   int lm_begin, int lm_end, int lane) {
   constexpr int LPW = 64 / P2;
   const int seg = lane / P2, r = lane - P2 * seg;
   const int s = lm_begin + t_in_class * LPW + seg;
-  const int64_t row = RT[T * 64 + lane];  // -1: padding lane
+  const int2 slot = OT[T * 32 + (lane >> 1)];  // {camera, first block row} of the lane's observation
+  const int64_t row = slot.x >= 0 ? slot.y + (lane & 1) : -1;  // -1: padding lane
   double v0 = 0, v1 = 0, v2 = 0;
   if (row >= 0) {
     const float4 v = reinterpret_cast<const float4*>(p.Vh)[row];
@@ -92,20 +93,20 @@ __device__ __forceinline__ void a64_landmark_tile(const A64Params& p, const int*
   if (r == 0 && s < lm_end) a64_store_lq(p, s, n, g10, g20, g21);
 }
 
-__global__ __launch_bounds__(256) void k_a64_landmark(A64Params p, const int* __restrict__ RT, ImplicitTiles it) {
+__global__ __launch_bounds__(256) void k_a64_landmark(A64Params p, const int2* __restrict__ OT, ImplicitTiles it) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int T = blockIdx.x * 4 + wave;
   if (T >= it.tile_begin[5]) return;
   if (T >= it.tile_begin[4])
-    a64_landmark_tile<64>(p, RT, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], lane);
+    a64_landmark_tile<64>(p, OT, T, T - it.tile_begin[4], it.lm_begin[4], it.lm_end[4], lane);
   else if (T >= it.tile_begin[3])
-    a64_landmark_tile<32>(p, RT, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], lane);
+    a64_landmark_tile<32>(p, OT, T, T - it.tile_begin[3], it.lm_begin[3], it.lm_end[3], lane);
   else if (T >= it.tile_begin[2])
-    a64_landmark_tile<16>(p, RT, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], lane);
+    a64_landmark_tile<16>(p, OT, T, T - it.tile_begin[2], it.lm_begin[2], it.lm_end[2], lane);
   else if (T >= it.tile_begin[1])
-    a64_landmark_tile<8>(p, RT, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], lane);
+    a64_landmark_tile<8>(p, OT, T, T - it.tile_begin[1], it.lm_begin[1], it.lm_end[1], lane);
   else
-    a64_landmark_tile<4>(p, RT, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], lane);
+    a64_landmark_tile<4>(p, OT, T, T - it.tile_begin[0], it.lm_begin[0], it.lm_end[0], lane);
 }
 
 // long tracks: one wavefront per landmark

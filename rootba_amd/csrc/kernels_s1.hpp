@@ -114,7 +114,9 @@ __device__ __forceinline__ void s1_qr_tile(const Params<S>& p, size_t T, int t_i
   const int seg = lane / P2, r = lane - P2 * seg, base = lane - r;
   const int s = lm_begin + t_in_class * LPW + seg;
   const bool lm_ok = s < lm_end;
-  const int64_t row = p.RT[T * 64 + lane];  // -1: padding lane
+  int cam_unused, row_i;
+  tile_map(p, T, lane, cam_unused, row_i);
+  const int64_t row = row_i;  // -1: padding lane
   const bool rvalid = row >= 0;
   S jl[3] = {S(0), S(0), S(0)}, rs = S(0);
   if (rvalid) {
@@ -231,7 +233,11 @@ __device__ __forceinline__ void s1_fused_obs(const Params<S>& p, int T0, int n_t
   const int seg = q / P, r = q - P * seg, base = lane - r;
   const int s = lm_begin + t_in_class * LPW + seg;
   const bool lm_ok = tile_ok && s < lm_end;
-  const int row_of_tile = p.RT[T * 64 + 2 * q];                 // (unconditional load of a valid address, then masked)
+  // {camera, first block row} of the lane's observation slot (unconditional loads of valid addresses, then masked; the
+  // row - -1 in a padding slot - here, the camera where it is used: as ONE 8-byte load the pair stayed live across the
+  // kernel's register peak, 66 registers instead of 64 = one wavefront per SIMD less, + 6 us)
+  const int* __restrict__ slot = reinterpret_cast<const int*>(p.OT + (T * 32 + q));
+  const int row_of_tile = slot[1];
   const int64_t row = tile_ok ? int64_t(row_of_tile) : int64_t(-1);  // first row of the observation; -1: padding
   const bool valid_lane = row >= 0;
   const uint64_t live = __ballot(valid_lane);
@@ -241,7 +247,7 @@ __device__ __forceinline__ void s1_fused_obs(const Params<S>& p, int T0, int n_t
   {
     // branch-free (padding lanes evaluate a clamped observation and are masked at the end): inside a conditional the
     // compiler sinks the index and point loads behind the wait for `row` - three round trips instead of two
-    const int cam = max(p.CT[T * 64 + 2 * q], 0);
+    const int cam = max(slot[0], 0);
     const S* __restrict__ lp = p.lms + 3 * size_t(min(max(s, lm_begin), lm_end - 1));
     const int64_t o = (valid_lane ? row : int64_t(0)) >> 1;
     S res[2], Jp[18], Jl[6];

@@ -579,10 +579,16 @@ class Solver final : public rba_solver {
     d_Zd_.zero(stream_);
     d_LQ_.alloc(sc_ ? 0 : 12 * size_t(n_lms));
     if (n_tiles_ > 0) {
-      d_CT_.alloc(size_t(n_tiles_) * 64);
-      d_RT_.alloc(size_t(n_tiles_) * 64);
-      d_CT_.upload(tile_cam.data(), tile_cam.size(), stream_);
-      d_RT_.upload(tile_row.data(), tile_row.size(), stream_);
+      // the tile map, per OBSERVATION slot (lanes 2 q and 2 q + 1 of a tile are the two rows of one observation)
+      std::vector<int2> tile_obs(size_t(n_tiles_) * 32);
+      for (size_t i = 0; i < tile_obs.size(); ++i) {
+        if ((tile_cam[2 * i] >= 0) != (tile_cam[2 * i + 1] >= 0) || (tile_cam[2 * i] >= 0 &&
+            (tile_cam[2 * i + 1] != tile_cam[2 * i] || tile_row[2 * i + 1] != tile_row[2 * i] + 1 || (tile_row[2 * i] & 1))))
+          throw HipError{"tile map: the two lanes of an observation slot disagree", RBA_ERR_INVALID_ARGUMENT};
+        tile_obs[i] = int2{tile_cam[2 * i], tile_cam[2 * i] >= 0 ? tile_row[2 * i] : -1};
+      }
+      d_OT_.alloc(tile_obs.size());
+      d_OT_.upload(tile_obs.data(), tile_obs.size(), stream_);
     }
     n_obs_small_ = lm_obs[big_begin_];  // observations of the landmarks with k <= 112 (sorted first)
     n_obs_tiled_ = lm_obs[imp_end_[4]];  // ... with k <= 32 (the wave tiles)
@@ -650,8 +656,7 @@ class Solver final : public rba_solver {
     prm_.tauH = d_tauH_.get();
     prm_.Zd = d_Zd_.get();
     prm_.LQ = d_LQ_.get();
-    prm_.CT = d_CT_.get();
-    prm_.RT = d_RT_.get();
+    prm_.OT = d_OT_.get();
     prm_.cams = d_cams_.get();
     prm_.lms = d_lms_.get();
     prm_.lm_inc = mixed_ ? d_lm_inc_.get() : nullptr;
@@ -1211,7 +1216,7 @@ class Solver final : public rba_solver {
       if (!a64_lm_valid_) {  // per linearisation point: tau and the reflector cross products in double
         const int short_end = n_tiles_ > 0 ? imp_end_[4] : 0;  // k <= 32: the wave tiles; longer tracks: a wavefront each
         if (n_tiles_ > 0)
-          hipLaunchKernelGGL(rba::k_a64_landmark, dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, a64_, prm_.RT,
+          hipLaunchKernelGGL(rba::k_a64_landmark, dim3((n_tiles_ + 3) / 4), dim3(256), 0, stream_, a64_, prm_.OT,
                              implicit_tiles());
         if (n_lms_ > short_end)
           hipLaunchKernelGGL(rba::k_a64_landmark_wave, dim3((n_lms_ - short_end + 3) / 4), dim3(256), 0, stream_, a64_,
@@ -3426,13 +3431,13 @@ class Solver final : public rba_solver {
       // same 42 scalars per observation in all.)
       m->stage2 = no * (10 * s + 4) + no * 8 * s + no_untiled * 8 * s + nl * (30 + 37) * s + no * (24 * s + 4) +
                   nc * 108 * s;
-      // back-substitution, one pass on the wave tiles (k_bs_tile): JpS 18 + Vh 8 and the two lane maps (4 B each per
-      // block row) per observation = 120 B in float; tau 3 + givens 16 + R0 6 + Rd 6 + Q1^T r 3 + Jl_col_scale 3 in,
+      // back-substitution, one pass on the wave tiles (k_bs_tile): JpS 18 + Vh 8 and the tile map (8 B per observation
+      // since round 6: Params::OT) per observation = 112 B in float; tau 3 + givens 16 + R0 6 + Rd 6 + Q1^T r 3 + Jl_col_scale 3 in,
       // the point in and out (6) and l_diff (8 B) out per landmark. The two-kernel form of the untiled landmarks adds
       // JlS 6 + rS 2, the eight coefficients and its 5-scalar scratch (write + read) per observation.
-      m->back_substitution = no * (26 * s + 16) + no_untiled * (8 + 8 + 10) * s + nl * (43 * s + 8) + nc * 9 * s;
-      // implicit-Q product: JpS row 9 + Vh row 4 per block row, camera / row maps, tau + Z per landmark
-      m->product_matrix_free = no * (26 * s + 16) + nl * 12 * s + nc * 18 * s;
+      m->back_substitution = no * (26 * s + 8) + no_untiled * (8 + 8 + 10) * s + nl * (43 * s + 8) + nc * 9 * s;
+      // implicit-Q product: JpS row 9 + Vh row 4 per block row, the tile map (8 B per observation), tau + Z per landmark
+      m->product_matrix_free = no * (26 * s + 8) + nl * 12 * s + nc * 18 * s;
     }
     const int64_t nnz = sc_ ? sc_nnz_ : ex_nnz_;
     const int64_t ms = sc_ ? s : int64_t(sizeof(double));  // the assembled matrix of the square-root solver is double
@@ -3759,7 +3764,7 @@ class Solver final : public rba_solver {
   DevBuf<int64_t> d_lm_obs_, d_cam_off_;
   DevBuf<int> d_cam_obs_;
   DevBuf<S> d_JpS_, d_Vh_, d_tauH_, d_Zd_, d_LQ_, d_JlS_, d_rS_, d_bsO_, d_givens_;
-  DevBuf<int> d_CT_, d_RT_;
+  DevBuf<int2> d_OT_;  // tile map (kernels.hpp: Params::OT)
   int64_t n_obs_small_ = 0, n_obs_tiled_ = 0;
   DevBuf<S> d_big_scratch_;
   DevBuf<S> d_pg_xsave_;                  // sharded runs: x and the PCG state at the entry of a persistent solve
