@@ -31,7 +31,11 @@
  *    rba_options.explicit_after), RBA_EX_PAIR_BUDGET_GB, RBA_FORCE_EXPLICIT_FALLBACK, RBA_HX_LDS, RBA_HX_WIN,
  *    RBA_HX_TIMING_STRIDE, RBA_SORT_BY_CAMERA, RBA_VERIFY_ASSEMBLED (diagnostic, default off since round 4),
  *    RBA_VERIFY_TOLERANCE, RBA_PCG_SPLIT, RBA_HALF_LOWER_MAX, RBA_S1_FUSED, RBA_HX_WIDE_INSIDE, RBA_PCG_PERSISTENT (0: the PCG on
- *    the assembled matrix in two launches per iteration instead of the persistent kernel), RBA_PCGP_TRACE (file for that
+ *    the assembled matrix in two launches per iteration instead of the persistent kernel), RBA_SPMV_STREAM (0: the product
+ *    with an assembled matrix that does not fit the register files always one wavefront per work item; 1, default:
+ *    persistent streaming wavefronts for matrices of >= 4 items per resident wavefront; 2: always), RBA_SPMV_STREAM_WAVES,
+ *    RBA_SERIES_F32 (0: the terms of the power-series preconditioner through the double matrix instead of its float copy),
+ *    RBA_PCGP_TRACE (file for that
  *    kernel's phase stamps), RBA_STAGE_TIMERS (0: rba_iter_timings stays zero; 1, default: device clock stamps at the stage
  *    boundaries inside rba_lm_step, HIP events around single calls; 2: HIP events everywhere), RBA_DETERMINISTIC (1: the matrix-free products are summed camera-major in a fixed order
  *    instead of with floating-point atomics and the measured break-even of the operator switch is frozen - float32
