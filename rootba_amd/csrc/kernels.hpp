@@ -1682,13 +1682,28 @@ __global__ __launch_bounds__(1024) void k_finish_increment(S* __restrict__ x, S*
     if (f & flag_clear) *flag = f & ~flag_clear;
   }
   double acc = 0, bad = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const S v = -x[i];
-    x[i] = v;
-    inc[i] = v;
-    if (xs) xs[i] = pose_scaling[i] * v;
-    acc += double(v) * double(v);
-    bad += is_finite(v) ? 0.0 : 1.0;
+  // (batches of eight entries per work-item, every load of a batch requested before its first store: as a plain strided
+  //  loop the sixteen entries of a work-item were sixteen memory round trips in a row - x is read and written)
+  for (int base = 0; base < n; base += 8 * 1024) {
+    S xv[8], ps[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int ic = min(base + u * 1024 + int(threadIdx.x), n - 1);
+      xv[u] = x[ic];
+      ps[u] = xs ? pose_scaling[ic] : S(0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 1024 + int(threadIdx.x);
+      if (i < n) {
+        const S v = -xv[u];
+        x[i] = v;
+        inc[i] = v;
+        if (xs) xs[i] = ps[u] * v;
+        acc += double(v) * double(v);
+        bad += is_finite(v) ? 0.0 : 1.0;
+      }
+    }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const double t0 = wave_sum(acc), t1 = wave_sum(bad);

@@ -397,16 +397,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
 // same iteration (loads return in order: what the next multiply waits for must not queue behind a chunk that is needed
 // two iterations later). Same arithmetic, same summation order per item as k_pcgs_spmv: bit-identical products
 // (tests/test_gpu_parity.py::test_streaming_spmv_is_the_item_spmv).
-// the nine entries of a camera in few memory operations (4-byte aligned 12- / 16-byte loads)
+// the nine entries of a camera in three memory operations (4-byte aligned 16-byte loads + one scalar; exactly the
+// 36 bytes: a three-component vector type is sixteen bytes wide on the host side of the test harness)
 __device__ __forceinline__ void load_nine(const float* __restrict__ p, float (&v)[9]) {
-  typedef float f3 __attribute__((ext_vector_type(3), aligned(4)));
-#pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const f3 t = *reinterpret_cast<const f3*>(p + 3 * u);
-    v[3 * u] = t.x;
-    v[3 * u + 1] = t.y;
-    v[3 * u + 2] = t.z;
-  }
+  typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
+  const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4);
+  v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w;
+  v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+  v[8] = p[8];
 }
 __device__ __forceinline__ void load_nine(const double* __restrict__ p, double (&v)[9]) {
   typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));

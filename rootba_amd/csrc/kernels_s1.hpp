@@ -379,7 +379,7 @@ __device__ __forceinline__ void s1_fused_obs(const Params<S>& p, int T0, int n_t
 template <class S>
 __global__ __launch_bounds__(256) void k_s1_fused_obs(Params<S> p, ImplicitTiles it, FusedObsWaves fw) {
   stage_stamp(p.stamp);
-  __shared__ __attribute__((aligned(16))) S stage[4][64 * 18];
+  __shared__ __attribute__((aligned(32))) S stage[4][64 * 18];  // (32: copied out as four-scalar vectors, double4 in the double solver)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int W = blockIdx.x * 4 + wave;  // wavefront = a pair of row tiles of one class
   if (W >= fw.wave_begin[5]) return;
