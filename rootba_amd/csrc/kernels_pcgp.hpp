@@ -533,8 +533,11 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
     __syncthreads();
     rowsums(1, S(0));
     __syncthreads();
-    if (roww)
-      for (int j = lane; j < nout; j += 64) rs[j] = bs[j] - qss[j];
+    if (roww) {
+      unsigned j0 = unsigned(lane);
+      PG_OPAQUE(j0);  // (its own copy of the lane index, made here: the one kept for these two cold loops was the kernel's last spill)
+      for (int j = int(j0); j < nout; j += 64) rs[j] = bs[j] - qss[j];
+    }
   }
   if (!close_all(P.tag_base + pg_u32(it + 1) * pg_u32(P.tag_stride))) return;
 
@@ -793,8 +796,11 @@ __global__ __launch_bounds__(kPgThreads) void k_pcgp(PgParams<S> P) {
       __syncthreads();  // #5
       rowsums(1, S(0));
       __syncthreads();  // #6
-      if (roww)
-        for (int j = lane; j < nout; j += 64) rs[j] = bs[j] - qss[j];
+      if (roww) {
+        unsigned j0 = unsigned(lane);
+        PG_OPAQUE(j0);  // (as at the operator switch above)
+        for (int j = int(j0); j < nout; j += 64) rs[j] = bs[j] - qss[j];
+      }
     }
     if (!(NR == 3 && !refresh && NR * W.nrows <= 64 && P.series == 0))
       if (!close_all(tag + pg_u32(P.tag_stride))) return;
