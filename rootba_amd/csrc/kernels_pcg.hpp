@@ -154,7 +154,12 @@ struct ChunkStage {
 // HALF (see the top of the file): the same pass over the block also forms the transposed product S_cj^T v_c (stored to
 // the block's slot `tdst` unless the block is the diagonal one or is stored in both rows) and the lane's share
 // w v_c^T S_cj v_j of p.q.
-template <class S, class MT, bool HALF>
+// (fused multiply-adds spelled out: left to the compiler's contraction, which of a float block's products are fused and
+//  which become a packed multiply and an add is decided per kernel - the item kernel and the streaming kernels then
+//  differ in the last bit of a product)
+__device__ __forceinline__ float fma_of(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_of(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <class S, class MT, bool HALF, int ROWS = 3>
 __device__ __forceinline__ void spmv_block_times(const MT* lds, int off, int lane, bool act, const S xv[9],
                                                  double acc[9], const S vc[9], bool single, double* tdst,
                                                  double& pq) {
@@ -165,16 +170,16 @@ __device__ __forceinline__ void spmv_block_times(const MT* lds, int off, int lan
     for (int a = 0; a < 9; ++a) {
       // (three block rows at a time: left alone the scheduler hoists all 81 LDS reads of a double block - 162
       //  registers - above the arithmetic, and the kernel needs more than 256 registers: one wavefront per SIMD)
-      if (sizeof(MT) == 8 && a % 3 == 0 && a > 0) __builtin_amdgcn_sched_barrier(0);
+      if (sizeof(MT) == 8 && a % ROWS == 0 && a > 0) __builtin_amdgcn_sched_barrier(0);
       MT t = MT(0);
 #pragma unroll
       for (int b = 0; b < 9; ++b) {
         const MT v = blk[9 * a + b];
-        t += v * MT(xv[b]);
-        if (HALF) tt[b] += v * MT(vc[a]);
+        t = fma_of(v, MT(xv[b]), t);
+        if (HALF) tt[b] = fma_of(v, MT(vc[a]), tt[b]);
       }
       acc[a] += double(t);
-      if (HALF) dot += MT(vc[a]) * t;
+      if (HALF) dot = fma_of(MT(vc[a]), t, dot);
     }
     if (HALF) {
       pq += double(dot) * (single ? 2.0 : 1.0);
@@ -417,8 +422,8 @@ __device__ __forceinline__ void load_nine(const double* __restrict__ p, double (
   v[8] = p[8];
 }
 
-template <class S, int MODE, class MT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_pcgs_spmv_stream(
+template <class S, int MODE, class MT, int NB>
+__device__ __forceinline__ void pcgs_spmv_stream_body(
     const int* __restrict__ cols, const MT* __restrict__ vals, const SpmvItem* __restrict__ items, int n_items,
     const S* __restrict__ z, S* pbuf0, S* pbuf1, const S* __restrict__ xvec, S* __restrict__ qmain,
     S* __restrict__ qextra, double* __restrict__ tpart, const int* __restrict__ tdst, CgState* st,
@@ -527,8 +532,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   csA.setup(vals, i0.y, nb0);
   csA.issue(0, lane, bufA);
   __builtin_amdgcn_sched_barrier(0);  // (A before B here too: the wait counts at the loop head are the minimum over its two entries)
-  csB.setup(vals, i1.y, nb1);
-  csB.issue(0, lane, bufB);  // (a wavefront with one item re-reads it: clamped descriptors, never stored)
+  if (NB == 2) {
+    csB.setup(vals, i1.y, nb1);
+    csB.issue(0, lane, bufB);  // (a wavefront with one item re-reads it: clamped descriptors, never stored)
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // one iteration: chunk k arrives in `buf` (stage `cs`), goes to LDS and is multiplied; `buf` is refilled with chunk
@@ -559,7 +566,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int c3 = cols[i3.y + min(lane, nb3 - 1)], t3 = tdst[i3.y + min(lane, nb3 - 1)];
     const int4 i4 = item_vec[min(k + 4 * W, n_items - 1)];
     __builtin_amdgcn_sched_barrier(0);
-    cs.setup(vals, i2.y, nb2);
+    if (NB == 2) cs.setup(vals, i2.y, nb2);
+    else cs.setup(vals, i1.y, nb1);
     cs.issue(0, lane, buf);
     __builtin_amdgcn_sched_barrier(0);
     // ---- multiply chunk k out of LDS ----------------------------------------------------------------------------------
@@ -572,7 +580,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int t = 0; t < 9; ++t) vc[t] = read_lane(pc, t);
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pq = 0.0;
-    spmv_block_times<S, MT, true>(lds, off, lane, act, xv, acc, vc, t0 >= 0, tpart + size_t(9) * max(t0, 0), pq);
+    spmv_block_times<S, MT, true, NB == 1 ? 1 : 3>(lds, off, lane, act, xv, acc, vc, t0 >= 0, tpart + size_t(9) * max(t0, 0), pq);
     S mine = S(0);
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
@@ -617,13 +625,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     zc = zc1;
     pcold = pcold1;
   };
-  for (;;) {
-    step(bufA, csA);
-    if (k >= n_items) break;
-    step(bufB, csB);
-    if (k >= n_items) break;
+  if (NB == 2) {
+    for (;;) {
+      step(bufA, csA);
+      if (k >= n_items) break;
+      step(bufB, csB);
+      if (k >= n_items) break;
+    }
+  } else {
+    do step(bufA, csA);
+    while (k < n_items);
   }
 }
+
+#define RBA_SPMV_STREAM_ARGS                                                                                      \
+  const int *__restrict__ cols, const MT *__restrict__ vals, const SpmvItem *__restrict__ items, int n_items,     \
+      const S *__restrict__ z, S *pbuf0, S *pbuf1, const S *__restrict__ xvec, S *__restrict__ qmain,             \
+      S *__restrict__ qextra, double *__restrict__ tpart, const int *__restrict__ tdst, CgState *st,              \
+      const double *__restrict__ part_rho, const double *__restrict__ part_q, double *__restrict__ part_pq,       \
+      double q_tolerance, int min_it, int max_it, int period, int *host_progress
+#define RBA_SPMV_STREAM_PASS                                                                                      \
+  cols, vals, items, n_items, z, pbuf0, pbuf1, xvec, qmain, qextra, tpart, tdst, st, part_rho, part_q, part_pq,   \
+      q_tolerance, min_it, max_it, period, host_progress
+// two chunks in flight per wavefront, one wavefront per SIMD
+template <class S, int MODE, class MT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_pcgs_spmv_stream(RBA_SPMV_STREAM_ARGS) {
+  pcgs_spmv_stream_body<S, MODE, MT, 2>(RBA_SPMV_STREAM_PASS);
+}
+// one chunk in flight per wavefront, two wavefronts per SIMD (as many as LDS slots fit on a compute unit: seven)
+template <class S, int MODE, class MT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pcgs_spmv_stream1(RBA_SPMV_STREAM_ARGS) {
+  pcgs_spmv_stream_body<S, MODE, MT, 1>(RBA_SPMV_STREAM_PASS);
+}
+#undef RBA_SPMV_STREAM_ARGS
+#undef RBA_SPMV_STREAM_PASS
 
 // float copy of the assembled double matrix (the terms of the power-series preconditioner: Solver::series_f32)
 __global__ __launch_bounds__(256) void k_narrow_matrix(const double* __restrict__ src, float* __restrict__ dst, size_t n) {

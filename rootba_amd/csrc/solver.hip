@@ -1316,7 +1316,19 @@ class Solver final : public rba_solver {
         const int waves = spmv_stream_waves();
         if (env_.spmv_stream != 0 && (env_.spmv_stream == 2 || ni >= 4 * waves)) {
           streamed = true;
-          hipLaunchKernelGGL((rba::k_pcgs_spmv_stream<S, MODE, MT>), dim3(std::min(ni, waves)), dim3(64),
+          // (a float matrix - the terms of the power series - leaves registers for two wavefronts per SIMD with one chunk
+          //  in flight each: seven per compute unit (their LDS slots) instead of four, 24.1 against 26.6 us per product on
+          //  final-13682 (profiles/r6x_*). A double matrix does not: its multiply alone takes 200 registers, and the
+          //  compiler spills the chunk in flight - 312 to 500 bytes of scratch per lane)
+          auto kernel = &rba::k_pcgs_spmv_stream<S, MODE, MT>;
+          int launch_waves = waves;
+          if constexpr (sizeof(MT) == 4) {
+            if (env_.spmv_stream_buffers == 1) {
+              kernel = &rba::k_pcgs_spmv_stream1<S, MODE, MT>;
+              if (env_.spmv_stream_waves_per_cu == 0) launch_waves = std::max(1, n_cus_) * 7;
+            }
+          }
+          hipLaunchKernelGGL(kernel, dim3(std::min(ni, launch_waves)), dim3(64),
                              size_t(rba::kSpmvPass) * 1024, stream_, cols, vals, d_items_.get() + i0, ni, z, p0, p1, xvec,
                              d_qmain_.get(), d_qpart_.get(), d_tpart_.get(), static_cast<const int*>(d_tdst_.get()),
                              d_cg_.get(), part_rho, part_q, part_pq, q_tol, min_it, max_it, period, progress);
@@ -3691,6 +3703,8 @@ class Solver final : public rba_solver {
     int spmv_stream = 1;               // RBA_SPMV_STREAM: 0 = one wavefront per item always, 1 = streaming SpMV for matrices of
                                        // >= 4 items per resident wavefront, 2 = always (tests)
     int spmv_stream_waves_per_cu = 0;  // RBA_SPMV_STREAM_WAVES: wavefronts per compute unit of the streaming SpMV (0 = 4; -1: two in all - tests)
+    int spmv_stream_buffers = 1;       // RBA_SPMV_STREAM_BUFFERS=2: the streaming product of a FLOAT matrix too with two chunks in flight per
+                                       // wavefront and four wavefronts per compute unit (default: one chunk, seven wavefronts; k_pcgs_spmv_stream1)
     int series_f32 = 1;                // RBA_SERIES_F32=0: the terms of the power-series preconditioner through the double matrix
     int pcg_persistent = 1;            // RBA_PCG_PERSISTENT=0: PCG on the assembled matrix always in two launches per
                                        // iteration (kernels_pcg.hpp; the test of the two forms)
@@ -3734,6 +3748,7 @@ class Solver final : public rba_solver {
     env_.series_f32 = geti("RBA_SERIES_F32", 1);
     env_.spmv_stream = geti("RBA_SPMV_STREAM", 1);
     env_.spmv_stream_waves_per_cu = geti("RBA_SPMV_STREAM_WAVES", 0);
+    env_.spmv_stream_buffers = geti("RBA_SPMV_STREAM_BUFFERS", 1);
     if (env_.hx_timing_stride >= 0) hx_timing_stride_ = env_.hx_timing_stride;
   }
 

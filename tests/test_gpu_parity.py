@@ -754,6 +754,33 @@ def test_streaming_spmv_is_the_item_spmv(small_problem, mixed_k_problem, ladybug
     assert out["item"][2] > 10  # (the residual refresh ran)
 
 
+@pytest.mark.parametrize("which", ["small", "ladybug"])
+def test_streaming_spmv_of_the_float_series_terms(small_problem, ladybug_far, which, monkeypatch):
+    """The terms of the power-series preconditioner of a float32 solver stream a FLOAT copy of the assembled matrix
+    (Solver::series_f32). Their three kernels - one wavefront per item, two chunks in flight per persistent wavefront
+    (k_pcgs_spmv_stream), one chunk in flight and two wavefronts per SIMD (k_pcgs_spmv_stream1,
+    RBA_SPMV_STREAM_BUFFERS=1) - do the same arithmetic in the same order per item: same iteration counts, increments
+    bitwise equal when two handles of the item form agree bitwise."""
+    prob = {"small": small_problem, "ladybug": ladybug_far}[which]
+    monkeypatch.setenv("RBA_PCG_PERSISTENT", "0")
+    monkeypatch.setenv("RBA_DETERMINISTIC", "1")
+    out = {}
+    for tag, mode, buffers, waves in (("item", "0", "2", "0"), ("item-again", "0", "2", "0"), ("stream", "2", "2", "0"),
+                                      ("stream1", "2", "1", "0"), ("stream1-few", "2", "1", "-1")):
+        monkeypatch.setenv("RBA_SPMV_STREAM", mode)
+        monkeypatch.setenv("RBA_SPMV_STREAM_BUFFERS", buffers)
+        monkeypatch.setenv("RBA_SPMV_STREAM_WAVES", waves)
+        g, _ = _pair(prob, np.float32, preconditioner_type=2, power_order=5, explicit_after=1, eta=1e-4, max_cg_it=40)
+        assert g.linearize() == 0
+        inc, cg = g.solve(1e-5)
+        out[tag] = (inc, cg.num_iterations, cg.termination_type)
+    same_bits = np.array_equal(out["item"][0], out["item-again"][0])
+    for tag in ("stream", "stream1", "stream1-few"):
+        assert out[tag][1:] == out["item"][1:], (tag, out[tag][1:], out["item"][1:])
+        assert np.array_equal(out[tag][0], out["item"][0]) if same_bits else rel_err(out[tag][0], out["item"][0]) < 1e-3, tag
+    assert out["item"][1] > 3
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_explicit_switch_inside_pcg(ladybug_far, dtype):
     """Switching to S x after 1 / 6 / never matrix-free products gives the same PCG solution
