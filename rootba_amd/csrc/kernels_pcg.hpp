@@ -159,18 +159,19 @@ struct ChunkStage {
 //  differ in the last bit of a product)
 __device__ __forceinline__ float fma_of(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_of(double a, double b, double c) { return __builtin_fma(a, b, c); }
-template <class S, class MT, bool HALF, int ROWS = 3>
+template <class S, class MT, bool HALF>
 __device__ __forceinline__ void spmv_block_times(const MT* lds, int off, int lane, bool act, const S xv[9],
-                                                 double acc[9], const S vc[9], bool single, double* tdst,
-                                                 double& pq) {
+                                                 double acc[9], const S vc[9], bool single, MT tt[9], double& pq) {
+#pragma unroll
+  for (int b = 0; b < 9; ++b) tt[b] = MT(0);
   if (act) {
     const MT* blk = lds + off + 81 * lane;
-    MT tt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dot = MT(0);
+    MT dot = MT(0);
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
       // (three block rows at a time: left alone the scheduler hoists all 81 LDS reads of a double block - 162
       //  registers - above the arithmetic, and the kernel needs more than 256 registers: one wavefront per SIMD)
-      if (sizeof(MT) == 8 && a % ROWS == 0 && a > 0) __builtin_amdgcn_sched_barrier(0);
+      if (sizeof(MT) == 8 && a % 3 == 0 && a > 0) __builtin_amdgcn_sched_barrier(0);
       MT t = MT(0);
 #pragma unroll
       for (int b = 0; b < 9; ++b) {
@@ -181,12 +182,49 @@ __device__ __forceinline__ void spmv_block_times(const MT* lds, int off, int lan
       acc[a] += double(t);
       if (HALF) dot = fma_of(MT(vc[a]), t, dot);
     }
-    if (HALF) {
-      pq += double(dot) * (single ? 2.0 : 1.0);
-      if (single) {
+    if (HALF) pq += double(dot) * (single ? 2.0 : 1.0);
+  }
+}
+
+// The transposed products of a chunk's blocks to their slots (half storage; td: the lane's slot, -1 = none), WHOLE SLOTS BY
+// NEIGHBOURING LANES: the lanes' nine values are laid side by side in LDS - the chunk's slot, whose multiply is over - and
+// stored as one run of 9 nb doubles, lane by lane, so that the 72 bytes of a slot leave in one memory operation of nine
+// neighbouring lanes. Stored by its own lane a slot is five partial writes (four 16-byte pieces and one of 8 bytes,
+// each a transaction of its own at the L2: 165 per chunk of 33 blocks - as many as the 168 lines of the chunk's
+// matrix bytes). Worth 3 % of the product of the double matrix of venice-1778+tail (stream 96.7 / 94.1 -> 91.9 / 92.5 us,
+// item kernel 91.6 / 94.7 -> 90.0 / 90.9; profiles/r6aa_*) - NOT the 16 us the slot stores cost in all (timing-only
+// variant without them: 79 us, profiles/r6z_*): that is their 56 MB of partial-line writes among 383 MB of reads, not
+// their number of transactions. It also takes nine 64-bit store addresses per lane out of the multiply: the double kernels
+// need 130-160 registers instead of 202-219, and the streaming form with one chunk in flight fits two wavefronts per
+// SIMD for a double matrix too. Called by all 64 lanes.
+template <class MT, int CB>
+__device__ __forceinline__ void store_slots(MT* lds, int lane, int nb, const MT tt[9], int td,
+                                            double* __restrict__ tpart) {
+  if constexpr (sizeof(MT) == 4) {
+    // (a float matrix - 64 blocks per chunk, nine passes below - measured 4 % SLOWER that way: every lane its own slot)
+    if (lane < nb && td >= 0) {
 #pragma unroll
-        for (int b = 0; b < 9; ++b) tdst[b] = double(tt[b]);
-      }
+      for (int b = 0; b < 9; ++b) tpart[size_t(9) * td + b] = double(tt[b]);
+    }
+    return;
+  }
+  MT* sv = lds;
+  int* st = reinterpret_cast<int*>(lds + 9 * CB);
+  wave_lds_fence();  // (the multiply has read the chunk)
+  if (lane < nb) {
+#pragma unroll
+    for (int b = 0; b < 9; ++b) sv[9 * lane + b] = tt[b];
+    st[lane] = td;
+  }
+  wave_lds_fence();
+  constexpr int PASSES = (9 * CB + 63) / 64;
+#pragma unroll
+  for (int u = 0; u < PASSES; ++u) {
+    const int e = 64 * u + lane;
+    if (e < 9 * nb) {
+      const int sl = e / 9;
+      const int t = st[sl];
+      if (t >= 0) tpart[size_t(9) * t + (e - 9 * sl)] = double(sv[e]);
     }
   }
 }
@@ -331,8 +369,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
   double pq = 0.0;
   cs.store(0, lane, tmp, lds);
   __syncthreads();
-  spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act0, xv, acc, vc, HALF && td0 >= 0,
-                                HALF ? tpart + size_t(9) * max(td0, 0) : nullptr, pq);
+  MT tt[9];
+  spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act0, xv, acc, vc, HALF && td0 >= 0, tt, pq);
+  if (HALF) store_slots<MT, CB>(lds, lane, nb0, tt, td0, tpart);
   // (half storage: an item is ONE chunk - Solver::build_explicit_structure splits rows at spmv_chunk_blocks<double>())
   for (int chunk = item.slot0 + CB; !HALF && chunk < item.slot1; chunk += CB) {  // long rows only
     __syncthreads();  // the staging buffer is overwritten
@@ -354,8 +393,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
       }
     }
     __syncthreads();
-    spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act, xv, acc, vc, HALF && td >= 0,
-                                  HALF ? tpart + size_t(9) * max(td, 0) : nullptr, pq);
+    spmv_block_times<S, MT, HALF>(lds, cs.off, lane, act, xv, acc, vc, HALF && td >= 0, tt, pq);  // (full storage only)
   }
   S mine = S(0);
 #pragma unroll
@@ -580,7 +618,9 @@ __device__ __forceinline__ void pcgs_spmv_stream_body(
 #pragma unroll
     for (int t = 0; t < 9; ++t) vc[t] = read_lane(pc, t);
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pq = 0.0;
-    spmv_block_times<S, MT, true, NB == 1 ? 1 : 3>(lds, off, lane, act, xv, acc, vc, t0 >= 0, tpart + size_t(9) * max(t0, 0), pq);
+    MT tt[9];
+    spmv_block_times<S, MT, true>(lds, off, lane, act, xv, acc, vc, t0 >= 0, tt, pq);
+    store_slots<MT, CB>(lds, lane, nb0, tt, t0, tpart);
     S mine = S(0);
 #pragma unroll
     for (int a = 0; a < 9; ++a) {

@@ -1316,17 +1316,14 @@ class Solver final : public rba_solver {
         const int waves = spmv_stream_waves();
         if (env_.spmv_stream != 0 && (env_.spmv_stream == 2 || ni >= 4 * waves)) {
           streamed = true;
-          // (a float matrix - the terms of the power series - leaves registers for two wavefronts per SIMD with one chunk
-          //  in flight each: seven per compute unit (their LDS slots) instead of four, 24.1 against 26.6 us per product on
-          //  final-13682 (profiles/r6x_*). A double matrix does not: its multiply alone takes 200 registers, and the
-          //  compiler spills the chunk in flight - 312 to 500 bytes of scratch per lane)
+          // (one chunk in flight per wavefront and two wavefronts per SIMD - seven per compute unit, their LDS slots -
+          //  against two chunks in flight and one wavefront per SIMD: 24.1 against 26.6 us per float product on
+          //  final-13682 (profiles/r6x_*), 92 against 92-96 us per double product on venice-1778+tail (profiles/r6aa_*))
           auto kernel = &rba::k_pcgs_spmv_stream<S, MODE, MT>;
           int launch_waves = waves;
-          if constexpr (sizeof(MT) == 4) {
-            if (env_.spmv_stream_buffers == 1) {
-              kernel = &rba::k_pcgs_spmv_stream1<S, MODE, MT>;
-              if (env_.spmv_stream_waves_per_cu == 0) launch_waves = std::max(1, n_cus_) * 7;
-            }
+          if (env_.spmv_stream_buffers == 1) {
+            kernel = &rba::k_pcgs_spmv_stream1<S, MODE, MT>;
+            if (env_.spmv_stream_waves_per_cu == 0) launch_waves = std::max(1, n_cus_) * 7;
           }
           hipLaunchKernelGGL(kernel, dim3(std::min(ni, launch_waves)), dim3(64),
                              size_t(rba::kSpmvPass) * 1024, stream_, cols, vals, d_items_.get() + i0, ni, z, p0, p1, xvec,
@@ -3703,8 +3700,8 @@ class Solver final : public rba_solver {
     int spmv_stream = 1;               // RBA_SPMV_STREAM: 0 = one wavefront per item always, 1 = streaming SpMV for matrices of
                                        // >= 4 items per resident wavefront, 2 = always (tests)
     int spmv_stream_waves_per_cu = 0;  // RBA_SPMV_STREAM_WAVES: wavefronts per compute unit of the streaming SpMV (0 = 4; -1: two in all - tests)
-    int spmv_stream_buffers = 1;       // RBA_SPMV_STREAM_BUFFERS=2: the streaming product of a FLOAT matrix too with two chunks in flight per
-                                       // wavefront and four wavefronts per compute unit (default: one chunk, seven wavefronts; k_pcgs_spmv_stream1)
+    int spmv_stream_buffers = 1;       // RBA_SPMV_STREAM_BUFFERS=2: the streaming product with two chunks in flight per wavefront and four
+                                       // wavefronts per compute unit (default: one chunk, seven wavefronts; k_pcgs_spmv_stream1)
     int series_f32 = 1;                // RBA_SERIES_F32=0: the terms of the power-series preconditioner through the double matrix
     int pcg_persistent = 1;            // RBA_PCG_PERSISTENT=0: PCG on the assembled matrix always in two launches per
                                        // iteration (kernels_pcg.hpp; the test of the two forms)

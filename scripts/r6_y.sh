@@ -1,0 +1,38 @@
+# round 6, call Y: dense regime, half-storage multiply of a double matrix with two lanes per block (spmv_block_times_pair)
+# - parity file first, then A/B on ONE box: last commit (head) / pair with two buffers (4 wavefronts per unit) / pair with
+# one buffer (7 wavefronts per unit; the default of this tree) / pair, item kernel; venice-1778+tail, then config 5
+set -x
+O=$GRAFT_REPO_ROOT/gpurun_out/r6y
+mkdir -p $O
+cd $GRAFT_REPO_ROOT
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_mixed.py -m gpu -q -x > $O/pytest.log 2>&1
+tail -3 $O/pytest.log
+run() {  # variant tag env...
+  v=$1; tag=$2; shift 2
+  cp variants/lib_$v.so rootba_amd/librootba_hip.so; touch rootba_amd/librootba_hip.so rootba_amd/bal_qr_hip
+  cd /tmp && export TMPDIR=/tmp
+  env "$@" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --cpu-baseline-iters 0 --no-reference-semantics --repeats 1 --no-pmc --no-dense-companion $WL > $O/prof_$tag.json 2> $O/prof_$tag.log
+  cd $GRAFT_REPO_ROOT
+  find $O/prof_$tag -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_${tag}.csv
+  rm -rf $O/prof_$tag
+  python - <<PY
+import csv,json
+rows=list(csv.DictReader(open('$O/kernel_stats_${tag}.csv')))
+out=[]
+for r in rows:
+    if 'k_pcgs_spmv' in r['Name'] or 'k_pcgs_reduce' in r['Name']: out.append(f"{r['Name'][10:48]} {r['Calls']}x{float(r['AverageNs'])/1e3:.1f}")
+d=json.loads(open('$O/prof_$tag.json').read().strip().splitlines()[-1])
+print('$tag:', ' | '.join(sorted(out)), '| value', round(d['value'],2), 'ms/step', round(d['ms_per_step'],2))
+PY
+}
+for rep in 1 2; do
+  WL="--workload venice-1778+tail"
+  run head tail_head_$rep RBA_X=0
+  run pair tail_pair_b2_$rep RBA_SPMV_STREAM_BUFFERS=2
+  run pair tail_pair_b1_$rep RBA_SPMV_STREAM_BUFFERS=1
+  run pair tail_pair_item_$rep RBA_SPMV_STREAM=0
+done
+WL="--workload final-13682 --mixed --preconditioner POWER_SCHUR_COMPLEMENT"
+run head final_head RBA_X=0
+run pair final_pair_b1 RBA_SPMV_STREAM_BUFFERS=1
+cp variants/lib_pair.so rootba_amd/librootba_hip.so; touch rootba_amd/librootba_hip.so rootba_amd/bal_qr_hip

@@ -733,9 +733,12 @@ def test_streaming_spmv_is_the_item_spmv(small_problem, mixed_k_problem, ladybug
     rng = np.random.default_rng(5)
     xs = [rng.uniform(-1, 1, 9 * prob.n_cams).astype(dtype) for _ in range(2)]
     out = {}
-    for tag, mode, waves in (("item", "0", "0"), ("item-again", "0", "0"), ("stream", "2", "0"), ("stream-few", "2", "-1")):
+    for tag, mode, waves, buffers in (("item", "0", "0", "1"), ("item-again", "0", "0", "1"), ("stream", "2", "0", "1"),
+                                      ("stream-few", "2", "-1", "1"), ("stream-two-buffers", "2", "0", "2"),
+                                      ("stream-two-buffers-few", "2", "-1", "2")):
         monkeypatch.setenv("RBA_SPMV_STREAM", mode)
         monkeypatch.setenv("RBA_SPMV_STREAM_WAVES", waves)
+        monkeypatch.setenv("RBA_SPMV_STREAM_BUFFERS", buffers)  # (chunks in flight per wavefront: k_pcgs_spmv_stream1 / _stream)
         g, _ = _pair(prob, dtype, explicit_after=1, eta=1e-4, max_cg_it=40)
         assert g.linearize() == 0
         g.stage2(1e-5)
@@ -745,7 +748,7 @@ def test_streaming_spmv_is_the_item_spmv(small_problem, mixed_k_problem, ladybug
         out[tag] = (ys, inc, cg.num_iterations, cg.termination_type)
     same_bits = all(np.array_equal(a, b) for a, b in zip(out["item"][0], out["item-again"][0])) and \
         np.array_equal(out["item"][1], out["item-again"][1])
-    for tag in ("stream", "stream-few"):
+    for tag in ("stream", "stream-few", "stream-two-buffers", "stream-two-buffers-few"):
         for a, b in zip(out["item"][0], out[tag][0]):
             assert np.array_equal(a, b) if same_bits else rel_err(a, b) < (1e-6 if dtype == np.float32 else 1e-13), tag
         assert out[tag][2:] == out["item"][2:], (tag, out[tag][2:], out["item"][2:])
