@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void k_ex_offdiag_mfma(const S* __restrict__ t
   // flight while step s is multiplied (two register sets, the loop unrolled by two), zero-selects of the staging in
   // a list's last step only.
   constexpr int U = sizeof(S) == 8 ? 2 : 4;
-  __shared__ __attribute__((aligned(16))) S stage[4][U][8][kTd];
+  __shared__ __attribute__((aligned(32))) S stage[4][U][8][kTd];
   const int rec = lane >> 3, vec = lane & 7;
   const int* __restrict__ pair_side = (rec < 4 ? pair_oi : pair_oj) + q0;
   const int rsub = rec & 3;
