@@ -757,13 +757,18 @@ def test_streaming_spmv_is_the_item_spmv(small_problem, mixed_k_problem, ladybug
     assert out["item"][2] > 10  # (the residual refresh ran)
 
 
-@pytest.mark.parametrize("which", ["small", "ladybug"])
+@pytest.mark.parametrize("which", ["small", "small-heavy-rows", "ladybug"])
 def test_streaming_spmv_of_the_float_series_terms(small_problem, ladybug_far, which, monkeypatch):
     """The terms of the power-series preconditioner of a float32 solver stream a FLOAT copy of the assembled matrix
     (Solver::series_f32). Their three kernels - one wavefront per item, two chunks in flight per persistent wavefront
     (k_pcgs_spmv_stream), one chunk in flight and two wavefronts per SIMD (k_pcgs_spmv_stream1,
     RBA_SPMV_STREAM_BUFFERS=1) - do the same arithmetic in the same order per item: same iteration counts, increments
-    bitwise equal when two handles of the item form agree bitwise."""
+    bitwise equal when two handles of the item form agree bitwise. "-heavy-rows": rows that receive more than three
+    transposed-product slots have them summed by k_pcgs_reduce_slots. The float series against the series through the
+    double matrix (RBA_SERIES_F32=0): same counts within one iteration, increments to what a float32 solve resolves."""
+    if which == "small-heavy-rows":
+        monkeypatch.setenv("RBA_HALF_LOWER_MAX", "3")
+        which = "small"
     prob = {"small": small_problem, "ladybug": ladybug_far}[which]
     monkeypatch.setenv("RBA_PCG_PERSISTENT", "0")
     monkeypatch.setenv("RBA_DETERMINISTIC", "1")
@@ -782,6 +787,13 @@ def test_streaming_spmv_of_the_float_series_terms(small_problem, ladybug_far, wh
         assert out[tag][1:] == out["item"][1:], (tag, out[tag][1:], out["item"][1:])
         assert np.array_equal(out[tag][0], out["item"][0]) if same_bits else rel_err(out[tag][0], out["item"][0]) < 1e-3, tag
     assert out["item"][1] > 3
+    monkeypatch.setenv("RBA_SERIES_F32", "0")
+    monkeypatch.setenv("RBA_SPMV_STREAM", "0")
+    g, _ = _pair(prob, np.float32, preconditioner_type=2, power_order=5, explicit_after=1, eta=1e-4, max_cg_it=40)
+    assert g.linearize() == 0
+    inc, cg = g.solve(1e-5)
+    assert abs(cg.num_iterations - out["item"][1]) <= 1 and cg.termination_type == out["item"][2]
+    assert rel_err(inc, out["item"][0]) < 1e-3, rel_err(inc, out["item"][0])
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
