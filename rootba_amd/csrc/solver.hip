@@ -2368,14 +2368,21 @@ class Solver final : public rba_solver {
   // through the double matrix as in rounds 3-5
   bool series_f32() const { return sizeof(S) == 4 && !sc_ && opt_.preconditioner_type == 2 && env_.series_f32 != 0; }
   S* series_t() { return series_fused() ? d_pw_t_.get() : static_cast<S*>(nullptr); }
+  // workgroups of a series step: a tile of 28 cameras each. The LAST term leaves the kPcgBlocks partials of rho the next
+  // kernels sum (one per workgroup: that many workgroups, whatever the number of tiles); the others have no such
+  // limit - on final-13682 (489 tiles) 64 workgroups walked eight tiles each, one dependent chain of loads after the
+  // other, on a quarter of the compute units
+  int series_step_grid(bool last) const {
+    const int n_tiles = (n_cams_ + 27) / 28;
+    return last ? rba::kPcgBlocks : std::max(rba::kPcgBlocks, std::min(n_tiles, 4096));
+  }
   void enqueue_series() {
     if (!series_fused()) return;
-    constexpr int NB = rba::kPcgBlocks;
     for (int i = 1; i <= opt_.power_order; ++i) {
       launch_spmv<2>(nullptr, nullptr, nullptr, d_pw_t_.get(), nullptr, nullptr, nullptr, -1.0, 0, 0, 1, nullptr, true);
-      hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), q_pieces(),
-                         d_pw_t_.get(), d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(), i == opt_.power_order ? 1 : 0,
-                         d_pcg_partials_.get());
+      hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(series_step_grid(i == opt_.power_order)), dim3(256), 0, stream_,
+                         d_inv_.get(), q_pieces(), d_pw_t_.get(), d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(),
+                         i == opt_.power_order ? 1 : 0, d_pcg_partials_.get());
     }
   }
 
@@ -2388,7 +2395,6 @@ class Solver final : public rba_solver {
   // (PowerSCPreconditioner::solve_assign, preconditioner.hpp:180-192: t <- Hpp^-1 E0 t, z += t), all-reduced per term.
   void enqueue_series_terms(S lambda, const int* done) {
     if (!series_fused()) return;
-    constexpr int NB = rba::kPcgBlocks;
     const int n = nvec_;
     const bool on_matrix = ex_active_ || (explicit_off_for_solve_ && ex_ready_ && ex_valid_);
     S* t = d_pw_t_.get();
@@ -2397,16 +2403,16 @@ class Solver final : public rba_solver {
       const int last = i == opt_.power_order ? 1 : 0;
       if (on_matrix) {
         launch_spmv<2>(nullptr, nullptr, nullptr, t, nullptr, nullptr, nullptr, double(lambda), 0, 0, 1, nullptr, true);
-        hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), q_pieces(), t,
-                           d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(), last, d_pcg_partials_.get(), 0);
+        hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(series_step_grid(last)), dim3(256), 0, stream_, d_inv_.get(),
+                           q_pieces(), t, d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(), last, d_pcg_partials_.get(), 0);
       } else {
         HIP_CHECK(hipMemsetAsync(e, 0, size_t(n) * sizeof(S), stream_));
         launch_e0(t, e, done);
         all_reduce(e, n);
         rba::QPieces<S> qp{};
         qp.qmain = e;
-        hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(NB), dim3(256), 0, stream_, d_inv_.get(), qp, t,
-                           d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(), last, d_pcg_partials_.get(), 1);
+        hipLaunchKernelGGL((rba::k_pcgs_series_step<S>), dim3(series_step_grid(last)), dim3(256), 0, stream_, d_inv_.get(), qp,
+                           t, d_z_.get(), d_r_.get(), n_cams_, d_cg_.get(), last, d_pcg_partials_.get(), 1);
       }
     }
   }
