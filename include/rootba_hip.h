@@ -34,7 +34,7 @@
  *    the assembled matrix in two launches per iteration instead of the persistent kernel), RBA_SPMV_STREAM (0: the product
  *    with an assembled matrix that does not fit the register files always one wavefront per work item; 1, default:
  *    persistent streaming wavefronts for matrices of >= 4 items per resident wavefront; 2: always), RBA_SPMV_STREAM_WAVES,
- *    RBA_SPMV_STREAM_BUFFERS (2: a float matrix too streamed with two chunks in flight per wavefront; default 1),
+ *    RBA_SPMV_STREAM_BUFFERS (chunks in flight per streaming wavefront: 1, default - seven wavefronts per compute unit; 2 - four),
  *    RBA_SERIES_F32 (0: the terms of the power-series preconditioner through the double matrix instead of its float copy),
  *    RBA_PCGP_TRACE (file for that
  *    kernel's phase stamps), RBA_STAGE_TIMERS (0: rba_iter_timings stays zero; 1, default: device clock stamps at the stage
