@@ -440,6 +440,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
 // same iteration (loads return in order: what the next multiply waits for must not queue behind a chunk that is needed
 // two iterations later). Same arithmetic, same summation order per item as k_pcgs_spmv: bit-identical products
 // (tests/test_gpu_parity.py::test_streaming_spmv_is_the_item_spmv).
+// What the measurements at the end of round 6 said: bytes in flight are NOT the bound - reading the
+// 424-MB matrix through this kernel takes 79 us (5.4 TB/s, the rate of the library's other read-bound kernels), the 56 MB
+// of transposed-product slots cost 13-17 us more. The form with ONE register buffer (NB = 1: chunk k + 1 in flight
+// while chunk k is multiplied) and two wavefronts per SIMD - seven per compute unit, their LDS slots - is as fast on the
+// double matrix and 9 % faster on the float copy of final-13682: it is the default (k_pcgs_spmv_stream1;
+// RBA_SPMV_STREAM_BUFFERS=2 selects the two-buffer form).
 // the nine entries of a camera in three memory operations (4-byte aligned 16-byte loads + one scalar; exactly the
 // 36 bytes: a three-component vector type is sixteen bytes wide on the host side of the test harness)
 __device__ __forceinline__ void load_nine(const float* __restrict__ p, float (&v)[9]) {
